@@ -1,0 +1,114 @@
+"""ctypes binding of include/gnf_hip.h (libgnf_hip.so).
+
+PyTorch is used only as the owner of device memory and streams: every entry point
+receives raw `data_ptr()`s, element strides and torch's current HIP stream.  There is
+NO CPU fallback: a missing library or a non-HIP tensor raises."""
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libgnf_hip.so")
+
+c_f = ctypes.c_void_p            # device float*
+c_i64 = ctypes.c_int64
+c_int = ctypes.c_int
+c_float = ctypes.c_float
+c_u64 = ctypes.c_uint64
+c_stream = ctypes.c_void_p
+
+MONO_MAX_LAYERS = 8
+
+
+class MonoNet(ctypes.Structure):
+    """gnf_mono_net (include/gnf_hip.h)."""
+    _fields_ = [("nl", c_int), ("dims", c_int * (MONO_MAX_LAYERS + 1)),
+                ("W", ctypes.c_void_p * MONO_MAX_LAYERS), ("b", ctypes.c_void_p * MONO_MAX_LAYERS)]
+
+
+# name -> (restype, argtypes); must list every symbol include/gnf_hip.h declares
+SIGNATURES = {
+    "gnf_abi_version": (c_int, []),
+    "gnf_affine_fwd": (c_int, [c_f, c_f, c_i64, c_i64, c_i64, c_f, c_f, c_f, c_int, c_i64, c_i64, c_stream]),
+    "gnf_affine_bwd": (c_int, [c_f, c_f, c_i64, c_i64, c_i64, c_f, c_f, c_f, c_f, c_f, c_i64, c_i64, c_i64, c_i64,
+                               c_i64, c_stream]),
+    "gnf_affine_inv": (c_int, [c_f, c_f, c_i64, c_i64, c_i64, c_f, c_i64, c_i64, c_stream]),
+    "gnf_logsum_rows_fwd": (c_int, [c_f, c_f, c_i64, c_i64, c_stream]),
+    "gnf_logsum_rows_bwd": (c_int, [c_f, c_f, c_f, c_i64, c_i64, c_stream]),
+    "gnf_normal_logdensity_fwd": (c_int, [c_f, c_f, c_i64, c_i64, c_stream]),
+    "gnf_normal_logdensity_bwd": (c_int, [c_f, c_f, c_f, c_i64, c_i64, c_stream]),
+    "gnf_colsum_ws_bytes": (c_i64, [c_i64, c_i64]),
+    "gnf_colsum": (c_int, [c_f, c_i64, c_f, c_i64, c_i64, c_f, c_stream]),
+    "gnf_gemm": (c_int, [c_f, c_i64, c_i64, c_f, c_f, c_i64, c_i64, c_f, c_i64, c_i64, c_f, c_f, c_i64, c_i64, c_f,
+                         c_i64, c_i64, c_int, c_i64, c_i64, c_i64, c_stream]),
+    "gnf_dag_gate_fwd": (c_int, [c_f, c_f, c_f, c_i64, c_int, c_int, c_float, c_float, c_f, c_f, c_u64, c_u64, c_int,
+                                 c_i64, c_i64, c_stream]),
+    "gnf_dag_gate_bwd_ws_bytes": (c_i64, [c_i64, c_i64]),
+    "gnf_dag_gate_bwd": (c_int, [c_f, c_f, c_f, c_i64, c_int, c_int, c_float, c_float, c_f, c_f, c_u64, c_u64, c_f,
+                                 c_f, c_f, c_i64, c_i64, c_stream]),
+    "gnf_monotonic_pack_floats": (c_i64, [ctypes.POINTER(MonoNet)]),
+    "gnf_monotonic_pack": (c_int, [ctypes.POINTER(MonoNet), c_f, c_stream]),
+    "gnf_monotonic_fwd": (c_int, [c_f, ctypes.POINTER(MonoNet), c_f, c_f, c_i64, c_i64, c_i64, c_f, c_f, c_int, c_f,
+                                  c_f, c_i64, c_i64, c_stream]),
+    "gnf_monotonic_inv": (c_int, [c_f, ctypes.POINTER(MonoNet), c_f, c_f, c_i64, c_i64, c_i64, c_f, c_f, c_int, c_f,
+                                  c_i64, c_i64, c_stream]),
+    "gnf_monotonic_bwd_ws_bytes": (c_i64, [ctypes.POINTER(MonoNet), c_int, c_i64, c_i64]),
+    "gnf_monotonic_bwd": (c_int, [c_f, ctypes.POINTER(MonoNet), c_f, c_f, c_i64, c_i64, c_i64, c_f, c_f, c_int, c_f,
+                                  c_f, c_f, c_f, c_i64, c_i64, c_i64, ctypes.POINTER(ctypes.c_void_p),
+                                  ctypes.POINTER(ctypes.c_void_p), ctypes.c_void_p, c_i64, c_i64, c_i64, c_stream]),
+    "gnf_adam_step": (c_int, [c_f, c_f, c_f, c_f, c_i64, c_float, c_float, c_float, c_float, c_float, c_float, c_int,
+                              c_stream]),
+}
+
+_lib = None
+
+
+class GnfError(RuntimeError):
+    pass
+
+
+def load():
+    """dlopen libgnf_hip.so (after `import torch`, so that the HIP runtime torch already
+    loaded -- same SONAME libamdhip64.so.7 -- is the one the kernels launch on)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError("libgnf_hip.so is not built: run `python __graft_entry__.py build` "
+                              "(hipcc --offload-arch=gfx950).  There is no CPU fallback. [%s]" % LIB_PATH)
+        lib = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)       # AttributeError if the symbol is missing
+            fn.restype = res
+            fn.argtypes = args
+        if lib.gnf_abi_version() != 1:
+            raise ImportError("libgnf_hip.so ABI version mismatch")
+        _lib = lib
+    return _lib
+
+
+_ERR = {-1: "GNF_EINVAL (bad argument)", -2: "GNF_ESHAPE (unsupported shape)", -3: "GNF_EWS (workspace too small)"}
+
+
+def check(rc, what):
+    if rc != 0:
+        raise GnfError("%s failed: %s" % (what, _ERR.get(rc, "hipError_t %d" % rc)))
+
+
+def stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def ptr(t):
+    """device pointer of a fp32 HIP tensor (None -> NULL)."""
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise GnfError("gnf_hip kernels run on the MI355X only: got a %s tensor (no CPU fallback)" % t.device)
+    if t.dtype != torch.float32:
+        raise GnfError("gnf_hip kernels are fp32: got %s" % t.dtype)
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def call(name, *args):
+    check(getattr(load(), name)(*args), name)

@@ -1,0 +1,25 @@
+// Internal (not part of the C ABI): argument block + launcher of the fp32 MFMA GEMM,
+// shared between gnf_gemm.hip and gnf_monotonic.hip.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+struct GemmArgs {
+  const float* A; int64_t sam, sak;
+  const float* B; const float* Bmask; int64_t sbk, sbn;
+  float* C; int64_t scm, scn;
+  const float* bias;
+  const float* Cmask; int64_t scmm, scmn;
+  const float* gate; int64_t sgm, sgn;
+  int flags; int64_t M, N, K;
+  int64_t k_per_split, c_split_stride;   // split-K: blockIdx.z owns [z*kps, (z+1)*kps), writes C + z*stride
+};
+
+// internal epilogue flag: C += result (chunked accumulation of split-K partials)
+#define GNF_GEMM_ACCUM (1 << 30)
+
+// splits > 1: split-K; partial z is written to C + z*c_split_stride (caller sets the
+// stride and reduces the partials); epilogue options other than ACCUM must be off.
+int gnf_gemm_launch(GemmArgs g, int splits, hipStream_t s);
+// number of partials gnf_gemm_launch(K, splits) writes (without ACCUM)
+int64_t gnf_gemm_num_splits(int64_t K, int splits);

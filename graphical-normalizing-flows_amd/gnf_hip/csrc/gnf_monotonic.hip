@@ -1,0 +1,767 @@
+// Monotonic (UMNN) normalizer: Clenshaw-Curtis quadrature of the integrand MLP, forward,
+// fused bisection inverse, and backward (models/Normalizers/MonotonicNormalizer.py:21-83 +
+// the UMNN 1.0 NeuralIntegral algorithm, restated in oracle/gnf_oracle.py).
+//
+// Compute-bound (>1000 flop/B): the work is (S+2) evaluations per element of a small MLP,
+// so everything is organised around v_mfma_f32_16x16x4_f32 (exact fp32):
+//
+//  * A wavefront owns a GROUP of 16 elements (b,i).  For one quadrature node the hidden
+//    state is a [H x 16] matrix held in the MFMA C/D layout: lane (q=lane>>4, j=lane&15)
+//    holds hidden units 16t+4q+r (t = tile, r = 0..3) of element j.
+//  * A hidden layer is out[H x 16] = W[H x H] * act[H x 16].  The weights are the MFMA
+//    A operand (one float4 per lane per (out-tile, in-tile) read from the padded weight
+//    image: LDS-resident when it fits, L1/L2 otherwise), the activations are the B
+//    operand.  Because the contraction index may be visited in any order, K-step (t,r)
+//    pairs lane-slot q with hidden unit 16t+4q+r -- exactly what the C/D registers of the
+//    previous layer already hold.  Layers therefore chain register-to-register: no LDS
+//    round trip, no cross-lane shuffle between layers.
+//  * Layer 1 is split: W1[:,1:]*h + b1 does not depend on the node, so it is computed once
+//    per group (MFMA) and each node only adds the rank-1 term w1x * x_k on the VALU.
+//  * The last layer (H -> 1) is a per-lane dot product + two __shfl_xor over the q axis.
+//  * Two nodes are processed together so every A fragment feeds 8 MFMAs.
+//
+// Backward = recompute-in-kernel (no saved activations): the chain kernel re-runs the
+// forward per node, back-propagates dpre through the transposed weights with the same
+// register chaining, writes dx, dh, and accumulates bias / first / last layer gradients
+// in per-lane registers.  Hidden->hidden weight gradients are reductions over (element,
+// node) rows: the chain kernel stages act[l-1] and dpre[l] row-major to a workspace and
+// the split-K fp32 MFMA GEMM (gnf_gemm.hip) contracts them, chunk by chunk.
+#include "gnf_common.h"
+#include "gnf_gemm.h"
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int kWaves = 4;          // wavefronts per workgroup
+constexpr int kMaxNH = GNF_MONO_MAX_LAYERS - 1;
+
+// ---------------------------------------------------------------------------------------
+// Padded weight image ("pack"): every matrix row-major with leading dimension LD = pad+4
+// floats (keeps float4 fragment reads 16-B aligned and staggers LDS banks).
+// ---------------------------------------------------------------------------------------
+struct MonoLayout {
+  int HT, HP, NH, c, CP, LDH, LDW;
+  int o_w1x, o_b1, o_wL, o_bL, o_W1h;
+  int o_W[kMaxNH], o_b[kMaxNH];       // hidden->hidden layers l = 1..NH-1
+  int fwd_floats;                     // prefix used by forward / inverse
+  int o_WT[kMaxNH], o_W1hT;           // transposes, backward only
+  int total_floats;
+};
+
+__host__ __device__ inline MonoLayout make_layout(int HT, int NH, int c) {
+  MonoLayout L;
+  L.HT = HT; L.HP = 16 * HT; L.NH = NH; L.c = c;
+  L.CP = (c + 15) / 16 * 16; L.LDH = L.CP + 4; L.LDW = L.HP + 4;
+  int o = 0;
+  L.o_w1x = o; o += L.HP;
+  L.o_b1 = o; o += L.HP;
+  L.o_wL = o; o += L.HP;
+  L.o_bL = o; o += 4;
+  L.o_W1h = o; o += L.HP * L.LDH;
+  for (int l = 1; l < NH; ++l) { L.o_W[l] = o; o += L.HP * L.LDW; L.o_b[l] = o; o += L.HP; }
+  L.fwd_floats = o;
+  for (int l = 1; l < NH; ++l) { L.o_WT[l] = o; o += L.HP * L.LDW; }
+  L.o_W1hT = o; o += L.CP * L.LDW;
+  L.total_floats = o;
+  return L;
+}
+
+struct PackArgs {
+  gnf_mono_net net;
+  MonoLayout L;
+};
+
+__global__ void mono_pack_k(PackArgs a, float* __restrict__ pack) {
+  const MonoLayout& L = a.L;
+  const gnf_mono_net& N = a.net;
+  const int H0 = N.dims[1];
+  for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < L.total_floats; idx += gridDim.x * blockDim.x) {
+    float v = 0.f;
+    if (idx < L.o_b1) { const int k = idx - L.o_w1x; if (k < H0) v = N.W[0][(int64_t)k * N.dims[0]]; }
+    else if (idx < L.o_wL) { const int k = idx - L.o_b1; if (k < H0) v = N.b[0][k]; }
+    else if (idx < L.o_bL) { const int k = idx - L.o_wL; if (k < N.dims[L.NH]) v = N.W[L.NH][k]; }
+    else if (idx < L.o_W1h) { if (idx == L.o_bL) v = N.b[L.NH][0]; }
+    else if (idx < (L.NH > 1 ? L.o_W[1] : L.fwd_floats)) {
+      const int k = idx - L.o_W1h; const int r = k / L.LDH, cc = k % L.LDH;
+      if (r < H0 && cc < L.c) v = N.W[0][(int64_t)r * N.dims[0] + 1 + cc];
+    } else if (idx < L.fwd_floats) {
+      for (int l = 1; l < L.NH; ++l) {
+        if (idx >= L.o_W[l] && idx < L.o_b[l]) {
+          const int k = idx - L.o_W[l]; const int r = k / L.LDW, cc = k % L.LDW;
+          if (r < N.dims[l + 1] && cc < N.dims[l]) v = N.W[l][(int64_t)r * N.dims[l] + cc];
+        } else if (idx >= L.o_b[l] && idx < L.o_b[l] + L.HP) {
+          const int k = idx - L.o_b[l]; if (k < N.dims[l + 1]) v = N.b[l][k];
+        }
+      }
+    } else if (idx < L.o_W1hT) {
+      for (int l = 1; l < L.NH; ++l) {
+        if (idx >= L.o_WT[l] && idx < L.o_WT[l] + L.HP * L.LDW) {
+          const int k = idx - L.o_WT[l]; const int r = k / L.LDW, cc = k % L.LDW;   // r = in, cc = out
+          if (r < N.dims[l] && cc < N.dims[l + 1]) v = N.W[l][(int64_t)cc * N.dims[l] + r];
+        }
+      }
+    } else {
+      const int k = idx - L.o_W1hT; const int r = k / L.LDW, cc = k % L.LDW;       // r = cond idx, cc = hidden
+      if (r < L.c && cc < H0) v = N.W[0][(int64_t)cc * N.dims[0] + 1 + r];
+    }
+    pack[idx] = v;
+  }
+}
+
+struct MonoArgs {
+  const float* pack; MonoLayout L;
+  const float* x; const float* h; int64_t h_sb, h_sd, h_sc;
+  const float* ccw; const float* cct; int S;
+  float* z; float* jac;                 // forward outputs
+  const float* zt; float* xo;           // inverse: target z, output x
+  int64_t n, d;                         // n = B*d elements
+  // backward
+  const float* gz; const float* gjac; float* gx; float* gh; int64_t g_sb, g_sd, g_sc;
+  float* SA[kMaxNH]; float* SD[kMaxNH]; float* Dsum; float* part;
+  int64_t e0, ecount;                   // element chunk [e0, e0+ecount)
+  int NK;                               // node slots per group (S+2 rounded up to even)
+};
+
+__device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+__device__ __forceinline__ f32x4 mfma(float a, float b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ float qsum(float v) {   // sum over the 4 lane-slots q (lanes j, j+16, j+32, j+48)
+  v += __shfl_xor(v, 16, 64);
+  v += __shfl_xor(v, 32, 64);
+  return v;
+}
+__device__ __forceinline__ float jsum(float v) {   // sum over the 16 elements of a lane-slot
+  v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 8, 64);
+  return v;
+}
+__device__ __forceinline__ float elu_plus(float s) { return (s > 0.f ? s : expm1f(s)) + 1.05f; }
+
+// c1[t][r] = b1[hid] + sum_cc W1h[hid][cc] * h[elem][cc],  hid = 16t+4q+r   (MFMA, once per group)
+template <int HT>
+__device__ __forceinline__ void cond_bias(const float* wp, const MonoLayout& L, const float* __restrict__ h,
+                                          int64_t hbase, int64_t h_sc, int q, int j, f32x4 (&c1)[HT]) {
+#pragma unroll
+  for (int t = 0; t < HT; ++t) c1[t] = ld4(wp + L.o_b1 + 16 * t + 4 * q);
+  for (int s = 0; s < L.CP / 16; ++s) {
+    float hv[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int cc = 16 * s + 4 * q + r;
+      hv[r] = cc < L.c ? h[hbase + cc * h_sc] : 0.f;
+    }
+#pragma unroll
+    for (int t = 0; t < HT; ++t) {
+      const f32x4 A = ld4(wp + L.o_W1h + (16 * t + j) * L.LDH + 16 * s + 4 * q);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) c1[t] = mfma(A[r], hv[r], c1[t]);
+    }
+  }
+}
+
+// f(xa;h), f(xb;h) for the 16 elements of the group: two nodes share every weight fragment.
+template <int HT>
+__device__ __forceinline__ void eval2(const float* wp, const MonoLayout& L, const f32x4 (&c1)[HT], float xa,
+                                      float xb, int q, int j, float& fa, float& fb) {
+  f32x4 a0[HT], a1[HT];
+#pragma unroll
+  for (int t = 0; t < HT; ++t) {
+    const f32x4 wx = ld4(wp + L.o_w1x + 16 * t + 4 * q);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      a0[t][r] = fmaxf(fmaf(wx[r], xa, c1[t][r]), 0.f);
+      a1[t][r] = fmaxf(fmaf(wx[r], xb, c1[t][r]), 0.f);
+    }
+  }
+  for (int l = 1; l < L.NH; ++l) {
+    const float* W = wp + L.o_W[l];
+    f32x4 o0[HT], o1[HT];
+#pragma unroll
+    for (int mt = 0; mt < HT; ++mt) { o0[mt] = ld4(wp + L.o_b[l] + 16 * mt + 4 * q); o1[mt] = o0[mt]; }
+#pragma unroll
+    for (int t = 0; t < HT; ++t) {
+#pragma unroll
+      for (int mt = 0; mt < HT; ++mt) {
+        const f32x4 A = ld4(W + (16 * mt + j) * L.LDW + 16 * t + 4 * q);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          o0[mt] = mfma(A[r], a0[t][r], o0[mt]);
+          o1[mt] = mfma(A[r], a1[t][r], o1[mt]);
+        }
+      }
+    }
+#pragma unroll
+    for (int t = 0; t < HT; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { a0[t][r] = fmaxf(o0[t][r], 0.f); a1[t][r] = fmaxf(o1[t][r], 0.f); }
+  }
+  float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+  for (int t = 0; t < HT; ++t) {
+    const f32x4 wl = ld4(wp + L.o_wL + 16 * t + 4 * q);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { s0 = fmaf(wl[r], a0[t][r], s0); s1 = fmaf(wl[r], a1[t][r], s1); }
+  }
+  const float bL = wp[L.o_bL];
+  fa = elu_plus(qsum(s0) + bL);
+  fb = elu_plus(qsum(s1) + bL);
+}
+
+// sum_k w_k f(xT (t_k+1)/2) over the S+1 quadrature nodes; optionally also f(xj) (Jacobian node)
+template <int HT, bool WITH_JAC>
+__device__ __forceinline__ float quadrature(const float* wp, const MonoLayout& L, const f32x4 (&c1)[HT],
+                                            const float* __restrict__ ccw, const float* __restrict__ cct, int S,
+                                            float xT, float xj, int q, int j, float& fjac) {
+  float acc = 0.f;
+  const int total = S + 1 + (WITH_JAC ? 1 : 0);
+  for (int k = 0; k < total; k += 2) {
+    const int k1 = k + 1;
+    const float wa = k <= S ? ccw[k] : 0.f;
+    const float wb = k1 <= S ? ccw[k1] : 0.f;
+    const float xa = k <= S ? xT * (cct[k] + 1.f) * .5f : xj;
+    const float xb = k1 <= S ? xT * (cct[k1] + 1.f) * .5f : xj;
+    float fa, fb;
+    eval2<HT>(wp, L, c1, xa, xb, q, j, fa, fb);
+    acc = fmaf(wa, fa, acc);
+    acc = fmaf(wb, fb, acc);
+    if (WITH_JAC) {
+      if (k == S + 1) fjac = fa;
+      if (k1 == S + 1) fjac = fb;
+    }
+  }
+  return acc;
+}
+
+template <int HT, bool WLDS, bool INV>
+__global__ __launch_bounds__(64 * kWaves) void mono_fwd_k(MonoArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const MonoLayout& L = a.L;
+  const float* wp = a.pack;
+  if (WLDS) {
+    for (int i = threadIdx.x * 4; i < L.fwd_floats; i += blockDim.x * 4)
+      *reinterpret_cast<f32x4*>(smem + i) = ld4(a.pack + i);
+    __syncthreads();
+    wp = smem;
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int q = lane >> 4, j = lane & 15;
+  const int64_t ngroups = (a.n + 15) / 16;
+  const float fS = (float)a.S;
+  for (int64_t grp = (int64_t)blockIdx.x * kWaves + wave; grp < ngroups; grp += (int64_t)gridDim.x * kWaves) {
+    const int64_t e = grp * 16 + j;
+    const bool valid = e < a.n;
+    const int64_t ec = valid ? e : a.n - 1;
+    const int64_t b = ec / a.d, i = ec - b * a.d;
+    const int64_t hbase = b * a.h_sb + i * a.h_sd;
+    f32x4 c1[HT];
+    cond_bias<HT>(wp, L, a.h, hbase, a.h_sc, q, j, c1);
+    const float h0 = a.h[hbase];
+    float dummy = 0.f;
+    if (!INV) {
+      const float xv = a.x[ec];
+      const float xT = fS * (xv / fS);                 // xT = x0 + nb_steps*step, x0 = 0
+      float fj = 0.f;
+      const float zs = quadrature<HT, true>(wp, L, c1, a.ccw, a.cct, a.S, xT, xv, q, j, fj);
+      if (valid && q == 0) {
+        a.z[e] = zs * xT * .5f + h0;
+        a.jac[e] = fj;
+      }
+    } else {
+      const float zt = a.zt[ec];
+      float xmax = 20.f, xmin = -20.f;
+      for (int it = 0; it < 20; ++it) {
+        const float xm = (xmax + xmin) * .5f;
+        const float xT = fS * (xm / fS);
+        const float zm = quadrature<HT, false>(wp, L, c1, a.ccw, a.cct, a.S, xT, 0.f, q, j, dummy) * xT * .5f + h0;
+        if (zm > zt) xmax = xm; else xmin = xm;
+      }
+      if (valid && q == 0) a.xo[e] = (xmax + xmin) * .5f;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// Backward chain kernel.  Vector gradients kept as per-lane partials over the wave's whole
+// persistent loop:  slot 0: d wL, 1: d w1x, 2+l: d b_l (l = 0..NH-1);  + scalar d bL.
+// ---------------------------------------------------------------------------------------
+template <int HT, int NH>
+__global__ __launch_bounds__(64 * kWaves) void mono_bwd_k(MonoArgs a) {
+  const MonoLayout& L = a.L;
+  const float* wp = a.pack;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int q = lane >> 4, j = lane & 15;
+  const int HP = 16 * HT;
+  const int64_t ngroups = (a.ecount + 15) / 16;
+  const float fS = (float)a.S;
+
+  f32x4 p_wL[HT], p_w1x[HT], p_b[NH][HT];
+  float p_bL = 0.f;
+#pragma unroll
+  for (int t = 0; t < HT; ++t) {
+    p_wL[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    p_w1x[t] = p_wL[t];
+#pragma unroll
+    for (int l = 0; l < NH; ++l) p_b[l][t] = p_wL[t];
+  }
+
+  for (int64_t grp = (int64_t)blockIdx.x * kWaves + wave; grp < ngroups; grp += (int64_t)gridDim.x * kWaves) {
+    const int64_t el = grp * 16 + j;                 // element index inside the chunk
+    const bool valid = el < a.ecount;
+    const int64_t e = a.e0 + (valid ? el : a.ecount - 1);
+    const int64_t b = e / a.d, i = e - b * a.d;
+    const int64_t hbase = b * a.h_sb + i * a.h_sd;
+    f32x4 c1[HT];
+    cond_bias<HT>(wp, L, a.h, hbase, a.h_sc, q, j, c1);
+    const float xv = a.x[e];
+    const float xT = fS * (xv / fS);
+    const float g_z = valid ? a.gz[e] : 0.f;
+    const float g_j = (valid && a.gjac) ? a.gjac[e] : 0.f;
+    const float cotq = g_z * xT * .5f;               // grad_out * (xT - x0)/2
+    f32x4 Ds[HT];
+#pragma unroll
+    for (int t = 0; t < HT; ++t) Ds[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float dx = 0.f;
+
+    for (int k = 0; k < a.NK; ++k) {
+      const bool isq = k <= a.S, isj = k == a.S + 1;
+      const float xk = isq ? xT * (a.cct[k] + 1.f) * .5f : xv;
+      const float cot = isq ? a.ccw[k] * cotq : (isj ? g_j : 0.f);
+      const int64_t row = (grp * a.NK + k) * 16 + j;
+
+      // ---- forward recompute, remembering ReLU masks; stage the inputs of layers 1..NH-1
+      f32x4 act[HT];
+      unsigned long long msk[NH];
+      msk[0] = 0ull;
+#pragma unroll
+      for (int t = 0; t < HT; ++t) {
+        const f32x4 wx = ld4(wp + L.o_w1x + 16 * t + 4 * q);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float pre = fmaf(wx[r], xk, c1[t][r]);
+          act[t][r] = fmaxf(pre, 0.f);
+          if (pre > 0.f) msk[0] |= 1ull << (4 * t + r);
+        }
+      }
+#pragma unroll
+      for (int l = 1; l < NH; ++l) {
+        float* sa = a.SA[l] + row * HP + 4 * q;
+#pragma unroll
+        for (int t = 0; t < HT; ++t) *reinterpret_cast<f32x4*>(sa + 16 * t) = act[t];
+        const float* W = wp + L.o_W[l];
+        f32x4 o[HT];
+#pragma unroll
+        for (int mt = 0; mt < HT; ++mt) o[mt] = ld4(wp + L.o_b[l] + 16 * mt + 4 * q);
+#pragma unroll
+        for (int t = 0; t < HT; ++t)
+#pragma unroll
+          for (int mt = 0; mt < HT; ++mt) {
+            const f32x4 A = ld4(W + (16 * mt + j) * L.LDW + 16 * t + 4 * q);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) o[mt] = mfma(A[r], act[t][r], o[mt]);
+          }
+        msk[l] = 0ull;
+#pragma unroll
+        for (int t = 0; t < HT; ++t)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            act[t][r] = fmaxf(o[t][r], 0.f);
+            if (o[t][r] > 0.f) msk[l] |= 1ull << (4 * t + r);
+          }
+      }
+      float s = 0.f;
+      f32x4 wl[HT];
+#pragma unroll
+      for (int t = 0; t < HT; ++t) {
+        wl[t] = ld4(wp + L.o_wL + 16 * t + 4 * q);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) s = fmaf(wl[t][r], act[t][r], s);
+      }
+      s = qsum(s) + wp[L.o_bL];
+      const float f = elu_plus(s);
+      if (isj) dx = g_z * f;                                   // Leibniz rule: dz/dx = f(x;h)
+
+      // ---- backward through the last layer and the ELU
+      const float dpl = cot * (s > 0.f ? 1.f : expf(s));
+      if (q == 0) p_bL += dpl;
+      f32x4 dp[HT];
+#pragma unroll
+      for (int t = 0; t < HT; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          p_wL[t][r] = fmaf(dpl, act[t][r], p_wL[t][r]);
+          dp[t][r] = ((msk[NH - 1] >> (4 * t + r)) & 1ull) ? wl[t][r] * dpl : 0.f;
+        }
+      // ---- hidden->hidden layers, top down
+#pragma unroll
+      for (int l = NH - 1; l >= 1; --l) {
+        float* sd = a.SD[l] + row * HP + 4 * q;
+#pragma unroll
+        for (int t = 0; t < HT; ++t) {
+          *reinterpret_cast<f32x4*>(sd + 16 * t) = dp[t];
+          p_b[l][t] += dp[t];
+        }
+        const float* WT = wp + L.o_WT[l];
+        f32x4 da[HT];
+#pragma unroll
+        for (int mt = 0; mt < HT; ++mt) da[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int t = 0; t < HT; ++t)
+#pragma unroll
+          for (int mt = 0; mt < HT; ++mt) {
+            const f32x4 A = ld4(WT + (16 * mt + j) * L.LDW + 16 * t + 4 * q);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) da[mt] = mfma(A[r], dp[t][r], da[mt]);
+          }
+#pragma unroll
+        for (int t = 0; t < HT; ++t)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) dp[t][r] = ((msk[l - 1] >> (4 * t + r)) & 1ull) ? da[t][r] : 0.f;
+      }
+      // ---- first layer: rank-1 in x_k, node-independent in h
+      float sx = 0.f;
+#pragma unroll
+      for (int t = 0; t < HT; ++t) {
+        const f32x4 wx = ld4(wp + L.o_w1x + 16 * t + 4 * q);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          Ds[t][r] += dp[t][r];
+          p_w1x[t][r] = fmaf(dp[t][r], xk, p_w1x[t][r]);
+          sx = fmaf(wx[r], dp[t][r], sx);
+        }
+      }
+      if (isj) dx += qsum(sx);                                 // gjac * df/dx(x;h)
+    }
+
+    // ---- per-group epilogue: d b_0, staged Dsum (for d W1h), dh, dx
+    float* ds = a.Dsum + (grp * 16 + j) * HP + 4 * q;
+#pragma unroll
+    for (int t = 0; t < HT; ++t) {
+      p_b[0][t] += Ds[t];
+      *reinterpret_cast<f32x4*>(ds + 16 * t) = Ds[t];
+    }
+    if (valid && q == 0 && a.gx) a.gx[e] = dx;
+    const int64_t gbase = b * a.g_sb + i * a.g_sd;
+    for (int mt = 0; mt < L.CP / 16; ++mt) {
+      f32x4 o = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int t = 0; t < HT; ++t) {
+        const f32x4 A = ld4(wp + L.o_W1hT + (16 * mt + j) * L.LDW + 16 * t + 4 * q);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o = mfma(A[r], Ds[t][r], o);
+      }
+      if (valid) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int cc = 16 * mt + 4 * q + r;
+          if (cc < L.c) a.gh[gbase + cc * a.g_sc] = o[r] + (cc == 0 ? g_z : 0.f);   // + gz: the "+ z0" term
+        }
+      }
+    }
+  }
+
+  // ---- reduce the per-lane partials over the 16 element lanes, one row per wavefront
+  float* prow = a.part + ((int64_t)blockIdx.x * kWaves + wave) * ((NH + 2) * HP + 4);
+#pragma unroll
+  for (int t = 0; t < HT; ++t)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int hid = 16 * t + 4 * q + r;
+      float v = jsum(p_wL[t][r]);
+      if (j == 0) prow[hid] = v;
+      v = jsum(p_w1x[t][r]);
+      if (j == 0) prow[HP + hid] = v;
+#pragma unroll
+      for (int l = 0; l < NH; ++l) {
+        v = jsum(p_b[l][t][r]);
+        if (j == 0) prow[(2 + l) * HP + hid] = v;
+      }
+    }
+  const float vbl = jsum(p_bL);
+  if (lane == 0) { prow[(NH + 2) * HP] = vbl; prow[(NH + 2) * HP + 1] = 0.f; prow[(NH + 2) * HP + 2] = 0.f; prow[(NH + 2) * HP + 3] = 0.f; }
+}
+
+// sum the split-K / per-wave partial rows:  out[n] = sum_p src[p*N + n]
+__global__ void mono_rowsum_k(const float* __restrict__ src, float* __restrict__ out, int64_t P, int64_t N,
+                              int accumulate) {
+  const int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= N) return;
+  float s = accumulate ? out[n] : 0.f;
+  for (int64_t p = 0; p < P; ++p) s += src[p * N + n];
+  out[n] = s;
+}
+
+struct UnpackArgs {
+  gnf_mono_net net; MonoLayout L;
+  float* gW[GNF_MONO_MAX_LAYERS]; float* gb[GNF_MONO_MAX_LAYERS];
+  const float* dWpad[kMaxNH];   // [HP][HP] (out,in) for l = 1..NH-1
+  const float* dW1h;            // [HP][c]
+  const float* vec;             // [(NH+2)*HP + 4]
+};
+
+__global__ void mono_unpack_k(UnpackArgs u) {
+  const MonoLayout& L = u.L;
+  const gnf_mono_net& N = u.net;
+  const int HP = L.HP, NH = L.NH;
+  const int tid = blockIdx.x * blockDim.x + threadIdx.x, nth = gridDim.x * blockDim.x;
+  const int H0 = N.dims[1], in0 = N.dims[0];
+  for (int k = tid; k < H0 * in0; k += nth) {
+    const int r = k / in0, cc = k % in0;
+    u.gW[0][k] = cc == 0 ? u.vec[HP + r] : u.dW1h[r * L.c + (cc - 1)];
+  }
+  for (int k = tid; k < H0; k += nth) u.gb[0][k] = u.vec[2 * HP + k];
+  for (int l = 1; l < NH; ++l) {
+    const int out = N.dims[l + 1], in = N.dims[l];
+    for (int k = tid; k < out * in; k += nth) u.gW[l][k] = u.dWpad[l][(k / in) * HP + (k % in)];
+    for (int k = tid; k < out; k += nth) u.gb[l][k] = u.vec[(2 + l) * HP + k];
+  }
+  for (int k = tid; k < N.dims[NH]; k += nth) u.gW[NH][k] = u.vec[k];
+  if (tid == 0) u.gb[NH][0] = u.vec[(NH + 2) * HP];
+}
+
+// ---------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------
+int pick_ht(const gnf_mono_net* net) {
+  if (!net || net->nl < 2 || net->nl > GNF_MONO_MAX_LAYERS) return -1;
+  if (net->dims[net->nl] != 1 || net->dims[0] < 1) return -1;
+  int hmax = 0;
+  for (int l = 1; l < net->nl; ++l) hmax = net->dims[l] > hmax ? net->dims[l] : hmax;
+  const int supported[] = {2, 4, 7, 10, 16};
+  for (int ht : supported)
+    if (hmax <= 16 * ht) return ht;
+  return -1;
+}
+
+constexpr int kLdsBudget = 160 * 1024;
+
+template <bool INV>
+int launch_fwd(const MonoArgs& a, hipStream_t s) {
+  const int HT = a.L.HT;
+  const int64_t ngroups = (a.n + 15) / 16;
+  int64_t grid = (ngroups + kWaves - 1) / kWaves;
+  if (grid > 256 * 2) grid = 256 * 2;            // persistent: <= 2 workgroups per CU
+  const size_t lds = (size_t)a.L.fwd_floats * sizeof(float);
+  const bool wlds = lds <= (size_t)kLdsBudget / 2;   // two workgroups per CU keep their own copy
+#define GNF_FWD_CASE(HT_)                                                                                     \
+  case HT_:                                                                                                  \
+    if (wlds) {                                                                                              \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mono_fwd_k<HT_, true, INV>),                      \
+                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                             \
+      hipLaunchKernelGGL((mono_fwd_k<HT_, true, INV>), dim3((unsigned)grid), dim3(64 * kWaves), lds, s, a);  \
+    } else {                                                                                                 \
+      hipLaunchKernelGGL((mono_fwd_k<HT_, false, INV>), dim3((unsigned)grid), dim3(64 * kWaves), 0, s, a);   \
+    }                                                                                                        \
+    break;
+  switch (HT) {
+    GNF_FWD_CASE(2) GNF_FWD_CASE(4) GNF_FWD_CASE(7) GNF_FWD_CASE(10) GNF_FWD_CASE(16)
+    default: return GNF_ESHAPE;
+  }
+#undef GNF_FWD_CASE
+  GNF_LAUNCH_CHECK();
+  return 0;
+}
+
+template <int HT>
+int launch_bwd_nh(const MonoArgs& a, unsigned grid, hipStream_t s) {
+  switch (a.L.NH) {
+    case 1: hipLaunchKernelGGL((mono_bwd_k<HT, 1>), dim3(grid), dim3(64 * kWaves), 0, s, a); break;
+    case 2: hipLaunchKernelGGL((mono_bwd_k<HT, 2>), dim3(grid), dim3(64 * kWaves), 0, s, a); break;
+    case 3: hipLaunchKernelGGL((mono_bwd_k<HT, 3>), dim3(grid), dim3(64 * kWaves), 0, s, a); break;
+    case 4: hipLaunchKernelGGL((mono_bwd_k<HT, 4>), dim3(grid), dim3(64 * kWaves), 0, s, a); break;
+    default: return GNF_ESHAPE;
+  }
+  GNF_LAUNCH_CHECK();
+  return 0;
+}
+
+int launch_bwd(const MonoArgs& a, unsigned grid, hipStream_t s) {
+  switch (a.L.HT) {
+    case 2: return launch_bwd_nh<2>(a, grid, s);
+    case 4: return launch_bwd_nh<4>(a, grid, s);
+    case 7: return launch_bwd_nh<7>(a, grid, s);
+    case 10: return launch_bwd_nh<10>(a, grid, s);
+    case 16: return launch_bwd_nh<16>(a, grid, s);
+    default: return GNF_ESHAPE;
+  }
+}
+
+constexpr unsigned kBwdGrid = 256 * 2;        // persistent workgroups of the chain kernel
+constexpr int kSplits = 256;                  // split-K partials per weight-gradient GEMM
+constexpr int64_t kWsTarget = 6ll << 30;      // staging budget the ws_bytes query asks for
+
+struct BwdPlan {
+  int64_t chunk_elems;      // elements per chain-kernel launch (multiple of 16)
+  int64_t o_SA[kMaxNH], o_SD[kMaxNH], o_Dsum, o_part, o_gpart[kMaxNH], o_hpart, o_dW[kMaxNH], o_dW1h, o_vec;
+  int64_t total_floats;
+};
+
+BwdPlan plan_bwd(const MonoLayout& L, int S, int64_t n, int64_t ws_floats) {
+  BwdPlan P;
+  const int64_t HP = L.HP, NK = (S + 2 + 1) / 2 * 2;
+  const int64_t vecw = (L.NH + 2) * HP + 4;
+  int64_t fixed = 0;
+  P.o_part = fixed; fixed += (int64_t)kBwdGrid * kWaves * vecw;
+  for (int l = 1; l < L.NH; ++l) { P.o_gpart[l] = fixed; fixed += (int64_t)kSplits * HP * HP; }
+  P.o_hpart = fixed; fixed += (int64_t)kSplits * HP * L.c;
+  for (int l = 1; l < L.NH; ++l) { P.o_dW[l] = fixed; fixed += HP * HP; }
+  P.o_dW1h = fixed; fixed += HP * L.c;
+  P.o_vec = fixed; fixed += vecw;
+  const int64_t per_elem = (int64_t)(L.NH - 1) * 2 * NK * HP + HP;     // SA+SD per hidden layer, Dsum
+  int64_t ce = (n + 15) / 16 * 16;
+  if (ws_floats > 0) {
+    const int64_t room = ws_floats - fixed;
+    int64_t fit = room > 0 ? room / per_elem / 16 * 16 : 0;
+    if (fit < ce) ce = fit;
+  }
+  P.chunk_elems = ce;
+  int64_t o = fixed;
+  for (int l = 1; l < L.NH; ++l) { P.o_SA[l] = o; o += ce * NK * HP; P.o_SD[l] = o; o += ce * NK * HP; }
+  P.o_Dsum = o; o += ce * HP;
+  P.total_floats = o;
+  return P;
+}
+
+}  // namespace
+
+extern "C" {
+
+int64_t gnf_monotonic_pack_floats(const gnf_mono_net* net) {
+  const int HT = pick_ht(net);
+  if (HT < 0) return GNF_ESHAPE;
+  return make_layout(HT, net->nl - 1, net->dims[0] - 1).total_floats;
+}
+
+int gnf_monotonic_pack(const gnf_mono_net* net, float* pack, gnf_stream_t stream) {
+  const int HT = pick_ht(net);
+  if (HT < 0) return GNF_ESHAPE;
+  if (!pack) return GNF_EINVAL;
+  PackArgs a;
+  a.net = *net;
+  a.L = make_layout(HT, net->nl - 1, net->dims[0] - 1);
+  hipLaunchKernelGGL(mono_pack_k, dim3((a.L.total_floats + 255) / 256), dim3(256), 0, (hipStream_t)stream, a, pack);
+  GNF_LAUNCH_CHECK();
+  return 0;
+}
+
+int gnf_monotonic_fwd(const float* pack, const gnf_mono_net* net, const float* x, const float* h, int64_t h_sb,
+                      int64_t h_sd, int64_t h_sc, const float* cc_w, const float* cc_t, int S, float* z,
+                      float* jac, int64_t B, int64_t d, gnf_stream_t stream) {
+  const int HT = pick_ht(net);
+  if (HT < 0) return GNF_ESHAPE;
+  if (!pack || !x || !h || !cc_w || !cc_t || !z || !jac || S < 1 || B < 0 || d <= 0) return GNF_EINVAL;
+  if (B == 0) return 0;
+  MonoArgs a{};
+  a.pack = pack; a.L = make_layout(HT, net->nl - 1, net->dims[0] - 1);
+  a.x = x; a.h = h; a.h_sb = h_sb; a.h_sd = h_sd; a.h_sc = h_sc;
+  a.ccw = cc_w; a.cct = cc_t; a.S = S; a.z = z; a.jac = jac; a.n = B * d; a.d = d;
+  return launch_fwd<false>(a, (hipStream_t)stream);
+}
+
+int gnf_monotonic_inv(const float* pack, const gnf_mono_net* net, const float* z, const float* h, int64_t h_sb,
+                      int64_t h_sd, int64_t h_sc, const float* cc_w, const float* cc_t, int S, float* x, int64_t B,
+                      int64_t d, gnf_stream_t stream) {
+  const int HT = pick_ht(net);
+  if (HT < 0) return GNF_ESHAPE;
+  if (!pack || !z || !h || !cc_w || !cc_t || !x || S < 1 || B < 0 || d <= 0) return GNF_EINVAL;
+  if (B == 0) return 0;
+  MonoArgs a{};
+  a.pack = pack; a.L = make_layout(HT, net->nl - 1, net->dims[0] - 1);
+  a.h = h; a.h_sb = h_sb; a.h_sd = h_sd; a.h_sc = h_sc;
+  a.ccw = cc_w; a.cct = cc_t; a.S = S; a.zt = z; a.xo = x; a.n = B * d; a.d = d;
+  return launch_fwd<true>(a, (hipStream_t)stream);
+}
+
+int64_t gnf_monotonic_bwd_ws_bytes(const gnf_mono_net* net, int S, int64_t B, int64_t d) {
+  const int HT = pick_ht(net);
+  if (HT < 0) return GNF_ESHAPE;
+  const MonoLayout L = make_layout(HT, net->nl - 1, net->dims[0] - 1);
+  const BwdPlan full = plan_bwd(L, S, B * d, 0);
+  const int64_t want = full.total_floats * (int64_t)sizeof(float);
+  if (want <= kWsTarget) return want;
+  // bounded staging: at least one 16-element group per persistent wavefront
+  const BwdPlan fixed_only = plan_bwd(L, S, 16, 0);
+  const int64_t min_bytes = fixed_only.total_floats * (int64_t)sizeof(float);
+  return kWsTarget > min_bytes ? kWsTarget : min_bytes;
+}
+
+int gnf_monotonic_bwd(const float* pack, const gnf_mono_net* net, const float* x, const float* h, int64_t h_sb,
+                      int64_t h_sd, int64_t h_sc, const float* cc_w, const float* cc_t, int S, const float* gz,
+                      const float* gjac, float* gx, float* gh, int64_t g_sb, int64_t g_sd, int64_t g_sc,
+                      float* const* gW, float* const* gb, void* ws, int64_t ws_bytes, int64_t B, int64_t d,
+                      gnf_stream_t stream) {
+  const int HT = pick_ht(net);
+  if (HT < 0) return GNF_ESHAPE;
+  if (!pack || !x || !h || !cc_w || !cc_t || !gz || !gh || !gW || !gb || !ws || S < 1 || B < 0 || d <= 0)
+    return GNF_EINVAL;
+  const int NH = net->nl - 1;
+  if (NH > 4) return GNF_ESHAPE;
+  if (h_sb != d * h_sd) return GNF_ESHAPE;   // element stride must collapse (caller makes h contiguous)
+  hipStream_t s = (hipStream_t)stream;
+  const MonoLayout L = make_layout(HT, NH, net->dims[0] - 1);
+  const int64_t n = B * d;
+  const BwdPlan P = plan_bwd(L, S, n, ws_bytes / (int64_t)sizeof(float));
+  if (P.chunk_elems < 16) return GNF_EWS;
+  float* w = (float*)ws;
+  const int64_t HP = L.HP, NK = (S + 2 + 1) / 2 * 2;
+  const int64_t vecw = (NH + 2) * HP + 4;
+
+  MonoArgs a{};
+  a.pack = pack; a.L = L; a.x = x; a.h = h; a.h_sb = h_sb; a.h_sd = h_sd; a.h_sc = h_sc;
+  a.ccw = cc_w; a.cct = cc_t; a.S = S; a.n = n; a.d = d;
+  a.gz = gz; a.gjac = gjac; a.gx = gx; a.gh = gh; a.g_sb = g_sb; a.g_sd = g_sd; a.g_sc = g_sc;
+  for (int l = 1; l < NH; ++l) { a.SA[l] = w + P.o_SA[l]; a.SD[l] = w + P.o_SD[l]; }
+  a.Dsum = w + P.o_Dsum; a.part = w + P.o_part; a.NK = (int)NK;
+
+  auto rowsum = [&](const float* src, float* out, int64_t Pn, int64_t N, int acc) -> int {
+    hipLaunchKernelGGL(mono_rowsum_k, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, s, src, out, Pn, N, acc);
+    GNF_LAUNCH_CHECK();
+    return 0;
+  };
+  const int64_t nchunks = (n + P.chunk_elems - 1) / P.chunk_elems;
+  const int64_t part_rows = (int64_t)kBwdGrid * kWaves;
+  int64_t nsp_w = 1, nsp_h = 1;
+  int rc = 0;
+  for (int64_t ck = 0; ck < nchunks; ++ck) {
+    a.e0 = ck * P.chunk_elems;
+    a.ecount = n - a.e0 < P.chunk_elems ? n - a.e0 : P.chunk_elems;
+    if ((rc = launch_bwd(a, kBwdGrid, s))) return rc;
+    const int64_t groups = (a.ecount + 15) / 16;
+    const int64_t rows = groups * NK * 16;
+    const int accum = ck > 0 ? GNF_GEMM_ACCUM : 0;     // chunk 0 is the largest: it defines the split count
+    // d W_l (+)= dpre_l^T * act_{l-1}   (split-K partials, accumulated across chunks)
+    for (int l = 1; l < NH; ++l) {
+      GemmArgs g{};
+      g.A = a.SD[l]; g.sam = 1; g.sak = HP;
+      g.B = a.SA[l]; g.sbk = HP; g.sbn = 1;
+      g.C = w + P.o_gpart[l]; g.scm = HP; g.scn = 1;
+      g.M = HP; g.N = HP; g.K = rows; g.c_split_stride = HP * HP; g.flags = accum;
+      if (ck == 0) nsp_w = gnf_gemm_num_splits(rows, kSplits);
+      if ((rc = gnf_gemm_launch(g, ck == 0 ? kSplits : (int)nsp_w, s))) return rc;
+    }
+    {  // d W1[:,1:] (+)= Dsum^T * h
+      GemmArgs g{};
+      g.A = a.Dsum; g.sam = 1; g.sak = HP;
+      g.B = h + a.e0 * h_sd; g.sbk = h_sd; g.sbn = h_sc;
+      g.C = w + P.o_hpart; g.scm = L.c; g.scn = 1;
+      g.M = HP; g.N = L.c; g.K = a.ecount; g.c_split_stride = HP * L.c; g.flags = accum;
+      if (ck == 0) nsp_h = gnf_gemm_num_splits(a.ecount, kSplits);
+      if ((rc = gnf_gemm_launch(g, ck == 0 ? kSplits : (int)nsp_h, s))) return rc;
+    }
+    if ((rc = rowsum(a.part, w + P.o_vec, part_rows, vecw, ck > 0))) return rc;
+  }
+  UnpackArgs u{};
+  u.net = *net; u.L = L;
+  for (int l = 0; l <= NH; ++l) { u.gW[l] = gW[l]; u.gb[l] = gb[l]; if (!gW[l] || !gb[l]) return GNF_EINVAL; }
+  for (int l = 1; l < NH; ++l) {
+    if ((rc = rowsum(w + P.o_gpart[l], w + P.o_dW[l], nsp_w, HP * HP, 0))) return rc;
+    u.dWpad[l] = w + P.o_dW[l];
+  }
+  if ((rc = rowsum(w + P.o_hpart, w + P.o_dW1h, nsp_h, HP * L.c, 0))) return rc;
+  u.dW1h = w + P.o_dW1h; u.vec = w + P.o_vec;
+  hipLaunchKernelGGL(mono_unpack_k, dim3(64), dim3(256), 0, s, u);
+  GNF_LAUNCH_CHECK();
+  return 0;
+}
+
+}  // extern "C"

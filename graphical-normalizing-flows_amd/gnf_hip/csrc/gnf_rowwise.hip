@@ -1,0 +1,283 @@
+// HBM-bound row-wise kernels: Affine normalizer (fwd/bwd/inverse) with the log-det
+// row reduction fused, log|det J| and Normal log-density row reductions, column sums
+// (bias gradients) and the flat Adam step.
+//
+// Layout: a "row" is one sample b of [B,d].  G = min(64, pow2 >= d) consecutive lanes
+// own one row (64/G rows per wavefront), lanes stride over the d columns so global
+// loads are coalesced, and the per-row reduction is a __shfl_xor butterfly inside the
+// lane group -- no LDS, no atomics, deterministic.
+#include "gnf_common.h"
+
+namespace {
+
+constexpr int kBlock = 256;
+
+#define GNF_DISPATCH_G(G_, KERNEL, grid_rows, ...)                                              \
+  do {                                                                                          \
+    const int rpb__ = kBlock / (G_);                                                            \
+    const unsigned grid__ = (unsigned)(((grid_rows) + rpb__ - 1) / rpb__);                      \
+    hipStream_t s__ = (hipStream_t)stream;                                                      \
+    switch (G_) {                                                                               \
+      case 1: hipLaunchKernelGGL((KERNEL<1>), dim3(grid__), dim3(kBlock), 0, s__, __VA_ARGS__); break;   \
+      case 2: hipLaunchKernelGGL((KERNEL<2>), dim3(grid__), dim3(kBlock), 0, s__, __VA_ARGS__); break;   \
+      case 4: hipLaunchKernelGGL((KERNEL<4>), dim3(grid__), dim3(kBlock), 0, s__, __VA_ARGS__); break;   \
+      case 8: hipLaunchKernelGGL((KERNEL<8>), dim3(grid__), dim3(kBlock), 0, s__, __VA_ARGS__); break;   \
+      case 16: hipLaunchKernelGGL((KERNEL<16>), dim3(grid__), dim3(kBlock), 0, s__, __VA_ARGS__); break; \
+      case 32: hipLaunchKernelGGL((KERNEL<32>), dim3(grid__), dim3(kBlock), 0, s__, __VA_ARGS__); break; \
+      default: hipLaunchKernelGGL((KERNEL<64>), dim3(grid__), dim3(kBlock), 0, s__, __VA_ARGS__); break; \
+    }                                                                                           \
+  } while (0)
+
+__device__ __forceinline__ float clampf(float v, float lo, float hi) { return fminf(fmaxf(v, lo), hi); }
+
+// ------------------------------------------------------------------ Affine normalizer
+template <int G>
+__global__ void affine_fwd_k(const float* __restrict__ x, float* __restrict__ h, int64_t h_sb, int64_t h_sd,
+                             int64_t h_sc, float* __restrict__ z, float* __restrict__ jac,
+                             float* __restrict__ logdet, int clamp_inplace, int64_t B, int64_t d) {
+  const int64_t row = (int64_t)blockIdx.x * (kBlock / G) + threadIdx.x / G;
+  const int g = threadIdx.x % G;
+  float ld = 0.f;
+  if (row < B) {
+    for (int64_t i = g; i < d; i += G) {
+      const int64_t hi = row * h_sb + i * h_sd;
+      const float mu = clampf(h[hi], -5.f, 5.f);
+      const float ls = clampf(h[hi + h_sc], -5.f, 2.f);
+      const float sg = expf(ls);
+      const int64_t e = row * d + i;
+      z[e] = fmaf(x[e], sg, mu);
+      if (jac) jac[e] = sg;
+      if (clamp_inplace) { h[hi] = mu; h[hi + h_sc] = ls; }
+      ld += ls;
+    }
+  }
+  ld = group_sum<G>(ld);
+  if (logdet && row < B && g == 0) logdet[row] = ld;
+}
+
+template <int G>
+__global__ void affine_bwd_k(const float* __restrict__ x, const float* __restrict__ h, int64_t h_sb, int64_t h_sd,
+                             int64_t h_sc, const float* __restrict__ gz, const float* __restrict__ gjac,
+                             const float* __restrict__ glogdet, float* __restrict__ gx, float* __restrict__ gh,
+                             int64_t g_sb, int64_t g_sd, int64_t g_sc, int64_t B, int64_t d) {
+  const int64_t row = (int64_t)blockIdx.x * (kBlock / G) + threadIdx.x / G;
+  const int g = threadIdx.x % G;
+  if (row >= B) return;
+  const float gl = glogdet ? glogdet[row] : 0.f;
+  for (int64_t i = g; i < d; i += G) {
+    const int64_t hi = row * h_sb + i * h_sd;
+    const float h0 = h[hi], h1 = h[hi + h_sc];
+    // torch clamp backward passes the gradient where min <= v <= max (boundaries included)
+    const float m0 = (h0 >= -5.f && h0 <= 5.f) ? 1.f : 0.f;
+    const float m1 = (h1 >= -5.f && h1 <= 2.f) ? 1.f : 0.f;
+    const float sg = expf(clampf(h1, -5.f, 2.f));
+    const int64_t e = row * d + i;
+    const float g_z = gz ? gz[e] : 0.f;
+    const float g_j = gjac ? gjac[e] : 0.f;
+    if (gx) gx[e] = g_z * sg;
+    const int64_t gi = row * g_sb + i * g_sd;
+    gh[gi] = g_z * m0;
+    gh[gi + g_sc] = (fmaf(g_z * x[e], sg, g_j * sg) + gl) * m1;
+  }
+}
+
+__global__ void affine_inv_k(const float* __restrict__ z, const float* __restrict__ h, int64_t h_sb, int64_t h_sd,
+                             int64_t h_sc, float* __restrict__ x, int64_t B, int64_t d) {
+  const int64_t n = B * d;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t b = e / d, i = e - b * d;
+    const int64_t hi = b * h_sb + i * h_sd;
+    const float mu = clampf(h[hi], -5.f, 5.f);
+    const float sg = expf(clampf(h[hi + h_sc], -5.f, 2.f));
+    x[e] = (z[e] - mu) / sg;
+  }
+}
+
+// ------------------------------------------------------------------ row reductions
+template <int G>
+__global__ void logsum_rows_k(const float* __restrict__ jac, float* __restrict__ out, int64_t B, int64_t d) {
+  const int64_t row = (int64_t)blockIdx.x * (kBlock / G) + threadIdx.x / G;
+  const int g = threadIdx.x % G;
+  float s = 0.f;
+  if (row < B)
+    for (int64_t i = g; i < d; i += G) s += logf(jac[row * d + i]);
+  s = group_sum<G>(s);
+  if (row < B && g == 0) out[row] = s;
+}
+
+template <int G>
+__global__ void normal_ld_rows_k(const float* __restrict__ z, float* __restrict__ out, int64_t B, int64_t d) {
+  const int64_t row = (int64_t)blockIdx.x * (kBlock / G) + threadIdx.x / G;
+  const int g = threadIdx.x % G;
+  float s = 0.f;
+  if (row < B)
+    for (int64_t i = g; i < d; i += G) {
+      const float v = z[row * d + i];
+      s += 1.8378770664093453f + v * v;  // log(2 pi) + z^2, summed like the reference does
+    }
+  s = group_sum<G>(s);
+  if (row < B && g == 0) out[row] = -0.5f * s;
+}
+
+__global__ void logsum_rows_bwd_k(const float* __restrict__ jac, const float* __restrict__ g, float* __restrict__ gj,
+                                  int64_t B, int64_t d) {
+  const int64_t n = B * d;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x)
+    gj[e] = g[e / d] / jac[e];
+}
+
+__global__ void normal_ld_bwd_k(const float* __restrict__ z, const float* __restrict__ g, float* __restrict__ gz,
+                                int64_t B, int64_t d) {
+  const int64_t n = B * d;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x)
+    gz[e] = -z[e] * g[e / d];
+}
+
+// ------------------------------------------------------------------ column sums
+// stage 1: block (bx, by) sums rows [by*R, by*R+R) of column tile bx into ws[by][n];
+// stage 2: sums the gridDim.y partials.  Fixed order -> bit-reproducible.
+constexpr int kColRows = 512;
+__global__ void colsum_stage1_k(const float* __restrict__ a, int64_t lda, float* __restrict__ ws, int64_t M,
+                                int64_t N) {
+  const int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= N) return;
+  const int64_t m0 = (int64_t)blockIdx.y * kColRows;
+  const int64_t m1 = m0 + kColRows < M ? m0 + kColRows : M;
+  float s = 0.f;
+  for (int64_t m = m0; m < m1; ++m) s += a[m * lda + n];
+  ws[(int64_t)blockIdx.y * N + n] = s;
+}
+__global__ void colsum_stage2_k(const float* __restrict__ ws, float* __restrict__ out, int64_t P, int64_t N) {
+  const int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= N) return;
+  float s = 0.f;
+  for (int64_t p = 0; p < P; ++p) s += ws[p * N + n];
+  out[n] = s;
+}
+
+// ------------------------------------------------------------------ Adam (L2 decay, bias-corrected)
+__global__ void adam_k(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                       float* __restrict__ v, int64_t n, float lr, float b1, float b2, float eps, float wd,
+                       float gscale, float bc1, float bc2_sqrt) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const float pi = p[i];
+    const float gi = fmaf(wd, pi, g[i] * gscale);
+    const float mi = fmaf(b1, m[i], (1.f - b1) * gi);
+    const float vi = fmaf(b2, v[i], (1.f - b2) * gi * gi);
+    m[i] = mi;
+    v[i] = vi;
+    // torch.optim.Adam: denom = sqrt(v)/sqrt(bc2) + eps; p -= lr/bc1 * m/denom
+    p[i] = pi - (lr / bc1) * (mi / (sqrtf(vi) / bc2_sqrt + eps));
+  }
+}
+
+inline unsigned grid_1d(int64_t n) {
+  int64_t g = (n + kBlock - 1) / kBlock;
+  if (g > 256 * 8) g = 256 * 8;   // 8 blocks per CU, grid-stride the rest
+  if (g < 1) g = 1;
+  return (unsigned)g;
+}
+
+}  // namespace
+
+extern "C" {
+
+int gnf_abi_version(void) { return GNF_ABI_VERSION; }
+
+int gnf_affine_fwd(const float* x, float* h, int64_t h_sb, int64_t h_sd, int64_t h_sc, float* z, float* jac,
+                   float* logdet, int clamp_inplace, int64_t B, int64_t d, gnf_stream_t stream) {
+  if (!x || !h || !z || B < 0 || d <= 0) return GNF_EINVAL;
+  if (B == 0) return 0;
+  const int G = gnf_pow2_ge(d, 64);
+  GNF_DISPATCH_G(G, affine_fwd_k, B, x, h, h_sb, h_sd, h_sc, z, jac, logdet, clamp_inplace, B, d);
+  GNF_LAUNCH_CHECK();
+  return 0;
+}
+
+int gnf_affine_bwd(const float* x, const float* h, int64_t h_sb, int64_t h_sd, int64_t h_sc, const float* gz,
+                   const float* gjac, const float* glogdet, float* gx, float* gh, int64_t g_sb, int64_t g_sd,
+                   int64_t g_sc, int64_t B, int64_t d, gnf_stream_t stream) {
+  if (!x || !h || !gh || B < 0 || d <= 0) return GNF_EINVAL;
+  if (B == 0) return 0;
+  const int G = gnf_pow2_ge(d, 64);
+  GNF_DISPATCH_G(G, affine_bwd_k, B, x, h, h_sb, h_sd, h_sc, gz, gjac, glogdet, gx, gh, g_sb, g_sd, g_sc, B, d);
+  GNF_LAUNCH_CHECK();
+  return 0;
+}
+
+int gnf_affine_inv(const float* z, const float* h, int64_t h_sb, int64_t h_sd, int64_t h_sc, float* x, int64_t B,
+                   int64_t d, gnf_stream_t stream) {
+  if (!z || !h || !x || B < 0 || d <= 0) return GNF_EINVAL;
+  if (B == 0) return 0;
+  hipLaunchKernelGGL(affine_inv_k, dim3(grid_1d(B * d)), dim3(kBlock), 0, (hipStream_t)stream, z, h, h_sb, h_sd,
+                     h_sc, x, B, d);
+  GNF_LAUNCH_CHECK();
+  return 0;
+}
+
+int gnf_logsum_rows_fwd(const float* jac, float* out, int64_t B, int64_t d, gnf_stream_t stream) {
+  if (!jac || !out || B < 0 || d <= 0) return GNF_EINVAL;
+  if (B == 0) return 0;
+  const int G = gnf_pow2_ge(d, 64);
+  GNF_DISPATCH_G(G, logsum_rows_k, B, jac, out, B, d);
+  GNF_LAUNCH_CHECK();
+  return 0;
+}
+
+int gnf_logsum_rows_bwd(const float* jac, const float* g, float* gjac, int64_t B, int64_t d, gnf_stream_t stream) {
+  if (!jac || !g || !gjac || B < 0 || d <= 0) return GNF_EINVAL;
+  if (B == 0) return 0;
+  hipLaunchKernelGGL(logsum_rows_bwd_k, dim3(grid_1d(B * d)), dim3(kBlock), 0, (hipStream_t)stream, jac, g, gjac, B,
+                     d);
+  GNF_LAUNCH_CHECK();
+  return 0;
+}
+
+int gnf_normal_logdensity_fwd(const float* z, float* out, int64_t B, int64_t d, gnf_stream_t stream) {
+  if (!z || !out || B < 0 || d <= 0) return GNF_EINVAL;
+  if (B == 0) return 0;
+  const int G = gnf_pow2_ge(d, 64);
+  GNF_DISPATCH_G(G, normal_ld_rows_k, B, z, out, B, d);
+  GNF_LAUNCH_CHECK();
+  return 0;
+}
+
+int gnf_normal_logdensity_bwd(const float* z, const float* g, float* gz, int64_t B, int64_t d, gnf_stream_t stream) {
+  if (!z || !g || !gz || B < 0 || d <= 0) return GNF_EINVAL;
+  if (B == 0) return 0;
+  hipLaunchKernelGGL(normal_ld_bwd_k, dim3(grid_1d(B * d)), dim3(kBlock), 0, (hipStream_t)stream, z, g, gz, B, d);
+  GNF_LAUNCH_CHECK();
+  return 0;
+}
+
+int64_t gnf_colsum_ws_bytes(int64_t M, int64_t N) {
+  const int64_t P = (M + kColRows - 1) / kColRows;
+  return (P > 0 ? P : 1) * N * (int64_t)sizeof(float);
+}
+
+int gnf_colsum(const float* a, int64_t lda, float* out, int64_t M, int64_t N, float* ws, gnf_stream_t stream) {
+  if (!a || !out || !ws || M < 0 || N <= 0) return GNF_EINVAL;
+  const int64_t P = (M + kColRows - 1) / kColRows;
+  const unsigned gx = (unsigned)((N + kBlock - 1) / kBlock);
+  if (P > 0) {
+    hipLaunchKernelGGL(colsum_stage1_k, dim3(gx, (unsigned)P), dim3(kBlock), 0, (hipStream_t)stream, a, lda, ws, M, N);
+    GNF_LAUNCH_CHECK();
+  }
+  hipLaunchKernelGGL(colsum_stage2_k, dim3(gx), dim3(kBlock), 0, (hipStream_t)stream, ws, out, P, N);
+  GNF_LAUNCH_CHECK();
+  return 0;
+}
+
+int gnf_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
+                  float eps, float weight_decay, float grad_scale, int step, gnf_stream_t stream) {
+  if (!p || !g || !m || !v || n < 0 || step < 1) return GNF_EINVAL;
+  if (n == 0) return 0;
+  const float bc1 = 1.f - powf(beta1, (float)step);
+  const float bc2s = sqrtf(1.f - powf(beta2, (float)step));
+  hipLaunchKernelGGL(adam_k, dim3(grid_1d(n)), dim3(kBlock), 0, (hipStream_t)stream, p, g, m, v, n, lr, beta1, beta2,
+                     eps, weight_decay, grad_scale, bc1, bc2s);
+  GNF_LAUNCH_CHECK();
+  return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,353 @@
+"""torch.autograd wrappers around the C-ABI kernels (gnf_hip.abi).
+
+PyTorch's role here is plumbing: tensor allocation, autograd graph bookkeeping and the
+current HIP stream.  Every numerical step of the flow hot path runs in libgnf_hip.so."""
+import ctypes
+import math
+
+import numpy as np
+import torch
+
+from . import abi
+from .abi import ptr, stream, call
+
+
+def _empty(shape, like):
+    return torch.empty(shape, dtype=torch.float32, device=like.device)
+
+
+def _ws(nbytes, like):
+    return torch.empty(max(int(nbytes) // 4, 1), dtype=torch.float32, device=like.device)
+
+
+# ----------------------------------------------------------------------------- Affine normalizer
+class AffineFn(torch.autograd.Function):
+    """(z, jac, logdet) of models/Normalizers/AffineNormalizer.py:9-12 fused with the
+    log|det J| row reduction of models/NormalizingFlow.py:70."""
+
+    @staticmethod
+    def forward(ctx, x, h, clamp_inplace=False):
+        x = x.contiguous()
+        B, d = x.shape
+        z, jac, logdet = _empty((B, d), x), _empty((B, d), x), _empty((B,), x)
+        h_bwd = h.detach().clone() if clamp_inplace else h
+        call("gnf_affine_fwd", ptr(x), ptr(h), h.stride(0), h.stride(1), h.stride(2), ptr(z), ptr(jac), ptr(logdet),
+             int(bool(clamp_inplace)), B, d, stream())
+        ctx.save_for_backward(x, h_bwd)
+        ctx.hshape = tuple(h.shape)
+        return z, jac, logdet
+
+    @staticmethod
+    def backward(ctx, gz, gjac, glogdet):
+        x, h = ctx.saved_tensors
+        B, d = x.shape
+        hs = ctx.hshape[2]
+        # same memory format as h so that e.g. MADE's permuted view flows back without a copy
+        gh = torch.empty_like(h) if hs == 2 else torch.zeros_like(h)
+        gx = _empty((B, d), x) if ctx.needs_input_grad[0] else None
+        call("gnf_affine_bwd", ptr(x), ptr(h), h.stride(0), h.stride(1), h.stride(2),
+             ptr(gz.contiguous()) if gz is not None else None,
+             ptr(gjac.contiguous()) if gjac is not None else None,
+             ptr(glogdet.contiguous()) if glogdet is not None else None,
+             ptr(gx), ptr(gh), gh.stride(0), gh.stride(1), gh.stride(2), B, d, stream())
+        return gx, gh, None
+
+
+def affine_inverse(z, h):
+    """(z - mu)/sigma   (AffineNormalizer.py:14-17)."""
+    z = z.contiguous()
+    B, d = z.shape
+    x = _empty((B, d), z)
+    call("gnf_affine_inv", ptr(z), ptr(h), h.stride(0), h.stride(1), h.stride(2), ptr(x), B, d, stream())
+    return x
+
+
+# ----------------------------------------------------------------------------- row reductions
+class LogSumRowsFn(torch.autograd.Function):
+    """torch.log(jac).sum(1)   (models/NormalizingFlow.py:70)."""
+
+    @staticmethod
+    def forward(ctx, jac):
+        jac = jac.contiguous()
+        B, d = jac.shape
+        out = _empty((B,), jac)
+        call("gnf_logsum_rows_fwd", ptr(jac), ptr(out), B, d, stream())
+        ctx.save_for_backward(jac)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        jac, = ctx.saved_tensors
+        B, d = jac.shape
+        gj = _empty((B, d), jac)
+        call("gnf_logsum_rows_bwd", ptr(jac), ptr(g.contiguous()), ptr(gj), B, d, stream())
+        return gj
+
+
+class NormalLogDensityFn(torch.autograd.Function):
+    """-.5*(log(2 pi) + z**2).sum(1)   (models/NormalizingFlowFactories.py:15-16)."""
+
+    @staticmethod
+    def forward(ctx, z):
+        z = z.contiguous()
+        B, d = z.shape
+        out = _empty((B,), z)
+        call("gnf_normal_logdensity_fwd", ptr(z), ptr(out), B, d, stream())
+        ctx.save_for_backward(z)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        z, = ctx.saved_tensors
+        B, d = z.shape
+        gz = _empty((B, d), z)
+        call("gnf_normal_logdensity_bwd", ptr(z), ptr(g.contiguous()), ptr(gz), B, d, stream())
+        return gz
+
+
+def colsum(a):
+    """sum over rows of a contiguous [M,N] tensor (bias gradients)."""
+    M, N = a.shape
+    out = _empty((N,), a)
+    ws = _ws(abi.load().gnf_colsum_ws_bytes(M, N), a)
+    call("gnf_colsum", ptr(a), N, ptr(out), M, N, ptr(ws), stream())
+    return out
+
+
+# ----------------------------------------------------------------------------- MFMA GEMM / MLP chains
+def gemm(A, a_strides, Bm, b_strides, C, c_strides, M, N, K, Bmask=None, bias=None, Cmask=None, cm_strides=(0, 0),
+         gate=None, g_strides=(0, 0), relu=False):
+    call("gnf_gemm", ptr(A), a_strides[0], a_strides[1], ptr(Bm), ptr(Bmask), b_strides[0], b_strides[1], ptr(C),
+         c_strides[0], c_strides[1], ptr(bias), ptr(Cmask), cm_strides[0], cm_strides[1], ptr(gate), g_strides[0],
+         g_strides[1], 1 if relu else 0, M, N, K, stream())
+
+
+class MLPFn(torch.autograd.Function):
+    """y = L_n(relu(L_{n-1}(... relu(L_1(x))))), L_i(a) = a @ (mask_i * W_i)^T + b_i.
+
+    One Function for every Linear/ReLU chain of the conditioners: CouplingMLP
+    (CouplingConditioner.py:6-19), DAGMLP (DAGConditioner.py:7-20), MADE's masked linears
+    (AutoregressiveConditioner.py:14-25, mask fused into the weight load instead of a
+    mask*weight product per forward), MNISTCNN.fc1/fc2 (MLP.py:44-47).  The backward fuses the
+    ReLU gate into the epilogue of the data-gradient GEMM and the mask into the
+    weight-gradient GEMM."""
+
+    @staticmethod
+    def forward(ctx, x, masks, *params):
+        x = x.contiguous()
+        n = len(params) // 2
+        acts = [x]
+        a = x
+        for li in range(n):
+            W, b = params[2 * li].contiguous(), params[2 * li + 1]
+            mk = masks[li] if masks is not None else None
+            out_f, in_f = W.shape
+            M = a.shape[0]
+            y = _empty((M, out_f), x)
+            gemm(a, (in_f, 1), W, (1, in_f), y, (out_f, 1), M, out_f, in_f, Bmask=mk, bias=b, relu=(li < n - 1))
+            a = y
+            if li < n - 1:
+                acts.append(y)
+        ctx.masks = masks
+        ctx.n = n
+        ctx.save_for_backward(*acts, *params)
+        return a
+
+    @staticmethod
+    def backward(ctx, gy):
+        n = ctx.n
+        saved = ctx.saved_tensors
+        acts, params = saved[:n], saved[n:]
+        g = gy.contiguous()
+        grads = [None] * (2 * n)
+        gx = None
+        for li in range(n - 1, -1, -1):
+            W = params[2 * li].contiguous()
+            mk = ctx.masks[li] if ctx.masks is not None else None
+            out_f, in_f = W.shape
+            a = acts[li]
+            M = a.shape[0]
+            if ctx.needs_input_grad[2 + 2 * li]:
+                gW = _empty((out_f, in_f), W)
+                gemm(g, (1, out_f), a, (in_f, 1), gW, (in_f, 1), out_f, in_f, M, Cmask=mk, cm_strides=(in_f, 1))
+                grads[2 * li] = gW
+            if ctx.needs_input_grad[3 + 2 * li]:
+                grads[2 * li + 1] = colsum(g)
+            if li > 0 or ctx.needs_input_grad[0]:
+                ga = _empty((M, in_f), W)
+                gemm(g, (out_f, 1), W, (in_f, 1), ga, (in_f, 1), M, in_f, out_f, Bmask=mk,
+                     gate=(a if li > 0 else None), g_strides=(in_f, 1))
+                g = ga
+                if li == 0:
+                    gx = ga
+        return (gx, None, *grads)
+
+
+def mlp(x, layers, masks=None):
+    """layers: list of (weight, bias) parameter pairs."""
+    flat = [p for Wb in layers for p in Wb]
+    return MLPFn.apply(x, masks, *flat)
+
+
+# ----------------------------------------------------------------------------- DAG gate
+IMP_RAW, IMP_SOFT, IMP_HARD_SOFT, IMP_HARD_SQ = 0, 1, 2, 3
+GATE_DET, GATE_GUMBEL, GATE_NOISE = 0, 1, 2
+
+
+class DagGateFn(torch.autograd.Function):
+    """e[b*d+i, :] = x[b, :] * gate(importance(A[i, :])) (+ one-hot(i))
+    (models/Conditionners/DAGConditioner.py:94-166)."""
+
+    @staticmethod
+    def forward(ctx, x, A, imp_mode, gate_mode, h_thresh, temperature, hot, u1, u2, seed, offset):
+        x = x.contiguous()
+        A = A.contiguous()
+        B, d = x.shape
+        ld = 2 * d if hot else d
+        e = _empty((B * d, ld), x)
+        u1 = u1.contiguous() if u1 is not None else None
+        u2 = u2.contiguous() if u2 is not None else None
+        call("gnf_dag_gate_fwd", ptr(x), ptr(A), ptr(e), ld, imp_mode, gate_mode, float(h_thresh), float(temperature),
+             ptr(u1), ptr(u2), seed, offset, int(hot), B, d, stream())
+        ctx.save_for_backward(x, A, u1, u2)
+        ctx.cfg = (imp_mode, gate_mode, float(h_thresh), float(temperature), ld, seed, offset)
+        return e
+
+    @staticmethod
+    def backward(ctx, ge):
+        x, A, u1, u2 = ctx.saved_tensors
+        imp_mode, gate_mode, h_thresh, temperature, ld, seed, offset = ctx.cfg
+        B, d = x.shape
+        ge = ge.contiguous()
+        gA = _empty((d, d), x) if ctx.needs_input_grad[1] else None
+        gx = _empty((B, d), x) if ctx.needs_input_grad[0] else None
+        ws = _ws(abi.load().gnf_dag_gate_bwd_ws_bytes(B, d), x) if gA is not None else None
+        call("gnf_dag_gate_bwd", ptr(x), ptr(A), ptr(ge), ld, imp_mode, gate_mode, h_thresh, temperature, ptr(u1),
+             ptr(u2), seed, offset, ptr(gA), ptr(gx), ptr(ws), B, d, stream())
+        return gx, gA, None, None, None, None, None, None, None, None, None
+
+
+# ----------------------------------------------------------------------------- Monotonic (UMNN) normalizer
+_CC = {}
+
+
+def cc_rule(nb_steps, device):
+    """Clenshaw-Curtis weights / nodes, built on the host in fp64 with the construction of
+    UMNN 1.0's compute_cc_weights (third-party, absent from the reference tree; restated
+    from its published algorithm -- parity unpinned), cast to fp32."""
+    key = (int(nb_steps), str(device))
+    if key not in _CC:
+        S = int(nb_steps)
+        k = np.arange(0, S + 1, dtype=np.float64).reshape(-1, 1)
+        lam = np.cos((k @ k.T) * math.pi / S)
+        lam[:, 0] = .5
+        lam[:, -1] = .5 * lam[:, -1]
+        lam = lam * 2 / S
+        W = k.copy()
+        odd = np.arange(1, S + 1, 2)
+        W[odd] = 0
+        W = 2 / (1 - W ** 2)
+        W[0] = 1
+        W[odd] = 0
+        w = (lam.T @ W).reshape(-1)
+        t = np.cos(np.arange(0, S + 1) * math.pi / S)
+        _CC[key] = (torch.tensor(w, dtype=torch.float32, device=device),
+                    torch.tensor(t, dtype=torch.float32, device=device))
+    return _CC[key]
+
+
+def _mono_net(params):
+    """params: [W0, b0, W1, b1, ...] contiguous fp32 HIP tensors -> gnf_mono_net."""
+    nl = len(params) // 2
+    if nl < 2 or nl > abi.MONO_MAX_LAYERS:
+        raise abi.GnfError("integrand net needs 2..%d Linear layers" % abi.MONO_MAX_LAYERS)
+    net = abi.MonoNet()
+    net.nl = nl
+    net.dims[0] = params[0].shape[1]
+    for l in range(nl):
+        W, b = params[2 * l], params[2 * l + 1]
+        if W.shape[1] != net.dims[l]:
+            raise abi.GnfError("integrand net layer %d: in_features mismatch" % l)
+        net.dims[l + 1] = W.shape[0]
+        net.W[l] = ptr(W).value
+        net.b[l] = ptr(b).value
+    return net
+
+
+def _mono_pack(net, like):
+    nfl = abi.load().gnf_monotonic_pack_floats(ctypes.byref(net))
+    if nfl < 0:
+        abi.check(int(nfl), "gnf_monotonic_pack_floats")
+    pack = _empty((int(nfl),), like)
+    call("gnf_monotonic_pack", ctypes.byref(net), ptr(pack), stream())
+    return pack
+
+
+class MonotonicFn(torch.autograd.Function):
+    """z = int_0^x f(t;h) dt + h[...,0],  jac = f(x;h)
+    (models/Normalizers/MonotonicNormalizer.py:51-66 + UMNN NeuralIntegral, incl. its
+    Leibniz-rule x-gradient)."""
+
+    @staticmethod
+    def forward(ctx, x, h, nb_steps, *params):
+        x = x.contiguous()
+        params = [p.contiguous() for p in params]
+        B, d = x.shape
+        net = _mono_net(params)
+        if h.shape[2] != net.dims[0] - 1:
+            raise abi.GnfError("cond_size %d != integrand net input %d - 1" % (h.shape[2], net.dims[0]))
+        pack = _mono_pack(net, x)
+        w, t = cc_rule(nb_steps, x.device)
+        z, jac = _empty((B, d), x), _empty((B, d), x)
+        call("gnf_monotonic_fwd", ptr(pack), ctypes.byref(net), ptr(x), ptr(h), h.stride(0), h.stride(1), h.stride(2),
+             ptr(w), ptr(t), int(nb_steps), ptr(z), ptr(jac), B, d, stream())
+        ctx.save_for_backward(x, h, pack, *params)
+        ctx.S = int(nb_steps)
+        return z, jac
+
+    @staticmethod
+    def backward(ctx, gz, gjac):
+        x, h, pack, *params = ctx.saved_tensors
+        B, d = x.shape
+        S = ctx.S
+        net = _mono_net(params)
+        if h.stride(0) != d * h.stride(1):
+            h = h.contiguous()          # element stride must collapse for the d W1 GEMM
+        w, t = cc_rule(S, x.device)
+        gz = gz.contiguous() if gz is not None else torch.zeros_like(x)
+        gjac = gjac.contiguous() if gjac is not None else None
+        gx = _empty((B, d), x)
+        gh = _empty(tuple(h.shape), x)
+        gparams = [torch.empty_like(p) for p in params]
+        nl = net.nl
+        gW = (ctypes.c_void_p * nl)(*[gparams[2 * l].data_ptr() for l in range(nl)])
+        gb = (ctypes.c_void_p * nl)(*[gparams[2 * l + 1].data_ptr() for l in range(nl)])
+        nbytes = abi.load().gnf_monotonic_bwd_ws_bytes(ctypes.byref(net), S, B, d)
+        if nbytes < 0:
+            abi.check(int(nbytes), "gnf_monotonic_bwd_ws_bytes")
+        ws = _ws(nbytes, x)
+        call("gnf_monotonic_bwd", ptr(pack), ctypes.byref(net), ptr(x), ptr(h), h.stride(0), h.stride(1), h.stride(2),
+             ptr(w), ptr(t), S, ptr(gz), ptr(gjac), ptr(gx), ptr(gh), gh.stride(0), gh.stride(1), gh.stride(2),
+             gW, gb, ctypes.c_void_p(ws.data_ptr()), ws.numel() * 4, B, d, stream())
+        return (gx, gh, None, *gparams)
+
+
+def monotonic_inverse(z, h, nb_steps, params):
+    """20-step bisection on [-20, 20], the quadrature fused in the kernel
+    (MonotonicNormalizer.py:69-83)."""
+    z = z.contiguous()
+    params = [p.detach().contiguous() for p in params]
+    B, d = z.shape
+    net = _mono_net(params)
+    pack = _mono_pack(net, z)
+    w, t = cc_rule(nb_steps, z.device)
+    x = _empty((B, d), z)
+    call("gnf_monotonic_inv", ptr(pack), ctypes.byref(net), ptr(z), ptr(h), h.stride(0), h.stride(1), h.stride(2),
+         ptr(w), ptr(t), int(nb_steps), ptr(x), B, d, stream())
+    return x
+
+
+# ----------------------------------------------------------------------------- Adam on a flat buffer
+def adam_step(p, g, m, v, step, lr=1e-3, betas=(.9, .999), eps=1e-8, weight_decay=0., grad_scale=1.):
+    call("gnf_adam_step", ptr(p), ptr(g), ptr(m), ptr(v), p.numel(), lr, betas[0], betas[1], eps, weight_decay,
+         grad_scale, int(step), stream())

@@ -1,0 +1,112 @@
+import numpy as np
+import torch
+import torch.nn as nn
+
+from gnf_hip import ops
+from .Conditioner import Conditioner, no_context
+
+
+class MaskedLinear(nn.Linear):
+    """nn.Linear with a fixed 0/1 `mask` buffer on the weights (reference
+    AutoregressiveConditioner.py:14-25).  The product mask*weight is never materialised:
+    the GEMM multiplies the mask in while it stages the weight tile."""
+
+    def __init__(self, in_features, out_features, bias=True):
+        super().__init__(in_features, out_features, bias)
+        self.register_buffer('mask', torch.ones(out_features, in_features))
+
+    def set_mask(self, mask):
+        self.mask.data.copy_(torch.from_numpy(mask.astype(np.uint8).T))
+
+    def forward(self, input):
+        return ops.mlp(input, [(self.weight, self.bias)], [self.mask])
+
+
+def made_degrees(nin, hidden_sizes):
+    """Natural-ordering degrees of the reference MADE (random=False branch, :85-87)."""
+    m = {-1: np.arange(nin)}
+    for l, hsz in enumerate(hidden_sizes):
+        m[l] = np.array([nin - 1 - (i % nin) for i in range(hsz)])
+    return m
+
+
+class MADE(nn.Module):
+    """Masked autoencoder with the reference's natural ordering (`random=False`),
+    AutoregressiveConditioner.py:28-109.  Output neurons are chunked component-major."""
+
+    def __init__(self, nin, hidden_sizes, nout, num_masks=1, natural_ordering=False, random=False, device="cpu"):
+        super().__init__()
+        if random or num_masks != 1:
+            raise NotImplementedError("only the natural-ordering single-mask MADE the reference's "
+                                      "AutoregressiveConditioner builds is supported")
+        self.random = random
+        self.nin = nin
+        self.nout = nout
+        self.hidden_sizes = hidden_sizes
+        assert self.nout % self.nin == 0, "nout must be integer multiple of nin"
+        net = []
+        hs = [nin] + hidden_sizes + [nout]
+        for h0, h1 in zip(hs, hs[1:]):
+            net.extend([MaskedLinear(h0, h1), nn.ReLU()])
+        net.pop()
+        self.net = nn.Sequential(*net)
+        self.natural_ordering = natural_ordering
+        self.num_masks = num_masks
+        self.seed = 0
+        self.m = {}
+        self.update_masks()
+
+    def update_masks(self):
+        if self.m and self.num_masks == 1:
+            return
+        L = len(self.hidden_sizes)
+        self.m = made_degrees(self.nin, self.hidden_sizes)
+        masks = [self.m[l - 1][:, None] <= self.m[l][None, :] for l in range(L)]
+        masks.append(self.m[L - 1][:, None] < self.m[-1][None, :])
+        if self.nout > self.nin:
+            masks[-1] = np.concatenate([masks[-1]] * int(self.nout / self.nin), axis=1)
+        for layer, mk in zip(self.masked_layers(), masks):
+            layer.set_mask(mk)
+        self.i_map = self.m[-1].copy()
+        for k in range(len(self.m[-1])):
+            self.i_map[self.m[-1][k]] = k
+
+    def masked_layers(self):
+        return [l for l in self.net if isinstance(l, MaskedLinear)]
+
+    def forward(self, x):
+        ls = self.masked_layers()
+        y = ops.mlp(x, [(l.weight, l.bias) for l in ls], [l.mask for l in ls])
+        return y.view(x.shape[0], -1, x.shape[1]).permute(0, 2, 1)
+
+
+class ConditionnalMADE(MADE):
+    """(sic) reference AutoregressiveConditioner.py:115-141; cond_in must be 0."""
+
+    def __init__(self, nin, cond_in, hidden_sizes, nout, num_masks=1, natural_ordering=False, random=False,
+                 device="cpu"):
+        super().__init__(nin + cond_in, hidden_sizes, nout, num_masks, natural_ordering, random, device)
+        self.nin_non_cond = nin
+        self.cond_in = cond_in
+
+    def forward(self, x, context):
+        no_context(context, self.cond_in)
+        return super().forward(x)
+
+
+class AutoregressiveConditioner(Conditioner):
+    """reference AutoregressiveConditioner.py:144-154: h[b,i,:] depends on x[b,:i] only.
+    Returns a permuted [B,d,hs] view (strides (hs*d, 1, d)) exactly like the reference; the
+    normalizer kernels take the strides as they are."""
+
+    def __init__(self, in_size, hidden, out_size, cond_in=0):
+        super(AutoregressiveConditioner, self).__init__()
+        self.in_size = in_size
+        self.masked_autoregressive_net = ConditionnalMADE(in_size, cond_in=cond_in, hidden_sizes=hidden,
+                                                          nout=out_size * in_size)
+
+    def forward(self, x, context=None):
+        return self.masked_autoregressive_net(x, context)
+
+    def depth(self):
+        return self.in_size - 1

@@ -1,0 +1,234 @@
+import networkx as nx
+import torch
+import torch.nn as nn
+
+from gnf_hip import ops
+from .Conditioner import Conditioner, linear_pairs, no_context
+
+
+class DAGMLP(nn.Module):
+    """Parameter container, same layout/keys as reference DAGConditioner.py:7-20."""
+
+    def __init__(self, in_size, hidden, out_size, cond_in=0):
+        super(DAGMLP, self).__init__()
+        l1 = [in_size + cond_in] + hidden
+        l2 = hidden + [out_size]
+        layers = []
+        for h1, h2 in zip(l1, l2):
+            layers += [nn.Linear(h1, h2), nn.ReLU()]
+        layers.pop()
+        self.net = nn.Sequential(*layers)
+
+    def forward(self, x):
+        return ops.mlp(x, linear_pairs(self.net))
+
+
+def _digraph(adj):
+    """networkx >= 3 spelling of the reference's nx.from_numpy_matrix(..., create_using=nx.DiGraph)."""
+    return nx.from_numpy_array(adj, create_using=nx.DiGraph)
+
+
+class DAGConditioner(Conditioner):
+    """Graphical conditioner (reference DAGConditioner.py:23-293): a learned adjacency A gates
+    which inputs each dimension's embedding may see; an acyclicity constraint with dual
+    variables is added to the loss.
+
+    Forward = fused gate kernel (soft/hard threshold of A, Gumbel-softmax or noise gate with
+    on-device Philox noise, masked expand, optional one-hot) -> embedding net.  The
+    epoch-level control logic (step / update_dual_param / post_process) is host Python as in
+    the reference.  `gate_noise = (u1, u2)` injects explicit uniforms for parity tests."""
+
+    def __init__(self, in_size, hidden, out_size, cond_in=0, soft_thresholding=True, h_thresh=0., gumble_T=1.,
+                 hot_encoding=False, l1=0., nb_epoch_update=1, A_prior=None):
+        super(DAGConditioner, self).__init__()
+        if A_prior is None:
+            self.A = nn.Parameter(torch.ones(in_size, in_size) * 1.5 + torch.randn((in_size, in_size)) * .02)
+        else:
+            self.A = nn.Parameter(A_prior)
+        self.in_size = in_size
+        self.cond_in = cond_in
+        self.exponent = self.in_size % 50
+        self.s_thresh = soft_thresholding
+        self.h_thresh = h_thresh
+        self.stoch_gate = True
+        self.noise_gate = False
+        in_net = in_size * 2 if hot_encoding else in_size
+        if issubclass(type(hidden), nn.Module):
+            self.embedding_net = hidden
+        else:
+            self.embedding_net = DAGMLP(in_net, hidden, out_size, cond_in)
+        self.gumble = True
+        self.hutchinson = False
+        self.gumble_T = gumble_T
+        self.hot_encoding = hot_encoding
+        with torch.no_grad():
+            self.constrainA(h_thresh)
+        # dual variables of the acyclicity constraint (same buffer names as the reference)
+        self.register_buffer("lambd", torch.tensor(.0))
+        self.register_buffer("c", torch.tensor(1e-3))
+        self.register_buffer("eta", torch.tensor(10.))
+        self.register_buffer("gamma", torch.tensor(.9))
+        self.register_buffer("l1_weight", torch.tensor(l1))
+        self.register_buffer("dag_const", torch.tensor(1.))
+        self.alpha_factor = 1.
+        self.d = in_size
+        self.tol = 1e-30
+        self.register_buffer("alpha", self.getAlpha())
+        self.register_buffer("prev_trace", self.get_power_trace())
+        self.nb_epoch_update = nb_epoch_update
+        self.no_update = 0
+        self.is_invertible = False
+        self.gate_noise = None          # (u1, u2) [B,d,d] uniforms (test hook); None -> Philox
+        self._gate_calls = 0
+        self.gate_seed = int(torch.randint(0, 2 ** 31 - 1, (1,)).item())
+
+    def getAlpha(self):
+        # the reference computes an SVD here and discards it (:66-71); alpha = 1/d
+        return torch.tensor(1. / self.in_size)
+
+    def get_dag(self):
+        return self
+
+    def soft_thresholded_A(self):
+        return 2 * (torch.sigmoid(2 * (self.A ** 2)) - .5)
+
+    def hard_thresholded_A(self):
+        if self.s_thresh:
+            return self.soft_thresholded_A() * (self.soft_thresholded_A() > self.h_thresh).float()
+        return self.A ** 2 * (self.A ** 2 > self.h_thresh).float()
+
+    def _modes(self):
+        """(importance mode, gate mode) from the reference's branch order (:126-153)."""
+        if self.h_thresh > 0:
+            imp = ops.IMP_HARD_SOFT if self.s_thresh else ops.IMP_HARD_SQ
+        elif self.s_thresh:
+            imp = ops.IMP_SOFT
+        else:
+            return ops.IMP_RAW, ops.GATE_DET
+        if self.stoch_gate:
+            if not self.gumble:
+                raise NotImplementedError("only the Gumbel-softmax stochastic gate is implemented "
+                                          "(`gumble` is always True in the reference)")
+            return imp, ops.GATE_GUMBEL
+        if self.noise_gate:
+            return imp, ops.GATE_NOISE
+        return imp, ops.GATE_DET
+
+    def masked_inputs(self, x):
+        """e: [B*d, d (+d one-hot)] -- rows are the masked copies of each sample."""
+        imp, gate = self._modes()
+        u1 = u2 = None
+        if self.gate_noise is not None and gate != ops.GATE_DET:
+            u1, u2 = self.gate_noise
+        self._gate_calls += 1
+        return ops.DagGateFn.apply(x, self.A, imp, gate, float(self.h_thresh), float(self.gumble_T),
+                                   bool(self.hot_encoding), u1, u2, self.gate_seed, self._gate_calls)
+
+    def forward(self, x, context=None):
+        no_context(context, self.cond_in)
+        e = self.masked_inputs(x)
+        return self.embedding_net(e).view(x.shape[0], self.in_size, -1)
+
+    def constrainA(self, zero_threshold=.0001):
+        self.A *= (self.A.clone().abs() > zero_threshold).float()
+        self.A *= 1. - torch.eye(self.in_size, device=self.A.device)
+        return
+
+    def get_power_trace(self):
+        """tr((I + alpha A∘A)^k) - d (:176-194).  d x d matrix power on rocBLAS through torch:
+        <1% of a step and a function of the parameters only."""
+        alpha = min(1., self.alpha)
+        alpha *= self.alpha_factor
+        if self.hutchinson != 0:
+            raise NotImplementedError("Hutchinson trace estimator is never enabled by the reference")
+        B = (torch.eye(self.in_size, device=self.A.device) + alpha * self.A ** 2)
+        M = torch.matrix_power(B, self.exponent)
+        return torch.diag(M).sum() - self.in_size
+
+    def loss(self):
+        lag_const = self.get_power_trace()
+        return self.dag_const * (self.lambd * lag_const + self.c / 2 * lag_const ** 2) \
+            + self.l1_weight * self.A.abs().mean()
+
+    def post_process(self, zero_threshold=None):
+        def adj(th):
+            return (self.soft_thresholded_A().data.clone().abs() > th).float().detach().cpu().numpy()
+        if zero_threshold is None:
+            zero_threshold = .1
+            while not nx.is_directed_acyclic_graph(_digraph(adj(zero_threshold))):
+                zero_threshold += .05
+        self.stoch_gate = False
+        self.noise_gate = False
+        self.s_thresh = False
+        self.h_thresh = 0.
+        self.A.data = (self.soft_thresholded_A().data.clone().abs() > zero_threshold).float()
+        self.A.requires_grad = False
+        self.A *= 1. - torch.eye(self.in_size, device=self.A.device)
+        self.A.grad = None
+
+    def _reopen(self, A=None):
+        self.stoch_gate = True
+        self.noise_gate = False
+        self.s_thresh = True
+        self.h_thresh = 0.
+        if A is not None:
+            self.A = nn.Parameter(A)
+        self.A.requires_grad = True
+        self.A.grad = self.A.detach().clone()
+        self.alpha = self.getAlpha().to(self.A.device)
+        self.prev_trace = self.get_power_trace().detach()
+
+    def update_dual_param(self):
+        """Augmented-Lagrangian update of (lambd, c) / post-processing (:196-260)."""
+        with torch.no_grad():
+            lag_const = self.get_power_trace()
+            while self.dag_const > 0. and lag_const < self.tol and self.exponent < self.in_size:
+                self.exponent += 50
+                lag_const = self.get_power_trace()
+            if self.dag_const > 0. and lag_const > self.tol:
+                self.lambd = self.lambd + self.c * lag_const
+                if lag_const.abs() > self.gamma * self.prev_trace.abs():
+                    self.c *= self.eta
+                self.prev_trace = lag_const
+            elif self.dag_const > 0.:
+                A_before = self.A.detach().clone()
+                self.post_process()
+                self.alpha = self.getAlpha().to(self.A.device)
+                lag_const = self.get_power_trace()
+                if lag_const > 0.:
+                    self._reopen(A_before)
+                    self.c *= 1 / self.eta
+                    self.lambd = self.lambd + self.c * lag_const
+                    self.dag_const = torch.tensor(1., device=self.A.device)
+                else:
+                    self.dag_const = torch.tensor(0., device=self.A.device)
+                    self.l1_weight = torch.tensor(0., device=self.A.device)
+            else:
+                G = _digraph(self.A.detach().cpu().numpy() ** 2)
+                try:
+                    nx.find_cycle(G)
+                    self._reopen()
+                    self.dag_const = torch.tensor(1., device=self.A.device)
+                except nx.NetworkXNoCycle:
+                    self.is_invertible = True
+        return lag_const
+
+    def depth(self):
+        G = _digraph((self.A.detach() > 0).float().cpu().numpy())
+        if self.is_invertible or nx.is_directed_acyclic_graph(G):
+            return int(nx.dag_longest_path_length(G))
+        return 0
+
+    def step(self, epoch_number, loss_avg=0.):
+        """Once per epoch (:273-293): exponent back-off and dual update schedule."""
+        with torch.no_grad():
+            lag_const = self.get_power_trace()
+            if lag_const > 50:
+                self.exponent -= 5
+                self.exponent = self.exponent if self.exponent > 3 else 3
+            if epoch_number % self.nb_epoch_update == 0 and epoch_number > 0:
+                if self.loss().abs() < abs(loss_avg) / 2 or self.no_update > 10:
+                    self.update_dual_param()
+                    self.no_update = 0
+                else:
+                    self.no_update += 1

@@ -1,0 +1,80 @@
+import torch
+import torch.nn as nn
+
+from gnf_hip import ops
+from .Normalizer import Normalizer
+
+
+class ELUPlus(nn.Module):
+    """ELU(x) + 1.05 (reference MonotonicNormalizer.py:12-18); evaluated inside the kernel."""
+
+    def __init__(self):
+        super().__init__()
+        self.elu = nn.ELU()
+
+    def forward(self, x):
+        return self.elu(x) + 1.05
+
+
+class IntegrandNet(nn.Module):
+    """Parameter container with the reference's layout and state_dict keys
+    (`net.<2k>.weight/bias`, MonotonicNormalizer.py:21-31).  Its arithmetic is fused into
+    the quadrature kernel; calling it evaluates f(x;h) through that same kernel."""
+
+    def __init__(self, hidden, cond_in):
+        super(IntegrandNet, self).__init__()
+        l1 = [1 + cond_in] + hidden
+        l2 = hidden + [1]
+        layers = []
+        for h1, h2 in zip(l1, l2):
+            layers += [nn.Linear(h1, h2), nn.ReLU()]
+        layers.pop()
+        layers.append(ELUPlus())
+        self.net = nn.Sequential(*layers)
+        self.cond_in = cond_in
+
+    def flat_params(self):
+        ps = []
+        for m in self.net:
+            if isinstance(m, nn.Linear):
+                ps += [m.weight, m.bias]
+        return ps
+
+    def forward(self, x, h):
+        """x: [B,d]; h: flattened cond-major [B, c*d] as the reference passes it (:33-38)."""
+        B, d = x.shape
+        h3 = h.view(B, -1, d).permute(0, 2, 1)
+        _, jac = ops.MonotonicFn.apply(x, h3, 2, *self.flat_params())
+        return jac
+
+
+class MonotonicNormalizer(Normalizer):
+    """UMNN monotonic transformer (reference MonotonicNormalizer.py:41-83): z = int_0^x f(t;h)dt
+    + h[...,0] by Clenshaw-Curtis quadrature with `nb_steps`+1 nodes, jac = f(x;h); inverse by
+    20-step bisection.  `nb_steps` is re-read on every call (drivers jitter it per batch)."""
+
+    def __init__(self, integrand_net, cond_size, nb_steps=20, solver="CC"):
+        super(MonotonicNormalizer, self).__init__()
+        if type(integrand_net) is list:
+            self.integrand_net = IntegrandNet(integrand_net, cond_size)
+        else:
+            self.integrand_net = integrand_net
+        self.solver = solver
+        self.nb_steps = nb_steps
+
+    def _params(self):
+        if not isinstance(self.integrand_net, IntegrandNet):
+            raise NotImplementedError("only the reference IntegrandNet architecture (list of hidden sizes) is "
+                                      "fused into the gfx950 quadrature kernel")
+        return self.integrand_net.flat_params()
+
+    def forward(self, x, h, context=None):
+        # "CC" loops over the nodes, "CCParallel" batches them: same rule, same numbers up to
+        # summation order; both map to the one fused kernel.  Unknown solver -> None (:64-65).
+        if self.solver not in ("CC", "CCParallel"):
+            return None
+        return ops.MonotonicFn.apply(x, h, int(self.nb_steps), *self._params())
+
+    def inverse_transform(self, z, h, context=None):
+        with torch.no_grad():
+            return ops.monotonic_inverse(z, h, int(self.nb_steps), self._params())

@@ -1,0 +1,163 @@
+import torch
+import torch.nn as nn
+
+from gnf_hip import ops
+from .Conditionners import Conditioner, DAGConditioner
+from .Normalizers import Normalizer
+
+
+class NormalizingFlow(nn.Module):
+    """Abstract flow (reference models/NormalizingFlow.py:7-58)."""
+
+    def __init__(self):
+        super(NormalizingFlow, self).__init__()
+
+    def forward(self, x, context=None):
+        """-> (z, log|det J|)"""
+        pass
+
+    def constraintsLoss(self):
+        pass
+
+    def DAGness(self):
+        pass
+
+    def step(self, epoch_number, loss_avg):
+        pass
+
+    def getConditioners(self):
+        pass
+
+    def isInvertible(self):
+        pass
+
+    def getNormalizers(self):
+        pass
+
+    def invert(self, z, context=None):
+        pass
+
+
+class NormalizingFlowStep(NormalizingFlow):
+    """h = conditioner(x); z, jac = normalizer(x, h); log|det J| = sum_i log jac
+    (reference :61-107).  Normalizers exposing `forward_logdet` get the reduction fused into
+    their kernel; any other Normalizer plug-in goes through the row-reduction kernel."""
+
+    def __init__(self, conditioner: Conditioner, normalizer: Normalizer):
+        super(NormalizingFlowStep, self).__init__()
+        self.conditioner = conditioner
+        self.normalizer = normalizer
+
+    def forward(self, x, context=None):
+        h = self.conditioner(x, context)
+        if hasattr(self.normalizer, "forward_logdet"):
+            return self.normalizer.forward_logdet(x, h, context)
+        z, jac = self.normalizer(x, h, context)
+        return z, ops.LogSumRowsFn.apply(jac)
+
+    def constraintsLoss(self):
+        if type(self.conditioner) is DAGConditioner:
+            return self.conditioner.loss()
+        return 0.
+
+    def DAGness(self):
+        if type(self.conditioner) is DAGConditioner:
+            return [self.conditioner.get_power_trace()]
+        return [0.]
+
+    def step(self, epoch_number, loss_avg):
+        if type(self.conditioner) is DAGConditioner:
+            self.conditioner.step(epoch_number, loss_avg)
+
+    def getConditioners(self):
+        return [self.conditioner]
+
+    def getNormalizers(self):
+        return [self.normalizer]
+
+    def isInvertible(self):
+        for conditioner in self.getConditioners():
+            if not conditioner.is_invertible:
+                return False
+        return True
+
+    def invert(self, z, context=None):
+        """Fixed-point inverse: depth()+1 passes, early exit on exact equality (:98-107;
+        the reference's progress print is dropped)."""
+        x = torch.zeros_like(z)
+        with torch.no_grad():
+            for i in range(self.conditioner.depth() + 1):
+                h = self.conditioner(x, context)
+                x_prev = x
+                x = self.normalizer.inverse_transform(z, h, context)
+                if torch.norm(x - x_prev) == 0.:
+                    break
+        return x
+
+
+class FCNormalizingFlow(NormalizingFlow):
+    """Stack of steps with the feature order reversed between steps (reference :110-169)."""
+
+    def __init__(self, steps, z_log_density):
+        super(FCNormalizingFlow, self).__init__()
+        self.steps = nn.ModuleList()
+        self.z_log_density = z_log_density
+        for step in steps:
+            self.steps.append(step)
+
+    def forward(self, x, context=None):
+        jac_tot = 0.
+        for i, step in enumerate(self.steps):
+            z, jac = step(x, context)
+            if i + 1 < len(self.steps):
+                x = torch.flip(z, dims=[1])      # z[:, inv_idx] of the reference (:120-123)
+            jac_tot = jac_tot + jac
+        return z, jac_tot                        # last step's z is returned un-flipped (:126)
+
+    def constraintsLoss(self):
+        loss = 0.
+        for step in self.steps:
+            loss += step.constraintsLoss()
+        return loss
+
+    def DAGness(self):
+        dagness = []
+        for step in self.steps:
+            dagness += step.DAGness()
+        return dagness
+
+    def step(self, epoch_number, loss_avg):
+        for step in self.steps:
+            step.step(epoch_number, loss_avg)
+
+    def loss(self, z, jac):
+        log_p_x = jac + self.z_log_density(z)
+        return self.constraintsLoss() - log_p_x.mean()
+
+    def getNormalizers(self):
+        normalizers = []
+        for step in self.steps:
+            normalizers += step.getNormalizers()
+        return normalizers
+
+    def getConditioners(self):
+        conditioners = []
+        for step in self.steps:
+            conditioners += step.getConditioners()
+        return conditioners
+
+    def isInvertible(self):
+        for conditioner in self.getConditioners():
+            if not conditioner.is_invertible:
+                return False
+        return True
+
+    def invert(self, z, context=None):
+        """Exact inverse of forward for any number of steps.  The reference (:166-169) visits
+        steps[-0] == steps[0] first and never undoes the flip, so it only inverts nb_flow=1
+        flows; for nb_flow=1 this is identical to it."""
+        n = len(self.steps)
+        for s in range(n - 1, -1, -1):
+            x = self.steps[s].invert(z, context)
+            z = torch.flip(x, dims=[1]) if s > 0 else x
+        return z

@@ -1,0 +1,159 @@
+/* gnf_hip.h -- C ABI of libgnf_hip.so: the MI355X (gfx950) kernels under the
+ * Conditioner / Normalizer plug-in API of Graphical-Normalizing-Flows.
+ *
+ * The reference has no FFI of its own (it is pure Python on torch ops); the drop-in
+ * boundary is the Python class protocol of models/ (SURVEY.md 8b).  Each entry point
+ * below replaces the torch-op sequence of the cited reference lines and is what the
+ * host-side mirror (graphical-normalizing-flows_amd/models) binds with ctypes.
+ *
+ * Conventions (all entry points):
+ *   - plain C types only; device pointers are raw (tensor.data_ptr()); fp32 everywhere;
+ *   - `stream` is a hipStream_t passed as void* (torch's current stream);
+ *   - returns 0 on success, a negative GNF_E* code for bad arguments, or a positive
+ *     hipError_t from the launch; never throws, never allocates, never synchronises;
+ *   - the caller owns and sizes every buffer, including workspaces (gnf_*_ws_bytes);
+ *   - no global mutable state: safe for one process per GPU and for several streams;
+ *   - strides are in ELEMENTS, not bytes.
+ */
+#ifndef GNF_HIP_H
+#define GNF_HIP_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GNF_ABI_VERSION 1
+#define GNF_EINVAL (-1)   /* bad argument (null pointer, negative size, ...)          */
+#define GNF_ESHAPE (-2)   /* shape not supported by any compiled kernel instantiation */
+#define GNF_EWS    (-3)   /* workspace too small                                      */
+
+typedef void* gnf_stream_t;
+
+int gnf_abi_version(void);
+
+/* ---- Affine normalizer: models/Normalizers/AffineNormalizer.py:9-17 -------------------
+ * mu = clamp(h[..,0],-5,5); sigma = exp(clamp(h[..,1],-5,2)); z = x*sigma + mu.
+ * x,z,jac: [B,d] contiguous.  h[b,i,c] at b*h_sb + i*h_sd + c*h_sc (MADE hands over a
+ * permuted view).  jac (= sigma) and logdet (= sum_i log sigma = sum_i clamp(h1)) may be
+ * NULL.  clamp_inplace != 0 writes the clamped values back into h like the reference's
+ * clamp_ does. */
+int gnf_affine_fwd(const float* x, float* h, int64_t h_sb, int64_t h_sd, int64_t h_sc,
+                   float* z, float* jac, float* logdet, int clamp_inplace,
+                   int64_t B, int64_t d, gnf_stream_t stream);
+/* Backward of the above.  gz: [B,d]; gjac: [B,d] or NULL; glogdet: [B] or NULL.
+ * gx: [B,d] or NULL.  gh[b,i,c] at b*g_sb + i*g_sd + c*g_sc receives components 0,1
+ * (components >= 2 are never read by the normalizer: caller zero-fills them). */
+int gnf_affine_bwd(const float* x, const float* h, int64_t h_sb, int64_t h_sd, int64_t h_sc,
+                   const float* gz, const float* gjac, const float* glogdet,
+                   float* gx, float* gh, int64_t g_sb, int64_t g_sd, int64_t g_sc,
+                   int64_t B, int64_t d, gnf_stream_t stream);
+/* x = (z - mu)/sigma  (AffineNormalizer.py:14-17). */
+int gnf_affine_inv(const float* z, const float* h, int64_t h_sb, int64_t h_sd, int64_t h_sc,
+                   float* x, int64_t B, int64_t d, gnf_stream_t stream);
+
+/* ---- row reductions: models/NormalizingFlow.py:70, NormalizingFlowFactories.py:15-16 --
+ * logsum:  out[b] = sum_i log(jac[b,i]);        bwd: gjac[b,i] = g[b]/jac[b,i]
+ * normal:  out[b] = -0.5*sum_i(log(2pi)+z^2);   bwd: gz[b,i]  = -z[b,i]*g[b]        */
+int gnf_logsum_rows_fwd(const float* jac, float* out, int64_t B, int64_t d, gnf_stream_t stream);
+int gnf_logsum_rows_bwd(const float* jac, const float* g, float* gjac, int64_t B, int64_t d, gnf_stream_t stream);
+int gnf_normal_logdensity_fwd(const float* z, float* out, int64_t B, int64_t d, gnf_stream_t stream);
+int gnf_normal_logdensity_bwd(const float* z, const float* g, float* gz, int64_t B, int64_t d, gnf_stream_t stream);
+/* out[n] = sum_m a[m*lda + n]  (bias gradients; deterministic two-level reduction).
+ * ws: >= gnf_colsum_ws_bytes(M,N) bytes. */
+int64_t gnf_colsum_ws_bytes(int64_t M, int64_t N);
+int gnf_colsum(const float* a, int64_t lda, float* out, int64_t M, int64_t N, float* ws, gnf_stream_t stream);
+
+/* ---- fp32 MFMA GEMM with fused masks / bias / ReLU ------------------------------------
+ * Replaces F.linear(input, mask*weight, bias) (AutoregressiveConditioner.py:24-25), the
+ * nn.Linear+ReLU chains of CouplingMLP / DAGMLP / MNISTCNN.fc* and their autograd
+ * backward.  C[m,n] = epi( sum_k A[m,k] * (B[k,n] * Bmask[k,n]) ):
+ *   A[m,k] at m*sam + k*sak;  B and Bmask (NULL = none) at k*sbk + n*sbn;
+ *   epi: + bias[n] (NULL = none);  * Cmask[m*scmm + n*scmn] (NULL = none);
+ *        relu if flags&GNF_GEMM_RELU;  * (gate[m*sgm + n*sgn] > 0) (NULL = none);
+ *   C[m,n] at m*scm + n*scn.  v_mfma_f32_32x32x2_f32: exact fp32, k-ordered fma chain. */
+#define GNF_GEMM_RELU 1
+int gnf_gemm(const float* A, int64_t sam, int64_t sak,
+             const float* B, const float* Bmask, int64_t sbk, int64_t sbn,
+             float* C, int64_t scm, int64_t scn,
+             const float* bias,
+             const float* Cmask, int64_t scmm, int64_t scmn,
+             const float* gate, int64_t sgm, int64_t sgn,
+             int flags, int64_t M, int64_t N, int64_t K, gnf_stream_t stream);
+
+/* ---- DAG conditioner gate: models/Conditionners/DAGConditioner.py:94-166 --------------
+ * e[(b*d+i)*ld_e + j] = x[b,j] * gate(importance(A[i,j])) (+ one-hot of i in columns
+ * d..2d-1 when hot != 0, ld_e >= 2d).
+ *   imp_mode 0: raw A (DAG:151-153)  1: soft threshold 2(sigmoid(2A^2)-.5) (:118-119)
+ *            2: soft * (soft > h_thresh)  3: A^2 * (A^2 > h_thresh)   (:121-124)
+ *   gate_mode 0: deterministic x*imp   1: Gumbel-softmax gate (:95-103)
+ *             2: noise gate imp*(x + n*|1-imp|) (:114-116)
+ * Randomness: if u1 != NULL the uniforms (gate 1: u1,u2; gate 2: u1 holds N(0,1)
+ * samples) are read from [B,d,d] arrays (parity tests); otherwise a Philox4x32-10
+ * stream keyed by (seed, offset) with the element index as counter is used, and the
+ * backward regenerates the same numbers from the same (seed, offset). */
+int gnf_dag_gate_fwd(const float* x, const float* A, float* e, int64_t ld_e,
+                     int imp_mode, int gate_mode, float h_thresh, float temperature,
+                     const float* u1, const float* u2, uint64_t seed, uint64_t offset,
+                     int hot, int64_t B, int64_t d, gnf_stream_t stream);
+/* ge: [(B*d), ld_e].  gA: [d,d] (written, not accumulated) or NULL; gx: [B,d] or NULL.
+ * ws: >= gnf_dag_gate_bwd_ws_bytes(B,d). */
+int64_t gnf_dag_gate_bwd_ws_bytes(int64_t B, int64_t d);
+int gnf_dag_gate_bwd(const float* x, const float* A, const float* ge, int64_t ld_e,
+                     int imp_mode, int gate_mode, float h_thresh, float temperature,
+                     const float* u1, const float* u2, uint64_t seed, uint64_t offset,
+                     float* gA, float* gx, float* ws, int64_t B, int64_t d, gnf_stream_t stream);
+
+/* ---- Monotonic (UMNN) normalizer: models/Normalizers/MonotonicNormalizer.py:21-83 -----
+ * Integrand net: Linear(1+c,H1) ReLU ... Linear(H_last,1) ELU+1.05 evaluated on rows
+ * (x[b,i], h[b,i,:]).  `nl` = number of Linear layers (>= 2); W[l]: [out_l,in_l]
+ * row-major, b[l]: [out_l]; dims[0]=1+c, dims[l+1]=out_l, dims[nl]=1.
+ *   z   = h[..,0] + (xT/2) * sum_k cc_w[k] f(xT (cc_t[k]+1)/2 ; h),  xT = S*(x/S)
+ *   jac = f(x; h)
+ * cc_w, cc_t: S+1 device floats (host-built Clenshaw-Curtis rule; UMNN 1.0's
+ * construction, see oracle/gnf_oracle.py: parity unpinned).  n = B*d elements; element
+ * e=(b,i): x[e], h at b*h_sb + i*h_sd + c*h_sc with b=e/d, i=e%d.
+ * pack: >= gnf_monotonic_pack_floats(...) floats of workspace holding the padded weight
+ * image (written by gnf_monotonic_pack, read by fwd/bwd/inv of the same step). */
+#define GNF_MONO_MAX_LAYERS 8
+typedef struct {
+  int nl;                                   /* number of Linear layers */
+  int dims[GNF_MONO_MAX_LAYERS + 1];
+  const float* W[GNF_MONO_MAX_LAYERS];
+  const float* b[GNF_MONO_MAX_LAYERS];
+} gnf_mono_net;
+
+int64_t gnf_monotonic_pack_floats(const gnf_mono_net* net);
+int gnf_monotonic_pack(const gnf_mono_net* net, float* pack, gnf_stream_t stream);
+int gnf_monotonic_fwd(const float* pack, const gnf_mono_net* net,
+                      const float* x, const float* h, int64_t h_sb, int64_t h_sd, int64_t h_sc,
+                      const float* cc_w, const float* cc_t, int S,
+                      float* z, float* jac, int64_t B, int64_t d, gnf_stream_t stream);
+/* 20-step bisection on [-20,20] with the quadrature inside (MonotonicNormalizer.py:69-83). */
+int gnf_monotonic_inv(const float* pack, const gnf_mono_net* net,
+                      const float* z, const float* h, int64_t h_sb, int64_t h_sd, int64_t h_sc,
+                      const float* cc_w, const float* cc_t, int S,
+                      float* x, int64_t B, int64_t d, gnf_stream_t stream);
+/* Backward with UMNN's conventions: gx = gz*f(x;h) + gjac*df/dx(x;h) (Leibniz rule);
+ * gh, gW, gb = quadrature of df/dh, df/dtheta weighted by gz*xT/2, plus the gjac path,
+ * plus gz on h[..,0].  gW[l]/gb[l] are WRITTEN (same shapes as W[l]/b[l]).
+ * gh[e,c] at b*g_sb + i*g_sd + c*g_sc.  ws: >= gnf_monotonic_bwd_ws_bytes(...) bytes. */
+int64_t gnf_monotonic_bwd_ws_bytes(const gnf_mono_net* net, int S, int64_t B, int64_t d);
+int gnf_monotonic_bwd(const float* pack, const gnf_mono_net* net,
+                      const float* x, const float* h, int64_t h_sb, int64_t h_sd, int64_t h_sc,
+                      const float* cc_w, const float* cc_t, int S,
+                      const float* gz, const float* gjac,
+                      float* gx, float* gh, int64_t g_sb, int64_t g_sd, int64_t g_sc,
+                      float* const* gW, float* const* gb,
+                      void* ws, int64_t ws_bytes, int64_t B, int64_t d, gnf_stream_t stream);
+
+/* ---- Adam on one flat fp32 buffer (torch.optim.Adam semantics, L2 weight decay) --------
+ * ImageExperiments.py:173 / UCIExperiments.py:97; used by the data-parallel harness after
+ * the single RCCL all-reduce.  grad_scale multiplies the (summed) gradient first. */
+int gnf_adam_step(float* p, const float* g, float* m, float* v, int64_t n,
+                  float lr, float beta1, float beta2, float eps, float weight_decay,
+                  float grad_scale, int step, gnf_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

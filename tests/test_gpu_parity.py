@@ -1,0 +1,450 @@
+"""GPU parity tests proper (-m gpu): the HIP path, called through the mirrored plug-in API
+and the C ABI, against (a) the golden vectors generated from the reference and (b) the CPU
+oracle on the same seeded inputs.  Tolerance: north_star's 1e-5 relative fp32 for
+transformed x, log|det J| and NLL; gradients 1e-4 relative to the tensor's max (sums of
+many fp32 products in a different order than torch's addmm)."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden, params_of, linear_layers, rel_err
+from oracle import gnf_oracle as O
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+TOL = 1e-5
+GTOL = 1e-4
+
+
+def cu(t):
+    return t.to(DEV)
+
+
+def req(t):
+    return t.clone().to(DEV).requires_grad_(True)
+
+
+def load_into(module, g, prefix="p."):
+    sd = {k[len(prefix):]: v for k, v in g.items() if k.startswith(prefix)}
+    missing, unexpected = module.load_state_dict(sd, strict=True), None
+    return module.to(DEV)
+
+
+def grads_match(module, g, tol=GTOL, prefix="g."):
+    named = dict(module.named_parameters())
+    n = 0
+    for k, v in g.items():
+        if k.startswith(prefix):
+            p = named[k[len(prefix):]]
+            assert p.grad is not None, k
+            assert rel_err(p.grad.cpu(), v) < tol, (k, rel_err(p.grad.cpu(), v))
+            n += 1
+    assert n > 0
+
+
+# --------------------------------------------------------------------------------- normalizers
+def test_affine_golden():
+    from models import AffineNormalizer
+    g = load_golden("affine")
+    x, h = req(g["x"]), req(g["h"])
+    norm = AffineNormalizer()
+    z, jac = norm(x, h)
+    assert rel_err(z.cpu(), g["z"]) < TOL and rel_err(jac.cpu(), g["jac"]) < TOL
+    gx, gh = torch.autograd.grad((z * cu(g["gz"])).sum(), (x, h), retain_graph=True)
+    assert rel_err(gx.cpu(), g["gx_from_z"]) < TOL and rel_err(gh.cpu(), g["gh_from_z"]) < TOL
+    z2, ld = norm.forward_logdet(x, h)
+    gh2, = torch.autograd.grad((ld * cu(g["gld"])).sum(), h)
+    assert rel_err(gh2.cpu(), g["gh_from_logdet"]) < TOL
+    assert rel_err(ld.detach().cpu(), torch.log(g["jac"]).sum(1)) < TOL
+    assert rel_err(norm.inverse_transform(cu(g["z"]), cu(g["h"])).cpu(), g["x_inverse"]) < TOL
+    # in-place clamp option reproduces the reference's mutation of h
+    norm.inplace_clamp = True
+    hc = cu(g["h"]).clone()
+    norm(cu(g["x"]), hc)
+    ref = g["h"].clone()
+    ref[:, :, 0].clamp_(-5., 5.)
+    ref[:, :, 1].clamp_(-5., 2.)
+    assert torch.equal(hc.cpu(), ref)
+
+
+def test_affine_strided_h_and_large():
+    from gnf_hip import ops
+    torch.manual_seed(0)
+    B, d = 3000, 63
+    x = torch.randn(B, d)
+    hraw = torch.randn(B, 2 * d) * 3
+    h = hraw.view(B, 2, d).permute(0, 2, 1)          # MADE layout: strides (2d, 1, d)
+    z0, j0 = O.affine_forward(x, h)
+    xg, hg = req(x), cu(hraw).requires_grad_(True)
+    z, jac, ld = ops.AffineFn.apply(xg, hg.view(B, 2, d).permute(0, 2, 1))
+    assert rel_err(z.cpu(), z0) < TOL and rel_err(jac.cpu(), j0) < TOL
+    assert rel_err(ld.cpu(), torch.log(j0).sum(1)) < TOL
+    (z.sum() + ld.sum()).backward()
+    xr, hr = x.clone().requires_grad_(True), hraw.clone().requires_grad_(True)
+    zr, jr = O.affine_forward(xr, hr.view(B, 2, d).permute(0, 2, 1))
+    (zr.sum() + torch.log(jr).sum()).backward()
+    assert rel_err(xg.grad.cpu(), xr.grad) < TOL and rel_err(hg.grad.cpu(), hr.grad) < TOL
+
+
+def test_normal_log_density_and_logsum():
+    from models.NormalizingFlowFactories import NormalLogDensity
+    from gnf_hip import ops
+    g = load_golden("normal_log_density")
+    z = req(g["z"])
+    out = NormalLogDensity().to(DEV)(z)
+    assert rel_err(out.cpu(), g["out"]) < TOL
+    out.sum().backward()
+    assert rel_err(z.grad.cpu(), -g["z"]) < TOL
+    for B, d in [(5, 1), (7, 2), (33, 6), (100, 784), (1000, 63)]:
+        jac = torch.rand(B, d) + .1
+        j = req(jac)
+        o = ops.LogSumRowsFn.apply(j)
+        assert rel_err(o.cpu(), torch.log(jac).sum(1)) < TOL
+        w = torch.randn(B)
+        (o * cu(w)).sum().backward()
+        assert rel_err(j.grad.cpu(), w[:, None] / jac) < TOL
+
+
+# --------------------------------------------------------------------------------- GEMM
+@pytest.mark.parametrize("M,N,K", [(1, 1, 1), (7, 5, 3), (100, 1024, 784), (64, 64, 16), (130, 70, 33),
+                                   (2500, 60, 12), (300, 300, 300), (1568, 128, 2304)])
+def test_gemm_shapes(M, N, K):
+    from gnf_hip import ops
+    torch.manual_seed(M + N + K)
+    A, W = torch.randn(M, K), torch.randn(N, K)
+    mask = (torch.rand(N, K) < .6).float()
+    bias = torch.randn(N)
+    ref = torch.relu(A.double() @ (W * mask).double().t() + bias.double())
+    C = torch.empty(M, N, device=DEV)
+    ops.gemm(cu(A), (K, 1), cu(W), (1, K), C, (N, 1), M, N, K, Bmask=cu(mask), bias=cu(bias), relu=True)
+    assert rel_err(C.cpu(), ref) < 2e-6
+    # transposed-A form used for weight gradients, with output mask
+    G = torch.randn(M, N)
+    ref2 = (G.double().t() @ A.double()) * mask.double()
+    C2 = torch.empty(N, K, device=DEV)
+    ops.gemm(cu(G), (1, N), cu(A), (K, 1), C2, (K, 1), N, K, M, Cmask=cu(mask), cm_strides=(K, 1))
+    assert rel_err(C2.cpu(), ref2) < 2e-6
+    # data-gradient form with ReLU gate
+    gate = torch.randn(M, K)
+    ref3 = (G.double() @ (W * mask).double()) * (gate > 0).double()
+    C3 = torch.empty(M, K, device=DEV)
+    ops.gemm(cu(G), (N, 1), cu(W), (K, 1), C3, (K, 1), M, K, N, Bmask=cu(mask), gate=cu(gate), g_strides=(K, 1))
+    assert rel_err(C3.cpu(), ref3) < 2e-6
+
+
+def test_colsum():
+    from gnf_hip import ops
+    for M, N in [(1, 1), (513, 7), (5000, 300)]:
+        a = torch.randn(M, N)
+        assert rel_err(ops.colsum(cu(a)).cpu(), a.double().sum(0)) < 2e-6
+
+
+# --------------------------------------------------------------------------------- conditioners
+def test_coupling_golden():
+    from models import CouplingConditioner
+    g = load_golden("coupling")
+    c = load_into(CouplingConditioner(5, [16, 16], 3), g)
+    x = req(g["x"])
+    h = c(x)
+    assert rel_err(h.cpu(), g["h"]) < TOL
+    (h * cu(g["gh"])).sum().backward()
+    assert rel_err(x.grad.cpu(), g["gx"]) < GTOL
+    grads_match(c, g)
+
+
+def test_autoregressive_golden():
+    from models import AutoregressiveConditioner
+    g = load_golden("autoregressive")
+    c = AutoregressiveConditioner(7, [16, 12, 16], 3)
+    for k, v in c.state_dict().items():          # masks built by the mirror == reference masks
+        if k.endswith("mask"):
+            assert torch.equal(v, g["p." + k])
+    c = load_into(c, g)
+    x = req(g["x"])
+    h = c(x)
+    assert h.shape == g["h"].shape and rel_err(h.cpu(), g["h"]) < TOL
+    (h * cu(g["gh"])).sum().backward()
+    assert rel_err(x.grad.cpu(), g["gx"]) < GTOL
+    grads_match(c, g)
+    assert c.depth() == 6
+
+
+@pytest.mark.parametrize("tag", ["det", "gumbel", "gumbel_hot_T05", "hard", "hard_gumbel"])
+def test_dag_golden(tag):
+    from models import DAGConditioner
+    g = load_golden("dag_" + tag)
+    hot, stoch, hth, T = g["flags"].tolist()
+    c = DAGConditioner(6, [12, 10], 4, hot_encoding=bool(hot), gumble_T=T, l1=.1)
+    c = load_into(c, g)
+    c.stoch_gate = bool(stoch)
+    c.h_thresh = hth
+    c.gate_noise = (cu(g["u1"]), cu(g["u2"]))
+    x = req(g["x"])
+    h = c(x)
+    assert rel_err(h.cpu(), g["h"]) < TOL
+    loss = c.loss()
+    assert rel_err(loss.detach().cpu(), g["loss"]) < TOL
+    assert rel_err(c.get_power_trace().detach().cpu(), g["trace"]) < TOL
+    ((h * cu(g["gh"])).sum() + loss).backward()
+    assert rel_err(x.grad.cpu(), g["gx"]) < GTOL
+    grads_match(c, g)
+
+
+def test_dag_gate_philox_statistics_and_determinism():
+    from gnf_hip import ops
+    torch.manual_seed(0)
+    B, d = 64, 48
+    x = torch.ones(B, d, device=DEV)
+    A = (torch.rand(d, d, device=DEV) * 1.5).requires_grad_(True)
+    args = (ops.IMP_SOFT, ops.GATE_GUMBEL, 0., 1., False, None, None, 1234, 7)
+    e1 = ops.DagGateFn.apply(x, A, *args)
+    e2 = ops.DagGateFn.apply(x, A, *args)
+    assert torch.equal(e1, e2)                                        # counter-based: reproducible
+    e3 = ops.DagGateFn.apply(x, A, ops.IMP_SOFT, ops.GATE_GUMBEL, 0., 1., False, None, None, 1234, 8)
+    assert not torch.equal(e1, e3)
+    # at T=1 the relaxed gate has E[gate] = (p+eps)/(1+2eps) ~= p  (logistic noise identity)
+    p = (2 * (torch.sigmoid(2 * A.detach() ** 2) - .5))
+    many = torch.stack([ops.DagGateFn.apply(x, A, ops.IMP_SOFT, ops.GATE_GUMBEL, 0., 1., False, None, None, 99, k)
+                        .detach().view(B, d, d) for k in range(40)]).mean((0, 1))
+    assert (many - p).abs().max() < .03
+    # backward regenerates the same noise: finite-difference check of d(sum e)/dA on one entry
+    e1.sum().backward()
+    gA = A.grad.clone()
+    with torch.no_grad():
+        Ap = A.detach().clone(); Ap[3, 5] += 1e-2
+        Am = A.detach().clone(); Am[3, 5] -= 1e-2
+        fd = (ops.DagGateFn.apply(x, Ap, *args).double().sum() - ops.DagGateFn.apply(x, Am, *args).double().sum()) / 2e-2
+    assert abs(fd.item() - gA[3, 5].item()) < 2e-2 * max(1., abs(fd.item()))
+
+
+def test_mnistcnn_golden():
+    from models.MLP import MNISTCNN
+    g = load_golden("mnistcnn")
+    net = load_into(MNISTCNN(out_d=30), g)
+    e = req(g["e"])
+    out = net(e)
+    assert rel_err(out.cpu(), g["out"]) < TOL
+    (out * cu(g["gout"])).sum().backward()
+    assert rel_err(e.grad.cpu(), g["ge"]) < GTOL
+    grads_match(net, g)
+
+
+# --------------------------------------------------------------------------------- flows (golden)
+def _build(name):
+    from models import (buildFCNormalizingFlow, CouplingConditioner, AutoregressiveConditioner, DAGConditioner,
+                        AffineNormalizer)
+    if name == "flow_affine_coupling_1":
+        return buildFCNormalizingFlow(1, CouplingConditioner, {"in_size": 2, "hidden": [32, 32], "out_size": 2},
+                                      AffineNormalizer, {})
+    if name == "flow_affine_coupling_3":
+        return buildFCNormalizingFlow(3, CouplingConditioner, {"in_size": 5, "hidden": [16, 16], "out_size": 2},
+                                      AffineNormalizer, {})
+    if name == "flow_affine_made_1":
+        return buildFCNormalizingFlow(1, AutoregressiveConditioner,
+                                      {"in_size": 8, "hidden": [24, 24, 24], "out_size": 2}, AffineNormalizer, {})
+    if name == "flow_affine_dag_2":
+        return buildFCNormalizingFlow(2, DAGConditioner, {"in_size": 6, "hidden": [16, 16], "out_size": 2,
+                                                          "l1": .05, "gumble_T": .5, "hot_encoding": True},
+                                      AffineNormalizer, {})
+    raise KeyError(name)
+
+
+@pytest.mark.parametrize("name", ["flow_affine_coupling_1", "flow_affine_coupling_3", "flow_affine_made_1",
+                                  "flow_affine_dag_2"])
+def test_flow_golden(name):
+    g = load_golden(name)
+    flow = _build(name)
+    assert list(flow.state_dict().keys()) == list(g["state_keys"])       # checkpoint-compatible keys
+    flow = load_into(flow, g)
+    for s, step in enumerate(flow.steps):
+        if "u1_%d" % s in g:
+            step.conditioner.gate_noise = (cu(g["u1_%d" % s]), cu(g["u2_%d" % s]))
+    x = req(g["x"])
+    z, ld = flow(x)
+    assert rel_err(z.cpu(), g["z"]) < TOL and rel_err(ld.cpu(), g["logdet"]) < TOL
+    loss = flow.loss(z, ld)
+    assert rel_err(loss.detach().cpu(), g["loss"]) < TOL
+    loss.backward()
+    assert rel_err(x.grad.cpu(), g["gx"]) < GTOL
+    grads_match(flow, g)
+
+
+@pytest.mark.parametrize("name", ["flow_affine_coupling_1", "flow_affine_made_1"])
+def test_flow_inverse_golden(name):
+    g, gi = load_golden(name), load_golden(name + "_inv")
+    flow = load_into(_build(name), g)
+    x = flow.invert(cu(gi["z"]))
+    assert rel_err(x.cpu(), gi["x"]) < TOL
+    assert rel_err(x.cpu(), g["x"]) < 1e-4
+
+
+def test_multi_step_inverse_round_trip():
+    g = load_golden("flow_affine_coupling_3")
+    flow = load_into(_build("flow_affine_coupling_3"), g)
+    with torch.no_grad():
+        z, _ = flow(cu(g["x"]))
+        x = flow.invert(z)
+    assert rel_err(x.cpu(), g["x"]) < 1e-4
+
+
+def test_mnist_affine_dag_flow_golden():
+    from models import AffineNormalizer
+    from models.NormalizingFlowFactories import buildMNISTNormalizingFlow
+    g = load_golden("flow_mnist_affine_dag")
+    flow = buildMNISTNormalizingFlow([1], AffineNormalizer, {}, l1=0., nb_epoch_update=10, hot_encoding=False,
+                                     prior_kernel=2)
+    assert list(flow.state_dict().keys()) == list(g["state_keys"])
+    sd = {k[2:]: v for k, v in g.items() if k.startswith("p.")}
+    sd["steps.0.conditioner.A"] = flow.steps[0].conditioner.A.detach().clone()   # the kernel-2 prior itself
+    flow.load_state_dict(sd)
+    flow = flow.to(DEV)
+    torch.manual_seed(int(g["gate_seed"]))
+    u1 = torch.rand(2, 784, 784)
+    u2 = torch.rand(2, 784, 784)
+    cond = flow.steps[0].conditioner
+    cond.gate_noise = (cu(u1), cu(u2))
+    z, ld = flow(cu(g["x"]))
+    assert rel_err(z.cpu(), g["z"]) < TOL and rel_err(ld.cpu(), g["logdet"]) < TOL
+    loss = flow.loss(z, ld)
+    assert rel_err(loss.detach().cpu(), g["loss"]) < TOL
+    loss.backward()
+    gA = cond.A.grad.cpu()
+    idx = g["gA_idx"].long()
+    assert rel_err(gA[idx[:, 0], idx[:, 1]], g["gA_val"]) < GTOL
+    assert int((gA != 0).sum()) == idx.shape[0]        # zero entries of A keep an exactly-zero gradient
+    named = dict(flow.named_parameters())
+    for k, v in g.items():
+        if k.startswith("g."):
+            assert rel_err(named[k[2:]].grad.cpu(), v) < GTOL, k
+
+
+# --------------------------------------------------------------------------------- Monotonic vs oracle
+def _mono_case(B, d, c, hidden, S, seed, h_layout="contig"):
+    from models import MonotonicNormalizer
+    torch.manual_seed(seed)
+    norm = MonotonicNormalizer(hidden, c, nb_steps=S, solver="CC")
+    x = torch.randn(B, d) * 1.5
+    if h_layout == "made":
+        hraw = torch.randn(B, c * d)
+        h = hraw.view(B, c, d).permute(0, 2, 1)
+    else:
+        hraw = torch.randn(B, d, c)
+        h = hraw
+    return norm, x, hraw, h
+
+
+def _layers_cpu(norm):
+    ps = [p.detach().cpu().clone() for p in norm.integrand_net.flat_params()]
+    return [(ps[i], ps[i + 1]) for i in range(0, len(ps), 2)]
+
+
+@pytest.mark.parametrize("hidden,S,layout", [([10], 20, "contig"), ([16, 16], 21, "made"), ([50, 50, 50], 20, "contig"),
+                                              ([50, 50, 50], 29, "made"), ([100, 100, 100], 20, "contig"),
+                                              ([150, 150, 150], 20, "made"), ([40, 64, 24], 15, "contig"),
+                                              ([200, 200], 22, "contig")])
+def test_monotonic_forward_backward_vs_oracle(hidden, S, layout):
+    B, d, c = 9, 7, 30 if len(hidden) == 3 else 5
+    norm, x, hraw, h = _mono_case(B, d, c, hidden, S, seed=len(hidden) * 100 + S, h_layout=layout)
+    layers = _layers_cpu(norm)
+    # oracle (fp32) and an fp64 oracle to measure what fp32 roundoff alone allows
+    xr, hr = x.clone().requires_grad_(True), hraw.clone().requires_grad_(True)
+    lr = [(W.clone().requires_grad_(True), b.clone().requires_grad_(True)) for W, b in layers]
+    hview = hr.view(B, c, d).permute(0, 2, 1) if layout == "made" else hr
+    z0, j0 = O.monotonic_forward(xr, hview, lr, S)
+    gz, gj = torch.randn(B, d), torch.randn(B, d)
+    ((z0 * gz).sum() + (torch.log(j0) * gj).sum()).backward()
+
+    norm = norm.to(DEV)
+    xg, hg = req(x), cu(hraw).requires_grad_(True)
+    hgv = hg.view(B, c, d).permute(0, 2, 1) if layout == "made" else hg
+    z, jac = norm(xg, hgv)
+    assert rel_err(z.cpu(), z0.detach()) < TOL, rel_err(z.cpu(), z0.detach())
+    assert rel_err(jac.cpu(), j0.detach()) < TOL
+    ((z * cu(gz)).sum() + (torch.log(jac) * cu(gj)).sum()).backward()
+    assert rel_err(xg.grad.cpu(), xr.grad) < GTOL
+    assert rel_err(hg.grad.cpu(), hr.grad) < GTOL
+    for (W, b), p_w, p_b in zip(lr, norm.integrand_net.flat_params()[0::2], norm.integrand_net.flat_params()[1::2]):
+        assert rel_err(p_w.grad.cpu(), W.grad) < GTOL, ("W", tuple(W.shape), rel_err(p_w.grad.cpu(), W.grad))
+        assert rel_err(p_b.grad.cpu(), b.grad) < GTOL, ("b", tuple(b.shape))
+
+
+def test_monotonic_golden_jacobian():
+    """Jacobian / log|det J| of a Monotonic flow: pinned by the reference itself."""
+    from models import buildFCNormalizingFlow, AutoregressiveConditioner, MonotonicNormalizer
+    g = load_golden("flow_mono_made_1")
+    flow = buildFCNormalizingFlow(1, AutoregressiveConditioner, {"in_size": 4, "hidden": [12, 12], "out_size": 6},
+                                  MonotonicNormalizer, {"integrand_net": [10, 10], "cond_size": 6, "nb_steps": 20,
+                                                        "solver": "CC"})
+    assert list(flow.state_dict().keys()) == list(g["state_keys"])
+    flow = load_into(flow, g)
+    x = cu(g["x"])
+    h = flow.steps[0].conditioner(x)
+    assert rel_err(h.cpu(), g["h"]) < TOL
+    z, jac = flow.steps[0].normalizer(x, h)
+    assert rel_err(jac.cpu(), g["jac"]) < TOL
+    _, ld = flow(x)
+    assert rel_err(ld.cpu(), g["logdet"]) < TOL
+
+
+def test_monotonic_golden_integrand_grads():
+    from models import MonotonicNormalizer
+    g = load_golden("integrand")
+    norm = MonotonicNormalizer([16, 16, 16], 5, nb_steps=20)
+    norm.integrand_net.load_state_dict({k[2:]: v for k, v in g.items() if k.startswith("p.")})
+    norm = norm.to(DEV)
+    x, h = req(g["x"]), req(g["h"])
+    _, jac = norm(x, h)
+    assert rel_err(jac.cpu(), g["jac"]) < TOL
+    (torch.log(jac) * cu(g["gj"])).sum().backward()
+    assert rel_err(x.grad.cpu(), g["gx"]) < GTOL and rel_err(h.grad.cpu(), g["gh"]) < GTOL
+    grads_match(norm.integrand_net, g)
+
+
+def test_monotonic_inverse_vs_oracle_and_round_trip():
+    norm, x, hraw, h = _mono_case(11, 5, 30, [50, 50, 50], 30, seed=5)
+    layers = _layers_cpu(norm)
+    z0, _ = O.monotonic_forward(x, h, layers, 30)
+    x0 = O.monotonic_inverse(z0.detach(), h, layers, 30)
+    norm = norm.to(DEV)
+    xi = norm.inverse_transform(cu(z0.detach()), cu(h))
+    # same bisection on nearly identical z(x): decisions can differ only by one last-step interval
+    assert (xi.cpu() - x0).abs().max() <= 40. / 2 ** 20 + 1e-6
+    assert (xi.cpu() - x).abs().max() < 1e-3
+
+
+# --------------------------------------------------------------------------------- size-independent properties at full size
+def test_full_size_cfg4_properties():
+    """MNIST d=784, B=100, Monotonic [50,50,50] c=30: z strictly increasing in x, z(0) = h0,
+    fixed-S determinism, and dz/dx ~ jac by central differences."""
+    from models import MonotonicNormalizer
+    torch.manual_seed(1)
+    B, d, c = 100, 784, 30
+    norm = MonotonicNormalizer([50, 50, 50], c, nb_steps=20).to(DEV)
+    x = torch.randn(B, d, device=DEV)
+    h = torch.randn(B, d, c, device=DEV)
+    with torch.no_grad():
+        z1, j1 = norm(x, h)
+        z1b, _ = norm(x, h)
+        assert torch.equal(z1, z1b)
+        z2, _ = norm(x + .25, h)
+        assert (z2 > z1).all() and (j1 > .05).all()
+        z0, _ = norm(torch.zeros_like(x), h)
+        assert torch.equal(z0, h[:, :, 0])
+        norm.nb_steps = 150
+        zp, _ = norm(x + 1e-2, h)
+        zm, _ = norm(x - 1e-2, h)
+        _, j = norm(x, h)
+        assert (((zp - zm) / 2e-2 - j).abs() / j).max() < 5e-2
+
+
+def test_full_size_cfg5_affine_roundtrip():
+    from models import AffineNormalizer
+    torch.manual_seed(2)
+    B, d = 50000, 63
+    x = torch.randn(B, d, device=DEV)
+    h = torch.randn(B, d, 2, device=DEV) * 2
+    n = AffineNormalizer()
+    with torch.no_grad():
+        z, jac = n(x, h)
+        xr = n.inverse_transform(z, h)
+    assert ((xr - x).abs() / (1 + x.abs())).max() < 1e-4
