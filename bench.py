@@ -1,0 +1,213 @@
+"""Headline benchmark: samples/sec of one full training step (fwd + log|det J| + NLL + bwd
++ gradient all-reduce + Adam) of the MNIST d=784 Monotonic+DAG flow (BASELINE.json
+configs[3]) on synthetic logit-space pseudo-MNIST, one process per GPU.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+Rank 0 prints ONE JSON line.  `roofline` is measured live with HIP events around the
+dominant hand-written kernel on the stream it is launched on; `cpu_baseline` times the
+CPU oracle (oracle/gnf_oracle.py, a PyTorch-CPU restatement of the reference path, parity
+checked against reference-generated golden vectors) on a bounded sample, rank 0, N=1 only.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+PKG = os.path.join(ROOT, "graphical-normalizing-flows_amd")
+for p in (ROOT, PKG):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+D = 784
+B_PER_GPU = 100
+INT_NET = [50, 50, 50]
+COND = 30
+S_NODES = 20
+PEAK_F32_TFLOPS = 157.3          # MI355X fp32 MFMA/vector peak (MI355X_MICROARCH.md)
+
+
+def pseudo_mnist(gen, B, d):
+    """logit-space pseudo-MNIST: reference transform (lib/transform.py:5-20) applied to a
+    synthetic pixel law (p=0 w.p. 0.8 else U{1..255}) -- real MNIST is not available."""
+    p = torch.where(torch.rand(B, d, generator=gen) < .8, torch.zeros(B, d),
+                    torch.randint(1, 256, (B, d), generator=gen).float())
+    y = (p + torch.rand(B, d, generator=gen)) / 256.
+    y = 1e-6 + (1 - 2e-6) * y
+    return torch.log(y) - torch.log(1 - y)
+
+
+def build_flow():
+    from models import MonotonicNormalizer
+    from models.NormalizingFlowFactories import buildMNISTNormalizingFlow
+    torch.manual_seed(0)
+    return buildMNISTNormalizingFlow([1], MonotonicNormalizer,
+                                     {"integrand_net": INT_NET, "nb_steps": 15, "solver": "CC"}, l1=0.,
+                                     nb_epoch_update=10, hot_encoding=False, prior_kernel=2)
+
+
+class FlatState:
+    """All trainable parameters and their gradients as views of two flat fp32 buffers: one
+    RCCL all-reduce and one fused Adam launch per step."""
+
+    def __init__(self, module):
+        self.params = [p for p in module.parameters() if p.requires_grad]
+        n = sum(p.numel() for p in self.params)
+        dev = self.params[0].device
+        self.flat = torch.empty(n, device=dev)
+        self.grad = torch.zeros(n, device=dev)
+        self.m = torch.zeros(n, device=dev)
+        self.v = torch.zeros(n, device=dev)
+        o = 0
+        for p in self.params:
+            k = p.numel()
+            self.flat[o:o + k].copy_(p.data.reshape(-1))
+            p.data = self.flat[o:o + k].view_as(p)
+            p.grad = self.grad[o:o + k].view_as(p)
+            o += k
+        self.t = 0
+
+
+def train_step(flow, state, x, world):
+    from gnf_hip import ops
+    state.grad.zero_()
+    for nrm in flow.getNormalizers():
+        nrm.nb_steps = S_NODES
+    z, ld = flow(x)
+    loss = flow.loss(z, ld)
+    loss.backward()
+    if world > 1:
+        dist.all_reduce(state.grad)          # ONE flat fp32 sum over xGMI (RCCL)
+    state.t += 1
+    ops.adam_step(state.flat, state.grad, state.m, state.v, state.t, lr=1e-3, weight_decay=1e-5,
+                  grad_scale=1. / world)
+    return loss
+
+
+def cpu_baseline():
+    """CPU oracle, same model/inputs, B=2 sample (B=100 needs >10 GB of conv activations
+    and minutes per step on the host): fwd + log|det J| + NLL + bwd, all host threads."""
+    from oracle import gnf_oracle as O
+    torch.manual_seed(0)
+    flow = build_flow()
+    sd = {k: v.detach().clone() for k, v in flow.state_dict().items()}
+    pre = "steps.0.conditioner."
+    cnn = {k[len(pre + "embedding_net."):]: v.requires_grad_(True) for k, v in sd.items() if "embedding_net." in k}
+    A = sd[pre + "A"].requires_grad_(True)
+    layers, k = [], 0
+    ipre = "steps.0.normalizer.integrand_net.net."
+    while ipre + "%d.weight" % k in sd:
+        layers.append((sd[ipre + "%d.weight" % k].requires_grad_(True), sd[ipre + "%d.bias" % k].requires_grad_(True)))
+        k += 2
+    Bc = 2
+    x = pseudo_mnist(torch.Generator().manual_seed(1234), Bc, D)
+    cores = min(os.cpu_count() or 1, 32)     # more threads only add contention at this size
+    torch.set_num_threads(cores)
+
+    def step():
+        u1, u2 = torch.rand(Bc, D, D), torch.rand(Bc, D, D)
+        e = O.dag_masked_inputs(x, A, True, 0., True, False, 1., u1, u2, None, False)
+        h = O.mnistcnn_forward(e, cnn).view(Bc, D, -1)
+        z, jac = O.monotonic_forward(x, h, layers, S_NODES)
+        closs = O.dag_loss(A, sd[pre + "alpha"], D % 50, sd[pre + "lambd"], sd[pre + "c"], sd[pre + "dag_const"],
+                           sd[pre + "l1_weight"])
+        O.flow_loss(z, torch.log(jac).sum(1), closs).backward()
+    step()                                   # warm-up
+    t0 = time.perf_counter()
+    n = 0
+    while n < 1 or (time.perf_counter() - t0 < 15. and n < 10):
+        step()
+        n += 1
+    dt = (time.perf_counter() - t0) / n
+    return {"value": Bc / dt, "unit": "samples/s", "cores": cores, "kind": "port",
+            "sample": "%d steps of B=%d (same d=784 model, S=20), fwd+logdet+NLL+bwd, torch %d threads"
+                      % (n, Bc, cores)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback of the product path)")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)      # "nccl" is RCCL on ROCm
+
+    from gnf_hip import abi, ops
+    abi.load()
+    flow = build_flow().to(dev)
+    for c in flow.getConditioners():                         # per-rank gate noise, like DP replicas
+        c.gate_seed = 1000003 * (rank + 1)
+    state = FlatState(flow)
+    if world > 1:
+        dist.broadcast(state.flat, 0)
+    x = pseudo_mnist(torch.Generator().manual_seed(1234 + rank), B_PER_GPU, D).to(dev)
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        train_step(flow, state, x, world)
+    fence()
+    abi.profile_enable(("gnf_monotonic_fwd", "gnf_monotonic_bwd", "gnf_dag_gate_fwd", "gnf_dag_gate_bwd"))
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = train_step(flow, state, x, world)
+    fence()
+    dt = time.perf_counter() - t0
+    prof = abi.profile_collect()
+    if not torch.isfinite(loss).item():
+        raise SystemExit("non-finite loss")
+    tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = tmax.item()
+
+    if rank == 0:
+        n_elem = B_PER_GPU * D
+        macs = (1 + COND) * INT_NET[0] + sum(a * b for a, b in zip(INT_NET[:-1], INT_NET[1:])) + INT_NET[-1]
+        flops_fwd = 2. * macs * (S_NODES + 2) * n_elem          # 2*M*(S+2) per element
+        ms_fwd = prof.get("gnf_monotonic_fwd", float("nan"))
+        achieved = flops_fwd / (ms_fwd * 1e-3) / 1e12
+        out = {
+            "metric": "samples/sec (fwd+log|detJ|+bwd) MNIST d=784 Monotonic-DAG",
+            "value": B_PER_GPU * world * args.steps / dt, "unit": "samples/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "cfg4: MNIST d=784, MonotonicNormalizer[50,50,50] cond 30 S=20 + DAGConditioner("
+                                   "MNISTCNN->30, prior_A_kernel=2, hot_encoding=False, Gumbel gate T=1), "
+                                   "b_size=100 per GPU; step = fwd+logdet+NLL+bwd+allreduce+Adam",
+                       "global_batch": B_PER_GPU * world, "parallelism": "dp%d" % world},
+            "roofline": {"bound": "mfma", "kernel": "mono_fwd_k<HT=4> (Clenshaw-Curtis quadrature of the integrand MLP)",
+                         "achieved": achieved, "peak": PEAK_F32_TFLOPS, "unit": "TFLOP/s",
+                         "frac": achieved / PEAK_F32_TFLOPS, "traffic": None},
+            "ops_ms": {k: round(v, 4) for k, v in prof.items()},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -110,5 +110,37 @@ def ptr(t):
     return ctypes.c_void_p(t.data_ptr())
 
 
+_prof = None        # name -> [(start_event, end_event), ...] while profiling is enabled
+
+
+def profile_enable(names):
+    """Record HIP events (on torch's current stream = the stream the kernels are launched
+    on) around every call of the named entry points; bench.py derives roofline numbers."""
+    global _prof
+    _prof = {n: [] for n in names}
+
+
+def profile_collect():
+    """-> {name: mean milliseconds per call}; disables profiling.  Synchronises."""
+    global _prof
+    out = {}
+    if _prof:
+        torch.cuda.synchronize()
+        for n, evs in _prof.items():
+            if evs:
+                out[n] = sum(a.elapsed_time(b) for a, b in evs) / len(evs)
+    _prof = None
+    return out
+
+
 def call(name, *args):
-    check(getattr(load(), name)(*args), name)
+    fn = getattr(load(), name)
+    if _prof is not None and name in _prof:
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        rc = fn(*args)
+        b.record()
+        _prof[name].append((a, b))
+        check(rc, name)
+    else:
+        check(fn(*args), name)

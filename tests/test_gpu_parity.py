@@ -202,11 +202,11 @@ def test_dag_gate_philox_statistics_and_determinism():
     assert torch.equal(e1, e2)                                        # counter-based: reproducible
     e3 = ops.DagGateFn.apply(x, A, ops.IMP_SOFT, ops.GATE_GUMBEL, 0., 1., False, None, None, 1234, 8)
     assert not torch.equal(e1, e3)
-    # at T=1 the relaxed gate has E[gate] = (p+eps)/(1+2eps) ~= p  (logistic noise identity)
+    # Gumbel-max identity: P(gate > 1/2) = P(log(p+eps)+g1 > log(1-p+eps)+g2) = (p+eps)/(1+2eps), any T
     p = (2 * (torch.sigmoid(2 * A.detach() ** 2) - .5))
-    many = torch.stack([ops.DagGateFn.apply(x, A, ops.IMP_SOFT, ops.GATE_GUMBEL, 0., 1., False, None, None, 99, k)
-                        .detach().view(B, d, d) for k in range(40)]).mean((0, 1))
-    assert (many - p).abs().max() < .03
+    frac = torch.stack([(ops.DagGateFn.apply(x, A, ops.IMP_SOFT, ops.GATE_GUMBEL, 0., .5, False, None, None, 99, k)
+                         .detach().view(B, d, d) > .5).float() for k in range(40)]).mean((0, 1))
+    assert (frac - p).abs().max() < .05          # 2560 draws per entry: sigma <= 0.01
     # backward regenerates the same noise: finite-difference check of d(sum e)/dA on one entry
     e1.sum().backward()
     gA = A.grad.clone()
