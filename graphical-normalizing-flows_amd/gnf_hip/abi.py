@@ -40,8 +40,9 @@ SIGNATURES = {
     "gnf_normal_logdensity_bwd": (c_int, [c_f, c_f, c_f, c_i64, c_i64, c_stream]),
     "gnf_colsum_ws_bytes": (c_i64, [c_i64, c_i64]),
     "gnf_colsum": (c_int, [c_f, c_i64, c_f, c_i64, c_i64, c_f, c_stream]),
+    "gnf_gemm_ws_bytes": (c_i64, [c_i64, c_i64, c_i64]),
     "gnf_gemm": (c_int, [c_f, c_i64, c_i64, c_f, c_f, c_i64, c_i64, c_f, c_i64, c_i64, c_f, c_f, c_i64, c_i64, c_f,
-                         c_i64, c_i64, c_int, c_i64, c_i64, c_i64, c_stream]),
+                         c_i64, c_i64, c_int, c_i64, c_i64, c_i64, c_f, c_i64, c_stream]),
     "gnf_dag_gate_fwd": (c_int, [c_f, c_f, c_f, c_i64, c_int, c_int, c_float, c_float, c_f, c_f, c_u64, c_u64, c_int,
                                  c_i64, c_i64, c_stream]),
     "gnf_dag_gate_bwd_ws_bytes": (c_i64, [c_i64, c_i64]),
@@ -57,6 +58,10 @@ SIGNATURES = {
     "gnf_monotonic_bwd": (c_int, [c_f, ctypes.POINTER(MonoNet), c_f, c_f, c_i64, c_i64, c_i64, c_f, c_f, c_int, c_f,
                                   c_f, c_f, c_f, c_i64, c_i64, c_i64, ctypes.POINTER(ctypes.c_void_p),
                                   ctypes.POINTER(ctypes.c_void_p), ctypes.c_void_p, c_i64, c_i64, c_i64, c_stream]),
+    "gnf_mnistcnn_conv_fwd": (c_int, [c_f, c_f, c_f, c_f, c_f, c_f, ctypes.c_void_p, c_i64, c_stream]),
+    "gnf_mnistcnn_conv_bwd_ws_bytes": (c_i64, [c_i64]),
+    "gnf_mnistcnn_conv_bwd": (c_int, [c_f, c_f, c_f, c_f, c_f, ctypes.c_void_p, c_f, c_f, c_f, c_f, c_f,
+                                      ctypes.c_void_p, c_i64, c_i64, c_stream]),
     "gnf_adam_step": (c_int, [c_f, c_f, c_f, c_f, c_i64, c_float, c_float, c_float, c_float, c_float, c_float, c_int,
                               c_stream]),
 }
@@ -107,6 +112,13 @@ def ptr(t):
         raise GnfError("gnf_hip kernels run on the MI355X only: got a %s tensor (no CPU fallback)" % t.device)
     if t.dtype != torch.float32:
         raise GnfError("gnf_hip kernels are fp32: got %s" % t.dtype)
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def rawptr(t):
+    """device pointer of a HIP tensor of any dtype (byte buffers)."""
+    if not t.is_cuda:
+        raise GnfError("gnf_hip kernels run on the MI355X only: got a %s tensor (no CPU fallback)" % t.device)
     return ctypes.c_void_p(t.data_ptr())
 
 

@@ -135,6 +135,23 @@ __global__ __launch_bounds__(256) void gemm_k(GemmArgs g) {
     }
 }
 
+
+// split-K epilogue: C = epi(sum_z partial[z]) with the same options as the fused epilogue
+__global__ void gemm_reduce_k(const float* __restrict__ part, int64_t nsp, GemmArgs g) {
+  const int64_t total = g.M * g.N;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t m = idx / g.N, n = idx - m * g.N;
+    float v = 0.f;
+    for (int64_t z = 0; z < nsp; ++z) v += part[z * total + idx];
+    if (g.bias) v += g.bias[n];
+    if (g.Cmask) v *= g.Cmask[m * g.scmm + n * g.scmn];
+    if (g.flags & GNF_GEMM_RELU) v = fmaxf(v, 0.f);
+    if (g.gate) v = g.gate[m * g.sgm + n * g.sgn] > 0.f ? v : 0.f;
+    g.C[m * g.scm + n * g.scn] = v;
+  }
+}
+
 }  // namespace
 
 static int64_t k_per_split(int64_t K, int splits) {
@@ -165,13 +182,42 @@ int gnf_gemm_launch(GemmArgs g, int splits, hipStream_t s) {
   return 0;
 }
 
+// split-K plan of the public entry: few output tiles and a long K -> spread K over the chip
+static int plan_splits(int64_t M, int64_t N, int64_t K) {
+  const int64_t tiles = ((M + 63) / 64) * ((N + 63) / 64);
+  if (tiles >= 256 || K < 2048) return 1;
+  int64_t s = (768 + tiles - 1) / tiles;
+  if (s > K / 512) s = K / 512;
+  if (s > 512) s = 512;
+  return s < 2 ? 1 : (int)s;
+}
+
+extern "C" int64_t gnf_gemm_ws_bytes(int64_t M, int64_t N, int64_t K) {
+  const int s = plan_splits(M, N, K);
+  return s > 1 ? (int64_t)s * M * N * (int64_t)sizeof(float) : 0;
+}
+
 extern "C" int gnf_gemm(const float* A, int64_t sam, int64_t sak, const float* B, const float* Bmask, int64_t sbk,
                         int64_t sbn, float* C, int64_t scm, int64_t scn, const float* bias, const float* Cmask,
                         int64_t scmm, int64_t scmn, const float* gate, int64_t sgm, int64_t sgn, int flags,
-                        int64_t M, int64_t N, int64_t K, gnf_stream_t stream) {
+                        int64_t M, int64_t N, int64_t K, float* ws, int64_t ws_bytes, gnf_stream_t stream) {
   if (!A || !B || !C || M < 0 || N < 0 || K < 0) return GNF_EINVAL;
   if (M == 0 || N == 0) return 0;
   GemmArgs g{A, sam, sak, B, Bmask, sbk, sbn, C, scm, scn, bias, Cmask, scmm, scmn, gate, sgm, sgn,
              flags & GNF_GEMM_RELU, M, N, K, 0, 0};
+  const int splits = plan_splits(M, N, K);
+  if (splits > 1 && ws && ws_bytes >= gnf_gemm_ws_bytes(M, N, K)) {
+    GemmArgs p = g;                       // partial products only: epilogue runs in the reduction
+    p.C = ws; p.scm = N; p.scn = 1; p.c_split_stride = M * N;
+    p.bias = nullptr; p.Cmask = nullptr; p.gate = nullptr; p.flags = 0;
+    int rc = gnf_gemm_launch(p, splits, (hipStream_t)stream);
+    if (rc) return rc;
+    const int64_t nsp = gnf_gemm_num_splits(K, splits);
+    int64_t grid = (M * N + 255) / 256;
+    if (grid > 4096) grid = 4096;
+    hipLaunchKernelGGL(gemm_reduce_k, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, ws, nsp, g);
+    GNF_LAUNCH_CHECK();
+    return 0;
+  }
   return gnf_gemm_launch(g, 1, (hipStream_t)stream);
 }

@@ -117,9 +117,11 @@ def colsum(a):
 # ----------------------------------------------------------------------------- MFMA GEMM / MLP chains
 def gemm(A, a_strides, Bm, b_strides, C, c_strides, M, N, K, Bmask=None, bias=None, Cmask=None, cm_strides=(0, 0),
          gate=None, g_strides=(0, 0), relu=False):
+    nws = abi.load().gnf_gemm_ws_bytes(M, N, K)
+    ws = _ws(nws, C) if nws > 0 else None
     call("gnf_gemm", ptr(A), a_strides[0], a_strides[1], ptr(Bm), ptr(Bmask), b_strides[0], b_strides[1], ptr(C),
          c_strides[0], c_strides[1], ptr(bias), ptr(Cmask), cm_strides[0], cm_strides[1], ptr(gate), g_strides[0],
-         g_strides[1], 1 if relu else 0, M, N, K, stream())
+         g_strides[1], 1 if relu else 0, M, N, K, ptr(ws), nws, stream())
 
 
 class MLPFn(torch.autograd.Function):
@@ -187,6 +189,37 @@ def mlp(x, layers, masks=None):
     """layers: list of (weight, bias) parameter pairs."""
     flat = [p for Wb in layers for p in Wb]
     return MLPFn.apply(x, masks, *flat)
+
+
+# ----------------------------------------------------------------------------- MNISTCNN conv front
+class MnistConvFn(torch.autograd.Function):
+    """flatten(max_pool2d(conv2(relu(conv1(e))), 2)) for 28x28 single-channel images
+    (models/MLP.py:36-43), fused in LDS; backward recomputes conv1 in-kernel."""
+
+    @staticmethod
+    def forward(ctx, e, W1, b1, W2, b2):
+        e = e.contiguous()
+        n = e.shape[0]
+        W1c, b1c, W2c, b2c = W1.contiguous(), b1.contiguous(), W2.contiguous(), b2.contiguous()
+        pooled = _empty((n, 2304), e)
+        arg = torch.empty((n, 2304), dtype=torch.uint8, device=e.device)
+        call("gnf_mnistcnn_conv_fwd", ptr(e), ptr(W1c), ptr(b1c), ptr(W2c), ptr(b2c), ptr(pooled), abi.rawptr(arg), n,
+             stream())
+        ctx.save_for_backward(e, W1c, b1c, W2c, arg)
+        return pooled
+
+    @staticmethod
+    def backward(ctx, gp):
+        e, W1, b1, W2, arg = ctx.saved_tensors
+        n = e.shape[0]
+        gp = gp.contiguous()
+        ge = _empty((n, 784), e)
+        gW1, gb1, gW2, gb2 = torch.empty_like(W1), torch.empty_like(b1), torch.empty_like(W2), torch.empty_like(b1)
+        nws = abi.load().gnf_mnistcnn_conv_bwd_ws_bytes(n)
+        ws = _ws(nws, e)
+        call("gnf_mnistcnn_conv_bwd", ptr(e), ptr(W1), ptr(b1), ptr(W2), ptr(gp), abi.rawptr(arg), ptr(ge), ptr(gW1),
+             ptr(gb1), ptr(gW2), ptr(gb2), abi.rawptr(ws), nws, n, stream())
+        return ge, gW1, gb1, gW2, gb2
 
 
 # ----------------------------------------------------------------------------- DAG gate

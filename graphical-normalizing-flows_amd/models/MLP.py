@@ -33,9 +33,9 @@ class MLP(nn.Module):
 
 class MNISTCNN(nn.Module):
     """Embedding net of the MNIST DAG flow (reference models/MLP.py:24-48): conv3x3(1->16) ReLU
-    conv3x3(16->16) maxpool2 flatten fc(2304->128) ReLU fc(128->out_d).  The two fc layers
-    run on the fused MFMA GEMM chain; the convolutions go through torch (MIOpen) in this
-    round -- the fused masked-image kernel is the next step."""
+    conv3x3(16->16) maxpool2 flatten fc(2304->128) ReLU fc(128->out_d).  For the 28x28
+    single-channel case the convolutional front is one fused LDS-resident MFMA kernel
+    (gnf_mnistcnn.hip) and the fc layers run on the MFMA GEMM chain."""
 
     def __init__(self, out_d=10, fc_l=[2304, 128], size_img=[1, 28, 28]):
         super(MNISTCNN, self).__init__()
@@ -48,13 +48,21 @@ class MNISTCNN(nn.Module):
         self.out_d = out_d
         self.size_img = size_img
 
+    def _fused_conv_ok(self, x):
+        return (x.is_cuda and list(self.size_img) == [1, 28, 28] and x.shape[-1] == 784
+                and tuple(self.conv1.weight.shape) == (16, 1, 3, 3) and tuple(self.conv2.weight.shape) == (16, 16, 3, 3))
+
     def forward(self, x, context=None):
         b_size = x.shape[0]
-        x = self.conv1(x.view(-1, self.size_img[0], self.size_img[1], self.size_img[2]))
-        x = F.relu(x)
-        x = self.conv2(x)
-        x = F.max_pool2d(x, 2)
-        x = torch.flatten(x, 1)
+        if self._fused_conv_ok(x):
+            x = ops.MnistConvFn.apply(x.view(-1, 784), self.conv1.weight, self.conv1.bias, self.conv2.weight,
+                                      self.conv2.bias)
+        else:   # other image sizes (the reference's multi-scale factory): library convolution
+            x = self.conv1(x.view(-1, self.size_img[0], self.size_img[1], self.size_img[2]))
+            x = F.relu(x)
+            x = self.conv2(x)
+            x = F.max_pool2d(x, 2)
+            x = torch.flatten(x, 1)
         x = ops.mlp(x, [(self.fc1.weight, self.fc1.bias), (self.fc2.weight, self.fc2.bias)])
         return x.view(b_size, -1)
 

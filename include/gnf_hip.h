@@ -72,13 +72,18 @@ int gnf_colsum(const float* a, int64_t lda, float* out, int64_t M, int64_t N, fl
  *        relu if flags&GNF_GEMM_RELU;  * (gate[m*sgm + n*sgn] > 0) (NULL = none);
  *   C[m,n] at m*scm + n*scn.  v_mfma_f32_32x32x2_f32: exact fp32, k-ordered fma chain. */
 #define GNF_GEMM_RELU 1
+/* Optional split-K workspace: when gnf_gemm_ws_bytes(M,N,K) > 0 and `ws` holds at least
+ * that many bytes, K is spread over several workgroups (few output tiles, long K: the
+ * weight-gradient shapes) and a second kernel reduces the partials and applies the
+ * epilogue.  ws == NULL always selects the single-pass kernel. */
+int64_t gnf_gemm_ws_bytes(int64_t M, int64_t N, int64_t K);
 int gnf_gemm(const float* A, int64_t sam, int64_t sak,
              const float* B, const float* Bmask, int64_t sbk, int64_t sbn,
              float* C, int64_t scm, int64_t scn,
              const float* bias,
              const float* Cmask, int64_t scmm, int64_t scmn,
              const float* gate, int64_t sgm, int64_t sgn,
-             int flags, int64_t M, int64_t N, int64_t K, gnf_stream_t stream);
+             int flags, int64_t M, int64_t N, int64_t K, float* ws, int64_t ws_bytes, gnf_stream_t stream);
 
 /* ---- DAG conditioner gate: models/Conditionners/DAGConditioner.py:94-166 --------------
  * e[(b*d+i)*ld_e + j] = x[b,j] * gate(importance(A[i,j])) (+ one-hot of i in columns
@@ -145,6 +150,22 @@ int gnf_monotonic_bwd(const float* pack, const gnf_mono_net* net,
                       float* gx, float* gh, int64_t g_sb, int64_t g_sd, int64_t g_sc,
                       float* const* gW, float* const* gb,
                       void* ws, int64_t ws_bytes, int64_t B, int64_t d, gnf_stream_t stream);
+
+/* ---- MNISTCNN convolutional front: models/MLP.py:36-41 as the DAG embedding net --------
+ * (ImageExperiments / NormalizingFlowFactories.py:83-86: size_img = [1,28,28]).
+ * e: [n_img, 784] masked images; W1 [16,1,3,3], b1 [16], W2 [16,16,3,3], b2 [16].
+ * pooled: [n_img, 2304] = flatten(maxpool2(conv2(relu(conv1(e))))) in [16,12,12] order;
+ * argmax: [n_img, 2304] bytes, index 0..3 of the first maximum of each 2x2 window in scan
+ * order (what torch's max_pool2d records), consumed by the backward. */
+int gnf_mnistcnn_conv_fwd(const float* e, const float* W1, const float* b1, const float* W2, const float* b2,
+                          float* pooled, unsigned char* argmax, int64_t n_img, gnf_stream_t stream);
+/* Backward: recomputes conv1, writes ge [n_img,784] and the parameter gradients (written,
+ * not accumulated).  ws: >= gnf_mnistcnn_conv_bwd_ws_bytes(n_img) bytes. */
+int64_t gnf_mnistcnn_conv_bwd_ws_bytes(int64_t n_img);
+int gnf_mnistcnn_conv_bwd(const float* e, const float* W1, const float* b1, const float* W2,
+                          const float* g_pooled, const unsigned char* argmax,
+                          float* ge, float* gW1, float* gb1, float* gW2, float* gb2,
+                          void* ws, int64_t ws_bytes, int64_t n_img, gnf_stream_t stream);
 
 /* ---- Adam on one flat fp32 buffer (torch.optim.Adam semantics, L2 weight decay) --------
  * ImageExperiments.py:173 / UCIExperiments.py:97; used by the data-parallel harness after
