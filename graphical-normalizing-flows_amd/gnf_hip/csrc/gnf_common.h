@@ -43,3 +43,6 @@ __device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t
 
 // 24-bit uniform in [0,1), the resolution torch.rand has for fp32.
 __device__ __forceinline__ float u01_24(uint32_t r) { return (float)(r >> 8) * (1.0f / 16777216.0f); }
+
+// out[n] (+)= sum_{p<P} src[p*N + n]   (gnf_rowwise.hip; deterministic order)
+int gnf_rowsum_launch(const float* src, float* out, int64_t P, int64_t N, int accumulate, hipStream_t s);

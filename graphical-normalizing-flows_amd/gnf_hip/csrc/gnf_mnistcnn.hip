@@ -314,13 +314,11 @@ __global__ __launch_bounds__(64 * BWD_WAVES) void cnn_bwd_k(CnnArgs a) {
   if (lane < NCH && (lane >> 1) != wave) prow[NCH * 144 + NCH * 16 + lane] = 0.f;
 }
 
-// out = sum of partial rows, unpacked into the parameter-shaped gradients
-__global__ void cnn_reduce_k(const float* __restrict__ part, int64_t rows, float* gW1, float* gb1, float* gW2,
-                             float* gb2) {
+// unpack the summed partial row into the parameter-shaped gradients
+__global__ void cnn_unpack_k(const float* __restrict__ vec, float* gW1, float* gb1, float* gW2, float* gb2) {
   const int n = blockIdx.x * blockDim.x + threadIdx.x;
   if (n >= PROW) return;
-  float s = 0.f;
-  for (int64_t p = 0; p < rows; ++p) s += part[p * PROW + n];
+  const float s = vec[n];
   if (n < NCH * 144) gW2[n] = s;
   else if (n < NCH * 144 + NCH * 16) {
     const int k = n - NCH * 144, oc = k >> 4, c = k & 15;
@@ -353,7 +351,7 @@ int gnf_mnistcnn_conv_fwd(const float* e, const float* W1, const float* b1, cons
 
 int64_t gnf_mnistcnn_conv_bwd_ws_bytes(int64_t n_img) {
   (void)n_img;
-  return (int64_t)kBwdGrid * BWD_WAVES * PROW * (int64_t)sizeof(float);
+  return ((int64_t)kBwdGrid * BWD_WAVES + 1) * PROW * (int64_t)sizeof(float);
 }
 
 int gnf_mnistcnn_conv_bwd(const float* e, const float* W1, const float* b1, const float* W2, const float* g_pooled,
@@ -370,8 +368,12 @@ int gnf_mnistcnn_conv_bwd(const float* e, const float* W1, const float* b1, cons
   // fixed grid: every workgroup (also one without images) writes its partial rows
   hipLaunchKernelGGL(cnn_bwd_k, dim3(kBwdGrid), dim3(64 * BWD_WAVES), kBwdLds, (hipStream_t)stream, a);
   GNF_LAUNCH_CHECK();
-  hipLaunchKernelGGL(cnn_reduce_k, dim3((PROW + 255) / 256), dim3(256), 0, (hipStream_t)stream, (const float*)ws,
-                     (int64_t)kBwdGrid * BWD_WAVES, gW1, gb1, gW2, gb2);
+  const int64_t rows = (int64_t)kBwdGrid * BWD_WAVES;
+  float* vec = (float*)ws + rows * PROW;
+  const int rc = gnf_rowsum_launch((const float*)ws, vec, rows, PROW, 0, (hipStream_t)stream);
+  if (rc) return rc;
+  hipLaunchKernelGGL(cnn_unpack_k, dim3((PROW + 255) / 256), dim3(256), 0, (hipStream_t)stream, vec, gW1, gb1, gW2,
+                     gb2);
   GNF_LAUNCH_CHECK();
   return 0;
 }

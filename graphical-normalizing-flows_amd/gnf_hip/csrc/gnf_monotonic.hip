@@ -481,16 +481,6 @@ __global__ __launch_bounds__(64 * kWaves) void mono_bwd_k(MonoArgs a) {
   if (lane == 0) { prow[(NH + 2) * HP] = vbl; prow[(NH + 2) * HP + 1] = 0.f; prow[(NH + 2) * HP + 2] = 0.f; prow[(NH + 2) * HP + 3] = 0.f; }
 }
 
-// sum the split-K / per-wave partial rows:  out[n] = sum_p src[p*N + n]
-__global__ void mono_rowsum_k(const float* __restrict__ src, float* __restrict__ out, int64_t P, int64_t N,
-                              int accumulate) {
-  const int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (n >= N) return;
-  float s = accumulate ? out[n] : 0.f;
-  for (int64_t p = 0; p < P; ++p) s += src[p * N + n];
-  out[n] = s;
-}
-
 struct UnpackArgs {
   gnf_mono_net net; MonoLayout L;
   float* gW[GNF_MONO_MAX_LAYERS]; float* gb[GNF_MONO_MAX_LAYERS];
@@ -714,9 +704,7 @@ int gnf_monotonic_bwd(const float* pack, const gnf_mono_net* net, const float* x
   a.Dsum = w + P.o_Dsum; a.part = w + P.o_part; a.NK = (int)NK;
 
   auto rowsum = [&](const float* src, float* out, int64_t Pn, int64_t N, int acc) -> int {
-    hipLaunchKernelGGL(mono_rowsum_k, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, s, src, out, Pn, N, acc);
-    GNF_LAUNCH_CHECK();
-    return 0;
+    return gnf_rowsum_launch(src, out, Pn, N, acc, s);
   };
   const int64_t nchunks = (n + P.chunk_elems - 1) / P.chunk_elems;
   const int64_t part_rows = (int64_t)kBwdGrid * kWaves;

@@ -171,6 +171,31 @@ __global__ void adam_k(float* __restrict__ p, const float* __restrict__ g, float
   }
 }
 
+// out[n] (+)= sum_p src[p*N + n]: 64 columns per block, 16 wavefronts stride over the rows
+// (coalesced 256-B row segments), fixed-order LDS tree across the wavefronts -> deterministic.
+__global__ __launch_bounds__(1024) void rowsum_k(const float* __restrict__ src, float* __restrict__ out, int64_t P,
+                                                 int64_t N, int accumulate) {
+  __shared__ float red[16][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t n = (int64_t)blockIdx.x * 64 + lane;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  if (n < N) {
+    int64_t p = wave;
+    for (; p + 48 < P; p += 64) {
+      s0 += src[p * N + n]; s1 += src[(p + 16) * N + n]; s2 += src[(p + 32) * N + n]; s3 += src[(p + 48) * N + n];
+    }
+    for (; p < P; p += 16) s0 += src[p * N + n];
+  }
+  red[wave][lane] = (s0 + s1) + (s2 + s3);
+  __syncthreads();
+  if (wave == 0 && n < N) {
+    float s = accumulate ? out[n] : 0.f;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) s += red[w][lane];
+    out[n] = s;
+  }
+}
+
 inline unsigned grid_1d(int64_t n) {
   int64_t g = (n + kBlock - 1) / kBlock;
   if (g > 256 * 8) g = 256 * 8;   // 8 blocks per CU, grid-stride the rest
@@ -179,6 +204,13 @@ inline unsigned grid_1d(int64_t n) {
 }
 
 }  // namespace
+
+int gnf_rowsum_launch(const float* src, float* out, int64_t P, int64_t N, int accumulate, hipStream_t s) {
+  if (N <= 0) return 0;
+  hipLaunchKernelGGL(rowsum_k, dim3((unsigned)((N + 63) / 64)), dim3(1024), 0, s, src, out, P, N, accumulate);
+  GNF_LAUNCH_CHECK();
+  return 0;
+}
 
 extern "C" {
 
