@@ -53,42 +53,13 @@ def build_flow():
                                      nb_epoch_update=10, hot_encoding=False, prior_kernel=2)
 
 
-class FlatState:
-    """All trainable parameters and their gradients as views of two flat fp32 buffers: one
-    RCCL all-reduce and one fused Adam launch per step."""
-
-    def __init__(self, module):
-        self.params = [p for p in module.parameters() if p.requires_grad]
-        n = sum(p.numel() for p in self.params)
-        dev = self.params[0].device
-        self.flat = torch.empty(n, device=dev)
-        self.grad = torch.zeros(n, device=dev)
-        self.m = torch.zeros(n, device=dev)
-        self.v = torch.zeros(n, device=dev)
-        o = 0
-        for p in self.params:
-            k = p.numel()
-            self.flat[o:o + k].copy_(p.data.reshape(-1))
-            p.data = self.flat[o:o + k].view_as(p)
-            p.grad = self.grad[o:o + k].view_as(p)
-            o += k
-        self.t = 0
-
-
-def train_step(flow, state, x, world):
-    from gnf_hip import ops
-    state.grad.zero_()
+def train_step(flow, state, x):
+    """one optimisation step on the local shard (gnf_hip.dp.train_step) at the headline node
+    count S=20 (the drivers jitter nb_steps per batch, ImageExperiments.py:201-203)."""
+    from gnf_hip import dp
     for nrm in flow.getNormalizers():
         nrm.nb_steps = S_NODES
-    z, ld = flow(x)
-    loss = flow.loss(z, ld)
-    loss.backward()
-    if world > 1:
-        dist.all_reduce(state.grad)          # ONE flat fp32 sum over xGMI (RCCL)
-    state.t += 1
-    ops.adam_step(state.flat, state.grad, state.m, state.v, state.t, lr=1e-3, weight_decay=1e-5,
-                  grad_scale=1. / world)
-    return loss
+    return dp.train_step(flow, state, x, lr=1e-3, weight_decay=1e-5)
 
 
 def cpu_baseline():
@@ -155,9 +126,9 @@ def main():
     flow = build_flow().to(dev)
     for c in flow.getConditioners():                         # per-rank gate noise, like DP replicas
         c.gate_seed = 1000003 * (rank + 1)
-    state = FlatState(flow)
-    if world > 1:
-        dist.broadcast(state.flat, 0)
+    from gnf_hip import dp
+    state = dp.FlatState(flow)
+    state.broadcast(0)
     x = pseudo_mnist(torch.Generator().manual_seed(1234 + rank), B_PER_GPU, D).to(dev)
 
     def fence():
@@ -166,12 +137,12 @@ def main():
         torch.cuda.synchronize()
 
     for _ in range(args.warmup):
-        train_step(flow, state, x, world)
+        train_step(flow, state, x)
     fence()
     abi.profile_enable(("gnf_monotonic_fwd", "gnf_monotonic_bwd", "gnf_dag_gate_fwd", "gnf_dag_gate_bwd"))
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        loss = train_step(flow, state, x, world)
+        loss = train_step(flow, state, x)
     fence()
     dt = time.perf_counter() - t0
     prof = abi.profile_collect()

@@ -1,0 +1,115 @@
+"""CPU (-m "not gpu"): the C-ABI library loads and exports every symbol include/gnf_hip.h
+declares; host-side logic of the mirrored plug-in API (constructors, masks, priors,
+state_dict keys, quadrature rule) against the reference-generated golden vectors; and the
+product path refuses to run without the GPU (no CPU fallback)."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import ROOT, load_golden
+from oracle import gnf_oracle as O
+
+
+def test_abi_exports_every_declared_symbol():
+    from gnf_hip import abi
+    header = open(os.path.join(ROOT, "include", "gnf_hip.h")).read()
+    header = re.sub(r"/\*.*?\*/", "", header, flags=re.S)
+    declared = set(re.findall(r"\b(gnf_[a-z0-9_]+)\s*\(", header))
+    assert declared == set(abi.SIGNATURES), declared ^ set(abi.SIGNATURES)
+    lib = abi.load()                                   # dlopen works without a GPU
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert lib.gnf_abi_version() == 1
+    # pure host queries work without a device
+    assert lib.gnf_colsum_ws_bytes(1000, 7) > 0
+    assert lib.gnf_gemm_ws_bytes(128, 2304, 78400) > 0 and lib.gnf_gemm_ws_bytes(4096, 4096, 64) == 0
+
+
+def test_no_cpu_fallback():
+    from gnf_hip import ops, GnfError
+    from models import AffineNormalizer
+    with pytest.raises(GnfError):
+        AffineNormalizer()(torch.randn(3, 2), torch.randn(3, 2, 2))
+    with pytest.raises(GnfError):
+        ops.mlp(torch.randn(3, 2), [(torch.randn(4, 2), torch.randn(4))])
+
+
+def test_made_masks_and_prior_match_reference():
+    from models import AutoregressiveConditioner
+    from models.NormalizingFlowFactories import MNIST_A_prior
+    g = load_golden("masks_prior")
+    for tag in "abc":
+        cfg = g[tag + "_cfg"].tolist()
+        c = AutoregressiveConditioner(cfg[0], cfg[2:], cfg[1])
+        for k, v in c.state_dict().items():
+            if k.endswith("mask"):
+                assert torch.equal(v, g["%s_%s" % (tag, k.replace("masked_autoregressive_net.", ""))])
+    for k in (1, 2):
+        assert torch.equal(torch.nonzero(MNIST_A_prior(28, k)).int(), g["A_prior_28_%d_idx" % k])
+    assert torch.equal(MNIST_A_prior(6, 1), g["A_prior_6_1"])
+
+
+def test_state_dict_keys_match_reference():
+    from models import (buildFCNormalizingFlow, CouplingConditioner, AutoregressiveConditioner, DAGConditioner,
+                        AffineNormalizer, MonotonicNormalizer)
+    from models.NormalizingFlowFactories import buildMNISTNormalizingFlow
+    cases = {
+        "flow_affine_coupling_3": buildFCNormalizingFlow(3, CouplingConditioner, {"in_size": 5, "hidden": [16, 16],
+                                                                                  "out_size": 2}, AffineNormalizer, {}),
+        "flow_affine_dag_2": buildFCNormalizingFlow(2, DAGConditioner, {"in_size": 6, "hidden": [16, 16], "out_size": 2,
+                                                                        "l1": .05, "gumble_T": .5, "hot_encoding": True},
+                                                    AffineNormalizer, {}),
+        "flow_mono_made_1": buildFCNormalizingFlow(1, AutoregressiveConditioner, {"in_size": 4, "hidden": [12, 12],
+                                                                                  "out_size": 6},
+                                                   MonotonicNormalizer, {"integrand_net": [10, 10], "cond_size": 6,
+                                                                         "nb_steps": 20, "solver": "CC"}),
+        "flow_mnist_affine_dag": buildMNISTNormalizingFlow([1], AffineNormalizer, {}, prior_kernel=2),
+    }
+    for name, flow in cases.items():
+        g = load_golden(name)
+        assert list(flow.state_dict().keys()) == list(g["state_keys"]), name
+        sd = {k[2:]: v for k, v in g.items() if k.startswith("p.")}
+        if name == "flow_mnist_affine_dag":
+            sd["steps.0.conditioner.A"] = flow.steps[0].conditioner.A.detach()
+        flow.load_state_dict(sd)                        # reference checkpoints load unchanged
+
+
+def test_dag_host_logic():
+    from models import DAGConditioner
+    torch.manual_seed(0)
+    g = load_golden("dag_trace84")
+    c = DAGConditioner(84, [8], 2)
+    with torch.no_grad():
+        c.A.copy_(g["A"])
+    assert abs(c.get_power_trace().item() - g["trace"].item()) < 1e-5 * abs(g["trace"].item())
+    assert abs(c.loss().item() - g["loss"].item()) < 1e-5 * abs(g["loss"].item())
+    assert c.exponent == int(g["exponent"]) and not c.is_invertible
+    # a strictly lower-triangular A is a DAG: depth = longest path, constrainA zeroes the diagonal
+    c2 = DAGConditioner(5, [4], 2, A_prior=torch.tril(torch.ones(5, 5)))
+    assert torch.equal(torch.diag(c2.A.detach()), torch.zeros(5))
+    assert c2.depth() == 4
+    assert c2._modes() == (1, 1)                        # soft threshold + Gumbel gate (training default)
+    c2.stoch_gate = False
+    c2.h_thresh = .5
+    assert c2._modes() == (2, 0)
+    c2.s_thresh = False
+    assert c2._modes() == (3, 0)
+    c2.h_thresh = 0.
+    assert c2._modes() == (0, 0)
+    with pytest.raises(NotImplementedError):
+        c2(torch.randn(2, 5), context=torch.randn(2, 1))
+
+
+def test_cc_rule_matches_oracle_and_solver_switch():
+    from gnf_hip import ops
+    from models import MonotonicNormalizer
+    for S in (15, 20, 29, 150):
+        w, t = ops.cc_rule(S, "cpu")
+        wo, to = O.cc_rule(S)
+        assert np.array_equal(w.numpy(), wo.astype(np.float32)) and np.array_equal(t.numpy(), to.astype(np.float32))
+    n = MonotonicNormalizer([8, 8], 3, nb_steps=20, solver="Euler")
+    assert n(torch.randn(2, 2), torch.randn(2, 2, 3)) is None      # unknown solver -> None (reference :64-65)
