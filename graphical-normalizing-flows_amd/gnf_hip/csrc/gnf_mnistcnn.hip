@@ -26,13 +26,21 @@ constexpr int ROW = 40, CH = C1 * ROW;                // conv1 activations: [16]
 constexpr int ROWD = 40, CHD = 28 * ROWD + 16;        // dY2 with a 2-wide zero border: [16][28][40], CHD = 1136 == 16 mod 32
 constexpr int CS = 688;                               // per-tap planes T: [9][688] flat 26x26 positions
 constexpr int NPOOL = NCH * PO * PO;                  // 2304
-constexpr int FWD_WAVES = 4, BWD_WAVES = 8;
+constexpr int FWD_WAVES = 8, BWD_WAVES = 8;
 constexpr int PROW = NCH * 144 + NCH * 16 + NCH;      // per-wave gradient partial row: dW2 | dW1+db1 | db2
 
 static_assert(CH % 32 == 16 && CHD % 32 == 16, "channel strides must sit 16 banks apart");
 
 __device__ __forceinline__ f32x4 mfma(float a, float b, f32x4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+
+// lane^1 (quad_perm [1,0,3,2]) and lane^8 (row_ror:8 inside a 16-lane row) without touching LDS
+__device__ __forceinline__ float dpp_xor1(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, false));
+}
+__device__ __forceinline__ float dpp_xor8(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x128, 0xF, 0xF, false));
 }
 
 struct CnnArgs {
@@ -42,18 +50,20 @@ struct CnnArgs {
   int64_t n;
 };
 
-// conv1 + ReLU of the image in e_s into a1_s; tiles: 13 row pairs x 4 column blocks (x >= 26 discarded)
+// conv1 + ReLU of the image in e_s into a1_s; 43 tiles of 16 consecutive positions of the 26x26 grid
 template <int NW>
 __device__ __forceinline__ void conv1_tiles(const float* e_s, float* a1_s, const float (&w1f)[3], const int (&off1)[3],
                                             const f32x4& b1v, int wave, int q, int j) {
 #pragma nounroll
-  for (int t = wave; t < 52; t += NW) {
-    const int y = 2 * (t >> 2) + (j >> 3), x = 8 * (t & 3) + (j & 7);
+  for (int t = wave; t < 43; t += NW) {
+    const int pos = 16 * t + j;
+    const int pc = pos < C1 * C1 ? pos : 0;
+    const int y = pc / C1, x = pc - y * C1;
     const int base = y * ROWE + x;
     f32x4 acc = b1v;
 #pragma unroll
     for (int s = 0; s < 3; ++s) acc = mfma(w1f[s], e_s[base + off1[s]], acc);
-    if (x < C1) {
+    if (pos < C1 * C1) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) a1_s[(4 * q + r) * CH + y * ROW + x] = fmaxf(acc[r], 0.f);
     }
@@ -87,10 +97,29 @@ __global__ __launch_bounds__(64 * FWD_WAVES) void cnn_fwd_k(CnnArgs a) {
 
   for (int i = tid; i < ESZ; i += blockDim.x) e_s[i] = 0.f;
 
+  constexpr int NT = 64 * FWD_WAVES, EPT = (IMG * IMG + NT - 1) / NT;   // image elements per thread
+  float pre[EPT];
+#pragma unroll
+  for (int k = 0; k < EPT; ++k) {
+    const int i = tid + k * NT;
+    pre[k] = (blockIdx.x < a.n && i < IMG * IMG) ? a.e[(int64_t)blockIdx.x * (IMG * IMG) + i] : 0.f;
+  }
   for (int64_t img = blockIdx.x; img < a.n; img += gridDim.x) {
     __syncthreads();                                   // previous image fully consumed
-    for (int i = tid; i < IMG * IMG; i += blockDim.x) e_s[(i / IMG) * ROWE + i % IMG] = a.e[img * (IMG * IMG) + i];
+#pragma unroll
+    for (int k = 0; k < EPT; ++k) {
+      const int i = tid + k * NT;
+      if (i < IMG * IMG) e_s[(i / IMG) * ROWE + i % IMG] = pre[k];
+    }
     __syncthreads();
+    {                                                  // next image's pixels: in flight under the MFMAs
+      const int64_t nx = img + gridDim.x;
+#pragma unroll
+      for (int k = 0; k < EPT; ++k) {
+        const int i = tid + k * NT;
+        pre[k] = (nx < a.n && i < IMG * IMG) ? a.e[nx * (IMG * IMG) + i] : 0.f;
+      }
+    }
     conv1_tiles<FWD_WAVES>(e_s, a1_s, w1f, off1, b1v, wave, q, j);
     __syncthreads();
     // conv2 (implicit GEMM, K = 16 channels x 9 taps) + 2x2 max pool: 36 tiles, two in flight per wave
@@ -120,7 +149,7 @@ __global__ __launch_bounds__(64 * FWD_WAVES) void cnn_fwd_k(CnnArgs a) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const float v00 = acc[r];
-          const float v01 = __shfl_xor(v00, 1, 64), v10 = __shfl_xor(v00, 8, 64), v11 = __shfl_xor(v00, 9, 64);
+          const float v01 = dpp_xor1(v00), v10 = dpp_xor8(v00), v11 = dpp_xor8(v01);
           if ((j & 9) == 0) {                          // top-left lane of a 2x2 window; first max wins ties
             float best = v00; int bi = 0;
             if (v01 > best) { best = v01; bi = 1; }
@@ -183,25 +212,56 @@ __global__ __launch_bounds__(64 * BWD_WAVES) void cnn_bwd_k(CnnArgs a) {
   for (int i = tid; i < ESZ; i += NT) e_s[i] = 0.f;
   for (int i = tid; i < NCH * CHD; i += NT) d_s[i] = 0.f;
 
+  // software prefetch: the next image's pixels, pooled gradients and argmax bytes are loaded into
+  // registers while the MFMA phases of the current image run
+  constexpr int EPT = (IMG * IMG + NT - 1) / NT, WPT = (PO * PO + 31) / 32;
+  float epre[EPT], gpre[WPT];
+  int apre[WPT];
+  auto prefetch = [&](int64_t im) {
+    const bool on = im < a.n;
+#pragma unroll
+    for (int k = 0; k < EPT; ++k) {
+      const int i = tid + k * NT;
+      epre[k] = (on && i < IMG * IMG) ? a.e[im * (IMG * IMG) + i] : 0.f;
+    }
+#pragma unroll
+    for (int k = 0; k < WPT; ++k) {
+      const int w = (tid & 31) + 32 * k;
+      const bool ok = on && w < PO * PO;
+      const int64_t o = im * NPOOL + (tid >> 5) * (PO * PO) + w;
+      gpre[k] = ok ? a.gp[o] : 0.f;
+      apre[k] = ok ? (int)a.argin[o] : 0;
+    }
+  };
+  prefetch(blockIdx.x);
+
   for (int64_t img = blockIdx.x; img < a.n; img += gridDim.x) {
     __syncthreads();
     // ---- P0: image, and dY2 = pool-backward scatter of g_pooled (one write per conv2 position)
-    for (int i = tid; i < IMG * IMG; i += NT) e_s[(i / IMG) * ROWE + i % IMG] = a.e[img * (IMG * IMG) + i];
+#pragma unroll
+    for (int k = 0; k < EPT; ++k) {
+      const int i = tid + k * NT;
+      if (i < IMG * IMG) e_s[(i / IMG) * ROWE + i % IMG] = epre[k];
+    }
     {
       const int oc = tid >> 5;                                // 32 threads per channel
-      for (int w = tid & 31; w < PO * PO; w += 32) {
-        const int64_t o = img * NPOOL + oc * (PO * PO) + w;
-        const float g = a.gp[o];
-        const int am = a.argin[o];
-        gb2 += g;
-        float* p = d_s + oc * CHD + (2 * (w / PO) + 2) * ROWD + 2 * (w % PO) + 2;
-        p[0] = am == 0 ? g : 0.f;
-        p[1] = am == 1 ? g : 0.f;
-        p[ROWD] = am == 2 ? g : 0.f;
-        p[ROWD + 1] = am == 3 ? g : 0.f;
+#pragma unroll
+      for (int k = 0; k < WPT; ++k) {
+        const int w = (tid & 31) + 32 * k;
+        if (w < PO * PO) {
+          const float g = gpre[k];
+          const int am = apre[k];
+          gb2 += g;
+          float* p = d_s + oc * CHD + (2 * (w / PO) + 2) * ROWD + 2 * (w % PO) + 2;
+          p[0] = am == 0 ? g : 0.f;
+          p[1] = am == 1 ? g : 0.f;
+          p[ROWD] = am == 2 ? g : 0.f;
+          p[ROWD + 1] = am == 3 ? g : 0.f;
+        }
       }
     }
     __syncthreads();
+    prefetch(img + gridDim.x);
     // ---- P1: recompute conv1 + ReLU
     conv1_tiles<NW>(e_s, a1_s, w1f, off1, b1v, wave, q, j);
     __syncthreads();
@@ -216,13 +276,14 @@ __global__ __launch_bounds__(64 * BWD_WAVES) void cnn_bwd_k(CnnArgs a) {
       for (int nt = 0; nt < 9; ++nt) gW2[nt] = mfma(av, bp[colo[nt]], gW2[nt]);
     }
     __syncthreads();                                           // a1 as im2col operand is done
-    // ---- P4: dpre1 = conv2^T(dY2) * (a1 > 0) on the 26x26 grid, 52 tiles (two in flight), written IN PLACE
-    //      over a1: element (ic,y,x) of a1 is read (ReLU gate) and overwritten by the same lane only
+    // ---- P4: dpre1 = conv2^T(dY2) * (a1 > 0) on the 26x26 grid, 43 tiles of 16 consecutive positions (two in
+    //      flight), written IN PLACE over a1: element (ic,y,x) is read (ReLU gate) and overwritten by one lane only
 #pragma nounroll
-    for (int t = wave; t < 52; t += 2 * NW) {
-      const int tB = t + NW < 52 ? t + NW : t;
-      const int yA = 2 * (t >> 2) + (j >> 3), xA = 8 * (t & 3) + (j & 7);
-      const int yB = 2 * (tB >> 2) + (j >> 3), xB = 8 * (tB & 3) + (j & 7);
+    for (int t = wave; t < 43; t += 2 * NW) {
+      const int tB = t + NW < 43 ? t + NW : t;
+      const int posA = 16 * t + j, posB = 16 * tB + j;
+      const int pcA = posA < C1 * C1 ? posA : 0, pcB = posB < C1 * C1 ? posB : 0;
+      const int yA = pcA / C1, xA = pcA - yA * C1, yB = pcB / C1, xB = pcB - yB * C1;
       const float* pA = d_s + q * CHD + (yA + 2) * ROWD + xA + 2;
       const float* pB = d_s + q * CHD + (yB + 2) * ROWD + xB + 2;
       f32x4 accA = f32x4{0.f, 0.f, 0.f, 0.f}, accB = accA;
@@ -236,14 +297,14 @@ __global__ __launch_bounds__(64 * BWD_WAVES) void cnn_bwd_k(CnnArgs a) {
             accA = mfma(w2t[g * 9 + ky * 3 + kx], pA[o], accA);
             accB = mfma(w2t[g * 9 + ky * 3 + kx], pB[o], accB);
           }
-      if (xA < C1) {
+      if (posA < C1 * C1) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           float* pa = a1_s + (4 * q + r) * CH + yA * ROW + xA;
           *pa = *pa > 0.f ? accA[r] : 0.f;
         }
       }
-      if (tB != t && xB < C1) {
+      if (tB != t && posB < C1 * C1) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           float* pa = a1_s + (4 * q + r) * CH + yB * ROW + xB;
@@ -253,16 +314,21 @@ __global__ __launch_bounds__(64 * BWD_WAVES) void cnn_bwd_k(CnnArgs a) {
     }
     __syncthreads();                                           // dpre1 complete; dY2 no longer needed
     // ---- P5a: dW1[oc][tap] += sum_pos dpre1[oc][pos] * e[pos + tap]; column 9 = ones -> db1.  704 = 8 x 88 positions
+    f32x4 gW1b = f32x4{0.f, 0.f, 0.f, 0.f};                       // second chain: hides the 40-cycle MFMA latency
 #pragma nounroll
-    for (int s = 0; s < 22; ++s) {
-      const int pos = 88 * wave + 4 * s + q;
-      const bool ok = pos < C1 * C1;
-      const int pc = ok ? pos : 0;
-      const int y = pc / C1, x = pc - y * C1;
-      const float av = ok ? a1_s[j * CH + y * ROW + x] : 0.f;
-      const float bv = j < 9 ? e_s[y * ROWE + x + tapo] : (j == 9 ? 1.f : 0.f);
-      gW1 = mfma(av, bv, gW1);
+    for (int s = 0; s < 22; s += 2) {
+#pragma unroll
+      for (int h2 = 0; h2 < 2; ++h2) {
+        const int pos = 88 * wave + 4 * (s + h2) + q;
+        const bool ok = pos < C1 * C1;
+        const int pc = ok ? pos : 0;
+        const int y = pc / C1, x = pc - y * C1;
+        const float av = ok ? a1_s[j * CH + y * ROW + x] : 0.f;
+        const float bv = j < 9 ? e_s[y * ROWE + x + tapo] : (j == 9 ? 1.f : 0.f);
+        if (h2) gW1b = mfma(av, bv, gW1b); else gW1 = mfma(av, bv, gW1);
+      }
     }
+    gW1 += gW1b;
     // ---- P5b: T[tap][pos] = sum_oc W1[oc][tap] * dpre1[oc][pos]  (43 position tiles), into the dY2 region
     float* T_s = d_s;
 #pragma nounroll

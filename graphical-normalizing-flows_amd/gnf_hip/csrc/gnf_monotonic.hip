@@ -285,10 +285,17 @@ __global__ __launch_bounds__(64 * kWaves) void mono_fwd_k(MonoArgs a) {
 // Backward chain kernel.  Vector gradients kept as per-lane partials over the wave's whole
 // persistent loop:  slot 0: d wL, 1: d w1x, 2+l: d b_l (l = 0..NH-1);  + scalar d bL.
 // ---------------------------------------------------------------------------------------
-template <int HT, int NH>
+template <int HT, int NH, bool WLDS>
 __global__ __launch_bounds__(64 * kWaves) void mono_bwd_k(MonoArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
   const MonoLayout& L = a.L;
   const float* wp = a.pack;
+  if (WLDS) {                                   // whole padded image (weights + transposes) LDS-resident
+    for (int i = threadIdx.x * 4; i < L.total_floats; i += blockDim.x * 4)
+      *reinterpret_cast<f32x4*>(smem + i) = ld4(a.pack + i);
+    __syncthreads();
+    wp = smem;
+  }
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int q = lane >> 4, j = lane & 15;
   const int HP = 16 * HT;
@@ -552,17 +559,30 @@ int launch_fwd(const MonoArgs& a, hipStream_t s) {
   return 0;
 }
 
-template <int HT>
-int launch_bwd_nh(const MonoArgs& a, unsigned grid, hipStream_t s) {
-  switch (a.L.NH) {
-    case 1: hipLaunchKernelGGL((mono_bwd_k<HT, 1>), dim3(grid), dim3(64 * kWaves), 0, s, a); break;
-    case 2: hipLaunchKernelGGL((mono_bwd_k<HT, 2>), dim3(grid), dim3(64 * kWaves), 0, s, a); break;
-    case 3: hipLaunchKernelGGL((mono_bwd_k<HT, 3>), dim3(grid), dim3(64 * kWaves), 0, s, a); break;
-    case 4: hipLaunchKernelGGL((mono_bwd_k<HT, 4>), dim3(grid), dim3(64 * kWaves), 0, s, a); break;
-    default: return GNF_ESHAPE;
+template <int HT, int NH>
+int launch_bwd_one(const MonoArgs& a, unsigned grid, hipStream_t s) {
+  const size_t lds = (size_t)a.L.total_floats * sizeof(float);
+  if constexpr (HT <= 4) {                      // larger images do not fit the 160 KiB LDS: weights stream from L2
+    if (lds > (size_t)150 * 1024) return GNF_ESHAPE;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mono_bwd_k<HT, NH, true>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL((mono_bwd_k<HT, NH, true>), dim3(grid), dim3(64 * kWaves), lds, s, a);
+  } else {
+    hipLaunchKernelGGL((mono_bwd_k<HT, NH, false>), dim3(grid), dim3(64 * kWaves), 0, s, a);
   }
   GNF_LAUNCH_CHECK();
   return 0;
+}
+
+template <int HT>
+int launch_bwd_nh(const MonoArgs& a, unsigned grid, hipStream_t s) {
+  switch (a.L.NH) {
+    case 1: return launch_bwd_one<HT, 1>(a, grid, s);
+    case 2: return launch_bwd_one<HT, 2>(a, grid, s);
+    case 3: return launch_bwd_one<HT, 3>(a, grid, s);
+    case 4: return launch_bwd_one<HT, 4>(a, grid, s);
+    default: return GNF_ESHAPE;
+  }
 }
 
 int launch_bwd(const MonoArgs& a, unsigned grid, hipStream_t s) {
