@@ -29,7 +29,7 @@ __global__ __launch_bounds__(256) void gemm_k(GemmArgs g) {
   __shared__ float Bs[BK][BN + PAD];
 
   const int tid = threadIdx.x;
-  const int lane = tid & 63, wave = tid >> 6;
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = (wave >> 1) * WM, wn = (wave & 1) * WN;
   const int64_t m0 = (int64_t)blockIdx.x * BM, n0 = (int64_t)blockIdx.y * BN;
   const int64_t kbeg = (int64_t)blockIdx.z * g.k_per_split;

@@ -74,7 +74,8 @@ __global__ __launch_bounds__(64 * FWD_WAVES) void cnn_fwd_k(CnnArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* e_s = smem;
   float* a1_s = smem + ESZ;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, q = lane >> 4, j = lane & 15;
+  const int tid = threadIdx.x, lane = tid & 63, q = lane >> 4, j = lane & 15;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // provably wave-uniform: scalar branches / SGPR math
 
   // weights as MFMA A operands (row i = j = output channel, K slot q), resident in registers
   float w1f[3];
@@ -165,12 +166,32 @@ __global__ __launch_bounds__(64 * FWD_WAVES) void cnn_fwd_k(CnnArgs a) {
   }
 }
 
+#ifdef GNF_CNN_TIMING
+#define TSTAMP(k) do { const long long t__ = __builtin_readcyclecounter(); tacc[k] += t__ - tlast; tlast = t__; } while (0)
+#else
+#define TSTAMP(k)
+#endif
+
+// dY2 planes: channel pairs sit PS dwords apart, the two channels of a pair CHD (== 16 mod 32) apart, so that
+//  - the dW2 A-operand read (16 channels x 2 consecutive positions per 32-lane group) and
+//  - the da1 B-operand gather (2 channels x 16 consecutive positions per 32-lane group)
+// are both bank-conflict free.
+constexpr int PS = 2 * CHD + 2;
+__device__ __forceinline__ int based(int c) { return (c >> 1) * PS + (c & 1) * CHD; }
+constexpr int DSZ = (NCH / 2) * PS;
+
 __global__ __launch_bounds__(64 * BWD_WAVES) void cnn_bwd_k(CnnArgs a) {
+#ifdef GNF_CNN_TIMING
+  long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  long long tlast = __builtin_readcyclecounter();
+#endif
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* e_s = smem;
-  float* a1_s = smem + ESZ;                 // conv1 activations, overwritten in place by dpre1
-  float* d_s = a1_s + NCH * CH;             // dY2 with zero border; later reused for the per-tap planes T
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, q = lane >> 4, j = lane & 15;
+  float* a1_s = smem + ESZ;            // conv1 activations; reused for the per-tap planes T after dW2
+  float* d_s = a1_s + NCH * CH;             // dY2 with a 2-wide zero border
+  float* T_s = a1_s;
+  const int tid = threadIdx.x, lane = tid & 63, q = lane >> 4, j = lane & 15;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // provably wave-uniform: scalar branches / SGPR math
   constexpr int NW = BWD_WAVES, NT = 64 * BWD_WAVES;
 
   float w1f[3];
@@ -191,10 +212,10 @@ __global__ __launch_bounds__(64 * BWD_WAVES) void cnn_bwd_k(CnnArgs a) {
   for (int g = 0; g < 4; ++g)
 #pragma unroll
     for (int k = 0; k < 9; ++k) w2t[g * 9 + k] = a.W2[((4 * g + q) * NCH + j) * 9 + k];
-  // W1^T as A operand of the per-tap planes: row i = j = tap, K slot q -> channel 4s+q
+  // W1^T as A operand of the per-tap planes: row i = j = tap, K slot q, step r -> channel 4q+r
   float w1t[4];
 #pragma unroll
-  for (int s = 0; s < 4; ++s) w1t[s] = j < 9 ? a.W1[(4 * s + q) * 9 + j] : 0.f;
+  for (int r = 0; r < 4; ++r) w1t[r] = j < 9 ? a.W1[(4 * q + r) * 9 + j] : 0.f;
   // per-lane column offsets of the im2col B operand of dW2: column c = 16 nt + j = ic*9 + ky*3 + kx
   int colo[9];
 #pragma unroll
@@ -202,15 +223,20 @@ __global__ __launch_bounds__(64 * BWD_WAVES) void cnn_bwd_k(CnnArgs a) {
     const int c = 16 * nt + j;
     colo[nt] = (c / 9) * CH + ((c % 9) / 3) * ROW + c % 3;
   }
-  const int tapo = j < 9 ? (j / 3) * ROWE + j % 3 : 0;       // B operand of dW1: e patch for tap j
 
-  f32x4 gW2[9], gW1 = f32x4{0.f, 0.f, 0.f, 0.f};
+  f32x4 gW2[9];
 #pragma unroll
   for (int nt = 0; nt < 9; ++nt) gW2[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  // dW1 / db1 as per-lane partials over this lane's positions: channel 4q+r, tap k (k = 9: bias)
+  float gW1p[4][10];
+#pragma unroll
+  for (int r = 0; r < 4; ++r)
+#pragma unroll
+    for (int k = 0; k < 10; ++k) gW1p[r][k] = 0.f;
   float gb2 = 0.f;                                           // thread tid accumulates channel tid/32
 
   for (int i = tid; i < ESZ; i += NT) e_s[i] = 0.f;
-  for (int i = tid; i < NCH * CHD; i += NT) d_s[i] = 0.f;
+  for (int i = tid; i < DSZ; i += NT) d_s[i] = 0.f;
 
   // software prefetch: the next image's pixels, pooled gradients and argmax bytes are loaded into
   // registers while the MFMA phases of the current image run
@@ -234,58 +260,105 @@ __global__ __launch_bounds__(64 * BWD_WAVES) void cnn_bwd_k(CnnArgs a) {
     }
   };
   prefetch(blockIdx.x);
+  int woff[WPT];                                            // this thread's pool windows: fixed LDS offsets
+#pragma unroll
+  for (int k = 0; k < WPT; ++k) {
+    const int w = (tid & 31) + 32 * k;
+    woff[k] = w < PO * PO ? based(tid >> 5) + (2 * (w / PO) + 2) * ROWD + 2 * (w % PO) + 2 : -1;
+  }
+  int eoff[EPT];
+#pragma unroll
+  for (int k = 0; k < EPT; ++k) {
+    const int i = tid + k * NT;
+    eoff[k] = i < IMG * IMG ? (i / IMG) * ROWE + i % IMG : -1;
+  }
 
   for (int64_t img = blockIdx.x; img < a.n; img += gridDim.x) {
     __syncthreads();
     // ---- P0: image, and dY2 = pool-backward scatter of g_pooled (one write per conv2 position)
 #pragma unroll
-    for (int k = 0; k < EPT; ++k) {
-      const int i = tid + k * NT;
-      if (i < IMG * IMG) e_s[(i / IMG) * ROWE + i % IMG] = epre[k];
-    }
-    {
-      const int oc = tid >> 5;                                // 32 threads per channel
+    for (int k = 0; k < EPT; ++k)
+      if (eoff[k] >= 0) e_s[eoff[k]] = epre[k];
 #pragma unroll
-      for (int k = 0; k < WPT; ++k) {
-        const int w = (tid & 31) + 32 * k;
-        if (w < PO * PO) {
-          const float g = gpre[k];
-          const int am = apre[k];
-          gb2 += g;
-          float* p = d_s + oc * CHD + (2 * (w / PO) + 2) * ROWD + 2 * (w % PO) + 2;
-          p[0] = am == 0 ? g : 0.f;
-          p[1] = am == 1 ? g : 0.f;
-          p[ROWD] = am == 2 ? g : 0.f;
-          p[ROWD + 1] = am == 3 ? g : 0.f;
-        }
+    for (int k = 0; k < WPT; ++k)
+      if (woff[k] >= 0) {
+        const float g = gpre[k];
+        const int am = apre[k];
+        gb2 += g;
+        float* p = d_s + woff[k];
+        p[0] = am == 0 ? g : 0.f;
+        p[1] = am == 1 ? g : 0.f;
+        p[ROWD] = am == 2 ? g : 0.f;
+        p[ROWD + 1] = am == 3 ? g : 0.f;
       }
-    }
     __syncthreads();
     prefetch(img + gridDim.x);
-    // ---- P1: recompute conv1 + ReLU
-    conv1_tiles<NW>(e_s, a1_s, w1f, off1, b1v, wave, q, j);
-    __syncthreads();
-    // ---- P3: dW2[oc][c] += sum_pos dY2[oc][pos] * a1[ic(c)][pos + tap(c)];  K = 576 positions, 72 per wave
-#pragma nounroll
-    for (int s = 0; s < 18; ++s) {
-      const int pos = 72 * wave + 4 * s + q;
-      const int y = pos / C2, x = pos - y * C2;
-      const float av = d_s[j * CHD + (y + 2) * ROWD + x + 2];
-      const float* bp = a1_s + y * ROW + x;
+    TSTAMP(0);
+    // ---- P1: recompute conv1 + ReLU (43 flat tiles in pairs: pair p = wave + 8k' owns tiles 2p, 2p+1); the ReLU gate
+    //      bits stay in registers: the da1 tiles below use the same tile -> lane mapping
+    unsigned gate = 0u;
+    {
+      int po[6];
+      f32x4 acc[6];
+      float ev[6][3];
 #pragma unroll
-      for (int nt = 0; nt < 9; ++nt) gW2[nt] = mfma(av, bp[colo[nt]], gW2[nt]);
+      for (int k = 0; k < 6; ++k) {                           // all operand reads first ...
+        const int pos = 16 * (2 * (wave + NW * (k >> 1)) + (k & 1)) + j;     // tile 2p + (k&1), pair p = wave + 8(k>>1)
+        const int pc = pos < C1 * C1 ? pos : 0;
+        const int y = pc / C1, x = pc - y * C1;
+        po[k] = pos < C1 * C1 ? y * ROW + x : -1;
+#pragma unroll
+        for (int s = 0; s < 3; ++s) ev[k][s] = e_s[y * ROWE + x + off1[s]];
+        acc[k] = b1v;
+      }
+#pragma unroll
+      for (int s = 0; s < 3; ++s)                             // ... then 6 independent MFMA chains
+#pragma unroll
+        for (int k = 0; k < 6; ++k) acc[k] = mfma(w1f[s], ev[k][s], acc[k]);
+#pragma unroll
+      for (int k = 0; k < 6; ++k)
+        if (po[k] >= 0) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            a1_s[(4 * q + r) * CH + po[k]] = fmaxf(acc[k][r], 0.f);
+            if (acc[k][r] > 0.f) gate |= 1u << (4 * k + r);
+          }
+        }
     }
-    __syncthreads();                                           // a1 as im2col operand is done
-    // ---- P4: dpre1 = conv2^T(dY2) * (a1 > 0) on the 26x26 grid, 43 tiles of 16 consecutive positions (two in
-    //      flight), written IN PLACE over a1: element (ic,y,x) is read (ReLU gate) and overwritten by one lane only
+    __syncthreads();
+    TSTAMP(1);
+    // ---- P3: dW2[oc][c] += sum_pos dY2[oc][pos] * a1[ic(c)][pos + tap(c)];  K = 576 positions, 72 (3 rows) per wave.
+    //      K slots of one 32-lane group are columns x and x+3: their im2col gathers (kx = 0..2) hit disjoint banks.
+    {
+      // K slot q covers column xs + 3(q&1) + 12(q>>1): the lane-dependent part folds into per-lane base
+      // pointers, the step-dependent part (row s/6, xs in {0,1,2,6,7,8}) is an immediate offset -> no VALU
+      // address arithmetic inside the 18 unrolled steps.
+      const int lq = 3 * (q & 1) + 12 * (q >> 1);
+      const float* ap = d_s + based(j) + (3 * wave + 2) * ROWD + lq + 2;
+      const float* bp = a1_s + 3 * wave * ROW + lq;
+#pragma unroll
+      for (int s = 0; s < 18; ++s) {
+        const int xs = (s % 6) < 3 ? (s % 6) : (s % 6) + 3;
+        const float av = ap[(s / 6) * ROWD + xs];
+#pragma unroll
+        for (int nt = 0; nt < 9; ++nt) gW2[nt] = mfma(av, bp[(s / 6) * ROW + xs + colo[nt]], gW2[nt]);
+      }
+    }
+    __syncthreads();                                           // a1 as im2col operand is done: region becomes T
+    TSTAMP(2);
+    // ---- P4: dpre1 = conv2^T(dY2) * gate on the 26x26 grid (same tile pairs, both tiles in flight).  Epilogue on the
+    //      VALU, straight from the accumulator registers: dW1/db1 partials and the per-tap planes
+    //      T[tap][pos] = sum_oc W1[oc][tap] dpre1[oc][pos] (lane sum over its 4 channels, then over the 4 lane slots)
 #pragma nounroll
-    for (int t = wave; t < 43; t += 2 * NW) {
-      const int tB = t + NW < 43 ? t + NW : t;
-      const int posA = 16 * t + j, posB = 16 * tB + j;
-      const int pcA = posA < C1 * C1 ? posA : 0, pcB = posB < C1 * C1 ? posB : 0;
+    for (int kk = 0; kk < 3; ++kk) {
+      const int tA = 2 * (wave + NW * kk);
+      if (tA >= 43) break;                                      // wave-uniform (scalar): waves 6,7 own two pairs
+      const int posA = 16 * tA + j, posB = posA + 16;
+      const bool okA = posA < C1 * C1, okB = posB < C1 * C1;
+      const int pcA = okA ? posA : 0, pcB = okB ? posB : 0;
       const int yA = pcA / C1, xA = pcA - yA * C1, yB = pcB / C1, xB = pcB - yB * C1;
-      const float* pA = d_s + q * CHD + (yA + 2) * ROWD + xA + 2;
-      const float* pB = d_s + q * CHD + (yB + 2) * ROWD + xB + 2;
+      const float* pA = d_s + based(q) + (yA + 2) * ROWD + xA + 2;
+      const float* pB = d_s + based(q) + (yB + 2) * ROWD + xB + 2;
       f32x4 accA = f32x4{0.f, 0.f, 0.f, 0.f}, accB = accA;
 #pragma unroll
       for (int g = 0; g < 4; ++g)
@@ -293,61 +366,37 @@ __global__ __launch_bounds__(64 * BWD_WAVES) void cnn_bwd_k(CnnArgs a) {
         for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
           for (int kx = 0; kx < 3; ++kx) {
-            const int o = 4 * g * CHD - ky * ROWD - kx;
+            const int o = g * 2 * PS - ky * ROWD - kx;
             accA = mfma(w2t[g * 9 + ky * 3 + kx], pA[o], accA);
-            accB = mfma(w2t[g * 9 + ky * 3 + kx], pB[o], accB);
+            accB = mfma(w2t[g * 9 + ky * 3 + kx], pB[o], accB);     // tile 43 does not exist: masked below
           }
-      if (posA < C1 * C1) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          float* pa = a1_s + (4 * q + r) * CH + yA * ROW + xA;
-          *pa = *pa > 0.f ? accA[r] : 0.f;
+      for (int half = 0; half < 2; ++half) {
+        const bool ok = half ? okB : okA;
+        const int y = half ? yB : yA, x = half ? xB : xA, pos = half ? posB : posA;
+        f32x4 dp = half ? accB : accA;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) dp[r] = (ok && ((gate >> (8 * kk + 4 * half + r)) & 1u)) ? dp[r] : 0.f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) gW1p[r][9] += dp[r];
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+          const float ev = e_s[(y + tap / 3) * ROWE + x + tap % 3];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) gW1p[r][tap] = fmaf(dp[r], ev, gW1p[r][tap]);
         }
-      }
-      if (tB != t && posB < C1 * C1) {
+        // T = W1^T[tap x oc] * dpre1[oc x pos]: dpre1 in the C/D layout IS the B operand (K slot q, step r -> oc 4q+r)
+        f32x4 tt = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          float* pa = a1_s + (4 * q + r) * CH + yB * ROW + xB;
-          *pa = *pa > 0.f ? accB[r] : 0.f;
-        }
-      }
-    }
-    __syncthreads();                                           // dpre1 complete; dY2 no longer needed
-    // ---- P5a: dW1[oc][tap] += sum_pos dpre1[oc][pos] * e[pos + tap]; column 9 = ones -> db1.  704 = 8 x 88 positions
-    f32x4 gW1b = f32x4{0.f, 0.f, 0.f, 0.f};                       // second chain: hides the 40-cycle MFMA latency
-#pragma nounroll
-    for (int s = 0; s < 22; s += 2) {
+        for (int r = 0; r < 4; ++r) tt = mfma(w1t[r], dp[r], tt);
+        // branch-free store: lanes without a valid (tap, pos) write to a scratch word behind the planes
 #pragma unroll
-      for (int h2 = 0; h2 < 2; ++h2) {
-        const int pos = 88 * wave + 4 * (s + h2) + q;
-        const bool ok = pos < C1 * C1;
-        const int pc = ok ? pos : 0;
-        const int y = pc / C1, x = pc - y * C1;
-        const float av = ok ? a1_s[j * CH + y * ROW + x] : 0.f;
-        const float bv = j < 9 ? e_s[y * ROWE + x + tapo] : (j == 9 ? 1.f : 0.f);
-        if (h2) gW1b = mfma(av, bv, gW1b); else gW1 = mfma(av, bv, gW1);
-      }
-    }
-    gW1 += gW1b;
-    // ---- P5b: T[tap][pos] = sum_oc W1[oc][tap] * dpre1[oc][pos]  (43 position tiles), into the dY2 region
-    float* T_s = d_s;
-#pragma nounroll
-    for (int t = wave; t < 43; t += NW) {
-      const int pos = 16 * t + j;
-      const int pc = pos < C1 * C1 ? pos : 0;
-      const int y = pc / C1, x = pc - y * C1;
-      const float* bp = a1_s + q * CH + y * ROW + x;
-      f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int s = 0; s < 4; ++s) acc = mfma(w1t[s], bp[4 * s * CH], acc);
-      if (pos < C1 * C1) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-          if (4 * q + r < 9) T_s[(4 * q + r) * CS + pos] = acc[r];
+        for (int r = 0; r < 4; ++r) T_s[(ok && 4 * q + r < 9) ? (4 * q + r) * CS + pos : 9 * CS + lane] = tt[r];
       }
     }
     __syncthreads();
-    // de[y][x] = sum_tap T[tap][y-ky][x-kx]
+    TSTAMP(3);
+    // ---- de[y][x] = sum_tap T[tap][y-ky][x-kx]
     for (int i = tid; i < IMG * IMG; i += NT) {
       const int y = i / IMG, x = i - y * IMG;
       float s = 0.f;
@@ -360,10 +409,12 @@ __global__ __launch_bounds__(64 * BWD_WAVES) void cnn_bwd_k(CnnArgs a) {
         }
       a.ge[img * (IMG * IMG) + i] = s;
     }
-    // restore the zero border of dY2 that T overwrote (the interior is rewritten by the next P0)
-    __syncthreads();
-    for (int i = tid; i < 9 * CS; i += NT) d_s[i] = 0.f;
+    TSTAMP(4);
   }
+#ifdef GNF_CNN_TIMING
+  if (blockIdx.x == 7 && (tid & 63) == 0)
+    for (int k = 0; k < 6; ++k) a.part[((int64_t)gridDim.x * NW + 1) * PROW + wave * 8 + k] = (float)tacc[k];
+#endif
 
   // ---- per-wave partial row: dW2 [16][144] | dW1+db1 [16][16] | db2 [16]
   float* prow = a.part + ((int64_t)blockIdx.x * NW + wave) * PROW;
@@ -372,7 +423,19 @@ __global__ __launch_bounds__(64 * BWD_WAVES) void cnn_bwd_k(CnnArgs a) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) prow[(4 * q + r) * 144 + 16 * nt + j] = gW2[nt][r];
 #pragma unroll
-  for (int r = 0; r < 4; ++r) prow[NCH * 144 + (4 * q + r) * 16 + j] = gW1[r];
+  for (int r = 0; r < 4; ++r)
+#pragma unroll
+    for (int k = 0; k < 10; ++k) {
+      float v = gW1p[r][k];                                    // sum over the 16 position lanes
+      v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 8, 64);
+      if (j == 0) prow[NCH * 144 + (4 * q + r) * 16 + k] = v;
+    }
+  if (j == 0) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int k = 10; k < 16; ++k) prow[NCH * 144 + (4 * q + r) * 16 + k] = 0.f;
+  }
 #pragma unroll
   for (int off = 16; off > 0; off >>= 1) gb2 += __shfl_xor(gb2, off, 64);    // over the 32 threads of a channel
   // wave w owns channels 2w, 2w+1 (lanes 0 and 32); the other 14 db2 slots of its row are zero
@@ -394,7 +457,7 @@ __global__ void cnn_unpack_k(const float* __restrict__ vec, float* gW1, float* g
 }
 
 constexpr size_t kFwdLds = (size_t)(ESZ + NCH * CH) * sizeof(float);
-constexpr size_t kBwdLds = (size_t)(ESZ + NCH * CH + NCH * CHD) * sizeof(float);
+constexpr size_t kBwdLds = (size_t)(ESZ + NCH * CH + DSZ) * sizeof(float);
 constexpr unsigned kFwdGrid = 512, kBwdGrid = 256;
 
 }  // namespace
@@ -417,7 +480,7 @@ int gnf_mnistcnn_conv_fwd(const float* e, const float* W1, const float* b1, cons
 
 int64_t gnf_mnistcnn_conv_bwd_ws_bytes(int64_t n_img) {
   (void)n_img;
-  return ((int64_t)kBwdGrid * BWD_WAVES + 1) * PROW * (int64_t)sizeof(float);
+  return ((int64_t)kBwdGrid * BWD_WAVES + 2) * PROW * (int64_t)sizeof(float);
 }
 
 int gnf_mnistcnn_conv_bwd(const float* e, const float* W1, const float* b1, const float* W2, const float* g_pooled,

@@ -244,7 +244,7 @@ __global__ __launch_bounds__(64 * kWaves) void mono_fwd_k(MonoArgs a) {
     __syncthreads();
     wp = smem;
   }
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int q = lane >> 4, j = lane & 15;
   const int64_t ngroups = (a.n + 15) / 16;
   const float fS = (float)a.S;
@@ -296,7 +296,7 @@ __global__ __launch_bounds__(64 * kWaves) void mono_bwd_k(MonoArgs a) {
     __syncthreads();
     wp = smem;
   }
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int q = lane >> 4, j = lane & 15;
   const int HP = 16 * HT;
   const int64_t ngroups = (a.ecount + 15) / 16;
