@@ -46,3 +46,7 @@ __device__ __forceinline__ float u01_24(uint32_t r) { return (float)(r >> 8) * (
 
 // out[n] (+)= sum_{p<P} src[p*N + n]   (gnf_rowwise.hip; deterministic order)
 int gnf_rowsum_launch(const float* src, float* out, int64_t P, int64_t N, int accumulate, hipStream_t s);
+// same for tall inputs: two-level, ws >= kRowsumChunks*N floats
+constexpr int kRowsumChunks = 1024;
+int gnf_rowsum_tall_launch(const float* src, float* out, int64_t P, int64_t N, int accumulate, float* ws,
+                           hipStream_t s);

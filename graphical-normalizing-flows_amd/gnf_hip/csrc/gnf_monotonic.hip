@@ -302,14 +302,19 @@ __global__ __launch_bounds__(64 * kWaves) void mono_bwd_k(MonoArgs a) {
   const int64_t ngroups = (a.ecount + 15) / 16;
   const float fS = (float)a.S;
 
-  f32x4 p_wL[HT], p_w1x[HT], p_b[NH][HT];
+  // bias gradients: per-lane register partials for small nets; for wide nets (register pressure) they are
+  // column sums of the staged dpre / Dsum arrays, taken by the host-side row-sum launches instead
+  constexpr bool BREG = HT <= 4;
+  f32x4 p_wL[HT], p_w1x[HT], p_b[BREG ? NH : 1][BREG ? HT : 1];
   float p_bL = 0.f;
 #pragma unroll
   for (int t = 0; t < HT; ++t) {
     p_wL[t] = f32x4{0.f, 0.f, 0.f, 0.f};
     p_w1x[t] = p_wL[t];
+    if constexpr (BREG) {
 #pragma unroll
-    for (int l = 0; l < NH; ++l) p_b[l][t] = p_wL[t];
+      for (int l = 0; l < NH; ++l) p_b[l][t] = p_wL[t];
+    }
   }
 
   for (int64_t grp = (int64_t)blockIdx.x * kWaves + wave; grp < ngroups; grp += (int64_t)gridDim.x * kWaves) {
@@ -360,13 +365,16 @@ __global__ __launch_bounds__(64 * kWaves) void mono_bwd_k(MonoArgs a) {
 #pragma unroll
         for (int mt = 0; mt < HT; ++mt) o[mt] = ld4(wp + L.o_b[l] + 16 * mt + 4 * q);
 #pragma unroll
-        for (int t = 0; t < HT; ++t)
+        for (int t = 0; t < HT; ++t) {
 #pragma unroll
           for (int mt = 0; mt < HT; ++mt) {
             const f32x4 A = ld4(W + (16 * mt + j) * L.LDW + 16 * t + 4 * q);
 #pragma unroll
             for (int r = 0; r < 4; ++r) o[mt] = mfma(A[r], act[t][r], o[mt]);
           }
+          // wide nets: keep the scheduler from hoisting all HT^2 weight fragments (400+ VGPRs) at once
+          if constexpr (WLDS) __builtin_amdgcn_sched_barrier(0);   // LDS-resident weights: bound the fragment hoisting (no spills)
+        }
         msk[l] = 0ull;
 #pragma unroll
         for (int t = 0; t < HT; ++t)
@@ -377,12 +385,11 @@ __global__ __launch_bounds__(64 * kWaves) void mono_bwd_k(MonoArgs a) {
           }
       }
       float s = 0.f;
-      f32x4 wl[HT];
 #pragma unroll
       for (int t = 0; t < HT; ++t) {
-        wl[t] = ld4(wp + L.o_wL + 16 * t + 4 * q);
+        const f32x4 wl = ld4(wp + L.o_wL + 16 * t + 4 * q);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) s = fmaf(wl[t][r], act[t][r], s);
+        for (int r = 0; r < 4; ++r) s = fmaf(wl[r], act[t][r], s);
       }
       s = qsum(s) + wp[L.o_bL];
       const float f = elu_plus(s);
@@ -393,12 +400,14 @@ __global__ __launch_bounds__(64 * kWaves) void mono_bwd_k(MonoArgs a) {
       if (q == 0) p_bL += dpl;
       f32x4 dp[HT];
 #pragma unroll
-      for (int t = 0; t < HT; ++t)
+      for (int t = 0; t < HT; ++t) {
+        const f32x4 wl = ld4(wp + L.o_wL + 16 * t + 4 * q);     // re-read (L1/LDS hit) rather than held across the node
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           p_wL[t][r] = fmaf(dpl, act[t][r], p_wL[t][r]);
-          dp[t][r] = ((msk[NH - 1] >> (4 * t + r)) & 1ull) ? wl[t][r] * dpl : 0.f;
+          dp[t][r] = ((msk[NH - 1] >> (4 * t + r)) & 1ull) ? wl[r] * dpl : 0.f;
         }
+      }
       // ---- hidden->hidden layers, top down
 #pragma unroll
       for (int l = NH - 1; l >= 1; --l) {
@@ -406,20 +415,22 @@ __global__ __launch_bounds__(64 * kWaves) void mono_bwd_k(MonoArgs a) {
 #pragma unroll
         for (int t = 0; t < HT; ++t) {
           *reinterpret_cast<f32x4*>(sd + 16 * t) = dp[t];
-          p_b[l][t] += dp[t];
+          if constexpr (BREG) p_b[l][t] += dp[t];
         }
         const float* WT = wp + L.o_WT[l];
         f32x4 da[HT];
 #pragma unroll
         for (int mt = 0; mt < HT; ++mt) da[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int t = 0; t < HT; ++t)
+        for (int t = 0; t < HT; ++t) {
 #pragma unroll
           for (int mt = 0; mt < HT; ++mt) {
             const f32x4 A = ld4(WT + (16 * mt + j) * L.LDW + 16 * t + 4 * q);
 #pragma unroll
             for (int r = 0; r < 4; ++r) da[mt] = mfma(A[r], dp[t][r], da[mt]);
           }
+          if constexpr (WLDS) __builtin_amdgcn_sched_barrier(0);   // LDS-resident weights: bound the fragment hoisting (no spills)
+        }
 #pragma unroll
         for (int t = 0; t < HT; ++t)
 #pragma unroll
@@ -444,7 +455,7 @@ __global__ __launch_bounds__(64 * kWaves) void mono_bwd_k(MonoArgs a) {
     float* ds = a.Dsum + (grp * 16 + j) * HP + 4 * q;
 #pragma unroll
     for (int t = 0; t < HT; ++t) {
-      p_b[0][t] += Ds[t];
+      if constexpr (BREG) p_b[0][t] += Ds[t];
       *reinterpret_cast<f32x4*>(ds + 16 * t) = Ds[t];
     }
     if (valid && q == 0 && a.gx) a.gx[e] = dx;
@@ -480,8 +491,12 @@ __global__ __launch_bounds__(64 * kWaves) void mono_bwd_k(MonoArgs a) {
       if (j == 0) prow[HP + hid] = v;
 #pragma unroll
       for (int l = 0; l < NH; ++l) {
-        v = jsum(p_b[l][t][r]);
-        if (j == 0) prow[(2 + l) * HP + hid] = v;
+        if constexpr (BREG) {
+          v = jsum(p_b[l][t][r]);
+          if (j == 0) prow[(2 + l) * HP + hid] = v;
+        } else {
+          if (j == 0) prow[(2 + l) * HP + hid] = 0.f;
+        }
       }
     }
   const float vbl = jsum(p_bL);
@@ -537,9 +552,10 @@ int launch_fwd(const MonoArgs& a, hipStream_t s) {
   const int HT = a.L.HT;
   const int64_t ngroups = (a.n + 15) / 16;
   int64_t grid = (ngroups + kWaves - 1) / kWaves;
-  if (grid > 256 * 2) grid = 256 * 2;            // persistent: <= 2 workgroups per CU
   const size_t lds = (size_t)a.L.fwd_floats * sizeof(float);
-  const bool wlds = lds <= (size_t)kLdsBudget / 2;   // two workgroups per CU keep their own copy
+  const bool wlds = lds <= (size_t)150 * 1024;                       // else: weight fragments stream from L1/L2
+  const int64_t per_cu = (wlds && lds > (size_t)kLdsBudget / 2) ? 1 : 2;   // resident workgroups per CU
+  if (grid > 256 * per_cu) grid = 256 * per_cu;                      // persistent
 #define GNF_FWD_CASE(HT_)                                                                                     \
   case HT_:                                                                                                  \
     if (wlds) {                                                                                              \
@@ -602,7 +618,7 @@ constexpr int64_t kWsTarget = 6ll << 30;      // staging budget the ws_bytes que
 
 struct BwdPlan {
   int64_t chunk_elems;      // elements per chain-kernel launch (multiple of 16)
-  int64_t o_SA[kMaxNH], o_SD[kMaxNH], o_Dsum, o_part, o_gpart[kMaxNH], o_hpart, o_dW[kMaxNH], o_dW1h, o_vec;
+  int64_t o_SA[kMaxNH], o_SD[kMaxNH], o_Dsum, o_part, o_gpart[kMaxNH], o_hpart, o_dW[kMaxNH], o_dW1h, o_vec, o_rs;
   int64_t total_floats;
 };
 
@@ -617,6 +633,7 @@ BwdPlan plan_bwd(const MonoLayout& L, int S, int64_t n, int64_t ws_floats) {
   for (int l = 1; l < L.NH; ++l) { P.o_dW[l] = fixed; fixed += HP * HP; }
   P.o_dW1h = fixed; fixed += HP * L.c;
   P.o_vec = fixed; fixed += vecw;
+  P.o_rs = fixed; fixed += (int64_t)kRowsumChunks * HP;     // scratch of the tall row-sums (bias gradients)
   const int64_t per_elem = (int64_t)(L.NH - 1) * 2 * NK * HP + HP;     // SA+SD per hidden layer, Dsum
   int64_t ce = (n + 15) / 16 * 16;
   if (ws_floats > 0) {
@@ -757,6 +774,11 @@ int gnf_monotonic_bwd(const float* pack, const gnf_mono_net* net, const float* x
       if ((rc = gnf_gemm_launch(g, ck == 0 ? kSplits : (int)nsp_h, s))) return rc;
     }
     if ((rc = rowsum(a.part, w + P.o_vec, part_rows, vecw, ck > 0))) return rc;
+    if (HT > 4) {                      // bias gradients of wide nets: column sums of the staged arrays
+      if ((rc = gnf_rowsum_tall_launch(a.Dsum, w + P.o_vec + 2 * HP, groups * 16, HP, 1, w + P.o_rs, s))) return rc;
+      for (int l = 1; l < NH; ++l)
+        if ((rc = gnf_rowsum_tall_launch(a.SD[l], w + P.o_vec + (2 + l) * HP, rows, HP, 1, w + P.o_rs, s))) return rc;
+    }
   }
   UnpackArgs u{};
   u.net = *net; u.L = L;

@@ -173,11 +173,19 @@ __global__ void adam_k(float* __restrict__ p, const float* __restrict__ g, float
 
 // out[n] (+)= sum_p src[p*N + n]: 64 columns per block, 16 wavefronts stride over the rows
 // (coalesced 256-B row segments), fixed-order LDS tree across the wavefronts -> deterministic.
+// blockIdx.y selects a chunk of `rpc` rows (tall inputs: first level of a two-level reduction); the chunk's
+// result goes to out + blockIdx.y*N.
 __global__ __launch_bounds__(1024) void rowsum_k(const float* __restrict__ src, float* __restrict__ out, int64_t P,
-                                                 int64_t N, int accumulate) {
+                                                 int64_t N, int accumulate, int64_t rpc) {
   __shared__ float red[16][64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int64_t n = (int64_t)blockIdx.x * 64 + lane;
+  src += (int64_t)blockIdx.y * rpc * N;
+  out += (int64_t)blockIdx.y * N;
+  {
+    const int64_t left = P - (int64_t)blockIdx.y * rpc;
+    P = left < rpc ? left : rpc;
+  }
   float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
   if (n < N) {
     int64_t p = wave;
@@ -207,9 +215,22 @@ inline unsigned grid_1d(int64_t n) {
 
 int gnf_rowsum_launch(const float* src, float* out, int64_t P, int64_t N, int accumulate, hipStream_t s) {
   if (N <= 0) return 0;
-  hipLaunchKernelGGL(rowsum_k, dim3((unsigned)((N + 63) / 64)), dim3(1024), 0, s, src, out, P, N, accumulate);
+  hipLaunchKernelGGL(rowsum_k, dim3((unsigned)((N + 63) / 64), 1), dim3(1024), 0, s, src, out, P, N, accumulate,
+                     P > 0 ? P : 1);
   GNF_LAUNCH_CHECK();
   return 0;
+}
+
+// tall inputs (P >> N): kRowsumChunks partial rows in ws (kRowsumChunks*N floats), then the plain row-sum
+int gnf_rowsum_tall_launch(const float* src, float* out, int64_t P, int64_t N, int accumulate, float* ws,
+                           hipStream_t s) {
+  if (N <= 0) return 0;
+  if (P <= 8192 || !ws) return gnf_rowsum_launch(src, out, P, N, accumulate, s);
+  const int64_t rpc = (P + kRowsumChunks - 1) / kRowsumChunks;
+  const int64_t nch = (P + rpc - 1) / rpc;
+  hipLaunchKernelGGL(rowsum_k, dim3((unsigned)((N + 63) / 64), (unsigned)nch), dim3(1024), 0, s, src, ws, P, N, 0, rpc);
+  GNF_LAUNCH_CHECK();
+  return gnf_rowsum_launch(ws, out, nch, N, accumulate, s);
 }
 
 extern "C" {
