@@ -136,6 +136,164 @@ __global__ __launch_bounds__(256) void gemm_k(GemmArgs g) {
 }
 
 
+// ---------------------------------------------------------------------------------------------
+// Vectorised variant for operands whose contiguous dimension is 16-B aligned (every hot shape of
+// the flows): 128-bit global loads, K-slab 32.  A k-contiguous operand is staged row-major
+// [rows][32+1] (odd stride: conflict-free fragment reads and scattered writes), a row-contiguous one
+// k-major [32][rows+4] with ds_write_b128.  Same MFMA tiling and epilogue as gemm_k.
+// ---------------------------------------------------------------------------------------------
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+constexpr int BKV = 32;
+
+template <int BX, bool KF>
+struct Slab {            // staging of one operand: BX rows/cols x 32 k
+  static constexpr int NV = BX * BKV / 4 / 256;                       // float4 per thread
+  static constexpr int SZ = KF ? BX * (BKV + 1) : BKV * (BX + 4);
+  // coordinates of this thread's it-th float4: x = row/col inside the tile, k inside the slab
+  static __device__ __forceinline__ void coord(int tid, int it, int& x, int& k) {
+    const int idx = tid + it * 256;
+    if (KF) { x = idx / (BKV / 4); k = 4 * (idx % (BKV / 4)); }
+    else { x = 4 * (idx % (BX / 4)); k = idx / (BX / 4); }
+  }
+  static __device__ __forceinline__ f32x4v load(const float* __restrict__ P, const float* __restrict__ Mk,
+                                                 int64_t sx, int64_t sk, int64_t gx, int64_t gk, int64_t X,
+                                                 int64_t kend) {
+    f32x4v v = {0.f, 0.f, 0.f, 0.f};
+    if (KF) {
+      if (gx < X) {
+        const int64_t o = gx * sx + gk;
+        if (gk + 3 < kend) {
+          v = *reinterpret_cast<const f32x4v*>(P + o);
+          if (Mk) v *= *reinterpret_cast<const f32x4v*>(Mk + o);
+        } else {
+#pragma unroll
+          for (int c = 0; c < 4; ++c)
+            if (gk + c < kend) v[c] = Mk ? P[o + c] * Mk[o + c] : P[o + c];
+        }
+      }
+    } else {
+      if (gk < kend) {
+        const int64_t o = gk * sk + gx;
+        if (gx + 3 < X) {
+          v = *reinterpret_cast<const f32x4v*>(P + o);
+          if (Mk) v *= *reinterpret_cast<const f32x4v*>(Mk + o);
+        } else {
+#pragma unroll
+          for (int c = 0; c < 4; ++c)
+            if (gx + c < X) v[c] = Mk ? P[o + c] * Mk[o + c] : P[o + c];
+        }
+      }
+    }
+    return v;
+  }
+  static __device__ __forceinline__ void store(float* S, int x, int k, const f32x4v& v) {
+    if (KF) {
+#pragma unroll
+      for (int c = 0; c < 4; ++c) S[x * (BKV + 1) + k + c] = v[c];
+    } else {
+      *reinterpret_cast<f32x4v*>(S + k * (BX + 4) + x) = v;
+    }
+  }
+  static __device__ __forceinline__ float frag(const float* S, int x, int k) {
+    return KF ? S[x * (BKV + 1) + k] : S[k * (BX + 4) + x];
+  }
+};
+
+template <int BM, int BN, bool AKF, bool BKF>
+__global__ __launch_bounds__(256) void gemm_vec_k(GemmArgs g) {
+  constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 32, TN = WN / 32;
+  using SA = Slab<BM, AKF>;
+  using SB = Slab<BN, BKF>;
+  __shared__ __attribute__((aligned(16))) float As[SA::SZ];
+  __shared__ __attribute__((aligned(16))) float Bs[SB::SZ];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = (wave >> 1) * WM, wn = (wave & 1) * WN;
+  const int64_t m0 = (int64_t)blockIdx.x * BM, n0 = (int64_t)blockIdx.y * BN;
+  const int64_t kbeg = (int64_t)blockIdx.z * g.k_per_split;
+  const int64_t kend = kbeg + g.k_per_split < g.K ? kbeg + g.k_per_split : g.K;
+  float* __restrict__ Cz = g.C + (int64_t)blockIdx.z * g.c_split_stride;
+
+  f32x4v ra[SA::NV], rb[SB::NV];
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  auto load_tile = [&](int64_t k0) {
+#pragma unroll
+    for (int it = 0; it < SA::NV; ++it) {
+      int x, k;
+      SA::coord(tid, it, x, k);
+      ra[it] = SA::load(g.A, nullptr, g.sam, g.sak, m0 + x, k0 + k, g.M, kend);
+    }
+#pragma unroll
+    for (int it = 0; it < SB::NV; ++it) {
+      int x, k;
+      SB::coord(tid, it, x, k);
+      rb[it] = SB::load(g.B, g.Bmask, g.sbn, g.sbk, n0 + x, k0 + k, g.N, kend);
+    }
+  };
+  auto store_tile = [&]() {
+#pragma unroll
+    for (int it = 0; it < SA::NV; ++it) {
+      int x, k;
+      SA::coord(tid, it, x, k);
+      SA::store(As, x, k, ra[it]);
+    }
+#pragma unroll
+    for (int it = 0; it < SB::NV; ++it) {
+      int x, k;
+      SB::coord(tid, it, x, k);
+      SB::store(Bs, x, k, rb[it]);
+    }
+  };
+
+  const int fi = lane & 31, fk = lane >> 5;
+  load_tile(kbeg);
+  for (int64_t k0 = kbeg; k0 < kend; k0 += BKV) {
+    __syncthreads();
+    store_tile();
+    __syncthreads();
+    if (k0 + BKV < kend) load_tile(k0 + BKV);
+#pragma unroll
+    for (int ks = 0; ks < BKV / 2; ++ks) {
+      float af[TM], bf[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) af[i] = SA::frag(As, wm + 32 * i + fi, 2 * ks + fk);
+#pragma unroll
+      for (int j = 0; j < TN; ++j) bf[j] = SB::frag(Bs, wn + 32 * j + fi, 2 * ks + fk);
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i], bf[j], acc[i][j], 0, 0, 0);
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int64_t n = n0 + wn + 32 * j + fi;
+      if (n >= g.N) continue;
+      const float bv = g.bias ? g.bias[n] : 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int64_t m = m0 + wm + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * fk;
+        if (m >= g.M) continue;
+        float v = acc[i][j][r] + bv;
+        if (g.Cmask) v *= g.Cmask[m * g.scmm + n * g.scmn];
+        if (g.flags & GNF_GEMM_RELU) v = fmaxf(v, 0.f);
+        if (g.gate) v = g.gate[m * g.sgm + n * g.sgn] > 0.f ? v : 0.f;
+        float* cp = Cz + m * g.scm + n * g.scn;
+        *cp = (g.flags & GNF_GEMM_ACCUM) ? *cp + v : v;
+      }
+    }
+}
+
 // split-K epilogue: C = epi(sum_z partial[z]) with the same options as the fused epilogue
 __global__ void gemm_reduce_k(const float* __restrict__ part, int64_t nsp, GemmArgs g) {
   const int64_t total = g.M * g.N;
@@ -156,8 +314,8 @@ __global__ void gemm_reduce_k(const float* __restrict__ part, int64_t nsp, GemmA
 
 static int64_t k_per_split(int64_t K, int splits) {
   if (splits < 1) splits = 1;
-  int64_t kps = ((K + splits - 1) / splits + BK - 1) / BK * BK;
-  return kps < BK ? BK : kps;
+  int64_t kps = ((K + splits - 1) / splits + BKV - 1) / BKV * BKV;
+  return kps < BKV ? BKV : kps;
 }
 
 int64_t gnf_gemm_num_splits(int64_t K, int splits) {
@@ -176,8 +334,26 @@ int gnf_gemm_launch(GemmArgs g, int splits, hipStream_t s) {
   const int64_t gx = (g.M + bt - 1) / bt, gy = (g.N + bt - 1) / bt;
   if (gy > 65535 || nsp > 65535) return GNF_ESHAPE;
   const dim3 grid((unsigned)gx, (unsigned)gy, (unsigned)nsp);
-  if (bt == 128) hipLaunchKernelGGL((gemm_k<128, 128>), grid, dim3(256), 0, s, g);
-  else hipLaunchKernelGGL((gemm_k<64, 64>), grid, dim3(256), 0, s, g);
+  // vector path: contiguous dimension of A and B (and the weight mask) 16-B aligned
+  auto al16 = [](const void* p) { return p == nullptr || ((uintptr_t)p & 15) == 0; };
+  const bool akf = g.sak == 1 && g.sam % 4 == 0, amf = g.sam == 1 && g.sak % 4 == 0;
+  const bool bkf = g.sbk == 1 && g.sbn % 4 == 0, bnf = g.sbn == 1 && g.sbk % 4 == 0;
+  const bool vec = (akf || amf) && (bkf || bnf) && al16(g.A) && al16(g.B) && al16(g.Bmask) &&
+                   g.k_per_split % 4 == 0;
+#define GNF_VEC_LAUNCH(BT)                                                                              \
+  do {                                                                                                  \
+    if (akf && bkf) hipLaunchKernelGGL((gemm_vec_k<BT, BT, true, true>), grid, dim3(256), 0, s, g);      \
+    else if (akf) hipLaunchKernelGGL((gemm_vec_k<BT, BT, true, false>), grid, dim3(256), 0, s, g);       \
+    else if (bkf) hipLaunchKernelGGL((gemm_vec_k<BT, BT, false, true>), grid, dim3(256), 0, s, g);       \
+    else hipLaunchKernelGGL((gemm_vec_k<BT, BT, false, false>), grid, dim3(256), 0, s, g);               \
+  } while (0)
+  if (vec) {
+    if (bt == 128) GNF_VEC_LAUNCH(128); else GNF_VEC_LAUNCH(64);
+  } else {
+    if (bt == 128) hipLaunchKernelGGL((gemm_k<128, 128>), grid, dim3(256), 0, s, g);
+    else hipLaunchKernelGGL((gemm_k<64, 64>), grid, dim3(256), 0, s, g);
+  }
+#undef GNF_VEC_LAUNCH
   GNF_LAUNCH_CHECK();
   return 0;
 }

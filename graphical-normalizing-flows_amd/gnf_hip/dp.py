@@ -16,9 +16,10 @@ class FlatState:
 
     def __init__(self, module):
         self.params = [p for p in module.parameters() if p.requires_grad]
-        n = sum(p.numel() for p in self.params)
+        pad4 = lambda k: (k + 3) // 4 * 4          # every parameter starts 16-B aligned (vector loads)
+        n = sum(pad4(p.numel()) for p in self.params)
         dev = self.params[0].device
-        self.flat = torch.empty(n, device=dev)
+        self.flat = torch.zeros(n, device=dev)
         self.grad = torch.zeros(n, device=dev)
         self.m = torch.zeros(n, device=dev)
         self.v = torch.zeros(n, device=dev)
@@ -28,7 +29,7 @@ class FlatState:
             self.flat[o:o + k].copy_(p.data.reshape(-1))
             p.data = self.flat[o:o + k].view_as(p)
             p.grad = self.grad[o:o + k].view_as(p)
-            o += k
+            o += pad4(k)
         self.t = 0
 
     def broadcast(self, src=0):

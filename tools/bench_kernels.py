@@ -1,0 +1,115 @@
+"""Per-kernel roofline table: each C-ABI entry point at representative sizes, timed with HIP events
+(median of N launches), against its algorithmic bytes / flops.
+Usage: python tools/bench_kernels.py [--json out.json]"""
+import json
+import sys
+
+import torch
+
+sys.path[:0] = ['/root/repo', '/root/repo/graphical-normalizing-flows_amd']
+from gnf_hip import ops  # noqa: E402
+from models import MonotonicNormalizer  # noqa: E402
+
+DEV = "cuda:0"
+HBM_PEAK, F32_PEAK = 8000., 157.3       # GB/s (spec), TFLOP/s (fp32 MFMA)
+
+
+def timeit(fn, n=20, warm=3):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    ts = []
+    for _ in range(n):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        fn()
+        b.record()
+        torch.cuda.synchronize()
+        ts.append(a.elapsed_time(b))
+    ts.sort()
+    return ts[len(ts) // 2]
+
+
+rows = []
+
+
+def hbm(name, shape, ms, nbytes):
+    gbs = nbytes / ms / 1e6
+    rows.append({"kernel": name, "shape": shape, "ms": round(ms, 4), "bound": "hbm", "achieved_GBps": round(gbs, 1),
+                 "frac_of_8TBps": round(gbs / HBM_PEAK, 3)})
+
+
+def mfma(name, shape, ms, flops):
+    tf = flops / ms / 1e9
+    rows.append({"kernel": name, "shape": shape, "ms": round(ms, 4), "bound": "mfma", "achieved_TFLOPs": round(tf, 1),
+                 "frac_of_157TF": round(tf / F32_PEAK, 3)})
+
+
+def main():
+    torch.manual_seed(0)
+    # ---- Affine normalizer (16 B/elem fwd, 28 B/elem bwd)
+    for B, d in [(100, 784), (50000, 63), (1000000, 63)]:
+        x = torch.randn(B, d, device=DEV, requires_grad=True)
+        h = torch.randn(B, d, 2, device=DEV, requires_grad=True)
+        with torch.no_grad():
+            hbm("affine_fwd", [B, d], timeit(lambda: ops.AffineFn.apply(x, h)), 16. * B * d + 4 * B)
+        z, jac, ld = ops.AffineFn.apply(x, h)
+        gz, gl = torch.randn_like(z), torch.randn_like(ld)
+        hbm("affine_bwd", [B, d], timeit(lambda: torch.autograd.grad((z, ld), (x, h), (gz, gl), retain_graph=True)),
+            28. * B * d + 4 * B)
+        with torch.no_grad():
+            hbm("normal_logdensity_fwd", [B, d], timeit(lambda: ops.NormalLogDensityFn.apply(x)), 4. * B * d)
+    # ---- DAG gate (writes 4 B per (b,i,j))
+    for B, d in [(100, 784), (10000, 6)]:
+        x = torch.randn(B, d, device=DEV)
+        A = torch.rand(d, d, device=DEV)
+        with torch.no_grad():
+            f = lambda: ops.DagGateFn.apply(x, A, ops.IMP_SOFT, ops.GATE_GUMBEL, 0., 1., False, None, None, 1, 1)
+            hbm("dag_gate_fwd(gumbel)", [B, d, d], timeit(f), 4. * B * d * d)
+    # ---- GEMM shapes on the measured configurations
+    for M, N, K, what in [(78400, 128, 2304, "cfg4 fc1 fwd"), (78400, 2304, 128, "cfg4 fc1 dX"),
+                          (128, 2304, 78400, "cfg4 fc1 dW (split-K)"), (100, 1024, 1024, "cfg3 MADE hidden"),
+                          (50000, 630, 630, "cfg5 MADE hidden"), (4096, 4096, 4096, "square")]:
+        Am, Bm = torch.randn(M, K, device=DEV), torch.randn(N, K, device=DEV)
+        C = torch.empty(M, N, device=DEV)
+        mfma("gemm " + what, [M, N, K], timeit(lambda: ops.gemm(Am, (K, 1), Bm, (1, K), C, (N, 1), M, N, K)),
+             2. * M * N * K)
+    # ---- Monotonic quadrature, forward: 2*M*(S+2) flop per element
+    for (B, d, c, hid, tag) in [(100, 784, 30, [50, 50, 50], "cfg4"), (10000, 6, 30, [100, 100, 100], "cfg2"),
+                                (50000, 63, 30, [150, 150, 150], "cfg5")]:
+        S = 20
+        norm = MonotonicNormalizer(hid, c, nb_steps=S).to(DEV)
+        x, h = torch.randn(B, d, device=DEV), torch.randn(B, d, c, device=DEV)
+        dims = [1 + c] + hid + [1]
+        macs = sum(a * b for a, b in zip(dims[:-1], dims[1:]))
+        with torch.no_grad():
+            mfma("monotonic_fwd " + tag, [B, d, hid[0]], timeit(lambda: norm(x, h), n=10), 2. * macs * (S + 2) * B * d)
+        xg, hg = x.clone().requires_grad_(True), h.clone().requires_grad_(True)
+        z, jac = norm(xg, hg)
+        gz = torch.randn_like(z)
+        ps = list(norm.parameters())
+        mfma("monotonic_bwd " + tag, [B, d, hid[0]],
+             timeit(lambda: torch.autograd.grad((z, jac), [xg, hg] + ps, (gz, gz), retain_graph=True), n=5, warm=1),
+             4. * macs * (S + 2) * B * d)
+    # ---- MNISTCNN conv front at cfg4 (78 400 images)
+    n = 78400
+    e = torch.randn(n, 784, device=DEV).requires_grad_(True)
+    W1, b1 = torch.randn(16, 1, 3, 3, device=DEV, requires_grad=True), torch.randn(16, device=DEV, requires_grad=True)
+    W2, b2 = torch.randn(16, 16, 3, 3, device=DEV, requires_grad=True), torch.randn(16, device=DEV, requires_grad=True)
+    with torch.no_grad():
+        mfma("mnistcnn_conv_fwd", [n, 784], timeit(lambda: ops.MnistConvFn.apply(e, W1, b1, W2, b2), n=10),
+             2. * (97344 + 1327104) * n)
+    out = ops.MnistConvFn.apply(e, W1, b1, W2, b2)
+    gp = torch.randn_like(out)
+    # dW2 + da1 (2 x conv2 MACs) + conv1 recompute + dW1 + de (3 x conv1 MACs)
+    mfma("mnistcnn_conv_bwd", [n, 784],
+         timeit(lambda: torch.autograd.grad(out, (e, W1, b1, W2, b2), gp, retain_graph=True), n=10),
+         2. * (2 * 1327104 + 3 * 97344) * n)
+    for r in rows:
+        print(json.dumps(r))
+    if "--json" in sys.argv:
+        json.dump(rows, open(sys.argv[sys.argv.index("--json") + 1], "w"), indent=1)
+
+
+if __name__ == "__main__":
+    main()
