@@ -115,11 +115,19 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback of the product path)")
+    ndev = torch.cuda.device_count()
+    backend = os.environ.get("GNF_DIST_BACKEND", "nccl")     # "nccl" is RCCL on ROCm; "gloo" only to exercise the
+    if backend == "nccl" and local >= ndev:                  # N>1 path on a 1-GPU box (ranks share the device)
+        raise SystemExit("rank %d has no GPU (%d visible)" % (local, ndev))
+    local = local % max(ndev, 1)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)      # "nccl" is RCCL on ROCm
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     from gnf_hip import abi, ops
     abi.load()

@@ -43,8 +43,9 @@ SIGNATURES = {
     "gnf_gemm_ws_bytes": (c_i64, [c_i64, c_i64, c_i64]),
     "gnf_gemm": (c_int, [c_f, c_i64, c_i64, c_f, c_f, c_i64, c_i64, c_f, c_i64, c_i64, c_f, c_f, c_i64, c_i64, c_f,
                          c_i64, c_i64, c_int, c_i64, c_i64, c_i64, c_f, c_i64, c_stream]),
+    "gnf_dag_gate_fwd_ws_bytes": (c_i64, [c_i64]),
     "gnf_dag_gate_fwd": (c_int, [c_f, c_f, c_f, c_i64, c_int, c_int, c_float, c_float, c_f, c_f, c_u64, c_u64, c_int,
-                                 c_i64, c_i64, c_stream]),
+                                 c_f, c_i64, c_i64, c_stream]),
     "gnf_dag_gate_bwd_ws_bytes": (c_i64, [c_i64, c_i64]),
     "gnf_dag_gate_bwd": (c_int, [c_f, c_f, c_f, c_i64, c_int, c_int, c_float, c_float, c_f, c_f, c_u64, c_u64, c_f,
                                  c_f, c_f, c_i64, c_i64, c_stream]),

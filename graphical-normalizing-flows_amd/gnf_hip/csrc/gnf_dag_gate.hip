@@ -32,9 +32,29 @@ __device__ __forceinline__ float importance(float a, int mode, float h_thresh, f
   return G;
 }
 
+// Per-(i,j) table, built once per call (d*d entries, negligible next to the B*d*d gate work):
+//   P  = importance p,   dP = dp/dA,
+//   ET = ((1-p+eps)/(p+eps))^(1/T)         Gumbel gate:  z1/(z1+z2) = 1/(1 + ET * (ln u1/ln u2)^(1/T))
+//   Q  = (1/(p+eps) + 1/(1-p+eps))/T       d gate/dp = gate (1-gate) Q
+// so the per-element work is the noise plus two logarithms (the reference's four logs, two exps and the
+// sigmoid collapse algebraically; same value to fp32 rounding, no overflow for large Gumbel draws).
+__global__ void dag_gate_tab_k(const float* __restrict__ A, float* __restrict__ tab, int imp_mode, float h_thresh,
+                               float T, int64_t dd) {
+  const int64_t ij = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (ij >= dd) return;
+  float dpda;
+  const float p = importance(A[ij], imp_mode, h_thresh, &dpda);
+  const float eps = 1e-6f;
+  const float pa = p + eps, pb = 1.f - p + eps;
+  tab[ij] = p;
+  tab[dd + ij] = dpda;
+  tab[2 * dd + ij] = expf((logf(pb) - logf(pa)) / T);
+  tab[3 * dd + ij] = (1.f / pa + 1.f / pb) / T;
+}
+
 struct Noise { float a, b; };
 
-// gate_mode 1: two uniforms; gate_mode 2: one standard normal (Box-Muller on the Philox pair).
+// gate_mode 1: two uniforms in (0,1); gate_mode 2: one standard normal (Box-Muller on the Philox pair).
 __device__ __forceinline__ Noise draw(int gate_mode, const float* u1, const float* u2, uint64_t seed, uint64_t offset,
                                       int64_t idx) {
   Noise n{0.f, 0.f};
@@ -47,86 +67,67 @@ __device__ __forceinline__ Noise draw(int gate_mode, const float* u1, const floa
   uint32_t r[4];
   philox4x32_10((uint32_t)idx, (uint32_t)((uint64_t)idx >> 32), (uint32_t)offset, (uint32_t)(offset >> 32),
                 (uint32_t)seed, (uint32_t)(seed >> 32), r);
-  if (gate_mode == 1) {
-    n.a = u01_24(r[0]);
-    n.b = u01_24(r[1]);
-  } else {
-    const float ua = (float)((r[0] >> 8) + 1u) * (1.0f / 16777216.0f);  // (0,1]
-    n.a = sqrtf(-2.f * logf(ua)) * cosf(6.283185307179586f * u01_24(r[1]));
-  }
+  // 24-bit uniforms centred in their cell: never exactly 0 or 1
+  const float ua = ((float)(r[0] >> 8) + .5f) * (1.0f / 16777216.0f);
+  const float ub = ((float)(r[1] >> 8) + .5f) * (1.0f / 16777216.0f);
+  if (gate_mode == 1) { n.a = ua; n.b = ub; }
+  else n.a = sqrtf(-2.f * logf(ua)) * cosf(6.283185307179586f * ub);
   return n;
 }
 
-// gate value s and ds/dp for the Gumbel relaxation (DAG:95-103):
-//   z1/(z1+z2) with z1 = exp((log(p+eps)+g1)/T), z2 = exp((log(1-p+eps)+g2)/T)
-//   == sigmoid((log(p+eps) - log(1-p+eps) + g1 - g2)/T)   (same value, no overflow)
-__device__ __forceinline__ float gumbel_gate(float p, Noise n, float T, float* ds_dp) {
-  const float eps = 1e-6f;
-  const float g1 = -logf(-logf(n.a));
-  const float g2 = -logf(-logf(n.b));
-  const float pa = p + eps, pb = 1.f - p + eps;
-  const float t = ((logf(pa) + g1) - (logf(pb) + g2)) / T;
-  const float s = sigmoidf(t);
-  *ds_dp = s * (1.f - s) / T * (1.f / pa + 1.f / pb);
-  return s;
+// Gumbel-softmax gate from the table entry ET and the two uniforms
+__device__ __forceinline__ float gumbel_gate(float ET, Noise n, float T) {
+  const float r = log2f(n.a) / log2f(n.b);            // = ln u1 / ln u2 = exp(g2 - g1)
+  const float rT = T == 1.f ? r : (T == .5f ? r * r : exp2f(log2f(r) / T));
+  return 1.f / (1.f + ET * rT);                       // u1 -> 0: gate 0;  u2 -> 0: gate 1 (as the reference)
 }
 
-__global__ void dag_gate_fwd_k(const float* __restrict__ x, const float* __restrict__ A, float* __restrict__ e,
-                               int64_t ld_e, int imp_mode, int gate_mode, float h_thresh, float T,
-                               const float* __restrict__ u1, const float* __restrict__ u2, uint64_t seed,
-                               uint64_t offset, int hot, int64_t B, int64_t d) {
-  const int64_t total = B * d * d;
-  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
-       idx += (int64_t)gridDim.x * blockDim.x) {
-    const int64_t j = idx % d;
-    const int64_t bi = idx / d;       // b*d + i
-    const int64_t i = bi % d;
-    const int64_t b = bi / d;
-    float dpda;
-    const float p = importance(A[i * d + j], imp_mode, h_thresh, &dpda);
-    const float xv = x[b * d + j];
-    float out;
-    if (gate_mode == 0) {
-      out = xv * p;
-    } else {
-      const Noise n = draw(gate_mode, u1, u2, seed, offset, idx);
-      if (gate_mode == 1) {
-        float ds;
-        out = xv * gumbel_gate(p, n, T, &ds);
-      } else {
-        out = p * (xv + n.a * fabsf(1.f - p));
-      }
-    }
-    e[bi * ld_e + j] = out;
-    if (hot) e[bi * ld_e + d + j] = (j == i) ? 1.f : 0.f;
+struct GateArgs {
+  const float* x; const float* tab; float* e; const float* ge; int64_t ld_e;
+  int gate_mode; float T; const float* u1; const float* u2; uint64_t seed, offset; int hot;
+  float* ws; float* gA; float* gx; int64_t B, d, chunk;
+};
+
+// one workgroup row per (b,i): blockIdx.x = b*d + i, blockIdx.y tiles the d columns
+__global__ void dag_gate_fwd_k(GateArgs a) {
+  const int64_t bi = blockIdx.x;
+  const int64_t j = (int64_t)blockIdx.y * blockDim.x + threadIdx.x;
+  if (j >= a.d) return;
+  const int64_t b = bi / a.d, i = bi - b * a.d;
+  const int64_t ij = i * a.d + j, dd = a.d * a.d;
+  const float p = a.tab[ij];
+  const float xv = a.x[b * a.d + j];
+  float out;
+  if (a.gate_mode == 0) {
+    out = xv * p;
+  } else {
+    const Noise n = draw(a.gate_mode, a.u1, a.u2, a.seed, a.offset, bi * a.d + j);
+    out = a.gate_mode == 1 ? xv * gumbel_gate(a.tab[2 * dd + ij], n, a.T) : p * (xv + n.a * fabsf(1.f - p));
   }
+  a.e[bi * a.ld_e + j] = out;
+  if (a.hot) a.e[bi * a.ld_e + a.d + j] = (j == i) ? 1.f : 0.f;
 }
 
 // dL/dp partial sums over a chunk of b:  ws[chunk][i*d+j] = sum_b ge[b,i,j] * de/dp[b,i,j]
-__global__ void dag_gate_bwd_dp_k(const float* __restrict__ x, const float* __restrict__ A,
-                                  const float* __restrict__ ge, int64_t ld_e, int imp_mode, int gate_mode,
-                                  float h_thresh, float T, const float* __restrict__ u1,
-                                  const float* __restrict__ u2, uint64_t seed, uint64_t offset,
-                                  float* __restrict__ ws, int64_t B, int64_t d, int64_t chunk) {
+__global__ void dag_gate_bwd_dp_k(GateArgs a) {
   const int64_t ij = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (ij >= d * d) return;
+  const int64_t d = a.d, dd = d * d;
+  if (ij >= dd) return;
   const int64_t i = ij / d, j = ij - i * d;
-  float dpda;
-  const float p = importance(A[ij], imp_mode, h_thresh, &dpda);
-  const int64_t b0 = (int64_t)blockIdx.y * chunk;
-  const int64_t b1 = b0 + chunk < B ? b0 + chunk : B;
+  const float p = a.tab[ij], ET = a.tab[2 * dd + ij], Q = a.tab[3 * dd + ij];
+  const int64_t b0 = (int64_t)blockIdx.y * a.chunk;
+  const int64_t b1 = b0 + a.chunk < a.B ? b0 + a.chunk : a.B;
   float acc = 0.f;
   for (int64_t b = b0; b < b1; ++b) {
-    const float g = ge[(b * d + i) * ld_e + j];
-    const float xv = x[b * d + j];
-    if (gate_mode == 0) {
+    const float g = a.ge[(b * d + i) * a.ld_e + j];
+    const float xv = a.x[b * d + j];
+    if (a.gate_mode == 0) {
       acc = fmaf(g, xv, acc);
     } else {
-      const Noise n = draw(gate_mode, u1, u2, seed, offset, (b * d + i) * d + j);
-      if (gate_mode == 1) {
-        float ds;
-        gumbel_gate(p, n, T, &ds);
-        acc = fmaf(g * xv, ds, acc);
+      const Noise n = draw(a.gate_mode, a.u1, a.u2, a.seed, a.offset, (b * d + i) * d + j);
+      if (a.gate_mode == 1) {
+        const float s = gumbel_gate(ET, n, a.T);
+        acc = fmaf(g * xv, s * (1.f - s) * Q, acc);
       } else {
         const float om = 1.f - p;
         const float sgn = om > 0.f ? 1.f : (om < 0.f ? -1.f : 0.f);
@@ -134,41 +135,31 @@ __global__ void dag_gate_bwd_dp_k(const float* __restrict__ x, const float* __re
       }
     }
   }
-  ws[(int64_t)blockIdx.y * d * d + ij] = acc;
+  a.ws[(int64_t)blockIdx.y * dd + ij] = acc;
 }
 
-__global__ void dag_gate_bwd_dA_k(const float* __restrict__ A, const float* __restrict__ ws, float* __restrict__ gA,
-                                  int imp_mode, float h_thresh, int64_t d, int64_t nchunk) {
+__global__ void dag_gate_bwd_dA_k(const float* __restrict__ tab, const float* __restrict__ ws, float* __restrict__ gA,
+                                  int64_t dd, int64_t nchunk) {
   const int64_t ij = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (ij >= d * d) return;
+  if (ij >= dd) return;
   float s = 0.f;
-  for (int64_t c = 0; c < nchunk; ++c) s += ws[c * d * d + ij];
-  float dpda;
-  importance(A[ij], imp_mode, h_thresh, &dpda);
-  gA[ij] = s * dpda;
+  for (int64_t c = 0; c < nchunk; ++c) s += ws[c * dd + ij];
+  gA[ij] = s * tab[dd + ij];
 }
 
 // gx[b,j] = sum_i ge[b,i,j] * de/dx[b,i,j]
-__global__ void dag_gate_bwd_dx_k(const float* __restrict__ A, const float* __restrict__ ge, int64_t ld_e,
-                                  int imp_mode, int gate_mode, float h_thresh, float T,
-                                  const float* __restrict__ u1, const float* __restrict__ u2, uint64_t seed,
-                                  uint64_t offset, float* __restrict__ gx, int64_t B, int64_t d) {
-  const int64_t n = B * d;
+__global__ void dag_gate_bwd_dx_k(GateArgs a) {
+  const int64_t n = a.B * a.d, d = a.d, dd = d * d;
   for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x) {
     const int64_t b = e / d, j = e - b * d;
     float acc = 0.f;
     for (int64_t i = 0; i < d; ++i) {
-      float dpda;
-      const float p = importance(A[i * d + j], imp_mode, h_thresh, &dpda);
-      float gate = p;
-      if (gate_mode == 1) {
-        const Noise nz = draw(gate_mode, u1, u2, seed, offset, (b * d + i) * d + j);
-        float ds;
-        gate = gumbel_gate(p, nz, T, &ds);
-      }
-      acc = fmaf(ge[(b * d + i) * ld_e + j], gate, acc);
+      float gate = a.tab[i * d + j];
+      if (a.gate_mode == 1)
+        gate = gumbel_gate(a.tab[2 * dd + i * d + j], draw(1, a.u1, a.u2, a.seed, a.offset, (b * d + i) * d + j), a.T);
+      acc = fmaf(a.ge[(b * d + i) * a.ld_e + j], gate, acc);
     }
-    gx[e] = acc;
+    a.gx[e] = acc;
   }
 }
 
@@ -188,49 +179,69 @@ inline unsigned grid_1d(int64_t n) {
   return (unsigned)g;
 }
 
+inline int launch_tab(const float* A, float* tab, int imp_mode, float h_thresh, float T, int64_t d, hipStream_t s) {
+  hipLaunchKernelGGL(dag_gate_tab_k, dim3((unsigned)((d * d + kBlock - 1) / kBlock)), dim3(kBlock), 0, s, A, tab,
+                     imp_mode, h_thresh, T, d * d);
+  GNF_LAUNCH_CHECK();
+  return 0;
+}
+
 }  // namespace
 
 extern "C" {
 
+int64_t gnf_dag_gate_fwd_ws_bytes(int64_t d) { return 4 * d * d * (int64_t)sizeof(float); }
+
 int gnf_dag_gate_fwd(const float* x, const float* A, float* e, int64_t ld_e, int imp_mode, int gate_mode,
                      float h_thresh, float temperature, const float* u1, const float* u2, uint64_t seed,
-                     uint64_t offset, int hot, int64_t B, int64_t d, gnf_stream_t stream) {
-  if (!x || !A || !e || B < 0 || d <= 0 || imp_mode < 0 || imp_mode > 3 || gate_mode < 0 || gate_mode > 2)
+                     uint64_t offset, int hot, float* ws, int64_t B, int64_t d, gnf_stream_t stream) {
+  if (!x || !A || !e || !ws || B < 0 || d <= 0 || imp_mode < 0 || imp_mode > 3 || gate_mode < 0 || gate_mode > 2)
     return GNF_EINVAL;
   if (ld_e < (hot ? 2 * d : d)) return GNF_EINVAL;
   if (gate_mode == 1 && u1 && !u2) return GNF_EINVAL;
   if (imp_mode == 0) gate_mode = 0;   // DAG:151-153: raw A, no gate
   if (B == 0) return 0;
-  hipLaunchKernelGGL(dag_gate_fwd_k, dim3(grid_1d(B * d * d)), dim3(kBlock), 0, (hipStream_t)stream, x, A, e, ld_e,
-                     imp_mode, gate_mode, h_thresh, temperature, u1, u2, seed, offset, hot, B, d);
+  hipStream_t s = (hipStream_t)stream;
+  int rc = launch_tab(A, ws, imp_mode, h_thresh, temperature, d, s);
+  if (rc) return rc;
+  GateArgs a{};
+  a.x = x; a.tab = ws; a.e = e; a.ld_e = ld_e; a.gate_mode = gate_mode; a.T = temperature; a.u1 = u1; a.u2 = u2;
+  a.seed = seed; a.offset = offset; a.hot = hot; a.B = B; a.d = d;
+  const int bs = d >= 256 ? 256 : (d >= 128 ? 128 : 64);
+  hipLaunchKernelGGL(dag_gate_fwd_k, dim3((unsigned)(B * d), (unsigned)((d + bs - 1) / bs)), dim3(bs), 0, s, a);
   GNF_LAUNCH_CHECK();
   return 0;
 }
 
-int64_t gnf_dag_gate_bwd_ws_bytes(int64_t B, int64_t d) { return bwd_chunks(B, d) * d * d * (int64_t)sizeof(float); }
+int64_t gnf_dag_gate_bwd_ws_bytes(int64_t B, int64_t d) {
+  return (bwd_chunks(B, d) + 4) * d * d * (int64_t)sizeof(float);
+}
 
 int gnf_dag_gate_bwd(const float* x, const float* A, const float* ge, int64_t ld_e, int imp_mode, int gate_mode,
                      float h_thresh, float temperature, const float* u1, const float* u2, uint64_t seed,
                      uint64_t offset, float* gA, float* gx, float* ws, int64_t B, int64_t d, gnf_stream_t stream) {
-  if (!x || !A || !ge || B < 0 || d <= 0 || imp_mode < 0 || imp_mode > 3 || gate_mode < 0 || gate_mode > 2)
+  if (!x || !A || !ge || !ws || B < 0 || d <= 0 || imp_mode < 0 || imp_mode > 3 || gate_mode < 0 || gate_mode > 2)
     return GNF_EINVAL;
-  if (gA && !ws) return GNF_EINVAL;
   if (gate_mode == 1 && u1 && !u2) return GNF_EINVAL;
   if (imp_mode == 0) gate_mode = 0;
   hipStream_t s = (hipStream_t)stream;
+  float* tab = ws;                           // [4][d*d] table, then the chunk partials
+  int rc = launch_tab(A, tab, imp_mode, h_thresh, temperature, d, s);
+  if (rc) return rc;
+  GateArgs a{};
+  a.x = x; a.tab = tab; a.ge = ge; a.ld_e = ld_e; a.gate_mode = gate_mode; a.T = temperature; a.u1 = u1; a.u2 = u2;
+  a.seed = seed; a.offset = offset; a.B = B; a.d = d; a.gA = gA; a.gx = gx; a.ws = ws + 4 * d * d;
   if (gA) {
     const int64_t nc = bwd_chunks(B, d);
-    const int64_t chunk = B > 0 ? (B + nc - 1) / nc : 1;
+    a.chunk = B > 0 ? (B + nc - 1) / nc : 1;
     const unsigned gxd = (unsigned)((d * d + kBlock - 1) / kBlock);
-    hipLaunchKernelGGL(dag_gate_bwd_dp_k, dim3(gxd, (unsigned)nc), dim3(kBlock), 0, s, x, A, ge, ld_e, imp_mode,
-                       gate_mode, h_thresh, temperature, u1, u2, seed, offset, ws, B, d, chunk);
+    hipLaunchKernelGGL(dag_gate_bwd_dp_k, dim3(gxd, (unsigned)nc), dim3(kBlock), 0, s, a);
     GNF_LAUNCH_CHECK();
-    hipLaunchKernelGGL(dag_gate_bwd_dA_k, dim3(gxd), dim3(kBlock), 0, s, A, ws, gA, imp_mode, h_thresh, d, nc);
+    hipLaunchKernelGGL(dag_gate_bwd_dA_k, dim3(gxd), dim3(kBlock), 0, s, tab, a.ws, gA, d * d, nc);
     GNF_LAUNCH_CHECK();
   }
   if (gx && B > 0) {
-    hipLaunchKernelGGL(dag_gate_bwd_dx_k, dim3(grid_1d(B * d)), dim3(kBlock), 0, s, A, ge, ld_e, imp_mode, gate_mode,
-                       h_thresh, temperature, u1, u2, seed, offset, gx, B, d);
+    hipLaunchKernelGGL(dag_gate_bwd_dx_k, dim3(grid_1d(B * d)), dim3(kBlock), 0, s, a);
     GNF_LAUNCH_CHECK();
   }
   return 0;

@@ -304,13 +304,16 @@ int gnf_normal_logdensity_bwd(const float* z, const float* g, float* gz, int64_t
 }
 
 int64_t gnf_colsum_ws_bytes(int64_t M, int64_t N) {
-  const int64_t P = (M + kColRows - 1) / kColRows;
-  return (P > 0 ? P : 1) * N * (int64_t)sizeof(float);
+  (void)M;
+  return (int64_t)kRowsumChunks * N * (int64_t)sizeof(float);
 }
 
 int gnf_colsum(const float* a, int64_t lda, float* out, int64_t M, int64_t N, float* ws, gnf_stream_t stream) {
   if (!a || !out || !ws || M < 0 || N <= 0) return GNF_EINVAL;
+  if (lda == N) return gnf_rowsum_tall_launch(a, out, M, N, 0, ws, (hipStream_t)stream);
+  // strided rows: generic two-stage kernels
   const int64_t P = (M + kColRows - 1) / kColRows;
+  if (P > kRowsumChunks) return GNF_ESHAPE;
   const unsigned gx = (unsigned)((N + kBlock - 1) / kBlock);
   if (P > 0) {
     hipLaunchKernelGGL(colsum_stage1_k, dim3(gx, (unsigned)P), dim3(kBlock), 0, (hipStream_t)stream, a, lda, ws, M, N);

@@ -96,10 +96,12 @@ int gnf_gemm(const float* A, int64_t sam, int64_t sak,
  * samples) are read from [B,d,d] arrays (parity tests); otherwise a Philox4x32-10
  * stream keyed by (seed, offset) with the element index as counter is used, and the
  * backward regenerates the same numbers from the same (seed, offset). */
+/* ws: >= gnf_dag_gate_fwd_ws_bytes(d) bytes (per-(i,j) table of importance / gate constants). */
+int64_t gnf_dag_gate_fwd_ws_bytes(int64_t d);
 int gnf_dag_gate_fwd(const float* x, const float* A, float* e, int64_t ld_e,
                      int imp_mode, int gate_mode, float h_thresh, float temperature,
                      const float* u1, const float* u2, uint64_t seed, uint64_t offset,
-                     int hot, int64_t B, int64_t d, gnf_stream_t stream);
+                     int hot, float* ws, int64_t B, int64_t d, gnf_stream_t stream);
 /* ge: [(B*d), ld_e].  gA: [d,d] (written, not accumulated) or NULL; gx: [B,d] or NULL.
  * ws: >= gnf_dag_gate_bwd_ws_bytes(B,d). */
 int64_t gnf_dag_gate_bwd_ws_bytes(int64_t B, int64_t d);
