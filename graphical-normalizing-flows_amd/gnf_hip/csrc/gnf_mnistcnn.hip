@@ -50,27 +50,55 @@ struct CnnArgs {
   int64_t n;
 };
 
-// conv1 + ReLU of the image in e_s into a1_s; 43 tiles of 16 consecutive positions of the 26x26 grid
+// conv1 + ReLU of the image in e_s into a1_s; 43 tiles of 16 consecutive positions of the 26x26 grid.
+// All operand reads of a wave's (up to 6) tiles are issued first, then 6 independent 3-step MFMA chains,
+// then the stores: the phase is latency-bound, so nothing may serialise behind a single chain.
 template <int NW>
 __device__ __forceinline__ void conv1_tiles(const float* e_s, float* a1_s, const float (&w1f)[3], const int (&off1)[3],
                                             const f32x4& b1v, int wave, int q, int j) {
-#pragma nounroll
-  for (int t = wave; t < 43; t += NW) {
-    const int pos = 16 * t + j;
-    const int pc = pos < C1 * C1 ? pos : 0;
-    const int y = pc / C1, x = pc - y * C1;
-    const int base = y * ROWE + x;
-    f32x4 acc = b1v;
+  constexpr int NTL = (43 + NW - 1) / NW, NB = NTL;           // tiles per wave, processed NB at a time
 #pragma unroll
-    for (int s = 0; s < 3; ++s) acc = mfma(w1f[s], e_s[base + off1[s]], acc);
-    if (pos < C1 * C1) {
+  for (int k0 = 0; k0 < NTL; k0 += NB) {
+    int po[NB];
+    f32x4 acc[NB];
+    float ev[NB][3];
 #pragma unroll
-      for (int r = 0; r < 4; ++r) a1_s[(4 * q + r) * CH + y * ROW + x] = fmaxf(acc[r], 0.f);
+    for (int k = 0; k < NB; ++k) {
+      const int pos = 16 * (wave + NW * (k0 + k)) + j;
+      const int pc = pos < C1 * C1 ? pos : 0;
+      const int y = pc / C1, x = pc - y * C1;
+      po[k] = pos < C1 * C1 ? y * ROW + x : -1;
+#pragma unroll
+      for (int s = 0; s < 3; ++s) ev[k][s] = e_s[y * ROWE + x + off1[s]];
+      acc[k] = b1v;
     }
+#pragma unroll
+    for (int s = 0; s < 3; ++s)
+#pragma unroll
+      for (int k = 0; k < NB; ++k) acc[k] = mfma(w1f[s], ev[k][s], acc[k]);
+#pragma unroll
+    for (int k = 0; k < NB; ++k)
+      if (po[k] >= 0) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) a1_s[(4 * q + r) * CH + po[k]] = fmaxf(acc[k][r], 0.f);
+      }
   }
 }
 
+#ifdef GNF_CNN_TIMING
+__device__ float g_fwd_timing[64];
+__device__ long long g_fwd_start[1024];
+#define TSTAMP(k) do { const long long t__ = __builtin_readcyclecounter(); tacc[k] += t__ - tlast; tlast = t__; } while (0)
+#else
+#define TSTAMP(k)
+#endif
+
 __global__ __launch_bounds__(64 * FWD_WAVES) void cnn_fwd_k(CnnArgs a) {
+#ifdef GNF_CNN_TIMING
+  long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  long long tlast = __builtin_readcyclecounter();
+  const long long tstart0 = tlast;
+#endif
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* e_s = smem;
   float* a1_s = smem + ESZ;
@@ -121,8 +149,10 @@ __global__ __launch_bounds__(64 * FWD_WAVES) void cnn_fwd_k(CnnArgs a) {
         pre[k] = (nx < a.n && i < IMG * IMG) ? a.e[nx * (IMG * IMG) + i] : 0.f;
       }
     }
+    TSTAMP(0);
     conv1_tiles<FWD_WAVES>(e_s, a1_s, w1f, off1, b1v, wave, q, j);
     __syncthreads();
+    TSTAMP(1);
     // conv2 (implicit GEMM, K = 16 channels x 9 taps) + 2x2 max pool: 36 tiles, two in flight per wave
 #pragma nounroll
     for (int t = wave; t < 36; t += 2 * FWD_WAVES) {
@@ -133,7 +163,7 @@ __global__ __launch_bounds__(64 * FWD_WAVES) void cnn_fwd_k(CnnArgs a) {
       const float* pB = a1_s + q * CH + yB * ROW + xB;
       f32x4 accA = b2v, accB = b2v;
 #pragma unroll
-      for (int g = 0; g < 4; ++g)
+      for (int g = 0; g < 4; ++g) {
 #pragma unroll
         for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
@@ -142,6 +172,7 @@ __global__ __launch_bounds__(64 * FWD_WAVES) void cnn_fwd_k(CnnArgs a) {
             accA = mfma(w2f[g * 9 + ky * 3 + kx], pA[o], accA);
             accB = mfma(w2f[g * 9 + ky * 3 + kx], pB[o], accB);
           }
+      }
 #pragma unroll
       for (int half = 0; half < 2; ++half) {
         const f32x4 acc = half ? accB : accA;
@@ -163,14 +194,14 @@ __global__ __launch_bounds__(64 * FWD_WAVES) void cnn_fwd_k(CnnArgs a) {
         }
       }
     }
+    TSTAMP(2);
   }
-}
-
 #ifdef GNF_CNN_TIMING
-#define TSTAMP(k) do { const long long t__ = __builtin_readcyclecounter(); tacc[k] += t__ - tlast; tlast = t__; } while (0)
-#else
-#define TSTAMP(k)
+  if (blockIdx.x == 7 && (tid & 63) == 0)
+    for (int k = 0; k < 3; ++k) g_fwd_timing[wave * 8 + k] = (float)tacc[k];
+  if (tid == 0) { g_fwd_start[blockIdx.x] = tstart0; g_fwd_start[512 + blockIdx.x] = __builtin_readcyclecounter(); }
 #endif
+}
 
 // dY2 planes: channel pairs sit PS dwords apart, the two channels of a pair CHD (== 16 mod 32) apart, so that
 //  - the dW2 A-operand read (16 channels x 2 consecutive positions per 32-lane group) and
@@ -458,11 +489,35 @@ __global__ void cnn_unpack_k(const float* __restrict__ vec, float* gW1, float* g
 
 constexpr size_t kFwdLds = (size_t)(ESZ + NCH * CH) * sizeof(float);
 constexpr size_t kBwdLds = (size_t)(ESZ + NCH * CH + DSZ) * sizeof(float);
-constexpr unsigned kFwdGrid = 512, kBwdGrid = 256;
+// one 8-wave workgroup per CU: at its 128 VGPRs a second one is not admitted (measured with tools/census.hip and
+// the occupancy API; the 96-VGPR variant that admits two spills and is slower)
+constexpr unsigned kFwdGrid = 512, kBwdGrid = 256;   // 512 measured faster than 256 for the forward
 
 }  // namespace
 
 extern "C" {
+
+#ifdef GNF_CNN_TIMING
+int gnf_debug_occupancy_lds(int lds) {
+  int nb = -1;
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&cnn_fwd_k), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+  (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, cnn_fwd_k, 64 * FWD_WAVES, (size_t)lds);
+  return nb;
+}
+int gnf_debug_occupancy(int which) {
+  int nb = -1;
+  if (which == 0) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&cnn_fwd_k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kFwdLds);
+    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, cnn_fwd_k, 64 * FWD_WAVES, kFwdLds);
+  } else {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&cnn_bwd_k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kBwdLds);
+    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, cnn_bwd_k, 64 * BWD_WAVES, kBwdLds);
+  }
+  return nb;
+}
+int gnf_debug_fwd_start(long long* host1024) { return (int)hipMemcpyFromSymbol(host1024, HIP_SYMBOL(g_fwd_start), 1024 * sizeof(long long)); }
+int gnf_debug_fwd_timing(float* host64) { return (int)hipMemcpyFromSymbol(host64, HIP_SYMBOL(g_fwd_timing), 64 * sizeof(float)); }
+#endif
 
 int gnf_mnistcnn_conv_fwd(const float* e, const float* W1, const float* b1, const float* W2, const float* b2,
                           float* pooled, unsigned char* argmax, int64_t n_img, gnf_stream_t stream) {
