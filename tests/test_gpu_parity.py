@@ -481,3 +481,85 @@ def test_full_size_cfg5_affine_roundtrip():
         z, jac = n(x, h)
         xr = n.inverse_transform(z, h)
     assert ((xr - x).abs() / (1 + x.abs())).max() < 1e-4
+
+
+# --------------------------------------------------------------------------------- more coverage
+def test_dag_noise_gate_vs_oracle():
+    """noise gate branch (DAG:114-116) with explicit N(0,1) samples."""
+    from gnf_hip import ops
+    torch.manual_seed(3)
+    B, d = 7, 9
+    x, A, nz = torch.randn(B, d), torch.rand(d, d) * 1.2, torch.randn(B, d, d)
+    xr, Ar = x.clone().requires_grad_(True), A.clone().requires_grad_(True)
+    e0 = O.dag_masked_inputs(xr, Ar, True, 0., False, True, 1., None, None, nz, False)
+    w = torch.randn_like(e0)
+    (e0 * w).sum().backward()
+    xg, Ag = req(x), req(A)
+    e = ops.DagGateFn.apply(xg, Ag, ops.IMP_SOFT, ops.GATE_NOISE, 0., 1., False, cu(nz), None, 0, 0)
+    assert rel_err(e.cpu(), e0.detach()) < TOL
+    (e * cu(w)).sum().backward()
+    assert rel_err(xg.grad.cpu(), xr.grad) < GTOL and rel_err(Ag.grad.cpu(), Ar.grad) < GTOL
+
+
+def test_dag_flow_invert_round_trip():
+    """A DAG conditioner whose A is a (post-processed) strictly lower-triangular 0/1 matrix is invertible:
+    depth()+1 fixed-point passes recover x (NormalizingFlow.py:98-107, DAG:262-266)."""
+    from models import buildFCNormalizingFlow, DAGConditioner, AffineNormalizer
+    torch.manual_seed(5)
+    d = 6
+    flow = buildFCNormalizingFlow(1, DAGConditioner, {"in_size": d, "hidden": [16, 16], "out_size": 2,
+                                                      "A_prior": torch.tril(torch.ones(d, d), -1)},
+                                  AffineNormalizer, {})
+    cond = flow.steps[0].conditioner
+    cond.stoch_gate, cond.noise_gate, cond.s_thresh, cond.h_thresh = False, False, False, 0.
+    cond.is_invertible = True
+    flow = flow.to(DEV)
+    assert cond.depth() == d - 1
+    x = torch.randn(32, d, device=DEV)
+    with torch.no_grad():
+        z, _ = flow(x)
+        xr = flow.invert(z)
+    assert rel_err(xr.cpu(), x.cpu()) < 1e-4
+
+
+def test_abi_error_codes():
+    import ctypes
+    from gnf_hip import abi
+    lib = abi.load()
+    st = abi.stream()
+    x = torch.zeros(4, 4, device=DEV)
+    P = ctypes.c_void_p
+    assert lib.gnf_affine_fwd(None, P(x.data_ptr()), 8, 2, 1, P(x.data_ptr()), None, None, 0, 2, 2, st) == -1
+    assert lib.gnf_gemm(P(x.data_ptr()), 4, 1, None, None, 1, 4, P(x.data_ptr()), 4, 1, None, None, 0, 0, None, 0, 0, 0,
+                        4, 4, 4, None, 0, st) == -1
+    net = abi.MonoNet()
+    net.nl = 1                                  # needs >= 2 Linear layers
+    assert lib.gnf_monotonic_pack_floats(ctypes.byref(net)) == -2
+    net.nl = 2
+    net.dims[0], net.dims[1], net.dims[2] = 4, 300, 1      # hidden wider than any compiled instantiation (256)
+    assert lib.gnf_monotonic_pack_floats(ctypes.byref(net)) == -2
+    with pytest.raises(abi.GnfError):
+        abi.ptr(torch.zeros(2, dtype=torch.float64, device=DEV))
+
+
+@pytest.mark.parametrize("name,B", [("cfg1", 512), ("cfg2", 10000), ("cfg3", 100), ("cfg5", 2000)])
+def test_baseline_configs_train_step(name, B):
+    """every BASELINE.json configuration (cfg4 is the bench itself; cfg5 at a reduced batch to bound the test time):
+    a full fwd + log|det J| + NLL + bwd step runs, the loss is finite, every parameter gets a finite gradient,
+    and the log-likelihood decomposition loss = constraints - mean(logdet + logN(z)) holds."""
+    import sys
+    sys.path.insert(0, str(__import__("pathlib").Path(__file__).resolve().parents[1] / "tools"))
+    import bench_configs as bc
+    flow, x = bc.cfg(name)
+    x = x[:B]
+    for nrm in flow.getNormalizers():
+        if hasattr(nrm, "nb_steps"):
+            nrm.nb_steps = 20
+    z, ld = flow(x)
+    loss = flow.loss(z, ld)
+    loss.backward()
+    assert torch.isfinite(loss).item() and z.shape == x.shape and ld.shape == (x.shape[0],)
+    ref = flow.constraintsLoss() - (ld + O.normal_log_density(z.detach().cpu()).to(DEV)).mean()
+    assert abs(ref.item() - loss.item()) < 1e-4 * max(1., abs(loss.item()))
+    for k, p in flow.named_parameters():
+        assert p.grad is not None and torch.isfinite(p.grad).all(), k
