@@ -285,17 +285,29 @@ __global__ __launch_bounds__(64 * kWaves) void mono_fwd_k(MonoArgs a) {
 // Backward chain kernel.  Vector gradients kept as per-lane partials over the wave's whole
 // persistent loop:  slot 0: d wL, 1: d w1x, 2+l: d b_l (l = 0..NH-1);  + scalar d bL.
 // ---------------------------------------------------------------------------------------
-template <int HT, int NH, bool WLDS>
+// WMODE 0: weight fragments stream from L1/L2;  1: whole padded image LDS-resident (small nets);
+//       2: one hidden->hidden matrix at a time in LDS, swapped in before each layer pass by the whole workgroup
+//          (wide nets: the image does not fit, and L2 fragment loads starve the MFMA pipe)
+template <int HT, int NH, int WMODE>
 __global__ __launch_bounds__(64 * kWaves) void mono_bwd_k(MonoArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
+  constexpr bool WLDS = WMODE == 1, SWAP = WMODE == 2;
   const MonoLayout& L = a.L;
   const float* wp = a.pack;
-  if (WLDS) {                                   // whole padded image (weights + transposes) LDS-resident
+  if (WLDS) {
     for (int i = threadIdx.x * 4; i < L.total_floats; i += blockDim.x * 4)
       *reinterpret_cast<f32x4*>(smem + i) = ld4(a.pack + i);
     __syncthreads();
     wp = smem;
   }
+  // SWAP: copy one [HP][LDW] matrix of the pack into LDS; every wave of the workgroup calls it at the same point
+  auto load_mat = [&](int off) -> const float* {
+    __syncthreads();                              // previous matrix no longer read
+    for (int i = threadIdx.x * 4; i < L.HP * L.LDW; i += blockDim.x * 4)
+      *reinterpret_cast<f32x4*>(smem + i) = ld4(a.pack + off + i);
+    __syncthreads();
+    return smem;
+  };
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int q = lane >> 4, j = lane & 15;
   const int HP = 16 * HT;
@@ -317,10 +329,14 @@ __global__ __launch_bounds__(64 * kWaves) void mono_bwd_k(MonoArgs a) {
     }
   }
 
-  for (int64_t grp = (int64_t)blockIdx.x * kWaves + wave; grp < ngroups; grp += (int64_t)gridDim.x * kWaves) {
+  // all waves of a workgroup run the same number of iterations (SWAP needs workgroup barriers inside); a wave
+  // without a group of its own recomputes the last group with zero cotangents and writes nothing new
+  for (int64_t g0 = (int64_t)blockIdx.x * kWaves; g0 < ngroups; g0 += (int64_t)gridDim.x * kWaves) {
+    const bool gvalid = g0 + wave < ngroups;
+    const int64_t grp = gvalid ? g0 + wave : ngroups - 1;
     const int64_t el = grp * 16 + j;                 // element index inside the chunk
-    const bool valid = el < a.ecount;
-    const int64_t e = a.e0 + (valid ? el : a.ecount - 1);
+    const bool valid = gvalid && el < a.ecount;
+    const int64_t e = a.e0 + (el < a.ecount ? el : a.ecount - 1);
     const int64_t b = e / a.d, i = e - b * a.d;
     const int64_t hbase = b * a.h_sb + i * a.h_sd;
     f32x4 c1[HT];
@@ -360,7 +376,7 @@ __global__ __launch_bounds__(64 * kWaves) void mono_bwd_k(MonoArgs a) {
         float* sa = a.SA[l] + row * HP + 4 * q;
 #pragma unroll
         for (int t = 0; t < HT; ++t) *reinterpret_cast<f32x4*>(sa + 16 * t) = act[t];
-        const float* W = wp + L.o_W[l];
+        const float* W = SWAP ? load_mat(L.o_W[l]) : wp + L.o_W[l];
         f32x4 o[HT];
 #pragma unroll
         for (int mt = 0; mt < HT; ++mt) o[mt] = ld4(wp + L.o_b[l] + 16 * mt + 4 * q);
@@ -373,7 +389,7 @@ __global__ __launch_bounds__(64 * kWaves) void mono_bwd_k(MonoArgs a) {
             for (int r = 0; r < 4; ++r) o[mt] = mfma(A[r], act[t][r], o[mt]);
           }
           // wide nets: keep the scheduler from hoisting all HT^2 weight fragments (400+ VGPRs) at once
-          if constexpr (WLDS) __builtin_amdgcn_sched_barrier(0);   // LDS-resident weights: bound the fragment hoisting (no spills)
+          if constexpr (WMODE != 0) __builtin_amdgcn_sched_barrier(0);   // LDS weights: bound the fragment hoisting (no spills)
         }
         msk[l] = 0ull;
 #pragma unroll
@@ -417,7 +433,7 @@ __global__ __launch_bounds__(64 * kWaves) void mono_bwd_k(MonoArgs a) {
           *reinterpret_cast<f32x4*>(sd + 16 * t) = dp[t];
           if constexpr (BREG) p_b[l][t] += dp[t];
         }
-        const float* WT = wp + L.o_WT[l];
+        const float* WT = SWAP ? load_mat(L.o_WT[l]) : wp + L.o_WT[l];
         f32x4 da[HT];
 #pragma unroll
         for (int mt = 0; mt < HT; ++mt) da[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -429,7 +445,7 @@ __global__ __launch_bounds__(64 * kWaves) void mono_bwd_k(MonoArgs a) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) da[mt] = mfma(A[r], dp[t][r], da[mt]);
           }
-          if constexpr (WLDS) __builtin_amdgcn_sched_barrier(0);   // LDS-resident weights: bound the fragment hoisting (no spills)
+          if constexpr (WMODE != 0) __builtin_amdgcn_sched_barrier(0);   // LDS weights: bound the fragment hoisting (no spills)
         }
 #pragma unroll
         for (int t = 0; t < HT; ++t)
@@ -577,14 +593,19 @@ int launch_fwd(const MonoArgs& a, hipStream_t s) {
 
 template <int HT, int NH>
 int launch_bwd_one(const MonoArgs& a, unsigned grid, hipStream_t s) {
-  const size_t lds = (size_t)a.L.total_floats * sizeof(float);
-  if constexpr (HT <= 4) {                      // larger images do not fit the 160 KiB LDS: weights stream from L2
-    if (lds > (size_t)150 * 1024) return GNF_ESHAPE;
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mono_bwd_k<HT, NH, true>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL((mono_bwd_k<HT, NH, true>), dim3(grid), dim3(64 * kWaves), lds, s, a);
+  const size_t lds_all = (size_t)a.L.total_floats * sizeof(float);
+  const size_t lds_one = (size_t)a.L.HP * a.L.LDW * sizeof(float);
+  if constexpr (HT <= 4) {                      // whole image resident
+    if (lds_all > (size_t)150 * 1024) return GNF_ESHAPE;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mono_bwd_k<HT, NH, 1>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_all);
+    hipLaunchKernelGGL((mono_bwd_k<HT, NH, 1>), dim3(grid), dim3(64 * kWaves), lds_all, s, a);
+  } else if constexpr (HT <= 10) {              // one matrix at a time
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mono_bwd_k<HT, NH, 2>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_one);
+    hipLaunchKernelGGL((mono_bwd_k<HT, NH, 2>), dim3(grid), dim3(64 * kWaves), lds_one, s, a);
   } else {
-    hipLaunchKernelGGL((mono_bwd_k<HT, NH, false>), dim3(grid), dim3(64 * kWaves), 0, s, a);
+    hipLaunchKernelGGL((mono_bwd_k<HT, NH, 0>), dim3(grid), dim3(64 * kWaves), 0, s, a);
   }
   GNF_LAUNCH_CHECK();
   return 0;
