@@ -328,9 +328,11 @@ int gnf_gemm_launch(GemmArgs g, int splits, hipStream_t s) {
   g.k_per_split = k_per_split(g.K, splits);
   // an accumulating launch must cover every partial written by the first one: exactly `splits` of them
   const int64_t nsp = (g.flags & GNF_GEMM_ACCUM) ? splits : gnf_gemm_num_splits(g.K, splits);
-  // 128x128 tiles once there is >= 2 workgroups per CU of them, else 64x64
-  const int64_t big = ((g.M + 127) / 128) * ((g.N + 127) / 128) * nsp;
-  const int bt = big >= 512 ? 128 : 64;
+  // 128x128 tiles once there are >= 2 workgroups per CU of them, unless 64x64 tiles waste much less padding
+  // (e.g. the 160x160 weight gradients of the wide integrand nets: 192^2 vs 256^2)
+  const int64_t t128 = ((g.M + 127) / 128) * ((g.N + 127) / 128), t64 = ((g.M + 63) / 64) * ((g.N + 63) / 64);
+  const bool pad_heavy = t128 * 4 * 4 > t64 * 5;            // 128-tiling computes > 1.25x the 64-tiling's area
+  const int bt = (t128 * nsp >= 512 && !pad_heavy) ? 128 : 64;
   const int64_t gx = (g.M + bt - 1) / bt, gy = (g.N + bt - 1) / bt;
   if (gy > 65535 || nsp > 65535) return GNF_ESHAPE;
   const dim3 grid((unsigned)gx, (unsigned)gy, (unsigned)nsp);

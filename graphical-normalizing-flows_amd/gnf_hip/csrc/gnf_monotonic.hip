@@ -374,8 +374,10 @@ __global__ __launch_bounds__(64 * kWaves) void mono_bwd_k(MonoArgs a) {
 #pragma unroll
       for (int l = 1; l < NH; ++l) {
         float* sa = a.SA[l] + row * HP + 4 * q;
+        if (gvalid) {                           // a wave re-running the last group must not clobber its owner's rows
 #pragma unroll
-        for (int t = 0; t < HT; ++t) *reinterpret_cast<f32x4*>(sa + 16 * t) = act[t];
+          for (int t = 0; t < HT; ++t) *reinterpret_cast<f32x4*>(sa + 16 * t) = act[t];
+        }
         const float* W = SWAP ? load_mat(L.o_W[l]) : wp + L.o_W[l];
         f32x4 o[HT];
 #pragma unroll
@@ -430,7 +432,7 @@ __global__ __launch_bounds__(64 * kWaves) void mono_bwd_k(MonoArgs a) {
         float* sd = a.SD[l] + row * HP + 4 * q;
 #pragma unroll
         for (int t = 0; t < HT; ++t) {
-          *reinterpret_cast<f32x4*>(sd + 16 * t) = dp[t];
+          if (gvalid) *reinterpret_cast<f32x4*>(sd + 16 * t) = dp[t];
           if constexpr (BREG) p_b[l][t] += dp[t];
         }
         const float* WT = SWAP ? load_mat(L.o_WT[l]) : wp + L.o_WT[l];
@@ -472,7 +474,7 @@ __global__ __launch_bounds__(64 * kWaves) void mono_bwd_k(MonoArgs a) {
 #pragma unroll
     for (int t = 0; t < HT; ++t) {
       if constexpr (BREG) p_b[0][t] += Ds[t];
-      *reinterpret_cast<f32x4*>(ds + 16 * t) = Ds[t];
+      if (gvalid) *reinterpret_cast<f32x4*>(ds + 16 * t) = Ds[t];
     }
     if (valid && q == 0 && a.gx) a.gx[e] = dx;
     const int64_t gbase = b * a.g_sb + i * a.g_sd;

@@ -563,3 +563,29 @@ def test_baseline_configs_train_step(name, B):
     assert abs(ref.item() - loss.item()) < 1e-4 * max(1., abs(loss.item()))
     for k, p in flow.named_parameters():
         assert p.grad is not None and torch.isfinite(p.grad).all(), k
+
+
+@pytest.mark.parametrize("B,d,hidden", [(1, 1, [50, 50, 50]), (3, 7, [50, 50, 50]), (5, 13, [100, 100, 100]),
+                                        (2, 9, [150, 150]), (70, 3, [100, 100, 100])])
+def test_monotonic_ragged_sizes(B, d, hidden):
+    """element counts that leave wavefronts of the last workgroup without a group of their own (and the wide-net
+    weight-swapping mode, whose workgroups iterate in lockstep) -- regression for a staging clobber by tail waves."""
+    from models import MonotonicNormalizer
+    torch.manual_seed(B * 100 + d)
+    c, S = 30, 20
+    norm = MonotonicNormalizer(hidden, c, nb_steps=S)
+    x, h = torch.randn(B, d), torch.randn(B, d, c)
+    layers = [(W.clone().requires_grad_(True), b.clone().requires_grad_(True)) for W, b in _layers_cpu(norm)]
+    xr, hr = x.clone().requires_grad_(True), h.clone().requires_grad_(True)
+    z0, j0 = O.monotonic_forward(xr, hr, layers, S)
+    gz, gj = torch.randn(B, d), torch.randn(B, d)
+    ((z0 * gz).sum() + (j0 * gj).sum()).backward()
+    norm = norm.to(DEV)
+    xg, hg = req(x), req(h)
+    z, jac = norm(xg, hg)
+    assert rel_err(z.cpu(), z0.detach()) < TOL and rel_err(jac.cpu(), j0.detach()) < TOL
+    ((z * cu(gz)).sum() + (jac * cu(gj)).sum()).backward()
+    assert rel_err(xg.grad.cpu(), xr.grad) < GTOL and rel_err(hg.grad.cpu(), hr.grad) < GTOL
+    ps = norm.integrand_net.flat_params()
+    for (W, b), pw, pb in zip(layers, ps[0::2], ps[1::2]):
+        assert rel_err(pw.grad.cpu(), W.grad) < GTOL and rel_err(pb.grad.cpu(), b.grad) < GTOL
