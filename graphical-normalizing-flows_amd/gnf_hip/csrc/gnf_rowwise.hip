@@ -12,6 +12,22 @@ namespace {
 
 constexpr int kBlock = 256;
 
+#define GNF_DISPATCH_GR(G_, R_, KERNEL, grid_rows, ...)                                          \
+  do {                                                                                          \
+    const int rpb__ = (kBlock / (G_)) * (R_);                                                   \
+    const unsigned grid__ = (unsigned)(((grid_rows) + rpb__ - 1) / rpb__);                      \
+    hipStream_t s__ = (hipStream_t)stream;                                                      \
+    switch (G_) {                                                                               \
+      case 1: hipLaunchKernelGGL((KERNEL<1, R_>), dim3(grid__), dim3(kBlock), 0, s__, __VA_ARGS__); break;   \
+      case 2: hipLaunchKernelGGL((KERNEL<2, R_>), dim3(grid__), dim3(kBlock), 0, s__, __VA_ARGS__); break;   \
+      case 4: hipLaunchKernelGGL((KERNEL<4, R_>), dim3(grid__), dim3(kBlock), 0, s__, __VA_ARGS__); break;   \
+      case 8: hipLaunchKernelGGL((KERNEL<8, R_>), dim3(grid__), dim3(kBlock), 0, s__, __VA_ARGS__); break;   \
+      case 16: hipLaunchKernelGGL((KERNEL<16, R_>), dim3(grid__), dim3(kBlock), 0, s__, __VA_ARGS__); break; \
+      case 32: hipLaunchKernelGGL((KERNEL<32, R_>), dim3(grid__), dim3(kBlock), 0, s__, __VA_ARGS__); break; \
+      default: hipLaunchKernelGGL((KERNEL<64, R_>), dim3(grid__), dim3(kBlock), 0, s__, __VA_ARGS__); break; \
+    }                                                                                           \
+  } while (0)
+
 #define GNF_DISPATCH_G(G_, KERNEL, grid_rows, ...)                                              \
   do {                                                                                          \
     const int rpb__ = kBlock / (G_);                                                            \
@@ -31,53 +47,95 @@ constexpr int kBlock = 256;
 __device__ __forceinline__ float clampf(float v, float lo, float hi) { return fminf(fmaxf(v, lo), hi); }
 
 // ------------------------------------------------------------------ Affine normalizer
-template <int G>
+// R rows per lane group per pass: R independent load streams per lane hide the HBM latency at large B; when h is the
+// contiguous [B,d,2] layout its two components are one 8-byte load / store.
+template <int G, int R>
 __global__ void affine_fwd_k(const float* __restrict__ x, float* __restrict__ h, int64_t h_sb, int64_t h_sd,
                              int64_t h_sc, float* __restrict__ z, float* __restrict__ jac,
                              float* __restrict__ logdet, int clamp_inplace, int64_t B, int64_t d) {
-  const int64_t row = (int64_t)blockIdx.x * (kBlock / G) + threadIdx.x / G;
+  const int64_t row0 = ((int64_t)blockIdx.x * (kBlock / G) + threadIdx.x / G) * R;
   const int g = threadIdx.x % G;
-  float ld = 0.f;
-  if (row < B) {
-    for (int64_t i = g; i < d; i += G) {
+  const bool pair = (h_sc == 1 && h_sd == 2 && (h_sb & 1) == 0);
+  float ld[R];
+#pragma unroll
+  for (int k = 0; k < R; ++k) ld[k] = 0.f;
+  for (int64_t i = g; i < d; i += G) {
+    float h0[R], h1[R], xv[R];
+#pragma unroll
+    for (int k = 0; k < R; ++k) {
+      const int64_t row = row0 + k < B ? row0 + k : B - 1;
       const int64_t hi = row * h_sb + i * h_sd;
-      const float mu = clampf(h[hi], -5.f, 5.f);
-      const float ls = clampf(h[hi + h_sc], -5.f, 2.f);
+      if (pair) {
+        const float2 hv = *reinterpret_cast<const float2*>(h + hi);
+        h0[k] = hv.x; h1[k] = hv.y;
+      } else {
+        h0[k] = h[hi]; h1[k] = h[hi + h_sc];
+      }
+      xv[k] = x[row * d + i];
+    }
+#pragma unroll
+    for (int k = 0; k < R; ++k) {
+      if (row0 + k >= B) continue;
+      const int64_t row = row0 + k;
+      const float mu = clampf(h0[k], -5.f, 5.f);
+      const float ls = clampf(h1[k], -5.f, 2.f);
       const float sg = expf(ls);
       const int64_t e = row * d + i;
-      z[e] = fmaf(x[e], sg, mu);
+      z[e] = fmaf(xv[k], sg, mu);
       if (jac) jac[e] = sg;
-      if (clamp_inplace) { h[hi] = mu; h[hi + h_sc] = ls; }
-      ld += ls;
+      if (clamp_inplace) { const int64_t hi = row * h_sb + i * h_sd; h[hi] = mu; h[hi + h_sc] = ls; }
+      ld[k] += ls;
     }
   }
-  ld = group_sum<G>(ld);
-  if (logdet && row < B && g == 0) logdet[row] = ld;
+#pragma unroll
+  for (int k = 0; k < R; ++k) {
+    const float s = group_sum<G>(ld[k]);
+    if (logdet && row0 + k < B && g == 0) logdet[row0 + k] = s;
+  }
 }
 
-template <int G>
+template <int G, int R>
 __global__ void affine_bwd_k(const float* __restrict__ x, const float* __restrict__ h, int64_t h_sb, int64_t h_sd,
                              int64_t h_sc, const float* __restrict__ gz, const float* __restrict__ gjac,
                              const float* __restrict__ glogdet, float* __restrict__ gx, float* __restrict__ gh,
                              int64_t g_sb, int64_t g_sd, int64_t g_sc, int64_t B, int64_t d) {
-  const int64_t row = (int64_t)blockIdx.x * (kBlock / G) + threadIdx.x / G;
+  const int64_t row0 = ((int64_t)blockIdx.x * (kBlock / G) + threadIdx.x / G) * R;
   const int g = threadIdx.x % G;
-  if (row >= B) return;
-  const float gl = glogdet ? glogdet[row] : 0.f;
+  const bool pair = (h_sc == 1 && h_sd == 2 && (h_sb & 1) == 0);
+  const bool gpair = (g_sc == 1 && g_sd == 2 && (g_sb & 1) == 0);
   for (int64_t i = g; i < d; i += G) {
-    const int64_t hi = row * h_sb + i * h_sd;
-    const float h0 = h[hi], h1 = h[hi + h_sc];
-    // torch clamp backward passes the gradient where min <= v <= max (boundaries included)
-    const float m0 = (h0 >= -5.f && h0 <= 5.f) ? 1.f : 0.f;
-    const float m1 = (h1 >= -5.f && h1 <= 2.f) ? 1.f : 0.f;
-    const float sg = expf(clampf(h1, -5.f, 2.f));
-    const int64_t e = row * d + i;
-    const float g_z = gz ? gz[e] : 0.f;
-    const float g_j = gjac ? gjac[e] : 0.f;
-    if (gx) gx[e] = g_z * sg;
-    const int64_t gi = row * g_sb + i * g_sd;
-    gh[gi] = g_z * m0;
-    gh[gi + g_sc] = (fmaf(g_z * x[e], sg, g_j * sg) + gl) * m1;
+    float h0[R], h1[R], xv[R], gzv[R], gjv[R];
+#pragma unroll
+    for (int k = 0; k < R; ++k) {
+      const int64_t row = row0 + k < B ? row0 + k : B - 1;
+      const int64_t hi = row * h_sb + i * h_sd;
+      if (pair) {
+        const float2 hv = *reinterpret_cast<const float2*>(h + hi);
+        h0[k] = hv.x; h1[k] = hv.y;
+      } else {
+        h0[k] = h[hi]; h1[k] = h[hi + h_sc];
+      }
+      const int64_t e = row * d + i;
+      xv[k] = x[e];
+      gzv[k] = gz ? gz[e] : 0.f;
+      gjv[k] = gjac ? gjac[e] : 0.f;
+    }
+#pragma unroll
+    for (int k = 0; k < R; ++k) {
+      if (row0 + k >= B) continue;
+      const int64_t row = row0 + k;
+      const float gl = glogdet ? glogdet[row] : 0.f;
+      // torch clamp backward passes the gradient where min <= v <= max (boundaries included)
+      const float m0 = (h0[k] >= -5.f && h0[k] <= 5.f) ? 1.f : 0.f;
+      const float m1 = (h1[k] >= -5.f && h1[k] <= 2.f) ? 1.f : 0.f;
+      const float sg = expf(clampf(h1[k], -5.f, 2.f));
+      const int64_t e = row * d + i;
+      if (gx) gx[e] = gzv[k] * sg;
+      const int64_t gi = row * g_sb + i * g_sd;
+      const float o0 = gzv[k] * m0, o1 = (fmaf(gzv[k] * xv[k], sg, gjv[k] * sg) + gl) * m1;
+      if (gpair) *reinterpret_cast<float2*>(gh + gi) = make_float2(o0, o1);
+      else { gh[gi] = o0; gh[gi + g_sc] = o1; }
+    }
   }
 }
 
@@ -242,7 +300,8 @@ int gnf_affine_fwd(const float* x, float* h, int64_t h_sb, int64_t h_sd, int64_t
   if (!x || !h || !z || B < 0 || d <= 0) return GNF_EINVAL;
   if (B == 0) return 0;
   const int G = gnf_pow2_ge(d, 64);
-  GNF_DISPATCH_G(G, affine_fwd_k, B, x, h, h_sb, h_sd, h_sc, z, jac, logdet, clamp_inplace, B, d);
+  if (B * d >= (1 << 20)) GNF_DISPATCH_GR(G, 4, affine_fwd_k, B, x, h, h_sb, h_sd, h_sc, z, jac, logdet, clamp_inplace, B, d);
+  else GNF_DISPATCH_GR(G, 1, affine_fwd_k, B, x, h, h_sb, h_sd, h_sc, z, jac, logdet, clamp_inplace, B, d);
   GNF_LAUNCH_CHECK();
   return 0;
 }
@@ -253,7 +312,8 @@ int gnf_affine_bwd(const float* x, const float* h, int64_t h_sb, int64_t h_sd, i
   if (!x || !h || !gh || B < 0 || d <= 0) return GNF_EINVAL;
   if (B == 0) return 0;
   const int G = gnf_pow2_ge(d, 64);
-  GNF_DISPATCH_G(G, affine_bwd_k, B, x, h, h_sb, h_sd, h_sc, gz, gjac, glogdet, gx, gh, g_sb, g_sd, g_sc, B, d);
+  if (B * d >= (1 << 20)) GNF_DISPATCH_GR(G, 4, affine_bwd_k, B, x, h, h_sb, h_sd, h_sc, gz, gjac, glogdet, gx, gh, g_sb, g_sd, g_sc, B, d);
+  else GNF_DISPATCH_GR(G, 1, affine_bwd_k, B, x, h, h_sb, h_sd, h_sc, gz, gjac, glogdet, gx, gh, g_sb, g_sd, g_sc, B, d);
   GNF_LAUNCH_CHECK();
   return 0;
 }

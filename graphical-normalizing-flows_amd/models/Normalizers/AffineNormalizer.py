@@ -20,7 +20,7 @@ class AffineNormalizer(Normalizer):
 
     def forward_logdet(self, x, h, context=None):
         """(z, log|det J|) with the row reduction fused (used by NormalizingFlowStep)."""
-        z, _, logdet = ops.AffineFn.apply(x, h, self.inplace_clamp)
+        z, _, logdet = ops.AffineFn.apply(x, h, self.inplace_clamp, False)
         return z, logdet
 
     def inverse_transform(self, z, h, context=None):

@@ -52,7 +52,7 @@ def main():
         x = torch.randn(B, d, device=DEV, requires_grad=True)
         h = torch.randn(B, d, 2, device=DEV, requires_grad=True)
         with torch.no_grad():
-            hbm("affine_fwd", [B, d], timeit(lambda: ops.AffineFn.apply(x, h)), 16. * B * d + 4 * B)
+            hbm("affine_fwd(z,logdet)", [B, d], timeit(lambda: ops.AffineFn.apply(x, h, False, False)), 16. * B * d + 4 * B)
         z, jac, ld = ops.AffineFn.apply(x, h)
         gz, gl = torch.randn_like(z), torch.randn_like(ld)
         hbm("affine_bwd", [B, d], timeit(lambda: torch.autograd.grad((z, ld), (x, h), (gz, gl), retain_graph=True)),
