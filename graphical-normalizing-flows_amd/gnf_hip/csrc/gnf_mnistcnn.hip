@@ -401,6 +401,10 @@ __global__ __launch_bounds__(64 * BWD_WAVES) void cnn_bwd_k(CnnArgs a) {
             accA = mfma(w2t[g * 9 + ky * 3 + kx], pA[o], accA);
             accB = mfma(w2t[g * 9 + ky * 3 + kx], pB[o], accB);     // tile 43 does not exist: masked below
           }
+#ifdef GNF_CNN_EXP_NOEPI
+      asm volatile("" ::"v"(accA[0]), "v"(accA[1]), "v"(accA[2]), "v"(accA[3]), "v"(accB[0]), "v"(accB[1]), "v"(accB[2]), "v"(accB[3]));
+      if (false)
+#endif
 #pragma unroll
       for (int half = 0; half < 2; ++half) {
         const bool ok = half ? okB : okA;
