@@ -137,7 +137,8 @@ class DAGConditioner(Conditioner):
     def get_power_trace(self):
         """tr((I + alpha A∘A)^k) - d (:176-194).  d x d matrix power on rocBLAS through torch:
         <1% of a step and a function of the parameters only."""
-        alpha = min(1., self.alpha) * self.alpha_factor      # out-of-place (the reference's `*=` edits the buffer)
+        # min(1., alpha) as a tensor op: Python's min() on a device tensor forces a host<->GPU sync every step
+        alpha = torch.clamp(self.alpha, max=1.) * self.alpha_factor
         if self.hutchinson != 0:
             raise NotImplementedError("Hutchinson trace estimator is never enabled by the reference")
         B = (torch.eye(self.in_size, device=self.A.device) + alpha * self.A ** 2)
