@@ -176,6 +176,13 @@ int gnf_adam_step(float* p, const float* g, float* m, float* v, int64_t n,
                   float lr, float beta1, float beta2, float eps, float weight_decay,
                   float grad_scale, int step, gnf_stream_t stream);
 
+/* ---- device-ceiling probes (measurement aids for bench.py) ---------------
+ * gnf_probe_mfma_f32 launches `blocks` workgroups of 8 wavefronts that do nothing but
+ * independent v_mfma_f32_16x16x4_f32 chains and returns the number of flops the launch issues
+ * (negative on error); gnf_probe_copy is a STREAM copy of n floats (n % 4 == 0). */
+int64_t gnf_probe_mfma_f32(float* out, int iters, int blocks, gnf_stream_t stream);
+int gnf_probe_copy(float* dst, const float* src, int64_t n, gnf_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif
