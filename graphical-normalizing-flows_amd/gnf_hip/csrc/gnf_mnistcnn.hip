@@ -203,6 +203,177 @@ __global__ __launch_bounds__(64 * FWD_WAVES) void cnn_fwd_k(CnnArgs a) {
 #endif
 }
 
+// ---------------------------------------------------------------------------------------------
+// Forward with conv2 as Winograd F(2x2,3x3): 2.25x fewer MFMAs than the implicit GEMM above.
+//   Y = A^T [ sum_c (G w G^T)_c (.) (B^T d_c B) ] A  per 2x2 output tile, d = 4x4 input patch.
+// The 2x2 output tile IS the pool window, so pooling happens in registers of one lane.
+// GEMM view per transform point xi (16 of them): M_xi[o][tile] = sum_c U_xi[o][c] V_xi[c][tile];
+//   A operand = U_xi (transformed weights, 64 registers per lane, resident for the whole kernel),
+//   B operand = V_xi computed by the lane itself from its 4x4 patch (8 ds_read_b64 + 32 adds feed 16 MFMAs),
+//   D: lane (q,j) holds out-channels 4q..4q+3 of tile j for all 16 xi -> the output transform is lane-local.
+// A workgroup handles two images per iteration (18 groups of 16 tiles over 8 wavefronts: 5/5/4/4 per SIMD).
+// ---------------------------------------------------------------------------------------------
+constexpr int A1SZ = NCH * CH;
+
+__global__ __launch_bounds__(64 * FWD_WAVES) void cnn_fwd_wino_k(CnnArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* e_s = smem;                       // [2][ESZ]
+  float* a1_s = smem + 2 * ESZ;            // [2][16][26][ROW]
+  const int tid = threadIdx.x, lane = tid & 63, q = lane >> 4, j = lane & 15;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  constexpr int NW = FWD_WAVES, NT = 64 * FWD_WAVES;
+
+  float w1f[3];
+  int off1[3];
+#pragma unroll
+  for (int s = 0; s < 3; ++s) {
+    const int tap = 4 * s + q;
+    w1f[s] = tap < 9 ? a.W1[j * 9 + tap] : 0.f;
+    const int tt = tap < 9 ? tap : 0;
+    off1[s] = (tt / 3) * ROWE + tt % 3;
+  }
+  f32x4 b1v, b2v;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) { b1v[r] = a.b1[4 * q + r]; b2v[r] = a.b2[4 * q + r]; }
+
+  // U = G w G^T of W2[o = j][c = 4g+q], G = [[1,0,0],[.5,.5,.5],[.5,-.5,.5],[0,0,1]]; fp64 once, rounded to fp32
+  float uw[64];
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    const float* w = a.W2 + (j * NCH + 4 * g + q) * 9;
+    double gw[4][3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const double w0 = w[c], w1 = w[3 + c], w2 = w[6 + c];
+      gw[0][c] = w0; gw[1][c] = 0.5 * (w0 + w1 + w2); gw[2][c] = 0.5 * (w0 - w1 + w2); gw[3][c] = w2;
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      uw[(4 * r + 0) * 4 + g] = (float)gw[r][0];
+      uw[(4 * r + 1) * 4 + g] = (float)(0.5 * (gw[r][0] + gw[r][1] + gw[r][2]));
+      uw[(4 * r + 2) * 4 + g] = (float)(0.5 * (gw[r][0] - gw[r][1] + gw[r][2]));
+      uw[(4 * r + 3) * 4 + g] = (float)gw[r][2];
+    }
+  }
+
+  for (int i = tid; i < 2 * ESZ; i += NT) e_s[i] = 0.f;
+
+  const int64_t npair = (a.n + 1) >> 1;
+  constexpr int EPT = (2 * IMG * IMG + NT - 1) / NT;          // pixels of an image pair per thread
+  float pre[EPT];
+  auto fetch = [&](int64_t pair) {
+#pragma unroll
+    for (int k = 0; k < EPT; ++k) {
+      const int i = tid + k * NT;
+      const int64_t o = pair * (2 * IMG * IMG) + i;
+      pre[k] = (pair < npair && i < 2 * IMG * IMG && o < a.n * (IMG * IMG)) ? a.e[o] : 0.f;
+    }
+  };
+  fetch(blockIdx.x);
+  for (int64_t pair = blockIdx.x; pair < npair; pair += gridDim.x) {
+    __syncthreads();                                   // previous pair fully consumed
+#pragma unroll
+    for (int k = 0; k < EPT; ++k) {
+      const int i = tid + k * NT;
+      if (i < 2 * IMG * IMG) {
+        const int s = i >= IMG * IMG, p = i - s * (IMG * IMG);
+        e_s[s * ESZ + (p / IMG) * ROWE + p % IMG] = pre[k];
+      }
+    }
+    __syncthreads();
+    fetch(pair + gridDim.x);                           // next pair's pixels: in flight under the MFMAs
+
+    // conv1 + ReLU of both images: 86 tiles of 16 consecutive positions, up to 6 in flight per wavefront
+#pragma unroll
+    for (int k0 = 0; k0 < 12; k0 += 6) {
+      int po[6];
+      f32x4 acc[6];
+      float ev[6][3];
+#pragma unroll
+      for (int k = 0; k < 6; ++k) {
+        const int tile = wave + NW * (k0 + k);         // wave-uniform
+        const int s = tile >= 43, pos = 16 * (tile - 43 * s) + j;
+        const bool ok = tile < 86 && pos < C1 * C1;
+        const int pc = ok ? pos : 0;
+        const int y = pc / C1, x = pc - y * C1;
+        po[k] = ok ? s * A1SZ + y * ROW + x : -1;
+#pragma unroll
+        for (int t = 0; t < 3; ++t) ev[k][t] = e_s[(tile < 86 ? s : 0) * ESZ + y * ROWE + x + off1[t]];
+        acc[k] = b1v;
+      }
+#pragma unroll
+      for (int t = 0; t < 3; ++t)
+#pragma unroll
+        for (int k = 0; k < 6; ++k) acc[k] = mfma(w1f[t], ev[k][t], acc[k]);
+#pragma unroll
+      for (int k = 0; k < 6; ++k)
+        if (po[k] >= 0) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) a1_s[(4 * q + r) * CH + po[k]] = fmaxf(acc[k][r], 0.f);
+        }
+    }
+    __syncthreads();
+
+#pragma nounroll
+    for (int item = wave; item < 18; item += NW) {
+      const int s = item >= 9, grp = item - 9 * s;     // wave-uniform
+      const int64_t img = 2 * pair + s;
+      if (img >= a.n) continue;
+      const int t = 16 * grp + j, ty = t / 12, tx = t - 12 * ty;
+      const float* base = a1_s + s * A1SZ + q * CH + 2 * ty * ROW + 2 * tx;
+      f32x4 acc[16];
+#pragma unroll
+      for (int xi = 0; xi < 16; ++xi) acc[xi] = f32x4{0.f, 0.f, 0.f, 0.f};
+      acc[5] = b2v;                                    // xi = (1,1) reaches all four outputs with weight +1: the bias
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const float* p = base + 4 * g * CH;
+        float d[4][4];
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+          const float2 lo = *reinterpret_cast<const float2*>(p + rr * ROW);
+          const float2 hi = *reinterpret_cast<const float2*>(p + rr * ROW + 2);
+          d[rr][0] = lo.x; d[rr][1] = lo.y; d[rr][2] = hi.x; d[rr][3] = hi.y;
+        }
+        float tt[4][4];                                // B^T d
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          tt[0][c] = d[0][c] - d[2][c]; tt[1][c] = d[1][c] + d[2][c];
+          tt[2][c] = d[2][c] - d[1][c]; tt[3][c] = d[1][c] - d[3][c];
+        }
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {               // (B^T d) B, fed straight into the 4 MFMAs of this row
+          const float v0 = tt[rr][0] - tt[rr][2], v1 = tt[rr][1] + tt[rr][2];
+          const float v2 = tt[rr][2] - tt[rr][1], v3 = tt[rr][1] - tt[rr][3];
+          acc[4 * rr + 0] = mfma(uw[(4 * rr + 0) * 4 + g], v0, acc[4 * rr + 0]);
+          acc[4 * rr + 1] = mfma(uw[(4 * rr + 1) * 4 + g], v1, acc[4 * rr + 1]);
+          acc[4 * rr + 2] = mfma(uw[(4 * rr + 2) * 4 + g], v2, acc[4 * rr + 2]);
+          acc[4 * rr + 3] = mfma(uw[(4 * rr + 3) * 4 + g], v3, acc[4 * rr + 3]);
+        }
+      }
+      // output transform A^T M A (A^T = [[1,1,1,0],[0,1,-1,-1]]) + 2x2 max pool, lane-local
+      const int64_t ob = img * NPOOL + 4 * q * (PO * PO) + t;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float s0[4], s1[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          s0[c] = acc[c][r] + acc[4 + c][r] + acc[8 + c][r];
+          s1[c] = acc[4 + c][r] - acc[8 + c][r] - acc[12 + c][r];
+        }
+        const float v00 = s0[0] + s0[1] + s0[2], v01 = s0[1] - s0[2] - s0[3];
+        const float v10 = s1[0] + s1[1] + s1[2], v11 = s1[1] - s1[2] - s1[3];
+        float best = v00; int bi = 0;                  // first max wins ties (torch max_pool2d order)
+        if (v01 > best) { best = v01; bi = 1; }
+        if (v10 > best) { best = v10; bi = 2; }
+        if (v11 > best) { best = v11; bi = 3; }
+        a.pooled[ob + r * (PO * PO)] = best;
+        a.arg[ob + r * (PO * PO)] = (unsigned char)bi;
+      }
+    }
+  }
+}
+
 // dY2 planes: channel pairs sit PS dwords apart, the two channels of a pair CHD (== 16 mod 32) apart, so that
 //  - the dW2 A-operand read (16 channels x 2 consecutive positions per 32-lane group) and
 //  - the da1 B-operand gather (2 channels x 16 consecutive positions per 32-lane group)
@@ -492,6 +663,8 @@ __global__ void cnn_unpack_k(const float* __restrict__ vec, float* gW1, float* g
 }
 
 constexpr size_t kFwdLds = (size_t)(ESZ + NCH * CH) * sizeof(float);
+constexpr size_t kWinoLds = (size_t)(2 * ESZ + 2 * A1SZ) * sizeof(float);
+constexpr unsigned kWinoGrid = 256;                  // one 8-wave workgroup per CU, two images per iteration
 constexpr size_t kBwdLds = (size_t)(ESZ + NCH * CH + DSZ) * sizeof(float);
 // one 8-wave workgroup per CU: at its 128 VGPRs a second one is not admitted (measured with tools/census.hip and
 // the occupancy API; the 96-VGPR variant that admits two spills and is slower)
@@ -529,10 +702,18 @@ int gnf_mnistcnn_conv_fwd(const float* e, const float* W1, const float* b1, cons
   if (n_img == 0) return 0;
   CnnArgs a{};
   a.e = e; a.W1 = W1; a.b1 = b1; a.W2 = W2; a.b2 = b2; a.pooled = pooled; a.arg = argmax; a.n = n_img;
+#ifdef GNF_CNN_DIRECT_FWD
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&cnn_fwd_k), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)kFwdLds);
   const unsigned grid = n_img < kFwdGrid ? (unsigned)n_img : kFwdGrid;
   hipLaunchKernelGGL(cnn_fwd_k, dim3(grid), dim3(64 * FWD_WAVES), kFwdLds, (hipStream_t)stream, a);
+#else
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&cnn_fwd_wino_k),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)kWinoLds);
+  const int64_t npair = (n_img + 1) / 2;
+  const unsigned grid = npair < kWinoGrid ? (unsigned)npair : kWinoGrid;
+  hipLaunchKernelGGL(cnn_fwd_wino_k, dim3(grid), dim3(64 * FWD_WAVES), kWinoLds, (hipStream_t)stream, a);
+#endif
   GNF_LAUNCH_CHECK();
   return 0;
 }
