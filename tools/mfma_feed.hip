@@ -1,0 +1,61 @@
+// Microbenchmark: v_mfma_f32_16x16x4_f32 whose B operand is produced by a VALU op right before it (Winograd input
+// transform pattern) vs. operands produced in a batch ahead of the MFMAs.  One workgroup per CU; cycles per MFMA per wave.
+#include <hip/hip_runtime.h>
+#include <cstdio>
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+template <int MODE>
+__global__ void k(float* out, long long* cyc, int iters, float seed) {
+  f32x4 acc[16];
+  float a = threadIdx.x * 1e-3f, t[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) t[i] = seed * (i + 1) + i * i + threadIdx.x;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) acc[i] = f32x4{(float)i, 0.f, seed, 0.f};
+  const long long t0 = __builtin_readcyclecounter();
+  for (int it = 0; it < iters; ++it) {
+    if (MODE == 0) {            // constant operands
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, t[i], acc[i], 0, 0, 0);
+    } else if (MODE == 1) {     // VALU result consumed by the very next MFMA
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const float v = t[i] - t[(i + 3) & 15];
+        acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, v, acc[i], 0, 0, 0);
+      }
+#pragma unroll
+      for (int i = 0; i < 16; ++i) t[i] += 1.0f;
+    } else {                    // 16 operands computed ahead, then 16 MFMAs
+      float v[16];
+#pragma unroll
+      for (int i = 0; i < 16; ++i) v[i] = t[i] - t[(i + 3) & 15];
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, v[i], acc[i], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int i = 0; i < 16; ++i) t[i] += 1.0f;
+    }
+  }
+  const long long t1 = __builtin_readcyclecounter();
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
+  out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+  if (threadIdx.x == 0 && blockIdx.x == 0) cyc[0] = t1 - t0;
+}
+template <int MODE>
+void run(int threads) {
+  float* out; long long* cyc; hipMalloc(&out, 256 * 1024 * 4); hipMalloc(&cyc, 8);
+  const int iters = 2000;
+  for (int r = 0; r < 2; ++r) hipLaunchKernelGGL(k<MODE>, dim3(256), dim3(threads), 0, 0, out, cyc, iters, 1.0f);
+  hipDeviceSynchronize();
+  long long c; hipMemcpy(&c, cyc, 8, hipMemcpyDeviceToHost);
+  printf("mode=%d waves/SIMD=%d : %.1f cycles per MFMA per wave (pipe: %.1f)\n", MODE, threads / 256,
+         (double)c / (iters * 16.0), (double)c / (iters * 16.0) / (threads / 256));
+  hipFree(out); hipFree(cyc);
+}
+int main() {
+  run<0>(256); run<1>(256); run<2>(256);
+  run<0>(512); run<1>(512); run<2>(512);
+  return 0;
+}
