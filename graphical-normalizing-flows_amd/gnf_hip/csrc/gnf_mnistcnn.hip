@@ -649,6 +649,385 @@ __global__ __launch_bounds__(64 * BWD_WAVES) void cnn_bwd_k(CnnArgs a) {
   if (lane < NCH && (lane >> 1) != wave) prow[NCH * 144 + NCH * 16 + lane] = 0.f;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Backward with both conv2-sized contractions in the Winograd F(2x2,3x3) domain (2.25x fewer MFMAs):
+//   forward   Y = A^T [ sum_c U[o][c] (.) V[c] ] A,  U = G w G^T,  V = B^T d B   (d = 4x4 patch of a1)
+//   dW2:      dU[o][c] = sum_tiles (A dY A^T)[o] (.) V[c],  dw = G^T dU G once at the end of the kernel.
+//             The 2x2 output tile is the pool window, so dY has ONE non-zero g at the saved argmax (py,px):
+//             A dY A^T = g * alpha_py alpha_px^T with alpha_0 = (1,1,1,0), alpha_1 = (0,1,-1,-1) -- read
+//             straight from g_pooled/argmax, no transform.  GEMM per xi: M = o, N = c, K = tiles (144/image).
+//   da1:      a 3x3 valid correlation of the zero-bordered dY2 (28x28) with the flipped kernel
+//             w'[c][o][a][b] = W2[o][c][2-a][2-b] -> 13x13 tiles of 2x2; U' = G w' G^T lives in LDS (A operand),
+//             the lane transforms its own dY2 patch (B operand); the output transform, ReLU gate, dW1/db1
+//             partials and the per-tap planes T are lane-local as in the direct kernel.
+// conv1 is recomputed in the same tile -> lane mapping (lane (q,j): channels 4q..4q+3 of tile j, 4 sub-positions),
+// so its ReLU gate bits stay in registers for da1.
+// ---------------------------------------------------------------------------------------------
+constexpr int NG4 = 11;                              // groups of 16 da1 tiles (13 x 13 = 169 tiles of 2x2)
+constexpr int USZ = 16 * 4 * 64;                     // U' as [xi_y][g][lane][xi_x]
+// a1 channel stride of this kernel: the dW2 gather reads 16 CHANNELS x one 8-byte column pair per 16-lane group,
+// so CHB*j mod 64 must be 16 distinct even banks (CHB = 2 * odd); with CH = 1040 the gather is 4-way conflicted
+// and the phase LDS-bound (measured: 4.4k of 11.5k cycles)
+constexpr int CHB = 1042;
+
+__global__ __launch_bounds__(64 * BWD_WAVES) void cnn_bwd_wino_k(CnnArgs a) {
+#ifdef GNF_CNN_TIMING
+  long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  long long tlast = __builtin_readcyclecounter();
+#endif
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* e_s = smem;
+  float* a1_s = smem + ESZ;                 // conv1 activations; reused for the per-tap planes T after dW2
+  float* d_s = a1_s + NCH * CHB;            // dY2 with a 2-wide zero border
+  float* u_s = d_s + DSZ;                   // U' (16-B aligned: ESZ, NCH*CH and DSZ are multiples of 4)
+  float* T_s = a1_s;
+  const int tid = threadIdx.x, lane = tid & 63, q = lane >> 4, j = lane & 15;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  constexpr int NW = BWD_WAVES, NT = 64 * BWD_WAVES;
+  static_assert((ESZ % 4 == 0) && ((NCH * CHB) % 4 == 0) && (DSZ % 4 == 0), "u_s must be 16-B aligned");
+
+  float w1f[3];
+  int off1[3];
+#pragma unroll
+  for (int s = 0; s < 3; ++s) {
+    const int tap = 4 * s + q;
+    w1f[s] = tap < 9 ? a.W1[j * 9 + tap] : 0.f;
+    const int tt = tap < 9 ? tap : 0;
+    off1[s] = (tt / 3) * ROWE + tt % 3;
+  }
+  f32x4 b1v;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) b1v[r] = a.b1[4 * q + r];
+  float w1t[4];                              // W1^T as A operand of the per-tap planes: row = tap j, K slot q, step r
+#pragma unroll
+  for (int r = 0; r < 4; ++r) w1t[r] = j < 9 ? a.W1[(4 * q + r) * 9 + j] : 0.f;
+
+  // U'[c = j][o = 4g+q] = G w' G^T, w'[a][b] = W2[o][c][2-a][2-b]; fp64 once, stored for ds_read_b128 per (xi_y, g)
+  if (wave == 0) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const float* w = a.W2 + ((4 * g + q) * NCH + j) * 9;
+      double gw[4][3];
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        const double w0 = w[8 - c], w1 = w[5 - c], w2 = w[2 - c];       // rows a = 0,1,2 of the flipped kernel, column b = c
+        gw[0][c] = w0; gw[1][c] = 0.5 * (w0 + w1 + w2); gw[2][c] = 0.5 * (w0 - w1 + w2); gw[3][c] = w2;
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        f32x4 u;
+        u[0] = (float)gw[r][0];
+        u[1] = (float)(0.5 * (gw[r][0] + gw[r][1] + gw[r][2]));
+        u[2] = (float)(0.5 * (gw[r][0] - gw[r][1] + gw[r][2]));
+        u[3] = (float)gw[r][2];
+        *reinterpret_cast<f32x4*>(u_s + ((r * 4 + g) * 64 + lane) * 4) = u;
+      }
+    }
+  }
+
+  f32x4 dU[16];                              // dU_xi[o = 4q+r][c = j], summed over all images of this wavefront
+#pragma unroll
+  for (int xi = 0; xi < 16; ++xi) dU[xi] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float gW1p[4][10];                         // dW1 / db1 per-lane partials: channel 4q+r, tap k (k = 9: bias)
+#pragma unroll
+  for (int r = 0; r < 4; ++r)
+#pragma unroll
+    for (int k = 0; k < 10; ++k) gW1p[r][k] = 0.f;
+  float gb2 = 0.f;                           // thread tid accumulates channel tid/32
+
+  for (int i = tid; i < ESZ; i += NT) e_s[i] = 0.f;
+  for (int i = tid; i < DSZ; i += NT) d_s[i] = 0.f;
+
+  constexpr int EPT = (IMG * IMG + NT - 1) / NT, WPT = (PO * PO + 31) / 32;
+  float epre[EPT], gpre[WPT];
+  unsigned apre;                             // WPT argmax codes, 2 bits each
+  auto prefetch = [&](int64_t im) {
+    const bool on = im < a.n;
+#pragma unroll
+    for (int k = 0; k < EPT; ++k) {
+      const int i = tid + k * NT;
+      epre[k] = (on && i < IMG * IMG) ? a.e[im * (IMG * IMG) + i] : 0.f;
+    }
+    apre = 0u;
+#pragma unroll
+    for (int k = 0; k < WPT; ++k) {
+      const int w = (tid & 31) + 32 * k;
+      const bool ok = on && w < PO * PO;
+      const int64_t o = im * NPOOL + (tid >> 5) * (PO * PO) + w;
+      gpre[k] = ok ? a.gp[o] : 0.f;
+      apre |= (ok ? (unsigned)a.argin[o] : 0u) << (2 * k);
+    }
+  };
+  prefetch(blockIdx.x);
+
+  for (int64_t img = blockIdx.x; img < a.n; img += gridDim.x) {
+    __syncthreads();
+    // ---- P0: image, and dY2 = pool-backward scatter of g_pooled (one write per conv2 position)
+#pragma unroll
+    for (int k = 0; k < EPT; ++k) {
+      const int i = tid + k * NT;
+      if (i < IMG * IMG) e_s[(i / IMG) * ROWE + i % IMG] = epre[k];
+    }
+#pragma unroll
+    for (int k = 0; k < WPT; ++k) {
+      const int w = (tid & 31) + 32 * k;
+      if (w < PO * PO) {
+        const float g = gpre[k];
+        const int am = (int)((apre >> (2 * k)) & 3u);
+        gb2 += g;
+        float* p = d_s + based(tid >> 5) + (2 * (w / PO) + 2) * ROWD + 2 * (w % PO) + 2;
+        p[0] = am == 0 ? g : 0.f;
+        p[1] = am == 1 ? g : 0.f;
+        p[ROWD] = am == 2 ? g : 0.f;
+        p[ROWD + 1] = am == 3 ? g : 0.f;
+      }
+    }
+    __syncthreads();
+    prefetch(img + gridDim.x);
+    TSTAMP(0);
+    // ---- P1: conv1 + ReLU in the 2x2-tile layout: group grp = wave + 8k, 4 sub-positions = 4 MFMA chains
+    unsigned gate = 0u;
+#pragma nounroll
+    for (int k = 0; k < 2; ++k) {
+      const int grp = wave + NW * k;                            // wave-uniform
+      if (grp < NG4) {
+        const int t = 16 * grp + j;
+        const bool ok = t < 169;
+        const int tc = ok ? t : 0, ty = tc / 13, tx = tc - 13 * ty;
+        f32x4 acc[4];
+        float ev[4][3];
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+#pragma unroll
+          for (int s = 0; s < 3; ++s) ev[p][s] = e_s[(2 * ty + (p >> 1)) * ROWE + 2 * tx + (p & 1) + off1[s]];
+          acc[p] = b1v;
+        }
+#pragma unroll
+        for (int s = 0; s < 3; ++s)
+#pragma unroll
+          for (int p = 0; p < 4; ++p) acc[p] = mfma(w1f[s], ev[p][s], acc[p]);
+        if (ok) {
+#pragma unroll
+          for (int p = 0; p < 4; ++p)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              a1_s[(4 * q + r) * CHB + (2 * ty + (p >> 1)) * ROW + 2 * tx + (p & 1)] = fmaxf(acc[p][r], 0.f);
+              if (acc[p][r] > 0.f) gate |= 1u << (16 * k + 4 * p + r);
+            }
+        }
+      }
+    }
+    __syncthreads();
+    TSTAMP(1);
+    // ---- P3: dU_xi[o][c] += sum_tiles Z_xi[o][tile] V_xi[c][tile]; K-step s = 4 tiles, s = wave, wave+8, ...
+    //      Z = A dY A^T from the 2x2 window of dY2 in LDS (A = [[1,0],[1,1],[1,-1],[0,-1]])
+#pragma nounroll
+    for (int s = wave; s < 36; s += NW) {
+      const int T = 4 * s + q, ty = T / 12, tx = T - 12 * ty;
+      const float* p = a1_s + j * CHB + 2 * ty * ROW + 2 * tx;
+      const float* pz = d_s + based(j) + (2 * ty + 2) * ROWD + 2 * tx + 2;
+#ifdef GNF_EXP_P3_NOLDS
+      const float2 y0 = make_float2(__int_as_float(s), __int_as_float(T)), y1 = make_float2(__int_as_float(ty), __int_as_float(tx));
+      float d[4][4];
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) d[rr][c] = __int_as_float(T + rr * 4 + c + (int)(p - a1_s) + (int)(pz - d_s));
+#else
+      const float2 y0 = *reinterpret_cast<const float2*>(pz);
+      const float2 y1 = *reinterpret_cast<const float2*>(pz + ROWD);
+      float d[4][4];
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr) {
+        const float2 lo = *reinterpret_cast<const float2*>(p + rr * ROW);
+        const float2 hi = *reinterpret_cast<const float2*>(p + rr * ROW + 2);
+        d[rr][0] = lo.x; d[rr][1] = lo.y; d[rr][2] = hi.x; d[rr][3] = hi.y;
+      }
+#endif
+      float tt[4][4];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        tt[0][c] = d[0][c] - d[2][c]; tt[1][c] = d[1][c] + d[2][c];
+        tt[2][c] = d[2][c] - d[1][c]; tt[3][c] = d[1][c] - d[3][c];
+      }
+      float zr[4][2];                                           // A dY
+      zr[0][0] = y0.x; zr[0][1] = y0.y; zr[1][0] = y0.x + y1.x; zr[1][1] = y0.y + y1.y;
+      zr[2][0] = y0.x - y1.x; zr[2][1] = y0.y - y1.y; zr[3][0] = -y1.x; zr[3][1] = -y1.y;
+      // all 32 operands first, then 16 back-to-back MFMAs: VALU and MFMA of ONE wavefront do not overlap
+      // (tools/mfma_feed.hip), so a VALU op in front of every MFMA would stall the pipe for both wavefronts
+      float vv[16], zz[16];
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr) {
+        vv[4 * rr + 0] = tt[rr][0] - tt[rr][2]; vv[4 * rr + 1] = tt[rr][1] + tt[rr][2];
+        vv[4 * rr + 2] = tt[rr][2] - tt[rr][1]; vv[4 * rr + 3] = tt[rr][1] - tt[rr][3];
+        zz[4 * rr + 0] = zr[rr][0]; zz[4 * rr + 1] = zr[rr][0] + zr[rr][1];
+        zz[4 * rr + 2] = zr[rr][0] - zr[rr][1]; zz[4 * rr + 3] = -zr[rr][1];
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#ifdef GNF_EXP_P3_NOMFMA
+#pragma unroll
+      for (int xi = 0; xi < 16; ++xi) dU[xi][0] += zz[xi] * vv[xi];
+#else
+#pragma unroll
+      for (int xi = 0; xi < 16; ++xi) dU[xi] = mfma(zz[xi], vv[xi], dU[xi]);
+#endif
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    __syncthreads();                                           // a1 as dW2 operand is done: region becomes T
+    TSTAMP(2);
+    // ---- P4: dpre1 = conv2^T(dY2) * gate, 2x2 tiles; xi_y outermost keeps only 4 MFMA accumulators live
+#pragma nounroll
+    for (int k = 0; k < 2; ++k) {
+      const int grp = wave + NW * k;                            // wave-uniform
+      if (grp < NG4) {
+        const int t = 16 * grp + j;
+        const bool ok = t < 169;
+        const int tc = ok ? t : 0, ty = tc / 13, tx = tc - 13 * ty;
+        const float* pd = d_s + 2 * ty * ROWD + 2 * tx;
+        f32x4 s0[4], s1[4];                                     // A^T M, rows 0 and 1, columns xi_x
+#pragma unroll
+        for (int c = 0; c < 4; ++c) { s0[c] = f32x4{0.f, 0.f, 0.f, 0.f}; s1[c] = s0[c]; }
+#pragma unroll
+        for (int xy = 0; xy < 4; ++xy) {
+          f32x4 m[4];
+#pragma unroll
+          for (int c = 0; c < 4; ++c) m[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+          constexpr int RA[4] = {0, 1, 2, 1}, RB[4] = {2, 2, 1, 3};   // row xy of B^T d = d[RA] -/+ d[RB]
+          float vv[4][4];
+          f32x4 uf[4];
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            const float* pp = pd + based(4 * g + q);
+            const float2 alo = *reinterpret_cast<const float2*>(pp + RA[xy] * ROWD);
+            const float2 ahi = *reinterpret_cast<const float2*>(pp + RA[xy] * ROWD + 2);
+            const float2 blo = *reinterpret_cast<const float2*>(pp + RB[xy] * ROWD);
+            const float2 bhi = *reinterpret_cast<const float2*>(pp + RB[xy] * ROWD + 2);
+            float tr[4];
+            if (xy == 1) { tr[0] = alo.x + blo.x; tr[1] = alo.y + blo.y; tr[2] = ahi.x + bhi.x; tr[3] = ahi.y + bhi.y; }
+            else { tr[0] = alo.x - blo.x; tr[1] = alo.y - blo.y; tr[2] = ahi.x - bhi.x; tr[3] = ahi.y - bhi.y; }
+            uf[g] = *reinterpret_cast<const f32x4*>(u_s + ((xy * 4 + g) * 64 + lane) * 4);
+            vv[g][0] = tr[0] - tr[2]; vv[g][1] = tr[1] + tr[2]; vv[g][2] = tr[2] - tr[1]; vv[g][3] = tr[1] - tr[3];
+          }
+          __builtin_amdgcn_sched_barrier(0);                    // operands first, then 16 back-to-back MFMAs
+#pragma unroll
+          for (int g = 0; g < 4; ++g)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) m[c] = mfma(uf[g][c], vv[g][c], m[c]);
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {                         // A^T = [[1,1,1,0],[0,1,-1,-1]]
+            if (xy < 3) s0[c] += m[c];
+            if (xy == 1) s1[c] += m[c];
+            if (xy >= 2) s1[c] -= m[c];
+          }
+          __builtin_amdgcn_sched_barrier(0);                    // keep the xi_y rounds apart: bounded live ranges
+        }
+        f32x4 dp[4];                                            // dpre1 at sub-position p, channels 4q+r
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float y00 = s0[0][r] + s0[1][r] + s0[2][r], y01 = s0[1][r] - s0[2][r] - s0[3][r];
+          const float y10 = s1[0][r] + s1[1][r] + s1[2][r], y11 = s1[1][r] - s1[2][r] - s1[3][r];
+          const unsigned gb = ok ? (gate >> (16 * k + r)) : 0u;
+          dp[0][r] = (gb & 1u) ? y00 : 0.f;
+          dp[1][r] = (gb & 16u) ? y01 : 0.f;
+          dp[2][r] = (gb & 256u) ? y10 : 0.f;
+          dp[3][r] = (gb & 4096u) ? y11 : 0.f;
+        }
+        // dW1 / db1 partials against the 4x4 image patch of this tile
+        float ep[4][4];
+        {
+          const float* pe = e_s + 2 * ty * ROWE + 2 * tx;
+#pragma unroll
+          for (int rr = 0; rr < 4; ++rr) {
+            const float2 lo = *reinterpret_cast<const float2*>(pe + rr * ROWE);
+            const float2 hi = *reinterpret_cast<const float2*>(pe + rr * ROWE + 2);
+            ep[rr][0] = lo.x; ep[rr][1] = lo.y; ep[rr][2] = hi.x; ep[rr][3] = hi.y;
+          }
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          gW1p[r][9] += (dp[0][r] + dp[1][r]) + (dp[2][r] + dp[3][r]);
+#pragma unroll
+          for (int tap = 0; tap < 9; ++tap) {
+            const int ky = tap / 3, kx = tap % 3;
+            float acc = gW1p[r][tap];
+#pragma unroll
+            for (int p = 0; p < 4; ++p) acc = fmaf(dp[p][r], ep[(p >> 1) + ky][(p & 1) + kx], acc);
+            gW1p[r][tap] = acc;
+          }
+        }
+        // T[tap][pos] = sum_oc W1[oc][tap] dpre1[oc][pos]: dpre1 in the C/D layout IS the B operand
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+          f32x4 tt = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int r = 0; r < 4; ++r) tt = mfma(w1t[r], dp[p][r], tt);
+          const int pos = (2 * ty + (p >> 1)) * C1 + 2 * tx + (p & 1);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) T_s[(ok && 4 * q + r < 9) ? (4 * q + r) * CS + pos : 9 * CS + lane] = tt[r];
+        }
+      }
+    }
+    __syncthreads();
+    TSTAMP(3);
+    // ---- de[y][x] = sum_tap T[tap][y-ky][x-kx]
+    for (int i = tid; i < IMG * IMG; i += NT) {
+      const int y = i / IMG, x = i - y * IMG;
+      float s = 0.f;
+#pragma unroll
+      for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+          const int yy = y - ky, xx = x - kx;
+          if (yy >= 0 && yy < C1 && xx >= 0 && xx < C1) s += T_s[(ky * 3 + kx) * CS + yy * C1 + xx];
+        }
+      a.ge[img * (IMG * IMG) + i] = s;
+    }
+    TSTAMP(4);
+  }
+#ifdef GNF_CNN_TIMING
+  if (blockIdx.x == 7 && (tid & 63) == 0)
+    for (int k = 0; k < 6; ++k) a.part[((int64_t)gridDim.x * NW + 1) * PROW + wave * 8 + k] = (float)tacc[k];
+#endif
+
+  // ---- per-wave partial row: dW2 [16][144] | dW1+db1 [16][16] | db2 [16]
+  float* prow = a.part + ((int64_t)blockIdx.x * NW + wave) * PROW;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {                                // dw = G^T dU G for (o = 4q+r, c = j)
+    float ar[3][4];
+#pragma unroll
+    for (int x = 0; x < 4; ++x) {
+      const float u0 = dU[x][r], u1 = dU[4 + x][r], u2 = dU[8 + x][r], u3 = dU[12 + x][r];
+      ar[0][x] = u0 + 0.5f * (u1 + u2); ar[1][x] = 0.5f * (u1 - u2); ar[2][x] = 0.5f * (u1 + u2) + u3;
+    }
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      float* o = prow + (4 * q + r) * 144 + j * 9 + 3 * i;
+      o[0] = ar[i][0] + 0.5f * (ar[i][1] + ar[i][2]);
+      o[1] = 0.5f * (ar[i][1] - ar[i][2]);
+      o[2] = 0.5f * (ar[i][1] + ar[i][2]) + ar[i][3];
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r)
+#pragma unroll
+    for (int k = 0; k < 10; ++k) {
+      float v = gW1p[r][k];                                    // sum over the 16 tile lanes
+      v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 8, 64);
+      if (j == 0) prow[NCH * 144 + (4 * q + r) * 16 + k] = v;
+    }
+  if (j == 0) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int k = 10; k < 16; ++k) prow[NCH * 144 + (4 * q + r) * 16 + k] = 0.f;
+  }
+#pragma unroll
+  for (int off = 16; off > 0; off >>= 1) gb2 += __shfl_xor(gb2, off, 64);    // over the 32 threads of a channel
+  if ((lane & 31) == 0) prow[NCH * 144 + NCH * 16 + 2 * wave + (lane >> 5)] = gb2;
+  if (lane < NCH && (lane >> 1) != wave) prow[NCH * 144 + NCH * 16 + lane] = 0.f;
+}
+
 // unpack the summed partial row into the parameter-shaped gradients
 __global__ void cnn_unpack_k(const float* __restrict__ vec, float* gW1, float* gb1, float* gW2, float* gb2) {
   const int n = blockIdx.x * blockDim.x + threadIdx.x;
@@ -666,6 +1045,7 @@ constexpr size_t kFwdLds = (size_t)(ESZ + NCH * CH) * sizeof(float);
 constexpr size_t kWinoLds = (size_t)(2 * ESZ + 2 * A1SZ) * sizeof(float);
 constexpr unsigned kWinoGrid = 256;                  // one 8-wave workgroup per CU, two images per iteration
 constexpr size_t kBwdLds = (size_t)(ESZ + NCH * CH + DSZ) * sizeof(float);
+constexpr size_t kBwdWinoLds = (size_t)(ESZ + NCH * CHB + DSZ + USZ) * sizeof(float);
 // one 8-wave workgroup per CU: at its 128 VGPRs a second one is not admitted (measured with tools/census.hip and
 // the occupancy API; the 96-VGPR variant that admits two spills and is slower)
 constexpr unsigned kFwdGrid = 512, kBwdGrid = 256;   // 512 measured faster than 256 for the forward
@@ -732,10 +1112,16 @@ int gnf_mnistcnn_conv_bwd(const float* e, const float* W1, const float* b1, cons
   CnnArgs a{};
   a.e = e; a.W1 = W1; a.b1 = b1; a.W2 = W2; a.gp = g_pooled; a.argin = argmax; a.ge = ge; a.part = (float*)ws;
   a.n = n_img;
+  // fixed grid: every workgroup (also one without images) writes its partial rows
+#ifdef GNF_CNN_DIRECT_BWD
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&cnn_bwd_k), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)kBwdLds);
-  // fixed grid: every workgroup (also one without images) writes its partial rows
   hipLaunchKernelGGL(cnn_bwd_k, dim3(kBwdGrid), dim3(64 * BWD_WAVES), kBwdLds, (hipStream_t)stream, a);
+#else
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&cnn_bwd_wino_k),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)kBwdWinoLds);
+  hipLaunchKernelGGL(cnn_bwd_wino_k, dim3(kBwdGrid), dim3(64 * BWD_WAVES), kBwdWinoLds, (hipStream_t)stream, a);
+#endif
   GNF_LAUNCH_CHECK();
   const int64_t rows = (int64_t)kBwdGrid * BWD_WAVES;
   float* vec = (float*)ws + rows * PROW;
