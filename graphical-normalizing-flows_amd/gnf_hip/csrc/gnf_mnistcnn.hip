@@ -665,10 +665,20 @@ __global__ __launch_bounds__(64 * BWD_WAVES) void cnn_bwd_k(CnnArgs a) {
 // ---------------------------------------------------------------------------------------------
 constexpr int NG4 = 11;                              // groups of 16 da1 tiles (13 x 13 = 169 tiles of 2x2)
 constexpr int USZ = 16 * 4 * 64;                     // U' as [xi_y][g][lane][xi_x]
-// a1 channel stride of this kernel: the dW2 gather reads 16 CHANNELS x one 8-byte column pair per 16-lane group,
-// so CHB*j mod 64 must be 16 distinct even banks (CHB = 2 * odd); with CH = 1040 the gather is 4-way conflicted
-// and the phase LDS-bound (measured: 4.4k of 11.5k cycles)
-constexpr int CHB = 1042;
+// LDS layouts of this kernel.  Every gather is a ds_read_b64 whose 16-lane (ds_read2) / 32-lane groups must spread
+// over the 64 banks; with the direct kernel's strides the dW2 gather was 4-way and the da1 gather 2-way conflicted
+// and both phases LDS-bound (measured: 4.4k of 11.5k and ~5k of 17k cycles per image).
+//  a1 [16][26][ROWB]: the dW2 gather reads 16 CHANNELS x one column pair per 16-lane group -> CHB*j mod 64 must be
+//     16 distinct even banks (CHB = 2 * odd).
+//  dY2 (zero-bordered 28x28) per channel as [14 tile rows][TRD] with the odd image row at +ROD: the da1 gather reads
+//     16 consecutive 2x2 TILES (13 per tile row) of 2 channels per 32-lane group -> consecutive tiles are +2 dwords,
+//     the tile-row wrap TRD - 24 == 2 (mod 64), the two channels of a pair CHDW == 32 (mod 64) apart; channel pairs
+//     PSD == 2 (mod 64) apart keep the 16-channel Z read of dW2 conflict-free too.
+constexpr int ROWB = 28, CHB = 730;
+constexpr int TRD = 90, ROD = 44, CHDW = 1312, PSD = 2 * CHDW + 2, DSZW = (NCH / 2) * PSD;
+static_assert(CHB >= C1 * ROWB && (CHB % 4) == 2, "a1 channel stride");
+static_assert((TRD - 24) % 64 == 2 && CHDW % 64 == 32 && PSD % 64 == 2 && 13 * TRD + ROD + 28 <= CHDW, "dY2 layout");
+__device__ __forceinline__ int dofs(int c) { return (c >> 1) * PSD + (c & 1) * CHDW; }
 
 __global__ __launch_bounds__(64 * BWD_WAVES) void cnn_bwd_wino_k(CnnArgs a) {
 #ifdef GNF_CNN_TIMING
@@ -678,13 +688,14 @@ __global__ __launch_bounds__(64 * BWD_WAVES) void cnn_bwd_wino_k(CnnArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* e_s = smem;
   float* a1_s = smem + ESZ;                 // conv1 activations; reused for the per-tap planes T after dW2
-  float* d_s = a1_s + NCH * CHB;            // dY2 with a 2-wide zero border
-  float* u_s = d_s + DSZ;                   // U' (16-B aligned: ESZ, NCH*CH and DSZ are multiples of 4)
+  float* d_s = a1_s + NCH * CHB;            // dY2 with a 2-wide zero border, tile-row layout
+  float* u_s = d_s + DSZW;                  // U' as [g][xi_y][lane][xi_x]
   float* T_s = a1_s;
   const int tid = threadIdx.x, lane = tid & 63, q = lane >> 4, j = lane & 15;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   constexpr int NW = BWD_WAVES, NT = 64 * BWD_WAVES;
-  static_assert((ESZ % 4 == 0) && ((NCH * CHB) % 4 == 0) && (DSZ % 4 == 0), "u_s must be 16-B aligned");
+  static_assert((ESZ % 4 == 0) && ((NCH * CHB) % 4 == 0) && (DSZW % 4 == 0), "u_s must be 16-B aligned");
+  static_assert(9 * CS + 64 <= NCH * CHB, "T planes alias the a1 region");
 
   float w1f[3];
   int off1[3];
@@ -702,32 +713,34 @@ __global__ __launch_bounds__(64 * BWD_WAVES) void cnn_bwd_wino_k(CnnArgs a) {
 #pragma unroll
   for (int r = 0; r < 4; ++r) w1t[r] = j < 9 ? a.W1[(4 * q + r) * 9 + j] : 0.f;
 
-  // U'[c = j][o = 4g+q] = G w' G^T, w'[a][b] = W2[o][c][2-a][2-b]; fp64 once, stored for ds_read_b128 per (xi_y, g)
-  if (wave == 0) {
+  // U'[c = j][o = 4g+q] = G w' G^T, w'[a][b] = W2[o][c][2-a][2-b]; fp64 once, stored for one ds_read_b128 per (g, xi_y)
+  if (wave < 4) {
+    const int g = wave;
+    const float* w = a.W2 + ((4 * g + q) * NCH + j) * 9;
+    double gw[4][3];
 #pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      const float* w = a.W2 + ((4 * g + q) * NCH + j) * 9;
-      double gw[4][3];
+    for (int c = 0; c < 3; ++c) {
+      const double w0 = w[8 - c], w1 = w[5 - c], w2 = w[2 - c];         // rows a = 0,1,2 of the flipped kernel, column b = c
+      gw[0][c] = w0; gw[1][c] = 0.5 * (w0 + w1 + w2); gw[2][c] = 0.5 * (w0 - w1 + w2); gw[3][c] = w2;
+    }
 #pragma unroll
-      for (int c = 0; c < 3; ++c) {
-        const double w0 = w[8 - c], w1 = w[5 - c], w2 = w[2 - c];       // rows a = 0,1,2 of the flipped kernel, column b = c
-        gw[0][c] = w0; gw[1][c] = 0.5 * (w0 + w1 + w2); gw[2][c] = 0.5 * (w0 - w1 + w2); gw[3][c] = w2;
-      }
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        f32x4 u;
-        u[0] = (float)gw[r][0];
-        u[1] = (float)(0.5 * (gw[r][0] + gw[r][1] + gw[r][2]));
-        u[2] = (float)(0.5 * (gw[r][0] - gw[r][1] + gw[r][2]));
-        u[3] = (float)gw[r][2];
-        *reinterpret_cast<f32x4*>(u_s + ((r * 4 + g) * 64 + lane) * 4) = u;
-      }
+    for (int r = 0; r < 4; ++r) {
+      f32x4 u;
+      u[0] = (float)gw[r][0];
+      u[1] = (float)(0.5 * (gw[r][0] + gw[r][1] + gw[r][2]));
+      u[2] = (float)(0.5 * (gw[r][0] - gw[r][1] + gw[r][2]));
+      u[3] = (float)gw[r][2];
+      *reinterpret_cast<f32x4*>(u_s + ((g * 4 + r) * 64 + lane) * 4) = u;
     }
   }
 
-  f32x4 dU[16];                              // dU_xi[o = 4q+r][c = j], summed over all images of this wavefront
+  // dW2 in the Winograd domain, split by xi_y over the two wavefronts of a SIMD: wavefronts 0-3 own xi_y in {0,1},
+  // wavefronts 4-7 xi_y in {2,3}; each covers all 36 K-steps of an image with its three partners (s = wave&3 mod 4).
+  // dU[4*(xi_y & 1) + xi_x][r] = dU_xi[o = 4q+r][c = j]
+  const int hy = wave >> 2;                  // wave-uniform
+  f32x4 dU[8];
 #pragma unroll
-  for (int xi = 0; xi < 16; ++xi) dU[xi] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int xi = 0; xi < 8; ++xi) dU[xi] = f32x4{0.f, 0.f, 0.f, 0.f};
   float gW1p[4][10];                         // dW1 / db1 per-lane partials: channel 4q+r, tap k (k = 9: bias)
 #pragma unroll
   for (int r = 0; r < 4; ++r)
@@ -736,7 +749,7 @@ __global__ __launch_bounds__(64 * BWD_WAVES) void cnn_bwd_wino_k(CnnArgs a) {
   float gb2 = 0.f;                           // thread tid accumulates channel tid/32
 
   for (int i = tid; i < ESZ; i += NT) e_s[i] = 0.f;
-  for (int i = tid; i < DSZ; i += NT) d_s[i] = 0.f;
+  for (int i = tid; i < DSZW; i += NT) d_s[i] = 0.f;
 
   constexpr int EPT = (IMG * IMG + NT - 1) / NT, WPT = (PO * PO + 31) / 32;
   float epre[EPT], gpre[WPT];
@@ -759,6 +772,14 @@ __global__ __launch_bounds__(64 * BWD_WAVES) void cnn_bwd_wino_k(CnnArgs a) {
     }
   };
   prefetch(blockIdx.x);
+  // this thread's pool windows (channel tid/32, window (tid&31) + 32k) and pixels: fixed LDS offsets
+  const int dwin = dofs(tid >> 5) + TRD + 2;
+  int woff[WPT];
+#pragma unroll
+  for (int k = 0; k < WPT; ++k) {
+    const int w = (tid & 31) + 32 * k;
+    woff[k] = w < PO * PO ? dwin + (w / PO) * TRD + 2 * (w % PO) : -1;
+  }
 
   for (int64_t img = blockIdx.x; img < a.n; img += gridDim.x) {
     __syncthreads();
@@ -769,19 +790,17 @@ __global__ __launch_bounds__(64 * BWD_WAVES) void cnn_bwd_wino_k(CnnArgs a) {
       if (i < IMG * IMG) e_s[(i / IMG) * ROWE + i % IMG] = epre[k];
     }
 #pragma unroll
-    for (int k = 0; k < WPT; ++k) {
-      const int w = (tid & 31) + 32 * k;
-      if (w < PO * PO) {
+    for (int k = 0; k < WPT; ++k)
+      if (woff[k] >= 0) {
         const float g = gpre[k];
         const int am = (int)((apre >> (2 * k)) & 3u);
         gb2 += g;
-        float* p = d_s + based(tid >> 5) + (2 * (w / PO) + 2) * ROWD + 2 * (w % PO) + 2;
+        float* p = d_s + woff[k];
         p[0] = am == 0 ? g : 0.f;
         p[1] = am == 1 ? g : 0.f;
-        p[ROWD] = am == 2 ? g : 0.f;
-        p[ROWD + 1] = am == 3 ? g : 0.f;
+        p[ROD] = am == 2 ? g : 0.f;
+        p[ROD + 1] = am == 3 ? g : 0.f;
       }
-    }
     __syncthreads();
     prefetch(img + gridDim.x);
     TSTAMP(0);
@@ -811,7 +830,7 @@ __global__ __launch_bounds__(64 * BWD_WAVES) void cnn_bwd_wino_k(CnnArgs a) {
           for (int p = 0; p < 4; ++p)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-              a1_s[(4 * q + r) * CHB + (2 * ty + (p >> 1)) * ROW + 2 * tx + (p & 1)] = fmaxf(acc[p][r], 0.f);
+              a1_s[(4 * q + r) * CHB + (2 * ty + (p >> 1)) * ROWB + 2 * tx + (p & 1)] = fmaxf(acc[p][r], 0.f);
               if (acc[p][r] > 0.f) gate |= 1u << (16 * k + 4 * p + r);
             }
         }
@@ -819,63 +838,48 @@ __global__ __launch_bounds__(64 * BWD_WAVES) void cnn_bwd_wino_k(CnnArgs a) {
     }
     __syncthreads();
     TSTAMP(1);
-    // ---- P3: dU_xi[o][c] += sum_tiles Z_xi[o][tile] V_xi[c][tile]; K-step s = 4 tiles, s = wave, wave+8, ...
-    //      Z = A dY A^T from the 2x2 window of dY2 in LDS (A = [[1,0],[1,1],[1,-1],[0,-1]])
+    // ---- P3: dU_xi[o][c] += sum_tiles Z_xi[o][tile] V_xi[c][tile]; K-step s = 4 tiles; this wavefront's xi_y half.
+    //      Z = A dY A^T from the 2x2 window of dY2 in LDS (A = [[1,0],[1,1],[1,-1],[0,-1]]); V = B^T d B needs the
+    //      patch rows hy..hy+2 only: xi_y 0,1 = d0-d2, d1+d2;  xi_y 2,3 = d2-d1, d1-d3
 #pragma nounroll
-    for (int s = wave; s < 36; s += NW) {
+    for (int s = wave & 3; s < 36; s += 4) {
       const int T = 4 * s + q, ty = T / 12, tx = T - 12 * ty;
-      const float* p = a1_s + j * CHB + 2 * ty * ROW + 2 * tx;
-      const float* pz = d_s + based(j) + (2 * ty + 2) * ROWD + 2 * tx + 2;
-#ifdef GNF_EXP_P3_NOLDS
-      const float2 y0 = make_float2(__int_as_float(s), __int_as_float(T)), y1 = make_float2(__int_as_float(ty), __int_as_float(tx));
-      float d[4][4];
-#pragma unroll
-      for (int rr = 0; rr < 4; ++rr)
-#pragma unroll
-        for (int c = 0; c < 4; ++c) d[rr][c] = __int_as_float(T + rr * 4 + c + (int)(p - a1_s) + (int)(pz - d_s));
-#else
+      const float* p = a1_s + j * CHB + (2 * ty + hy) * ROWB + 2 * tx;
+      const float* pz = d_s + dofs(j) + (ty + 1) * TRD + 2 * tx + 2;
       const float2 y0 = *reinterpret_cast<const float2*>(pz);
-      const float2 y1 = *reinterpret_cast<const float2*>(pz + ROWD);
-      float d[4][4];
+      const float2 y1 = *reinterpret_cast<const float2*>(pz + ROD);
+      float d[3][4];
 #pragma unroll
-      for (int rr = 0; rr < 4; ++rr) {
-        const float2 lo = *reinterpret_cast<const float2*>(p + rr * ROW);
-        const float2 hi = *reinterpret_cast<const float2*>(p + rr * ROW + 2);
+      for (int rr = 0; rr < 3; ++rr) {
+        const float2 lo = *reinterpret_cast<const float2*>(p + rr * ROWB);
+        const float2 hi = *reinterpret_cast<const float2*>(p + rr * ROWB + 2);
         d[rr][0] = lo.x; d[rr][1] = lo.y; d[rr][2] = hi.x; d[rr][3] = hi.y;
       }
-#endif
-      float tt[4][4];
+      float ta[4], tb[4], za[2], zb[2];
+      if (hy == 0) {
 #pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        tt[0][c] = d[0][c] - d[2][c]; tt[1][c] = d[1][c] + d[2][c];
-        tt[2][c] = d[2][c] - d[1][c]; tt[3][c] = d[1][c] - d[3][c];
-      }
-      float zr[4][2];                                           // A dY
-      zr[0][0] = y0.x; zr[0][1] = y0.y; zr[1][0] = y0.x + y1.x; zr[1][1] = y0.y + y1.y;
-      zr[2][0] = y0.x - y1.x; zr[2][1] = y0.y - y1.y; zr[3][0] = -y1.x; zr[3][1] = -y1.y;
-      // all 32 operands first, then 16 back-to-back MFMAs: VALU and MFMA of ONE wavefront do not overlap
-      // (tools/mfma_feed.hip), so a VALU op in front of every MFMA would stall the pipe for both wavefronts
-      float vv[16], zz[16];
+        for (int c = 0; c < 4; ++c) { ta[c] = d[0][c] - d[2][c]; tb[c] = d[1][c] + d[2][c]; }
+        za[0] = y0.x; za[1] = y0.y; zb[0] = y0.x + y1.x; zb[1] = y0.y + y1.y;
+      } else {
 #pragma unroll
-      for (int rr = 0; rr < 4; ++rr) {
-        vv[4 * rr + 0] = tt[rr][0] - tt[rr][2]; vv[4 * rr + 1] = tt[rr][1] + tt[rr][2];
-        vv[4 * rr + 2] = tt[rr][2] - tt[rr][1]; vv[4 * rr + 3] = tt[rr][1] - tt[rr][3];
-        zz[4 * rr + 0] = zr[rr][0]; zz[4 * rr + 1] = zr[rr][0] + zr[rr][1];
-        zz[4 * rr + 2] = zr[rr][0] - zr[rr][1]; zz[4 * rr + 3] = -zr[rr][1];
+        for (int c = 0; c < 4; ++c) { ta[c] = d[1][c] - d[0][c]; tb[c] = d[0][c] - d[2][c]; }
+        za[0] = y0.x - y1.x; za[1] = y0.y - y1.y; zb[0] = -y1.x; zb[1] = -y1.y;
       }
+      // all operands first, then 8 back-to-back MFMAs: VALU and MFMA of ONE wavefront do not overlap
+      // (tools/mfma_feed.hip); a VALU op in front of every MFMA would stall the pipe for both wavefronts
+      float vv[8], zz[8];
+      vv[0] = ta[0] - ta[2]; vv[1] = ta[1] + ta[2]; vv[2] = ta[2] - ta[1]; vv[3] = ta[1] - ta[3];
+      vv[4] = tb[0] - tb[2]; vv[5] = tb[1] + tb[2]; vv[6] = tb[2] - tb[1]; vv[7] = tb[1] - tb[3];
+      zz[0] = za[0]; zz[1] = za[0] + za[1]; zz[2] = za[0] - za[1]; zz[3] = -za[1];
+      zz[4] = zb[0]; zz[5] = zb[0] + zb[1]; zz[6] = zb[0] - zb[1]; zz[7] = -zb[1];
       __builtin_amdgcn_sched_barrier(0);
-#ifdef GNF_EXP_P3_NOMFMA
 #pragma unroll
-      for (int xi = 0; xi < 16; ++xi) dU[xi][0] += zz[xi] * vv[xi];
-#else
-#pragma unroll
-      for (int xi = 0; xi < 16; ++xi) dU[xi] = mfma(zz[xi], vv[xi], dU[xi]);
-#endif
+      for (int xi = 0; xi < 8; ++xi) dU[xi] = mfma(zz[xi], vv[xi], dU[xi]);
       __builtin_amdgcn_sched_barrier(0);
     }
     __syncthreads();                                           // a1 as dW2 operand is done: region becomes T
     TSTAMP(2);
-    // ---- P4: dpre1 = conv2^T(dY2) * gate, 2x2 tiles; xi_y outermost keeps only 4 MFMA accumulators live
+    // ---- P4: dpre1 = conv2^T(dY2) * gate on 2x2 tiles: per 4 input channels (g) 16 operands, then 16 MFMAs
 #pragma nounroll
     for (int k = 0; k < 2; ++k) {
       const int grp = wave + NW * k;                            // wave-uniform
@@ -883,50 +887,51 @@ __global__ __launch_bounds__(64 * BWD_WAVES) void cnn_bwd_wino_k(CnnArgs a) {
         const int t = 16 * grp + j;
         const bool ok = t < 169;
         const int tc = ok ? t : 0, ty = tc / 13, tx = tc - 13 * ty;
-        const float* pd = d_s + 2 * ty * ROWD + 2 * tx;
-        f32x4 s0[4], s1[4];                                     // A^T M, rows 0 and 1, columns xi_x
+        const float* pd = d_s + ty * TRD + 2 * tx;
+        f32x4 m[16];
 #pragma unroll
-        for (int c = 0; c < 4; ++c) { s0[c] = f32x4{0.f, 0.f, 0.f, 0.f}; s1[c] = s0[c]; }
+        for (int xi = 0; xi < 16; ++xi) m[xi] = f32x4{0.f, 0.f, 0.f, 0.f};
+        constexpr int RO4[4] = {0, ROD, TRD, TRD + ROD};           // patch row a at (a>>1)*TRD + (a&1)*ROD
 #pragma unroll
-        for (int xy = 0; xy < 4; ++xy) {
-          f32x4 m[4];
+        for (int g = 0; g < 4; ++g) {
+          const float* pp = pd + dofs(4 * g + q);
+          float d[4][4];
 #pragma unroll
-          for (int c = 0; c < 4; ++c) m[c] = f32x4{0.f, 0.f, 0.f, 0.f};
-          constexpr int RA[4] = {0, 1, 2, 1}, RB[4] = {2, 2, 1, 3};   // row xy of B^T d = d[RA] -/+ d[RB]
-          float vv[4][4];
+          for (int rr = 0; rr < 4; ++rr) {
+            const float2 lo = *reinterpret_cast<const float2*>(pp + RO4[rr]);
+            const float2 hi = *reinterpret_cast<const float2*>(pp + RO4[rr] + 2);
+            d[rr][0] = lo.x; d[rr][1] = lo.y; d[rr][2] = hi.x; d[rr][3] = hi.y;
+          }
           f32x4 uf[4];
 #pragma unroll
-          for (int g = 0; g < 4; ++g) {
-            const float* pp = pd + based(4 * g + q);
-            const float2 alo = *reinterpret_cast<const float2*>(pp + RA[xy] * ROWD);
-            const float2 ahi = *reinterpret_cast<const float2*>(pp + RA[xy] * ROWD + 2);
-            const float2 blo = *reinterpret_cast<const float2*>(pp + RB[xy] * ROWD);
-            const float2 bhi = *reinterpret_cast<const float2*>(pp + RB[xy] * ROWD + 2);
-            float tr[4];
-            if (xy == 1) { tr[0] = alo.x + blo.x; tr[1] = alo.y + blo.y; tr[2] = ahi.x + bhi.x; tr[3] = ahi.y + bhi.y; }
-            else { tr[0] = alo.x - blo.x; tr[1] = alo.y - blo.y; tr[2] = ahi.x - bhi.x; tr[3] = ahi.y - bhi.y; }
-            uf[g] = *reinterpret_cast<const f32x4*>(u_s + ((xy * 4 + g) * 64 + lane) * 4);
-            vv[g][0] = tr[0] - tr[2]; vv[g][1] = tr[1] + tr[2]; vv[g][2] = tr[2] - tr[1]; vv[g][3] = tr[1] - tr[3];
+          for (int xy = 0; xy < 4; ++xy) uf[xy] = *reinterpret_cast<const f32x4*>(u_s + ((g * 4 + xy) * 64 + lane) * 4);
+          float tt[4][4], vv[16];
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            tt[0][c] = d[0][c] - d[2][c]; tt[1][c] = d[1][c] + d[2][c];
+            tt[2][c] = d[2][c] - d[1][c]; tt[3][c] = d[1][c] - d[3][c];
           }
-          __builtin_amdgcn_sched_barrier(0);                    // operands first, then 16 back-to-back MFMAs
 #pragma unroll
-          for (int g = 0; g < 4; ++g)
-#pragma unroll
-            for (int c = 0; c < 4; ++c) m[c] = mfma(uf[g][c], vv[g][c], m[c]);
+          for (int rr = 0; rr < 4; ++rr) {
+            vv[4 * rr + 0] = tt[rr][0] - tt[rr][2]; vv[4 * rr + 1] = tt[rr][1] + tt[rr][2];
+            vv[4 * rr + 2] = tt[rr][2] - tt[rr][1]; vv[4 * rr + 3] = tt[rr][1] - tt[rr][3];
+          }
           __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-          for (int c = 0; c < 4; ++c) {                         // A^T = [[1,1,1,0],[0,1,-1,-1]]
-            if (xy < 3) s0[c] += m[c];
-            if (xy == 1) s1[c] += m[c];
-            if (xy >= 2) s1[c] -= m[c];
-          }
-          __builtin_amdgcn_sched_barrier(0);                    // keep the xi_y rounds apart: bounded live ranges
+          for (int xi = 0; xi < 16; ++xi) m[xi] = mfma(uf[xi >> 2][xi & 3], vv[xi], m[xi]);
+          __builtin_amdgcn_sched_barrier(0);
         }
         f32x4 dp[4];                                            // dpre1 at sub-position p, channels 4q+r
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const float y00 = s0[0][r] + s0[1][r] + s0[2][r], y01 = s0[1][r] - s0[2][r] - s0[3][r];
-          const float y10 = s1[0][r] + s1[1][r] + s1[2][r], y11 = s1[1][r] - s1[2][r] - s1[3][r];
+        for (int r = 0; r < 4; ++r) {                           // A^T M A, A^T = [[1,1,1,0],[0,1,-1,-1]]
+          float s0[4], s1[4];
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            s0[c] = m[c][r] + m[4 + c][r] + m[8 + c][r];
+            s1[c] = m[4 + c][r] - m[8 + c][r] - m[12 + c][r];
+          }
+          const float y00 = s0[0] + s0[1] + s0[2], y01 = s0[1] - s0[2] - s0[3];
+          const float y10 = s1[0] + s1[1] + s1[2], y11 = s1[1] - s1[2] - s1[3];
           const unsigned gb = ok ? (gate >> (16 * k + r)) : 0u;
           dp[0][r] = (gb & 1u) ? y00 : 0.f;
           dp[1][r] = (gb & 16u) ? y01 : 0.f;
@@ -957,14 +962,18 @@ __global__ __launch_bounds__(64 * BWD_WAVES) void cnn_bwd_wino_k(CnnArgs a) {
           }
         }
         // T[tap][pos] = sum_oc W1[oc][tap] dpre1[oc][pos]: dpre1 in the C/D layout IS the B operand
+        f32x4 tq[4];
+#pragma unroll
+        for (int p = 0; p < 4; ++p) tq[p] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+          for (int p = 0; p < 4; ++p) tq[p] = mfma(w1t[r], dp[p][r], tq[p]);
 #pragma unroll
         for (int p = 0; p < 4; ++p) {
-          f32x4 tt = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-          for (int r = 0; r < 4; ++r) tt = mfma(w1t[r], dp[p][r], tt);
           const int pos = (2 * ty + (p >> 1)) * C1 + 2 * tx + (p & 1);
 #pragma unroll
-          for (int r = 0; r < 4; ++r) T_s[(ok && 4 * q + r < 9) ? (4 * q + r) * CS + pos : 9 * CS + lane] = tt[r];
+          for (int r = 0; r < 4; ++r) T_s[(ok && 4 * q + r < 9) ? (4 * q + r) * CS + pos : 9 * CS + lane] = tq[p][r];
         }
       }
     }
@@ -993,12 +1002,13 @@ __global__ __launch_bounds__(64 * BWD_WAVES) void cnn_bwd_wino_k(CnnArgs a) {
   // ---- per-wave partial row: dW2 [16][144] | dW1+db1 [16][16] | db2 [16]
   float* prow = a.part + ((int64_t)blockIdx.x * NW + wave) * PROW;
 #pragma unroll
-  for (int r = 0; r < 4; ++r) {                                // dw = G^T dU G for (o = 4q+r, c = j)
-    float ar[3][4];
+  for (int r = 0; r < 4; ++r) {          // this half's share of dw = G^T dU G for (o = 4q+r, c = j); the halves add up
+    float ar[3][4];                      // G^T = [[1,.5,.5,0],[0,.5,-.5,0],[0,.5,.5,1]]
 #pragma unroll
     for (int x = 0; x < 4; ++x) {
-      const float u0 = dU[x][r], u1 = dU[4 + x][r], u2 = dU[8 + x][r], u3 = dU[12 + x][r];
-      ar[0][x] = u0 + 0.5f * (u1 + u2); ar[1][x] = 0.5f * (u1 - u2); ar[2][x] = 0.5f * (u1 + u2) + u3;
+      const float ua = dU[x][r], ub = dU[4 + x][r];            // xi_y = 2hy, 2hy+1
+      if (hy == 0) { ar[0][x] = ua + 0.5f * ub; ar[1][x] = 0.5f * ub; ar[2][x] = 0.5f * ub; }
+      else { ar[0][x] = 0.5f * ua; ar[1][x] = -0.5f * ua; ar[2][x] = 0.5f * ua + ub; }
     }
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
@@ -1045,7 +1055,7 @@ constexpr size_t kFwdLds = (size_t)(ESZ + NCH * CH) * sizeof(float);
 constexpr size_t kWinoLds = (size_t)(2 * ESZ + 2 * A1SZ) * sizeof(float);
 constexpr unsigned kWinoGrid = 256;                  // one 8-wave workgroup per CU, two images per iteration
 constexpr size_t kBwdLds = (size_t)(ESZ + NCH * CH + DSZ) * sizeof(float);
-constexpr size_t kBwdWinoLds = (size_t)(ESZ + NCH * CHB + DSZ + USZ) * sizeof(float);
+constexpr size_t kBwdWinoLds = (size_t)(ESZ + NCH * CHB + DSZW + USZ) * sizeof(float);
 // one 8-wave workgroup per CU: at its 128 VGPRs a second one is not admitted (measured with tools/census.hip and
 // the occupancy API; the 96-VGPR variant that admits two spills and is slower)
 constexpr unsigned kFwdGrid = 512, kBwdGrid = 256;   // 512 measured faster than 256 for the forward

@@ -24,6 +24,23 @@ __global__ void k(float* out, long long* cyc, int iters, float seed) {
       }
 #pragma unroll
       for (int i = 0; i < 16; ++i) t[i] += 1.0f;
+    } else if (MODE == 3) {     // 16 operands ahead, then 4 chains x 4 dependent MFMAs starting from 0 (Winograd da1 round)
+      float v[16];
+#pragma unroll
+      for (int i = 0; i < 16; ++i) v[i] = t[i] - t[(i + 3) & 15];
+      __builtin_amdgcn_sched_barrier(0);
+      f32x4 m[4];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) m[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) m[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, v[4 * g + c], m[c], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int c = 0; c < 4; ++c) acc[c] += m[c];
+#pragma unroll
+      for (int i = 0; i < 16; ++i) t[i] += 1.0f;
     } else {                    // 16 operands computed ahead, then 16 MFMAs
       float v[16];
 #pragma unroll
@@ -55,7 +72,7 @@ void run(int threads) {
   hipFree(out); hipFree(cyc);
 }
 int main() {
-  run<0>(256); run<1>(256); run<2>(256);
-  run<0>(512); run<1>(512); run<2>(512);
+  run<0>(256); run<1>(256); run<2>(256); run<3>(256);
+  run<0>(512); run<1>(512); run<2>(512); run<3>(512);
   return 0;
 }
