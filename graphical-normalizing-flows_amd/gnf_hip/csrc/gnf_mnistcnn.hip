@@ -325,31 +325,45 @@ __global__ __launch_bounds__(64 * FWD_WAVES) void cnn_fwd_wino_k(CnnArgs a) {
 #pragma unroll
       for (int xi = 0; xi < 16; ++xi) acc[xi] = f32x4{0.f, 0.f, 0.f, 0.f};
       acc[5] = b2v;                                    // xi = (1,1) reaches all four outputs with weight +1: the bias
+      // per 4 input channels: 16 operands first, then 16 back-to-back MFMAs (VALU and MFMA of one wavefront do not
+      // overlap, tools/mfma_feed.hip); the next channel group's patch is loaded before the MFMAs so that its LDS
+      // latency hides under them
+      float2 raw[8];
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr) {
+        raw[2 * rr] = *reinterpret_cast<const float2*>(base + rr * ROW);
+        raw[2 * rr + 1] = *reinterpret_cast<const float2*>(base + rr * ROW + 2);
+      }
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
-        const float* p = base + 4 * g * CH;
         float d[4][4];
 #pragma unroll
         for (int rr = 0; rr < 4; ++rr) {
-          const float2 lo = *reinterpret_cast<const float2*>(p + rr * ROW);
-          const float2 hi = *reinterpret_cast<const float2*>(p + rr * ROW + 2);
-          d[rr][0] = lo.x; d[rr][1] = lo.y; d[rr][2] = hi.x; d[rr][3] = hi.y;
+          d[rr][0] = raw[2 * rr].x; d[rr][1] = raw[2 * rr].y; d[rr][2] = raw[2 * rr + 1].x; d[rr][3] = raw[2 * rr + 1].y;
         }
-        float tt[4][4];                                // B^T d
+        float tt[4][4], vv[16];                        // B^T d, then (B^T d) B
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
           tt[0][c] = d[0][c] - d[2][c]; tt[1][c] = d[1][c] + d[2][c];
           tt[2][c] = d[2][c] - d[1][c]; tt[3][c] = d[1][c] - d[3][c];
         }
 #pragma unroll
-        for (int rr = 0; rr < 4; ++rr) {               // (B^T d) B, fed straight into the 4 MFMAs of this row
-          const float v0 = tt[rr][0] - tt[rr][2], v1 = tt[rr][1] + tt[rr][2];
-          const float v2 = tt[rr][2] - tt[rr][1], v3 = tt[rr][1] - tt[rr][3];
-          acc[4 * rr + 0] = mfma(uw[(4 * rr + 0) * 4 + g], v0, acc[4 * rr + 0]);
-          acc[4 * rr + 1] = mfma(uw[(4 * rr + 1) * 4 + g], v1, acc[4 * rr + 1]);
-          acc[4 * rr + 2] = mfma(uw[(4 * rr + 2) * 4 + g], v2, acc[4 * rr + 2]);
-          acc[4 * rr + 3] = mfma(uw[(4 * rr + 3) * 4 + g], v3, acc[4 * rr + 3]);
+        for (int rr = 0; rr < 4; ++rr) {
+          vv[4 * rr + 0] = tt[rr][0] - tt[rr][2]; vv[4 * rr + 1] = tt[rr][1] + tt[rr][2];
+          vv[4 * rr + 2] = tt[rr][2] - tt[rr][1]; vv[4 * rr + 3] = tt[rr][1] - tt[rr][3];
         }
+        if (g < 3) {
+          const float* p = base + 4 * (g + 1) * CH;
+#pragma unroll
+          for (int rr = 0; rr < 4; ++rr) {
+            raw[2 * rr] = *reinterpret_cast<const float2*>(p + rr * ROW);
+            raw[2 * rr + 1] = *reinterpret_cast<const float2*>(p + rr * ROW + 2);
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int xi = 0; xi < 16; ++xi) acc[xi] = mfma(uw[xi * 4 + g], vv[xi], acc[xi]);
+        __builtin_amdgcn_sched_barrier(0);
       }
       // output transform A^T M A (A^T = [[1,1,1,0],[0,1,-1,-1]]) + 2x2 max pool, lane-local
       const int64_t ob = img * NPOOL + 4 * q * (PO * PO) + t;
