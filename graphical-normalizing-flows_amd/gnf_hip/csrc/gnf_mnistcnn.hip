@@ -767,22 +767,21 @@ __global__ __launch_bounds__(64 * BWD_WAVES) void cnn_bwd_wino_k(CnnArgs a) {
 
   constexpr int EPT = (IMG * IMG + NT - 1) / NT, WPT = (PO * PO + 31) / 32;
   float epre[EPT], gpre[WPT];
-  unsigned apre;                             // WPT argmax codes, 2 bits each
-  auto prefetch = [&](int64_t im) {
+  unsigned apre[WPT];                        // raw loads only: any arithmetic here would wait for the data and make
+  auto prefetch = [&](int64_t im) {          // the prefetch synchronous
     const bool on = im < a.n;
 #pragma unroll
     for (int k = 0; k < EPT; ++k) {
       const int i = tid + k * NT;
       epre[k] = (on && i < IMG * IMG) ? a.e[im * (IMG * IMG) + i] : 0.f;
     }
-    apre = 0u;
 #pragma unroll
     for (int k = 0; k < WPT; ++k) {
       const int w = (tid & 31) + 32 * k;
       const bool ok = on && w < PO * PO;
       const int64_t o = im * NPOOL + (tid >> 5) * (PO * PO) + w;
       gpre[k] = ok ? a.gp[o] : 0.f;
-      apre |= (ok ? (unsigned)a.argin[o] : 0u) << (2 * k);
+      apre[k] = ok ? (unsigned)a.argin[o] : 0u;
     }
   };
   prefetch(blockIdx.x);
@@ -807,7 +806,7 @@ __global__ __launch_bounds__(64 * BWD_WAVES) void cnn_bwd_wino_k(CnnArgs a) {
     for (int k = 0; k < WPT; ++k)
       if (woff[k] >= 0) {
         const float g = gpre[k];
-        const int am = (int)((apre >> (2 * k)) & 3u);
+        const int am = (int)apre[k];
         gb2 += g;
         float* p = d_s + woff[k];
         p[0] = am == 0 ? g : 0.f;
