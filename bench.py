@@ -196,9 +196,9 @@ def main():
         # algorithmic flop per launch (SURVEY.md 8d / DESIGN.md 4); padding and recompute are NOT counted as work
         CONV1, CONV2 = 97344, 1327104                           # MACs per 28x28 image (MLP.py:36-41)
         work = {
-            "gnf_mnistcnn_conv_bwd": ("cnn_bwd_k (conv backward: dW2, da1, dW1, de; conv1 recomputed)",
+            "gnf_mnistcnn_conv_bwd": ("cnn_bwd_wino_k (conv backward: dW2 and da1 as Winograd F(2x2,3x3) on MFMA, dW1, de; conv1 recomputed)",
                                       2. * (2 * CONV2 + 2 * CONV1) * n_elem),
-            "gnf_mnistcnn_conv_fwd": ("cnn_fwd_k (conv1+ReLU+conv2+maxpool)", 2. * (CONV1 + CONV2) * n_elem),
+            "gnf_mnistcnn_conv_fwd": ("cnn_fwd_wino_k (conv1+ReLU, conv2 as Winograd F(2x2,3x3) on MFMA, maxpool)", 2. * (CONV1 + CONV2) * n_elem),
             "gnf_monotonic_fwd": ("mono_fwd_k<HT=4> (Clenshaw-Curtis quadrature)", 2. * macs * (S_NODES + 2) * n_elem),
             "gnf_monotonic_bwd": ("mono_bwd_k<4,3> + weight-gradient GEMMs", 4. * macs * (S_NODES + 2) * n_elem),
         }

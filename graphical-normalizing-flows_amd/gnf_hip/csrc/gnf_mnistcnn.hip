@@ -819,7 +819,7 @@ __global__ __launch_bounds__(64 * BWD_WAVES) void cnn_bwd_wino_k(CnnArgs a) {
     TSTAMP(0);
     // ---- P1: conv1 + ReLU in the 2x2-tile layout: group grp = wave + 8k, 4 sub-positions = 4 MFMA chains
     unsigned gate = 0u;
-#pragma nounroll
+#pragma unroll
     for (int k = 0; k < 2; ++k) {
       const int grp = wave + NW * k;                            // wave-uniform
       if (grp < NG4) {
