@@ -225,6 +225,12 @@ def main():
             "roofline_other": [v for k, v in kern.items() if k != dom],
             "ops_ms": {k: round(v, 4) for k, v in prof.items()},
         }
+        # MFMA issue slots used by the dominant kernel: v_mfma_f32_16x16x4_f32 issued per image (Winograd form, incl.
+        # padding and the conv1 recompute) x 2048 flop / time / peak -- the head-room left, see DESIGN.md section 4
+        issued = {"gnf_mnistcnn_conv_bwd": 11 * 12 + 36 * 16 + 11 * 64 + 11 * 16, "gnf_mnistcnn_conv_fwd": 129 + 9 * 64}
+        if dom in issued:
+            out["roofline"]["mfma_issue_frac"] = round(issued[dom] * 2048. * n_elem / (prof[dom] * 1e-3) / 1e12
+                                                       / PEAK_F32_TFLOPS, 4)
         out["measured_peaks"] = measured_peaks(dev)
         out["roofline"]["frac_of_measured_peak"] = round(achieved / out["measured_peaks"]["mfma_f32_TFLOPs"], 4)
         if world == 1 and not args.no_cpu_baseline:
