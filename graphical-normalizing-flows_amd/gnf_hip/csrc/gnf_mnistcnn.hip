@@ -35,6 +35,30 @@ __device__ __forceinline__ f32x4 mfma(float a, float b, f32x4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }
 
+// Packed fp32 VALU (2 flops per lane per op) for the Winograd transforms.  One row (t0,t1,t2,t3) of B^T d held as
+// A = (t0,t1), B = (t2,t3) gives the four outputs of (B^T d) B in two instructions:
+//   A - B                       = (t0 - t2, t1 - t3) = (v0, v3)
+//   (A.hi + B.lo, -A.hi + B.lo) = (t1 + t2, t2 - t1) = (v1, v2)      [op_sel picks the halves, neg_hi negates src0]
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2 pk_v12(f32x2 a, f32x2 b) {
+  f32x2 r;
+  asm("v_pk_add_f32 %0, %1, %2 op_sel:[1,0] op_sel_hi:[1,0] neg_hi:[1,0]" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+// B^T d B of a 4x4 patch given as 4 rows x 2 column pairs; out[xi = 4*xi_y + xi_x]
+__device__ __forceinline__ void wino_in(const f32x2 (&lo)[4], const f32x2 (&hi)[4], float (&v)[16]) {
+  f32x2 tl[4], th[4];                                 // B^T d: rows d0-d2, d1+d2, d2-d1, d1-d3
+  tl[0] = lo[0] - lo[2]; th[0] = hi[0] - hi[2];
+  tl[1] = lo[1] + lo[2]; th[1] = hi[1] + hi[2];
+  tl[2] = lo[2] - lo[1]; th[2] = hi[2] - hi[1];
+  tl[3] = lo[1] - lo[3]; th[3] = hi[1] - hi[3];
+#pragma unroll
+  for (int rr = 0; rr < 4; ++rr) {
+    const f32x2 v03 = tl[rr] - th[rr], v12 = pk_v12(tl[rr], th[rr]);
+    v[4 * rr + 0] = v03.x; v[4 * rr + 1] = v12.x; v[4 * rr + 2] = v12.y; v[4 * rr + 3] = v03.y;
+  }
+}
+
 // lane^1 (quad_perm [1,0,3,2]) and lane^8 (row_ror:8 inside a 16-lane row) without touching LDS
 __device__ __forceinline__ float dpp_xor1(float v) {
   return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, false));
@@ -328,36 +352,22 @@ __global__ __launch_bounds__(64 * FWD_WAVES) void cnn_fwd_wino_k(CnnArgs a) {
       // per 4 input channels: 16 operands first, then 16 back-to-back MFMAs (VALU and MFMA of one wavefront do not
       // overlap, tools/mfma_feed.hip); the next channel group's patch is loaded before the MFMAs so that its LDS
       // latency hides under them
-      float2 raw[8];
+      f32x2 plo[4], phi[4];                            // patch rows as two column pairs
 #pragma unroll
       for (int rr = 0; rr < 4; ++rr) {
-        raw[2 * rr] = *reinterpret_cast<const float2*>(base + rr * ROW);
-        raw[2 * rr + 1] = *reinterpret_cast<const float2*>(base + rr * ROW + 2);
+        plo[rr] = *reinterpret_cast<const f32x2*>(base + rr * ROW);
+        phi[rr] = *reinterpret_cast<const f32x2*>(base + rr * ROW + 2);
       }
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
-        float d[4][4];
-#pragma unroll
-        for (int rr = 0; rr < 4; ++rr) {
-          d[rr][0] = raw[2 * rr].x; d[rr][1] = raw[2 * rr].y; d[rr][2] = raw[2 * rr + 1].x; d[rr][3] = raw[2 * rr + 1].y;
-        }
-        float tt[4][4], vv[16];                        // B^T d, then (B^T d) B
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-          tt[0][c] = d[0][c] - d[2][c]; tt[1][c] = d[1][c] + d[2][c];
-          tt[2][c] = d[2][c] - d[1][c]; tt[3][c] = d[1][c] - d[3][c];
-        }
-#pragma unroll
-        for (int rr = 0; rr < 4; ++rr) {
-          vv[4 * rr + 0] = tt[rr][0] - tt[rr][2]; vv[4 * rr + 1] = tt[rr][1] + tt[rr][2];
-          vv[4 * rr + 2] = tt[rr][2] - tt[rr][1]; vv[4 * rr + 3] = tt[rr][1] - tt[rr][3];
-        }
+        float vv[16];
+        wino_in(plo, phi, vv);
         if (g < 3) {
           const float* p = base + 4 * (g + 1) * CH;
 #pragma unroll
           for (int rr = 0; rr < 4; ++rr) {
-            raw[2 * rr] = *reinterpret_cast<const float2*>(p + rr * ROW);
-            raw[2 * rr + 1] = *reinterpret_cast<const float2*>(p + rr * ROW + 2);
+            plo[rr] = *reinterpret_cast<const f32x2*>(p + rr * ROW);
+            phi[rr] = *reinterpret_cast<const f32x2*>(p + rr * ROW + 2);
           }
         }
         __builtin_amdgcn_sched_barrier(0);
