@@ -871,28 +871,29 @@ __global__ __launch_bounds__(64 * BWD_WAVES) void cnn_bwd_wino_k(CnnArgs a) {
       const float* pz = d_s + dofs(j) + (ty + 1) * TRD + 2 * tx + 2;
       const float2 y0 = *reinterpret_cast<const float2*>(pz);
       const float2 y1 = *reinterpret_cast<const float2*>(pz + ROD);
-      float d[3][4];
+      f32x2 dl[3], dh[3];                                        // patch rows hy..hy+2 as two column pairs
 #pragma unroll
       for (int rr = 0; rr < 3; ++rr) {
-        const float2 lo = *reinterpret_cast<const float2*>(p + rr * ROWB);
-        const float2 hi = *reinterpret_cast<const float2*>(p + rr * ROWB + 2);
-        d[rr][0] = lo.x; d[rr][1] = lo.y; d[rr][2] = hi.x; d[rr][3] = hi.y;
+        dl[rr] = *reinterpret_cast<const f32x2*>(p + rr * ROWB);
+        dh[rr] = *reinterpret_cast<const f32x2*>(p + rr * ROWB + 2);
       }
-      float ta[4], tb[4], za[2], zb[2];
+      f32x2 tal, tah, tbl, tbh;                                  // the two rows of B^T d of this half
+      float za[2], zb[2];
       if (hy == 0) {
-#pragma unroll
-        for (int c = 0; c < 4; ++c) { ta[c] = d[0][c] - d[2][c]; tb[c] = d[1][c] + d[2][c]; }
+        tal = dl[0] - dl[2]; tah = dh[0] - dh[2]; tbl = dl[1] + dl[2]; tbh = dh[1] + dh[2];
         za[0] = y0.x; za[1] = y0.y; zb[0] = y0.x + y1.x; zb[1] = y0.y + y1.y;
       } else {
-#pragma unroll
-        for (int c = 0; c < 4; ++c) { ta[c] = d[1][c] - d[0][c]; tb[c] = d[0][c] - d[2][c]; }
+        tal = dl[1] - dl[0]; tah = dh[1] - dh[0]; tbl = dl[0] - dl[2]; tbh = dh[0] - dh[2];
         za[0] = y0.x - y1.x; za[1] = y0.y - y1.y; zb[0] = -y1.x; zb[1] = -y1.y;
       }
       // all operands first, then 8 back-to-back MFMAs: VALU and MFMA of ONE wavefront do not overlap
       // (tools/mfma_feed.hip); a VALU op in front of every MFMA would stall the pipe for both wavefronts
       float vv[8], zz[8];
-      vv[0] = ta[0] - ta[2]; vv[1] = ta[1] + ta[2]; vv[2] = ta[2] - ta[1]; vv[3] = ta[1] - ta[3];
-      vv[4] = tb[0] - tb[2]; vv[5] = tb[1] + tb[2]; vv[6] = tb[2] - tb[1]; vv[7] = tb[1] - tb[3];
+      {
+        const f32x2 a03 = tal - tah, a12 = pk_v12(tal, tah), b03 = tbl - tbh, b12 = pk_v12(tbl, tbh);
+        vv[0] = a03.x; vv[1] = a12.x; vv[2] = a12.y; vv[3] = a03.y;
+        vv[4] = b03.x; vv[5] = b12.x; vv[6] = b12.y; vv[7] = b03.y;
+      }
       zz[0] = za[0]; zz[1] = za[0] + za[1]; zz[2] = za[0] - za[1]; zz[3] = -za[1];
       zz[4] = zb[0]; zz[5] = zb[0] + zb[1]; zz[6] = zb[0] - zb[1]; zz[7] = -zb[1];
       __builtin_amdgcn_sched_barrier(0);
@@ -918,27 +919,17 @@ __global__ __launch_bounds__(64 * BWD_WAVES) void cnn_bwd_wino_k(CnnArgs a) {
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
           const float* pp = pd + dofs(4 * g + q);
-          float d[4][4];
+          f32x2 plo[4], phi[4];
 #pragma unroll
           for (int rr = 0; rr < 4; ++rr) {
-            const float2 lo = *reinterpret_cast<const float2*>(pp + RO4[rr]);
-            const float2 hi = *reinterpret_cast<const float2*>(pp + RO4[rr] + 2);
-            d[rr][0] = lo.x; d[rr][1] = lo.y; d[rr][2] = hi.x; d[rr][3] = hi.y;
+            plo[rr] = *reinterpret_cast<const f32x2*>(pp + RO4[rr]);
+            phi[rr] = *reinterpret_cast<const f32x2*>(pp + RO4[rr] + 2);
           }
           f32x4 uf[4];
 #pragma unroll
           for (int xy = 0; xy < 4; ++xy) uf[xy] = *reinterpret_cast<const f32x4*>(u_s + ((g * 4 + xy) * 64 + lane) * 4);
-          float tt[4][4], vv[16];
-#pragma unroll
-          for (int c = 0; c < 4; ++c) {
-            tt[0][c] = d[0][c] - d[2][c]; tt[1][c] = d[1][c] + d[2][c];
-            tt[2][c] = d[2][c] - d[1][c]; tt[3][c] = d[1][c] - d[3][c];
-          }
-#pragma unroll
-          for (int rr = 0; rr < 4; ++rr) {
-            vv[4 * rr + 0] = tt[rr][0] - tt[rr][2]; vv[4 * rr + 1] = tt[rr][1] + tt[rr][2];
-            vv[4 * rr + 2] = tt[rr][2] - tt[rr][1]; vv[4 * rr + 3] = tt[rr][1] - tt[rr][3];
-          }
+          float vv[16];
+          wino_in(plo, phi, vv);
           __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
           for (int xi = 0; xi < 16; ++xi) m[xi] = mfma(uf[xi >> 2][xi & 3], vv[xi], m[xi]);
