@@ -765,11 +765,11 @@ __global__ __launch_bounds__(64 * BWD_WAVES) void cnn_bwd_wino_k(CnnArgs a) {
   f32x4 dU[8];
 #pragma unroll
   for (int xi = 0; xi < 8; ++xi) dU[xi] = f32x4{0.f, 0.f, 0.f, 0.f};
-  float gW1p[4][10];                         // dW1 / db1 per-lane partials: channel 4q+r, tap k (k = 9: bias)
+  f32x2 gW1p[2][10];                         // dW1 / db1 per-lane partials: channels 4q+2h, 4q+2h+1 (packed), tap k (9: bias)
 #pragma unroll
-  for (int r = 0; r < 4; ++r)
+  for (int h = 0; h < 2; ++h)
 #pragma unroll
-    for (int k = 0; k < 10; ++k) gW1p[r][k] = 0.f;
+    for (int k = 0; k < 10; ++k) gW1p[h][k] = f32x2{0.f, 0.f};
   float gb2 = 0.f;                           // thread tid accumulates channel tid/32
 
   for (int i = tid; i < ESZ; i += NT) e_s[i] = 0.f;
@@ -964,15 +964,21 @@ __global__ __launch_bounds__(64 * BWD_WAVES) void cnn_bwd_wino_k(CnnArgs a) {
           }
         }
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          gW1p[r][9] += (dp[0][r] + dp[1][r]) + (dp[2][r] + dp[3][r]);
+        for (int h = 0; h < 2; ++h) {                           // packed over the channel pair (2 flops per lane per op)
+          f32x2 d2[4];
+#pragma unroll
+          for (int p = 0; p < 4; ++p) d2[p] = f32x2{dp[p][2 * h], dp[p][2 * h + 1]};
+          gW1p[h][9] += (d2[0] + d2[1]) + (d2[2] + d2[3]);
 #pragma unroll
           for (int tap = 0; tap < 9; ++tap) {
             const int ky = tap / 3, kx = tap % 3;
-            float acc = gW1p[r][tap];
+            f32x2 acc = gW1p[h][tap];
 #pragma unroll
-            for (int p = 0; p < 4; ++p) acc = fmaf(dp[p][r], ep[(p >> 1) + ky][(p & 1) + kx], acc);
-            gW1p[r][tap] = acc;
+            for (int p = 0; p < 4; ++p) {
+              const float ev = ep[(p >> 1) + ky][(p & 1) + kx];
+              acc = __builtin_elementwise_fma(d2[p], f32x2{ev, ev}, acc);
+            }
+            gW1p[h][tap] = acc;
           }
         }
         // T[tap][pos] = sum_oc W1[oc][tap] dpre1[oc][pos]: dpre1 in the C/D layout IS the B operand
@@ -1036,7 +1042,7 @@ __global__ __launch_bounds__(64 * BWD_WAVES) void cnn_bwd_wino_k(CnnArgs a) {
   for (int r = 0; r < 4; ++r)
 #pragma unroll
     for (int k = 0; k < 10; ++k) {
-      float v = gW1p[r][k];                                    // sum over the 16 tile lanes
+      float v = gW1p[r >> 1][k][r & 1];                        // sum over the 16 tile lanes
       v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 8, 64);
       if (j == 0) prow[NCH * 144 + (4 * q + r) * 16 + k] = v;
     }
