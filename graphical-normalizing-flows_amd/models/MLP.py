@@ -31,6 +31,14 @@ class MLP(nn.Module):
         return self.net(x)
 
 
+def _conv3x3(x, weight, bias):
+    """valid 3x3 convolution as im2col (F.unfold) + one batched matmul; same values as nn.Conv2d."""
+    n, c, h, w = x.shape
+    cols = F.unfold(x, 3)                                        # [n, c*9, (h-2)*(w-2)]
+    y = torch.matmul(weight.view(weight.shape[0], -1), cols) + bias.view(1, -1, 1)
+    return y.view(n, weight.shape[0], h - 2, w - 2)
+
+
 class MNISTCNN(nn.Module):
     """Embedding net of the MNIST DAG flow (reference models/MLP.py:24-48): conv3x3(1->16) ReLU
     conv3x3(16->16) maxpool2 flatten fc(2304->128) ReLU fc(128->out_d).  For the 28x28
@@ -57,10 +65,12 @@ class MNISTCNN(nn.Module):
         if self._fused_conv_ok(x):
             x = ops.MnistConvFn.apply(x.view(-1, 784), self.conv1.weight, self.conv1.bias, self.conv2.weight,
                                       self.conv2.bias)
-        else:   # other image sizes (the reference's multi-scale factory): library convolution
-            x = self.conv1(x.view(-1, self.size_img[0], self.size_img[1], self.size_img[2]))
+        else:   # other image sizes (the 14x14 / 7x7 scales of the multi-scale factory, 7 % of its images):
+            # im2col + library GEMM (no MIOpen: its find step costs minutes on this stack)
+            x = _conv3x3(x.view(-1, self.size_img[0], self.size_img[1], self.size_img[2]), self.conv1.weight,
+                         self.conv1.bias)
             x = F.relu(x)
-            x = self.conv2(x)
+            x = _conv3x3(x, self.conv2.weight, self.conv2.bias)
             x = F.max_pool2d(x, 2)
             x = torch.flatten(x, 1)
         x = ops.mlp(x, [(self.fc1.weight, self.fc1.bias), (self.fc2.weight, self.fc2.bias)])

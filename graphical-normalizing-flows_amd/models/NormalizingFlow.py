@@ -161,3 +161,56 @@ class FCNormalizingFlow(NormalizingFlow):
             x = self.steps[s].invert(z, context)
             z = torch.flip(x, dims=[1]) if s > 0 else x
         return z
+
+
+class CNNormalizingFlow(FCNormalizingFlow):
+    """Multi-scale flow (reference :172-226): after every scale the image is cut into d_c x d_h x d_w blocks; the first
+    element of each block goes on to the next (coarser) flow, the others are emitted as latent variables."""
+
+    def __init__(self, steps, z_log_density, dropping_factors):
+        super(CNNormalizingFlow, self).__init__(steps, z_log_density)
+        self.dropping_factors = dropping_factors
+
+    @staticmethod
+    def _blocks(z, img_size, drop):
+        """[B, C*H*W] -> [B, c, h, w, d_c*d_h*d_w]  (the unfold chain of reference :184-185)"""
+        C, H, W = img_size
+        d_c, d_h, d_w = drop
+        c, h, w = int(C / d_c), int(H / d_h), int(W / d_w)
+        return z.view(-1, c, d_c, h, d_h, w, d_w).permute(0, 1, 3, 5, 2, 4, 6).reshape(z.shape[0], c, h, w, -1)
+
+    def forward(self, x, context=None):
+        b_size = x.shape[0]
+        jac_tot = 0.
+        z_all = []
+        for step, drop in zip(self.steps, self.dropping_factors):
+            z, jac = step(x, context)
+            blocks = self._blocks(z, step.img_sizes, drop)
+            z_all.append(blocks[..., 1:].reshape(b_size, -1))
+            x = blocks[..., 0].reshape(b_size, -1)
+            jac_tot = jac_tot + jac
+        z_all.append(x)
+        return torch.cat(z_all, 1), jac_tot
+
+    def invert(self, z, context=None):
+        b_size = z.shape[0]
+        parts, i = [], 0
+        for step, drop in zip(self.steps, self.dropping_factors):
+            C, H, W = step.img_sizes
+            c, h, w = int(C / drop[0]), int(H / drop[1]), int(W / drop[2])
+            nb_z = C * H * W - c * h * w if C * H * W != c * h * w else c * h * w
+            parts.append(z[:, i:i + nb_z])
+            i += nb_z
+        x = None
+        for k in range(len(self.steps) - 1, -1, -1):
+            step, drop = self.steps[k], self.dropping_factors[k]
+            C, H, W = step.img_sizes
+            d_c, d_h, d_w = drop
+            c, h, w = int(C / d_c), int(H / d_h), int(W / d_w)
+            zk = parts[k]
+            if c * h * w != C * H * W:       # re-interleave the kept element with the dropped ones of each block
+                blocks = torch.cat((x.view(b_size, c, h, w, 1), zk.reshape(b_size, c, h, w, -1)), 4)
+                zk = blocks.view(b_size, c, h, w, d_c, d_h, d_w).permute(0, 1, 4, 2, 5, 3, 6).reshape(b_size, -1)
+            x = step.invert(zk.reshape(b_size, -1), context)
+        return x
+

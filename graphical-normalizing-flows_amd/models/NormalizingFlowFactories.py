@@ -6,7 +6,7 @@ import torch.nn as nn
 from gnf_hip import ops
 from .Normalizers import *
 from .Conditionners import *
-from .NormalizingFlow import NormalizingFlowStep, FCNormalizingFlow
+from .NormalizingFlow import NormalizingFlowStep, FCNormalizingFlow, CNNormalizingFlow
 from .MLP import MNISTCNN, CIFAR10CNN
 
 
@@ -50,10 +50,31 @@ def MNIST_A_prior(in_size, kernel):
 
 def buildMNISTNormalizingFlow(nb_inner_steps, normalizer_type, normalizer_args, l1=0., nb_epoch_update=10,
                               hot_encoding=False, prior_kernel=None):
-    """Single-scale MNIST DAG flow (reference :79-95).  The 3-scale variant (:51-78) needs
-    CNNormalizingFlow, which is outside the hot path of this build."""
+    """MNIST DAG flows of the reference (:49-97): one 28x28 scale, or three scales 28/14/7 (CNNormalizingFlow)."""
     if len(nb_inner_steps) == 3:
-        raise NotImplementedError("multi-scale CNNormalizingFlow is out of scope of the hot-path build")
+        img_sizes = [[1, 28, 28], [1, 14, 14], [1, 7, 7]]
+        dropping_factors = [[1, 2, 2], [1, 2, 2], [1, 1, 1]]
+        fc_l = [[2304, 128], [400, 64], [16, 16]]
+        outter_steps = []
+        for i, fc in enumerate(fc_l):
+            in_size = img_sizes[i][0] * img_sizes[i][1] * img_sizes[i][2]
+            inner_steps = []
+            for step in range(nb_inner_steps[i]):
+                emb_s = 2 if normalizer_type is AffineNormalizer else 30
+                hidden = MNISTCNN(fc_l=fc, size_img=img_sizes[i], out_d=emb_s)
+                A_prior = MNIST_A_prior(img_sizes[i][1], prior_kernel) if prior_kernel is not None else None
+                cond = DAGConditioner(in_size, hidden, emb_s, l1=l1, nb_epoch_update=nb_epoch_update,
+                                      hot_encoding=hot_encoding, A_prior=A_prior)
+                if normalizer_type is MonotonicNormalizer:
+                    emb_s = 30 + in_size if hot_encoding else 30
+                    norm = normalizer_type(**normalizer_args, cond_size=emb_s)
+                else:
+                    norm = normalizer_type(**normalizer_args)
+                inner_steps.append(NormalizingFlowStep(cond, norm))
+            flow = FCNormalizingFlow(inner_steps, None)
+            flow.img_sizes = img_sizes[i]
+            outter_steps.append(flow)
+        return CNNormalizingFlow(outter_steps, NormalLogDensity(), dropping_factors)
     elif len(nb_inner_steps) == 1:
         inner_steps = []
         for step in range(nb_inner_steps[0]):

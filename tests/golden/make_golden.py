@@ -275,6 +275,33 @@ def main():
     save("flow_mono_made_1", x=npy(x), h=npy(hcond), jac=npy(jac), logdet=npy(torch.log(jac).sum(1)),
          state_keys=np.array(list(f.state_dict().keys())), **state_np(f, "p."))
 
+    # 3-scale MNIST factory (CNNormalizingFlow, Factories.py:51-78), Affine, kernel-2 priors, deterministic gates, B=2.
+    # invert() is not recordable here (DAGConditioner.depth needs networkx < 3).  Gradients of the large fc1 weights
+    # are stored for their first 8 rows only.
+    CNNormalizingFlow = models.NormalizingFlow.CNNormalizingFlow if hasattr(models, "NormalizingFlow") else None
+    torch.manual_seed(16)
+    f = buildMNISTNormalizingFlow([1, 1, 1], AffineNormalizer, {}, l1=0., nb_epoch_update=10, hot_encoding=False,
+                                  prior_kernel=2)
+    for c in f.getConditioners():
+        c.stoch_gate = False
+    xt = logit_mnist_like(gen, 2, 784)
+    z, ld = f(xt.clone())
+    loss = f.loss(z, ld)
+    loss.backward()
+    arr = {"p." + k: npy(v) for k, v in f.state_dict().items() if not k.endswith("conditioner.A")}
+    for k, p_ in f.named_parameters():
+        if k.endswith("conditioner.A"):
+            gA = npy(p_.grad)
+            nz = np.argwhere(gA != 0).astype(np.int32)
+            arr["gAidx." + k] = nz
+            arr["gAval." + k] = gA[nz[:, 0], nz[:, 1]]
+        elif p_.numel() > 50000:
+            arr["g8." + k] = npy(p_.grad)[:8]
+        else:
+            arr["g." + k] = npy(p_.grad)
+    save("flow_mnist3_affine", x=npy(xt), z=npy(z), logdet=npy(ld), loss=npy(loss),
+         state_keys=np.array(list(f.state_dict().keys())), **arr)
+
 
 if __name__ == "__main__":
     main()

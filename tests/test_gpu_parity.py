@@ -351,6 +351,59 @@ def test_mnist_affine_dag_flow_golden():
             assert rel_err(named[k[2:]].grad.cpu(), v) < GTOL, k
 
 
+def test_mnist_three_scale_flow_golden():
+    """CNNormalizingFlow of the 3-scale MNIST factory (reference Factories.py:51-78, NormalizingFlow.py:172-194),
+    deterministic gates: z, log-det, loss and gradients against the reference."""
+    from models import AffineNormalizer
+    from models.NormalizingFlowFactories import buildMNISTNormalizingFlow
+    g = load_golden("flow_mnist3_affine")
+    flow = buildMNISTNormalizingFlow([1, 1, 1], AffineNormalizer, {}, l1=0., nb_epoch_update=10, hot_encoding=False,
+                                     prior_kernel=2)
+    assert list(flow.state_dict().keys()) == list(g["state_keys"])
+    sd = {k[2:]: v for k, v in g.items() if k.startswith("p.")}
+    for k, v in flow.state_dict().items():
+        if k.endswith("conditioner.A"):
+            sd[k] = v.detach().clone()                   # the kernel-2 priors themselves
+    flow.load_state_dict(sd)
+    flow = flow.to(DEV)
+    for c in flow.getConditioners():
+        c.stoch_gate = False
+    z, ld = flow(cu(g["x"]))
+    assert rel_err(z.cpu(), g["z"]) < TOL and rel_err(ld.cpu(), g["logdet"]) < TOL
+    loss = flow.loss(z, ld)
+    assert rel_err(loss.detach().cpu(), g["loss"]) < TOL
+    loss.backward()
+    named = dict(flow.named_parameters())
+    for k, v in g.items():
+        if k.startswith("g."):
+            assert rel_err(named[k[2:]].grad.cpu(), v) < GTOL, k
+        elif k.startswith("g8."):
+            assert rel_err(named[k[3:]].grad.cpu()[:8], v) < GTOL, k
+        elif k.startswith("gAidx."):
+            gA = named[k[6:]].grad.cpu()
+            idx = v.long()
+            assert rel_err(gA[idx[:, 0], idx[:, 1]], g["gAval." + k[6:]]) < GTOL, k
+            assert int((gA != 0).sum()) == idx.shape[0]
+
+
+def test_mnist_three_scale_invert_round_trip():
+    from models import AffineNormalizer
+    from models.NormalizingFlowFactories import buildMNISTNormalizingFlow
+    torch.manual_seed(3)
+    flow = buildMNISTNormalizingFlow([1, 1, 1], AffineNormalizer, {}, prior_kernel=1).to(DEV)
+    for c in flow.getConditioners():
+        c.stoch_gate = False
+        n = int(round(c.in_size ** .5))          # the window prior is symmetric (not a DAG): keep "pixel above" only
+        A = torch.zeros(c.in_size, c.in_size)
+        A[torch.arange(n, c.in_size), torch.arange(0, c.in_size - n)] = 1.
+        c.A.data.copy_(A)
+    x = cu(torch.randn(2, 784))
+    with torch.no_grad():
+        z, _ = flow(x)
+        xr = flow.invert(z)
+    assert rel_err(xr.cpu(), x.cpu()) < 1e-4
+
+
 # --------------------------------------------------------------------------------- Monotonic vs oracle
 def _mono_case(B, d, c, hidden, S, seed, h_layout="contig"):
     from models import MonotonicNormalizer

@@ -113,3 +113,20 @@ def test_cc_rule_matches_oracle_and_solver_switch():
         assert np.array_equal(w.numpy(), wo.astype(np.float32)) and np.array_equal(t.numpy(), to.astype(np.float32))
     n = MonotonicNormalizer([8, 8], 3, nb_steps=20, solver="Euler")
     assert n(torch.randn(2, 2), torch.randn(2, 2, 3)) is None      # unknown solver -> None (reference :64-65)
+
+
+def test_cn_flow_block_split_matches_reference_unfold():
+    """CNNormalizingFlow._blocks == the reference's unfold chain (NormalizingFlow.py:184-185), and the re-interleave of
+    invert() is its exact inverse (reference :215-222)."""
+    from models.NormalizingFlow import CNNormalizingFlow
+    b, C, H, W = 3, 1, 6, 6
+    for drop in ([1, 2, 2], [1, 3, 3], [1, 1, 1]):
+        d_c, d_h, d_w = drop
+        c, h, w = C // d_c, H // d_h, W // d_w
+        z = torch.arange(b * C * H * W, dtype=torch.float32).view(b, -1)
+        ref = z.view(-1, C, H, W).unfold(1, d_c, d_c).unfold(2, d_h, d_h).unfold(3, d_w, d_w).contiguous().view(b, c, h, w, -1)
+        own = CNNormalizingFlow._blocks(z, [C, H, W], drop)
+        assert torch.equal(own, ref)
+        back = own.view(b, c, h, w, d_c, d_h, d_w).permute(0, 1, 4, 2, 5, 3, 6).reshape(b, -1)
+        assert torch.equal(back, z)
+
