@@ -1,4 +1,5 @@
 import networkx as nx
+import numpy as np
 import torch
 import torch.nn as nn
 
@@ -218,6 +219,51 @@ class DAGConditioner(Conditioner):
         if self.is_invertible or nx.is_directed_acyclic_graph(G):
             return int(nx.dag_longest_path_length(G))
         return 0
+
+    def levels(self, P=None):
+        """Topological generations of the dependency graph (edge j -> i where the importance P[i, j] != 0; default: the
+        graph depth() measures, A[i, j] > 0): level k holds the variables whose longest parent chain has length k.
+        None if the graph has a cycle."""
+        adj = ((self.A.detach() > 0) if P is None else (P.detach() != 0)).cpu().numpy()
+        d = adj.shape[0]
+        indeg = adj.sum(1).astype(np.int64)                 # number of parents of i
+        children = [np.nonzero(adj[:, j])[0] for j in range(d)]
+        frontier = np.nonzero(indeg == 0)[0]
+        out, done = [], 0
+        while frontier.size:
+            out.append(torch.as_tensor(frontier, dtype=torch.long, device=self.A.device))
+            done += frontier.size
+            nxt = []
+            for j in frontier:
+                for i in children[j]:
+                    indeg[i] -= 1
+                    if indeg[i] == 0:
+                        nxt.append(i)
+            frontier = np.array(sorted(nxt), dtype=np.int64)
+        return out if done == d else None
+
+    def deterministic_importance(self):
+        """The matrix the deterministic branches of forward multiply x with (reference :126-153), or None when a
+        stochastic / noisy gate is active."""
+        if self.stoch_gate or self.noise_gate:
+            if self.h_thresh > 0 or self.s_thresh:
+                return None
+        if self.h_thresh > 0:
+            return self.hard_thresholded_A()
+        if self.s_thresh:
+            return self.soft_thresholded_A()
+        return self.A
+
+    def forward_rows(self, x, rows, P):
+        """h[:, rows, :] only: the conditioner output of row i depends on x through x * P[i] alone, so a
+        level-scheduled inversion evaluates each row exactly once."""
+        B, R = x.shape[0], rows.numel()
+        e = x.unsqueeze(1) * P[rows].unsqueeze(0)                        # [B, R, d]
+        if self.hot_encoding:
+            hot = torch.zeros(R, self.in_size, device=x.device, dtype=x.dtype)
+            hot[torch.arange(R, device=x.device), rows] = 1.
+            e = torch.cat((e, hot.unsqueeze(0).expand(B, -1, -1)), 2)
+        return self.embedding_net(e.reshape(B * R, -1)).view(B, R, -1)
 
     def step(self, epoch_number, loss_avg=0.):
         """Once per epoch (:273-293): exponent back-off and dual update schedule."""

@@ -47,6 +47,7 @@ class NormalizingFlowStep(NormalizingFlow):
         super(NormalizingFlowStep, self).__init__()
         self.conditioner = conditioner
         self.normalizer = normalizer
+        self.level_schedule = True       # invert(): topological level schedule for DAG conditioners
 
     def forward(self, x, context=None):
         h = self.conditioner(x, context)
@@ -85,6 +86,18 @@ class NormalizingFlowStep(NormalizingFlow):
         """Fixed-point inverse: depth()+1 passes, early exit on exact equality (:98-107;
         the reference's progress print is dropped)."""
         x = torch.zeros_like(z)
+        if type(self.conditioner) is DAGConditioner and context is None and self.level_schedule:
+            # DAG-ordered inversion: every variable is inverted once, after its parents -- d conditioner rows in total
+            # instead of (depth + 1) * d; same values as the fixed-point passes below (non-parents are masked by
+            # exact zeros either way)
+            P = self.conditioner.deterministic_importance()
+            levels = self.conditioner.levels(P) if P is not None else None
+            if levels is not None:
+                with torch.no_grad():
+                    for rows in levels:
+                        h = self.conditioner.forward_rows(x, rows, P)
+                        x[:, rows] = self.normalizer.inverse_transform(z[:, rows].contiguous(), h, context)
+                return x
         with torch.no_grad():
             for i in range(self.conditioner.depth() + 1):
                 h = self.conditioner(x, context)

@@ -404,6 +404,40 @@ def test_mnist_three_scale_invert_round_trip():
     assert rel_err(xr.cpu(), x.cpu()) < 1e-4
 
 
+@pytest.mark.parametrize("normalizer", ["affine", "monotonic"])
+def test_dag_level_schedule_inversion_equals_fixed_point(normalizer):
+    """inverting each variable once, in topological order, gives the values of the reference's
+    depth()+1 full passes (NormalizingFlow.py:98-107)."""
+    from models import DAGConditioner, AffineNormalizer, MonotonicNormalizer, buildFCNormalizingFlow
+    torch.manual_seed(21)
+    d = 9
+    if normalizer == "affine":
+        flow = buildFCNormalizingFlow(1, DAGConditioner, {"in_size": d, "hidden": [24, 24], "out_size": 2,
+                                                          "hot_encoding": True}, AffineNormalizer, {})
+    else:
+        flow = buildFCNormalizingFlow(1, DAGConditioner, {"in_size": d, "hidden": [24, 24], "out_size": 6,
+                                                          "hot_encoding": True},
+                                      MonotonicNormalizer, {"integrand_net": [16, 16], "cond_size": 6,
+                                                            "nb_steps": 20, "solver": "CC"})
+    cond = flow.steps[0].conditioner
+    # non-negative entries: depth() of the reference counts A > 0 edges only (post-processed A is 0/1)
+    cond.A.data.copy_(torch.tril(torch.rand(d, d) + .1, -1) * (torch.rand(d, d) < .5).float())
+    cond.stoch_gate = False
+    flow = flow.to(DEV)
+    z = cu(torch.randn(16, d) * .7)
+    step = flow.steps[0]
+    step.level_schedule = True
+    x_lvl = step.invert(z)
+    step.level_schedule = False
+    x_it = step.invert(z)
+    # Affine: identical up to fp32 rounding of the importance table.  Monotonic: every variable is a 20-step bisection
+    # (resolution 1.9e-5) whose quantisation error is amplified from level to level, in both schedules alike.
+    assert rel_err(x_lvl.cpu(), x_it.cpu()) < (1e-6 if normalizer == "affine" else 5e-3)
+    with torch.no_grad():
+        zz, _ = flow(x_lvl)
+    assert rel_err(zz.cpu(), z.cpu()) < (1e-4 if normalizer == "affine" else 2e-3)   # bisection resolution 1.9e-5 abs
+
+
 # --------------------------------------------------------------------------------- Monotonic vs oracle
 def _mono_case(B, d, c, hidden, S, seed, h_layout="contig"):
     from models import MonotonicNormalizer

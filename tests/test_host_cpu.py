@@ -130,3 +130,22 @@ def test_cn_flow_block_split_matches_reference_unfold():
         back = own.view(b, c, h, w, d_c, d_h, d_w).permute(0, 1, 4, 2, 5, 3, 6).reshape(b, -1)
         assert torch.equal(back, z)
 
+
+def test_dag_levels_match_networkx_generations():
+    import networkx as nx
+    from models import DAGConditioner
+    torch.manual_seed(0)
+    d = 12
+    cond = DAGConditioner(d, [8], 2)
+    A = torch.tril(torch.rand(d, d), -1) * (torch.rand(d, d) < .3).float()
+    perm = torch.randperm(d)
+    A = A[perm][:, perm]                                     # a DAG in a shuffled variable order
+    cond.A.data.copy_(A)
+    lv = cond.levels()
+    G = nx.from_numpy_array((A > 0).numpy().T, create_using=nx.DiGraph)      # edge j -> i where A[i, j] > 0
+    ref = [sorted(g) for g in nx.topological_generations(G)]
+    assert [sorted(t.tolist()) for t in lv] == ref
+    assert len(lv) == cond.depth() + 1
+    cond.A.data[perm[0], perm[1]] = 1.; cond.A.data[perm[1], perm[0]] = 1.   # a 2-cycle
+    assert cond.levels() is None
+
