@@ -97,9 +97,15 @@ def cpu_baseline():
         step()
         n += 1
     dt = (time.perf_counter() - t0) / n
+    torch.set_num_threads(1)                 # plus a 1-thread figure
+    t0 = time.perf_counter()
+    step()
+    dt1 = time.perf_counter() - t0
+    torch.set_num_threads(cores)
     return {"value": Bc / dt, "unit": "samples/s", "cores": cores, "kind": "port",
             "sample": "%d steps of B=%d (same d=784 model, S=20), fwd+logdet+NLL+bwd, torch %d threads"
-                      % (n, Bc, cores)}
+                      % (n, Bc, cores),
+            "value_1thread": Bc / dt1}
 
 
 def measured_peaks(dev):
@@ -185,6 +191,31 @@ def main():
     prof = abi.profile_collect()
     if not torch.isfinite(loss).item():
         raise SystemExit("non-finite loss")
+
+    # secondary figures of SURVEY.md 8(d), outside the timed region of the headline: (i) fwd + log-det + NLL + bwd
+    # without all-reduce / Adam, (ii) the full step with the training-realistic node count S ~ U{20..29}
+    def timed(fn, n):
+        fence()
+        t = time.perf_counter()
+        for i in range(n):
+            fn(i)
+        fence()
+        return (time.perf_counter() - t) / n
+
+    def fwd_bwd(_):
+        for p in flow.parameters():
+            p.grad = None
+        z, ld = flow(x)
+        flow.loss(z, ld).backward()
+
+    def mixed(i):
+        for nrm in flow.getNormalizers():
+            nrm.nb_steps = 20 + (7 * i + 3) % 10
+        from gnf_hip import dp as _dp
+        _dp.train_step(flow, state, x, lr=1e-3, weight_decay=1e-5)
+
+    t_fb = timed(fwd_bwd, 10)
+    t_mix = timed(mixed, 10)
     tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -231,6 +262,9 @@ def main():
         if dom in issued:
             out["roofline"]["mfma_issue_frac"] = round(issued[dom] * 2048. * n_elem / (prof[dom] * 1e-3) / 1e12
                                                        / PEAK_F32_TFLOPS, 4)
+        out["secondary"] = {"fwd_bwd_only_samples_per_s": round(B_PER_GPU * world / t_fb, 1),
+                            "full_step_S_mix_20_29_samples_per_s": round(B_PER_GPU * world / t_mix, 1),
+                            "note": "10 steps each, per-rank wall clock of rank 0 (not max over ranks)"}
         out["measured_peaks"] = measured_peaks(dev)
         out["roofline"]["frac_of_measured_peak"] = round(achieved / out["measured_peaks"]["mfma_f32_TFLOPs"], 4)
         if world == 1 and not args.no_cpu_baseline:
