@@ -36,6 +36,35 @@ class FlatState:
         if dist.is_initialized() and dist.get_world_size() > 1:
             dist.broadcast(self.flat, src)
 
+    # ---- checkpoint compatibility with the reference drivers, which save `torch.optim.Adam(model.parameters())
+    #      .state_dict()` as ADAM.pt (UCIExperiments.py:216-220, ImageExperiments.py:251-253)
+    def optimizer_state_dict(self, module, lr=1e-3, weight_decay=1e-5):
+        index = {id(p): i for i, p in enumerate(module.parameters())}
+        state, o = {}, 0
+        for p in self.params:
+            k = p.numel()
+            if self.t > 0:
+                state[index[id(p)]] = {"step": torch.tensor(float(self.t)),
+                                       "exp_avg": self.m[o:o + k].view_as(p).clone(),
+                                       "exp_avg_sq": self.v[o:o + k].view_as(p).clone()}
+            o += (k + 3) // 4 * 4
+        group = {"lr": lr, "betas": (0.9, 0.999), "eps": 1e-8, "weight_decay": weight_decay, "amsgrad": False,
+                 "maximize": False, "foreach": None, "capturable": False, "differentiable": False, "fused": None,
+                 "params": list(range(len(index)))}
+        return {"state": state, "param_groups": [group]}
+
+    def load_optimizer_state_dict(self, module, sd):
+        index = {id(p): i for i, p in enumerate(module.parameters())}
+        o = 0
+        for p in self.params:
+            k = p.numel()
+            st = sd["state"].get(index[id(p)])
+            if st is not None:
+                self.m[o:o + k].copy_(st["exp_avg"].reshape(-1))
+                self.v[o:o + k].copy_(st["exp_avg_sq"].reshape(-1))
+                self.t = max(self.t, int(float(st["step"])))
+            o += (k + 3) // 4 * 4
+
 
 def hip_adam(state, lr, weight_decay, grad_scale):
     from . import ops

@@ -52,7 +52,7 @@ def _worker(rank, world, port, x, out):
     gathered = [torch.empty_like(state.flat) for _ in range(world)]
     dist.all_gather(gathered, state.flat)
     if rank == 0:
-        out.put([g.clone() for g in gathered])
+        out.put([g.numpy().copy() for g in gathered])      # by value: a shared-memory tensor handle can die with the worker
     dist.destroy_process_group()
 
 
@@ -68,7 +68,7 @@ def test_two_rank_step_matches_single_process():
     procs = [ctx.Process(target=_worker, args=(r, 2, port, x, q)) for r in range(2)]
     for p in procs:
         p.start()
-    flats = q.get()
+    flats = [torch.from_numpy(a) for a in q.get()]
     for p in procs:
         p.join(60)
         assert p.exitcode == 0

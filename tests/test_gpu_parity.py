@@ -676,3 +676,32 @@ def test_monotonic_ragged_sizes(B, d, hidden):
     ps = norm.integrand_net.flat_params()
     for (W, b), pw, pb in zip(layers, ps[0::2], ps[1::2]):
         assert rel_err(pw.grad.cpu(), W.grad) < GTOL and rel_err(pb.grad.cpu(), b.grad) < GTOL
+
+
+def test_train_uci_driver_and_checkpoint_formats(tmp_path):
+    """train_uci.py (UCIExperiments.py's role): two epochs on synthetic POWER-shaped data; model.pt carries the
+    reference's state_dict keys and ADAM.pt loads into torch.optim.Adam(model.parameters())."""
+    import train_uci
+    args = train_uci.parse(["-dataset", "power", "-data", "synthetic", "-folder", str(tmp_path), "-nb_epoch", "2",
+                            "-b_size", "2000", "-conditioner", "DAG", "-emb_net", "20", "20", "6", "-normalizer",
+                            "monotonic", "-int_net", "16", "16", "-nb_steps_dual", "30", "-l1", "0."])
+    model = train_uci.train(args)
+    lines = [l for l in open(tmp_path / "logs") if l.startswith("epoch")]
+    assert len(lines) == 2
+    losses = [float(l.split("Train loss:")[1].split()[0]) for l in lines]
+    assert losses[1] < losses[0]                               # N(0,1) data: the NLL goes down from the random init
+    sd = torch.load(tmp_path / "model.pt", map_location="cpu")
+    assert list(sd.keys()) == list(model.state_dict().keys())
+    fresh, _, _ = train_uci.build(args, 6)
+    fresh.load_state_dict(sd)
+    opt = torch.optim.Adam(fresh.parameters(), lr=1e-3, weight_decay=1e-5)
+    opt.load_state_dict(torch.load(tmp_path / "ADAM.pt", map_location="cpu"))
+    assert all("exp_avg" in st for st in opt.state_dict()["state"].values())
+    # resuming restores the fused-Adam moments
+    args2 = train_uci.parse(["-dataset", "power", "-data", "synthetic", "-folder", str(tmp_path), "-nb_epoch", "1",
+                             "-b_size", "2000", "-conditioner", "DAG", "-emb_net", "20", "20", "6", "-normalizer",
+                             "monotonic", "-int_net", "16", "16", "-nb_steps_dual", "30", "-l1", "0.", "-load"])
+    train_uci.train(args2)
+    lines = [l for l in open(tmp_path / "logs") if l.startswith("epoch")]
+    assert float(lines[2].split("Train loss:")[1].split()[0]) < losses[0]
+
