@@ -24,13 +24,27 @@ class FlatState:
         self.m = torch.zeros(n, device=dev)
         self.v = torch.zeros(n, device=dev)
         o = 0
+        self._pads = []                            # zero fillers between parameters, for the one-launch gradient pack
         for p in self.params:
             k = p.numel()
             self.flat[o:o + k].copy_(p.data.reshape(-1))
             p.data = self.flat[o:o + k].view_as(p)
-            p.grad = self.grad[o:o + k].view_as(p)
+            p.grad = None
+            self._pads.append(torch.zeros(pad4(k) - k, device=dev))
             o += pad4(k)
         self.t = 0
+
+    def pack_grads(self):
+        """flat gradient buffer <- the .grad tensors autograd just produced, in ONE concatenation launch.  (.grad views
+        into the flat buffer would cost a zero-fill plus one accumulate kernel per parameter per step.)"""
+        parts = []
+        for p, pad in zip(self.params, self._pads):
+            parts.append(p.grad.reshape(-1) if p.grad is not None else torch.zeros(p.numel(), device=pad.device))
+            if pad.numel():
+                parts.append(pad)
+        torch.cat(parts, out=self.grad)
+        for p in self.params:
+            p.grad = None
 
     def broadcast(self, src=0):
         if dist.is_initialized() and dist.get_world_size() > 1:
@@ -76,10 +90,10 @@ def train_step(flow, state, x_shard, lr=1e-3, weight_decay=1e-5, optimizer=hip_a
     """fwd + log|det J| + NLL (+ constraints) + bwd on the local shard, one all-reduce, Adam.
     loss_rank = constraints - mean_local(log p); averaging over ranks gives the global mean."""
     world = dist.get_world_size() if dist.is_initialized() else 1
-    state.grad.zero_()
     z, logdet = flow(x_shard)
     loss = flow.loss(z, logdet)
     loss.backward()
+    state.pack_grads()
     if world > 1:
         dist.all_reduce(state.grad)                 # the step's only collective
     state.t += 1

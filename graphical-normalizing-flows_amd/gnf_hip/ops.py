@@ -389,3 +389,29 @@ def monotonic_inverse(z, h, nb_steps, params):
 def adam_step(p, g, m, v, step, lr=1e-3, betas=(.9, .999), eps=1e-8, weight_decay=0., grad_scale=1.):
     call("gnf_adam_step", ptr(p), ptr(g), ptr(m), ptr(v), p.numel(), lr, betas[0], betas[1], eps, weight_decay,
          grad_scale, int(step), stream())
+
+
+class PowerTraceFn(torch.autograd.Function):
+    """tr(B^k) of the DAG acyclicity term (DAGConditioner.py:192-194) with the closed-form gradient
+    d tr(B^k) / dB = k (B^(k-1))^T: one power B^(k-1) serves the value (tr(B^k) = sum_ij (B^(k-1))_ij B_ji) and the
+    gradient, instead of autograd through every product of torch.matrix_power (6 instead of 18 d x d GEMMs per step
+    at d = 784, k = 34).  The GEMMs themselves stay on the library."""
+
+    @staticmethod
+    def forward(ctx, B, k):
+        k = int(k)
+        ctx.k = k
+        if k == 0:
+            ctx.save_for_backward(None)
+            return B.new_tensor(float(B.shape[0]))
+        P = torch.matrix_power(B, k - 1)
+        ctx.save_for_backward(P)
+        return (P * B.t()).sum()
+
+    @staticmethod
+    def backward(ctx, g):
+        (P,) = ctx.saved_tensors
+        if ctx.k == 0:
+            return None, None
+        return (g * ctx.k) * P.t(), None
+
