@@ -635,13 +635,112 @@ int launch_bwd(const MonoArgs& a, unsigned grid, hipStream_t s) {
   }
 }
 
+// ---------------------------------------------------------------------------------------
+// Weight gradient of one hidden->hidden layer of a WIDE net from the staged rows:
+//   dW[i][k] (+)= sum_rows dpre[row][i] * act[row][k],   db[i] (+)= sum_rows dpre[row][i]
+// A tall-skinny A^T B: the output is only HP x HP (112^2 / 160^2), the contraction runs over 10^6..10^8 rows.  The
+// generic GEMM tiles the output 64x64 and so streams both staged arrays once per tile row/column (3x at HP = 160);
+// here a workgroup owns the WHOLE output for its slice of rows, so every staged byte is read exactly once
+// (HBM-bound by construction), and the bias gradient rides along as one extra MFMA column against a constant 1.
+// Wavefront w owns output row tiles {w, w+4, w+8}; row slab of 32 staged rows in LDS, next slab prefetched in registers.
+// ---------------------------------------------------------------------------------------
+constexpr int kDwRows = 32;
+template <int HT>
+__global__ __launch_bounds__(256) void mono_dw_k(const float* __restrict__ Y, const float* __restrict__ X,
+                                                 float* __restrict__ Cpart, float* __restrict__ bpart, int64_t rows,
+                                                 int64_t rows_per_wg, int accum) {
+  constexpr int HP = 16 * HT, LD = HP + 4, MT = (HT + 3) / 4;
+  constexpr int NV4 = kDwRows * HP / 4, V4 = (NV4 + 255) / 256;          // float4 per slab and array / per thread
+  __shared__ __attribute__((aligned(16))) float Ys[kDwRows * LD];
+  __shared__ __attribute__((aligned(16))) float Xs[kDwRows * LD];
+  const int tid = threadIdx.x, lane = tid & 63, q = lane >> 4, j = lane & 15;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int64_t r0 = (int64_t)blockIdx.x * rows_per_wg;
+  const int64_t r1 = r0 + rows_per_wg < rows ? r0 + rows_per_wg : rows;
+
+  f32x4 acc[MT][HT + 1];
+#pragma unroll
+  for (int m = 0; m < MT; ++m)
+#pragma unroll
+    for (int n = 0; n <= HT; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  f32x4 py[V4], px[V4];
+  auto fetch = [&](int64_t rb) {
+#pragma unroll
+    for (int v = 0; v < V4; ++v) {
+      const int idx = tid + v * 256, rr = idx / (HP / 4), c4 = idx - rr * (HP / 4);
+      const int64_t row = rb + rr;
+      if (idx < NV4 && row < r1) { py[v] = ld4(Y + row * HP + 4 * c4); px[v] = ld4(X + row * HP + 4 * c4); }
+      else { py[v] = f32x4{0.f, 0.f, 0.f, 0.f}; px[v] = py[v]; }
+    }
+  };
+  if (r0 < r1) fetch(r0);
+  for (int64_t rb = r0; rb < r1; rb += kDwRows) {
+    __syncthreads();                                  // previous slab consumed
+#pragma unroll
+    for (int v = 0; v < V4; ++v) {
+      const int idx = tid + v * 256, rr = idx / (HP / 4), c4 = idx - rr * (HP / 4);
+      if (idx < NV4) {
+        *reinterpret_cast<f32x4*>(Ys + rr * LD + 4 * c4) = py[v];
+        *reinterpret_cast<f32x4*>(Xs + rr * LD + 4 * c4) = px[v];
+      }
+    }
+    __syncthreads();
+    if (rb + kDwRows < r1) fetch(rb + kDwRows);       // in flight under the MFMAs
+#pragma unroll 2
+    for (int ks = 0; ks < kDwRows / 4; ++ks) {
+      float a[MT], b[HT];
+#pragma unroll
+      for (int m = 0; m < MT; ++m) {
+        const int mt = wave + 4 * m;
+        a[m] = mt < HT ? Ys[(4 * ks + q) * LD + 16 * mt + j] : 0.f;
+      }
+#pragma unroll
+      for (int n = 0; n < HT; ++n) b[n] = Xs[(4 * ks + q) * LD + 16 * n + j];
+#pragma unroll
+      for (int m = 0; m < MT; ++m) {
+        if (wave + 4 * m < HT) {
+#pragma unroll
+          for (int n = 0; n < HT; ++n) acc[m][n] = mfma(a[m], b[n], acc[m][n]);
+          acc[m][HT] = mfma(a[m], 1.0f, acc[m][HT]);            // column sums of dpre: the bias gradient
+        }
+      }
+    }
+  }
+  float* C = Cpart + (int64_t)blockIdx.x * HP * HP;
+  float* bp = bpart + (int64_t)blockIdx.x * HP;
+#pragma unroll
+  for (int m = 0; m < MT; ++m) {
+    const int mt = wave + 4 * m;
+    if (mt < HT) {
+#pragma unroll
+      for (int n = 0; n < HT; ++n)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float* cp = C + (16 * mt + 4 * q + r) * HP + 16 * n + j;
+          *cp = accum ? *cp + acc[m][n][r] : acc[m][n][r];
+        }
+      if (j == 0) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float* cp = bp + 16 * mt + 4 * q + r;
+          *cp = accum ? *cp + acc[m][HT][r] : acc[m][HT][r];
+        }
+      }
+    }
+  }
+}
+
+constexpr int kDwGrid = 512;                  // workgroups (= partials) of mono_dw_k
+
 constexpr unsigned kBwdGrid = 256 * 2;        // persistent workgroups of the chain kernel
 constexpr int kSplits = 256;                  // split-K partials per weight-gradient GEMM
 constexpr int64_t kWsTarget = 6ll << 30;      // staging budget the ws_bytes query asks for
 
 struct BwdPlan {
   int64_t chunk_elems;      // elements per chain-kernel launch (multiple of 16)
-  int64_t o_SA[kMaxNH], o_SD[kMaxNH], o_Dsum, o_part, o_gpart[kMaxNH], o_hpart, o_dW[kMaxNH], o_dW1h, o_vec, o_rs;
+  int64_t o_SA[kMaxNH], o_SD[kMaxNH], o_Dsum, o_part, o_gpart[kMaxNH], o_bpart[kMaxNH], o_hpart, o_dW[kMaxNH], o_dW1h,
+      o_vec, o_rs;
   int64_t total_floats;
 };
 
@@ -651,7 +750,9 @@ BwdPlan plan_bwd(const MonoLayout& L, int S, int64_t n, int64_t ws_floats) {
   const int64_t vecw = (L.NH + 2) * HP + 4;
   int64_t fixed = 0;
   P.o_part = fixed; fixed += (int64_t)kBwdGrid * kWaves * vecw;
-  for (int l = 1; l < L.NH; ++l) { P.o_gpart[l] = fixed; fixed += (int64_t)kSplits * HP * HP; }
+  const int64_t npart = (L.HT == 7 || L.HT == 10) ? kDwGrid : kSplits;
+  for (int l = 1; l < L.NH; ++l) { P.o_gpart[l] = fixed; fixed += npart * HP * HP; }
+  for (int l = 1; l < L.NH; ++l) { P.o_bpart[l] = fixed; fixed += (int64_t)kDwGrid * HP; }
   P.o_hpart = fixed; fixed += (int64_t)kSplits * HP * L.c;
   for (int l = 1; l < L.NH; ++l) { P.o_dW[l] = fixed; fixed += HP * HP; }
   P.o_dW1h = fixed; fixed += HP * L.c;
@@ -779,6 +880,17 @@ int gnf_monotonic_bwd(const float* pack, const gnf_mono_net* net, const float* x
     const int accum = ck > 0 ? GNF_GEMM_ACCUM : 0;     // chunk 0 is the largest: it defines the split count
     // d W_l (+)= dpre_l^T * act_{l-1}   (split-K partials, accumulated across chunks)
     for (int l = 1; l < NH; ++l) {
+      if (HT == 7 || HT == 10) {       // wide nets: one pass over the staged rows, bias gradient fused
+        const int64_t rpw = ((rows + kDwGrid - 1) / kDwGrid + kDwRows - 1) / kDwRows * kDwRows;
+        nsp_w = kDwGrid;
+        float* cp = w + P.o_gpart[l];
+        float* bp = w + P.o_bpart[l];
+        const int acc = ck > 0;
+        if (HT == 7) hipLaunchKernelGGL((mono_dw_k<7>), dim3(kDwGrid), dim3(256), 0, s, a.SD[l], a.SA[l], cp, bp, rows, rpw, acc);
+        else hipLaunchKernelGGL((mono_dw_k<10>), dim3(kDwGrid), dim3(256), 0, s, a.SD[l], a.SA[l], cp, bp, rows, rpw, acc);
+        GNF_LAUNCH_CHECK();
+        continue;
+      }
       GemmArgs g{};
       g.A = a.SD[l]; g.sam = 1; g.sak = HP;
       g.B = a.SA[l]; g.sbk = HP; g.sbn = 1;
@@ -799,10 +911,14 @@ int gnf_monotonic_bwd(const float* pack, const gnf_mono_net* net, const float* x
     if ((rc = rowsum(a.part, w + P.o_vec, part_rows, vecw, ck > 0))) return rc;
     if (HT > 4) {                      // bias gradients of wide nets: column sums of the staged arrays
       if ((rc = gnf_rowsum_tall_launch(a.Dsum, w + P.o_vec + 2 * HP, groups * 16, HP, 1, w + P.o_rs, s))) return rc;
-      for (int l = 1; l < NH; ++l)
-        if ((rc = gnf_rowsum_tall_launch(a.SD[l], w + P.o_vec + (2 + l) * HP, rows, HP, 1, w + P.o_rs, s))) return rc;
+      if (HT > 10)
+        for (int l = 1; l < NH; ++l)
+          if ((rc = gnf_rowsum_tall_launch(a.SD[l], w + P.o_vec + (2 + l) * HP, rows, HP, 1, w + P.o_rs, s))) return rc;
     }
   }
+  if (HT == 7 || HT == 10)             // bias gradients of the hidden->hidden layers: partial column sums of mono_dw_k
+    for (int l = 1; l < NH; ++l)
+      if ((rc = rowsum(w + P.o_bpart[l], w + P.o_vec + (2 + l) * HP, kDwGrid, HP, 1))) return rc;
   UnpackArgs u{};
   u.net = *net; u.L = L;
   for (int l = 0; l <= NH; ++l) { u.gW[l] = gW[l]; u.gb[l] = gb[l]; if (!gW[l] || !gb[l]) return GNF_EINVAL; }
