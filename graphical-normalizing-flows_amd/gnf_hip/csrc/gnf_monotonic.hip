@@ -644,9 +644,9 @@ int launch_bwd(const MonoArgs& a, unsigned grid, hipStream_t s) {
 // (HBM-bound by construction), and the bias gradient rides along as one extra MFMA column against a constant 1.
 // Wavefront w owns output row tiles {w, w+4, w+8}; row slab of 32 staged rows in LDS, next slab prefetched in registers.
 // ---------------------------------------------------------------------------------------
-constexpr int kDwRows = 32;
+constexpr int kDwRows = 16;
 template <int HT>
-__global__ __launch_bounds__(256) void mono_dw_k(const float* __restrict__ Y, const float* __restrict__ X,
+__global__ __launch_bounds__(256, 2) void mono_dw_k(const float* __restrict__ Y, const float* __restrict__ X,
                                                  float* __restrict__ Cpart, float* __restrict__ bpart, int64_t rows,
                                                  int64_t rows_per_wg, int accum) {
   constexpr int HP = 16 * HT, LD = HP + 4, MT = (HT + 3) / 4;
