@@ -65,6 +65,8 @@ SIGNATURES = {
                                       ctypes.c_void_p, c_i64, c_i64, c_stream]),
     "gnf_adam_step": (c_int, [c_f, c_f, c_f, c_f, c_i64, c_float, c_float, c_float, c_float, c_float, c_float, c_int,
                               c_stream]),
+    "gnf_adam_step_dev": (c_int, [c_f, c_f, c_f, c_f, c_i64, c_float, c_float, c_float, c_float, c_float, c_float,
+                                  ctypes.c_void_p, c_stream]),
     "gnf_probe_mfma_f32": (c_i64, [c_f, c_int, c_int, c_stream]),
     "gnf_probe_copy": (c_int, [c_f, c_f, c_i64, c_stream]),
 }

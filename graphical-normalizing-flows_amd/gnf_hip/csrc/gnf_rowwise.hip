@@ -229,6 +229,25 @@ __global__ void adam_k(float* __restrict__ p, const float* __restrict__ g, float
   }
 }
 
+// Same update with the step count in device memory, so that a captured hipGraph of the whole training step can be
+// replayed: the bias corrections are recomputed on the device from *step_dev + 1; adam_bump_k then advances it.
+__global__ void adam_dev_k(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                           float* __restrict__ v, int64_t n, float lr, float b1, float b2, float eps, float wd,
+                           float gscale, const int* __restrict__ step_dev) {
+  const float t = (float)(*step_dev + 1);
+  const float bc1 = 1.f - powf(b1, t), bc2_sqrt = sqrtf(1.f - powf(b2, t));
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const float pi = p[i];
+    const float gi = fmaf(wd, pi, g[i] * gscale);
+    const float mi = fmaf(b1, m[i], (1.f - b1) * gi);
+    const float vi = fmaf(b2, v[i], (1.f - b2) * gi * gi);
+    m[i] = mi;
+    v[i] = vi;
+    p[i] = pi - (lr / bc1) * (mi / (sqrtf(vi) / bc2_sqrt + eps));
+  }
+}
+__global__ void adam_bump_k(int* step_dev) { *step_dev += 1; }
+
 // out[n] (+)= sum_p src[p*N + n]: 64 columns per block, 16 wavefronts stride over the rows
 // (coalesced 256-B row segments), fixed-order LDS tree across the wavefronts -> deterministic.
 // blockIdx.y selects a chunk of `rpc` rows (tall inputs: first level of a two-level reduction); the chunk's
@@ -392,6 +411,17 @@ int gnf_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float
   const float bc2s = sqrtf(1.f - powf(beta2, (float)step));
   hipLaunchKernelGGL(adam_k, dim3(grid_1d(n)), dim3(kBlock), 0, (hipStream_t)stream, p, g, m, v, n, lr, beta1, beta2,
                      eps, weight_decay, grad_scale, bc1, bc2s);
+  GNF_LAUNCH_CHECK();
+  return 0;
+}
+
+int gnf_adam_step_dev(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
+                      float eps, float weight_decay, float grad_scale, int* step_dev, gnf_stream_t stream) {
+  if (!p || !g || !m || !v || !step_dev || n < 0) return GNF_EINVAL;
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(adam_dev_k, dim3(grid_1d(n)), dim3(kBlock), 0, (hipStream_t)stream, p, g, m, v, n, lr, beta1,
+                     beta2, eps, weight_decay, grad_scale, (const int*)step_dev);
+  hipLaunchKernelGGL(adam_bump_k, dim3(1), dim3(1), 0, (hipStream_t)stream, step_dev);
   GNF_LAUNCH_CHECK();
   return 0;
 }

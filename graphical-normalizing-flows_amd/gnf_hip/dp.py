@@ -34,17 +34,20 @@ class FlatState:
             o += pad4(k)
         self.t = 0
 
-    def pack_grads(self):
-        """flat gradient buffer <- the .grad tensors autograd just produced, in ONE concatenation launch.  (.grad views
-        into the flat buffer would cost a zero-fill plus one accumulate kernel per parameter per step.)"""
+    def pack_grads(self, grads=None):
+        """flat gradient buffer <- the .grad tensors autograd just produced (or the given list, in self.params order),
+        in ONE concatenation launch.  (.grad views into the flat buffer would cost a zero-fill plus one accumulate
+        kernel per parameter per step.)"""
         parts = []
-        for p, pad in zip(self.params, self._pads):
-            parts.append(p.grad.reshape(-1) if p.grad is not None else torch.zeros(p.numel(), device=pad.device))
+        for i, (p, pad) in enumerate(zip(self.params, self._pads)):
+            g = p.grad if grads is None else grads[i]
+            parts.append(g.reshape(-1) if g is not None else torch.zeros(p.numel(), device=pad.device))
             if pad.numel():
                 parts.append(pad)
         torch.cat(parts, out=self.grad)
-        for p in self.params:
-            p.grad = None
+        if grads is None:
+            for p in self.params:
+                p.grad = None
 
     def broadcast(self, src=0):
         if dist.is_initialized() and dist.get_world_size() > 1:
@@ -99,3 +102,69 @@ def train_step(flow, state, x_shard, lr=1e-3, weight_decay=1e-5, optimizer=hip_a
     state.t += 1
     optimizer(state, lr, weight_decay, 1. / world)
     return loss
+
+
+class GraphedStep:
+    """The whole optimisation step (fwd + log|det J| + NLL + bwd + gradient pack + Adam) captured ONCE into a hipGraph
+    and replayed: for the launch-bound configurations (toy d=2, MADE at B=100: ~100 launches of a few microseconds,
+    host enqueue ~0.8 ms per step) the replay removes the per-launch host cost.  Single-GPU only (the all-reduce stays
+    eager); nothing step-dependent may be passed to a kernel by value, so Adam's step count lives in device memory
+    (gnf_adam_step_dev).  Flows whose conditioner draws Philox noise from a host-side call counter (stochastic DAG
+    gate) would replay the same noise: they are refused.
+
+    Construction runs `warmup` real steps on x_example (they count as training steps), then captures."""
+
+    def __init__(self, flow, state, x_example, lr=1e-3, weight_decay=1e-5, warmup=3):
+        from . import ops
+        if dist.is_initialized() and dist.get_world_size() > 1:
+            raise RuntimeError("GraphedStep is single-process; use train_step under torchrun")
+        for c in flow.getConditioners():
+            if getattr(c, "stoch_gate", False) or getattr(c, "noise_gate", False):
+                if getattr(c, "h_thresh", 0) > 0 or getattr(c, "s_thresh", False):
+                    raise RuntimeError("a stochastic DAG gate draws its noise from a host-side counter: not graphable")
+        self.state, self.flow = state, flow
+        self.x = x_example.clone()
+        self.step_dev = torch.full((1,), state.t, dtype=torch.int32, device=self.x.device)
+
+        # The captured step differentiates w.r.t. FRESH leaves aliasing the parameters (torch.func.functional_call), not
+        # the nn.Parameters themselves: a Parameter's gradient accumulator remembers the stream it was created on and is
+        # kept alive by any older graph the caller still references (a stored loss); capturing through it would record a
+        # dependency on the default stream and the HIP runtime crashes in hipGraphInstantiate.
+        class _Loss(torch.nn.Module):
+            def __init__(self, f):
+                super().__init__()
+                self.flow = f
+
+            def forward(self, x):
+                z, logdet = self.flow(x)
+                return self.flow.loss(z, logdet)
+
+        wrapper = _Loss(flow)
+        name_of = {id(p): n for n, p in wrapper.named_parameters()}
+        names = [name_of[id(p)] for p in state.params]
+
+        def body():
+            leaves = [p.detach().requires_grad_() for p in state.params]
+            loss = torch.func.functional_call(wrapper, dict(zip(names, leaves)), (self.x,))
+            state.pack_grads(torch.autograd.grad(loss, leaves, allow_unused=True))
+            ops.adam_step_dev(state.flat, state.grad, state.m, state.v, self.step_dev, lr=lr,
+                              weight_decay=weight_decay)
+            return loss.detach()
+
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(max(warmup, 1)):
+                body()
+                state.t += 1
+        torch.cuda.current_stream().wait_stream(side)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.loss = body()
+
+    def __call__(self, x):
+        self.x.copy_(x, non_blocking=True)
+        self.graph.replay()
+        self.state.t += 1
+        return self.loss
+

@@ -176,6 +176,13 @@ int gnf_adam_step(float* p, const float* g, float* m, float* v, int64_t n,
                   float lr, float beta1, float beta2, float eps, float weight_decay,
                   float grad_scale, int step, gnf_stream_t stream);
 
+/* Same, with the step count in device memory (*step_dev = number of steps already taken; incremented by the call):
+ * nothing step-dependent is passed by value, so a captured hipGraph of a whole training step can be replayed
+ * (gnf_hip.dp.GraphedStep -- the launch-bound configurations). */
+int gnf_adam_step_dev(float* p, const float* g, float* m, float* v, int64_t n,
+                      float lr, float beta1, float beta2, float eps, float weight_decay,
+                      float grad_scale, int* step_dev, gnf_stream_t stream);
+
 /* ---- device-ceiling probes (measurement aids for bench.py) ---------------
  * gnf_probe_mfma_f32 launches `blocks` workgroups of 8 wavefronts that do nothing but
  * independent v_mfma_f32_16x16x4_f32 chains and returns the number of flops the launch issues

@@ -705,3 +705,46 @@ def test_train_uci_driver_and_checkpoint_formats(tmp_path):
     lines = [l for l in open(tmp_path / "logs") if l.startswith("epoch")]
     assert float(lines[2].split("Train loss:")[1].split()[0]) < losses[0]
 
+
+@pytest.mark.parametrize("kind", ["coupling", "made"])
+def test_graphed_step_equals_eager_steps(kind):
+    """gnf_hip.dp.GraphedStep (one hipGraph per optimisation step, Adam step count in device memory) follows the same
+    parameter trajectory as dp.train_step issued launch by launch."""
+    from gnf_hip import dp
+    from models import (buildFCNormalizingFlow, CouplingConditioner, AutoregressiveConditioner, AffineNormalizer)
+
+    def make():
+        torch.manual_seed(5)
+        if kind == "coupling":
+            f = buildFCNormalizingFlow(2, CouplingConditioner, {"in_size": 4, "hidden": [32, 32], "out_size": 2},
+                                       AffineNormalizer, {})
+        else:
+            f = buildFCNormalizingFlow(1, AutoregressiveConditioner, {"in_size": 12, "hidden": [64, 64], "out_size": 2},
+                                       AffineNormalizer, {})
+        return f.to(DEV)
+    d = 4 if kind == "coupling" else 12
+    xs = [cu(torch.randn(64, d, generator=torch.Generator().manual_seed(100 + i))) for i in range(4)]
+    fa = make()
+    sa = dp.FlatState(fa)
+    for _ in range(3):
+        dp.train_step(fa, sa, xs[0], lr=1e-2)
+    for x in xs:
+        la = dp.train_step(fa, sa, x, lr=1e-2)
+    fb = make()
+    sb = dp.FlatState(fb)
+    gs = dp.GraphedStep(fb, sb, xs[0], lr=1e-2, warmup=3)
+    for x in xs:
+        lb = gs(x)
+    torch.cuda.synchronize()
+    assert sb.t == sa.t == 7 and int(gs.step_dev.item()) == 7
+    # an eager graph of the same flow that is still referenced must not disturb the capture (its gradient accumulators
+    # are bound to the default stream; GraphedStep differentiates w.r.t. fresh leaves instead)
+    fc = make()
+    z, ld = fc(xs[0])
+    keep = fc.loss(z, ld)
+    keep.backward()
+    gc = dp.GraphedStep(fc, dp.FlatState(fc), xs[0])
+    assert torch.isfinite(gc(xs[1])).item() and keep.requires_grad
+    assert rel_err(lb.cpu(), la.detach().cpu()) < 1e-5
+    assert rel_err(sb.flat.cpu(), sa.flat.cpu()) < 1e-5
+

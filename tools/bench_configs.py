@@ -75,8 +75,37 @@ def main():
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t0) / steps
         prof = abi.profile_collect()
+        graphed = None
+        if "--graph" in sys.argv and name in ("cfg1", "cfg3"):
+            # launch-bound configurations: the full optimisation step (incl. Adam) replayed from one hipGraph, next to
+            # the same step issued launch by launch
+            from gnf_hip import dp
+            loss_value = round(loss.item(), 4)
+            del loss                                   # GraphedStep needs the eager graphs gone
+            state = dp.FlatState(flow)
+            for _ in range(3):
+                dp.train_step(flow, state, x)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(50):
+                dp.train_step(flow, state, x)
+            torch.cuda.synchronize()
+            t_eager = (time.perf_counter() - t0) / 50
+            gs = dp.GraphedStep(flow, state, x)
+            for _ in range(3):
+                gs(x)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(50):
+                gl = gs(x)
+            torch.cuda.synchronize()
+            t_graph = (time.perf_counter() - t0) / 50
+            graphed = {"full_step_eager_ms": round(t_eager * 1e3, 3), "full_step_hipgraph_ms": round(t_graph * 1e3, 3),
+                       "samples_per_s_hipgraph": round(x.shape[0] / t_graph, 1), "loss": round(gl.item(), 4)}
         print(json.dumps({"config": name, "B": x.shape[0], "d": x.shape[1], "ms_per_step": round(dt * 1e3, 3),
-                          "samples_per_s": round(x.shape[0] / dt, 1), "loss": round(loss.item(), 4),
+                          "hipgraph": graphed,
+                          "samples_per_s": round(x.shape[0] / dt, 1),
+                          "loss": loss_value if graphed is not None else round(loss.item(), 4),
                           "ops_ms_per_call": {k: round(v, 4) for k, v in sorted(prof.items())},
                           "peak_mem_GB": round(torch.cuda.max_memory_allocated() / 2 ** 30, 2)}), flush=True)
         del flow, x
