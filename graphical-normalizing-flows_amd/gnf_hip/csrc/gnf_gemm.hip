@@ -362,10 +362,13 @@ int gnf_gemm_launch(GemmArgs g, int splits, hipStream_t s) {
 
 // split-K plan of the public entry: few output tiles and a long K -> spread K over the chip
 static int plan_splits(int64_t M, int64_t N, int64_t K) {
+  // Fewer 64x64 output tiles than ~3/4 of the CUs: split K until the chip is covered, at least 128 of K per split.
+  // (The MADE layers at B = 100 are 2 x 16 tiles with K = 1024: unsplit they ran on 32 of the 256 CUs.)
   const int64_t tiles = ((M + 63) / 64) * ((N + 63) / 64);
-  if (tiles >= 256 || K < 2048) return 1;
-  int64_t s = (768 + tiles - 1) / tiles;
-  if (s > K / 512) s = K / 512;
+  if (K < 512 || tiles >= (K < 2048 ? 192 : 256)) return 1;
+  int64_t s = ((K < 2048 ? 512 : 768) + tiles - 1) / tiles;
+  const int64_t kmin = K < 2048 ? 128 : 512;
+  if (s > K / kmin) s = K / kmin;
   if (s > 512) s = 512;
   return s < 2 ? 1 : (int)s;
 }
