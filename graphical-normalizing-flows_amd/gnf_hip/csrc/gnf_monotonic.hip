@@ -301,10 +301,24 @@ __global__ __launch_bounds__(64 * kWaves) void mono_bwd_k(MonoArgs a) {
     wp = smem;
   }
   // SWAP: copy one [HP][LDW] matrix of the pack into LDS; every wave of the workgroup calls it at the same point
+  // (8 independent loads in flight per thread: a load -> store chain per 16 bytes exposes one L2 round trip per
+  //  iteration, 26 of them per matrix at H = 150 -- measured 60 % of the kernel stalled with the MFMA pipe idle)
   auto load_mat = [&](int off) -> const float* {
     __syncthreads();                              // previous matrix no longer read
-    for (int i = threadIdx.x * 4; i < L.HP * L.LDW; i += blockDim.x * 4)
-      *reinterpret_cast<f32x4*>(smem + i) = ld4(a.pack + off + i);
+    const int n = L.HP * L.LDW, stride = blockDim.x * 4;
+    for (int i0 = threadIdx.x * 4; i0 < n; i0 += 8 * stride) {
+      f32x4 t[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int i = i0 + u * stride;
+        t[u] = i < n ? ld4(a.pack + off + i) : f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int i = i0 + u * stride;
+        if (i < n) *reinterpret_cast<f32x4*>(smem + i) = t[u];
+      }
+    }
     __syncthreads();
     return smem;
   };
