@@ -65,15 +65,19 @@ def main():
             loss = flow.loss(z, ld)
             loss.backward()
             return loss
-        for _ in range(2):
+        for _ in range(3):
             loss = step()
         torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        loss = step()
+        torch.cuda.synchronize()
+        nst = steps if time.perf_counter() - t0 > .05 else max(steps, 30)     # short steps: average over more of them
         abi.profile_enable(list(abi.SIGNATURES))
         t0 = time.perf_counter()
-        for _ in range(steps):
+        for _ in range(nst):
             loss = step()
         torch.cuda.synchronize()
-        dt = (time.perf_counter() - t0) / steps
+        dt = (time.perf_counter() - t0) / nst
         prof = abi.profile_collect()
         graphed = None
         if "--graph" in sys.argv and name in ("cfg1", "cfg3"):
