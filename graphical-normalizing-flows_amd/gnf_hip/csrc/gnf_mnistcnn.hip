@@ -281,6 +281,18 @@ __global__ __launch_bounds__(64 * FWD_WAVES) void cnn_fwd_wino_k(CnnArgs a) {
   }
 
   for (int i = tid; i < 2 * ESZ; i += NT) e_s[i] = 0.f;
+  // conv1 tile k of this wavefront: (image slot, 16 positions) -> e_s offset (high half) | a1_s offset (low half,
+  // 0xFFFF: nothing to store).  a1 offsets of slot 1 exceed 16 bits, so the slot is folded in as s * A1SZ at use.
+  int c1off[12];
+#pragma unroll
+  for (int k = 0; k < 12; ++k) {
+    const int tile = wave + NW * k;
+    const int sl = tile >= 43, pos = 16 * (tile - 43 * sl) + j;
+    const bool ok = tile < 86 && pos < C1 * C1;
+    const int pc = ok ? pos : 0;
+    const int y = pc / C1, x = pc - y * C1;
+    c1off[k] = (((tile < 86 ? sl : 0) * ESZ + y * ROWE + x) << 16) | (ok ? (sl << 15) | (y * ROW + x) : 0xFFFF);
+  }
 
   const int64_t npair = (a.n + 1) >> 1;
   constexpr int EPT = (2 * IMG * IMG + NT - 1) / NT;          // pixels of an image pair per thread
@@ -307,22 +319,17 @@ __global__ __launch_bounds__(64 * FWD_WAVES) void cnn_fwd_wino_k(CnnArgs a) {
     __syncthreads();
     fetch(pair + gridDim.x);                           // next pair's pixels: in flight under the MFMAs
 
-    // conv1 + ReLU of both images: 86 tiles of 16 consecutive positions, up to 6 in flight per wavefront
+    // conv1 + ReLU of both images: 86 tiles of 16 consecutive positions, up to 6 in flight per wavefront; the tile ->
+    // LDS offsets are the same for every image pair and come packed from c1off (computed once per kernel)
 #pragma unroll
     for (int k0 = 0; k0 < 12; k0 += 6) {
-      int po[6];
       f32x4 acc[6];
       float ev[6][3];
 #pragma unroll
       for (int k = 0; k < 6; ++k) {
-        const int tile = wave + NW * (k0 + k);         // wave-uniform
-        const int s = tile >= 43, pos = 16 * (tile - 43 * s) + j;
-        const bool ok = tile < 86 && pos < C1 * C1;
-        const int pc = ok ? pos : 0;
-        const int y = pc / C1, x = pc - y * C1;
-        po[k] = ok ? s * A1SZ + y * ROW + x : -1;
+        const float* pe = e_s + (c1off[k0 + k] >> 16);
 #pragma unroll
-        for (int t = 0; t < 3; ++t) ev[k][t] = e_s[(tile < 86 ? s : 0) * ESZ + y * ROWE + x + off1[t]];
+        for (int t = 0; t < 3; ++t) ev[k][t] = pe[off1[t]];
         acc[k] = b1v;
       }
 #pragma unroll
@@ -330,11 +337,14 @@ __global__ __launch_bounds__(64 * FWD_WAVES) void cnn_fwd_wino_k(CnnArgs a) {
 #pragma unroll
         for (int k = 0; k < 6; ++k) acc[k] = mfma(w1f[t], ev[k][t], acc[k]);
 #pragma unroll
-      for (int k = 0; k < 6; ++k)
-        if (po[k] >= 0) {
+      for (int k = 0; k < 6; ++k) {
+        const int pk = c1off[k0 + k] & 0xFFFF;
+        if (pk != 0xFFFF) {
+          const int po = (pk >> 15) * A1SZ + (pk & 0x7FFF);
 #pragma unroll
-          for (int r = 0; r < 4; ++r) a1_s[(4 * q + r) * CH + po[k]] = fmaxf(acc[k][r], 0.f);
+          for (int r = 0; r < 4; ++r) a1_s[(4 * q + r) * CH + po] = fmaxf(acc[k][r], 0.f);
         }
+      }
     }
     __syncthreads();
 
