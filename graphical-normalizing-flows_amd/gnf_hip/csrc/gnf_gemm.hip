@@ -365,6 +365,14 @@ static int plan_splits(int64_t M, int64_t N, int64_t K) {
   // Fewer 64x64 output tiles than ~3/4 of the CUs: split K until the chip is covered, at least 128 of K per split.
   // (The MADE layers at B = 100 are 2 x 16 tiles with K = 1024: unsplit they ran on 32 of the 256 CUs.)
   const int64_t tiles = ((M + 63) / 64) * ((N + 63) / 64);
+  // Long-K weight-gradient shapes with a small output (fc1 dW: 128 x 2304 x 78400): 128x128 tiles read the tall
+  // operands half as often as 64x64 ones (the launch is L2/HBM-bound on them); enough splits to fill the chip.
+  const int64_t t128 = ((M + 127) / 128) * ((N + 127) / 128);
+  if (K >= 8192 && t128 <= 64 && t128 * 16 <= tiles * 5) {
+    int64_t s128 = (640 + t128 - 1) / t128;
+    if (s128 > K / 512) s128 = K / 512;
+    if (s128 >= 2) return (int)(s128 > 512 ? 512 : s128);
+  }
   if (K < 512 || tiles >= (K < 2048 ? 192 : 256)) return 1;
   int64_t s = ((K < 2048 ? 512 : 768) + tiles - 1) / tiles;
   const int64_t kmin = K < 2048 ? 128 : 512;
