@@ -176,7 +176,8 @@ int gnf_adam_step(float* p, const float* g, float* m, float* v, int64_t n,
                   float lr, float beta1, float beta2, float eps, float weight_decay,
                   float grad_scale, int step, gnf_stream_t stream);
 
-/* Same, with the step count in device memory (*step_dev = number of steps already taken; incremented by the call):
+/* Same update (torch.optim.Adam at ImageExperiments.py:173 / UCIExperiments.py:97), with the step count in device
+ * memory (*step_dev = number of steps already taken; incremented by the call):
  * nothing step-dependent is passed by value, so a captured hipGraph of a whole training step can be replayed
  * (gnf_hip.dp.GraphedStep -- the launch-bound configurations). */
 int gnf_adam_step_dev(float* p, const float* g, float* m, float* v, int64_t n,
