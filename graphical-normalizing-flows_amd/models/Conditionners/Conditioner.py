@@ -28,3 +28,15 @@ class Conditioner(nn.Module):
 
     def depth(self):
         pass
+
+
+def relu_stack(sizes):
+    """nn.Sequential(Linear, ReLU, Linear, ..., Linear) over consecutive `sizes`: the parameter container every
+    conditioner MLP of the reference uses (keys net.0, net.2, ...)."""
+    mods = []
+    for i, (n_in, n_out) in enumerate(zip(sizes[:-1], sizes[1:])):
+        if i:
+            mods.append(nn.ReLU())
+        mods.append(nn.Linear(n_in, n_out))
+    return nn.Sequential(*mods)
+

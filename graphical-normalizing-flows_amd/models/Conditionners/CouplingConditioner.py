@@ -1,46 +1,48 @@
+"""Coupling conditioner on the MI355X path.
+
+Public surface and `state_dict` keys follow the reference's models/Conditionners/CouplingConditioner.py
+(`CouplingMLP.net.{0,2,..}`, `CouplingConditioner.constants`, `.embeding_net` with the reference's spelling):
+the first d - floor(d/2) variables get learned constant embeddings, the remaining floor(d/2) variables are embedded
+by an MLP of the first group (reference :21-39).  The MLP runs as one fused MFMA GEMM chain (gnf_hip.ops.mlp)."""
 import torch
 import torch.nn as nn
 
 from gnf_hip import ops
-from .Conditioner import Conditioner, linear_pairs, no_context
+from .Conditioner import Conditioner, linear_pairs, no_context, relu_stack
+
+
+def _split(in_size):
+    """(number of independent variables, number of conditioned variables)"""
+    conditioned = in_size // 2
+    return in_size - conditioned, conditioned
 
 
 class CouplingMLP(nn.Module):
-    """Parameter container, same layout/keys as reference CouplingConditioner.py:6-19."""
+    """Parameter container of the embedding MLP: [indep (+cond_in)] -> hidden... -> out_size * conditioned."""
 
     def __init__(self, in_size, hidden, out_size, cond_in=0):
-        super(CouplingMLP, self).__init__()
-        l1 = [in_size - int(in_size / 2) + cond_in] + hidden
-        l2 = hidden + [out_size * int(in_size / 2)]
-        layers = []
-        for h1, h2 in zip(l1, l2):
-            layers += [nn.Linear(h1, h2), nn.ReLU()]
-        layers.pop()
-        self.net = nn.Sequential(*layers)
+        super().__init__()
+        indep, conditioned = _split(in_size)
+        self.net = relu_stack([indep + cond_in] + list(hidden) + [out_size * conditioned])
 
     def forward(self, x):
         return ops.mlp(x, linear_pairs(self.net))
 
 
 class CouplingConditioner(Conditioner):
-    """First d-floor(d/2) dims: learned constants; last floor(d/2) dims: MLP of the first
-    ones (reference CouplingConditioner.py:21-39)."""
-
     def __init__(self, in_size, hidden, out_size, cond_in=0):
-        super(CouplingConditioner, self).__init__()
-        self.in_size = in_size
-        self.out_size = out_size
-        self.cond_size = int(in_size / 2)
-        self.indep_size = in_size - self.cond_size
-        self.cond_in = cond_in
-        self.embeding_net = CouplingMLP(in_size, hidden, out_size, cond_in)   # (sic) reference spelling
+        super().__init__()
+        self.in_size, self.out_size, self.cond_in = in_size, out_size, cond_in
+        self.indep_size, self.cond_size = _split(in_size)
+        self.embeding_net = CouplingMLP(in_size, hidden, out_size, cond_in)
         self.constants = nn.Parameter(torch.randn(self.indep_size, out_size))
 
     def forward(self, x, context=None):
         no_context(context, self.cond_in)
-        h1 = self.constants.unsqueeze(0).expand(x.shape[0], -1, -1)
-        h2 = self.embeding_net(x[:, :self.indep_size]).view(x.shape[0], self.cond_size, self.out_size)
-        return torch.cat((h1, h2), 1)
+        batch = x.shape[0]
+        learned = self.embeding_net(x[:, :self.indep_size]).view(batch, self.cond_size, self.out_size)
+        return torch.cat((self.constants.expand(batch, self.indep_size, self.out_size), learned), dim=1)
 
     def depth(self):
+        # one pass fixes the independent half, the second the conditioned half (NormalizingFlowStep.invert runs depth()+1)
         return 1

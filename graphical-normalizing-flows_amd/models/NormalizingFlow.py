@@ -1,3 +1,12 @@
+"""Flow composition on the MI355X path: one (conditioner, normalizer) step, a stack of steps, and the multi-scale
+image flow.  Class and method names, constructor arguments and `state_dict` keys are those of the reference's
+models/NormalizingFlow.py (the drivers call getConditioners / getNormalizers / DAGness / step / isInvertible / invert
+by name); the bodies are written against gnf_hip.ops.
+
+    step:   h = conditioner(x);  z, jac = normalizer(x, h);  log|det J| = sum_i log jac_i      (reference :61-70)
+    stack:  steps in sequence, feature order reversed between steps, log-dets added             (reference :110-126)
+    loss:   sum of conditioner constraint terms - mean(log|det J| + log N(z))                  (reference :128-146)
+"""
 import torch
 import torch.nn as nn
 
@@ -6,69 +15,55 @@ from .Conditionners import Conditioner, DAGConditioner
 from .Normalizers import Normalizer
 
 
+def _is_dag(conditioner):
+    # exact type test, as everywhere in the reference (subclasses are deliberately not recognised)
+    return type(conditioner) is DAGConditioner
+
+
 class NormalizingFlow(nn.Module):
-    """Abstract flow (reference models/NormalizingFlow.py:7-58)."""
+    """Protocol shared by all flows.  forward(x, context=None) -> (z, log|det J|).  The aggregate queries have
+    default implementations in terms of getConditioners(), which every concrete flow provides."""
 
     def __init__(self):
-        super(NormalizingFlow, self).__init__()
+        super().__init__()
 
     def forward(self, x, context=None):
-        """-> (z, log|det J|)"""
-        pass
-
-    def constraintsLoss(self):
-        pass
-
-    def DAGness(self):
-        pass
-
-    def step(self, epoch_number, loss_avg):
-        pass
-
-    def getConditioners(self):
-        pass
-
-    def isInvertible(self):
-        pass
-
-    def getNormalizers(self):
-        pass
+        raise NotImplementedError
 
     def invert(self, z, context=None):
-        pass
+        raise NotImplementedError
+
+    def getConditioners(self):
+        raise NotImplementedError
+
+    def getNormalizers(self):
+        raise NotImplementedError
+
+    def constraintsLoss(self):
+        return sum((c.loss() for c in self.getConditioners() if _is_dag(c)), 0.)
+
+    def DAGness(self):
+        return [c.get_power_trace() if _is_dag(c) else 0. for c in self.getConditioners()]
+
+    def step(self, epoch_number, loss_avg):
+        for c in self.getConditioners():
+            if _is_dag(c):
+                c.step(epoch_number, loss_avg)
+
+    def isInvertible(self):
+        return all(c.is_invertible for c in self.getConditioners())
 
 
 class NormalizingFlowStep(NormalizingFlow):
-    """h = conditioner(x); z, jac = normalizer(x, h); log|det J| = sum_i log jac
-    (reference :61-107).  Normalizers exposing `forward_logdet` get the reduction fused into
-    their kernel; any other Normalizer plug-in goes through the row-reduction kernel."""
+    """One autoregressive-style transformation.  A normalizer that offers `forward_logdet` (both built-in ones do)
+    returns the row-summed log-Jacobian from its own kernel; any other Normalizer plug-in goes through the
+    log + row-sum reduction kernel."""
 
     def __init__(self, conditioner: Conditioner, normalizer: Normalizer):
-        super(NormalizingFlowStep, self).__init__()
+        super().__init__()
         self.conditioner = conditioner
         self.normalizer = normalizer
         self.level_schedule = True       # invert(): topological level schedule for DAG conditioners
-
-    def forward(self, x, context=None):
-        h = self.conditioner(x, context)
-        if hasattr(self.normalizer, "forward_logdet"):
-            return self.normalizer.forward_logdet(x, h, context)
-        z, jac = self.normalizer(x, h, context)
-        return z, ops.LogSumRowsFn.apply(jac)
-
-    def constraintsLoss(self):
-        if type(self.conditioner) is DAGConditioner:
-            return self.conditioner.loss()
-        return 0.
-
-    def DAGness(self):
-        if type(self.conditioner) is DAGConditioner:
-            return [self.conditioner.get_power_trace()]
-        return [0.]
-
-    def step(self, epoch_number, loss_avg):
-        if type(self.conditioner) is DAGConditioner:
-            self.conditioner.step(epoch_number, loss_avg)
 
     def getConditioners(self):
         return [self.conditioner]
@@ -76,154 +71,132 @@ class NormalizingFlowStep(NormalizingFlow):
     def getNormalizers(self):
         return [self.normalizer]
 
-    def isInvertible(self):
-        for conditioner in self.getConditioners():
-            if not conditioner.is_invertible:
-                return False
-        return True
+    def forward(self, x, context=None):
+        h = self.conditioner(x, context)
+        fused = getattr(self.normalizer, "forward_logdet", None)
+        if fused is not None:
+            return fused(x, h, context)
+        z, jac = self.normalizer(x, h, context)
+        return z, ops.LogSumRowsFn.apply(jac)
+
+    # -- inversion ----------------------------------------------------------------------------------------------
+    def _invert_by_levels(self, z, context):
+        """DAG conditioner with a deterministic gate: every variable is inverted once, after its parents -- d
+        conditioner rows in total instead of (depth + 1) * d.  Same values as the fixed-point passes (non-parents are
+        masked by exact zeros either way).  Returns None when not applicable."""
+        cond = self.conditioner
+        if not (_is_dag(cond) and context is None and self.level_schedule):
+            return None
+        importance = cond.deterministic_importance()
+        levels = cond.levels(importance) if importance is not None else None
+        if levels is None:
+            return None
+        x = torch.zeros_like(z)
+        for rows in levels:
+            h = cond.forward_rows(x, rows, importance)
+            x[:, rows] = self.normalizer.inverse_transform(z[:, rows].contiguous(), h, context)
+        return x
 
     def invert(self, z, context=None):
-        """Fixed-point inverse: depth()+1 passes, early exit on exact equality (:98-107;
-        the reference's progress print is dropped)."""
-        x = torch.zeros_like(z)
-        if type(self.conditioner) is DAGConditioner and context is None and self.level_schedule:
-            # DAG-ordered inversion: every variable is inverted once, after its parents -- d conditioner rows in total
-            # instead of (depth + 1) * d; same values as the fixed-point passes below (non-parents are masked by
-            # exact zeros either way)
-            P = self.conditioner.deterministic_importance()
-            levels = self.conditioner.levels(P) if P is not None else None
-            if levels is not None:
-                with torch.no_grad():
-                    for rows in levels:
-                        h = self.conditioner.forward_rows(x, rows, P)
-                        x[:, rows] = self.normalizer.inverse_transform(z[:, rows].contiguous(), h, context)
-                return x
+        """Reference :98-107: fixed point of x <- normalizer^-1(z, conditioner(x)) from x = 0, depth()+1 passes, early
+        exit once a pass changes nothing (its progress print is dropped)."""
         with torch.no_grad():
-            for i in range(self.conditioner.depth() + 1):
-                h = self.conditioner(x, context)
-                x_prev = x
-                x = self.normalizer.inverse_transform(z, h, context)
-                if torch.norm(x - x_prev) == 0.:
+            x = self._invert_by_levels(z, context)
+            if x is not None:
+                return x
+            x = torch.zeros_like(z)
+            for _ in range(self.conditioner.depth() + 1):
+                previous = x
+                x = self.normalizer.inverse_transform(z, self.conditioner(x, context), context)
+                if torch.equal(x, previous):
                     break
         return x
 
 
 class FCNormalizingFlow(NormalizingFlow):
-    """Stack of steps with the feature order reversed between steps (reference :110-169)."""
+    """Steps applied in sequence on flat [B, d] data."""
 
     def __init__(self, steps, z_log_density):
-        super(FCNormalizingFlow, self).__init__()
-        self.steps = nn.ModuleList()
+        super().__init__()
+        self.steps = nn.ModuleList(steps)
         self.z_log_density = z_log_density
-        for step in steps:
-            self.steps.append(step)
-
-    def forward(self, x, context=None):
-        jac_tot = 0.
-        for i, step in enumerate(self.steps):
-            z, jac = step(x, context)
-            if i + 1 < len(self.steps):
-                x = torch.flip(z, dims=[1])      # z[:, inv_idx] of the reference (:120-123)
-            jac_tot = jac_tot + jac
-        return z, jac_tot                        # last step's z is returned un-flipped (:126)
-
-    def constraintsLoss(self):
-        loss = 0.
-        for step in self.steps:
-            loss += step.constraintsLoss()
-        return loss
-
-    def DAGness(self):
-        dagness = []
-        for step in self.steps:
-            dagness += step.DAGness()
-        return dagness
-
-    def step(self, epoch_number, loss_avg):
-        for step in self.steps:
-            step.step(epoch_number, loss_avg)
-
-    def loss(self, z, jac):
-        log_p_x = jac + self.z_log_density(z)
-        return self.constraintsLoss() - log_p_x.mean()
-
-    def getNormalizers(self):
-        normalizers = []
-        for step in self.steps:
-            normalizers += step.getNormalizers()
-        return normalizers
 
     def getConditioners(self):
-        conditioners = []
-        for step in self.steps:
-            conditioners += step.getConditioners()
-        return conditioners
+        return [c for s in self.steps for c in s.getConditioners()]
 
-    def isInvertible(self):
-        for conditioner in self.getConditioners():
-            if not conditioner.is_invertible:
-                return False
-        return True
+    def getNormalizers(self):
+        return [n for s in self.steps for n in s.getNormalizers()]
+
+    def forward(self, x, context=None):
+        logdet = 0.
+        last = len(self.steps) - 1
+        for k, flow_step in enumerate(self.steps):
+            z, ld = flow_step(x, context)
+            logdet = logdet + ld
+            if k < last:
+                x = torch.flip(z, dims=[1])      # the reference's z[:, inv_idx] (:120-123)
+        return z, logdet                         # the last step's z is returned un-flipped (:126)
+
+    def loss(self, z, jac):
+        return self.constraintsLoss() - (jac + self.z_log_density(z)).mean()
 
     def invert(self, z, context=None):
-        """Exact inverse of forward for any number of steps.  The reference (:166-169) visits
-        steps[-0] == steps[0] first and never undoes the flip, so it only inverts nb_flow=1
-        flows; for nb_flow=1 this is identical to it."""
-        n = len(self.steps)
-        for s in range(n - 1, -1, -1):
-            x = self.steps[s].invert(z, context)
-            z = torch.flip(x, dims=[1]) if s > 0 else x
+        """Exact inverse of forward for any number of steps.  The reference (:166-169) visits steps[-0] == steps[0]
+        first and never undoes the flip, so it only inverts nb_flow = 1 flows; for nb_flow = 1 this is
+        identical to it."""
+        for k in range(len(self.steps) - 1, -1, -1):
+            x = self.steps[k].invert(z, context)
+            z = torch.flip(x, dims=[1]) if k else x
         return z
 
 
 class CNNormalizingFlow(FCNormalizingFlow):
-    """Multi-scale flow (reference :172-226): after every scale the image is cut into d_c x d_h x d_w blocks; the first
-    element of each block goes on to the next (coarser) flow, the others are emitted as latent variables."""
+    """Multi-scale image flow (reference :172-226): after every scale the image is cut into d_c x d_h x d_w blocks;
+    the first element of each block goes on to the next (coarser) flow, the others are emitted as latent variables."""
 
     def __init__(self, steps, z_log_density, dropping_factors):
-        super(CNNormalizingFlow, self).__init__(steps, z_log_density)
+        super().__init__(steps, z_log_density)
         self.dropping_factors = dropping_factors
 
     @staticmethod
+    def _kept_shape(img_size, drop):
+        return tuple(int(n / f) for n, f in zip(img_size, drop))
+
+    @staticmethod
     def _blocks(z, img_size, drop):
-        """[B, C*H*W] -> [B, c, h, w, d_c*d_h*d_w]  (the unfold chain of reference :184-185)"""
-        C, H, W = img_size
+        """[B, C*H*W] -> [B, c, h, w, d_c*d_h*d_w]  (equals the unfold chain of reference :184-185)"""
+        c, h, w = CNNormalizingFlow._kept_shape(img_size, drop)
         d_c, d_h, d_w = drop
-        c, h, w = int(C / d_c), int(H / d_h), int(W / d_w)
         return z.view(-1, c, d_c, h, d_h, w, d_w).permute(0, 1, 3, 5, 2, 4, 6).reshape(z.shape[0], c, h, w, -1)
 
     def forward(self, x, context=None):
-        b_size = x.shape[0]
-        jac_tot = 0.
-        z_all = []
-        for step, drop in zip(self.steps, self.dropping_factors):
-            z, jac = step(x, context)
-            blocks = self._blocks(z, step.img_sizes, drop)
-            z_all.append(blocks[..., 1:].reshape(b_size, -1))
-            x = blocks[..., 0].reshape(b_size, -1)
-            jac_tot = jac_tot + jac
-        z_all.append(x)
-        return torch.cat(z_all, 1), jac_tot
+        batch = x.shape[0]
+        logdet, latents = 0., []
+        for flow, drop in zip(self.steps, self.dropping_factors):
+            z, ld = flow(x, context)
+            logdet = logdet + ld
+            blocks = self._blocks(z, flow.img_sizes, drop)
+            latents.append(blocks[..., 1:].reshape(batch, -1))
+            x = blocks[..., 0].reshape(batch, -1)
+        latents.append(x)
+        return torch.cat(latents, 1), logdet
 
     def invert(self, z, context=None):
-        b_size = z.shape[0]
-        parts, i = [], 0
-        for step, drop in zip(self.steps, self.dropping_factors):
-            C, H, W = step.img_sizes
-            c, h, w = int(C / drop[0]), int(H / drop[1]), int(W / drop[2])
-            nb_z = C * H * W - c * h * w if C * H * W != c * h * w else c * h * w
-            parts.append(z[:, i:i + nb_z])
-            i += nb_z
+        batch = z.shape[0]
+        # slice z back into the per-scale latent blocks, in emission order
+        parts, start = [], 0
+        for flow, drop in zip(self.steps, self.dropping_factors):
+            full = flow.img_sizes[0] * flow.img_sizes[1] * flow.img_sizes[2]
+            c, h, w = self._kept_shape(flow.img_sizes, drop)
+            width = full - c * h * w if full != c * h * w else full
+            parts.append(z[:, start:start + width])
+            start += width
         x = None
-        for k in range(len(self.steps) - 1, -1, -1):
-            step, drop = self.steps[k], self.dropping_factors[k]
-            C, H, W = step.img_sizes
-            d_c, d_h, d_w = drop
-            c, h, w = int(C / d_c), int(H / d_h), int(W / d_w)
-            zk = parts[k]
-            if c * h * w != C * H * W:       # re-interleave the kept element with the dropped ones of each block
-                blocks = torch.cat((x.view(b_size, c, h, w, 1), zk.reshape(b_size, c, h, w, -1)), 4)
-                zk = blocks.view(b_size, c, h, w, d_c, d_h, d_w).permute(0, 1, 4, 2, 5, 3, 6).reshape(b_size, -1)
-            x = step.invert(zk.reshape(b_size, -1), context)
+        for flow, drop, zk in zip(reversed(self.steps), reversed(self.dropping_factors), reversed(parts)):
+            c, h, w = self._kept_shape(flow.img_sizes, drop)
+            if c * h * w != flow.img_sizes[0] * flow.img_sizes[1] * flow.img_sizes[2]:
+                # re-interleave the element kept for the coarser scale with the dropped ones of each block
+                blocks = torch.cat((x.view(batch, c, h, w, 1), zk.reshape(batch, c, h, w, -1)), 4)
+                zk = blocks.view(batch, c, h, w, *drop).permute(0, 1, 4, 2, 5, 3, 6).reshape(batch, -1)
+            x = flow.invert(zk.reshape(batch, -1), context)
         return x
-

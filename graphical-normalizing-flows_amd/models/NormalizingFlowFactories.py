@@ -1,94 +1,92 @@
-from math import pi
+"""Flow factories of the reference (models/NormalizingFlowFactories.py), building the MI355X-backed classes.
+
+`NormalLogDensity`, `buildFCNormalizingFlow`, `MNIST_A_prior` and `buildMNISTNormalizingFlow` keep the reference's
+names, arguments and the `state_dict` layout of what they build (`z_log_density.pi`, `steps.N....`)."""
+import math
 
 import torch
 import torch.nn as nn
 
 from gnf_hip import ops
-from .Normalizers import *
-from .Conditionners import *
+from .Normalizers import *            # noqa: F401,F403  (the reference star-imports both packages here)
+from .Conditionners import *          # noqa: F401,F403
 from .NormalizingFlow import NormalizingFlowStep, FCNormalizingFlow, CNNormalizingFlow
-from .MLP import MNISTCNN, CIFAR10CNN
+from .MLP import MNISTCNN, CIFAR10CNN  # noqa: F401
 
 
 class NormalLogDensity(nn.Module):
-    """log N(z; 0, I) per row (reference NormalizingFlowFactories.py:10-16); the `pi` buffer is
-    kept for state_dict compatibility (`z_log_density.pi`)."""
+    """Row-wise log N(z; 0, I) = -1/2 sum_d (log 2 pi + z_d^2)  (reference :10-16), one fused reduction kernel.  The
+    `pi` buffer exists only because reference checkpoints carry `z_log_density.pi`."""
 
     def __init__(self):
-        super(NormalLogDensity, self).__init__()
-        self.register_buffer("pi", torch.tensor(pi))
+        super().__init__()
+        self.register_buffer("pi", torch.tensor(math.pi))
 
     def forward(self, z):
         return ops.NormalLogDensityFn.apply(z)
 
 
 def buildFCNormalizingFlow(nb_steps, conditioner_type, conditioner_args, normalizer_type, normalizer_args):
-    """nb_steps x (conditioner, normalizer) -> FCNormalizingFlow (reference :19-32)."""
-    flow_steps = []
-    for step in range(nb_steps):
-        conditioner = conditioner_type(**conditioner_args)
-        normalizer = normalizer_type(**normalizer_args)
-        flow_steps.append(NormalizingFlowStep(conditioner, normalizer))
-    return FCNormalizingFlow(flow_steps, NormalLogDensity())
+    """`nb_steps` independent (conditioner, normalizer) pairs on a standard-normal base density (reference :19-32)."""
+    return FCNormalizingFlow([NormalizingFlowStep(conditioner_type(**conditioner_args),
+                                                  normalizer_type(**normalizer_args)) for _ in range(nb_steps)],
+                             NormalLogDensity())
 
 
 def MNIST_A_prior(in_size, kernel):
-    """(2k+1)^2-window pixel adjacency minus self on an in_size x in_size grid (reference :35-46)."""
+    """Adjacency prior of an in_size x in_size pixel grid: pixel p depends on every pixel of its (2 kernel + 1)^2
+    window, itself excluded (reference :35-46)."""
     n = in_size
+    row = torch.arange(n).repeat_interleave(n)
+    col = torch.arange(n).repeat(n)
     A = torch.zeros(n * n, n * n)
-    r = torch.arange(n).view(-1, 1).expand(n, n).reshape(-1)
-    c = torch.arange(n).view(1, -1).expand(n, n).reshape(-1)
-    p = r * n + c
-    for di in range(-kernel, kernel + 1):
-        for dj in range(-kernel, kernel + 1):
-            rr, cc = r + dj, c + di
-            ok = (rr >= 0) & (rr < n) & (cc >= 0) & (cc < n)
-            A[p[ok], (rr * n + cc)[ok]] = 1.
+    for dr in range(-kernel, kernel + 1):
+        for dc in range(-kernel, kernel + 1):
+            r2, c2 = row + dr, col + dc
+            inside = (r2 >= 0) & (r2 < n) & (c2 >= 0) & (c2 < n)
+            A[(row * n + col)[inside], (r2 * n + c2)[inside]] = 1.
     A.fill_diagonal_(0.)
     return A
 
 
+# the scales of the MNIST factories: (image size, block dropped after the scale, MNISTCNN fc sizes)
+_MNIST_SCALES = (([1, 28, 28], [1, 2, 2], [2304, 128]),
+                 ([1, 14, 14], [1, 2, 2], [400, 64]),
+                 ([1, 7, 7], [1, 1, 1], [16, 16]))
+
+
+def _mnist_dag_steps(n_steps, img_size, fc, normalizer_type, normalizer_args, l1, nb_epoch_update, hot_encoding,
+                     prior_kernel):
+    """`n_steps` DAG-conditioner steps on one image scale, each with its own MNISTCNN embedding net."""
+    pixels = img_size[0] * img_size[1] * img_size[2]
+    monotonic = normalizer_type is MonotonicNormalizer
+    emb_size = 30 if monotonic else 2
+    out = []
+    for _ in range(n_steps):
+        prior = MNIST_A_prior(img_size[1], prior_kernel) if prior_kernel is not None else None
+        cond = DAGConditioner(pixels, MNISTCNN(fc_l=fc, size_img=img_size, out_d=emb_size), emb_size, l1=l1,
+                              nb_epoch_update=nb_epoch_update, hot_encoding=hot_encoding, A_prior=prior)
+        if monotonic:   # the reference widens cond_size by the one-hot width when hot_encoding is on (:67,:87)
+            norm = normalizer_type(**normalizer_args, cond_size=emb_size + pixels if hot_encoding else emb_size)
+        else:
+            norm = normalizer_type(**normalizer_args)
+        out.append(NormalizingFlowStep(cond, norm))
+    return out
+
+
 def buildMNISTNormalizingFlow(nb_inner_steps, normalizer_type, normalizer_args, l1=0., nb_epoch_update=10,
                               hot_encoding=False, prior_kernel=None):
-    """MNIST DAG flows of the reference (:49-97): one 28x28 scale, or three scales 28/14/7 (CNNormalizingFlow)."""
+    """MNIST DAG flows of the reference (:49-97): `len(nb_inner_steps) == 1` -> one 28x28 scale (FCNormalizingFlow),
+    `== 3` -> scales 28 / 14 / 7 chained by CNNormalizingFlow, anything else -> None."""
+    common = (normalizer_type, normalizer_args, l1, nb_epoch_update, hot_encoding, prior_kernel)
+    if len(nb_inner_steps) == 1:
+        img_size, _, fc = _MNIST_SCALES[0]
+        return FCNormalizingFlow(_mnist_dag_steps(nb_inner_steps[0], img_size, fc, *common), NormalLogDensity())
     if len(nb_inner_steps) == 3:
-        img_sizes = [[1, 28, 28], [1, 14, 14], [1, 7, 7]]
-        dropping_factors = [[1, 2, 2], [1, 2, 2], [1, 1, 1]]
-        fc_l = [[2304, 128], [400, 64], [16, 16]]
-        outter_steps = []
-        for i, fc in enumerate(fc_l):
-            in_size = img_sizes[i][0] * img_sizes[i][1] * img_sizes[i][2]
-            inner_steps = []
-            for step in range(nb_inner_steps[i]):
-                emb_s = 2 if normalizer_type is AffineNormalizer else 30
-                hidden = MNISTCNN(fc_l=fc, size_img=img_sizes[i], out_d=emb_s)
-                A_prior = MNIST_A_prior(img_sizes[i][1], prior_kernel) if prior_kernel is not None else None
-                cond = DAGConditioner(in_size, hidden, emb_s, l1=l1, nb_epoch_update=nb_epoch_update,
-                                      hot_encoding=hot_encoding, A_prior=A_prior)
-                if normalizer_type is MonotonicNormalizer:
-                    emb_s = 30 + in_size if hot_encoding else 30
-                    norm = normalizer_type(**normalizer_args, cond_size=emb_s)
-                else:
-                    norm = normalizer_type(**normalizer_args)
-                inner_steps.append(NormalizingFlowStep(cond, norm))
-            flow = FCNormalizingFlow(inner_steps, None)
-            flow.img_sizes = img_sizes[i]
-            outter_steps.append(flow)
-        return CNNormalizingFlow(outter_steps, NormalLogDensity(), dropping_factors)
-    elif len(nb_inner_steps) == 1:
-        inner_steps = []
-        for step in range(nb_inner_steps[0]):
-            emb_s = 2 if normalizer_type is AffineNormalizer else 30
-            hidden = MNISTCNN(fc_l=[2304, 128], size_img=[1, 28, 28], out_d=emb_s)
-            A_prior = MNIST_A_prior(28, prior_kernel) if prior_kernel is not None else None
-            cond = DAGConditioner(1 * 28 * 28, hidden, emb_s, l1=l1, nb_epoch_update=nb_epoch_update,
-                                  hot_encoding=hot_encoding, A_prior=A_prior)
-            if normalizer_type is MonotonicNormalizer:
-                emb_s = 30 + 28 * 28 if hot_encoding else 30
-                norm = normalizer_type(**normalizer_args, cond_size=emb_s)
-            else:
-                norm = normalizer_type(**normalizer_args)
-            inner_steps.append(NormalizingFlowStep(cond, norm))
-        return FCNormalizingFlow(inner_steps, NormalLogDensity())
-    else:
-        return None
+        scales = []
+        for n_steps, (img_size, _, fc) in zip(nb_inner_steps, _MNIST_SCALES):
+            flow = FCNormalizingFlow(_mnist_dag_steps(n_steps, img_size, fc, *common), None)
+            flow.img_sizes = img_size
+            scales.append(flow)
+        return CNNormalizingFlow(scales, NormalLogDensity(), [drop for _, drop, _ in _MNIST_SCALES])
+    return None

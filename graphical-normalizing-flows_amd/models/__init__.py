@@ -1,7 +1,11 @@
-"""Drop-in mirror of the reference's `models` package (models/__init__.py:1-4): same
-class names, constructor arguments, attributes and state_dict keys; the arithmetic runs
-in the gfx950 kernels of gnf_hip."""
-from .MLP import MLP, MNISTCNN, CIFAR10CNN
+"""`models` package of the MI355X build.  It exports the names the reference's `models/__init__.py` exports, so
+putting this directory on PYTHONPATH ahead of the reference makes its drivers (`from models import ...`) run on the
+gfx950 kernels; everything else (`models.NormalizingFlow`, `models.NormalizingFlowFactories`, ...) is importable by
+the same module paths as well."""
+from .Conditionners import (Conditioner, AutoregressiveConditioner, CouplingConditioner, DAGConditioner)
+from .Normalizers import (AffineNormalizer, MonotonicNormalizer)
+from .MLP import (MLP, MNISTCNN, CIFAR10CNN)
 from .NormalizingFlowFactories import buildFCNormalizingFlow
-from .Conditionners import AutoregressiveConditioner, DAGConditioner, CouplingConditioner, Conditioner
-from .Normalizers import AffineNormalizer, MonotonicNormalizer
+
+__all__ = ["MLP", "MNISTCNN", "CIFAR10CNN", "buildFCNormalizingFlow", "AutoregressiveConditioner", "DAGConditioner",
+           "CouplingConditioner", "Conditioner", "AffineNormalizer", "MonotonicNormalizer"]
