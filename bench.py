@@ -93,7 +93,7 @@ def cpu_baseline():
     step()                                   # warm-up
     t0 = time.perf_counter()
     n = 0
-    while n < 1 or (time.perf_counter() - t0 < 15. and n < 10):
+    while n < 1 or (time.perf_counter() - t0 < 12. and n < 40):     # a bounded sample: ~12 s of host work
         step()
         n += 1
     dt = (time.perf_counter() - t0) / n
