@@ -81,3 +81,36 @@ def test_two_rank_step_matches_single_process():
     for p in flow.parameters():                           # parameters really are views of the flat buffer
         assert p.data.data_ptr() >= state.flat.data_ptr()
         assert p.data.data_ptr() < state.flat.data_ptr() + state.flat.numel() * 4
+
+
+def test_adam_checkpoint_round_trips_through_torch_optim():
+    """FlatState.optimizer_state_dict() is a valid torch.optim.Adam state: a torch Adam resumed from it takes the same
+    next step as the flat optimiser, and loading it back restores the moments (ADAM.pt compatibility with the
+    reference drivers, UCIExperiments.py:216-220)."""
+    torch.manual_seed(1)
+    x = torch.randn(32, 4)
+    flow = TinyFlow()
+    state = dp.FlatState(flow)
+    for _ in range(3):
+        dp.train_step(flow, state, x, lr=1e-2, weight_decay=1e-5, optimizer=torch_adam)
+    sd = state.optimizer_state_dict(flow, lr=1e-2, weight_decay=1e-5)
+    # a stock torch model + Adam resumed from the exported files
+    ref = TinyFlow()
+    ref.load_state_dict({k: v.clone() for k, v in flow.state_dict().items()})
+    opt = torch.optim.Adam(ref.parameters(), lr=1e-2, weight_decay=1e-5)
+    opt.load_state_dict(sd)
+    z, ld = ref(x)
+    opt.zero_grad()
+    ref.loss(z, ld).backward()
+    opt.step()
+    dp.train_step(flow, state, x, lr=1e-2, weight_decay=1e-5, optimizer=torch_adam)
+    for (k, a), (_, b) in zip(flow.state_dict().items(), ref.state_dict().items()):
+        assert torch.allclose(a, b, rtol=1e-5, atol=1e-7), k
+    # and back: a fresh FlatState picks the moments and the step count up again
+    flow2 = TinyFlow()
+    flow2.load_state_dict({k: v.clone() for k, v in ref.state_dict().items()})
+    state2 = dp.FlatState(flow2)
+    state2.load_optimizer_state_dict(flow2, opt.state_dict())
+    assert state2.t == 4
+    assert torch.allclose(state2.m, state.m, rtol=1e-5, atol=1e-8) and torch.allclose(state2.v, state.v, rtol=1e-5, atol=1e-10)
+
