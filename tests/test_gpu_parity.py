@@ -627,6 +627,22 @@ def test_abi_error_codes():
     assert lib.gnf_monotonic_pack_floats(ctypes.byref(net)) == -2
     with pytest.raises(abi.GnfError):
         abi.ptr(torch.zeros(2, dtype=torch.float64, device=DEV))
+    # graph-capturable Adam and the ceiling probes validate their arguments the same way
+    assert lib.gnf_adam_step_dev(P(x.data_ptr()), P(x.data_ptr()), P(x.data_ptr()), P(x.data_ptr()), 16, 1e-3, .9, .999,
+                                 1e-8, 0., 1., None, st) == -1
+    assert lib.gnf_probe_copy(P(x.data_ptr()), P(x.data_ptr()), 6, st) == -1          # n must be a multiple of 4
+    assert lib.gnf_probe_mfma_f32(None, 1, 1, st) == -1
+    # the device-side step counter advances by one per call and the update equals the by-value entry point
+    from gnf_hip import ops
+    torch.manual_seed(2)
+    p0, g0 = torch.randn(1000, device=DEV), torch.randn(1000, device=DEV)
+    pa, ma, va = p0.clone(), torch.zeros_like(p0), torch.zeros_like(p0)
+    pb, mb, vb = p0.clone(), torch.zeros_like(p0), torch.zeros_like(p0)
+    step = torch.zeros(1, dtype=torch.int32, device=DEV)
+    for t in (1, 2, 3):
+        ops.adam_step(pa, g0, ma, va, t, lr=1e-2, weight_decay=1e-4)
+        ops.adam_step_dev(pb, g0, mb, vb, step, lr=1e-2, weight_decay=1e-4)
+    assert int(step.item()) == 3 and rel_err(pb.cpu(), pa.cpu()) < 1e-6
 
 
 @pytest.mark.parametrize("name,B", [("cfg1", 512), ("cfg2", 10000), ("cfg3", 100), ("cfg5", 2000)])
