@@ -291,7 +291,13 @@ __global__ __launch_bounds__(64 * kWaves) void mono_fwd_k(MonoArgs a) {
 template <int HT, int NH, int WMODE>
 __global__ __launch_bounds__(64 * kWaves) void mono_bwd_k(MonoArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  constexpr bool WLDS = WMODE == 1, SWAP = WMODE == 2;
+  // WMODE 0: weights from L2.  1: the whole pack (incl. transposes) in LDS (narrow nets).  2: ONE hidden->hidden matrix in
+  // LDS at a time, swapped by the workgroup.  3: all hidden->hidden matrices resident in LDS.  Modes 2 and 3 keep only
+  // the untransposed matrices: the backward reads W^T fragments as 4 ds_read_b32 at stride LDW (lanes j consecutive, the
+  // two q of a 32-lane group 16 banks apart: conflict-free), so a node needs the matrices in the order
+  // W1 .. W_{NH-1} | W_{NH-1} .. W1 and the one the forward loaded last / the backward used last is still there:
+  // 2 swaps per node instead of 4 at NH = 3, none in mode 3.
+  constexpr bool WLDS = WMODE == 1, SWAP = WMODE == 2, RES = WMODE == 3, UNT = SWAP || RES;
   const MonoLayout& L = a.L;
   const float* wp = a.pack;
   if (WLDS) {
@@ -300,26 +306,37 @@ __global__ __launch_bounds__(64 * kWaves) void mono_bwd_k(MonoArgs a) {
     __syncthreads();
     wp = smem;
   }
-  // SWAP: copy one [HP][LDW] matrix of the pack into LDS; every wave of the workgroup calls it at the same point
-  // (8 independent loads in flight per thread: a load -> store chain per 16 bytes exposes one L2 round trip per
-  //  iteration, 26 of them per matrix at H = 150 -- measured 60 % of the kernel stalled with the MFMA pipe idle)
-  auto load_mat = [&](int off) -> const float* {
-    __syncthreads();                              // previous matrix no longer read
-    const int n = L.HP * L.LDW, stride = blockDim.x * 4;
-    for (int i0 = threadIdx.x * 4; i0 < n; i0 += 8 * stride) {
+  const int matf = L.HP * L.LDW;                 // floats per hidden->hidden matrix
+  auto copy_mat = [&](int off, float* dst) {     // 8 independent loads in flight per thread
+    const int stride = blockDim.x * 4;
+    for (int i0 = threadIdx.x * 4; i0 < matf; i0 += 8 * stride) {
       f32x4 t[8];
 #pragma unroll
       for (int u = 0; u < 8; ++u) {
         const int i = i0 + u * stride;
-        t[u] = i < n ? ld4(a.pack + off + i) : f32x4{0.f, 0.f, 0.f, 0.f};
+        t[u] = i < matf ? ld4(a.pack + off + i) : f32x4{0.f, 0.f, 0.f, 0.f};
       }
 #pragma unroll
       for (int u = 0; u < 8; ++u) {
         const int i = i0 + u * stride;
-        if (i < n) *reinterpret_cast<f32x4*>(smem + i) = t[u];
+        if (i < matf) *reinterpret_cast<f32x4*>(dst + i) = t[u];
       }
     }
+  };
+  if (RES) {
+    for (int l = 1; l < NH; ++l) copy_mat(L.o_W[l], smem + (l - 1) * matf);
     __syncthreads();
+  }
+  int resident = 0;                              // SWAP: layer whose matrix is in LDS (0: none); workgroup-uniform
+  // every wave of the workgroup calls get_mat at the same points with the same l
+  auto get_mat = [&](int l) -> const float* {
+    if (RES) return smem + (l - 1) * matf;
+    if (resident != l) {
+      __syncthreads();                            // previous matrix no longer read
+      copy_mat(L.o_W[l], smem);
+      __syncthreads();
+      resident = l;
+    }
     return smem;
   };
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -392,7 +409,7 @@ __global__ __launch_bounds__(64 * kWaves) void mono_bwd_k(MonoArgs a) {
 #pragma unroll
           for (int t = 0; t < HT; ++t) *reinterpret_cast<f32x4*>(sa + 16 * t) = act[t];
         }
-        const float* W = SWAP ? load_mat(L.o_W[l]) : wp + L.o_W[l];
+        const float* W = UNT ? get_mat(l) : wp + L.o_W[l];
         f32x4 o[HT];
 #pragma unroll
         for (int mt = 0; mt < HT; ++mt) o[mt] = ld4(wp + L.o_b[l] + 16 * mt + 4 * q);
@@ -449,7 +466,7 @@ __global__ __launch_bounds__(64 * kWaves) void mono_bwd_k(MonoArgs a) {
           if (gvalid) *reinterpret_cast<f32x4*>(sd + 16 * t) = dp[t];
           if constexpr (BREG) p_b[l][t] += dp[t];
         }
-        const float* WT = SWAP ? load_mat(L.o_WT[l]) : wp + L.o_WT[l];
+        const float* WT = UNT ? get_mat(l) : wp + L.o_WT[l];      // UNT: the untransposed matrix, read transposed below
         f32x4 da[HT];
 #pragma unroll
         for (int mt = 0; mt < HT; ++mt) da[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -457,7 +474,13 @@ __global__ __launch_bounds__(64 * kWaves) void mono_bwd_k(MonoArgs a) {
         for (int t = 0; t < HT; ++t) {
 #pragma unroll
           for (int mt = 0; mt < HT; ++mt) {
-            const f32x4 A = ld4(WT + (16 * mt + j) * L.LDW + 16 * t + 4 * q);
+            f32x4 A;
+            if constexpr (UNT) {
+#pragma unroll
+              for (int r = 0; r < 4; ++r) A[r] = WT[(16 * t + 4 * q + r) * L.LDW + 16 * mt + j];
+            } else {
+              A = ld4(WT + (16 * mt + j) * L.LDW + 16 * t + 4 * q);
+            }
 #pragma unroll
             for (int r = 0; r < 4; ++r) da[mt] = mfma(A[r], dp[t][r], da[mt]);
           }
@@ -616,10 +639,17 @@ int launch_bwd_one(const MonoArgs& a, unsigned grid, hipStream_t s) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mono_bwd_k<HT, NH, 1>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_all);
     hipLaunchKernelGGL((mono_bwd_k<HT, NH, 1>), dim3(grid), dim3(64 * kWaves), lds_all, s, a);
-  } else if constexpr (HT <= 10) {              // one matrix at a time
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mono_bwd_k<HT, NH, 2>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_one);
-    hipLaunchKernelGGL((mono_bwd_k<HT, NH, 2>), dim3(grid), dim3(64 * kWaves), lds_one, s, a);
+  } else if constexpr (HT <= 10) {
+    const size_t lds_res = lds_one * (NH > 1 ? NH - 1 : 1);
+    if (NH > 1 && lds_res <= (size_t)150 * 1024) {          // all hidden->hidden matrices resident (H <= 112, 3 hidden layers)
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mono_bwd_k<HT, NH, 3>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_res);
+      hipLaunchKernelGGL((mono_bwd_k<HT, NH, 3>), dim3(grid), dim3(64 * kWaves), lds_res, s, a);
+    } else {                                                 // one matrix at a time
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mono_bwd_k<HT, NH, 2>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_one);
+      hipLaunchKernelGGL((mono_bwd_k<HT, NH, 2>), dim3(grid), dim3(64 * kWaves), lds_one, s, a);
+    }
   } else {
     hipLaunchKernelGGL((mono_bwd_k<HT, NH, 0>), dim3(grid), dim3(64 * kWaves), 0, s, a);
   }
