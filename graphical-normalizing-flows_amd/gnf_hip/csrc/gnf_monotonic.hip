@@ -161,9 +161,9 @@ __device__ __forceinline__ void cond_bias(const float* wp, const MonoLayout& L, 
 }
 
 // f(xa;h), f(xb;h) for the 16 elements of the group: two nodes share every weight fragment.
-template <int HT>
+template <int HT, class GetW>
 __device__ __forceinline__ void eval2(const float* wp, const MonoLayout& L, const f32x4 (&c1)[HT], float xa,
-                                      float xb, int q, int j, float& fa, float& fb) {
+                                      float xb, int q, int j, float& fa, float& fb, GetW&& getW) {
   f32x4 a0[HT], a1[HT];
 #pragma unroll
   for (int t = 0; t < HT; ++t) {
@@ -175,7 +175,7 @@ __device__ __forceinline__ void eval2(const float* wp, const MonoLayout& L, cons
     }
   }
   for (int l = 1; l < L.NH; ++l) {
-    const float* W = wp + L.o_W[l];
+    const float* W = getW(l);                  // hidden->hidden matrix of layer l (L2, resident LDS image, or swapped in)
     f32x4 o0[HT], o1[HT];
 #pragma unroll
     for (int mt = 0; mt < HT; ++mt) { o0[mt] = ld4(wp + L.o_b[l] + 16 * mt + 4 * q); o1[mt] = o0[mt]; }
@@ -209,10 +209,10 @@ __device__ __forceinline__ void eval2(const float* wp, const MonoLayout& L, cons
 }
 
 // sum_k w_k f(xT (t_k+1)/2) over the S+1 quadrature nodes; optionally also f(xj) (Jacobian node)
-template <int HT, bool WITH_JAC>
+template <int HT, bool WITH_JAC, class GetW>
 __device__ __forceinline__ float quadrature(const float* wp, const MonoLayout& L, const f32x4 (&c1)[HT],
                                             const float* __restrict__ ccw, const float* __restrict__ cct, int S,
-                                            float xT, float xj, int q, int j, float& fjac) {
+                                            float xT, float xj, int q, int j, float& fjac, GetW&& getW) {
   float acc = 0.f;
   const int total = S + 1 + (WITH_JAC ? 1 : 0);
   for (int k = 0; k < total; k += 2) {
@@ -222,7 +222,7 @@ __device__ __forceinline__ float quadrature(const float* wp, const MonoLayout& L
     const float xa = k <= S ? xT * (cct[k] + 1.f) * .5f : xj;
     const float xb = k1 <= S ? xT * (cct[k1] + 1.f) * .5f : xj;
     float fa, fb;
-    eval2<HT>(wp, L, c1, xa, xb, q, j, fa, fb);
+    eval2<HT>(wp, L, c1, xa, xb, q, j, fa, fb, getW);
     acc = fmaf(wa, fa, acc);
     acc = fmaf(wb, fb, acc);
     if (WITH_JAC) {
@@ -233,25 +233,56 @@ __device__ __forceinline__ float quadrature(const float* wp, const MonoLayout& L
   return acc;
 }
 
-template <int HT, bool WLDS, bool INV>
+// WM 0: weight fragments from L1/L2.  1: the forward part of the pack LDS-resident (H <= 112).  2: wide nets -- one
+// hidden->hidden matrix in LDS at a time, swapped in by the whole workgroup (two quadrature nodes share every residency);
+// the wavefronts of a workgroup then run the same number of group iterations (a surplus wavefront recomputes the last
+// group and writes nothing).
+template <int HT, int WM, bool INV>
 __global__ __launch_bounds__(64 * kWaves) void mono_fwd_k(MonoArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const MonoLayout& L = a.L;
   const float* wp = a.pack;
-  if (WLDS) {
+  if (WM == 1) {
     for (int i = threadIdx.x * 4; i < L.fwd_floats; i += blockDim.x * 4)
       *reinterpret_cast<f32x4*>(smem + i) = ld4(a.pack + i);
     __syncthreads();
     wp = smem;
   }
+  int resident = 0;                              // WM 2: layer whose matrix sits in LDS; workgroup-uniform
+  auto getW = [&](int l) -> const float* {
+    if (WM != 2) return wp + L.o_W[l];
+    if (resident != l) {
+      const int matf = L.HP * L.LDW, stride = blockDim.x * 4;
+      __syncthreads();                            // previous matrix no longer read
+      for (int i0 = threadIdx.x * 4; i0 < matf; i0 += 8 * stride) {     // 8 independent loads in flight per thread
+        f32x4 t[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int i = i0 + u * stride;
+          t[u] = i < matf ? ld4(a.pack + L.o_W[l] + i) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int i = i0 + u * stride;
+          if (i < matf) *reinterpret_cast<f32x4*>(smem + i) = t[u];
+        }
+      }
+      __syncthreads();
+      resident = l;
+    }
+    return smem;
+  };
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int q = lane >> 4, j = lane & 15;
   const int64_t ngroups = (a.n + 15) / 16;
   const float fS = (float)a.S;
-  for (int64_t grp = (int64_t)blockIdx.x * kWaves + wave; grp < ngroups; grp += (int64_t)gridDim.x * kWaves) {
+  for (int64_t g0 = (int64_t)blockIdx.x * kWaves; g0 < ngroups; g0 += (int64_t)gridDim.x * kWaves) {
+    const bool gvalid = g0 + wave < ngroups;
+    if (WM != 2 && !gvalid) break;               // without workgroup barriers a surplus wavefront simply stops
+    const int64_t grp = gvalid ? g0 + wave : ngroups - 1;
     const int64_t e = grp * 16 + j;
-    const bool valid = e < a.n;
-    const int64_t ec = valid ? e : a.n - 1;
+    const bool valid = gvalid && e < a.n;
+    const int64_t ec = e < a.n ? e : a.n - 1;
     const int64_t b = ec / a.d, i = ec - b * a.d;
     const int64_t hbase = b * a.h_sb + i * a.h_sd;
     f32x4 c1[HT];
@@ -262,7 +293,7 @@ __global__ __launch_bounds__(64 * kWaves) void mono_fwd_k(MonoArgs a) {
       const float xv = a.x[ec];
       const float xT = fS * (xv / fS);                 // xT = x0 + nb_steps*step, x0 = 0
       float fj = 0.f;
-      const float zs = quadrature<HT, true>(wp, L, c1, a.ccw, a.cct, a.S, xT, xv, q, j, fj);
+      const float zs = quadrature<HT, true>(wp, L, c1, a.ccw, a.cct, a.S, xT, xv, q, j, fj, getW);
       if (valid && q == 0) {
         a.z[e] = zs * xT * .5f + h0;
         a.jac[e] = fj;
@@ -273,7 +304,7 @@ __global__ __launch_bounds__(64 * kWaves) void mono_fwd_k(MonoArgs a) {
       for (int it = 0; it < 20; ++it) {
         const float xm = (xmax + xmin) * .5f;
         const float xT = fS * (xm / fS);
-        const float zm = quadrature<HT, false>(wp, L, c1, a.ccw, a.cct, a.S, xT, 0.f, q, j, dummy) * xT * .5f + h0;
+        const float zm = quadrature<HT, false>(wp, L, c1, a.ccw, a.cct, a.S, xT, 0.f, q, j, dummy, getW) * xT * .5f + h0;
         if (zm > zt) xmax = xm; else xmin = xm;
       }
       if (valid && q == 0) a.xo[e] = (xmax + xmin) * .5f;
@@ -608,17 +639,23 @@ int launch_fwd(const MonoArgs& a, hipStream_t s) {
   const int64_t ngroups = (a.n + 15) / 16;
   int64_t grid = (ngroups + kWaves - 1) / kWaves;
   const size_t lds = (size_t)a.L.fwd_floats * sizeof(float);
-  const bool wlds = lds <= (size_t)150 * 1024;                       // else: weight fragments stream from L1/L2
-  const int64_t per_cu = (wlds && lds > (size_t)kLdsBudget / 2) ? 1 : 2;   // resident workgroups per CU
+  const size_t lds_one = (size_t)a.L.HP * a.L.LDW * sizeof(float);
+  const bool wlds = lds <= (size_t)150 * 1024;                       // whole forward image resident
+  const bool swap = !wlds && a.L.NH > 1 && lds_one <= (size_t)150 * 1024;   // else one matrix at a time, else L1/L2
+  const int64_t per_cu = ((wlds && lds > (size_t)kLdsBudget / 2) || swap) ? 1 : 2;   // resident workgroups per CU
   if (grid > 256 * per_cu) grid = 256 * per_cu;                      // persistent
 #define GNF_FWD_CASE(HT_)                                                                                     \
   case HT_:                                                                                                  \
     if (wlds) {                                                                                              \
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mono_fwd_k<HT_, true, INV>),                      \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mono_fwd_k<HT_, 1, INV>),                     \
                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                             \
-      hipLaunchKernelGGL((mono_fwd_k<HT_, true, INV>), dim3((unsigned)grid), dim3(64 * kWaves), lds, s, a);  \
+      hipLaunchKernelGGL((mono_fwd_k<HT_, 1, INV>), dim3((unsigned)grid), dim3(64 * kWaves), lds, s, a);     \
+    } else if (swap) {                                                                                       \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mono_fwd_k<HT_, 2, INV>),                     \
+                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_one);                         \
+      hipLaunchKernelGGL((mono_fwd_k<HT_, 2, INV>), dim3((unsigned)grid), dim3(64 * kWaves), lds_one, s, a); \
     } else {                                                                                                 \
-      hipLaunchKernelGGL((mono_fwd_k<HT_, false, INV>), dim3((unsigned)grid), dim3(64 * kWaves), 0, s, a);   \
+      hipLaunchKernelGGL((mono_fwd_k<HT_, 0, INV>), dim3((unsigned)grid), dim3(64 * kWaves), 0, s, a);       \
     }                                                                                                        \
     break;
   switch (HT) {
