@@ -383,7 +383,7 @@ static int plan_splits(int64_t M, int64_t N, int64_t K) {
 
 extern "C" int64_t gnf_gemm_ws_bytes(int64_t M, int64_t N, int64_t K) {
   const int s = plan_splits(M, N, K);
-  return s > 1 ? (int64_t)s * M * N * (int64_t)sizeof(float) : 0;
+  return s > 1 ? (int64_t)(s + 1) * M * N * (int64_t)sizeof(float) : 0;     // partials + one row for their sum
 }
 
 extern "C" int gnf_gemm(const float* A, int64_t sam, int64_t sak, const float* B, const float* Bmask, int64_t sbk,
@@ -401,10 +401,20 @@ extern "C" int gnf_gemm(const float* A, int64_t sam, int64_t sak, const float* B
     p.bias = nullptr; p.Cmask = nullptr; p.gate = nullptr; p.flags = 0;
     int rc = gnf_gemm_launch(p, splits, (hipStream_t)stream);
     if (rc) return rc;
-    const int64_t nsp = gnf_gemm_num_splits(K, splits);
+    int64_t nsp = gnf_gemm_num_splits(K, splits);
+    const float* part = ws;
+    if (M * N < 16384 && nsp > 8) {
+      // small output, many partials (the 60 x 60 weight gradients of the POWER embedding MLP over 60 000 rows): one
+      // thread per output walking the partials serially is latency-bound; sum them with the parallel row-sum kernel first
+      float* sum = ws + nsp * M * N;
+      rc = gnf_rowsum_launch(ws, sum, nsp, M * N, 0, (hipStream_t)stream);
+      if (rc) return rc;
+      part = sum;
+      nsp = 1;
+    }
     int64_t grid = (M * N + 255) / 256;
     if (grid > 4096) grid = 4096;
-    hipLaunchKernelGGL(gemm_reduce_k, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, ws, nsp, g);
+    hipLaunchKernelGGL(gemm_reduce_k, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, part, nsp, g);
     GNF_LAUNCH_CHECK();
     return 0;
   }
