@@ -18,7 +18,7 @@ LIB = os.path.join(HERE, "libgnf_hip.so")
 OBJ = os.path.join(HERE, "_obj")
 ARCH = "gfx950"
 SOURCES = ["gnf_rowwise.hip", "gnf_dag_gate.hip", "gnf_gemm.hip", "gnf_monotonic.hip", "gnf_mnistcnn.hip",
-           "gnf_probe.hip"]
+           "gnf_mnistcnn_sparse.hip", "gnf_probe.hip"]
 FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-I" + INCLUDE, "-I" + CSRC,
          "-Wno-unused-value"]
 

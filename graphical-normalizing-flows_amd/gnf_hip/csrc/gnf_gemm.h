@@ -13,6 +13,9 @@ struct GemmArgs {
   const float* gate; int64_t sgm, sgn;
   int flags; int64_t M, N, K;
   int64_t k_per_split, c_split_stride;   // split-K: blockIdx.z owns [z*kps, (z+1)*kps), writes C + z*stride
+  // grouped launch (gnf_gemm_grouped_launch): blockIdx.z = group z owns rows [grp[2z], grp[2z] + grp[2z+1]) of A and C
+  // and multiplies them with its own B = B + z * b_grp_stride; M is the largest group's row count; no split-K
+  const int32_t* grp; int64_t b_grp_stride;
 };
 
 // internal epilogue flag: C += result (chunked accumulation of split-K partials)
@@ -21,5 +24,7 @@ struct GemmArgs {
 // splits > 1: split-K; partial z is written to C + z*c_split_stride (caller sets the
 // stride and reduces the partials); epilogue options other than ACCUM must be off.
 int gnf_gemm_launch(GemmArgs g, int splits, hipStream_t s);
+// C[rows of group z] = epi(A[rows of group z] * B_z): ngroups row ranges (device table g.grp, see GemmArgs), one launch
+int gnf_gemm_grouped_launch(GemmArgs g, int ngroups, hipStream_t s);
 // number of partials gnf_gemm_launch(K, splits) writes (without ACCUM)
 int64_t gnf_gemm_num_splits(int64_t K, int splits);

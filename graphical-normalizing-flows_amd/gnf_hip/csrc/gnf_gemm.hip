@@ -210,9 +210,22 @@ __global__ __launch_bounds__(256) void gemm_vec_k(GemmArgs g) {
   const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = (wave >> 1) * WM, wn = (wave & 1) * WN;
   const int64_t m0 = (int64_t)blockIdx.x * BM, n0 = (int64_t)blockIdx.y * BN;
-  const int64_t kbeg = (int64_t)blockIdx.z * g.k_per_split;
-  const int64_t kend = kbeg + g.k_per_split < g.K ? kbeg + g.k_per_split : g.K;
+  int64_t kbeg = (int64_t)blockIdx.z * g.k_per_split;
+  int64_t kend = kbeg + g.k_per_split < g.K ? kbeg + g.k_per_split : g.K;
   float* __restrict__ Cz = g.C + (int64_t)blockIdx.z * g.c_split_stride;
+  const float* __restrict__ Ag = g.A;
+  const float* __restrict__ Bg = g.B;
+  int64_t Mr = g.M;
+  if (g.grp) {                               // grouped launch: blockIdx.z selects a row range and its own B
+    const int64_t first = g.grp[2 * blockIdx.z];
+    Mr = g.grp[2 * blockIdx.z + 1];
+    if (m0 >= Mr) return;                    // workgroup-uniform
+    Ag += first * g.sam;
+    Bg += (int64_t)blockIdx.z * g.b_grp_stride;
+    Cz = g.C + first * g.scm;
+    kbeg = 0;
+    kend = g.K;
+  }
 
   f32x4v ra[SA::NV], rb[SB::NV];
   f32x16 acc[TM][TN];
@@ -228,13 +241,13 @@ __global__ __launch_bounds__(256) void gemm_vec_k(GemmArgs g) {
     for (int it = 0; it < SA::NV; ++it) {
       int x, k;
       SA::coord(tid, it, x, k);
-      ra[it] = SA::load(g.A, nullptr, g.sam, g.sak, m0 + x, k0 + k, g.M, kend);
+      ra[it] = SA::load(Ag, nullptr, g.sam, g.sak, m0 + x, k0 + k, Mr, kend);
     }
 #pragma unroll
     for (int it = 0; it < SB::NV; ++it) {
       int x, k;
       SB::coord(tid, it, x, k);
-      rb[it] = SB::load(g.B, g.Bmask, g.sbn, g.sbk, n0 + x, k0 + k, g.N, kend);
+      rb[it] = SB::load(Bg, g.Bmask, g.sbn, g.sbk, n0 + x, k0 + k, g.N, kend);
     }
   };
   auto store_tile = [&]() {
@@ -283,7 +296,7 @@ __global__ __launch_bounds__(256) void gemm_vec_k(GemmArgs g) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int64_t m = m0 + wm + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * fk;
-        if (m >= g.M) continue;
+        if (m >= Mr) continue;
         float v = acc[i][j][r] + bv;
         if (g.Cmask) v *= g.Cmask[m * g.scmm + n * g.scmn];
         if (g.flags & GNF_GEMM_RELU) v = fmaxf(v, 0.f);
@@ -356,6 +369,22 @@ int gnf_gemm_launch(GemmArgs g, int splits, hipStream_t s) {
     else hipLaunchKernelGGL((gemm_k<64, 64>), grid, dim3(256), 0, s, g);
   }
 #undef GNF_VEC_LAUNCH
+  GNF_LAUNCH_CHECK();
+  return 0;
+}
+
+int gnf_gemm_grouped_launch(GemmArgs g, int ngroups, hipStream_t s) {
+  auto al16 = [](const void* p) { return ((uintptr_t)p & 15) == 0; };
+  const bool akf = g.sak == 1 && g.sam % 4 == 0, bnf = g.sbn == 1 && g.sbk % 4 == 0;
+  if (!g.grp || ngroups < 1 || ngroups > 65535 || !akf || !bnf || !al16(g.A) || !al16(g.B) || g.K % 4 ||
+      g.b_grp_stride % 4 || g.Bmask || g.Cmask || g.gate)
+    return GNF_ESHAPE;                       // the one layout it is used with: A row-major, B_z k-major
+  g.k_per_split = (g.K + BKV - 1) / BKV * BKV;
+  g.c_split_stride = 0;
+  const int bt = g.M >= 1024 ? 128 : 64;
+  const dim3 grid((unsigned)((g.M + bt - 1) / bt), (unsigned)((g.N + bt - 1) / bt), (unsigned)ngroups);
+  if (bt == 128) hipLaunchKernelGGL((gemm_vec_k<128, 128, true, false>), grid, dim3(256), 0, s, g);
+  else hipLaunchKernelGGL((gemm_vec_k<64, 64, true, false>), grid, dim3(256), 0, s, g);
   GNF_LAUNCH_CHECK();
   return 0;
 }

@@ -226,6 +226,59 @@ class MnistConvFn(torch.autograd.Function):
         return ge, gW1, gb1, gW2, gb2
 
 
+def crop_origin(p):
+    """cell origin of the 5x5 pooled block that can deviate from the background for a pixel row / column p"""
+    return min(max((p - 6) >> 1, 0), 7)
+
+
+def mnist_window_mask(device, kernel=2):
+    """[784,784] bool: True where pixel j lies in the (2 kernel + 1)^2 window around pixel i (the support
+    MNIST_A_prior(28, kernel) allows, diagonal included)"""
+    r = torch.arange(28, device=device).repeat_interleave(28)
+    c = torch.arange(28, device=device).repeat(28)
+    return ((r[:, None] - r[None, :]).abs() <= kernel) & ((c[:, None] - c[None, :]).abs() <= kernel)
+
+
+class SparseRows:
+    """Masked copies to evaluate, in the order the sparse kernels want them: sorted by crop origin, with the
+    (first output row, row count) table of the 64 origins for a batch of B samples."""
+
+    def __init__(self, rows, B, device):
+        rows = [int(r) for r in rows]
+        origin = [8 * crop_origin(r // 28) + crop_origin(r % 28) for r in rows]
+        order = sorted(range(len(rows)), key=lambda k: (origin[k], rows[k]))
+        self.R, self.B = len(rows), B
+        self.pix = torch.tensor([rows[k] for k in order], dtype=torch.int32, device=device)
+        inv = [0] * len(rows)
+        for pos, k in enumerate(order):
+            inv[k] = pos
+        self.unsort = torch.tensor(inv, dtype=torch.long, device=device)   # position of rows[k] in the sorted order
+        counts = [0] * 64
+        for g in origin:
+            counts[g] += 1
+        table, first = [], 0
+        for g in range(64):
+            table += [first * B, counts[g] * B]
+            first += counts[g]
+        self.groups = torch.tensor(table, dtype=torch.int32, device=device)
+        self.max_group_rows = max(max(counts) * B, 1)
+
+
+def mnistcnn_sparse_fwd(x, P, sr, W1, b1, W2, b2, Wfc1, bfc1):
+    """relu(fc1(flatten(maxpool(conv2(relu(conv1(x * P[i]))))))) for the masked copies i in `sr` (a SparseRows), P
+    zero outside the 5x5 windows: [R*B, F] in sr's sorted order (row = position * B + sample).  Forward only."""
+    x, P = x.contiguous(), P.contiguous()
+    F = Wfc1.shape[0]
+    n = sr.R * sr.B
+    h1 = _empty((n, F), x)
+    nws = abi.load().gnf_mnistcnn_sparse_ws_bytes(n, F)
+    ws = _ws(nws, x)
+    call("gnf_mnistcnn_sparse_fwd", ptr(x), sr.B, ptr(P), abi.rawptr(sr.pix), sr.R, abi.rawptr(sr.groups),
+         sr.max_group_rows, ptr(W1.contiguous()), ptr(b1.contiguous()), ptr(W2.contiguous()), ptr(b2.contiguous()),
+         ptr(Wfc1.contiguous()), ptr(bfc1.contiguous()), F, ptr(h1), abi.rawptr(ws), nws, stream())
+    return h1
+
+
 # ----------------------------------------------------------------------------- DAG gate
 IMP_RAW, IMP_SOFT, IMP_HARD_SOFT, IMP_HARD_SQ = 0, 1, 2, 3
 GATE_DET, GATE_GUMBEL, GATE_NOISE = 0, 1, 2

@@ -79,6 +79,9 @@ class DAGConditioner(Conditioner):
         self.nb_epoch_update = nb_epoch_update
         self.no_update = 0
         self.is_invertible = False
+        self.sparse_front = True        # deterministic gate + windowed A + no autograd: sparse embedding front
+        self._sparse_outside = None     # 1 outside the 5x5 pixel windows (device mask, built on first use)
+        self._sparse_plans = {}
         self.gate_noise = None          # (u1, u2) [B,d,d] uniforms (test hook); None -> Philox
         self._gate_calls = 0
         self.gate_seed = int(torch.randint(0, 2 ** 31 - 1, (1,)).item())
@@ -125,8 +128,38 @@ class DAGConditioner(Conditioner):
         return ops.DagGateFn.apply(x, self.A, imp, gate, float(self.h_thresh), float(self.gumble_T),
                                    bool(self.hot_encoding), u1, u2, self.gate_seed, self._gate_calls)
 
+    def _sparse_plan(self, x, rows, P):
+        """gnf_hip.ops.SparseRows when the sparse masked-image front applies -- an MNISTCNN embedding net on the GPU, no
+        gradient wanted, and every row of P zero outside its pixel's 5x5 window --
+        else None.  rows: iterable of variable indices, None = all."""
+        net = self.embedding_net
+        if not self.sparse_front or self.hot_encoding or self.cond_in or not hasattr(net, "sparse_rows"):
+            return None
+        if not net.supports_sparse(x):
+            return None
+        if torch.is_grad_enabled() and (x.requires_grad or P.requires_grad
+                                        or any(p.requires_grad for p in net.parameters())):
+            return None
+        # checked on every call (one small reduction + a host read): A can be edited in ways no version counter sees
+        if self._sparse_outside is None or self._sparse_outside.device != P.device:
+            self._sparse_outside = (~ops.mnist_window_mask(P.device)).float()
+        if bool((P.detach() * self._sparse_outside).count_nonzero()):
+            return None
+        rows = tuple(range(self.in_size)) if rows is None else tuple(int(r) for r in rows)
+        plan_key = (rows, x.shape[0], x.device)
+        if plan_key not in self._sparse_plans:
+            if len(self._sparse_plans) > 4096:
+                self._sparse_plans.clear()
+            self._sparse_plans[plan_key] = ops.SparseRows(rows, x.shape[0], x.device)
+        return self._sparse_plans[plan_key]
+
     def forward(self, x, context=None):
         no_context(context, self.cond_in)
+        P = self.deterministic_importance()
+        if P is not None:
+            plan = self._sparse_plan(x, None, P)
+            if plan is not None:
+                return self.embedding_net.sparse_rows(x, P, plan)
         e = self.masked_inputs(x)
         return self.embedding_net(e).view(x.shape[0], self.in_size, -1)
 
@@ -257,6 +290,9 @@ class DAGConditioner(Conditioner):
         """h[:, rows, :] only: the conditioner output of row i depends on x through x * P[i] alone, so a
         level-scheduled inversion evaluates each row exactly once."""
         B, R = x.shape[0], rows.numel()
+        plan = self._sparse_plan(x, rows.tolist(), P)
+        if plan is not None:
+            return self.embedding_net.sparse_rows(x, P, plan)
         e = x.unsqueeze(1) * P[rows].unsqueeze(0)                        # [B, R, d]
         if self.hot_encoding:
             hot = torch.zeros(R, self.in_size, device=x.device, dtype=x.dtype)

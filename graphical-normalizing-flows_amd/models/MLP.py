@@ -62,6 +62,19 @@ class MNISTCNN(nn.Module):
         return (x.is_cuda and list(self.size_img) == [1, 28, 28] and x.shape[-1] == 784
                 and self.conv1.weight.shape == (16, 1, 3, 3) and self.conv2.weight.shape == (16, 16, 3, 3))
 
+    def supports_sparse(self, x):
+        """the sparse masked-copy front (gnf_hip.ops.mnistcnn_sparse_fwd) covers the 28x28 net with fc1 on 2304 inputs"""
+        return (self._fused_front(x) and self.fc1.in_features == 2304 and self.fc1.out_features % 4 == 0)
+
+    def sparse_rows(self, x, P, sr):
+        """Embeddings [B, R, out_d] of the masked copies x * P[i], i in the gnf_hip.ops.SparseRows `sr` (returned in the
+        caller's order), for an importance matrix P that is zero outside the 5x5 pixel windows: only the 14x14 crop
+        that can differ from the all-zero image is convolved.  No autograd graph is recorded."""
+        h1 = ops.mnistcnn_sparse_fwd(x.view(-1, 784), P, sr, self.conv1.weight, self.conv1.bias, self.conv2.weight,
+                                     self.conv2.bias, self.fc1.weight, self.fc1.bias)
+        out = ops.mlp(h1, [(self.fc2.weight, self.fc2.bias)])
+        return out.view(sr.R, sr.B, -1)[sr.unsort].permute(1, 0, 2)
+
     def forward(self, x, context=None):
         rows = x.shape[0]
         if self._fused_front(x):

@@ -764,3 +764,122 @@ def test_graphed_step_equals_eager_steps(kind):
     assert rel_err(lb.cpu(), la.detach().cpu()) < 1e-5
     assert rel_err(sb.flat.cpu(), sa.flat.cpu()) < 1e-5
 
+
+
+# --------------------------------------------------------------------------------- sparse masked-image front (8(f)1)
+def _windowed_conditioner(seed, post_processed):
+    """DAGConditioner(MNISTCNN) on 28x28 with the kernel-2 prior; deterministic gate"""
+    from models import DAGConditioner
+    from models.MLP import MNISTCNN
+    from models.NormalizingFlowFactories import MNIST_A_prior
+    torch.manual_seed(seed)
+    prior = MNIST_A_prior(28, 2)
+    A = prior * (torch.rand(784, 784) < .7).float() * (.5 + torch.rand(784, 784))
+    cond = DAGConditioner(784, MNISTCNN(out_d=30), 30, A_prior=A.clone()).to(DEV)
+    cond.stoch_gate = False                        # deterministic soft-thresholded importance
+    if post_processed:                             # what post_process() leaves: binary A, raw product
+        cond.s_thresh, cond.h_thresh = False, 0.
+        cond.A.data = (cond.A.data != 0).float()
+        cond.A.requires_grad = False
+    with torch.no_grad():
+        for p in cond.embedding_net.parameters():  # biases of both signs: background relu(b) partly 0, partly > 0
+            if p.dim() == 1:
+                p.copy_(torch.randn_like(p) * .3)
+    return cond
+
+
+@pytest.mark.parametrize("post_processed", [False, True])
+def test_sparse_front_matches_oracle_and_dense(post_processed):
+    """forward of the conditioner under a deterministic gate: sparse crop path == CPU oracle on the explicit
+    78 400-wide masked copies == the dense HIP kernels"""
+    cond = _windowed_conditioner(3, post_processed)
+    B = 3
+    x = torch.rand(B, 784)
+    with torch.no_grad():
+        P = cond.deterministic_importance()
+        assert cond._sparse_plan(cu(x), None, P) is not None
+        h_sparse = cond(cu(x))
+        cond.sparse_front = False
+        h_dense = cond(cu(x))
+        cond.sparse_front = True
+        e = (x.unsqueeze(1) * P.cpu().unsqueeze(0)).reshape(B * 784, 784)
+        ref = O.mnistcnn_forward(e, {k: v.detach().cpu() for k, v in cond.embedding_net.state_dict().items()})
+    ref = ref.view(B, 784, 30)
+    assert h_sparse.shape == (B, 784, 30)
+    assert rel_err(h_sparse.cpu(), ref) < TOL, rel_err(h_sparse.cpu(), ref)
+    assert rel_err(h_dense.cpu(), ref) < TOL
+    # per-row check as well (a wrong row permutation of a few copies would hide in a global norm)
+    err = (h_sparse.cpu() - ref).abs().amax(2) / ref.abs().amax(2).clamp_min(1e-6)
+    assert err.max() < 1e-4, err.max()
+
+
+def test_sparse_front_row_subsets_and_fallbacks():
+    cond = _windowed_conditioner(5, True)
+    B = 5
+    x = cu(torch.rand(B, 784))
+    rows = torch.tensor([783, 0, 27, 28, 400, 401, 13 * 28 + 13, 6 * 28 + 7, 21 * 28 + 20, 755], device=DEV)
+    with torch.no_grad():
+        P = cond.deterministic_importance()
+        got = cond.forward_rows(x, rows, P)
+        cond.sparse_front = False
+        want = cond.forward_rows(x, rows, P)
+        cond.sparse_front = True
+        assert got.shape == want.shape == (B, rows.numel(), 30)
+        assert rel_err(got.cpu(), want.cpu()) < TOL
+        # an entry outside the 5x5 window: the sparse front must step aside (dense result unchanged)
+        cond.A.data[0, 300] = 1.
+        assert cond._sparse_plan(x, None, cond.deterministic_importance()) is None
+        cond.A.data[0, 300] = 0.
+        assert cond._sparse_plan(x, None, cond.deterministic_importance()) is not None
+    # gradients wanted -> dense path with an autograd graph
+    for p in cond.embedding_net.parameters():
+        assert p.requires_grad
+    assert cond._sparse_plan(x, None, cond.deterministic_importance()) is None
+    h = cond(x)
+    assert h.requires_grad
+    # stochastic gate -> never sparse
+    cond.stoch_gate, cond.s_thresh = True, True
+    assert cond.deterministic_importance() is None
+
+
+def test_sparse_front_abi_validation():
+    import ctypes
+    from gnf_hip import abi
+    lib = abi.load()
+    assert lib.gnf_mnistcnn_sparse_ws_bytes(10, 128) == (10 * 400 + 64 * 400 * 128 + 16 + 128 + 64) * 4
+    assert lib.gnf_mnistcnn_sparse_fwd(None, 1, None, None, 1, None, 1, None, None, None, None, None, None, 128, None,
+                                       None, 0, None) == -1
+    t = torch.zeros(64 * 400 * 6 + 4096, device=DEV)
+    i32 = torch.zeros(128, dtype=torch.int32, device=DEV)
+    p, ip = ctypes.c_void_p(t.data_ptr()), ctypes.c_void_p(i32.data_ptr())
+    # F not a multiple of 4 -> shape error; zero rows -> no-op success
+    assert lib.gnf_mnistcnn_sparse_fwd(p, 1, p, ip, 1, ip, 1, p, p, p, p, p, p, 6, p, p, t.numel() * 4, None) == -2
+    assert lib.gnf_mnistcnn_sparse_fwd(p, 0, p, ip, 1, ip, 1, p, p, p, p, p, p, 8, p, p, 0, None) == 0
+    # workspace too small
+    assert lib.gnf_mnistcnn_sparse_fwd(p, 1, p, ip, 1, ip, 1, p, p, p, p, p, p, 8, p, p, 16, None) == -1
+
+
+def test_mnist_level_inversion_uses_sparse_front():
+    """DAG 'pixel above and left-above': level-scheduled inversion with the sparse front == with the dense kernels"""
+    from models import DAGConditioner, AffineNormalizer
+    from models.NormalizingFlow import NormalizingFlowStep
+    from models.MLP import MNISTCNN
+    torch.manual_seed(11)
+    A = torch.zeros(784, 784)
+    for i in range(28, 784):
+        A[i, i - 28] = 1.
+        if i % 28:
+            A[i, i - 29] = 1.
+    cond = DAGConditioner(784, MNISTCNN(out_d=2), 2, A_prior=A).to(DEV)
+    cond.stoch_gate, cond.s_thresh, cond.h_thresh = False, False, 0.
+    cond.A.requires_grad = False
+    step = NormalizingFlowStep(cond, AffineNormalizer()).to(DEV)
+    z = cu(torch.randn(4, 784) * .5)
+    x_sparse = step.invert(z)
+    assert len(cond._sparse_plans) >= 28
+    cond.sparse_front = False
+    x_dense = step.invert(z)
+    assert rel_err(x_sparse.cpu(), x_dense.cpu()) < 1e-4
+    with torch.no_grad():
+        z_back, _ = step(x_sparse)
+    assert rel_err(z_back.cpu(), z.cpu()) < 1e-4
