@@ -16,6 +16,9 @@ struct GemmArgs {
   // grouped launch (gnf_gemm_grouped_launch): blockIdx.z = group z owns rows [grp[2z], grp[2z] + grp[2z+1]) of A and C
   // and multiplies them with its own B = B + z * b_grp_stride; M is the largest group's row count; no split-K
   const int32_t* grp; int64_t b_grp_stride;
+  // grp_k != 0: the group table partitions K instead (group z contracts k in [grp[2z], grp[2z] + grp[2z+1]) of the
+  // shared A and B and writes its own C + z * c_split_stride): per-group weight gradients
+  int grp_k;
 };
 
 // internal epilogue flag: C += result (chunked accumulation of split-K partials)

@@ -217,14 +217,19 @@ __global__ __launch_bounds__(256) void gemm_vec_k(GemmArgs g) {
   const float* __restrict__ Bg = g.B;
   int64_t Mr = g.M;
   if (g.grp) {                               // grouped launch: blockIdx.z selects a row range and its own B
-    const int64_t first = g.grp[2 * blockIdx.z];
-    Mr = g.grp[2 * blockIdx.z + 1];
-    if (m0 >= Mr) return;                    // workgroup-uniform
-    Ag += first * g.sam;
-    Bg += (int64_t)blockIdx.z * g.b_grp_stride;
-    Cz = g.C + first * g.scm;
-    kbeg = 0;
-    kend = g.K;
+    const int64_t first = g.grp[2 * blockIdx.z], cnt = g.grp[2 * blockIdx.z + 1];
+    if (g.grp_k) {                           // K range of the shared operands, own output
+      kbeg = first;
+      kend = first + cnt;
+    } else {
+      Mr = cnt;
+      if (m0 >= Mr) return;                  // workgroup-uniform
+      Ag += first * g.sam;
+      Bg += (int64_t)blockIdx.z * g.b_grp_stride;
+      Cz = g.C + first * g.scm;
+      kbeg = 0;
+      kend = g.K;
+    }
   }
 
   f32x4v ra[SA::NV], rb[SB::NV];
@@ -375,16 +380,30 @@ int gnf_gemm_launch(GemmArgs g, int splits, hipStream_t s) {
 
 int gnf_gemm_grouped_launch(GemmArgs g, int ngroups, hipStream_t s) {
   auto al16 = [](const void* p) { return ((uintptr_t)p & 15) == 0; };
-  const bool akf = g.sak == 1 && g.sam % 4 == 0, bnf = g.sbn == 1 && g.sbk % 4 == 0;
-  if (!g.grp || ngroups < 1 || ngroups > 65535 || !akf || !bnf || !al16(g.A) || !al16(g.B) || g.K % 4 ||
+  const bool akf = g.sak == 1 && g.sam % 4 == 0, amf = g.sam == 1 && g.sak % 4 == 0;
+  const bool bkf = g.sbk == 1 && g.sbn % 4 == 0, bnf = g.sbn == 1 && g.sbk % 4 == 0;
+  if (!g.grp || ngroups < 1 || ngroups > 65535 || !(akf || amf) || !(bkf || bnf) || !al16(g.A) || !al16(g.B) ||
       g.b_grp_stride % 4 || g.Bmask || g.Cmask || g.gate)
-    return GNF_ESHAPE;                       // the one layout it is used with: A row-major, B_z k-major
-  g.k_per_split = (g.K + BKV - 1) / BKV * BKV;
-  g.c_split_stride = 0;
-  const int bt = g.M >= 1024 ? 128 : 64;
+    return GNF_ESHAPE;
+  if (g.grp_k) {
+    if (akf || bkf) return GNF_ESHAPE;       // K ranges start anywhere: K must be the strided dimension of both operands
+    g.k_per_split = BKV;                     // unused (the table gives the range)
+  } else {
+    if (g.K % 4) return GNF_ESHAPE;
+    g.k_per_split = (g.K + BKV - 1) / BKV * BKV;
+    g.c_split_stride = 0;
+  }
+  const int bt = g.M >= 1024 || g.grp_k ? 128 : 64;
   const dim3 grid((unsigned)((g.M + bt - 1) / bt), (unsigned)((g.N + bt - 1) / bt), (unsigned)ngroups);
-  if (bt == 128) hipLaunchKernelGGL((gemm_vec_k<128, 128, true, false>), grid, dim3(256), 0, s, g);
-  else hipLaunchKernelGGL((gemm_vec_k<64, 64, true, false>), grid, dim3(256), 0, s, g);
+#define GNF_GRP_LAUNCH(BT)                                                                              \
+  do {                                                                                                  \
+    if (akf && bkf) hipLaunchKernelGGL((gemm_vec_k<BT, BT, true, true>), grid, dim3(256), 0, s, g);      \
+    else if (akf) hipLaunchKernelGGL((gemm_vec_k<BT, BT, true, false>), grid, dim3(256), 0, s, g);       \
+    else if (bkf) hipLaunchKernelGGL((gemm_vec_k<BT, BT, false, true>), grid, dim3(256), 0, s, g);       \
+    else hipLaunchKernelGGL((gemm_vec_k<BT, BT, false, false>), grid, dim3(256), 0, s, g);               \
+  } while (0)
+  if (bt == 128) GNF_GRP_LAUNCH(128); else GNF_GRP_LAUNCH(64);
+#undef GNF_GRP_LAUNCH
   GNF_LAUNCH_CHECK();
   return 0;
 }

@@ -14,7 +14,8 @@
 // The stochastic (Gumbel) gate leaks ~1e-6 e^(g1-g2) of every pixel through, occasionally O(1): it stays on the dense
 // kernels (gnf_mnistcnn.hip).
 //
-// gfx950 mapping (forward only; a training step needing gradients uses the dense pair):
+// gfx950 mapping (forward, and the backward w.r.t. the network parameters for training with a FROZEN deterministic
+// gate -- gradients w.r.t. x or P are not produced here, such a step stays on the dense pair):
 //   crop kernel: ONE WAVEFRONT per masked copy, everything in that wave's 10 KB of LDS -> 12 waves per CU.
 //     conv1 as 9 x 3 and conv2 as 7 x 36 v_mfma_f32_16x16x4_f32 (direct convolution as implicit GEMM: M = 16 output
 //     channels, N = 16 positions, K = taps / (tap, input channel)); the weights are the A operand and stay in registers
@@ -23,12 +24,19 @@
 //     quad stores 4 channels of a cell as a float4: rows of `pd` are [cell][channel].
 //   fc1: the 64 column blocks are gathered once per call into k-major images Wg[64][400][F]; masked copies arrive
 //     sorted by block, so ONE grouped launch of the fp32 MFMA GEMM (gnf_gemm.hip) does bias + ReLU for all of them.
+//   backward: d pd = g . Wg^T and dWg = pd^T . g as grouped GEMMs (row groups / K groups), dWg scattered back to the
+//     fc1 weight; the crop backward kernel (one wavefront per masked copy again) recomputes conv1, rebuilds the
+//     max-pooled cotangent from the saved argmax, and contracts dW2 (K = the 100 conv2 positions), d a1 (K = (output
+//     channel, tap)) and dW1/db1 (K = the 144 conv1 positions, against the crop and a constant-1 image) on MFMA with
+//     the accumulators in registers across all copies of the wave.  What the constant background contributes (bg
+//     depends on b1, W2, b2) is a closed form of the column sums and is added by a one-workgroup epilogue.
 #include "gnf_common.h"
 #include "gnf_gemm.h"
 
 namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 constexpr int IMG = 28, NPIX = IMG * IMG, NCH = 16;
 constexpr int CROP = 14, ES = 16, ESZ = CROP * ES;     // crop of the masked image, row stride 16
@@ -68,6 +76,7 @@ __global__ void sparse_bg_k(const float* __restrict__ b1, const float* __restric
   __syncthreads();
   // every workgroup recomputes the 16 background values (2304 fma) and reduces 4 rows of Wfc1
   const int lane = threadIdx.x & 63, nw = blockDim.x >> 6, wave = blockIdx.x * nw + (threadIdx.x >> 6);
+  if (!hbg) return;
   for (int n = wave; n < F; n += nw * gridDim.x) {
     float s = 0.f;
     for (int k = lane; k < NCH * 144; k += 64) s = fmaf(Wfc1[(int64_t)n * (NCH * 144) + k], sbg[k / 144], s);
@@ -91,9 +100,17 @@ __global__ void sparse_gather_fc1_k(const float* __restrict__ Wfc1, int F, float
 struct SparseArgs {
   const float* x; const float* P; const int32_t* pix;
   const float* W1; const float* b1; const float* W2; const float* b2; const float* bg;
-  float* pd; int64_t B, items;
+  float* pd; unsigned char* arg; int64_t B, items;
 };
 
+__device__ __forceinline__ int quad_min(int v) {
+  v = min(v, __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xF, 0xF, false));
+  return min(v, __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xF, 0xF, false));
+}
+
+// SAVE: also record, per (cell, channel), which of the 4 positions won the max-pool (first maximum in scan order, what
+// torch's max_pool2d backward uses) -- one byte each, same [cell][channel] layout as pd
+template <bool SAVE>
 __global__ __launch_bounds__(64 * WAVES, 3) void sparse_crop_k(SparseArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -187,11 +204,257 @@ __global__ __launch_bounds__(64 * WAVES, 3) void sparse_crop_k(SparseArgs a) {
         d1 = mfma(wa2[s + 1], bp[4 * ((s + 1) & 3) * PL + (t1 / 3) * A1 + t1 % 3], d1);
       }
       f32x4 v;
+      unsigned am = 0;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) v[r] = quad_max(d0[r] + d1[r]) + bias2[r] - bgv[r];
+      for (int r = 0; r < 4; ++r) {
+        const float pre = d0[r] + d1[r], mx = quad_max(pre);
+        v[r] = mx + bias2[r] - bgv[r];
+        if (SAVE) am |= (unsigned)quad_min(pre == mx ? (j & 3) : 4) << (8 * r);
+      }
       const int cell = 4 * nb + (j >> 2);
-      if ((j & 3) == 0 && cell < NCELL) *reinterpret_cast<f32x4*>(prow + cell * NCH) = v;
+      if ((j & 3) == 0 && cell < NCELL) {
+        *reinterpret_cast<f32x4*>(prow + cell * NCH) = v;
+        if (SAVE) *reinterpret_cast<unsigned*>(a.arg + item * KD + cell * NCH + 4 * q) = am;
+      }
     }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Backward of the crop network w.r.t. W1, b1, W2 (b2 and the background terms are closed forms, see sparse_finish_k).
+// One wavefront (= one workgroup) per masked copy.  LDS: the crop e (row stride 16) followed by a constant-1 image of
+// the same shape, conv1 activations / their cotangent [16][12 rows x stride 14] (plane 172 == 44 mod 64: the 16 lanes
+// of an operand read sit 4 banks apart), the conv2 cotangent with a 2-wide zero border [16][14][14] (plane 196 == 4).
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int A1S = 14, BPL = 172, DPL = 196, ONES = ESZ, EB = 2 * ESZ;
+constexpr int BLDS = EB + NCH * BPL + NCH * DPL;            // 6336 floats = 25 KB per wavefront: 6 per CU
+constexpr int PROW = NCH * NCH * 9 + NCH * 9 + NCH;         // partial row: dW2 | dW1 | db1
+constexpr int BWD_GRID = 256 * 6;
+
+struct SparseBwdArgs {
+  const float* x; const float* P; const int32_t* pix;
+  const float* W1; const float* b1; const float* W2;
+  const float* dpd; const unsigned char* arg;
+  float* part; int64_t B, items;
+};
+
+__global__ __launch_bounds__(64) void sparse_crop_bwd_k(SparseBwdArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int lane = threadIdx.x, q = lane >> 4, j = lane & 15;
+  float* e_s = smem;
+  float* a1_s = smem + EB;
+  float* dy_s = a1_s + NCH * BPL;
+  for (int i = lane; i < ESZ; i += 64) e_s[ONES + i] = 1.f;
+  for (int i = lane; i < NCH * DPL; i += 64) dy_s[i] = 0.f;           // the border stays zero: only the interior is rewritten
+
+  float wa1[3], wf[36];
+#pragma unroll
+  for (int s = 0; s < 3; ++s) {
+    const int tap = 4 * s + q;
+    wa1[s] = tap < 9 ? a.W1[j * 9 + tap] : 0.f;
+  }
+#pragma unroll
+  for (int s = 0; s < 36; ++s) wf[s] = a.W2[((4 * (s & 3) + q) * NCH + j) * 9 + (s >> 2)];   // A[c_in = j][(tap, c_out)]
+  f32x4 bias1;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) bias1[r] = a.b1[4 * q + r];
+
+  int eo[9][3], pao[9];           // conv1 position 16 nb + j: crop offsets per K step, offset in the stride-14 planes
+#pragma unroll
+  for (int nb = 0; nb < 9; ++nb) {
+    const int p = 16 * nb + j, y = p / A1, x = p - A1 * y;
+    pao[nb] = y * A1S + x;
+#pragma unroll
+    for (int s = 0; s < 3; ++s) {
+      const int tap = 4 * s + q, ty = tap < 9 ? tap / 3 : 0, tx = tap < 9 ? tap - 3 * ty : 0;
+      eo[nb][s] = (y + ty) * ES + x + tx;
+    }
+  }
+  int pixo[25];                   // conv2 position 4 s + q of the 10x10 region, in the stride-14 planes
+#pragma unroll
+  for (int s = 0; s < 25; ++s) {
+    const int pix = 4 * s + q, y = pix / 10, x = pix - 10 * y;
+    pixo[s] = y * A1S + x;
+  }
+  int dyo[7];                     // cotangent scatter: pair (cell, channel) = lane + 64 t, top-left of the cell's 2x2
+#pragma unroll
+  for (int t = 0; t < 7; ++t) {
+    const int idx = lane + 64 * t, cell = idx >> 4, c = idx & 15, cy = cell / 5, cx = cell - 5 * cy;
+    dyo[t] = idx < KD ? c * DPL + (2 * cy + 2) * A1S + 2 * cx + 2 : -1;
+  }
+  const int eb = j < 9 ? (j / 3) * ES + j % 3 + q : (j == 9 ? ONES + q : q);   // dW1 B operand: tap j | ones (db1) | unused
+  int ce[4], cl[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const int idx = lane + 64 * t, ey = idx / CROP, ex = idx - CROP * ey;
+    ce[t] = ey * IMG + ex;
+    cl[t] = idx < CROP * CROP ? ey * ES + ex : -1;
+  }
+
+  f32x4 acc2[9], acc1a = {0.f, 0.f, 0.f, 0.f}, acc1b = acc1a;
+#pragma unroll
+  for (int t = 0; t < 9; ++t) acc2[t] = acc1a;
+
+  float xv[4], pv[4], gv[7];
+  int av[7];
+  auto fetch = [&](int64_t item) {
+    const int64_t r = item / a.B, b = item - r * a.B;
+    const int pix = a.pix[r];
+    const int corner = 2 * crop_origin(pix / IMG) * IMG + 2 * crop_origin(pix % IMG);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const bool ok = cl[t] >= 0;
+      xv[t] = ok ? a.x[b * NPIX + corner + ce[t]] : 0.f;
+      pv[t] = ok ? a.P[(int64_t)pix * NPIX + corner + ce[t]] : 0.f;
+    }
+#pragma unroll
+    for (int t = 0; t < 7; ++t) {
+      const bool ok = dyo[t] >= 0;
+      gv[t] = ok ? a.dpd[item * KD + lane + 64 * t] : 0.f;
+      av[t] = ok ? (int)a.arg[item * KD + lane + 64 * t] : 0;
+    }
+  };
+
+  int64_t item = blockIdx.x;
+  if (item < a.items) fetch(item);
+  for (; item < a.items; item += gridDim.x) {
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+      if (cl[t] >= 0) e_s[cl[t]] = xv[t] * pv[t];
+#pragma unroll
+    for (int t = 0; t < 7; ++t)
+      if (dyo[t] >= 0) {
+        f32x2 r0, r1;
+        r0.x = av[t] == 0 ? gv[t] : 0.f; r0.y = av[t] == 1 ? gv[t] : 0.f;
+        r1.x = av[t] == 2 ? gv[t] : 0.f; r1.y = av[t] == 3 ? gv[t] : 0.f;
+        *reinterpret_cast<f32x2*>(dy_s + dyo[t]) = r0;
+        *reinterpret_cast<f32x2*>(dy_s + dyo[t] + A1S) = r1;
+      }
+    if (item + gridDim.x < a.items) fetch(item + gridDim.x);
+
+    // ---- conv1 + ReLU (recomputed) -> a1_s
+#pragma unroll
+    for (int nb = 0; nb < 9; ++nb) {
+      f32x4 d = bias1;
+#pragma unroll
+      for (int s = 0; s < 3; ++s) d = mfma(wa1[s], e_s[eo[nb][s]], d);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) a1_s[(4 * q + r) * BPL + pao[nb]] = fmaxf(d[r], 0.f);
+    }
+    // ---- dW2[c_out][c_in][tap] += sum_pos dY2[c_out][pos] a1[c_in][pos + tap]: 9 independent chains
+    {
+      const float* ap = dy_s + j * DPL + 2 * A1S + 2;
+      const float* bp = a1_s + j * BPL;
+#pragma unroll
+      for (int s = 0; s < 25; ++s) {
+        const float av2 = ap[pixo[s]];
+        const float* b0 = bp + pixo[s];
+#pragma unroll
+        for (int t = 0; t < 9; ++t) acc2[t] = mfma(av2, b0[(t / 3) * A1S + t % 3], acc2[t]);
+      }
+    }
+    // ---- d a1[c_in][pos] = sum_{c_out,tap} W2[c_out][c_in][tap] dY2[c_out][pos - tap], gated by a1 > 0, in place
+#pragma unroll
+    for (int nb = 0; nb < 9; ++nb) {
+      f32x4 d0 = {0.f, 0.f, 0.f, 0.f}, d1 = d0;
+      const float* bp = dy_s + q * DPL + pao[nb] + 2 * A1S + 2;
+#pragma unroll
+      for (int s = 0; s < 36; s += 2) {
+        const int t0 = s >> 2, t1 = (s + 1) >> 2;
+        d0 = mfma(wf[s], bp[4 * (s & 3) * DPL - (t0 / 3) * A1S - t0 % 3], d0);
+        d1 = mfma(wf[s + 1], bp[4 * ((s + 1) & 3) * DPL - (t1 / 3) * A1S - t1 % 3], d1);
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float* g = a1_s + (4 * q + r) * BPL + pao[nb];
+        *g = *g > 0.f ? d0[r] + d1[r] : 0.f;
+      }
+    }
+    // ---- dW1[c][tap] += sum_pos da1[c][pos] e[pos + tap];  db1[c] += sum_pos da1[c][pos]  (column 9: constant 1)
+    {
+      const float* ap = a1_s + j * BPL + q;
+      const float* bp = e_s + eb;
+#pragma unroll
+      for (int s = 0; s < 36; s += 2) {
+        acc1a = mfma(ap[(s / 3) * A1S + 4 * (s % 3)], bp[(s / 3) * ES + 4 * (s % 3)], acc1a);
+        acc1b = mfma(ap[((s + 1) / 3) * A1S + 4 * ((s + 1) % 3)], bp[((s + 1) / 3) * ES + 4 * ((s + 1) % 3)], acc1b);
+      }
+    }
+  }
+
+  float* prow = a.part + (int64_t)blockIdx.x * PROW;
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) prow[((4 * q + r) * NCH + j) * 9 + t] = acc2[t][r];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const float v = acc1a[r] + acc1b[r];
+    if (j < 9) prow[NCH * NCH * 9 + (4 * q + r) * 9 + j] = v;
+    else if (j == 9) prow[NCH * NCH * 9 + NCH * 9 + 4 * q + r] = v;
+  }
+}
+
+// gWfc1[n][c*144 + py*12 + px] = bg[c] S[n] + sum over the <= 25 crop origins whose 5x5 block holds cell (py, px)
+__global__ void sparse_scatter_fc1_k(const float* __restrict__ dWg, const float* __restrict__ S,
+                                     const float* __restrict__ bg, int F, float* __restrict__ gW) {
+  const int64_t total = (int64_t)F * NCH * 144;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+    const int n = (int)(idx % F), col = (int)(idx / F);
+    const int c = col / 144, pos = col - 144 * c, py = pos / 12, px = pos - 12 * py;
+    float s = bg[c] * S[n];
+    for (int r0 = max(0, py - 4); r0 <= min(7, py); ++r0)
+      for (int c0 = max(0, px - 4); c0 <= min(7, px); ++c0)
+        s += dWg[((int64_t)(r0 * 8 + c0) * KD + ((py - r0) * 5 + px - c0) * NCH + c) * F + n];
+    gW[(int64_t)n * (NCH * 144) + col] = s;
+  }
+}
+
+// One workgroup.  With S = column sums of g (= d bfc1), T[c] = sum over copies and cells of d pd[.., c] and
+// Wsum[n][c] = sum_pos Wfc1[n][c*144+pos]:   d b2 = S . Wsum,   d bg = d b2 - T,  and through
+// bg[c] = b2[c] + sum_{c',tap} W2[c][c'][tap] relu(b1[c']):   dW2 += d bg (x) relu(b1),   d b1 += [b1 > 0] W2^T d bg.
+__global__ __launch_bounds__(1024) void sparse_finish_k(const float* __restrict__ red, const float* __restrict__ S,
+                                                        const float* __restrict__ T, const float* __restrict__ Wfc1,
+                                                        const float* __restrict__ b1, const float* __restrict__ W2, int F,
+                                                        float* __restrict__ gW1, float* __restrict__ gb1,
+                                                        float* __restrict__ gW2, float* __restrict__ gb2) {
+  __shared__ float wsum[16][NCH + 1];
+  __shared__ float dbg[NCH];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  float acc[NCH];
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) acc[c] = 0.f;
+  for (int idx = tid; idx < F * 144; idx += 1024) {
+    const int n = idx / 144, pos = idx - 144 * n;
+    const float sn = S[n];
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) acc[c] = fmaf(sn, Wfc1[(int64_t)n * (NCH * 144) + c * 144 + pos], acc[c]);
+  }
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) {
+    const float v = group_sum<64>(acc[c]);
+    if (lane == 0) wsum[wave][c] = v;
+  }
+  __syncthreads();
+  if (tid < NCH) {
+    float v = 0.f, t = 0.f;
+    for (int w = 0; w < 16; ++w) v += wsum[w][tid];
+    for (int cell = 0; cell < NCELL; ++cell) t += T[cell * NCH + tid];
+    gb2[tid] = v;
+    dbg[tid] = v - t;
+  }
+  __syncthreads();
+  for (int i = tid; i < NCH * NCH * 9; i += 1024) {
+    const int c = i / 144, ci = (i / 9) % NCH;
+    gW2[i] = red[i] + dbg[c] * fmaxf(b1[ci], 0.f);
+  }
+  if (tid < NCH * 9) gW1[tid] = red[NCH * NCH * 9 + tid];
+  if (tid < NCH) {
+    float v = 0.f;
+    if (b1[tid] > 0.f)
+      for (int c = 0; c < NCH; ++c)
+        for (int t = 0; t < 9; ++t) v = fmaf(dbg[c], W2[(c * NCH + tid) * 9 + t], v);
+    gb1[tid] = red[NCH * NCH * 9 + NCH * 9 + tid] + v;
   }
 }
 
@@ -208,8 +471,10 @@ int gnf_mnistcnn_sparse_fwd(const float* x, int64_t B, const float* P, const int
                             const int32_t* groups, int64_t max_group_rows,
                             const float* W1, const float* b1, const float* W2, const float* b2,
                             const float* Wfc1, const float* bfc1, int64_t F,
-                            float* h1, void* ws, int64_t ws_bytes, gnf_stream_t stream) {
-  if (!x || !P || !pix || !groups || !W1 || !b1 || !W2 || !b2 || !Wfc1 || !bfc1 || !h1 || B < 0 || R < 0 || F <= 0)
+                            float* h1, float* pd_save, unsigned char* argmax_save,
+                            void* ws, int64_t ws_bytes, gnf_stream_t stream) {
+  if (!x || !P || !pix || !groups || !W1 || !b1 || !W2 || !b2 || !Wfc1 || !bfc1 || !h1 || B < 0 || R < 0 || F <= 0 ||
+      (pd_save == nullptr) != (argmax_save == nullptr))
     return GNF_EINVAL;
   if (F % 4 || F > 65535 * 64) return GNF_ESHAPE;
   const int64_t items = R * B;
@@ -217,8 +482,8 @@ int gnf_mnistcnn_sparse_fwd(const float* x, int64_t B, const float* P, const int
   if (!ws || ws_bytes < gnf_mnistcnn_sparse_ws_bytes(items, F) || max_group_rows <= 0 || max_group_rows > items)
     return GNF_EINVAL;
   hipStream_t s = (hipStream_t)stream;
-  float* pd = (float*)ws;                       // [items][400]
-  float* Wg = pd + items * KD;                  // [64][400][F]
+  float* pd = pd_save ? pd_save : (float*)ws;   // [items][400]
+  float* Wg = (float*)ws + items * KD;          // [64][400][F]
   float* bg = Wg + (int64_t)NORIG * KD * F;     // [16]
   float* hbg = bg + NCH;                        // [F]
 
@@ -227,11 +492,12 @@ int gnf_mnistcnn_sparse_fwd(const float* x, int64_t B, const float* P, const int
   hipLaunchKernelGGL(sparse_gather_fc1_k, dim3(2048), dim3(256), 0, s, Wfc1, (int)F, Wg);
   GNF_LAUNCH_CHECK();
 
-  SparseArgs a{x, P, pix, W1, b1, W2, b2, bg, pd, B, items};
+  SparseArgs a{x, P, pix, W1, b1, W2, b2, bg, pd, argmax_save, B, items};
   constexpr size_t lds = (size_t)WAVES * WLDS * sizeof(float);
   int64_t grid = (items + WAVES - 1) / WAVES;
   if (grid > 256 * 3) grid = 256 * 3;
-  hipLaunchKernelGGL(sparse_crop_k, dim3((unsigned)grid), dim3(64 * WAVES), lds, s, a);
+  if (argmax_save) hipLaunchKernelGGL(sparse_crop_k<true>, dim3((unsigned)grid), dim3(64 * WAVES), lds, s, a);
+  else hipLaunchKernelGGL(sparse_crop_k<false>, dim3((unsigned)grid), dim3(64 * WAVES), lds, s, a);
   GNF_LAUNCH_CHECK();
 
   GemmArgs g{};
@@ -242,6 +508,85 @@ int gnf_mnistcnn_sparse_fwd(const float* x, int64_t B, const float* P, const int
   g.M = max_group_rows; g.N = F; g.K = KD;
   g.grp = groups;
   return gnf_gemm_grouped_launch(g, NORIG, s);
+}
+
+static int64_t bwd_rows_n(int64_t F) {                 // widest row the two-level column sums see
+  int64_t n = PROW;
+  if (F > n) n = F;
+  return n;
+}
+
+int64_t gnf_mnistcnn_sparse_bwd_ws_bytes(int64_t n_rows, int64_t F) {
+  if (n_rows < 0 || F < 0) return 0;
+  return (n_rows * KD + 2 * (int64_t)NORIG * KD * F + NCH + KD + (int64_t)BWD_GRID * PROW + PROW +
+          (int64_t)kRowsumChunks * bwd_rows_n(F) + 64) * (int64_t)sizeof(float);
+}
+
+int gnf_mnistcnn_sparse_bwd(const float* x, int64_t B, const float* P, const int32_t* pix, int64_t R,
+                            const int32_t* groups, int64_t max_group_rows,
+                            const float* W1, const float* b1, const float* W2, const float* b2,
+                            const float* Wfc1, int64_t F,
+                            const float* pd, const unsigned char* argmax, const float* g_h1,
+                            float* gW1, float* gb1, float* gW2, float* gb2, float* gWfc1, float* gbfc1,
+                            void* ws, int64_t ws_bytes, gnf_stream_t stream) {
+  if (!x || !P || !pix || !groups || !W1 || !b1 || !W2 || !b2 || !Wfc1 || !pd || !argmax || !g_h1 || !gW1 || !gb1 ||
+      !gW2 || !gb2 || !gWfc1 || !gbfc1 || B < 0 || R < 0 || F <= 0)
+    return GNF_EINVAL;
+  if (F % 4 || F > 65535 * 64) return GNF_ESHAPE;
+  const int64_t items = R * B;
+  hipStream_t s = (hipStream_t)stream;
+  if (items == 0) {
+    (void)hipMemsetAsync(gW1, 0, NCH * 9 * sizeof(float), s); (void)hipMemsetAsync(gb1, 0, NCH * sizeof(float), s);
+    (void)hipMemsetAsync(gW2, 0, NCH * NCH * 9 * sizeof(float), s); (void)hipMemsetAsync(gb2, 0, NCH * sizeof(float), s);
+    (void)hipMemsetAsync(gWfc1, 0, F * NCH * 144 * sizeof(float), s); (void)hipMemsetAsync(gbfc1, 0, F * sizeof(float), s);
+    return 0;
+  }
+  if (!ws || ws_bytes < gnf_mnistcnn_sparse_bwd_ws_bytes(items, F) || max_group_rows <= 0 || max_group_rows > items)
+    return GNF_EINVAL;
+  float* dpd = (float*)ws;                              // [items][400]
+  float* Wg = dpd + items * KD;                         // [64][400][F]
+  float* dWg = Wg + (int64_t)NORIG * KD * F;            // [64][400][F]
+  float* bg = dWg + (int64_t)NORIG * KD * F;            // [16]
+  float* T = bg + NCH;                                  // [400]
+  float* part = T + KD;                                 // [BWD_GRID][PROW]
+  float* red = part + (int64_t)BWD_GRID * PROW;         // [PROW]
+  float* rws = red + PROW;                              // two-level column-sum scratch
+  int rc;
+
+  hipLaunchKernelGGL(sparse_bg_k, dim3(1), dim3(64), 0, s, b1, W2, b2, (const float*)nullptr, (const float*)nullptr, (int)F,
+                     bg, (float*)nullptr);
+  GNF_LAUNCH_CHECK();
+  hipLaunchKernelGGL(sparse_gather_fc1_k, dim3(2048), dim3(256), 0, s, Wfc1, (int)F, Wg);
+  GNF_LAUNCH_CHECK();
+  if ((rc = gnf_rowsum_tall_launch(g_h1, gbfc1, items, F, 0, rws, s))) return rc;           // S = d bfc1
+
+  GemmArgs g{};                                         // d pd = g . Wg[origin]^T
+  g.A = g_h1; g.sam = F; g.sak = 1;
+  g.B = Wg; g.sbk = 1; g.sbn = F; g.b_grp_stride = (int64_t)KD * F;
+  g.C = dpd; g.scm = KD; g.scn = 1;
+  g.M = max_group_rows; g.N = KD; g.K = F;
+  g.grp = groups;
+  if ((rc = gnf_gemm_grouped_launch(g, NORIG, s))) return rc;
+  if ((rc = gnf_rowsum_tall_launch(dpd, T, items, KD, 0, rws, s))) return rc;
+
+  GemmArgs w{};                                         // dWg[origin] = pd[rows of origin]^T . g[rows of origin]
+  w.A = pd; w.sam = 1; w.sak = KD;
+  w.B = g_h1; w.sbk = F; w.sbn = 1;
+  w.C = dWg; w.scm = F; w.scn = 1; w.c_split_stride = (int64_t)KD * F;
+  w.M = KD; w.N = F; w.K = items;
+  w.grp = groups; w.grp_k = 1;
+  if ((rc = gnf_gemm_grouped_launch(w, NORIG, s))) return rc;
+  hipLaunchKernelGGL(sparse_scatter_fc1_k, dim3(2048), dim3(256), 0, s, dWg, gbfc1, bg, (int)F, gWfc1);
+  GNF_LAUNCH_CHECK();
+
+  SparseBwdArgs a{x, P, pix, W1, b1, W2, dpd, argmax, part, B, items};
+  const int64_t grid = items < BWD_GRID ? items : BWD_GRID;
+  hipLaunchKernelGGL(sparse_crop_bwd_k, dim3((unsigned)grid), dim3(64), BLDS * sizeof(float), s, a);
+  GNF_LAUNCH_CHECK();
+  if ((rc = gnf_rowsum_launch(part, red, grid, PROW, 0, s))) return rc;
+  hipLaunchKernelGGL(sparse_finish_k, dim3(1), dim3(1024), 0, s, red, gbfc1, T, Wfc1, b1, W2, (int)F, gW1, gb1, gW2, gb2);
+  GNF_LAUNCH_CHECK();
+  return 0;
 }
 
 }  // extern "C"

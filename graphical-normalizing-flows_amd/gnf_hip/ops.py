@@ -264,19 +264,50 @@ class SparseRows:
         self.max_group_rows = max(max(counts) * B, 1)
 
 
+class MnistSparseFn(torch.autograd.Function):
+    """relu(fc1(flatten(maxpool(conv2(relu(conv1(x * P[i]))))))) for the masked copies i of a SparseRows, P zero outside
+    the 5x5 pixel windows: [R*B, F] in the SparseRows' sorted order (row = position * B + sample).  Differentiable w.r.t.
+    the six network parameters only (x and P are treated as constants: frozen deterministic gate)."""
+
+    @staticmethod
+    def forward(ctx, x, P, sr, W1, b1, W2, b2, Wfc1, bfc1):
+        x, P = x.contiguous(), P.contiguous()
+        ws_ = [t.contiguous() for t in (W1, b1, W2, b2, Wfc1, bfc1)]
+        F = Wfc1.shape[0]
+        n = sr.R * sr.B
+        h1 = _empty((n, F), x)
+        train = any(ctx.needs_input_grad[3:])
+        pd = _empty((n, 400), x) if train else None
+        arg = torch.empty((n, 400), dtype=torch.uint8, device=x.device) if train else None
+        nws = abi.load().gnf_mnistcnn_sparse_ws_bytes(n, F)
+        ws = _ws(nws, x)
+        call("gnf_mnistcnn_sparse_fwd", ptr(x), sr.B, ptr(P), abi.rawptr(sr.pix), sr.R, abi.rawptr(sr.groups),
+             sr.max_group_rows, *[ptr(t) for t in ws_], F, ptr(h1), ptr(pd), abi.rawptr(arg) if train else None,
+             abi.rawptr(ws), nws, stream())
+        if train:
+            ctx.save_for_backward(x, P, *ws_[:5], pd, arg, h1)
+            ctx.sr = sr
+        return h1
+
+    @staticmethod
+    def backward(ctx, gh1):
+        x, P, W1, b1, W2, b2, Wfc1, pd, arg, h1 = ctx.saved_tensors
+        sr = ctx.sr
+        F = Wfc1.shape[0]
+        n = sr.R * sr.B
+        g = (gh1 * (h1 > 0)).contiguous()
+        gW1, gb1, gW2, gb2 = torch.empty_like(W1), torch.empty_like(b1), torch.empty_like(W2), torch.empty_like(b2)
+        gWf, gbf = torch.empty_like(Wfc1), _empty((F,), x)
+        nws = abi.load().gnf_mnistcnn_sparse_bwd_ws_bytes(n, F)
+        ws = _ws(nws, x)
+        call("gnf_mnistcnn_sparse_bwd", ptr(x), sr.B, ptr(P), abi.rawptr(sr.pix), sr.R, abi.rawptr(sr.groups),
+             sr.max_group_rows, ptr(W1), ptr(b1), ptr(W2), ptr(b2), ptr(Wfc1), F, ptr(pd), abi.rawptr(arg), ptr(g),
+             ptr(gW1), ptr(gb1), ptr(gW2), ptr(gb2), ptr(gWf), ptr(gbf), abi.rawptr(ws), nws, stream())
+        return None, None, None, gW1, gb1, gW2, gb2, gWf, gbf
+
+
 def mnistcnn_sparse_fwd(x, P, sr, W1, b1, W2, b2, Wfc1, bfc1):
-    """relu(fc1(flatten(maxpool(conv2(relu(conv1(x * P[i]))))))) for the masked copies i in `sr` (a SparseRows), P
-    zero outside the 5x5 windows: [R*B, F] in sr's sorted order (row = position * B + sample).  Forward only."""
-    x, P = x.contiguous(), P.contiguous()
-    F = Wfc1.shape[0]
-    n = sr.R * sr.B
-    h1 = _empty((n, F), x)
-    nws = abi.load().gnf_mnistcnn_sparse_ws_bytes(n, F)
-    ws = _ws(nws, x)
-    call("gnf_mnistcnn_sparse_fwd", ptr(x), sr.B, ptr(P), abi.rawptr(sr.pix), sr.R, abi.rawptr(sr.groups),
-         sr.max_group_rows, ptr(W1.contiguous()), ptr(b1.contiguous()), ptr(W2.contiguous()), ptr(b2.contiguous()),
-         ptr(Wfc1.contiguous()), ptr(bfc1.contiguous()), F, ptr(h1), abi.rawptr(ws), nws, stream())
-    return h1
+    return MnistSparseFn.apply(x, P, sr, W1, b1, W2, b2, Wfc1, bfc1)
 
 
 # ----------------------------------------------------------------------------- DAG gate

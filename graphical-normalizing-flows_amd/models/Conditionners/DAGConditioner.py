@@ -79,7 +79,7 @@ class DAGConditioner(Conditioner):
         self.nb_epoch_update = nb_epoch_update
         self.no_update = 0
         self.is_invertible = False
-        self.sparse_front = True        # deterministic gate + windowed A + no autograd: sparse embedding front
+        self.sparse_front = True        # deterministic gate + windowed, frozen A: sparse embedding front
         self._sparse_outside = None     # 1 outside the 5x5 pixel windows (device mask, built on first use)
         self._sparse_plans = {}
         self.gate_noise = None          # (u1, u2) [B,d,d] uniforms (test hook); None -> Philox
@@ -130,16 +130,15 @@ class DAGConditioner(Conditioner):
 
     def _sparse_plan(self, x, rows, P):
         """gnf_hip.ops.SparseRows when the sparse masked-image front applies -- an MNISTCNN embedding net on the GPU, no
-        gradient wanted, and every row of P zero outside its pixel's 5x5 window --
+        gradient wanted for x or A (frozen gate), and every row of P zero outside its pixel's 5x5 window --
         else None.  rows: iterable of variable indices, None = all."""
         net = self.embedding_net
         if not self.sparse_front or self.hot_encoding or self.cond_in or not hasattr(net, "sparse_rows"):
             return None
         if not net.supports_sparse(x):
             return None
-        if torch.is_grad_enabled() and (x.requires_grad or P.requires_grad
-                                        or any(p.requires_grad for p in net.parameters())):
-            return None
+        if torch.is_grad_enabled() and (x.requires_grad or P.requires_grad):
+            return None                  # the sparse kernels differentiate w.r.t. the network parameters only
         # checked on every call (one small reduction + a host read): A can be edited in ways no version counter sees
         if self._sparse_outside is None or self._sparse_outside.device != P.device:
             self._sparse_outside = (~ops.mnist_window_mask(P.device)).float()

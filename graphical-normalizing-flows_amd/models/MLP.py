@@ -69,7 +69,8 @@ class MNISTCNN(nn.Module):
     def sparse_rows(self, x, P, sr):
         """Embeddings [B, R, out_d] of the masked copies x * P[i], i in the gnf_hip.ops.SparseRows `sr` (returned in the
         caller's order), for an importance matrix P that is zero outside the 5x5 pixel windows: only the 14x14 crop
-        that can differ from the all-zero image is convolved.  No autograd graph is recorded."""
+        that can differ from the all-zero image is convolved.  Differentiable w.r.t. the network's
+        parameters (not x, not P)."""
         h1 = ops.mnistcnn_sparse_fwd(x.view(-1, 784), P, sr, self.conv1.weight, self.conv1.bias, self.conv2.weight,
                                      self.conv2.bias, self.fc1.weight, self.fc1.bias)
         out = ops.mlp(h1, [(self.fc2.weight, self.fc2.bias)])

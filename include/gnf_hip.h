@@ -174,20 +174,34 @@ int gnf_mnistcnn_conv_bwd(const float* e, const float* W1, const float* b1, cons
  * -> conv1/ReLU/conv2/maxpool (MLP.py:36-41) -> fc1 + ReLU (MLP.py:43-44)  when every row i of the importance matrix
  * P [784,784] is zero outside the 5x5 window around pixel i (MNIST_A_prior with kernel 2,
  * NormalizingFlowFactories.py:35-46): only the 14x14 crop around the window is convolved and fc1 contracts the
- * 5x5x16 pooled block that can differ from the constant background (exact, not an approximation; forward only).
+ * 5x5x16 pooled block that can differ from the constant background (exact, not an approximation).
  *   x [B,784];  pix [R] (device): the masked copies (pixel indices i) to evaluate, SORTED by crop origin
  *   g(i) = 8*o(i/28) + o(i%28), o(p) = clamp(floor((p-6)/2), 0, 7);
  *   groups [2*64] (device): for each origin g the first output row and the number of output rows (= B * number of
  *   pix entries with that origin);  max_group_rows: the largest of those counts (host value, sizes the grid);
  *   W1 [16,1,3,3], b1, W2 [16,16,3,3], b2: conv parameters;  Wfc1 [F,2304], bfc1 [F]  (F % 4 == 0);
- *   h1 [R*B, F] (out): relu(fc1(...)) of masked copy pix[r] of sample b at row r*B + b.
+ *   h1 [R*B, F] (out): relu(fc1(...)) of masked copy pix[r] of sample b at row r*B + b;
+ *   pd_save [R*B, 400], argmax_save [R*B, 400] bytes (both or neither; NULL for inference): what the backward
+ *   needs -- the pooled block minus the background in [cell][channel] order and the max-pool winners.
  * ws: >= gnf_mnistcnn_sparse_ws_bytes(R*B, F) bytes. */
 int64_t gnf_mnistcnn_sparse_ws_bytes(int64_t n_rows, int64_t F);
 int gnf_mnistcnn_sparse_fwd(const float* x, int64_t B, const float* P, const int32_t* pix, int64_t R,
                             const int32_t* groups, int64_t max_group_rows,
                             const float* W1, const float* b1, const float* W2, const float* b2,
                             const float* Wfc1, const float* bfc1, int64_t F,
-                            float* h1, void* ws, int64_t ws_bytes, gnf_stream_t stream);
+                            float* h1, float* pd_save, unsigned char* argmax_save,
+                            void* ws, int64_t ws_bytes, gnf_stream_t stream);
+/* Backward w.r.t. the network parameters (training with a frozen deterministic gate: P and x get no gradient).
+ * g_h1 [R*B, F]: cotangent of h1 with the ReLU already applied (zero where h1 == 0).  Gradients are written, not
+ * accumulated: gW1 [16,1,3,3], gb1 [16], gW2 [16,16,3,3], gb2 [16], gWfc1 [F,2304], gbfc1 [F]. */
+int64_t gnf_mnistcnn_sparse_bwd_ws_bytes(int64_t n_rows, int64_t F);
+int gnf_mnistcnn_sparse_bwd(const float* x, int64_t B, const float* P, const int32_t* pix, int64_t R,
+                            const int32_t* groups, int64_t max_group_rows,
+                            const float* W1, const float* b1, const float* W2, const float* b2,
+                            const float* Wfc1, int64_t F,
+                            const float* pd, const unsigned char* argmax, const float* g_h1,
+                            float* gW1, float* gb1, float* gW2, float* gb2, float* gWfc1, float* gbfc1,
+                            void* ws, int64_t ws_bytes, gnf_stream_t stream);
 
 /* ---- Adam on one flat fp32 buffer (torch.optim.Adam semantics, L2 weight decay) --------
  * ImageExperiments.py:173 / UCIExperiments.py:97; used by the data-parallel harness after

@@ -831,15 +831,43 @@ def test_sparse_front_row_subsets_and_fallbacks():
         assert cond._sparse_plan(x, None, cond.deterministic_importance()) is None
         cond.A.data[0, 300] = 0.
         assert cond._sparse_plan(x, None, cond.deterministic_importance()) is not None
-    # gradients wanted -> dense path with an autograd graph
-    for p in cond.embedding_net.parameters():
-        assert p.requires_grad
+    # a gradient wanted for x (or for A) -> dense path
+    assert cond._sparse_plan(x.clone().requires_grad_(True), None, cond.deterministic_importance()) is None
+    cond.A.requires_grad = True
     assert cond._sparse_plan(x, None, cond.deterministic_importance()) is None
-    h = cond(x)
-    assert h.requires_grad
+    cond.A.requires_grad = False
     # stochastic gate -> never sparse
     cond.stoch_gate, cond.s_thresh = True, True
     assert cond.deterministic_importance() is None
+
+
+@pytest.mark.parametrize("B", [2, 7])
+def test_sparse_front_parameter_gradients(B):
+    """training with a frozen deterministic gate: parameter gradients of the sparse pair == CPU oracle autograd on the
+    explicit masked copies == the dense HIP kernels"""
+    cond = _windowed_conditioner(7 + B, True)
+    net = cond.embedding_net
+    x = torch.rand(B, 784)
+    gh = torch.randn(B, 784, 30)
+    assert cond._sparse_plan(cu(x), None, cond.deterministic_importance()) is not None
+    h = cond(cu(x))
+    assert h.requires_grad
+    (h * cu(gh)).sum().backward()
+    got = {k: p.grad.clone() for k, p in net.named_parameters()}
+    for p in net.parameters():
+        p.grad = None
+    cond.sparse_front = False
+    (cond(cu(x)) * cu(gh)).sum().backward()
+    dense = {k: p.grad.clone() for k, p in net.named_parameters()}
+    # CPU oracle
+    params = {k: v.detach().cpu().clone().requires_grad_(True) for k, v in net.named_parameters()}
+    e = (x.unsqueeze(1) * cond.A.detach().cpu().unsqueeze(0)).reshape(B * 784, 784)
+    (O.mnistcnn_forward(e, params).view(B, 784, 30) * gh).sum().backward()
+    for k in got:
+        assert rel_err(got[k].cpu(), params[k].grad) < GTOL, (k, rel_err(got[k].cpu(), params[k].grad))
+        # the dense Winograd kernels break the exact max-pool ties of the constant background by rounding noise instead
+        # of torch's first-maximum rule (a different, equally valid subgradient): conv gradients agree to ~1e-3 only
+        assert rel_err(dense[k].cpu(), params[k].grad) < (5e-3 if k.startswith("conv") else GTOL), k
 
 
 def test_sparse_front_abi_validation():
@@ -847,16 +875,27 @@ def test_sparse_front_abi_validation():
     from gnf_hip import abi
     lib = abi.load()
     assert lib.gnf_mnistcnn_sparse_ws_bytes(10, 128) == (10 * 400 + 64 * 400 * 128 + 16 + 128 + 64) * 4
-    assert lib.gnf_mnistcnn_sparse_fwd(None, 1, None, None, 1, None, 1, None, None, None, None, None, None, 128, None,
-                                       None, 0, None) == -1
-    t = torch.zeros(64 * 400 * 6 + 4096, device=DEV)
+    assert lib.gnf_mnistcnn_sparse_bwd_ws_bytes(10, 128) > lib.gnf_mnistcnn_sparse_ws_bytes(10, 128)
+    N = None
+    assert lib.gnf_mnistcnn_sparse_fwd(N, 1, N, N, 1, N, 1, N, N, N, N, N, N, 128, N, N, N, N, 0, N) == -1
+    t = torch.zeros(64 * 400 * 8 * 2 + (1 << 22), device=DEV)
     i32 = torch.zeros(128, dtype=torch.int32, device=DEV)
     p, ip = ctypes.c_void_p(t.data_ptr()), ctypes.c_void_p(i32.data_ptr())
+    nb = t.numel() * 4
     # F not a multiple of 4 -> shape error; zero rows -> no-op success
-    assert lib.gnf_mnistcnn_sparse_fwd(p, 1, p, ip, 1, ip, 1, p, p, p, p, p, p, 6, p, p, t.numel() * 4, None) == -2
-    assert lib.gnf_mnistcnn_sparse_fwd(p, 0, p, ip, 1, ip, 1, p, p, p, p, p, p, 8, p, p, 0, None) == 0
-    # workspace too small
-    assert lib.gnf_mnistcnn_sparse_fwd(p, 1, p, ip, 1, ip, 1, p, p, p, p, p, p, 8, p, p, 16, None) == -1
+    assert lib.gnf_mnistcnn_sparse_fwd(p, 1, p, ip, 1, ip, 1, p, p, p, p, p, p, 6, p, N, N, p, nb, N) == -2
+    assert lib.gnf_mnistcnn_sparse_fwd(p, 0, p, ip, 1, ip, 1, p, p, p, p, p, p, 8, p, N, N, p, 0, N) == 0
+    # workspace too small; pd_save without argmax_save
+    assert lib.gnf_mnistcnn_sparse_fwd(p, 1, p, ip, 1, ip, 1, p, p, p, p, p, p, 8, p, N, N, p, 16, N) == -1
+    assert lib.gnf_mnistcnn_sparse_fwd(p, 1, p, ip, 1, ip, 1, p, p, p, p, p, p, 8, p, p, N, p, nb, N) == -1
+    # backward: null gradient output, bad F, zero rows (gradients zeroed)
+    assert lib.gnf_mnistcnn_sparse_bwd(p, 1, p, ip, 1, ip, 1, p, p, p, p, p, 8, p, p, p, N, p, p, p, p, p, p, nb, N) == -1
+    assert lib.gnf_mnistcnn_sparse_bwd(p, 1, p, ip, 1, ip, 1, p, p, p, p, p, 6, p, p, p, p, p, p, p, p, p, p, nb, N) == -2
+    g = torch.ones(8 * 2304, device=DEV)
+    gp = ctypes.c_void_p(g.data_ptr())
+    assert lib.gnf_mnistcnn_sparse_bwd(p, 0, p, ip, 1, ip, 1, p, p, p, p, p, 8, p, p, p, p, p, p, p, gp, p, p, nb, N) == 0
+    torch.cuda.synchronize()
+    assert float(g.abs().sum()) == 0.
 
 
 def test_mnist_level_inversion_uses_sparse_front():
