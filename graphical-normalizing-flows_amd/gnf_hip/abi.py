@@ -67,8 +67,9 @@ SIGNATURES = {
     "gnf_mnistcnn_sparse_fwd": (c_int, [c_f, c_i64, c_f, ctypes.c_void_p, c_i64, ctypes.c_void_p, c_i64, c_f, c_f, c_f,
                                         c_f, c_f, c_f, c_i64, c_f, c_f, ctypes.c_void_p, ctypes.c_void_p, c_i64,
                                         c_stream]),
-    "gnf_mnistcnn_sparse_bwd_ws_bytes": (c_i64, [c_i64, c_i64]),
-    "gnf_mnistcnn_sparse_bwd": (c_int, [c_f, c_i64, c_f, ctypes.c_void_p, c_i64, ctypes.c_void_p, c_i64, c_f, c_f, c_f,
+    "gnf_mnistcnn_sparse_bwd_ws_bytes": (c_i64, [c_i64, c_i64, c_i64]),
+    "gnf_mnistcnn_sparse_bwd": (c_int, [c_f, c_i64, c_f, ctypes.c_void_p, c_i64, ctypes.c_void_p, c_i64,
+                                        ctypes.c_void_p, c_i64, ctypes.c_void_p, c_f, c_f, c_f,
                                         c_f, c_f, c_i64, c_f, ctypes.c_void_p, c_f, c_f, c_f, c_f, c_f, c_f, c_f,
                                         ctypes.c_void_p, c_i64, c_stream]),
     "gnf_adam_step": (c_int, [c_f, c_f, c_f, c_f, c_i64, c_float, c_float, c_float, c_float, c_float, c_float, c_int,

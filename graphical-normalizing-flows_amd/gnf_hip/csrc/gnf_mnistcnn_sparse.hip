@@ -229,7 +229,7 @@ __global__ __launch_bounds__(64 * WAVES, 3) void sparse_crop_k(SparseArgs a) {
 constexpr int A1S = 14, BPL = 172, DPL = 196, ONES = ESZ, EB = 2 * ESZ;
 constexpr int BLDS = EB + NCH * BPL + NCH * DPL;            // 6336 floats = 25 KB per wavefront: 6 per CU
 constexpr int PROW = NCH * NCH * 9 + NCH * 9 + NCH;         // partial row: dW2 | dW1 | db1
-constexpr int BWD_GRID = 256 * 6;
+constexpr int BWD_GRID = 256 * 8;             // upper bound of the crop-backward grid (partials)
 
 struct SparseBwdArgs {
   const float* x; const float* P; const int32_t* pix;
@@ -238,7 +238,7 @@ struct SparseBwdArgs {
   float* part; int64_t B, items;
 };
 
-__global__ __launch_bounds__(64) void sparse_crop_bwd_k(SparseBwdArgs a) {
+__global__ __launch_bounds__(64, 2) void sparse_crop_bwd_k(SparseBwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int lane = threadIdx.x, q = lane >> 4, j = lane & 15;
   float* e_s = smem;
@@ -246,6 +246,7 @@ __global__ __launch_bounds__(64) void sparse_crop_bwd_k(SparseBwdArgs a) {
   float* dy_s = a1_s + NCH * BPL;
   for (int i = lane; i < ESZ; i += 64) e_s[ONES + i] = 1.f;
   for (int i = lane; i < NCH * DPL; i += 64) dy_s[i] = 0.f;           // the border stays zero: only the interior is rewritten
+  for (int i = lane; i < NCH * BPL; i += 64) a1_s[i] = 0.f;           // columns 12, 13 of every row are read (times 0): finite
 
   float wa1[3], wf[36];
 #pragma unroll
@@ -259,22 +260,17 @@ __global__ __launch_bounds__(64) void sparse_crop_bwd_k(SparseBwdArgs a) {
 #pragma unroll
   for (int r = 0; r < 4; ++r) bias1[r] = a.b1[4 * q + r];
 
-  int eo[9][3], pao[9];           // conv1 position 16 nb + j: crop offsets per K step, offset in the stride-14 planes
+  int pe[9], pao[9], to[3];       // conv1 position 16 nb + j in the crop (stride 16) / in the stride-14 planes; tap offsets
 #pragma unroll
   for (int nb = 0; nb < 9; ++nb) {
     const int p = 16 * nb + j, y = p / A1, x = p - A1 * y;
     pao[nb] = y * A1S + x;
-#pragma unroll
-    for (int s = 0; s < 3; ++s) {
-      const int tap = 4 * s + q, ty = tap < 9 ? tap / 3 : 0, tx = tap < 9 ? tap - 3 * ty : 0;
-      eo[nb][s] = (y + ty) * ES + x + tx;
-    }
+    pe[nb] = y * ES + x;
   }
-  int pixo[25];                   // conv2 position 4 s + q of the 10x10 region, in the stride-14 planes
 #pragma unroll
-  for (int s = 0; s < 25; ++s) {
-    const int pix = 4 * s + q, y = pix / 10, x = pix - 10 * y;
-    pixo[s] = y * A1S + x;
+  for (int s = 0; s < 3; ++s) {
+    const int tap = 4 * s + q, ty = tap < 9 ? tap / 3 : 0, tx = tap < 9 ? tap - 3 * ty : 0;
+    to[s] = ty * ES + tx;
   }
   int dyo[7];                     // cotangent scatter: pair (cell, channel) = lane + 64 t, top-left of the cell's 2x2
 #pragma unroll
@@ -337,20 +333,22 @@ __global__ __launch_bounds__(64) void sparse_crop_bwd_k(SparseBwdArgs a) {
     for (int nb = 0; nb < 9; ++nb) {
       f32x4 d = bias1;
 #pragma unroll
-      for (int s = 0; s < 3; ++s) d = mfma(wa1[s], e_s[eo[nb][s]], d);
+      for (int s = 0; s < 3; ++s) d = mfma(wa1[s], e_s[pe[nb] + to[s]], d);
 #pragma unroll
       for (int r = 0; r < 4; ++r) a1_s[(4 * q + r) * BPL + pao[nb]] = fmaxf(d[r], 0.f);
     }
     // ---- dW2[c_out][c_in][tap] += sum_pos dY2[c_out][pos] a1[c_in][pos + tap]: 9 independent chains
+    //      K runs over 10 rows x 12 columns (3 steps of 4 per row): columns 10, 11 are the zero border of dY2
     {
-      const float* ap = dy_s + j * DPL + 2 * A1S + 2;
-      const float* bp = a1_s + j * BPL;
+      const float* ap = dy_s + j * DPL + 2 * A1S + 2 + q;
+      const float* bp = a1_s + j * BPL + q;
 #pragma unroll
-      for (int s = 0; s < 25; ++s) {
-        const float av2 = ap[pixo[s]];
-        const float* b0 = bp + pixo[s];
+      for (int s = 0; s < 30; ++s) {
+        const int o = (s / 3) * A1S + 4 * (s % 3);
+        const float av2 = ap[o];
 #pragma unroll
-        for (int t = 0; t < 9; ++t) acc2[t] = mfma(av2, b0[(t / 3) * A1S + t % 3], acc2[t]);
+        for (int t = 0; t < 9; ++t) acc2[t] = mfma(av2, bp[o + (t / 3) * A1S + t % 3], acc2[t]);
+        if (s % 3 == 2) __builtin_amdgcn_sched_barrier(0);       // bound the operand hoisting (registers)
       }
     }
     // ---- d a1[c_in][pos] = sum_{c_out,tap} W2[c_out][c_in][tap] dY2[c_out][pos - tap], gated by a1 > 0, in place
@@ -369,6 +367,7 @@ __global__ __launch_bounds__(64) void sparse_crop_bwd_k(SparseBwdArgs a) {
         float* g = a1_s + (4 * q + r) * BPL + pao[nb];
         *g = *g > 0.f ? d0[r] + d1[r] : 0.f;
       }
+      __builtin_amdgcn_sched_barrier(0);
     }
     // ---- dW1[c][tap] += sum_pos da1[c][pos] e[pos + tap];  db1[c] += sum_pos da1[c][pos]  (column 9: constant 1)
     {
@@ -395,17 +394,21 @@ __global__ __launch_bounds__(64) void sparse_crop_bwd_k(SparseBwdArgs a) {
   }
 }
 
-// gWfc1[n][c*144 + py*12 + px] = bg[c] S[n] + sum over the <= 25 crop origins whose 5x5 block holds cell (py, px)
-__global__ void sparse_scatter_fc1_k(const float* __restrict__ dWg, const float* __restrict__ S,
-                                     const float* __restrict__ bg, int F, float* __restrict__ gW) {
+// gWfc1[n][c*144 + py*12 + px] = bg[c] S[n] + sum over the <= 25 crop origins whose 5x5 block holds cell (py, px), each
+// origin's gradient being the sum of its K chunks (oc[2g], oc[2g+1] = first chunk, number of chunks of origin g)
+__global__ void sparse_scatter_fc1_k(const float* __restrict__ dWg, const int32_t* __restrict__ oc,
+                                     const float* __restrict__ S, const float* __restrict__ bg, int F,
+                                     float* __restrict__ gW) {
   const int64_t total = (int64_t)F * NCH * 144;
   for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
     const int n = (int)(idx % F), col = (int)(idx / F);
     const int c = col / 144, pos = col - 144 * c, py = pos / 12, px = pos - 12 * py;
     float s = bg[c] * S[n];
     for (int r0 = max(0, py - 4); r0 <= min(7, py); ++r0)
-      for (int c0 = max(0, px - 4); c0 <= min(7, px); ++c0)
-        s += dWg[((int64_t)(r0 * 8 + c0) * KD + ((py - r0) * 5 + px - c0) * NCH + c) * F + n];
+      for (int c0 = max(0, px - 4); c0 <= min(7, px); ++c0) {
+        const int g = r0 * 8 + c0, k = ((py - r0) * 5 + px - c0) * NCH + c;
+        for (int ch = oc[2 * g]; ch < oc[2 * g] + oc[2 * g + 1]; ++ch) s += dWg[((int64_t)ch * KD + k) * F + n];
+      }
     gW[(int64_t)n * (NCH * 144) + col] = s;
   }
 }
@@ -516,19 +519,21 @@ static int64_t bwd_rows_n(int64_t F) {                 // widest row the two-lev
   return n;
 }
 
-int64_t gnf_mnistcnn_sparse_bwd_ws_bytes(int64_t n_rows, int64_t F) {
-  if (n_rows < 0 || F < 0) return 0;
-  return (n_rows * KD + 2 * (int64_t)NORIG * KD * F + NCH + KD + (int64_t)BWD_GRID * PROW + PROW +
+int64_t gnf_mnistcnn_sparse_bwd_ws_bytes(int64_t n_rows, int64_t F, int64_t n_kgroups) {
+  if (n_rows < 0 || F < 0 || n_kgroups < 0) return 0;
+  return (n_rows * KD + (int64_t)(NORIG + n_kgroups) * KD * F + NCH + KD + (int64_t)BWD_GRID * PROW + PROW +
           (int64_t)kRowsumChunks * bwd_rows_n(F) + 64) * (int64_t)sizeof(float);
 }
 
 int gnf_mnistcnn_sparse_bwd(const float* x, int64_t B, const float* P, const int32_t* pix, int64_t R,
                             const int32_t* groups, int64_t max_group_rows,
+                            const int32_t* kgroups, int64_t n_kgroups, const int32_t* origin_chunks,
                             const float* W1, const float* b1, const float* W2, const float* b2,
                             const float* Wfc1, int64_t F,
                             const float* pd, const unsigned char* argmax, const float* g_h1,
                             float* gW1, float* gb1, float* gW2, float* gb2, float* gWfc1, float* gbfc1,
                             void* ws, int64_t ws_bytes, gnf_stream_t stream) {
+  if (!kgroups || !origin_chunks || n_kgroups < 0 || n_kgroups > 65535) return GNF_EINVAL;
   if (!x || !P || !pix || !groups || !W1 || !b1 || !W2 || !b2 || !Wfc1 || !pd || !argmax || !g_h1 || !gW1 || !gb1 ||
       !gW2 || !gb2 || !gWfc1 || !gbfc1 || B < 0 || R < 0 || F <= 0)
     return GNF_EINVAL;
@@ -541,12 +546,13 @@ int gnf_mnistcnn_sparse_bwd(const float* x, int64_t B, const float* P, const int
     (void)hipMemsetAsync(gWfc1, 0, F * NCH * 144 * sizeof(float), s); (void)hipMemsetAsync(gbfc1, 0, F * sizeof(float), s);
     return 0;
   }
-  if (!ws || ws_bytes < gnf_mnistcnn_sparse_bwd_ws_bytes(items, F) || max_group_rows <= 0 || max_group_rows > items)
+  if (!ws || ws_bytes < gnf_mnistcnn_sparse_bwd_ws_bytes(items, F, n_kgroups) || max_group_rows <= 0 ||
+      max_group_rows > items || n_kgroups < 1)
     return GNF_EINVAL;
   float* dpd = (float*)ws;                              // [items][400]
   float* Wg = dpd + items * KD;                         // [64][400][F]
-  float* dWg = Wg + (int64_t)NORIG * KD * F;            // [64][400][F]
-  float* bg = dWg + (int64_t)NORIG * KD * F;            // [16]
+  float* dWg = Wg + (int64_t)NORIG * KD * F;            // [n_kgroups][400][F]
+  float* bg = dWg + n_kgroups * KD * F;                 // [16]
   float* T = bg + NCH;                                  // [400]
   float* part = T + KD;                                 // [BWD_GRID][PROW]
   float* red = part + (int64_t)BWD_GRID * PROW;         // [PROW]
@@ -569,18 +575,33 @@ int gnf_mnistcnn_sparse_bwd(const float* x, int64_t B, const float* P, const int
   if ((rc = gnf_gemm_grouped_launch(g, NORIG, s))) return rc;
   if ((rc = gnf_rowsum_tall_launch(dpd, T, items, KD, 0, rws, s))) return rc;
 
-  GemmArgs w{};                                         // dWg[origin] = pd[rows of origin]^T . g[rows of origin]
+  GemmArgs w{};                                         // dWg[chunk] = pd[rows of chunk]^T . g[rows of chunk]
   w.A = pd; w.sam = 1; w.sak = KD;
   w.B = g_h1; w.sbk = F; w.sbn = 1;
   w.C = dWg; w.scm = F; w.scn = 1; w.c_split_stride = (int64_t)KD * F;
   w.M = KD; w.N = F; w.K = items;
-  w.grp = groups; w.grp_k = 1;
-  if ((rc = gnf_gemm_grouped_launch(w, NORIG, s))) return rc;
-  hipLaunchKernelGGL(sparse_scatter_fc1_k, dim3(2048), dim3(256), 0, s, dWg, gbfc1, bg, (int)F, gWfc1);
+  w.grp = kgroups; w.grp_k = 1;
+  if ((rc = gnf_gemm_grouped_launch(w, (int)n_kgroups, s))) return rc;
+  hipLaunchKernelGGL(sparse_scatter_fc1_k, dim3(2048), dim3(256), 0, s, dWg, origin_chunks, gbfc1, bg, (int)F, gWfc1);
   GNF_LAUNCH_CHECK();
 
   SparseBwdArgs a{x, P, pix, W1, b1, W2, dpd, argmax, part, B, items};
-  const int64_t grid = items < BWD_GRID ? items : BWD_GRID;
+  // exactly one resident wave of workgroups: a second, partial wave would idle most of the chip (every workgroup
+  // walks the same number of copies)
+  static int per_cu = 0, n_cu = 0;
+  if (!per_cu) {
+    int dev = 0, nb = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess ||
+        hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, sparse_crop_bwd_k, 64, BLDS * sizeof(float)) != hipSuccess ||
+        nb < 1)
+      return GNF_EINVAL;
+    n_cu = prop.multiProcessorCount;
+    per_cu = nb;
+  }
+  int64_t grid = (int64_t)per_cu * n_cu;
+  if (grid > BWD_GRID) grid = BWD_GRID;
+  if (grid > items) grid = items;
   hipLaunchKernelGGL(sparse_crop_bwd_k, dim3((unsigned)grid), dim3(64), BLDS * sizeof(float), s, a);
   GNF_LAUNCH_CHECK();
   if ((rc = gnf_rowsum_launch(part, red, grid, PROW, 0, s))) return rc;

@@ -262,6 +262,16 @@ class SparseRows:
             first += counts[g]
         self.groups = torch.tensor(table, dtype=torch.int32, device=device)
         self.max_group_rows = max(max(counts) * B, 1)
+        # chunks of <= 512 output rows inside each origin's range (the backward's per-chunk fc1 weight gradients)
+        chunks, per_origin = [], []
+        for g in range(64):
+            first, rows_g = table[2 * g], table[2 * g + 1]
+            per_origin += [len(chunks) // 2, (rows_g + 511) // 512]
+            for o in range(0, rows_g, 512):
+                chunks += [first + o, min(512, rows_g - o)]
+        self.n_kgroups = len(chunks) // 2
+        self.kgroups = torch.tensor(chunks or [0, 0], dtype=torch.int32, device=device)
+        self.origin_chunks = torch.tensor(per_origin, dtype=torch.int32, device=device)
 
 
 class MnistSparseFn(torch.autograd.Function):
@@ -298,10 +308,10 @@ class MnistSparseFn(torch.autograd.Function):
         g = (gh1 * (h1 > 0)).contiguous()
         gW1, gb1, gW2, gb2 = torch.empty_like(W1), torch.empty_like(b1), torch.empty_like(W2), torch.empty_like(b2)
         gWf, gbf = torch.empty_like(Wfc1), _empty((F,), x)
-        nws = abi.load().gnf_mnistcnn_sparse_bwd_ws_bytes(n, F)
+        nws = abi.load().gnf_mnistcnn_sparse_bwd_ws_bytes(n, F, sr.n_kgroups)
         ws = _ws(nws, x)
         call("gnf_mnistcnn_sparse_bwd", ptr(x), sr.B, ptr(P), abi.rawptr(sr.pix), sr.R, abi.rawptr(sr.groups),
-             sr.max_group_rows, ptr(W1), ptr(b1), ptr(W2), ptr(b2), ptr(Wfc1), F, ptr(pd), abi.rawptr(arg), ptr(g),
+             sr.max_group_rows, abi.rawptr(sr.kgroups), sr.n_kgroups, abi.rawptr(sr.origin_chunks), ptr(W1), ptr(b1), ptr(W2), ptr(b2), ptr(Wfc1), F, ptr(pd), abi.rawptr(arg), ptr(g),
              ptr(gW1), ptr(gb1), ptr(gW2), ptr(gb2), ptr(gWf), ptr(gbf), abi.rawptr(ws), nws, stream())
         return None, None, None, gW1, gb1, gW2, gb2, gWf, gbf
 

@@ -193,10 +193,14 @@ int gnf_mnistcnn_sparse_fwd(const float* x, int64_t B, const float* P, const int
                             void* ws, int64_t ws_bytes, gnf_stream_t stream);
 /* Backward w.r.t. the network parameters (training with a frozen deterministic gate: P and x get no gradient).
  * g_h1 [R*B, F]: cotangent of h1 with the ReLU already applied (zero where h1 == 0).  Gradients are written, not
- * accumulated: gW1 [16,1,3,3], gb1 [16], gW2 [16,16,3,3], gb2 [16], gWfc1 [F,2304], gbfc1 [F]. */
-int64_t gnf_mnistcnn_sparse_bwd_ws_bytes(int64_t n_rows, int64_t F);
+ * accumulated: gW1 [16,1,3,3], gb1 [16], gW2 [16,16,3,3], gb2 [16], gWfc1 [F,2304], gbfc1 [F].
+ * The fc1 weight gradient is contracted per CHUNK of output rows so that the few large origins do not serialise:
+ *   kgroups [2*n_kgroups] (device): (first output row, row count) of each chunk, a chunk lying inside one origin's
+ *   rows, the chunks of an origin consecutive;  origin_chunks [2*64] (device): (first chunk, number of chunks). */
+int64_t gnf_mnistcnn_sparse_bwd_ws_bytes(int64_t n_rows, int64_t F, int64_t n_kgroups);
 int gnf_mnistcnn_sparse_bwd(const float* x, int64_t B, const float* P, const int32_t* pix, int64_t R,
                             const int32_t* groups, int64_t max_group_rows,
+                            const int32_t* kgroups, int64_t n_kgroups, const int32_t* origin_chunks,
                             const float* W1, const float* b1, const float* W2, const float* b2,
                             const float* Wfc1, int64_t F,
                             const float* pd, const unsigned char* argmax, const float* g_h1,

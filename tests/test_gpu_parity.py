@@ -875,7 +875,7 @@ def test_sparse_front_abi_validation():
     from gnf_hip import abi
     lib = abi.load()
     assert lib.gnf_mnistcnn_sparse_ws_bytes(10, 128) == (10 * 400 + 64 * 400 * 128 + 16 + 128 + 64) * 4
-    assert lib.gnf_mnistcnn_sparse_bwd_ws_bytes(10, 128) > lib.gnf_mnistcnn_sparse_ws_bytes(10, 128)
+    assert lib.gnf_mnistcnn_sparse_bwd_ws_bytes(10, 128, 3) > lib.gnf_mnistcnn_sparse_ws_bytes(10, 128)
     N = None
     assert lib.gnf_mnistcnn_sparse_fwd(N, 1, N, N, 1, N, 1, N, N, N, N, N, N, 128, N, N, N, N, 0, N) == -1
     t = torch.zeros(64 * 400 * 8 * 2 + (1 << 22), device=DEV)
@@ -889,11 +889,11 @@ def test_sparse_front_abi_validation():
     assert lib.gnf_mnistcnn_sparse_fwd(p, 1, p, ip, 1, ip, 1, p, p, p, p, p, p, 8, p, N, N, p, 16, N) == -1
     assert lib.gnf_mnistcnn_sparse_fwd(p, 1, p, ip, 1, ip, 1, p, p, p, p, p, p, 8, p, p, N, p, nb, N) == -1
     # backward: null gradient output, bad F, zero rows (gradients zeroed)
-    assert lib.gnf_mnistcnn_sparse_bwd(p, 1, p, ip, 1, ip, 1, p, p, p, p, p, 8, p, p, p, N, p, p, p, p, p, p, nb, N) == -1
-    assert lib.gnf_mnistcnn_sparse_bwd(p, 1, p, ip, 1, ip, 1, p, p, p, p, p, 6, p, p, p, p, p, p, p, p, p, p, nb, N) == -2
+    assert lib.gnf_mnistcnn_sparse_bwd(p, 1, p, ip, 1, ip, 1, ip, 1, ip, p, p, p, p, p, 8, p, p, p, N, p, p, p, p, p, p, nb, N) == -1
+    assert lib.gnf_mnistcnn_sparse_bwd(p, 1, p, ip, 1, ip, 1, ip, 1, ip, p, p, p, p, p, 6, p, p, p, p, p, p, p, p, p, p, nb, N) == -2
     g = torch.ones(8 * 2304, device=DEV)
     gp = ctypes.c_void_p(g.data_ptr())
-    assert lib.gnf_mnistcnn_sparse_bwd(p, 0, p, ip, 1, ip, 1, p, p, p, p, p, 8, p, p, p, p, p, p, p, gp, p, p, nb, N) == 0
+    assert lib.gnf_mnistcnn_sparse_bwd(p, 0, p, ip, 1, ip, 1, ip, 1, ip, p, p, p, p, p, 8, p, p, p, p, p, p, p, gp, p, p, nb, N) == 0
     torch.cuda.synchronize()
     assert float(g.abs().sum()) == 0.
 
