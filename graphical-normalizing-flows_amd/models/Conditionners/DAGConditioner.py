@@ -81,6 +81,7 @@ class DAGConditioner(Conditioner):
         self.is_invertible = False
         self.sparse_front = True        # deterministic gate + windowed, frozen A: sparse embedding front
         self._sparse_outside = None     # 1 outside the 5x5 pixel windows (device mask, built on first use)
+        self._sparse_checked = (None, False)
         self._sparse_plans = {}
         self.gate_noise = None          # (u1, u2) [B,d,d] uniforms (test hook); None -> Philox
         self._gate_calls = 0
@@ -139,10 +140,16 @@ class DAGConditioner(Conditioner):
             return None
         if torch.is_grad_enabled() and (x.requires_grad or P.requires_grad):
             return None                  # the sparse kernels differentiate w.r.t. the network parameters only
-        # checked on every call (one small reduction + a host read): A can be edited in ways no version counter sees
-        if self._sparse_outside is None or self._sparse_outside.device != P.device:
-            self._sparse_outside = (~ops.mnist_window_mask(P.device)).float()
-        if bool((P.detach() * self._sparse_outside).count_nonzero()):
+        # One small reduction + a host read.  A trainable A is checked on every call (the optimiser rewrites it); a
+        # frozen one (post_process) only when its storage or version counter changed, so that a training step with
+        # the frozen gate has no host synchronisation in it.
+        key = None if self.A.requires_grad else (self.A.data_ptr(), self.A._version, float(self.h_thresh),
+                                                 bool(self.s_thresh))
+        if key is None or key != self._sparse_checked[0]:
+            if self._sparse_outside is None or self._sparse_outside.device != P.device:
+                self._sparse_outside = (~ops.mnist_window_mask(P.device)).float()
+            self._sparse_checked = (key, not bool((P.detach() * self._sparse_outside).count_nonzero()))
+        if not self._sparse_checked[1]:
             return None
         rows = tuple(range(self.in_size)) if rows is None else tuple(int(r) for r in rows)
         plan_key = (rows, x.shape[0], x.device)

@@ -827,9 +827,9 @@ def test_sparse_front_row_subsets_and_fallbacks():
         assert got.shape == want.shape == (B, rows.numel(), 30)
         assert rel_err(got.cpu(), want.cpu()) < TOL
         # an entry outside the 5x5 window: the sparse front must step aside (dense result unchanged)
-        cond.A.data[0, 300] = 1.
+        cond.A[0, 300] = 1.
         assert cond._sparse_plan(x, None, cond.deterministic_importance()) is None
-        cond.A.data[0, 300] = 0.
+        cond.A[0, 300] = 0.
         assert cond._sparse_plan(x, None, cond.deterministic_importance()) is not None
     # a gradient wanted for x (or for A) -> dense path
     assert cond._sparse_plan(x.clone().requires_grad_(True), None, cond.deterministic_importance()) is None

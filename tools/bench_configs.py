@@ -39,6 +39,12 @@ def cfg(name):
     elif name == "cfg4":
         x = bench.pseudo_mnist(g, 100, 784)
         f = bench.build_flow()
+    elif name == "cfg4det":  # cfg4 after the DAG phase: post_process() froze a binary A, the gate is deterministic
+        x = bench.pseudo_mnist(g, 100, 784)
+        f = bench.build_flow()
+        for c in f.getConditioners():
+            with torch.no_grad():
+                c.post_process(zero_threshold=.1)
     elif name == "cfg5":    # BSDS300 d=63 synthetic (yml:347-358), B=50000
         x = torch.randn(50000, 63, generator=g)
         f = buildFCNormalizingFlow(1, AutoregressiveConditioner, {"in_size": 63, "hidden": [630] * 3, "out_size": 30},
@@ -90,7 +96,7 @@ def main():
         dt = min(dt_mean, singles[len(singles) // 2])
         prof = abi.profile_collect()
         graphed = None
-        if "--graph" in sys.argv and name in ("cfg1", "cfg3"):
+        if "--graph" in sys.argv and name in ("cfg1", "cfg3", "cfg4det"):
             # launch-bound configurations: the full optimisation step (incl. Adam) replayed from one hipGraph, next to
             # the same step issued launch by launch
             from gnf_hip import dp
