@@ -1,5 +1,6 @@
 """Deterministic-gate embedding front at the cfg4 size (B = 100 -> 78 400 masked copies): the sparse crop path
-(gnf_mnistcnn_sparse_fwd) against the dense kernels (gate + Winograd conv + fc1), forward only.
+(gnf_mnistcnn_sparse_fwd / _bwd) against the dense kernels (gate + Winograd conv + fc1): conditioner forward under
+no_grad, and forward + backward w.r.t. the network parameters (frozen binary A, as after post_process()).
 Usage: python tools/bench_sparse_front.py [B]"""
 import json
 import sys
@@ -47,6 +48,22 @@ def main():
         cond(x)
         out["sparse_entry_ms"] = {k: round(v, 4) for k, v in abi.profile_collect().items()}
     out["speedup"] = out["dense_ms"] / out["sparse_ms"]
+    # training with the frozen gate
+    cond.s_thresh = False
+    cond.A.requires_grad = False
+    gh = torch.randn(B, 784, 30, device=DEV)
+
+    def step():
+        for p in cond.parameters():
+            p.grad = None
+        (cond(x) * gh).sum().backward()
+    out["sparse_fwd_bwd_ms"] = timed(step)
+    abi.profile_enable(["gnf_mnistcnn_sparse_fwd", "gnf_mnistcnn_sparse_bwd"])
+    step()
+    out["sparse_train_entry_ms"] = {k: round(v, 4) for k, v in abi.profile_collect().items()}
+    cond.sparse_front = False
+    out["dense_fwd_bwd_ms"] = timed(step)
+    out["train_speedup"] = out["dense_fwd_bwd_ms"] / out["sparse_fwd_bwd_ms"]
     # algorithmic work of the sparse path: conv1 12*12*16*9 + conv2 10*10*16*16*9 + fc1 400*128 MAC per copy
     mac = 12 * 12 * 16 * 9 + 10 * 10 * 16 * 16 * 9 + 400 * 128
     out["sparse_TFLOPs"] = 2 * mac * B * 784 / (out["sparse_ms"] * 1e-3) / 1e12
