@@ -27,7 +27,8 @@
 //   backward: d pd = g . Wg^T and dWg = pd^T . g as grouped GEMMs (row groups / K groups), dWg scattered back to the
 //     fc1 weight; the crop backward kernel (one wavefront per masked copy again) recomputes conv1, rebuilds the
 //     max-pooled cotangent from the saved argmax, and contracts dW2 (K = the 100 conv2 positions), d a1 (K = (output
-//     channel, tap)) and dW1/db1 (K = the 144 conv1 positions, against the crop and a constant-1 image) on MFMA with
+//     channel, tap), only on the 8x8 box of conv1 positions around the pixel's window) and dW1/db1 (K = the box,
+//     against the crop and a constant-1 image) on MFMA with
 //     the accumulators in registers across all copies of the wave.  What the constant background contributes (bg
 //     depends on b1, W2, b2) is a closed form of the column sums and is added by a one-workgroup epilogue.
 #include "gnf_common.h"
@@ -228,7 +229,7 @@ __global__ __launch_bounds__(64 * WAVES, 3) void sparse_crop_k(SparseArgs a) {
 // ---------------------------------------------------------------------------------------------------------------
 constexpr int A1S = 14, BPL = 172, DPL = 196, ONES = ESZ, EB = 2 * ESZ;
 constexpr int BLDS = EB + NCH * BPL + NCH * DPL;            // 6336 floats = 25 KB per wavefront: 6 per CU
-constexpr int PROW = NCH * NCH * 9 + NCH * 9 + NCH;         // partial row: dW2 | dW1 | db1
+constexpr int PROW = NCH * NCH * 9 + NCH * 9 + 2 * NCH;     // partial row: dW2 | dW1 | db1 (box) | sum of d a1 (box)
 constexpr int BWD_GRID = 256 * 8;             // upper bound of the crop-backward grid (partials)
 
 struct SparseBwdArgs {
@@ -279,6 +280,9 @@ __global__ __launch_bounds__(64, 2) void sparse_crop_bwd_k(SparseBwdArgs a) {
     dyo[t] = idx < KD ? c * DPL + (2 * cy + 2) * A1S + 2 * cx + 2 : -1;
   }
   const int eb = j < 9 ? (j / 3) * ES + j % 3 + q : (j == 9 ? ONES + q : q);   // dW1 B operand: tap j | ones (db1) | unused
+  int pb[4];                      // box position 16 nb + j of the 8x8 box, in the stride-14 planes
+#pragma unroll
+  for (int nb = 0; nb < 4; ++nb) pb[nb] = (2 * nb + (j >> 3)) * A1S + (j & 7);
   int ce[4], cl[4];
 #pragma unroll
   for (int t = 0; t < 4; ++t) {
@@ -287,7 +291,7 @@ __global__ __launch_bounds__(64, 2) void sparse_crop_bwd_k(SparseBwdArgs a) {
     cl[t] = idx < CROP * CROP ? ey * ES + ex : -1;
   }
 
-  f32x4 acc2[9], acc1a = {0.f, 0.f, 0.f, 0.f}, acc1b = acc1a;
+  f32x4 acc2[9], acc1a = {0.f, 0.f, 0.f, 0.f}, acc1b = acc1a, dsum = acc1a;
 #pragma unroll
   for (int t = 0; t < 9; ++t) acc2[t] = acc1a;
 
@@ -351,11 +355,25 @@ __global__ __launch_bounds__(64, 2) void sparse_crop_bwd_k(SparseBwdArgs a) {
         if (s % 3 == 2) __builtin_amdgcn_sched_barrier(0);       // bound the operand hoisting (registers)
       }
     }
-    // ---- d a1[c_in][pos] = sum_{c_out,tap} W2[c_out][c_in][tap] dY2[c_out][pos - tap], gated by a1 > 0, in place
+    // ---- d a1[c_in][pos] = sum_{c_out,tap} W2[c_out][c_in][tap] dY2[c_out][pos - tap], gated by a1 > 0, in place --
+    //      only on the 8x8 box of conv1 positions that holds every position whose activation can differ from
+    //      relu(b1) (the 7x7 neighbourhood of the pixel's window): e is zero under every other position, so they
+    //      contribute nothing to dW1, and their constant gate makes their share of db1 a closed form of the column
+    //      sums (sparse_finish_k) once the UNgated sum over the box is known (dsum).
+    int boxo, boxe;
+    {
+      const int pix = __builtin_amdgcn_readfirstlane(a.pix[item / a.B]);
+      const int yi = pix / IMG, xi = pix - IMG * yi;
+      int oy = yi - 4 - 2 * crop_origin(yi), ox = xi - 4 - 2 * crop_origin(xi);
+      oy = oy < 0 ? 0 : (oy > 4 ? 4 : oy);
+      ox = ox < 0 ? 0 : (ox > 4 ? 4 : ox);
+      boxo = oy * A1S + ox;
+      boxe = oy * ES + ox;
+    }
 #pragma unroll
-    for (int nb = 0; nb < 9; ++nb) {
+    for (int nb = 0; nb < 4; ++nb) {
       f32x4 d0 = {0.f, 0.f, 0.f, 0.f}, d1 = d0;
-      const float* bp = dy_s + q * DPL + pao[nb] + 2 * A1S + 2;
+      const float* bp = dy_s + q * DPL + boxo + pb[nb] + 2 * A1S + 2;
 #pragma unroll
       for (int s = 0; s < 36; s += 2) {
         const int t0 = s >> 2, t1 = (s + 1) >> 2;
@@ -364,19 +382,21 @@ __global__ __launch_bounds__(64, 2) void sparse_crop_bwd_k(SparseBwdArgs a) {
       }
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        float* g = a1_s + (4 * q + r) * BPL + pao[nb];
-        *g = *g > 0.f ? d0[r] + d1[r] : 0.f;
+        float* g = a1_s + (4 * q + r) * BPL + boxo + pb[nb];
+        const float v = d0[r] + d1[r];
+        dsum[r] += v;
+        *g = *g > 0.f ? v : 0.f;
       }
       __builtin_amdgcn_sched_barrier(0);
     }
-    // ---- dW1[c][tap] += sum_pos da1[c][pos] e[pos + tap];  db1[c] += sum_pos da1[c][pos]  (column 9: constant 1)
+    // ---- dW1[c][tap] += sum_box da1[c][pos] e[pos + tap];  db1[c] += sum_box da1[c][pos]  (column 9: constant 1)
     {
-      const float* ap = a1_s + j * BPL + q;
-      const float* bp = e_s + eb;
+      const float* ap = a1_s + j * BPL + boxo + q;
+      const float* bp = e_s + boxe + eb;
 #pragma unroll
-      for (int s = 0; s < 36; s += 2) {
-        acc1a = mfma(ap[(s / 3) * A1S + 4 * (s % 3)], bp[(s / 3) * ES + 4 * (s % 3)], acc1a);
-        acc1b = mfma(ap[((s + 1) / 3) * A1S + 4 * ((s + 1) % 3)], bp[((s + 1) / 3) * ES + 4 * ((s + 1) % 3)], acc1b);
+      for (int s = 0; s < 16; s += 2) {
+        acc1a = mfma(ap[(s / 2) * A1S + 4 * (s % 2)], bp[(s / 2) * ES + 4 * (s % 2)], acc1a);
+        acc1b = mfma(ap[((s + 1) / 2) * A1S + 4 * ((s + 1) % 2)], bp[((s + 1) / 2) * ES + 4 * ((s + 1) % 2)], acc1b);
       }
     }
   }
@@ -391,6 +411,8 @@ __global__ __launch_bounds__(64, 2) void sparse_crop_bwd_k(SparseBwdArgs a) {
     const float v = acc1a[r] + acc1b[r];
     if (j < 9) prow[NCH * NCH * 9 + (4 * q + r) * 9 + j] = v;
     else if (j == 9) prow[NCH * NCH * 9 + NCH * 9 + 4 * q + r] = v;
+    const float ds = group_sum<16>(dsum[r]);
+    if (j == 0) prow[NCH * NCH * 9 + NCH * 9 + NCH + 4 * q + r] = ds;
   }
 }
 
@@ -415,14 +437,15 @@ __global__ void sparse_scatter_fc1_k(const float* __restrict__ dWg, const int32_
 
 // One workgroup.  With S = column sums of g (= d bfc1), T[c] = sum over copies and cells of d pd[.., c] and
 // Wsum[n][c] = sum_pos Wfc1[n][c*144+pos]:   d b2 = S . Wsum,   d bg = d b2 - T,  and through
-// bg[c] = b2[c] + sum_{c',tap} W2[c][c'][tap] relu(b1[c']):   dW2 += d bg (x) relu(b1),   d b1 += [b1 > 0] W2^T d bg.
+// bg[c] = b2[c] + sum_{c',tap} W2[c][c'][tap] relu(b1[c']):   dW2 += d bg (x) relu(b1),   d b1 += [b1 > 0] W2^T d bg
+// (+ the crop positions outside the boxes, see below).
 __global__ __launch_bounds__(1024) void sparse_finish_k(const float* __restrict__ red, const float* __restrict__ S,
                                                         const float* __restrict__ T, const float* __restrict__ Wfc1,
                                                         const float* __restrict__ b1, const float* __restrict__ W2, int F,
                                                         float* __restrict__ gW1, float* __restrict__ gb1,
                                                         float* __restrict__ gW2, float* __restrict__ gb2) {
   __shared__ float wsum[16][NCH + 1];
-  __shared__ float dbg[NCH];
+  __shared__ float dbg[NCH], gb2s[NCH];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   float acc[NCH];
 #pragma unroll
@@ -444,6 +467,7 @@ __global__ __launch_bounds__(1024) void sparse_finish_k(const float* __restrict_
     for (int w = 0; w < 16; ++w) v += wsum[w][tid];
     for (int cell = 0; cell < NCELL; ++cell) t += T[cell * NCH + tid];
     gb2[tid] = v;
+    gb2s[tid] = v;
     dbg[tid] = v - t;
   }
   __syncthreads();
@@ -453,10 +477,14 @@ __global__ __launch_bounds__(1024) void sparse_finish_k(const float* __restrict_
   }
   if (tid < NCH * 9) gW1[tid] = red[NCH * NCH * 9 + tid];
   if (tid < NCH) {
+    // outside the boxes the conv1 gate is the constant [b1 > 0] and the d a1 of ALL positions sum to W2^T (column sums of
+    // dY2 = T); together with the background path (d bg = d b2 - T) that is W2sum^T d b2 minus what the boxes hold
     float v = 0.f;
-    if (b1[tid] > 0.f)
+    if (b1[tid] > 0.f) {
       for (int c = 0; c < NCH; ++c)
-        for (int t = 0; t < 9; ++t) v = fmaf(dbg[c], W2[(c * NCH + tid) * 9 + t], v);
+        for (int t = 0; t < 9; ++t) v = fmaf(gb2s[c], W2[(c * NCH + tid) * 9 + t], v);
+      v -= red[NCH * NCH * 9 + NCH * 9 + NCH + tid];
+    }
     gb1[tid] = red[NCH * NCH * 9 + NCH * 9 + tid] + v;
   }
 }
