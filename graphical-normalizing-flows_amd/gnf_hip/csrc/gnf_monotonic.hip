@@ -121,6 +121,7 @@ struct MonoArgs {
   float* SA[kMaxNH]; float* SD[kMaxNH]; float* Dsum; float* part;
   int64_t e0, ecount;                   // element chunk [e0, e0+ecount)
   int NK;                               // node slots per group (S+2 rounded up to even)
+  int ones;                             // backward: bias gradients of the hidden layers via a ones column (see mono_bwd_k)
 };
 
 __device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
@@ -319,8 +320,12 @@ __global__ __launch_bounds__(64 * kWaves) void mono_fwd_k(MonoArgs a) {
 // WMODE 0: weight fragments stream from L1/L2;  1: whole padded image LDS-resident (small nets);
 //       2: one hidden->hidden matrix at a time in LDS, swapped in before each layer pass by the whole workgroup
 //          (wide nets: the image does not fit, and L2 fragment loads starve the MFMA pipe)
-template <int HT, int NH, int WMODE>
-__global__ __launch_bounds__(64 * kWaves) void mono_bwd_k(MonoArgs a) {
+// ONES (narrow nets whose hidden widths leave a padding column): the staged layer inputs carry a constant 1 in column
+// HP-1, so the weight-gradient GEMM returns the bias gradient in that column and the 3 x HT x 4 bias partial registers
+// go away -- together with reading W^T out of the untransposed LDS-resident matrices (WMODE 4, 54 KB instead of the
+// 89 KB image with transposes) that lets two workgroups share a CU (2 wavefronts per SIMD).
+template <int HT, int NH, int WMODE, bool ONES = false>
+__global__ __launch_bounds__(64 * kWaves, ONES ? 2 : 1) void mono_bwd_k(MonoArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   // WMODE 0: weights from L2.  1: the whole pack (incl. transposes) in LDS (narrow nets).  2: ONE hidden->hidden matrix in
   // LDS at a time, swapped by the workgroup.  3: all hidden->hidden matrices resident in LDS.  Modes 2 and 3 keep only
@@ -328,7 +333,9 @@ __global__ __launch_bounds__(64 * kWaves) void mono_bwd_k(MonoArgs a) {
   // two q of a 32-lane group 16 banks apart: conflict-free), so a node needs the matrices in the order
   // W1 .. W_{NH-1} | W_{NH-1} .. W1 and the one the forward loaded last / the backward used last is still there:
   // 2 swaps per node instead of 4 at NH = 3, none in mode 3.
-  constexpr bool WLDS = WMODE == 1, SWAP = WMODE == 2, RES = WMODE == 3, UNT = SWAP || RES;
+  // 4: the forward part of the pack (small vectors, W1h, the untransposed hidden matrices) plus W1h^T resident, W^T read
+  //    out of the untransposed matrices as in 3 (54 KB at H <= 64 instead of 89 KB: two workgroups per CU)
+  constexpr bool WLDS = WMODE == 1, SWAP = WMODE == 2, RES = WMODE == 3, FRES = WMODE == 4, UNT = SWAP || RES || FRES;
   const MonoLayout& L = a.L;
   const float* wp = a.pack;
   if (WLDS) {
@@ -336,6 +343,16 @@ __global__ __launch_bounds__(64 * kWaves) void mono_bwd_k(MonoArgs a) {
       *reinterpret_cast<f32x4*>(smem + i) = ld4(a.pack + i);
     __syncthreads();
     wp = smem;
+  }
+  const float* w1ht = wp + L.o_W1hT;
+  if (FRES) {
+    for (int i = threadIdx.x * 4; i < L.fwd_floats; i += blockDim.x * 4)
+      *reinterpret_cast<f32x4*>(smem + i) = ld4(a.pack + i);
+    for (int i = threadIdx.x * 4; i < L.CP * L.LDW; i += blockDim.x * 4)
+      *reinterpret_cast<f32x4*>(smem + L.fwd_floats + i) = ld4(a.pack + L.o_W1hT + i);
+    __syncthreads();
+    wp = smem;
+    w1ht = smem + L.fwd_floats;
   }
   const int matf = L.HP * L.LDW;                 // floats per hidden->hidden matrix
   auto copy_mat = [&](int off, float* dst) {     // 8 independent loads in flight per thread
@@ -362,6 +379,7 @@ __global__ __launch_bounds__(64 * kWaves) void mono_bwd_k(MonoArgs a) {
   // every wave of the workgroup calls get_mat at the same points with the same l
   auto get_mat = [&](int l) -> const float* {
     if (RES) return smem + (l - 1) * matf;
+    if (FRES) return smem + L.o_W[l];
     if (resident != l) {
       __syncthreads();                            // previous matrix no longer read
       copy_mat(L.o_W[l], smem);
@@ -378,7 +396,7 @@ __global__ __launch_bounds__(64 * kWaves) void mono_bwd_k(MonoArgs a) {
 
   // bias gradients: per-lane register partials for small nets; for wide nets (register pressure) they are
   // column sums of the staged dpre / Dsum arrays, taken by the host-side row-sum launches instead
-  constexpr bool BREG = HT <= 4;
+  constexpr bool BREG = HT <= 4 && !ONES;
   f32x4 p_wL[HT], p_w1x[HT], p_b[BREG ? NH : 1][BREG ? HT : 1];
   float p_bL = 0.f;
 #pragma unroll
@@ -438,7 +456,11 @@ __global__ __launch_bounds__(64 * kWaves) void mono_bwd_k(MonoArgs a) {
         float* sa = a.SA[l] + row * HP + 4 * q;
         if (gvalid) {                           // a wave re-running the last group must not clobber its owner's rows
 #pragma unroll
-          for (int t = 0; t < HT; ++t) *reinterpret_cast<f32x4*>(sa + 16 * t) = act[t];
+          for (int t = 0; t < HT; ++t) {
+            f32x4 v = act[t];
+            if (ONES && t == HT - 1 && q == 3) v[3] = 1.f;      // column HP-1: bias gradient rides the dW GEMM
+            *reinterpret_cast<f32x4*>(sa + 16 * t) = v;
+          }
         }
         const float* W = UNT ? get_mat(l) : wp + L.o_W[l];
         f32x4 o[HT];
@@ -550,7 +572,7 @@ __global__ __launch_bounds__(64 * kWaves) void mono_bwd_k(MonoArgs a) {
       f32x4 o = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int t = 0; t < HT; ++t) {
-        const f32x4 A = ld4(wp + L.o_W1hT + (16 * mt + j) * L.LDW + 16 * t + 4 * q);
+        const f32x4 A = ld4(w1ht + (16 * mt + j) * L.LDW + 16 * t + 4 * q);
 #pragma unroll
         for (int r = 0; r < 4; ++r) o = mfma(A[r], Ds[t][r], o);
       }
@@ -595,6 +617,7 @@ struct UnpackArgs {
   const float* dWpad[kMaxNH];   // [HP][HP] (out,in) for l = 1..NH-1
   const float* dW1h;            // [HP][c]
   const float* vec;             // [(NH+2)*HP + 4]
+  int ones;                     // hidden-layer bias gradients sit in column HP-1 of dWpad
 };
 
 __global__ void mono_unpack_k(UnpackArgs u) {
@@ -611,7 +634,7 @@ __global__ void mono_unpack_k(UnpackArgs u) {
   for (int l = 1; l < NH; ++l) {
     const int out = N.dims[l + 1], in = N.dims[l];
     for (int k = tid; k < out * in; k += nth) u.gW[l][k] = u.dWpad[l][(k / in) * HP + (k % in)];
-    for (int k = tid; k < out; k += nth) u.gb[l][k] = u.vec[(2 + l) * HP + k];
+    for (int k = tid; k < out; k += nth) u.gb[l][k] = u.ones ? u.dWpad[l][k * HP + HP - 1] : u.vec[(2 + l) * HP + k];
   }
   for (int k = tid; k < N.dims[NH]; k += nth) u.gW[NH][k] = u.vec[k];
   if (tid == 0) u.gb[NH][0] = u.vec[(NH + 2) * HP];
@@ -671,6 +694,16 @@ template <int HT, int NH>
 int launch_bwd_one(const MonoArgs& a, unsigned grid, hipStream_t s) {
   const size_t lds_all = (size_t)a.L.total_floats * sizeof(float);
   const size_t lds_one = (size_t)a.L.HP * a.L.LDW * sizeof(float);
+  if constexpr (HT <= 4 && NH > 1) {
+    if (a.ones) {                               // everything but the transposed hidden matrices resident, two workgroups per CU
+      const size_t lds_res = (size_t)(a.L.fwd_floats + a.L.CP * a.L.LDW) * sizeof(float);
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mono_bwd_k<HT, NH, 4, true>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_res);
+      hipLaunchKernelGGL((mono_bwd_k<HT, NH, 4, true>), dim3(grid), dim3(64 * kWaves), lds_res, s, a);
+      GNF_LAUNCH_CHECK();
+      return 0;
+    }
+  }
   if constexpr (HT <= 4) {                      // whole image resident
     if (lds_all > (size_t)150 * 1024) return GNF_ESHAPE;
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mono_bwd_k<HT, NH, 1>),
@@ -944,6 +977,8 @@ int gnf_monotonic_bwd(const float* pack, const gnf_mono_net* net, const float* x
   a.gz = gz; a.gjac = gjac; a.gx = gx; a.gh = gh; a.g_sb = g_sb; a.g_sd = g_sd; a.g_sc = g_sc;
   for (int l = 1; l < NH; ++l) { a.SA[l] = w + P.o_SA[l]; a.SD[l] = w + P.o_SD[l]; }
   a.Dsum = w + P.o_Dsum; a.part = w + P.o_part; a.NK = (int)NK;
+  a.ones = HT <= 4 && NH > 1;
+  for (int l = 1; l < NH; ++l) a.ones = a.ones && net->dims[l] < HP;
 
   auto rowsum = [&](const float* src, float* out, int64_t Pn, int64_t N, int acc) -> int {
     return gnf_rowsum_launch(src, out, Pn, N, acc, s);
@@ -990,7 +1025,7 @@ int gnf_monotonic_bwd(const float* pack, const gnf_mono_net* net, const float* x
       if ((rc = gnf_gemm_launch(g, ck == 0 ? kSplits : (int)nsp_h, s))) return rc;
     }
     if ((rc = rowsum(a.part, w + P.o_vec, part_rows, vecw, ck > 0))) return rc;
-    if (HT > 4) {                      // bias gradients of wide nets: column sums of the staged arrays
+    if (HT > 4 || a.ones) {            // first-layer bias gradient (and wide nets' others): column sums of staged arrays
       if ((rc = gnf_rowsum_tall_launch(a.Dsum, w + P.o_vec + 2 * HP, groups * 16, HP, 1, w + P.o_rs, s))) return rc;
       if (HT > 10)
         for (int l = 1; l < NH; ++l)
@@ -1008,7 +1043,7 @@ int gnf_monotonic_bwd(const float* pack, const gnf_mono_net* net, const float* x
     u.dWpad[l] = w + P.o_dW[l];
   }
   if ((rc = rowsum(w + P.o_hpart, w + P.o_dW1h, nsp_h, HP * L.c, 0))) return rc;
-  u.dW1h = w + P.o_dW1h; u.vec = w + P.o_vec;
+  u.dW1h = w + P.o_dW1h; u.vec = w + P.o_vec; u.ones = a.ones;
   hipLaunchKernelGGL(mono_unpack_k, dim3(64), dim3(256), 0, s, u);
   GNF_LAUNCH_CHECK();
   return 0;
