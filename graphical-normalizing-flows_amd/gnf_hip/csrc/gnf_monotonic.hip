@@ -313,6 +313,70 @@ __global__ __launch_bounds__(64 * kWaves) void mono_fwd_k(MonoArgs a) {
   }
 }
 
+// Inverse for FEW elements (level-scheduled sampling evaluates a handful of variables per DAG level): the bisection
+// is a chain of 20 dependent quadratures, so with fewer groups than SIMDs the launch is pure latency.  Here the (up to
+// 8) wavefronts of a workgroup share ONE group of 16 elements and split the quadrature nodes (pairs w, w+nw, ...); the
+// partial sums meet in LDS once per bisection step (double-buffered: one barrier per step) and are added in a fixed
+// order, so all wavefronts take identical decisions.  WM as in mono_fwd_k (0 or 1).
+constexpr int kSplitWaves = 8;
+template <int HT, int WM>
+__global__ __launch_bounds__(64 * kSplitWaves) void mono_inv_split_k(MonoArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const MonoLayout& L = a.L;
+  const float* wp = a.pack;
+  float* psum = smem;                            // [2][nw][16]
+  const int nw = blockDim.x >> 6;                // wavefronts sharing the group (<= kSplitWaves)
+  if (WM == 1) {
+    for (int i = threadIdx.x * 4; i < L.fwd_floats; i += blockDim.x * 4)
+      *reinterpret_cast<f32x4*>(smem + i) = ld4(a.pack + i);
+    __syncthreads();
+    wp = smem;
+    psum = smem + L.fwd_floats;
+  }
+  auto getW = [&](int l) -> const float* { return wp + L.o_W[l]; };
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int q = lane >> 4, j = lane & 15;
+  const int64_t ngroups = (a.n + 15) / 16;
+  const float fS = (float)a.S;
+  int buf = 0;
+  for (int64_t grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
+    const int64_t e = grp * 16 + j;
+    const bool valid = e < a.n;
+    const int64_t ec = valid ? e : a.n - 1;
+    const int64_t b = ec / a.d, i = ec - b * a.d;
+    const int64_t hbase = b * a.h_sb + i * a.h_sd;
+    f32x4 c1[HT];
+    cond_bias<HT>(wp, L, a.h, hbase, a.h_sc, q, j, c1);
+    const float h0 = a.h[hbase];
+    const float zt = a.zt[ec];
+    float xmax = 20.f, xmin = -20.f;
+    for (int it = 0; it < 20; ++it) {
+      const float xm = (xmax + xmin) * .5f;
+      const float xT = fS * (xm / fS);
+      float acc = 0.f;
+      for (int k = 2 * wave; k <= a.S; k += 2 * nw) {
+        const int k1 = k + 1;
+        const float wb = k1 <= a.S ? a.ccw[k1] : 0.f;
+        const float xa = xT * (a.cct[k] + 1.f) * .5f;
+        const float xb = k1 <= a.S ? xT * (a.cct[k1] + 1.f) * .5f : xa;
+        float fa, fb;
+        eval2<HT>(wp, L, c1, xa, xb, q, j, fa, fb, getW);
+        acc = fmaf(a.ccw[k], fa, acc);
+        acc = fmaf(wb, fb, acc);
+      }
+      if (q == 0) psum[(buf * nw + wave) * 16 + j] = acc;
+      __syncthreads();
+      const float* ps = psum + buf * nw * 16 + j;
+      float tot = ps[0];
+      for (int w = 1; w < nw; ++w) tot += ps[16 * w];
+      const float zm = tot * xT * .5f + h0;
+      buf ^= 1;
+      if (zm > zt) xmax = xm; else xmin = xm;
+    }
+    if (valid && q == 0 && wave == 0) a.xo[e] = (xmax + xmin) * .5f;
+  }
+}
+
 // ---------------------------------------------------------------------------------------
 // Backward chain kernel.  Vector gradients kept as per-lane partials over the wave's whole
 // persistent loop:  slot 0: d wL, 1: d w1x, 2+l: d b_l (l = 0..NH-1);  + scalar d bL.
@@ -665,6 +729,29 @@ int launch_fwd(const MonoArgs& a, hipStream_t s) {
   const size_t lds_one = (size_t)a.L.HP * a.L.LDW * sizeof(float);
   const bool wlds = lds <= (size_t)150 * 1024;                       // whole forward image resident
   const bool swap = !wlds && a.L.NH > 1 && lds_one <= (size_t)150 * 1024;   // else one matrix at a time, else L1/L2
+  if (INV && !swap && ngroups <= 512 && a.S >= 7) {
+    // fewer groups than a resident wave of workgroups: split the quadrature nodes over the workgroup's wavefronts
+    const int pairs = (a.S + 2) / 2;
+    const int nw = pairs < kSplitWaves ? pairs : kSplitWaves;
+    const size_t lds_split = (wlds ? lds : 0) + 2 * nw * 16 * sizeof(float);
+#define GNF_INV_CASE(HT_)                                                                                      \
+  case HT_:                                                                                                   \
+    if (wlds) {                                                                                               \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mono_inv_split_k<HT_, 1>),                     \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_split);                  \
+      hipLaunchKernelGGL((mono_inv_split_k<HT_, 1>), dim3((unsigned)ngroups), dim3(64 * nw), lds_split, s, a); \
+    } else {                                                                                                  \
+      hipLaunchKernelGGL((mono_inv_split_k<HT_, 0>), dim3((unsigned)ngroups), dim3(64 * nw), lds_split, s, a); \
+    }                                                                                                         \
+    break;
+    switch (HT) {
+      GNF_INV_CASE(2) GNF_INV_CASE(4) GNF_INV_CASE(7) GNF_INV_CASE(10) GNF_INV_CASE(16)
+      default: return GNF_ESHAPE;
+    }
+#undef GNF_INV_CASE
+    GNF_LAUNCH_CHECK();
+    return 0;
+  }
   const int64_t per_cu = ((wlds && lds > (size_t)kLdsBudget / 2) || swap) ? 1 : 2;   // resident workgroups per CU
   if (grid > 256 * per_cu) grid = 256 * per_cu;                      // persistent
 #define GNF_FWD_CASE(HT_)                                                                                     \

@@ -258,7 +258,7 @@ class DAGConditioner(Conditioner):
             return int(nx.dag_longest_path_length(G))
         return 0
 
-    def levels(self, P=None):
+    def levels(self, P=None, with_host=False):
         """Topological generations of the dependency graph (edge j -> i where the importance P[i, j] != 0; default: the
         graph depth() measures, A[i, j] > 0): level k holds the variables whose longest parent chain has length k.
         None if the graph has a cycle."""
@@ -269,7 +269,8 @@ class DAGConditioner(Conditioner):
         frontier = np.nonzero(indeg == 0)[0]
         out, done = [], 0
         while frontier.size:
-            out.append(torch.as_tensor(frontier, dtype=torch.long, device=self.A.device))
+            rows = torch.as_tensor(frontier, dtype=torch.long, device=self.A.device)
+            out.append((rows, tuple(int(r) for r in frontier)) if with_host else rows)   # host copy: no read-back later
             done += frontier.size
             nxt = []
             for j in frontier:
@@ -292,11 +293,11 @@ class DAGConditioner(Conditioner):
             return self.soft_thresholded_A()
         return self.A
 
-    def forward_rows(self, x, rows, P):
+    def forward_rows(self, x, rows, P, host_rows=None):
         """h[:, rows, :] only: the conditioner output of row i depends on x through x * P[i] alone, so a
         level-scheduled inversion evaluates each row exactly once."""
         B, R = x.shape[0], rows.numel()
-        plan = self._sparse_plan(x, rows.tolist(), P)
+        plan = self._sparse_plan(x, rows.tolist() if host_rows is None else host_rows, P)
         if plan is not None:
             return self.embedding_net.sparse_rows(x, P, plan)
         e = x.unsqueeze(1) * P[rows].unsqueeze(0)                        # [B, R, d]

@@ -88,12 +88,12 @@ class NormalizingFlowStep(NormalizingFlow):
         if not (_is_dag(cond) and context is None and self.level_schedule):
             return None
         importance = cond.deterministic_importance()
-        levels = cond.levels(importance) if importance is not None else None
+        levels = cond.levels(importance, with_host=True) if importance is not None else None
         if levels is None:
             return None
         x = torch.zeros_like(z)
-        for rows in levels:
-            h = cond.forward_rows(x, rows, importance)
+        for rows, host_rows in levels:
+            h = cond.forward_rows(x, rows, importance, host_rows)
             x[:, rows] = self.normalizer.inverse_transform(z[:, rows].contiguous(), h, context)
         return x
 
