@@ -870,6 +870,41 @@ def test_sparse_front_parameter_gradients(B):
         assert rel_err(dense[k].cpu(), params[k].grad) < (5e-3 if k.startswith("conv") else GTOL), k
 
 
+def test_sparse_front_reference_golden():
+    """MNIST DAG flow after the DAG phase against the REFERENCE's own numbers (tests/golden/make_golden_frozen.py):
+    z, log-det, loss (sparse forward) and the embedding-net gradients (sparse backward)"""
+    from models import AffineNormalizer
+    from models.NormalizingFlowFactories import buildMNISTNormalizingFlow
+    g0, g = load_golden("flow_mnist_affine_dag"), load_golden("flow_mnist_affine_dag_frozen")
+    flow = buildMNISTNormalizingFlow([1], AffineNormalizer, {}, l1=0., nb_epoch_update=10, hot_encoding=False,
+                                     prior_kernel=2)
+    sd = {k[2:]: v for k, v in g0.items() if k.startswith("p.")}
+    sd["steps.0.conditioner.A"] = flow.steps[0].conditioner.A.detach().clone()
+    flow.load_state_dict(sd)
+    flow = flow.to(DEV)
+    cond = flow.steps[0].conditioner
+    with torch.no_grad():
+        cond.post_process(zero_threshold=.1)
+    x = cu(g0["x"])
+    assert cond._sparse_plan(x, None, cond.deterministic_importance()) is not None
+    z, ld = flow(x)
+    assert rel_err(z.cpu(), g["z"]) < TOL and rel_err(ld.cpu(), g["logdet"]) < TOL
+    loss = flow.loss(z, ld)
+    assert rel_err(loss.detach().cpu(), g["loss"]) < TOL
+    loss.backward()
+    named = dict(flow.named_parameters())
+    n = 0
+    for k, v in g.items():
+        if k.startswith("g.") or k.startswith("g8."):
+            got = named[k.split(".", 1)[1]].grad.cpu()
+            assert rel_err(got[:8] if k.startswith("g8.") else got, v) < GTOL, (k, rel_err(got[:8] if k.startswith("g8.") else got, v))
+            n += 1
+    assert n == 8
+    with torch.no_grad():                              # evaluation path (no saved tensors)
+        z2, ld2 = flow(x)
+    assert rel_err(z2.cpu(), g["z"]) < TOL and rel_err(ld2.cpu(), g["logdet"]) < TOL
+
+
 def test_sparse_front_abi_validation():
     import ctypes
     from gnf_hip import abi

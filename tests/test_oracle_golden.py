@@ -212,6 +212,34 @@ def test_mnist_affine_dag_flow():
     assert int((A.grad != 0).sum()) == idx.shape[0]      # zero entries of A get exactly zero gradient
 
 
+def test_mnist_affine_dag_flow_frozen_gate():
+    """the same flow after the DAG phase (binary frozen A, deterministic product): reference z / log-det / loss and the
+    embedding-net gradients -- the case the sparse masked-image kernels cover"""
+    g0, g = load_golden("flow_mnist_affine_dag"), load_golden("flow_mnist_affine_dag_frozen")
+    p = params_of(g0)
+    A = O.mnist_a_prior(28, 2)
+    pre = "steps.0.conditioner.embedding_net."
+    cnn = {k[len(pre):]: v.clone().requires_grad_(True) for k, v in p.items() if "embedding_net." in k}
+
+    def cond(xx):
+        e = O.dag_masked_inputs(xx, A, False, 0., False, False, 1., None, None, None, False)
+        return O.mnistcnn_forward(e, cnn).view(2, 784, -1)
+    z, ld = O.fc_flow_forward(g0["x"], [(cond, O.affine_forward)])
+    assert rel_err(z, g["z"]) < TOL and rel_err(ld, g["logdet"]) < TOL
+    c = "steps.0.conditioner."
+    closs = O.dag_loss(A, p[c + "alpha"], 784 % 50, p[c + "lambd"], p[c + "c"], p[c + "dag_const"], p[c + "l1_weight"])
+    loss = O.flow_loss(z, ld, closs)
+    assert rel_err(loss, g["loss"]) < TOL
+    loss.backward()
+    n = 0
+    for k, v in g.items():
+        if k.startswith("g.") or k.startswith("g8."):
+            got = cnn[k.split("embedding_net.")[1]].grad
+            assert rel_err(got[:8] if k.startswith("g8.") else got, v) < 1e-4, k
+            n += 1
+    assert n == 8
+
+
 def test_monotonic_flow_jacobian():
     g = load_golden("flow_mono_made_1")
     p = params_of(g)
