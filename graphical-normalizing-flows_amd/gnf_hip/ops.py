@@ -139,7 +139,9 @@ class MLPFn(torch.autograd.Function):
     weight-gradient GEMM."""
 
     @staticmethod
-    def forward(ctx, x, masks, *params):
+    def forward(ctx, x, masks, relu_in, *params):
+        """relu_in: x is itself the output of a ReLU (e.g. fc1 of the sparse embedding front): its gradient leaves this
+        Function already gated by x > 0, fused into the data-gradient GEMM's epilogue."""
         x = x.contiguous()
         n = len(params) // 2
         acts = [x]
@@ -156,6 +158,7 @@ class MLPFn(torch.autograd.Function):
                 acts.append(y)
         ctx.masks = masks
         ctx.n = n
+        ctx.relu_in = bool(relu_in)
         ctx.save_for_backward(*acts, *params)
         return a
 
@@ -173,26 +176,26 @@ class MLPFn(torch.autograd.Function):
             out_f, in_f = W.shape
             a = acts[li]
             M = a.shape[0]
-            if ctx.needs_input_grad[2 + 2 * li]:
+            if ctx.needs_input_grad[3 + 2 * li]:
                 gW = _empty((out_f, in_f), W)
                 gemm(g, (1, out_f), a, (in_f, 1), gW, (in_f, 1), out_f, in_f, M, Cmask=mk, cm_strides=(in_f, 1))
                 grads[2 * li] = gW
-            if ctx.needs_input_grad[3 + 2 * li]:
+            if ctx.needs_input_grad[4 + 2 * li]:
                 grads[2 * li + 1] = colsum(g)
             if li > 0 or ctx.needs_input_grad[0]:
                 ga = _empty((M, in_f), W)
                 gemm(g, (out_f, 1), W, (in_f, 1), ga, (in_f, 1), M, in_f, out_f, Bmask=mk,
-                     gate=(a if li > 0 else None), g_strides=(in_f, 1))
+                     gate=(a if (li > 0 or ctx.relu_in) else None), g_strides=(in_f, 1))
                 g = ga
                 if li == 0:
                     gx = ga
-        return (gx, None, *grads)
+        return (gx, None, None, *grads)
 
 
-def mlp(x, layers, masks=None):
+def mlp(x, layers, masks=None, relu_in=False):
     """layers: list of (weight, bias) parameter pairs."""
     flat = [p for Wb in layers for p in Wb]
-    return MLPFn.apply(x, masks, *flat)
+    return MLPFn.apply(x, masks, relu_in, *flat)
 
 
 # ----------------------------------------------------------------------------- MNISTCNN conv front
@@ -253,6 +256,7 @@ class SparseRows:
         for pos, k in enumerate(order):
             inv[k] = pos
         self.unsort = torch.tensor(inv, dtype=torch.long, device=device)   # position of rows[k] in the sorted order
+        self.order = torch.tensor(order, dtype=torch.long, device=device)  # caller's index of the copy at a sorted position
         counts = [0] * 64
         for g in origin:
             counts[g] += 1
@@ -280,13 +284,15 @@ class MnistSparseFn(torch.autograd.Function):
     the six network parameters only (x and P are treated as constants: frozen deterministic gate)."""
 
     @staticmethod
-    def forward(ctx, x, P, sr, W1, b1, W2, b2, Wfc1, bfc1):
+    def forward(ctx, x, P, sr, pre_gated, W1, b1, W2, b2, Wfc1, bfc1):
+        """pre_gated: the consumer returns the cotangent of h1 already multiplied by [h1 > 0] (MLPFn's relu_in)"""
         x, P = x.contiguous(), P.contiguous()
         ws_ = [t.contiguous() for t in (W1, b1, W2, b2, Wfc1, bfc1)]
         F = Wfc1.shape[0]
         n = sr.R * sr.B
         h1 = _empty((n, F), x)
-        train = any(ctx.needs_input_grad[3:])
+        train = any(ctx.needs_input_grad[4:])
+        ctx.pre_gated = bool(pre_gated)
         pd = _empty((n, 400), x) if train else None
         arg = torch.empty((n, 400), dtype=torch.uint8, device=x.device) if train else None
         nws = abi.load().gnf_mnistcnn_sparse_ws_bytes(n, F)
@@ -305,7 +311,7 @@ class MnistSparseFn(torch.autograd.Function):
         sr = ctx.sr
         F = Wfc1.shape[0]
         n = sr.R * sr.B
-        g = (gh1 * (h1 > 0)).contiguous()
+        g = gh1.contiguous() if ctx.pre_gated else (gh1 * (h1 > 0)).contiguous()
         gW1, gb1, gW2, gb2 = torch.empty_like(W1), torch.empty_like(b1), torch.empty_like(W2), torch.empty_like(b2)
         gWf, gbf = torch.empty_like(Wfc1), _empty((F,), x)
         nws = abi.load().gnf_mnistcnn_sparse_bwd_ws_bytes(n, F, sr.n_kgroups)
@@ -313,11 +319,26 @@ class MnistSparseFn(torch.autograd.Function):
         call("gnf_mnistcnn_sparse_bwd", ptr(x), sr.B, ptr(P), abi.rawptr(sr.pix), sr.R, abi.rawptr(sr.groups),
              sr.max_group_rows, abi.rawptr(sr.kgroups), sr.n_kgroups, abi.rawptr(sr.origin_chunks), ptr(W1), ptr(b1), ptr(W2), ptr(b2), ptr(Wfc1), F, ptr(pd), abi.rawptr(arg), ptr(g),
              ptr(gW1), ptr(gb1), ptr(gW2), ptr(gb2), ptr(gWf), ptr(gbf), abi.rawptr(ws), nws, stream())
-        return None, None, None, gW1, gb1, gW2, gb2, gWf, gbf
+        return None, None, None, None, gW1, gb1, gW2, gb2, gWf, gbf
 
 
-def mnistcnn_sparse_fwd(x, P, sr, W1, b1, W2, b2, Wfc1, bfc1):
-    return MnistSparseFn.apply(x, P, sr, W1, b1, W2, b2, Wfc1, bfc1)
+def mnistcnn_sparse_fwd(x, P, sr, W1, b1, W2, b2, Wfc1, bfc1, pre_gated=False):
+    return MnistSparseFn.apply(x, P, sr, pre_gated, W1, b1, W2, b2, Wfc1, bfc1)
+
+
+class PermuteRowsFn(torch.autograd.Function):
+    """y = x[perm] along dim 0 with a gather in both directions (inv = inverse permutation): autograd's own backward
+    of an index is a sort + scatter-add"""
+
+    @staticmethod
+    def forward(ctx, x, perm, inv):
+        ctx.save_for_backward(inv)
+        return x.index_select(0, perm)
+
+    @staticmethod
+    def backward(ctx, g):
+        inv, = ctx.saved_tensors
+        return g.index_select(0, inv), None, None
 
 
 # ----------------------------------------------------------------------------- DAG gate

@@ -72,9 +72,9 @@ class MNISTCNN(nn.Module):
         that can differ from the all-zero image is convolved.  Differentiable w.r.t. the network's
         parameters (not x, not P)."""
         h1 = ops.mnistcnn_sparse_fwd(x.view(-1, 784), P, sr, self.conv1.weight, self.conv1.bias, self.conv2.weight,
-                                     self.conv2.bias, self.fc1.weight, self.fc1.bias)
-        out = ops.mlp(h1, [(self.fc2.weight, self.fc2.bias)])
-        return out.view(sr.R, sr.B, -1)[sr.unsort].permute(1, 0, 2)
+                                     self.conv2.bias, self.fc1.weight, self.fc1.bias, pre_gated=True)
+        out = ops.mlp(h1, [(self.fc2.weight, self.fc2.bias)], relu_in=True)       # gates h1's cotangent in its epilogue
+        return ops.PermuteRowsFn.apply(out.view(sr.R, sr.B, -1), sr.unsort, sr.order).permute(1, 0, 2)
 
     def forward(self, x, context=None):
         rows = x.shape[0]
