@@ -870,6 +870,33 @@ def test_sparse_front_parameter_gradients(B):
         assert rel_err(dense[k].cpu(), params[k].grad) < (5e-3 if k.startswith("conv") else GTOL), k
 
 
+@pytest.mark.parametrize("B,rows", [(1, [391]), (1, None), (33, [0, 783]), (130, [5, 6, 7, 300])])
+def test_sparse_front_edge_sizes(B, rows):
+    """single sample / single masked copy / batch sizes that are no multiple of anything"""
+    cond = _windowed_conditioner(21, True)
+    x = cu(torch.rand(B, 784))
+    with torch.no_grad():
+        P = cond.deterministic_importance()
+        r = torch.arange(784, device=DEV) if rows is None else torch.tensor(rows, device=DEV)
+        got = cond.forward_rows(x, r, P)
+        cond.sparse_front = False
+        want = cond.forward_rows(x, r, P)
+    assert got.shape == want.shape == (B, r.numel(), 30)
+    assert rel_err(got.cpu(), want.cpu()) < TOL
+    # and the parameter gradients on the same subset
+    cond.sparse_front = True
+    gh = cu(torch.randn(B, r.numel(), 30))
+    grads = []
+    for sparse in (True, False):
+        cond.sparse_front = sparse
+        for p in cond.embedding_net.parameters():
+            p.grad = None
+        (cond.forward_rows(x, r, P) * gh).sum().backward()
+        grads.append([p.grad.clone() for p in cond.embedding_net.parameters()])
+    for a, b, (k, _) in zip(grads[0], grads[1], cond.embedding_net.named_parameters()):
+        assert rel_err(a.cpu(), b.cpu()) < (5e-3 if k.startswith("conv") else GTOL), k
+
+
 def test_sparse_front_reference_golden():
     """MNIST DAG flow after the DAG phase against the REFERENCE's own numbers (tests/golden/make_golden_frozen.py):
     z, log-det, loss (sparse forward) and the embedding-net gradients (sparse backward)"""
