@@ -279,6 +279,15 @@ def main():
             "roofline_other": [v for k, v in kern.items() if k != dom],
             "ops_ms": {k: round(v, 4) for k, v in prof.items()},
         }
+        # HBM bytes per launch of the dominant kernel: PMC counters cannot be read from inside this process, so the
+        # figure is the one rocprofv3 measured for the same kernel at the same per-GPU size (profiles/r01_conv_hbm.json:
+        # 2 x FETCH_SIZE + WRITE_SIZE, separate --pmc passes), next to the algorithmic bytes; null for any other size
+        hbm = {"gnf_mnistcnn_conv_bwd": (1421.7e6, n_elem * (784 * 4 + 2304 * 5 + 784 * 4)),
+               "gnf_mnistcnn_conv_fwd": (1149.1e6, n_elem * (784 * 4 + 2304 * 5))}
+        if dom in hbm and n_elem == 78400:
+            out["roofline"]["traffic"] = hbm[dom][0]
+            out["roofline"]["traffic_algorithmic"] = float(hbm[dom][1])
+            out["roofline"]["traffic_source"] = "profiles/r01_conv_hbm.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE)"
         # MFMA issue slots used by the dominant kernel: v_mfma_f32_16x16x4_f32 issued per image (Winograd form, incl.
         # padding and the conv1 recompute) x 2048 flop / time / peak -- the head-room left, see DESIGN.md section 4
         issued = {"gnf_mnistcnn_conv_bwd": 11 * 12 + 36 * 16 + 11 * 64 + 11 * 16, "gnf_mnistcnn_conv_fwd": 129 + 9 * 64}
