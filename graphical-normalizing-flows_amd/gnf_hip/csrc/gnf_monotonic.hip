@@ -125,6 +125,12 @@ struct MonoArgs {
 };
 
 __device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+// 16 B per lane global -> LDS without passing through registers (global_load_lds_dwordx4): the LDS destination of a
+// wave-instruction is lane-linear, which a contiguous copy is.  Completion: s_waitcnt vmcnt(0) before the barrier.
+__device__ __forceinline__ void glds16(const float* g, float* l) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                   (__attribute__((address_space(3))) void*)l, 16, 0, 0);
+}
 __device__ __forceinline__ f32x4 mfma(float a, float b, f32x4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }
@@ -255,19 +261,8 @@ __global__ __launch_bounds__(64 * kWaves) void mono_fwd_k(MonoArgs a) {
     if (resident != l) {
       const int matf = L.HP * L.LDW, stride = blockDim.x * 4;
       __syncthreads();                            // previous matrix no longer read
-      for (int i0 = threadIdx.x * 4; i0 < matf; i0 += 8 * stride) {     // 8 independent loads in flight per thread
-        f32x4 t[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-          const int i = i0 + u * stride;
-          t[u] = i < matf ? ld4(a.pack + L.o_W[l] + i) : f32x4{0.f, 0.f, 0.f, 0.f};
-        }
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-          const int i = i0 + u * stride;
-          if (i < matf) *reinterpret_cast<f32x4*>(smem + i) = t[u];
-        }
-      }
+      for (int i = threadIdx.x * 4; i < matf; i += stride) glds16(a.pack + L.o_W[l] + i, smem + i);   // all in flight
+      __builtin_amdgcn_s_waitcnt(0);
       __syncthreads();
       resident = l;
     }
@@ -419,21 +414,9 @@ __global__ __launch_bounds__(64 * kWaves, ONES ? 2 : 1) void mono_bwd_k(MonoArgs
     w1ht = smem + L.fwd_floats;
   }
   const int matf = L.HP * L.LDW;                 // floats per hidden->hidden matrix
-  auto copy_mat = [&](int off, float* dst) {     // 8 independent loads in flight per thread
-    const int stride = blockDim.x * 4;
-    for (int i0 = threadIdx.x * 4; i0 < matf; i0 += 8 * stride) {
-      f32x4 t[8];
-#pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        const int i = i0 + u * stride;
-        t[u] = i < matf ? ld4(a.pack + off + i) : f32x4{0.f, 0.f, 0.f, 0.f};
-      }
-#pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        const int i = i0 + u * stride;
-        if (i < matf) *reinterpret_cast<f32x4*>(dst + i) = t[u];
-      }
-    }
+  auto copy_mat = [&](int off, float* dst) {     // every 1 KB piece in flight at once, no staging registers
+    for (int i = threadIdx.x * 4; i < matf; i += blockDim.x * 4) glds16(a.pack + off + i, dst + i);
+    __builtin_amdgcn_s_waitcnt(0);
   };
   if (RES) {
     for (int l = 1; l < NH; ++l) copy_mat(L.o_W[l], smem + (l - 1) * matf);
