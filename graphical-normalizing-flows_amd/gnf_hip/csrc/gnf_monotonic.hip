@@ -28,6 +28,7 @@
 // the split-K fp32 MFMA GEMM (gnf_gemm.hip) contracts them, chunk by chunk.
 #include "gnf_common.h"
 #include "gnf_gemm.h"
+#include <cstdlib>
 
 namespace {
 
@@ -122,6 +123,8 @@ struct MonoArgs {
   int64_t e0, ecount;                   // element chunk [e0, e0+ecount)
   int NK;                               // node slots per group (S+2 rounded up to even)
   int ones;                             // backward: bias gradients of the hidden layers via a ones column (see mono_bwd_k)
+  int indw;                             // backward: weight gradients accumulated in the chain kernel (narrow nets)
+  float* wpart;                         // [workgroups * kWaves][(NH-1) * HP * HP] accumulator rows of that variant
 };
 
 __device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
@@ -383,8 +386,14 @@ __global__ __launch_bounds__(64 * kSplitWaves) void mono_inv_split_k(MonoArgs a)
 // HP-1, so the weight-gradient GEMM returns the bias gradient in that column and the 3 x HT x 4 bias partial registers
 // go away -- together with reading W^T out of the untransposed LDS-resident matrices (WMODE 4, 54 KB instead of the
 // 89 KB image with transposes) that lets two workgroups share a CU (2 wavefronts per SIMD).
-template <int HT, int NH, int WMODE, bool ONES = false>
-__global__ __launch_bounds__(64 * kWaves, ONES ? 2 : 1) void mono_bwd_k(MonoArgs a) {
+// INDW (narrow nets, WMODE 1): nothing is staged in HBM at all.  Each wavefront keeps the layer inputs and the dpre of
+// its 16 elements in LDS, element-major, reads them back as MFMA operands with K = the 16 elements, and carries the
+// (NH-1) x HP x HP weight-gradient accumulators in registers for its whole persistent loop (one wavefront per SIMD:
+// 512 registers); the constant-1 column gives the bias gradients as with ONES.
+constexpr int kTS = 80;             // row pitch of the element-major LDS tiles: == 16 mod 64 banks -> conflict-free operand reads
+template <int HT, int NH, int WMODE, bool ONES = false, bool INDW = false>
+__global__ __launch_bounds__(64 * kWaves, (ONES && !INDW) ? 2 : 1) void mono_bwd_k(MonoArgs a) {
+  static_assert(!INDW || (ONES && WMODE == 1 && HT <= 4), "in-kernel weight gradients: narrow nets, resident image");
   extern __shared__ __attribute__((aligned(16))) float smem[];
   // WMODE 0: weights from L2.  1: the whole pack (incl. transposes) in LDS (narrow nets).  2: ONE hidden->hidden matrix in
   // LDS at a time, swapped by the workgroup.  3: all hidden->hidden matrices resident in LDS.  Modes 2 and 3 keep only
@@ -443,7 +452,7 @@ __global__ __launch_bounds__(64 * kWaves, ONES ? 2 : 1) void mono_bwd_k(MonoArgs
 
   // bias gradients: per-lane register partials for small nets; for wide nets (register pressure) they are
   // column sums of the staged dpre / Dsum arrays, taken by the host-side row-sum launches instead
-  constexpr bool BREG = HT <= 4 && !ONES;
+  constexpr bool BREG = HT <= 4 && !ONES && !INDW;
   f32x4 p_wL[HT], p_w1x[HT], p_b[BREG ? NH : 1][BREG ? HT : 1];
   float p_bL = 0.f;
 #pragma unroll
@@ -454,6 +463,20 @@ __global__ __launch_bounds__(64 * kWaves, ONES ? 2 : 1) void mono_bwd_k(MonoArgs
 #pragma unroll
       for (int l = 0; l < NH; ++l) p_b[l][t] = p_wL[t];
     }
+  }
+
+  // INDW: weight-gradient accumulators dW_l[out tile ti][in tile tn] (D layout: out = 16 ti + 4q + r, in = 16 tn + j) and
+  // this wavefront's element-major tiles behind the weight image: inputs of layers 1..NH-1, then one dpre tile
+  f32x4 accW[INDW ? NH - 1 : 1][INDW ? HT : 1][INDW ? HT : 1];
+  float* tiles = smem + (L.total_floats + 3) / 4 * 4 + wave * (NH * 16 * kTS);
+  if constexpr (INDW) {
+#pragma unroll
+    for (int l = 0; l < NH - 1; ++l)
+#pragma unroll
+      for (int ti = 0; ti < HT; ++ti)
+#pragma unroll
+        for (int tn = 0; tn < HT; ++tn) accW[l][ti][tn] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int i = lane; i < NH * 16 * kTS; i += 64) tiles[i] = 0.f;
   }
 
   // all waves of a workgroup run the same number of iterations (SWAP needs workgroup barriers inside); a wave
@@ -500,13 +523,23 @@ __global__ __launch_bounds__(64 * kWaves, ONES ? 2 : 1) void mono_bwd_k(MonoArgs
       }
 #pragma unroll
       for (int l = 1; l < NH; ++l) {
-        float* sa = a.SA[l] + row * HP + 4 * q;
-        if (gvalid) {                           // a wave re-running the last group must not clobber its owner's rows
+        if constexpr (INDW) {                   // layer input, element-major, into this wavefront's LDS tile
+          float* ta = tiles + (l - 1) * 16 * kTS + j * kTS + 4 * q;
 #pragma unroll
           for (int t = 0; t < HT; ++t) {
             f32x4 v = act[t];
-            if (ONES && t == HT - 1 && q == 3) v[3] = 1.f;      // column HP-1: bias gradient rides the dW GEMM
-            *reinterpret_cast<f32x4*>(sa + 16 * t) = v;
+            if (t == HT - 1 && q == 3) v[3] = 1.f;              // column HP-1 = 1: dW_l[:, HP-1] is the bias gradient
+            *reinterpret_cast<f32x4*>(ta + 16 * t) = v;
+          }
+        } else {
+          float* sa = a.SA[l] + row * HP + 4 * q;
+          if (gvalid) {                         // a wave re-running the last group must not clobber its owner's rows
+#pragma unroll
+            for (int t = 0; t < HT; ++t) {
+              f32x4 v = act[t];
+              if (ONES && t == HT - 1 && q == 3) v[3] = 1.f;    // column HP-1: bias gradient rides the dW GEMM
+              *reinterpret_cast<f32x4*>(sa + 16 * t) = v;
+            }
           }
         }
         const float* W = UNT ? get_mat(l) : wp + L.o_W[l];
@@ -560,11 +593,34 @@ __global__ __launch_bounds__(64 * kWaves, ONES ? 2 : 1) void mono_bwd_k(MonoArgs
       // ---- hidden->hidden layers, top down
 #pragma unroll
       for (int l = NH - 1; l >= 1; --l) {
-        float* sd = a.SD[l] + row * HP + 4 * q;
+        if constexpr (INDW) {
+          // dW_l[out][in] += sum over the 16 elements of dpre_l[elem][out] * input_l[elem][in]: K = elements, both
+          // operands read back element-major (lane (q, j): element 4 s + q, unit 16 tile + j).  A wave re-running the
+          // last group has zero cotangents, so it adds nothing.
+          float* td = tiles + (NH - 1) * 16 * kTS;
 #pragma unroll
-        for (int t = 0; t < HT; ++t) {
-          if (gvalid) *reinterpret_cast<f32x4*>(sd + 16 * t) = dp[t];
-          if constexpr (BREG) p_b[l][t] += dp[t];
+          for (int t = 0; t < HT; ++t) *reinterpret_cast<f32x4*>(td + j * kTS + 16 * t + 4 * q) = dp[t];
+          const float* ta = tiles + (l - 1) * 16 * kTS;
+#pragma unroll
+          for (int sK = 0; sK < 4; ++sK) {
+            float fa[HT], fb[HT];
+#pragma unroll
+            for (int t = 0; t < HT; ++t) {
+              fa[t] = td[(4 * sK + q) * kTS + 16 * t + j];
+              fb[t] = ta[(4 * sK + q) * kTS + 16 * t + j];
+            }
+#pragma unroll
+            for (int ti = 0; ti < HT; ++ti)
+#pragma unroll
+              for (int tn = 0; tn < HT; ++tn) accW[l - 1][ti][tn] = mfma(fa[ti], fb[tn], accW[l - 1][ti][tn]);
+          }
+        } else {
+          float* sd = a.SD[l] + row * HP + 4 * q;
+#pragma unroll
+          for (int t = 0; t < HT; ++t) {
+            if (gvalid) *reinterpret_cast<f32x4*>(sd + 16 * t) = dp[t];
+            if constexpr (BREG) p_b[l][t] += dp[t];
+          }
         }
         const float* WT = UNT ? get_mat(l) : wp + L.o_WT[l];      // UNT: the untransposed matrix, read transposed below
         f32x4 da[HT];
@@ -654,6 +710,17 @@ __global__ __launch_bounds__(64 * kWaves, ONES ? 2 : 1) void mono_bwd_k(MonoArgs
         }
       }
     }
+  if constexpr (INDW) {
+    float* wrow = a.wpart + ((int64_t)blockIdx.x * kWaves + wave) * ((NH - 1) * HP * HP);
+#pragma unroll
+    for (int l = 0; l < NH - 1; ++l)
+#pragma unroll
+      for (int ti = 0; ti < HT; ++ti)
+#pragma unroll
+        for (int tn = 0; tn < HT; ++tn)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) wrow[l * HP * HP + (16 * ti + 4 * q + r) * HP + 16 * tn + j] = accW[l][ti][tn][r];
+  }
   const float vbl = jsum(p_bL);
   if (lane == 0) { prow[(NH + 2) * HP] = vbl; prow[(NH + 2) * HP + 1] = 0.f; prow[(NH + 2) * HP + 2] = 0.f; prow[(NH + 2) * HP + 3] = 0.f; }
 }
@@ -765,6 +832,15 @@ int launch_bwd_one(const MonoArgs& a, unsigned grid, hipStream_t s) {
   const size_t lds_all = (size_t)a.L.total_floats * sizeof(float);
   const size_t lds_one = (size_t)a.L.HP * a.L.LDW * sizeof(float);
   if constexpr (HT <= 4 && NH > 1) {
+    if (a.indw) {                               // whole image + per-wavefront element-major tiles, one workgroup per CU
+      const size_t lds_in = ((size_t)(a.L.total_floats + 3) / 4 * 4 + (size_t)kWaves * NH * 16 * kTS) * sizeof(float);
+      if (lds_in > (size_t)kLdsBudget) return GNF_ESHAPE;
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mono_bwd_k<HT, NH, 1, true, true>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_in);
+      hipLaunchKernelGGL((mono_bwd_k<HT, NH, 1, true, true>), dim3(grid), dim3(64 * kWaves), lds_in, s, a);
+      GNF_LAUNCH_CHECK();
+      return 0;
+    }
     if (a.ones) {                               // everything but the transposed hidden matrices resident, two workgroups per CU
       const size_t lds_res = (size_t)(a.L.fwd_floats + a.L.CP * a.L.LDW) * sizeof(float);
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mono_bwd_k<HT, NH, 4, true>),
@@ -924,11 +1000,23 @@ constexpr int64_t kWsTarget = 6ll << 30;      // staging budget the ws_bytes que
 struct BwdPlan {
   int64_t chunk_elems;      // elements per chain-kernel launch (multiple of 16)
   int64_t o_SA[kMaxNH], o_SD[kMaxNH], o_Dsum, o_part, o_gpart[kMaxNH], o_bpart[kMaxNH], o_hpart, o_dW[kMaxNH], o_dW1h,
-      o_vec, o_rs;
+      o_vec, o_rs, o_wpart;
   int64_t total_floats;
 };
 
-BwdPlan plan_bwd(const MonoLayout& L, int S, int64_t n, int64_t ws_floats) {
+// narrow nets whose hidden widths leave a padding column (and whose image + tiles fit the LDS): the chain kernel
+// accumulates the hidden-layer weight gradients itself, nothing but Dsum is staged
+bool use_indw(const gnf_mono_net* net, const MonoLayout& L) {
+  if (L.HT > 4 || L.NH < 2) return false;
+  for (int l = 1; l < L.NH; ++l)
+    if (net->dims[l] >= L.HP) return false;
+  const size_t lds = ((size_t)(L.total_floats + 3) / 4 * 4 + (size_t)kWaves * L.NH * 16 * kTS) * sizeof(float);
+  static const bool off = getenv("GNF_MONO_INDW") && getenv("GNF_MONO_INDW")[0] == '0';     // A/B switch (measurement)
+  return lds <= (size_t)160 * 1024 && !off;
+}
+constexpr unsigned kInDwGrid = 256;           // one workgroup per CU (512 registers per wavefront)
+
+BwdPlan plan_bwd(const MonoLayout& L, int S, int64_t n, int64_t ws_floats, bool indw = false) {
   BwdPlan P;
   const int64_t HP = L.HP, NK = (S + 2 + 1) / 2 * 2;
   const int64_t vecw = (L.NH + 2) * HP + 4;
@@ -942,7 +1030,9 @@ BwdPlan plan_bwd(const MonoLayout& L, int S, int64_t n, int64_t ws_floats) {
   P.o_dW1h = fixed; fixed += HP * L.c;
   P.o_vec = fixed; fixed += vecw;
   P.o_rs = fixed; fixed += (int64_t)kRowsumChunks * HP;     // scratch of the tall row-sums (bias gradients)
-  const int64_t per_elem = (int64_t)(L.NH - 1) * 2 * NK * HP + HP;     // SA+SD per hidden layer, Dsum
+  P.o_wpart = fixed;
+  if (indw) fixed += (int64_t)kInDwGrid * kWaves * (L.NH - 1) * HP * HP;
+  const int64_t per_elem = indw ? HP : (int64_t)(L.NH - 1) * 2 * NK * HP + HP;     // SA+SD per hidden layer, Dsum
   int64_t ce = (n + 15) / 16 * 16;
   if (ws_floats > 0) {
     const int64_t room = ws_floats - fixed;
@@ -951,7 +1041,10 @@ BwdPlan plan_bwd(const MonoLayout& L, int S, int64_t n, int64_t ws_floats) {
   }
   P.chunk_elems = ce;
   int64_t o = fixed;
-  for (int l = 1; l < L.NH; ++l) { P.o_SA[l] = o; o += ce * NK * HP; P.o_SD[l] = o; o += ce * NK * HP; }
+  for (int l = 1; l < L.NH; ++l) {
+    P.o_SA[l] = o; if (!indw) o += ce * NK * HP;
+    P.o_SD[l] = o; if (!indw) o += ce * NK * HP;
+  }
   P.o_Dsum = o; o += ce * HP;
   P.total_floats = o;
   return P;
@@ -1011,11 +1104,12 @@ int64_t gnf_monotonic_bwd_ws_bytes(const gnf_mono_net* net, int S, int64_t B, in
   const int HT = pick_ht(net);
   if (HT < 0) return GNF_ESHAPE;
   const MonoLayout L = make_layout(HT, net->nl - 1, net->dims[0] - 1);
-  const BwdPlan full = plan_bwd(L, S, B * d, 0);
+  const bool indw = use_indw(net, L);
+  const BwdPlan full = plan_bwd(L, S, B * d, 0, indw);
   const int64_t want = full.total_floats * (int64_t)sizeof(float);
   if (want <= kWsTarget) return want;
   // bounded staging: at least one 16-element group per persistent wavefront
-  const BwdPlan fixed_only = plan_bwd(L, S, 16, 0);
+  const BwdPlan fixed_only = plan_bwd(L, S, 16, 0, indw);
   const int64_t min_bytes = fixed_only.total_floats * (int64_t)sizeof(float);
   return kWsTarget > min_bytes ? kWsTarget : min_bytes;
 }
@@ -1035,7 +1129,8 @@ int gnf_monotonic_bwd(const float* pack, const gnf_mono_net* net, const float* x
   hipStream_t s = (hipStream_t)stream;
   const MonoLayout L = make_layout(HT, NH, net->dims[0] - 1);
   const int64_t n = B * d;
-  const BwdPlan P = plan_bwd(L, S, n, ws_bytes / (int64_t)sizeof(float));
+  const bool indw = use_indw(net, L);
+  const BwdPlan P = plan_bwd(L, S, n, ws_bytes / (int64_t)sizeof(float), indw);
   if (P.chunk_elems < 16) return GNF_EWS;
   float* w = (float*)ws;
   const int64_t HP = L.HP, NK = (S + 2 + 1) / 2 * 2;
@@ -1049,23 +1144,29 @@ int gnf_monotonic_bwd(const float* pack, const gnf_mono_net* net, const float* x
   a.Dsum = w + P.o_Dsum; a.part = w + P.o_part; a.NK = (int)NK;
   a.ones = HT <= 4 && NH > 1;
   for (int l = 1; l < NH; ++l) a.ones = a.ones && net->dims[l] < HP;
+  a.indw = indw;
+  a.wpart = w + P.o_wpart;
+  const unsigned bwd_grid = indw ? kInDwGrid : kBwdGrid;
 
   auto rowsum = [&](const float* src, float* out, int64_t Pn, int64_t N, int acc) -> int {
     return gnf_rowsum_launch(src, out, Pn, N, acc, s);
   };
   const int64_t nchunks = (n + P.chunk_elems - 1) / P.chunk_elems;
-  const int64_t part_rows = (int64_t)kBwdGrid * kWaves;
+  const int64_t part_rows = (int64_t)bwd_grid * kWaves;
   int64_t nsp_w = 1, nsp_h = 1;
   int rc = 0;
   for (int64_t ck = 0; ck < nchunks; ++ck) {
     a.e0 = ck * P.chunk_elems;
     a.ecount = n - a.e0 < P.chunk_elems ? n - a.e0 : P.chunk_elems;
-    if ((rc = launch_bwd(a, kBwdGrid, s))) return rc;
+    if ((rc = launch_bwd(a, bwd_grid, s))) return rc;
     const int64_t groups = (a.ecount + 15) / 16;
     const int64_t rows = groups * NK * 16;
     const int accum = ck > 0 ? GNF_GEMM_ACCUM : 0;     // chunk 0 is the largest: it defines the split count
     // d W_l (+)= dpre_l^T * act_{l-1}   (split-K partials, accumulated across chunks)
-    for (int l = 1; l < NH; ++l) {
+    if (indw) {                        // the chain kernel's accumulator rows -> dW (accumulated across chunks)
+      if ((rc = rowsum(a.wpart, w + P.o_dW[1], part_rows, (int64_t)(NH - 1) * HP * HP, ck > 0))) return rc;
+    }
+    for (int l = 1; l < NH && !indw; ++l) {
       if (HT == 7 || HT == 10) {       // wide nets: one pass over the staged rows, bias gradient fused
         const int64_t rpw = ((rows + kDwGrid - 1) / kDwGrid + kDwRows - 1) / kDwRows * kDwRows;
         nsp_w = kDwGrid;
@@ -1109,7 +1210,7 @@ int gnf_monotonic_bwd(const float* pack, const gnf_mono_net* net, const float* x
   u.net = *net; u.L = L;
   for (int l = 0; l <= NH; ++l) { u.gW[l] = gW[l]; u.gb[l] = gb[l]; if (!gW[l] || !gb[l]) return GNF_EINVAL; }
   for (int l = 1; l < NH; ++l) {
-    if ((rc = rowsum(w + P.o_gpart[l], w + P.o_dW[l], nsp_w, HP * HP, 0))) return rc;
+    if (!indw && (rc = rowsum(w + P.o_gpart[l], w + P.o_dW[l], nsp_w, HP * HP, 0))) return rc;
     u.dWpad[l] = w + P.o_dW[l];
   }
   if ((rc = rowsum(w + P.o_hpart, w + P.o_dW1h, nsp_h, HP * L.c, 0))) return rc;
