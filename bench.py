@@ -254,7 +254,7 @@ def main():
                                       2. * (2 * CONV2 + 2 * CONV1) * n_elem),
             "gnf_mnistcnn_conv_fwd": ("cnn_fwd_wino_k (conv1+ReLU, conv2 as Winograd F(2x2,3x3) on MFMA, maxpool)", 2. * (CONV1 + CONV2) * n_elem),
             "gnf_monotonic_fwd": ("mono_fwd_k<HT=4> (Clenshaw-Curtis quadrature)", 2. * macs * (S_NODES + 2) * n_elem),
-            "gnf_monotonic_bwd": ("mono_bwd_k<4,3> + weight-gradient GEMMs", 4. * macs * (S_NODES + 2) * n_elem),
+            "gnf_monotonic_bwd": ("mono_bwd_k<4,3> (weight gradients accumulated in-kernel) + unpack", 4. * macs * (S_NODES + 2) * n_elem),
         }
         kern = {}
         for k, (label, fl) in work.items():
