@@ -390,7 +390,15 @@ __global__ __launch_bounds__(64 * kSplitWaves) void mono_inv_split_k(MonoArgs a)
 // its 16 elements in LDS, element-major, reads them back as MFMA operands with K = the 16 elements, and carries the
 // (NH-1) x HP x HP weight-gradient accumulators in registers for its whole persistent loop (one wavefront per SIMD:
 // 512 registers); the constant-1 column gives the bias gradients as with ONES.
-constexpr int kTS = 80;             // row pitch of the element-major LDS tiles: == 16 mod 64 banks -> conflict-free operand reads
+constexpr int kTS = 64;             // row pitch of the element-major LDS tiles (no padding: XOR-swizzled, see tile_w / tile_r)
+// Element-major tile of 16 elements x 64 units.  A lane (q, j) of the MFMA C/D layout WRITES units 16t+4q..+3 of element j
+// (one b128) and later READS, as an MFMA operand with K = elements, unit 16t+j of element 4s+q (one b32).  Unit u of
+// element e is stored at column 16 ((u>>4) ^ (e&3)) + 4 (((u>>2)&3) ^ (e>>2)) + (u&3): the 16 lanes of a write group
+// then cover all 64 banks, and so do the 64 lanes of an operand read.
+__device__ __forceinline__ int tile_w(int j, int t, int q) { return j * kTS + 16 * (t ^ (j & 3)) + 4 * (q ^ (j >> 2)); }
+__device__ __forceinline__ int tile_r(int s, int q, int t, int j) {
+  return (4 * s + q) * kTS + 16 * (t ^ q) + 4 * ((j >> 2) ^ s) + (j & 3);
+}
 template <int HT, int NH, int WMODE, bool ONES = false, bool INDW = false>
 __global__ __launch_bounds__(64 * kWaves, (ONES && !INDW) ? 2 : 1) void mono_bwd_k(MonoArgs a) {
   static_assert(!INDW || (ONES && WMODE == 1 && HT <= 4), "in-kernel weight gradients: narrow nets, resident image");
@@ -518,18 +526,18 @@ __global__ __launch_bounds__(64 * kWaves, (ONES && !INDW) ? 2 : 1) void mono_bwd
         for (int r = 0; r < 4; ++r) {
           const float pre = fmaf(wx[r], xk, c1[t][r]);
           act[t][r] = fmaxf(pre, 0.f);
-          if (pre > 0.f) msk[0] |= 1ull << (4 * t + r);
+          if (!INDW && pre > 0.f) msk[0] |= 1ull << (4 * t + r);
         }
       }
 #pragma unroll
       for (int l = 1; l < NH; ++l) {
         if constexpr (INDW) {                   // layer input, element-major, into this wavefront's LDS tile
-          float* ta = tiles + (l - 1) * 16 * kTS + j * kTS + 4 * q;
+          float* ta = tiles + (l - 1) * 16 * kTS;
 #pragma unroll
           for (int t = 0; t < HT; ++t) {
             f32x4 v = act[t];
             if (t == HT - 1 && q == 3) v[3] = 1.f;              // column HP-1 = 1: dW_l[:, HP-1] is the bias gradient
-            *reinterpret_cast<f32x4*>(ta + 16 * t) = v;
+            *reinterpret_cast<f32x4*>(ta + tile_w(j, t, q)) = v;
           }
         } else {
           float* sa = a.SA[l] + row * HP + 4 * q;
@@ -563,7 +571,7 @@ __global__ __launch_bounds__(64 * kWaves, (ONES && !INDW) ? 2 : 1) void mono_bwd
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             act[t][r] = fmaxf(o[t][r], 0.f);
-            if (o[t][r] > 0.f) msk[l] |= 1ull << (4 * t + r);
+            if (!INDW && o[t][r] > 0.f) msk[l] |= 1ull << (4 * t + r);
           }
       }
       float s = 0.f;
@@ -587,7 +595,10 @@ __global__ __launch_bounds__(64 * kWaves, (ONES && !INDW) ? 2 : 1) void mono_bwd
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           p_wL[t][r] = fmaf(dpl, act[t][r], p_wL[t][r]);
-          dp[t][r] = ((msk[NH - 1] >> (4 * t + r)) & 1ull) ? wl[r] * dpl : 0.f;
+          // INDW: the ReLU gates come from the activations themselves (registers here, the LDS tiles below) instead
+          // of 64-bit masks built and tested bit by bit
+          const bool on = INDW ? act[t][r] > 0.f : (bool)((msk[NH - 1] >> (4 * t + r)) & 1ull);
+          dp[t][r] = on ? wl[r] * dpl : 0.f;
         }
       }
       // ---- hidden->hidden layers, top down
@@ -599,15 +610,15 @@ __global__ __launch_bounds__(64 * kWaves, (ONES && !INDW) ? 2 : 1) void mono_bwd
           // last group has zero cotangents, so it adds nothing.
           float* td = tiles + (NH - 1) * 16 * kTS;
 #pragma unroll
-          for (int t = 0; t < HT; ++t) *reinterpret_cast<f32x4*>(td + j * kTS + 16 * t + 4 * q) = dp[t];
+          for (int t = 0; t < HT; ++t) *reinterpret_cast<f32x4*>(td + tile_w(j, t, q)) = dp[t];
           const float* ta = tiles + (l - 1) * 16 * kTS;
 #pragma unroll
           for (int sK = 0; sK < 4; ++sK) {
             float fa[HT], fb[HT];
 #pragma unroll
             for (int t = 0; t < HT; ++t) {
-              fa[t] = td[(4 * sK + q) * kTS + 16 * t + j];
-              fb[t] = ta[(4 * sK + q) * kTS + 16 * t + j];
+              fa[t] = td[tile_r(sK, q, t, j)];
+              fb[t] = ta[tile_r(sK, q, t, j)];
             }
 #pragma unroll
             for (int ti = 0; ti < HT; ++ti)
@@ -645,7 +656,19 @@ __global__ __launch_bounds__(64 * kWaves, (ONES && !INDW) ? 2 : 1) void mono_bwd
 #pragma unroll
         for (int t = 0; t < HT; ++t)
 #pragma unroll
-          for (int r = 0; r < 4; ++r) dp[t][r] = ((msk[l - 1] >> (4 * t + r)) & 1ull) ? da[t][r] : 0.f;
+          for (int r = 0; r < 4; ++r) {
+            if constexpr (INDW) continue;
+            dp[t][r] = ((msk[l - 1] >> (4 * t + r)) & 1ull) ? da[t][r] : 0.f;
+          }
+        if constexpr (INDW) {                   // gate = (input of layer l) > 0, read back from its tile in the layout it was written in
+          const float* tg = tiles + (l - 1) * 16 * kTS;
+#pragma unroll
+          for (int t = 0; t < HT; ++t) {
+            const f32x4 g = *reinterpret_cast<const f32x4*>(tg + tile_w(j, t, q));
+#pragma unroll
+            for (int r = 0; r < 4; ++r) dp[t][r] = g[r] > 0.f ? da[t][r] : 0.f;
+          }
+        }
       }
       // ---- first layer: rank-1 in x_k, node-independent in h
       float sx = 0.f;
