@@ -54,25 +54,37 @@ __global__ void dag_gate_tab_k(const float* __restrict__ A, float* __restrict__ 
 
 struct Noise { float a, b; };
 
-// gate_mode 1: two uniforms in (0,1); gate_mode 2: one standard normal (Box-Muller on the Philox pair).
-__device__ __forceinline__ Noise draw(int gate_mode, const float* u1, const float* u2, uint64_t seed, uint64_t offset,
-                                      int64_t idx) {
-  Noise n{0.f, 0.f};
-  if (gate_mode == 0) return n;
+// Noise of the two adjacent columns 2 jp, 2 jp + 1 of row (b*d + i).  gate_mode 1: two uniforms in (0,1) each;
+// gate_mode 2: one standard normal each (Box-Muller on a Philox pair).  One Philox4x32-10 call -- the dominant VALU
+// cost of these kernels -- yields four 32-bit words = exactly what two columns need, so the counter is the column
+// PAIR (row * ceil(d/2) + jp); forward and backward use the same mapping.
+__device__ __forceinline__ void draw2(int gate_mode, const float* u1, const float* u2, uint64_t seed, uint64_t offset,
+                                      int64_t row, int64_t jp, int64_t d, Noise (&n)[2]) {
+  n[0] = Noise{0.f, 0.f};
+  n[1] = n[0];
+  if (gate_mode == 0) return;
+  const int64_t j0 = 2 * jp;
   if (u1) {
-    n.a = u1[idx];
-    n.b = (gate_mode == 1) ? u2[idx] : 0.f;
-    return n;
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+      if (j0 + h < d) {
+        n[h].a = u1[row * d + j0 + h];
+        n[h].b = (gate_mode == 1) ? u2[row * d + j0 + h] : 0.f;
+      }
+    return;
   }
+  const uint64_t idx = (uint64_t)(row * ((d + 1) / 2) + jp);
   uint32_t r[4];
-  philox4x32_10((uint32_t)idx, (uint32_t)((uint64_t)idx >> 32), (uint32_t)offset, (uint32_t)(offset >> 32),
+  philox4x32_10((uint32_t)idx, (uint32_t)(idx >> 32), (uint32_t)offset, (uint32_t)(offset >> 32),
                 (uint32_t)seed, (uint32_t)(seed >> 32), r);
-  // 24-bit uniforms centred in their cell: never exactly 0 or 1
-  const float ua = ((float)(r[0] >> 8) + .5f) * (1.0f / 16777216.0f);
-  const float ub = ((float)(r[1] >> 8) + .5f) * (1.0f / 16777216.0f);
-  if (gate_mode == 1) { n.a = ua; n.b = ub; }
-  else n.a = sqrtf(-2.f * logf(ua)) * cosf(6.283185307179586f * ub);
-  return n;
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    // 24-bit uniforms centred in their cell: never exactly 0 or 1
+    const float ua = ((float)(r[2 * h] >> 8) + .5f) * (1.0f / 16777216.0f);
+    const float ub = ((float)(r[2 * h + 1] >> 8) + .5f) * (1.0f / 16777216.0f);
+    if (gate_mode == 1) { n[h].a = ua; n[h].b = ub; }
+    else n[h].a = sqrtf(-2.f * logf(ua)) * cosf(6.283185307179586f * ub);
+  }
 }
 
 // Gumbel-softmax gate from the table entry ET and the two uniforms
@@ -88,54 +100,66 @@ struct GateArgs {
   float* ws; float* gA; float* gx; int64_t B, d, chunk;
 };
 
-// one workgroup row per (b,i): blockIdx.x = b*d + i, blockIdx.y tiles the d columns
+// one workgroup row per (b,i): blockIdx.x = b*d + i, blockIdx.y tiles the ceil(d/2) column pairs
 __global__ void dag_gate_fwd_k(GateArgs a) {
   const int64_t bi = blockIdx.x;
-  const int64_t j = (int64_t)blockIdx.y * blockDim.x + threadIdx.x;
-  if (j >= a.d) return;
-  const int64_t b = bi / a.d, i = bi - b * a.d;
-  const int64_t ij = i * a.d + j, dd = a.d * a.d;
-  const float p = a.tab[ij];
-  const float xv = a.x[b * a.d + j];
-  float out;
-  if (a.gate_mode == 0) {
-    out = xv * p;
-  } else {
-    const Noise n = draw(a.gate_mode, a.u1, a.u2, a.seed, a.offset, bi * a.d + j);
-    out = a.gate_mode == 1 ? xv * gumbel_gate(a.tab[2 * dd + ij], n, a.T) : p * (xv + n.a * fabsf(1.f - p));
+  const int64_t jp = (int64_t)blockIdx.y * blockDim.x + threadIdx.x;
+  if (2 * jp >= a.d) return;
+  const int64_t b = bi / a.d, i = bi - b * a.d, dd = a.d * a.d;
+  Noise n[2];
+  draw2(a.gate_mode, a.u1, a.u2, a.seed, a.offset, bi, jp, a.d, n);
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const int64_t j = 2 * jp + h;
+    if (j >= a.d) break;
+    const int64_t ij = i * a.d + j;
+    const float p = a.tab[ij];
+    const float xv = a.x[b * a.d + j];
+    float out;
+    if (a.gate_mode == 0) out = xv * p;
+    else out = a.gate_mode == 1 ? xv * gumbel_gate(a.tab[2 * dd + ij], n[h], a.T) : p * (xv + n[h].a * fabsf(1.f - p));
+    a.e[bi * a.ld_e + j] = out;
+    if (a.hot) a.e[bi * a.ld_e + a.d + j] = (j == i) ? 1.f : 0.f;
   }
-  a.e[bi * a.ld_e + j] = out;
-  if (a.hot) a.e[bi * a.ld_e + a.d + j] = (j == i) ? 1.f : 0.f;
 }
 
-// dL/dp partial sums over a chunk of b:  ws[chunk][i*d+j] = sum_b ge[b,i,j] * de/dp[b,i,j]
+// dL/dp partial sums over a chunk of b:  ws[chunk][i*d+j] = sum_b ge[b,i,j] * de/dp[b,i,j];  one thread per (i, column pair)
 __global__ void dag_gate_bwd_dp_k(GateArgs a) {
-  const int64_t ij = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const int64_t d = a.d, dd = d * d;
-  if (ij >= dd) return;
-  const int64_t i = ij / d, j = ij - i * d;
-  const float p = a.tab[ij], ET = a.tab[2 * dd + ij], Q = a.tab[3 * dd + ij];
+  const int64_t d = a.d, dd = d * d, dh = (d + 1) / 2;
+  const int64_t ip = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (ip >= d * dh) return;
+  const int64_t i = ip / dh, jp = ip - i * dh, j0 = 2 * jp;
+  const bool two = j0 + 1 < d;
+  float p[2], ET[2], Q[2], acc[2] = {0.f, 0.f};
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const int64_t ij = i * d + j0 + (two ? h : 0);
+    p[h] = a.tab[ij]; ET[h] = a.tab[2 * dd + ij]; Q[h] = a.tab[3 * dd + ij];
+  }
   const int64_t b0 = (int64_t)blockIdx.y * a.chunk;
   const int64_t b1 = b0 + a.chunk < a.B ? b0 + a.chunk : a.B;
-  float acc = 0.f;
   for (int64_t b = b0; b < b1; ++b) {
-    const float g = a.ge[(b * d + i) * a.ld_e + j];
-    const float xv = a.x[b * d + j];
-    if (a.gate_mode == 0) {
-      acc = fmaf(g, xv, acc);
-    } else {
-      const Noise n = draw(a.gate_mode, a.u1, a.u2, a.seed, a.offset, (b * d + i) * d + j);
-      if (a.gate_mode == 1) {
-        const float s = gumbel_gate(ET, n, a.T);
-        acc = fmaf(g * xv, s * (1.f - s) * Q, acc);
+    Noise n[2];
+    draw2(a.gate_mode, a.u1, a.u2, a.seed, a.offset, b * d + i, jp, d, n);
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      if (h == 1 && !two) break;
+      const float g = a.ge[(b * d + i) * a.ld_e + j0 + h];
+      const float xv = a.x[b * d + j0 + h];
+      if (a.gate_mode == 0) {
+        acc[h] = fmaf(g, xv, acc[h]);
+      } else if (a.gate_mode == 1) {
+        const float s = gumbel_gate(ET[h], n[h], a.T);
+        acc[h] = fmaf(g * xv, s * (1.f - s) * Q[h], acc[h]);
       } else {
-        const float om = 1.f - p;
+        const float om = 1.f - p[h];
         const float sgn = om > 0.f ? 1.f : (om < 0.f ? -1.f : 0.f);
-        acc = fmaf(g, xv + n.a * fabsf(om) - p * n.a * sgn, acc);
+        acc[h] = fmaf(g, xv + n[h].a * fabsf(om) - p[h] * n[h].a * sgn, acc[h]);
       }
     }
   }
-  a.ws[(int64_t)blockIdx.y * dd + ij] = acc;
+  a.ws[(int64_t)blockIdx.y * dd + i * d + j0] = acc[0];
+  if (two) a.ws[(int64_t)blockIdx.y * dd + i * d + j0 + 1] = acc[1];
 }
 
 // gA = (sum over the batch chunks, taken by the shared deterministic row-sum kernel) * dP/dA
@@ -146,19 +170,27 @@ __global__ void dag_gate_bwd_dA_k(const float* __restrict__ tab, const float* __
   gA[ij] = sums[ij] * tab[dd + ij];
 }
 
-// gx[b,j] = sum_i ge[b,i,j] * de/dx[b,i,j]
+// gx[b,j] = sum_i ge[b,i,j] * de/dx[b,i,j];  one thread per (b, column pair)
 __global__ void dag_gate_bwd_dx_k(GateArgs a) {
-  const int64_t n = a.B * a.d, d = a.d, dd = d * d;
+  const int64_t d = a.d, dd = d * d, dh = (d + 1) / 2, n = a.B * dh;
   for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x) {
-    const int64_t b = e / d, j = e - b * d;
-    float acc = 0.f;
+    const int64_t b = e / dh, jp = e - b * dh, j0 = 2 * jp;
+    const bool two = j0 + 1 < d;
+    float acc[2] = {0.f, 0.f};
     for (int64_t i = 0; i < d; ++i) {
-      float gate = a.tab[i * d + j];
-      if (a.gate_mode == 1)
-        gate = gumbel_gate(a.tab[2 * dd + i * d + j], draw(1, a.u1, a.u2, a.seed, a.offset, (b * d + i) * d + j), a.T);
-      acc = fmaf(a.ge[(b * d + i) * a.ld_e + j], gate, acc);
+      Noise nz[2];
+      if (a.gate_mode == 1) draw2(1, a.u1, a.u2, a.seed, a.offset, b * d + i, jp, d, nz);
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        if (h == 1 && !two) break;
+        const int64_t j = j0 + h;
+        float gate = a.tab[i * d + j];
+        if (a.gate_mode == 1) gate = gumbel_gate(a.tab[2 * dd + i * d + j], nz[h], a.T);
+        acc[h] = fmaf(a.ge[(b * d + i) * a.ld_e + j], gate, acc[h]);
+      }
     }
-    a.gx[e] = acc;
+    a.gx[b * d + j0] = acc[0];
+    if (two) a.gx[b * d + j0 + 1] = acc[1];
   }
 }
 
@@ -206,8 +238,9 @@ int gnf_dag_gate_fwd(const float* x, const float* A, float* e, int64_t ld_e, int
   GateArgs a{};
   a.x = x; a.tab = ws; a.e = e; a.ld_e = ld_e; a.gate_mode = gate_mode; a.T = temperature; a.u1 = u1; a.u2 = u2;
   a.seed = seed; a.offset = offset; a.hot = hot; a.B = B; a.d = d;
-  const int bs = d >= 256 ? 256 : (d >= 128 ? 128 : 64);
-  hipLaunchKernelGGL(dag_gate_fwd_k, dim3((unsigned)(B * d), (unsigned)((d + bs - 1) / bs)), dim3(bs), 0, s, a);
+  const int64_t dh = (d + 1) / 2;                     // column pairs
+  const int bs = dh >= 256 ? 256 : (dh >= 128 ? 128 : 64);
+  hipLaunchKernelGGL(dag_gate_fwd_k, dim3((unsigned)(B * d), (unsigned)((dh + bs - 1) / bs)), dim3(bs), 0, s, a);
   GNF_LAUNCH_CHECK();
   return 0;
 }
@@ -234,7 +267,8 @@ int gnf_dag_gate_bwd(const float* x, const float* A, const float* ge, int64_t ld
     const int64_t nc = bwd_chunks(B, d);
     a.chunk = B > 0 ? (B + nc - 1) / nc : 1;
     const unsigned gxd = (unsigned)((d * d + kBlock - 1) / kBlock);
-    hipLaunchKernelGGL(dag_gate_bwd_dp_k, dim3(gxd, (unsigned)nc), dim3(kBlock), 0, s, a);
+    const unsigned gxp = (unsigned)((d * ((d + 1) / 2) + kBlock - 1) / kBlock);
+    hipLaunchKernelGGL(dag_gate_bwd_dp_k, dim3(gxp, (unsigned)nc), dim3(kBlock), 0, s, a);
     GNF_LAUNCH_CHECK();
     // second stage: a small-d / large-B call (POWER: d = 6, B = 10000) has 2048 chunk rows of only 36 columns; one thread
     // per column walking them serially took 0.45 ms, the row-sum kernel spreads the rows over 16 wavefronts
@@ -248,7 +282,7 @@ int gnf_dag_gate_bwd(const float* x, const float* A, const float* ge, int64_t ld
     GNF_LAUNCH_CHECK();
   }
   if (gx && B > 0) {
-    hipLaunchKernelGGL(dag_gate_bwd_dx_k, dim3(grid_1d(B * d)), dim3(kBlock), 0, s, a);
+    hipLaunchKernelGGL(dag_gate_bwd_dx_k, dim3(grid_1d(B * ((d + 1) / 2))), dim3(kBlock), 0, s, a);
     GNF_LAUNCH_CHECK();
   }
   return 0;

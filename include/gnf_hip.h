@@ -94,8 +94,9 @@ int gnf_gemm(const float* A, int64_t sam, int64_t sak,
  *             2: noise gate imp*(x + n*|1-imp|) (:114-116)
  * Randomness: if u1 != NULL the uniforms (gate 1: u1,u2; gate 2: u1 holds N(0,1)
  * samples) are read from [B,d,d] arrays (parity tests); otherwise a Philox4x32-10
- * stream keyed by (seed, offset) with the element index as counter is used, and the
- * backward regenerates the same numbers from the same (seed, offset). */
+ * stream keyed by (seed, offset) is used -- counter = (b*d+i)*ceil(d/2) + j/2, one call
+ * serving the two adjacent columns 2(j/2), 2(j/2)+1 -- and the backward regenerates the
+ * same numbers from the same (seed, offset). */
 /* ws: >= gnf_dag_gate_fwd_ws_bytes(d) bytes (per-(i,j) table of importance / gate constants). */
 int64_t gnf_dag_gate_fwd_ws_bytes(int64_t d);
 int gnf_dag_gate_fwd(const float* x, const float* A, float* e, int64_t ld_e,
