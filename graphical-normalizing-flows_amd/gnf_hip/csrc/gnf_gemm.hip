@@ -143,6 +143,10 @@ __global__ __launch_bounds__(256) void gemm_k(GemmArgs g) {
 // k-major [32][rows+4] with ds_write_b128.  Same MFMA tiling and epilogue as gemm_k.
 // ---------------------------------------------------------------------------------------------
 typedef float f32x4v __attribute__((ext_vector_type(4)));
+// global side: only dword alignment is assumed.  gfx950 executes global_load_dwordx4 at any dword address (checked by
+// tools/unaligned_vec.hip), so operands with odd leading strides (MADE's K = 630, the 30-wide embedding outputs) take
+// the vector path too; the LDS side keeps its 16-B aligned layout.
+typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
 constexpr int BKV = 32;
 
 template <int BX, bool KF>
@@ -163,8 +167,8 @@ struct Slab {            // staging of one operand: BX rows/cols x 32 k
       if (gx < X) {
         const int64_t o = gx * sx + gk;
         if (gk + 3 < kend) {
-          v = *reinterpret_cast<const f32x4v*>(P + o);
-          if (Mk) v *= *reinterpret_cast<const f32x4v*>(Mk + o);
+          v = *reinterpret_cast<const f32x4u*>(P + o);
+          if (Mk) v *= *reinterpret_cast<const f32x4u*>(Mk + o);
         } else {
 #pragma unroll
           for (int c = 0; c < 4; ++c)
@@ -175,8 +179,8 @@ struct Slab {            // staging of one operand: BX rows/cols x 32 k
       if (gk < kend) {
         const int64_t o = gk * sk + gx;
         if (gx + 3 < X) {
-          v = *reinterpret_cast<const f32x4v*>(P + o);
-          if (Mk) v *= *reinterpret_cast<const f32x4v*>(Mk + o);
+          v = *reinterpret_cast<const f32x4u*>(P + o);
+          if (Mk) v *= *reinterpret_cast<const f32x4u*>(Mk + o);
         } else {
 #pragma unroll
           for (int c = 0; c < 4; ++c)
@@ -354,12 +358,10 @@ int gnf_gemm_launch(GemmArgs g, int splits, hipStream_t s) {
   const int64_t gx = (g.M + bt - 1) / bt, gy = (g.N + bt - 1) / bt;
   if (gy > 65535 || nsp > 65535) return GNF_ESHAPE;
   const dim3 grid((unsigned)gx, (unsigned)gy, (unsigned)nsp);
-  // vector path: contiguous dimension of A and B (and the weight mask) 16-B aligned
-  auto al16 = [](const void* p) { return p == nullptr || ((uintptr_t)p & 15) == 0; };
-  const bool akf = g.sak == 1 && g.sam % 4 == 0, amf = g.sam == 1 && g.sak % 4 == 0;
-  const bool bkf = g.sbk == 1 && g.sbn % 4 == 0, bnf = g.sbn == 1 && g.sbk % 4 == 0;
-  const bool vec = (akf || amf) && (bkf || bnf) && al16(g.A) && al16(g.B) && al16(g.Bmask) &&
-                   g.k_per_split % 4 == 0;
+  // vector path: A and B each have a unit-stride dimension (any leading stride, dword alignment)
+  const bool akf = g.sak == 1, amf = !akf && g.sam == 1;
+  const bool bkf = g.sbk == 1, bnf = !bkf && g.sbn == 1;
+  const bool vec = (akf || amf) && (bkf || bnf) && g.k_per_split % 4 == 0;
 #define GNF_VEC_LAUNCH(BT)                                                                              \
   do {                                                                                                  \
     if (akf && bkf) hipLaunchKernelGGL((gemm_vec_k<BT, BT, true, true>), grid, dim3(256), 0, s, g);      \
