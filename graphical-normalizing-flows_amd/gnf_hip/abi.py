@@ -59,6 +59,9 @@ SIGNATURES = {
     "gnf_monotonic_bwd": (c_int, [c_f, ctypes.POINTER(MonoNet), c_f, c_f, c_i64, c_i64, c_i64, c_f, c_f, c_int, c_f,
                                   c_f, c_f, c_f, c_i64, c_i64, c_i64, ctypes.POINTER(ctypes.c_void_p),
                                   ctypes.POINTER(ctypes.c_void_p), ctypes.c_void_p, c_i64, c_i64, c_i64, c_stream]),
+    "gnf_dag_loss_prep": (c_int, [c_f, c_f, c_float, c_f, c_i64, c_stream]),
+    "gnf_dag_loss_value": (c_int, [c_f, c_f, c_f, c_f, c_float, c_f, c_f, c_f, c_f, c_int, c_f, c_f, c_i64, c_stream]),
+    "gnf_dag_loss_bwd": (c_int, [c_f, c_f, c_f, c_f, c_f, c_i64, c_stream]),
     "gnf_mnistcnn_conv_fwd": (c_int, [c_f, c_f, c_f, c_f, c_f, c_f, ctypes.c_void_p, c_i64, c_stream]),
     "gnf_mnistcnn_conv_bwd_ws_bytes": (c_i64, [c_i64]),
     "gnf_mnistcnn_conv_bwd": (c_int, [c_f, c_f, c_f, c_f, c_f, ctypes.c_void_p, c_f, c_f, c_f, c_f, c_f,

@@ -217,9 +217,115 @@ inline int launch_tab(const float* A, float* tab, int imp_mode, float h_thresh, 
   return 0;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Acyclicity + l1 term of the DAG conditioner (DAGConditioner.py:176-194, 268-271) around the library matrix power:
+//   Bm = I + min(1, alpha) * alpha_factor * A o A                                     (dag_loss_prep_k)
+//   h = sum_ij P_ij Bm_ji - d  with P = Bm^(k-1);  loss = dag_const (lambd h + c/2 h^2) + l1 mean|A|;
+//   coef = dag_const (lambd + c h) k 2 alpha: what d loss / dA needs besides P            (dag_loss_part_k + _final_k)
+//   dA = g (coef A o P^T + l1 sign(A) / d^2)                                           (dag_loss_bwd_k)
+// All scalars (alpha, lambd, c, dag_const, l1) are read from device memory: no host synchronisation.
+// ---------------------------------------------------------------------------------------------
+constexpr int kLossBlocks = 256;
+
+__device__ __forceinline__ float alpha_eff(const float* alpha, float factor) { return fminf(*alpha, 1.f) * factor; }
+
+__global__ void dag_loss_prep_k(const float* __restrict__ A, const float* __restrict__ alpha, float factor,
+                                float* __restrict__ Bm, int64_t d) {
+  const float al = alpha_eff(alpha, factor);
+  for (int64_t ij = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; ij < d * d; ij += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t i = ij / d, j = ij - i * d;
+    const float a = A[ij];
+    Bm[ij] = (i == j ? 1.f : 0.f) + al * a * a;
+  }
+}
+
+// partial sums per workgroup: part[2 b] = sum P_ij Bm_ji, part[2 b + 1] = sum |A_ij|   (P == nullptr: k = 0, trace = d)
+__global__ void dag_loss_part_k(const float* __restrict__ A, const float* __restrict__ Bm, const float* __restrict__ P,
+                                float* __restrict__ part, int64_t d) {
+  __shared__ float s0[kBlock / 64], s1[kBlock / 64];
+  float t = 0.f, l = 0.f;
+  for (int64_t ij = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; ij < d * d; ij += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t i = ij / d, j = ij - i * d;
+    if (P) t = fmaf(P[ij], Bm[j * d + i], t);
+    l += fabsf(A[ij]);
+  }
+  t = group_sum<64>(t);
+  l = group_sum<64>(l);
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  if (lane == 0) { s0[w] = t; s1[w] = l; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float a = 0.f, b = 0.f;
+    for (int k = 0; k < kBlock / 64; ++k) { a += s0[k]; b += s1[k]; }
+    part[2 * blockIdx.x] = a;
+    part[2 * blockIdx.x + 1] = b;
+  }
+}
+
+// out[0] = loss, out[1] = h (the trace term), out[2] = coef, out[3] = l1 / d^2
+__global__ void dag_loss_final_k(const float* __restrict__ part, int nparts, int has_P, const float* __restrict__ alpha,
+                                 float factor, const float* __restrict__ lambd, const float* __restrict__ c,
+                                 const float* __restrict__ dag_const, const float* __restrict__ l1, int k, int64_t d,
+                                 float* __restrict__ out) {
+  const int lane = threadIdx.x;
+  float t = 0.f, l = 0.f;
+  for (int b = lane; b < nparts; b += 64) { t += part[2 * b]; l += part[2 * b + 1]; }
+  t = group_sum<64>(t);
+  l = group_sum<64>(l);
+  if (lane == 0) {
+    const float h = has_P ? t - (float)d : 0.f;         // k = 0: tr(I) - d
+    const float dd = (float)d * (float)d;
+    out[0] = *dag_const * (*lambd * h + *c / 2.f * h * h) + *l1 * (l / dd);
+    out[1] = h;
+    out[2] = has_P ? *dag_const * (*lambd + *c * h) * (float)k * 2.f * alpha_eff(alpha, factor) : 0.f;
+    out[3] = *l1 / dd;
+  }
+}
+
+__global__ void dag_loss_bwd_k(const float* __restrict__ A, const float* __restrict__ P, const float* __restrict__ sc,
+                               const float* __restrict__ g, float* __restrict__ gA, int64_t d) {
+  const float go = *g, coef = sc[2], l1 = sc[3];
+  for (int64_t ij = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; ij < d * d; ij += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t i = ij / d, j = ij - i * d;
+    const float a = A[ij];
+    const float sgn = a > 0.f ? 1.f : (a < 0.f ? -1.f : 0.f);
+    gA[ij] = go * ((P ? coef * a * P[j * d + i] : 0.f) + l1 * sgn);
+  }
+}
+
 }  // namespace
 
 extern "C" {
+
+int gnf_dag_loss_prep(const float* A, const float* alpha, float alpha_factor, float* Bm, int64_t d,
+                      gnf_stream_t stream) {
+  if (!A || !alpha || !Bm || d <= 0) return GNF_EINVAL;
+  hipLaunchKernelGGL(dag_loss_prep_k, dim3(grid_1d(d * d)), dim3(kBlock), 0, (hipStream_t)stream, A, alpha, alpha_factor,
+                     Bm, d);
+  GNF_LAUNCH_CHECK();
+  return 0;
+}
+
+int gnf_dag_loss_value(const float* A, const float* Bm, const float* P, const float* alpha, float alpha_factor,
+                       const float* lambd, const float* c, const float* dag_const, const float* l1_weight, int k,
+                       float* out4, float* ws, int64_t d, gnf_stream_t stream) {
+  if (!A || !Bm || !alpha || !lambd || !c || !dag_const || !l1_weight || !out4 || !ws || d <= 0 || k < 0) return GNF_EINVAL;
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(dag_loss_part_k, dim3(kLossBlocks), dim3(kBlock), 0, s, A, Bm, P, ws, d);
+  GNF_LAUNCH_CHECK();
+  hipLaunchKernelGGL(dag_loss_final_k, dim3(1), dim3(64), 0, s, ws, kLossBlocks, P ? 1 : 0, alpha, alpha_factor, lambd, c,
+                     dag_const, l1_weight, k, d, out4);
+  GNF_LAUNCH_CHECK();
+  return 0;
+}
+
+int gnf_dag_loss_bwd(const float* A, const float* P, const float* out4, const float* g, float* gA, int64_t d,
+                     gnf_stream_t stream) {
+  if (!A || !out4 || !g || !gA || d <= 0) return GNF_EINVAL;
+  hipLaunchKernelGGL(dag_loss_bwd_k, dim3(grid_1d(d * d)), dim3(kBlock), 0, (hipStream_t)stream, A, P, out4, g, gA, d);
+  GNF_LAUNCH_CHECK();
+  return 0;
+}
 
 int64_t gnf_dag_gate_fwd_ws_bytes(int64_t d) { return 4 * d * d * (int64_t)sizeof(float); }
 

@@ -185,6 +185,11 @@ class DAGConditioner(Conditioner):
         return ops.PowerTraceFn.apply(B, self.exponent) - self.in_size
 
     def loss(self):
+        """dag_const (lambd h + c/2 h^2) + l1 mean|A|, h = get_power_trace()  (reference :268-271)"""
+        if self.A.is_cuda and self.hutchinson == 0:
+            # one fused op: three launches around the library matrix power, buffers read on the device
+            return ops.DagLossFn.apply(self.A, self.alpha, self.alpha_factor, self.lambd, self.c, self.dag_const,
+                                       self.l1_weight, self.exponent)
         lag_const = self.get_power_trace()
         return self.dag_const * (self.lambd * lag_const + self.c / 2 * lag_const ** 2) \
             + self.l1_weight * self.A.abs().mean()

@@ -111,6 +111,21 @@ int gnf_dag_gate_bwd(const float* x, const float* A, const float* ge, int64_t ld
                      const float* u1, const float* u2, uint64_t seed, uint64_t offset,
                      float* gA, float* gx, float* ws, int64_t B, int64_t d, gnf_stream_t stream);
 
+/* ---- DAG acyclicity + l1 term: DAGConditioner.get_power_trace / loss (DAGConditioner.py:176-194, 268-271) --------
+ * The d x d matrix power stays on the GEMM library; these entries fuse the ~40 elementwise / reduction
+ * launches around it.  alpha, lambd, c, dag_const, l1_weight: device scalars (the conditioner's buffers).
+ *   prep:  Bm = I + min(1, alpha) * alpha_factor * A o A                                 (:184-190)
+ *   value: out4 = [loss, h, coef, l1/d^2] with h = tr(Bm^k) - d = sum_ij P_ij Bm_ji - d, P = Bm^(k-1) (NULL when k = 0),
+ *          loss = dag_const (lambd h + c/2 h^2) + l1 mean|A|, coef = dag_const (lambd + c h) k 2 alpha_eff.
+ *          ws: >= 2 * 256 floats.
+ *   bwd:   gA = g (coef A o P^T + l1/d^2 sign(A))  with g the device scalar d/d loss.       (written, not accumulated) */
+int gnf_dag_loss_prep(const float* A, const float* alpha, float alpha_factor, float* Bm, int64_t d, gnf_stream_t stream);
+int gnf_dag_loss_value(const float* A, const float* Bm, const float* P, const float* alpha, float alpha_factor,
+                       const float* lambd, const float* c, const float* dag_const, const float* l1_weight, int k,
+                       float* out4, float* ws, int64_t d, gnf_stream_t stream);
+int gnf_dag_loss_bwd(const float* A, const float* P, const float* out4, const float* g, float* gA, int64_t d,
+                     gnf_stream_t stream);
+
 /* ---- Monotonic (UMNN) normalizer: models/Normalizers/MonotonicNormalizer.py:21-83 -----
  * Integrand net: Linear(1+c,H1) ReLU ... Linear(H_last,1) ELU+1.05 evaluated on rows
  * (x[b,i], h[b,i,:]).  `nl` = number of Linear layers (>= 2); W[l]: [out_l,in_l]

@@ -984,3 +984,26 @@ def test_mnist_level_inversion_uses_sparse_front():
     with torch.no_grad():
         z_back, _ = step(x_sparse)
     assert rel_err(z_back.cpu(), z.cpu()) < 1e-4
+
+
+@pytest.mark.parametrize("d,l1", [(84, .3), (6, 0.), (50, .5), (784, .1)])
+def test_dag_loss_fused_vs_reference_expression(d, l1):
+    """DAGConditioner.loss() through the fused kernels == the reference's expression (:176-194, :268-271) evaluated with
+    plain torch ops, value and gradient; d = 50 -> exponent 0 (the trace term is identically 0, Appendix B)"""
+    from models import DAGConditioner
+    torch.manual_seed(d)
+    cond = DAGConditioner(d, [8], 2, l1=l1).to(DEV)
+    with torch.no_grad():
+        cond.A.mul_(.2)
+        cond.lambd.fill_(.7)
+        cond.c.fill_(.05)
+    assert cond.exponent == d % 50
+    loss = cond.loss()
+    loss.backward()
+    got_g = cond.A.grad.clone()
+    cond.A.grad = None
+    lag = cond.get_power_trace()
+    ref = cond.dag_const * (cond.lambd * lag + cond.c / 2 * lag ** 2) + cond.l1_weight * cond.A.abs().mean()
+    ref.backward()
+    assert rel_err(loss.detach().cpu(), ref.detach().cpu()) < TOL, (loss.item(), ref.item())
+    assert rel_err(got_g.cpu(), cond.A.grad.cpu()) < GTOL
