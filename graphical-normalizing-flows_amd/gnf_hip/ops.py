@@ -551,7 +551,7 @@ class DagLossFn(torch.autograd.Function):
         A = A.contiguous()
         d = A.shape[0]
         k = int(k)
-        f32 = lambda t: t.detach().to(device=A.device, dtype=torch.float32).reshape(1)
+        f32 = lambda t: torch.as_tensor(t, dtype=torch.float32, device=A.device).detach().reshape(1)   # buffers or floats
         al, lm, cc, dc, l1 = f32(alpha), f32(lambd), f32(c), f32(dag_const), f32(l1_weight)
         Bm = _empty((d, d), A)
         call("gnf_dag_loss_prep", ptr(A), ptr(al), float(alpha_factor), ptr(Bm), d, stream())
