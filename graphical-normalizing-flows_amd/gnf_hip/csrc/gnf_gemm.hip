@@ -203,16 +203,19 @@ struct Slab {            // staging of one operand: BX rows/cols x 32 k
   }
 };
 
-template <int BM, int BN, bool AKF, bool BKF>
+// WGM = wavefronts along M: 2 (2x2 grid, the default) or 1 (1x4: every wavefront owns all BM rows and a quarter of the
+// columns -- the 160x128 tile that splits M = 78 400 into 490 tiles = 1.9 per CU instead of 613 = 2.4 of the 128x128 one)
+template <int BM, int BN, bool AKF, bool BKF, int WGM = 2>
 __global__ __launch_bounds__(256) void gemm_vec_k(GemmArgs g) {
-  constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 32, TN = WN / 32;
+  constexpr int WM = BM / WGM, WN = BN / (4 / WGM), TM = WM / 32, TN = WN / 32;
+  static_assert(WM % 32 == 0 && WN % 32 == 0, "wavefront sub-tile is a multiple of the 32x32 MFMA tile");
   using SA = Slab<BM, AKF>;
   using SB = Slab<BN, BKF>;
   __shared__ __attribute__((aligned(16))) float As[SA::SZ];
   __shared__ __attribute__((aligned(16))) float Bs[SB::SZ];
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = (wave >> 1) * WM, wn = (wave & 1) * WN;
+  const int wm = WGM == 2 ? (wave >> 1) * WM : 0, wn = WGM == 2 ? (wave & 1) * WN : wave * WN;
   const int64_t m0 = (int64_t)blockIdx.x * BM, n0 = (int64_t)blockIdx.y * BN;
   int64_t kbeg = (int64_t)blockIdx.z * g.k_per_split;
   int64_t kend = kbeg + g.k_per_split < g.K ? kbeg + g.k_per_split : g.K;
@@ -369,6 +372,16 @@ int gnf_gemm_launch(GemmArgs g, int splits, hipStream_t s) {
     else if (bkf) hipLaunchKernelGGL((gemm_vec_k<BT, BT, false, true>), grid, dim3(256), 0, s, g);       \
     else hipLaunchKernelGGL((gemm_vec_k<BT, BT, false, false>), grid, dim3(256), 0, s, g);               \
   } while (0)
+  // one column of 128-wide tiles over a tall M (fc1 forward: 78 400 x 128 x 2304): pick the tile height that leaves the
+  // fewest tile-rows on the busiest CU
+  if (vec && akf && bkf && bt == 128 && gy == 1 && nsp == 1 && !g.grp) {
+    const int64_t t160 = (g.M + 159) / 160;
+    if (((t160 + 255) / 256) * 160 < ((gx + 255) / 256) * 128) {
+      hipLaunchKernelGGL((gemm_vec_k<160, 128, true, true, 1>), dim3((unsigned)t160, 1, 1), dim3(256), 0, s, g);
+      GNF_LAUNCH_CHECK();
+      return 0;
+    }
+  }
   if (vec) {
     if (bt == 128) GNF_VEC_LAUNCH(128); else GNF_VEC_LAUNCH(64);
   } else {
