@@ -82,6 +82,7 @@ class DAGConditioner(Conditioner):
         self.sparse_front = True        # deterministic gate + windowed, frozen A: sparse embedding front
         self._sparse_outside = None     # 1 outside the 5x5 pixel windows (device mask, built on first use)
         self._sparse_checked = (None, False)
+        self._off_key, self._off = None, False
         self._sparse_plans = {}
         self.gate_noise = None          # (u1, u2) [B,d,d] uniforms (test hook); None -> Philox
         self._gate_calls = 0
@@ -184,8 +185,20 @@ class DAGConditioner(Conditioner):
         B = (torch.eye(self.in_size, device=self.A.device) + alpha * self.A ** 2)
         return ops.PowerTraceFn.apply(B, self.exponent) - self.in_size
 
+    def _constraints_off(self):
+        """True once update_dual_param() has switched both terms off (dag_const = 0 and l1_weight = 0, reference
+        :249-251): loss() is then identically 0 and its matrix power is skipped.  One host read per CHANGE of the two
+        buffers (they are replaced / rewritten at epoch level only), none per step."""
+        key = (id(self.dag_const), self.dag_const._version, id(self.l1_weight), self.l1_weight._version)
+        if self._off_key != key:
+            self._off_key = key
+            self._off = bool(((self.dag_const == 0) & (self.l1_weight == 0)).item())
+        return self._off
+
     def loss(self):
         """dag_const (lambd h + c/2 h^2) + l1 mean|A|, h = get_power_trace()  (reference :268-271)"""
+        if not self.A.requires_grad and self._constraints_off():
+            return torch.zeros((), device=self.A.device)
         if self.A.is_cuda and self.hutchinson == 0:
             # one fused op: three launches around the library matrix power, buffers read on the device
             return ops.DagLossFn.apply(self.A, self.alpha, self.alpha_factor, self.lambd, self.c, self.dag_const,

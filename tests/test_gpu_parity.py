@@ -1007,3 +1007,21 @@ def test_dag_loss_fused_vs_reference_expression(d, l1):
     ref.backward()
     assert rel_err(loss.detach().cpu(), ref.detach().cpu()) < TOL, (loss.item(), ref.item())
     assert rel_err(got_g.cpu(), cond.A.grad.cpu()) < GTOL
+
+
+def test_dag_loss_switched_off_after_dag_phase():
+    """dag_const = l1_weight = 0 with a frozen A (what update_dual_param() leaves): loss() is exactly 0 without touching
+    the matrix power, and comes back when the buffers change"""
+    from models import DAGConditioner
+    cond = DAGConditioner(12, [8], 2, l1=.2).to(DEV)
+    with torch.no_grad():
+        cond.post_process(zero_threshold=.1)
+    assert cond.loss().item() != 0.
+    cond.dag_const = torch.tensor(0., device=DEV)
+    cond.l1_weight = torch.tensor(0., device=DEV)
+    assert cond._constraints_off() and cond.loss().item() == 0.
+    cond.l1_weight = torch.tensor(.5, device=DEV)
+    assert not cond._constraints_off() and cond.loss().item() > 0.
+    with torch.no_grad():
+        cond.l1_weight.zero_()                       # in-place change is seen too (version counter)
+    assert cond._constraints_off()

@@ -45,6 +45,17 @@ def cfg(name):
         for c in f.getConditioners():
             with torch.no_grad():
                 c.post_process(zero_threshold=.1)
+    elif name == "cfg4dag":  # the state update_dual_param() ends in: an acyclic binary A (window parents that precede the
+        x = bench.pseudo_mnist(g, 100, 784)          # pixel in raster order), post-processed, dag_const = l1 = 0
+        f = bench.build_flow()
+        for c in f.getConditioners():
+            with torch.no_grad():
+                idx = torch.arange(784)
+                c.A.mul_((idx[None, :] < idx[:, None]).float())
+                c.post_process(zero_threshold=.1)
+                c.dag_const = torch.tensor(0.)
+                c.l1_weight = torch.tensor(0.)
+                c.is_invertible = True
     elif name == "cfg5":    # BSDS300 d=63 synthetic (yml:347-358), B=50000
         x = torch.randn(50000, 63, generator=g)
         f = buildFCNormalizingFlow(1, AutoregressiveConditioner, {"in_size": 63, "hidden": [630] * 3, "out_size": 30},
@@ -96,7 +107,7 @@ def main():
         dt = min(dt_mean, singles[len(singles) // 2])
         prof = abi.profile_collect()
         graphed = None
-        if "--graph" in sys.argv and name in ("cfg1", "cfg3", "cfg4det"):
+        if "--graph" in sys.argv and name in ("cfg1", "cfg3", "cfg4det", "cfg4dag"):
             # launch-bound configurations: the full optimisation step (incl. Adam) replayed from one hipGraph, next to
             # the same step issued launch by launch
             from gnf_hip import dp
