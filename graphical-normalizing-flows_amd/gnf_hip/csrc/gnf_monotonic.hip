@@ -748,6 +748,270 @@ __global__ __launch_bounds__(64 * kWaves, (ONES && !INDW) ? 2 : 1) void mono_bwd
   if (lane == 0) { prow[(NH + 2) * HP] = vbl; prow[(NH + 2) * HP + 1] = 0.f; prow[(NH + 2) * HP + 2] = 0.f; prow[(NH + 2) * HP + 3] = 0.f; }
 }
 
+// ---------------------------------------------------------------------------------------
+// Narrow nets (H <= 64), everything in-kernel, TWO quadrature nodes per pass: every weight fragment read from LDS feeds 8
+// MFMAs (as in the forward) and the two nodes' chains are independent.  Same outputs as mono_bwd_k<.., INDW>: dx, dh,
+// Dsum rows, vector partials (d wL, d w1x, d bL; the biases come out of the weight-gradient accumulators' ones column
+// and the Dsum column sums), and one (NH-1) x HP x HP accumulator row per wavefront.
+// LDS: small vectors | W_l, b_l | W_l^T (W1h and W1h^T, used once per group, stay in L2), then per wavefront the
+// element-major tiles of the layer inputs of BOTH nodes and one dpre tile (tile_w / tile_r swizzle).
+// ---------------------------------------------------------------------------------------
+template <int HT, int NH>
+__global__ __launch_bounds__(64 * kWaves, 1) void mono_bwd_pair_k(MonoArgs a) {
+  static_assert(HT <= 4 && NH >= 2, "narrow nets with at least one hidden->hidden layer");
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const MonoLayout& L = a.L;
+  constexpr int HP = 16 * HT;
+  const int matf = HP * L.LDW;
+  // LDS image: [0, o_W1h): w1x, b1, wL, bL;  then per hidden layer W_l (matf) + b_l (HP);  then per hidden layer W_l^T
+  const int small = L.o_W1h;
+  float* sW = smem + small;                      // W_l at sW + (l-1) * (matf + HP), b_l right behind it
+  float* sWT = sW + (NH - 1) * (matf + HP);      // W_l^T at sWT + (l-1) * matf
+  for (int i = threadIdx.x * 4; i < small; i += blockDim.x * 4) *reinterpret_cast<f32x4*>(smem + i) = ld4(a.pack + i);
+  for (int l = 1; l < NH; ++l) {
+    for (int i = threadIdx.x * 4; i < matf + HP; i += blockDim.x * 4)
+      *reinterpret_cast<f32x4*>(sW + (l - 1) * (matf + HP) + i) = ld4(a.pack + L.o_W[l] + i);
+    for (int i = threadIdx.x * 4; i < matf; i += blockDim.x * 4)
+      *reinterpret_cast<f32x4*>(sWT + (l - 1) * matf + i) = ld4(a.pack + L.o_WT[l] + i);
+  }
+  __syncthreads();
+  const float* wp = smem;                        // small vectors only (same offsets as in the pack)
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int q = lane >> 4, j = lane & 15;
+  constexpr int NT = 2 * (NH - 1) + 1;           // tiles per wavefront: layer inputs of node 0 / node 1, one dpre tile
+  float* tiles = sWT + (NH - 1) * matf + wave * (NT * 16 * kTS);
+  for (int i = lane; i < NT * 16 * kTS; i += 64) tiles[i] = 0.f;
+  float* td = tiles + (NT - 1) * 16 * kTS;
+  const int64_t ngroups = (a.ecount + 15) / 16;
+  const float fS = (float)a.S;
+
+  f32x4 p_wL[HT], p_w1x[HT], accW[NH - 1][HT][HT];
+  float p_bL = 0.f;
+#pragma unroll
+  for (int t = 0; t < HT; ++t) { p_wL[t] = f32x4{0.f, 0.f, 0.f, 0.f}; p_w1x[t] = p_wL[t]; }
+#pragma unroll
+  for (int l = 0; l < NH - 1; ++l)
+#pragma unroll
+    for (int ti = 0; ti < HT; ++ti)
+#pragma unroll
+      for (int tn = 0; tn < HT; ++tn) accW[l][ti][tn] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  for (int64_t grp = (int64_t)blockIdx.x * kWaves + wave; grp < ngroups; grp += (int64_t)gridDim.x * kWaves) {
+    const int64_t el = grp * 16 + j;
+    const bool valid = el < a.ecount;
+    const int64_t e = a.e0 + (valid ? el : a.ecount - 1);
+    const int64_t b = e / a.d, i = e - b * a.d;
+    const int64_t hbase = b * a.h_sb + i * a.h_sd;
+    f32x4 c1[HT];
+    cond_bias<HT>(a.pack, L, a.h, hbase, a.h_sc, q, j, c1);      // W1h from L2, b1 too (once per group)
+    const float xv = a.x[e];
+    const float xT = fS * (xv / fS);
+    const float g_z = valid ? a.gz[e] : 0.f;
+    const float g_j = (valid && a.gjac) ? a.gjac[e] : 0.f;
+    const float cotq = g_z * xT * .5f;
+    f32x4 Ds[HT];
+#pragma unroll
+    for (int t = 0; t < HT; ++t) Ds[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float dx = 0.f;
+
+    for (int k = 0; k < a.NK; k += 2) {
+      float xk[2], cot[2];
+      bool isj[2];
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int ku = k + u;
+        const bool isq = ku <= a.S;
+        isj[u] = ku == a.S + 1;
+        xk[u] = isq ? xT * (a.cct[ku] + 1.f) * .5f : xv;
+        cot[u] = isq ? a.ccw[ku] * cotq : (isj[u] ? g_j : 0.f);
+      }
+      // ---- forward recompute of both nodes
+      f32x4 act[2][HT];
+#pragma unroll
+      for (int t = 0; t < HT; ++t) {
+        const f32x4 wx = ld4(wp + L.o_w1x + 16 * t + 4 * q);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          act[0][t][r] = fmaxf(fmaf(wx[r], xk[0], c1[t][r]), 0.f);
+          act[1][t][r] = fmaxf(fmaf(wx[r], xk[1], c1[t][r]), 0.f);
+        }
+      }
+#pragma unroll
+      for (int l = 1; l < NH; ++l) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          float* ta = tiles + (2 * (l - 1) + u) * 16 * kTS;
+#pragma unroll
+          for (int t = 0; t < HT; ++t) {
+            f32x4 v = act[u][t];
+            if (t == HT - 1 && q == 3) v[3] = 1.f;              // column HP-1 = 1: the bias gradient rides dW_l
+            *reinterpret_cast<f32x4*>(ta + tile_w(j, t, q)) = v;
+          }
+        }
+        const float* W = sW + (l - 1) * (matf + HP);
+        f32x4 o[2][HT];
+#pragma unroll
+        for (int mt = 0; mt < HT; ++mt) { o[0][mt] = ld4(W + matf + 16 * mt + 4 * q); o[1][mt] = o[0][mt]; }
+#pragma unroll
+        for (int t = 0; t < HT; ++t)
+#pragma unroll
+          for (int mt = 0; mt < HT; ++mt) {
+            const f32x4 A = ld4(W + (16 * mt + j) * L.LDW + 16 * t + 4 * q);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              o[0][mt] = mfma(A[r], act[0][t][r], o[0][mt]);
+              o[1][mt] = mfma(A[r], act[1][t][r], o[1][mt]);
+            }
+          }
+#pragma unroll
+        for (int t = 0; t < HT; ++t)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) { act[0][t][r] = fmaxf(o[0][t][r], 0.f); act[1][t][r] = fmaxf(o[1][t][r], 0.f); }
+      }
+      float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+      for (int t = 0; t < HT; ++t) {
+        const f32x4 wl = ld4(wp + L.o_wL + 16 * t + 4 * q);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { s0 = fmaf(wl[r], act[0][t][r], s0); s1 = fmaf(wl[r], act[1][t][r], s1); }
+      }
+      const float bL = wp[L.o_bL];
+      float sv[2] = {qsum(s0) + bL, qsum(s1) + bL}, dpl[2];
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        if (isj[u]) dx = g_z * elu_plus(sv[u]);                  // Leibniz rule: dz/dx = f(x;h)
+        dpl[u] = cot[u] * (sv[u] > 0.f ? 1.f : expf(sv[u]));
+        if (q == 0) p_bL += dpl[u];
+      }
+      // ---- backward through the last layer
+      f32x4 dp[2][HT];
+#pragma unroll
+      for (int t = 0; t < HT; ++t) {
+        const f32x4 wl = ld4(wp + L.o_wL + 16 * t + 4 * q);
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+          for (int u = 0; u < 2; ++u) {
+            p_wL[t][r] = fmaf(dpl[u], act[u][t][r], p_wL[t][r]);
+            dp[u][t][r] = act[u][t][r] > 0.f ? wl[r] * dpl[u] : 0.f;
+          }
+      }
+      // ---- hidden->hidden layers, top down
+#pragma unroll
+      for (int l = NH - 1; l >= 1; --l) {
+        // dW_l += dpre_l^T * input_l, K = the 16 elements, node by node through the one dpre tile
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+#pragma unroll
+          for (int t = 0; t < HT; ++t) *reinterpret_cast<f32x4*>(td + tile_w(j, t, q)) = dp[u][t];
+          const float* ta = tiles + (2 * (l - 1) + u) * 16 * kTS;
+#pragma unroll
+          for (int sK = 0; sK < 4; ++sK) {
+            float fa[HT], fb[HT];
+#pragma unroll
+            for (int t = 0; t < HT; ++t) { fa[t] = td[tile_r(sK, q, t, j)]; fb[t] = ta[tile_r(sK, q, t, j)]; }
+#pragma unroll
+            for (int ti = 0; ti < HT; ++ti)
+#pragma unroll
+              for (int tn = 0; tn < HT; ++tn) accW[l - 1][ti][tn] = mfma(fa[ti], fb[tn], accW[l - 1][ti][tn]);
+          }
+        }
+        const float* WT = sWT + (l - 1) * matf;
+        f32x4 da[2][HT];
+#pragma unroll
+        for (int mt = 0; mt < HT; ++mt) { da[0][mt] = f32x4{0.f, 0.f, 0.f, 0.f}; da[1][mt] = da[0][mt]; }
+#pragma unroll
+        for (int t = 0; t < HT; ++t)
+#pragma unroll
+          for (int mt = 0; mt < HT; ++mt) {
+            const f32x4 A = ld4(WT + (16 * mt + j) * L.LDW + 16 * t + 4 * q);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              da[0][mt] = mfma(A[r], dp[0][t][r], da[0][mt]);
+              da[1][mt] = mfma(A[r], dp[1][t][r], da[1][mt]);
+            }
+          }
+        // gate = (input of layer l) > 0, read back from its tile in the layout it was written in
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          const float* tg = tiles + (2 * (l - 1) + u) * 16 * kTS;
+#pragma unroll
+          for (int t = 0; t < HT; ++t) {
+            const f32x4 g = *reinterpret_cast<const f32x4*>(tg + tile_w(j, t, q));
+#pragma unroll
+            for (int r = 0; r < 4; ++r) dp[u][t][r] = g[r] > 0.f ? da[u][t][r] : 0.f;
+          }
+        }
+      }
+      // ---- first layer: rank-1 in x_k, node-independent in h
+      float sx0 = 0.f, sx1 = 0.f;
+#pragma unroll
+      for (int t = 0; t < HT; ++t) {
+        const f32x4 wx = ld4(wp + L.o_w1x + 16 * t + 4 * q);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          Ds[t][r] += dp[0][t][r] + dp[1][t][r];
+          p_w1x[t][r] = fmaf(dp[0][t][r], xk[0], p_w1x[t][r]);
+          p_w1x[t][r] = fmaf(dp[1][t][r], xk[1], p_w1x[t][r]);
+          sx0 = fmaf(wx[r], dp[0][t][r], sx0);
+          sx1 = fmaf(wx[r], dp[1][t][r], sx1);
+        }
+      }
+      if (isj[0]) dx += qsum(sx0);                               // gjac * df/dx(x;h)
+      if (isj[1]) dx += qsum(sx1);
+    }
+
+    // ---- per-group epilogue: staged Dsum (for d W1h and d b_0), dh, dx
+    float* ds = a.Dsum + (grp * 16 + j) * HP + 4 * q;
+#pragma unroll
+    for (int t = 0; t < HT; ++t) *reinterpret_cast<f32x4*>(ds + 16 * t) = Ds[t];
+    if (valid && q == 0 && a.gx) a.gx[e] = dx;
+    const int64_t gbase = b * a.g_sb + i * a.g_sd;
+    for (int mt = 0; mt < L.CP / 16; ++mt) {
+      f32x4 o = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int t = 0; t < HT; ++t) {
+        const f32x4 A = ld4(a.pack + L.o_W1hT + (16 * mt + j) * L.LDW + 16 * t + 4 * q);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o = mfma(A[r], Ds[t][r], o);
+      }
+      if (valid) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int cc = 16 * mt + 4 * q + r;
+          if (cc < L.c) a.gh[gbase + cc * a.g_sc] = o[r] + (cc == 0 ? g_z : 0.f);
+        }
+      }
+    }
+  }
+
+  float* prow = a.part + ((int64_t)blockIdx.x * kWaves + wave) * ((NH + 2) * HP + 4);
+#pragma unroll
+  for (int t = 0; t < HT; ++t)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int hid = 16 * t + 4 * q + r;
+      float v = jsum(p_wL[t][r]);
+      if (j == 0) prow[hid] = v;
+      v = jsum(p_w1x[t][r]);
+      if (j == 0) prow[HP + hid] = v;
+#pragma unroll
+      for (int l = 0; l < NH; ++l)
+        if (j == 0) prow[(2 + l) * HP + hid] = 0.f;
+    }
+  const float vbl = jsum(p_bL);
+  if (lane == 0) { prow[(NH + 2) * HP] = vbl; prow[(NH + 2) * HP + 1] = 0.f; prow[(NH + 2) * HP + 2] = 0.f; prow[(NH + 2) * HP + 3] = 0.f; }
+  float* wrow = a.wpart + ((int64_t)blockIdx.x * kWaves + wave) * ((NH - 1) * HP * HP);
+#pragma unroll
+  for (int l = 0; l < NH - 1; ++l)
+#pragma unroll
+    for (int ti = 0; ti < HT; ++ti)
+#pragma unroll
+      for (int tn = 0; tn < HT; ++tn)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) wrow[l * HP * HP + (16 * ti + 4 * q + r) * HP + 16 * tn + j] = accW[l][ti][tn][r];
+}
+
 struct UnpackArgs {
   gnf_mono_net net; MonoLayout L;
   float* gW[GNF_MONO_MAX_LAYERS]; float* gb[GNF_MONO_MAX_LAYERS];
@@ -855,6 +1119,15 @@ int launch_bwd_one(const MonoArgs& a, unsigned grid, hipStream_t s) {
   const size_t lds_all = (size_t)a.L.total_floats * sizeof(float);
   const size_t lds_one = (size_t)a.L.HP * a.L.LDW * sizeof(float);
   if constexpr (HT <= 4 && NH > 1) {
+    if (a.indw == 2) {                          // two nodes per pass, image without W1h / W1h^T, 5 tiles per wavefront
+      const size_t lds_pair = ((size_t)a.L.o_W1h + (size_t)(NH - 1) * (2 * a.L.HP * a.L.LDW + a.L.HP) +
+                               (size_t)kWaves * (2 * (NH - 1) + 1) * 16 * kTS) * sizeof(float);
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mono_bwd_pair_k<HT, NH>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_pair);
+      hipLaunchKernelGGL((mono_bwd_pair_k<HT, NH>), dim3(grid), dim3(64 * kWaves), lds_pair, s, a);
+      GNF_LAUNCH_CHECK();
+      return 0;
+    }
     if (a.indw) {                               // whole image + per-wavefront element-major tiles, one workgroup per CU
       const size_t lds_in = ((size_t)(a.L.total_floats + 3) / 4 * 4 + (size_t)kWaves * NH * 16 * kTS) * sizeof(float);
       if (lds_in > (size_t)kLdsBudget) return GNF_ESHAPE;
@@ -1168,6 +1441,12 @@ int gnf_monotonic_bwd(const float* pack, const gnf_mono_net* net, const float* x
   a.ones = HT <= 4 && NH > 1;
   for (int l = 1; l < NH; ++l) a.ones = a.ones && net->dims[l] < HP;
   a.indw = indw;
+  if (indw) {                                     // the two-node kernel when its LDS plan fits (A/B: GNF_MONO_INDW=1 keeps one node)
+    const size_t lds_pair = ((size_t)L.o_W1h + (size_t)(NH - 1) * (2 * L.HP * L.LDW + L.HP) +
+                             (size_t)kWaves * (2 * (NH - 1) + 1) * 16 * kTS) * sizeof(float);
+    static const bool one = getenv("GNF_MONO_INDW") && getenv("GNF_MONO_INDW")[0] == '1';
+    if (lds_pair <= (size_t)160 * 1024 && !one) a.indw = 2;
+  }
   a.wpart = w + P.o_wpart;
   const unsigned bwd_grid = indw ? kInDwGrid : kBwdGrid;
 
