@@ -65,6 +65,12 @@ class MNISTCNN(nn.Module):
         return (x.is_cuda and list(self.size_img) == [1, 28, 28] and x.shape[-1] == 784
                 and self.conv1.weight.shape == (16, 1, 3, 3) and self.conv2.weight.shape == (16, 16, 3, 3))
 
+    def _embeddable(self, x):
+        """single-channel images of 6..28 pixels a side with the 1->16->16 3x3 convolutions: run on the 28x28 kernels"""
+        c, h, w = self.size_img
+        return (x.is_cuda and c == 1 and 6 <= h <= 28 and 6 <= w <= 28 and x.shape[-1] == h * w
+                and self.conv1.weight.shape == (16, 1, 3, 3) and self.conv2.weight.shape == (16, 16, 3, 3))
+
     def supports_sparse(self, x):
         """the sparse masked-copy front (gnf_hip.ops.mnistcnn_sparse_fwd) covers the 28x28 net with fc1 on 2304 inputs"""
         return (self._fused_front(x) and self.fc1.in_features == 2304 and self.fc1.out_features % 4 == 0)
@@ -84,9 +90,17 @@ class MNISTCNN(nn.Module):
         if self._fused_front(x):
             feat = ops.MnistConvFn.apply(x.view(-1, 784), self.conv1.weight, self.conv1.bias, self.conv2.weight,
                                          self.conv2.bias)
+        elif self._embeddable(x):
+            # the 14x14 / 7x7 scales of the multi-scale factory: the image sits in the top-left corner of a zero 28x28
+            # one.  Valid convolutions never look across the corner's edge for the output positions that exist in the
+            # small image, so conv1 / conv2 / pool agree there exactly and the fused kernels apply (4x / 16x the
+            # necessary area, still several times cheaper than an im2col round trip through HBM)
+            _, h, w = self.size_img
+            big = F.pad(x.view(-1, 1, h, w), (0, 28 - w, 0, 28 - h)).view(-1, 784)
+            pooled = ops.MnistConvFn.apply(big, self.conv1.weight, self.conv1.bias, self.conv2.weight, self.conv2.bias)
+            feat = pooled.view(-1, 16, 12, 12)[:, :, :(h - 4) // 2, :(w - 4) // 2].reshape(rows, -1)
         else:
-            # the 14x14 / 7x7 scales of the multi-scale factory (7 % of its images): im2col + library GEMM
-            # (no MIOpen: its find step costs minutes on this stack)
+            # any other geometry: batched im2col + MFMA GEMM (no MIOpen: its find step costs minutes on this stack)
             img = x.view(-1, *self.size_img)
             feat = F.relu(_conv3x3(img, self.conv1.weight, self.conv1.bias))
             feat = F.max_pool2d(_conv3x3(feat, self.conv2.weight, self.conv2.bias), 2).flatten(1)

@@ -1025,3 +1025,26 @@ def test_dag_loss_switched_off_after_dag_phase():
     with torch.no_grad():
         cond.l1_weight.zero_()                       # in-place change is seen too (version counter)
     assert cond._constraints_off()
+
+
+@pytest.mark.parametrize("size_img,fc_in", [([1, 14, 14], 400), ([1, 7, 7], 16), ([1, 9, 12], 16 * 2 * 4), ([2, 10, 10], 144)])
+def test_mnistcnn_other_geometries(size_img, fc_in):
+    """single-channel images up to 28x28 run zero-embedded on the fused 28x28 kernels, anything else on the batched
+    im2col + MFMA GEMM: both against the oracle's torch-CPU convolution, forward and gradients"""
+    from models.MLP import MNISTCNN
+    torch.manual_seed(sum(size_img))
+    net = MNISTCNN(out_d=5, fc_l=[fc_in, 12], size_img=size_img).to(DEV)
+    n, d = 37, size_img[0] * size_img[1] * size_img[2]
+    e = torch.randn(n, d)
+    gout = torch.randn(n, 5)
+    eg = req(e)
+    out = net(eg)
+    (out * cu(gout)).sum().backward()
+    params = {k: v.detach().cpu().clone().requires_grad_(True) for k, v in net.named_parameters()}
+    ec = e.clone().requires_grad_(True)
+    ref = O.mnistcnn_forward(ec, params, tuple(size_img))
+    (ref * gout).sum().backward()
+    assert rel_err(out.detach().cpu(), ref.detach()) < TOL
+    assert rel_err(eg.grad.cpu(), ec.grad) < GTOL
+    for k, p in net.named_parameters():
+        assert rel_err(p.grad.cpu(), params[k].grad) < GTOL, k
