@@ -461,7 +461,11 @@ def _layers_cpu(norm):
 @pytest.mark.parametrize("hidden,S,layout", [([10], 20, "contig"), ([16, 16], 21, "made"), ([50, 50, 50], 20, "contig"),
                                               ([50, 50, 50], 29, "made"), ([100, 100, 100], 20, "contig"),
                                               ([150, 150, 150], 20, "made"), ([40, 64, 24], 15, "contig"),
-                                              ([200, 200], 22, "contig")])
+                                              ([200, 200], 22, "contig"),
+                                              # four hidden layers: narrow -> bias gradients through the ones column of the
+                                              # staged activations (image + tiles exceed the LDS); wide (the reference's
+                                              # default integrand) -> one hidden matrix swapped through LDS at a time
+                                              ([48, 50, 50, 50], 20, "contig"), ([100, 100, 100, 100], 20, "made")])
 def test_monotonic_forward_backward_vs_oracle(hidden, S, layout):
     B, d, c = 9, 7, 30 if len(hidden) == 3 else 5
     norm, x, hraw, h = _mono_case(B, d, c, hidden, S, seed=len(hidden) * 100 + S, h_layout=layout)
