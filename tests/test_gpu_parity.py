@@ -1052,3 +1052,18 @@ def test_mnistcnn_other_geometries(size_img, fc_in):
     assert rel_err(eg.grad.cpu(), ec.grad) < GTOL
     for k, p in net.named_parameters():
         assert rel_err(p.grad.cpu(), params[k].grad) < GTOL, k
+
+
+@pytest.mark.parametrize("variant", ["0", "1"])
+def test_monotonic_backward_ab_variants(variant):
+    """the A/B switch of the narrow-net backward (GNF_MONO_INDW=0: HBM-staged weight gradients, =1: in-kernel, one node per
+    pass; default: two nodes per pass) is read once per process: run the gradient parity tests in a child process"""
+    import os
+    import subprocess
+    import sys
+    env = dict(os.environ, GNF_MONO_INDW=variant)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_gpu_parity.py"), "-q", "-m", "gpu",
+                        "-k", "test_monotonic_forward_backward_vs_oracle or test_monotonic_golden_integrand_grads or test_monotonic_ragged_sizes", "-x"],
+                       env=env, cwd=root, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
