@@ -14,6 +14,8 @@ checked against reference-generated golden vectors) on a bounded sample, rank 0,
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -79,8 +81,18 @@ def cpu_baseline():
         k += 2
     Bc = 2
     x = pseudo_mnist(torch.Generator().manual_seed(1234), Bc, D)
-    cores = min(os.cpu_count() or 1, 32)     # more threads only add contention at this size
+    ncpu = os.cpu_count() or 1
+    cores = min(ncpu, 32)                    # more threads only add contention at this size
     torch.set_num_threads(cores)
+    model = "unknown"
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    model = line.split(":", 1)[1].strip()
+                    break
+    except OSError:
+        pass
 
     def step():
         u1, u2 = torch.rand(Bc, D, D), torch.rand(Bc, D, D)
@@ -103,6 +115,7 @@ def cpu_baseline():
     dt1 = time.perf_counter() - t0
     torch.set_num_threads(cores)
     return {"value": Bc / dt, "unit": "samples/s", "cores": cores, "kind": "port",
+            "os_cpu_count": ncpu, "cpu_model": model, "threads": cores,
             "sample": "%d steps of B=%d (same d=784 model, S=20), fwd+logdet+NLL+bwd, torch %d threads"
                       % (n, Bc, cores),
             "value_1thread": Bc / dt1}
@@ -142,9 +155,23 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the secondary figures (tests of the N>1 path)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N`: this process becomes the launcher and never touches the GPU -- it starts one rank
+        # per GPU as CHILD processes (torch.distributed.run), waits, and exits with their code.
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            port = s.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        raise SystemExit(subprocess.call(cmd))
+
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d (launch one rank per GPU, or run `python bench.py --gpus N`"
+                         " and let it spawn them)" % (args.gpus, world))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
@@ -166,9 +193,8 @@ def main():
     from gnf_hip import abi, ops
     abi.load()
     flow = build_flow().to(dev)
-    for c in flow.getConditioners():                         # per-rank gate noise, like DP replicas
-        c.gate_seed = 1000003 * (rank + 1)
     from gnf_hip import dp
+    dp.seed_gates(flow, rank)                                # per-rank, per-conditioner Philox keys (like DP replicas)
     state = dp.FlatState(flow)
     state.broadcast(0)
     x = pseudo_mnist(torch.Generator().manual_seed(1234 + rank), B_PER_GPU, D).to(dev)
@@ -214,14 +240,19 @@ def main():
         from gnf_hip import dp as _dp
         _dp.train_step(flow, state, x, lr=1e-3, weight_decay=1e-5)
 
-    t_fb = timed(fwd_bwd, 10)
-    t_mix = timed(mixed, 10)
+    secondary = not args.no_secondary
+    t_fb = timed(fwd_bwd, 10) if secondary else None
+    for p in flow.parameters():
+        p.grad = None
+    t_mix = timed(mixed, 10) if secondary else None
 
     # (iii) the same full step after the DAG phase: post_process() froze a binary A and the gate is deterministic, so
     # the embedding net runs on the sparse crop kernels.  Fresh flow: A leaves the optimiser state.
     from gnf_hip import dp as _dp
     t_det, det_error = None, None
     try:                                   # a secondary figure must not take the headline down with it
+        if not secondary:
+            raise RuntimeError("skipped (--no-secondary)")
         flow_det = build_flow().to(dev)
         with torch.no_grad():
             for c in flow_det.getConditioners():
@@ -239,10 +270,18 @@ def main():
             raise RuntimeError("frozen-gate step did not run on the sparse embedding kernels")
     except Exception as exc:               # noqa: BLE001
         t_det, det_error = None, repr(exc)
-    tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
+    # max over ranks of every timing (a missing secondary figure travels as -1); replicas must have stayed identical:
+    # compare an order-independent bit checksum of the flat parameter buffer across ranks
+    tmax = torch.tensor([dt, t_fb or -1., t_mix or -1., t_det or -1.], dtype=torch.float64)
+    replicas_identical = dp.replicas_identical(state, flow)
     if world > 1:
+        cdev = dev if backend == "nccl" else torch.device("cpu")     # RCCL moves device buffers, gloo host buffers
+        tmax = tmax.to(cdev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    dt = tmax.item()
+        tmax = tmax.cpu()
+    dt, t_fb, t_mix, t_det = [v if v > 0 else None for v in tmax.tolist()]
+    if not replicas_identical:
+        raise SystemExit("data-parallel replicas diverged (parameter checksums differ across ranks)")
 
     if rank == 0:
         n_elem = B_PER_GPU * D                                  # = masked images per step = Monotonic elements
@@ -269,6 +308,10 @@ def main():
             "value": B_PER_GPU * world * args.steps / dt, "unit": "samples/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "parity_note": "UMNN 1.0 parity unpinned: the Clenshaw-Curtis integral of the Monotonic normalizer is "
+                           "checked against this repo's own restatement + mathematics, not against the absent package; "
+                           "everything else on the path is pinned by reference-generated fixtures",
+            "replicas_identical": replicas_identical, "dist_backend": backend if world > 1 else None,
             "config": {"workload": "cfg4: MNIST d=784, MonotonicNormalizer[50,50,50] cond 30 S=20 + DAGConditioner("
                                    "MNISTCNN->30, prior_A_kernel=2, hot_encoding=False, Gumbel gate T=1), "
                                    "b_size=100 per GPU; step = fwd+logdet+NLL+bwd+allreduce+Adam",
@@ -294,12 +337,12 @@ def main():
         if dom in issued:
             out["roofline"]["mfma_issue_frac"] = round(issued[dom] * 2048. * n_elem / (prof[dom] * 1e-3) / 1e12
                                                        / PEAK_F32_TFLOPS, 4)
-        out["secondary"] = {"fwd_bwd_only_samples_per_s": round(B_PER_GPU * world / t_fb, 1),
-                            "full_step_S_mix_20_29_samples_per_s": round(B_PER_GPU * world / t_mix, 1),
+        out["secondary"] = {"fwd_bwd_only_samples_per_s": round(B_PER_GPU * world / t_fb, 1) if t_fb else None,
+                            "full_step_S_mix_20_29_samples_per_s": round(B_PER_GPU * world / t_mix, 1) if t_mix else None,
                             "full_step_frozen_deterministic_gate_samples_per_s":
                                 round(B_PER_GPU * world / t_det, 1) if t_det else None,
                             "frozen_gate_error": det_error,
-                            "note": "10 steps each, per-rank wall clock of rank 0 (not max over ranks)"}
+                            "note": "10 steps each, wall clock between barriers, max over ranks"}
         out["measured_peaks"] = measured_peaks(dev)
         out["roofline"]["frac_of_measured_peak"] = round(achieved / out["measured_peaks"]["mfma_f32_TFLOPs"], 4)
         if world == 1 and not args.no_cpu_baseline:

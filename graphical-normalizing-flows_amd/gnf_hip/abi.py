@@ -19,6 +19,7 @@ c_u64 = ctypes.c_uint64
 c_stream = ctypes.c_void_p
 
 MONO_MAX_LAYERS = 8
+ABI_VERSION = 2           # GNF_ABI_VERSION of include/gnf_hip.h this binding was written against
 
 
 class MonoNet(ctypes.Structure):
@@ -78,7 +79,7 @@ SIGNATURES = {
     "gnf_adam_step": (c_int, [c_f, c_f, c_f, c_f, c_i64, c_float, c_float, c_float, c_float, c_float, c_float, c_int,
                               c_stream]),
     "gnf_adam_step_dev": (c_int, [c_f, c_f, c_f, c_f, c_i64, c_float, c_float, c_float, c_float, c_float, c_float,
-                                  ctypes.c_void_p, c_stream]),
+                                  ctypes.c_void_p, c_int, c_stream]),
     "gnf_probe_mfma_f32": (c_i64, [c_f, c_int, c_int, c_stream]),
     "gnf_probe_copy": (c_int, [c_f, c_f, c_i64, c_stream]),
 }
@@ -103,7 +104,7 @@ def load():
             fn = getattr(lib, name)       # AttributeError if the symbol is missing
             fn.restype = res
             fn.argtypes = args
-        if lib.gnf_abi_version() != 1:
+        if lib.gnf_abi_version() != ABI_VERSION:
             raise ImportError("libgnf_hip.so ABI version mismatch")
         _lib = lib
     return _lib

@@ -416,12 +416,13 @@ int gnf_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float
 }
 
 int gnf_adam_step_dev(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
-                      float eps, float weight_decay, float grad_scale, int* step_dev, gnf_stream_t stream) {
+                      float eps, float weight_decay, float grad_scale, int* step_dev, int advance,
+                      gnf_stream_t stream) {
   if (!p || !g || !m || !v || !step_dev || n < 0) return GNF_EINVAL;
   if (n == 0) return 0;
   hipLaunchKernelGGL(adam_dev_k, dim3(grid_1d(n)), dim3(kBlock), 0, (hipStream_t)stream, p, g, m, v, n, lr, beta1,
                      beta2, eps, weight_decay, grad_scale, (const int*)step_dev);
-  hipLaunchKernelGGL(adam_bump_k, dim3(1), dim3(1), 0, (hipStream_t)stream, step_dev);
+  if (advance) hipLaunchKernelGGL(adam_bump_k, dim3(1), dim3(1), 0, (hipStream_t)stream, step_dev);
   GNF_LAUNCH_CHECK();
   return 0;
 }

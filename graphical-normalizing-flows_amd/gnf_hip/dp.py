@@ -33,17 +33,42 @@ class FlatState:
             self._pads.append(torch.zeros(pad4(k) - k, device=dev))
             o += pad4(k)
         self.t = 0
+        self._offsets = []
+        o = 0
+        for q in self.params:
+            self._offsets.append(o)
+            o += pad4(q.numel())
+        self.active_runs = [(0, n)]                # [(offset, length)] of the flat buffer Adam steps; see pack_grads
+
+    def rebind(self):
+        """Re-alias every parameter to its slice of the flat buffer, keeping the parameter's CURRENT values -- for host
+        code that rebinds `p.data` (the reference's post_process does, DAGConditioner.py:88; this package's does not)."""
+        for q, o in zip(self.params, self._offsets):
+            k = q.numel()
+            view = self.flat[o:o + k].view_as(q)
+            if q.data.data_ptr() != view.data_ptr():
+                view.copy_(q.data)
+                q.data = view
 
     def pack_grads(self, grads=None):
         """flat gradient buffer <- the .grad tensors autograd just produced (or the given list, in self.params order),
         in ONE concatenation launch.  (.grad views into the flat buffer would cost a zero-fill plus one accumulate
         kernel per parameter per step.)"""
-        parts = []
+        parts, runs = [], []
         for i, (p, pad) in enumerate(zip(self.params, self._pads)):
             g = p.grad if grads is None else grads[i]
             parts.append(g.reshape(-1) if g is not None else torch.zeros(p.numel(), device=pad.device))
             if pad.numel():
                 parts.append(pad)
+            if g is not None:
+                # torch.optim.Adam skips parameters without a gradient (no weight decay, no moment update): a frozen A
+                # (post_process) must not decay.  Adam therefore steps the runs of consecutive parameters that have one.
+                o, k = self._offsets[i], (p.numel() + 3) // 4 * 4
+                if runs and runs[-1][0] + runs[-1][1] == o:
+                    runs[-1] = (runs[-1][0], runs[-1][1] + k)
+                else:
+                    runs.append((o, k))
+        self.active_runs = runs
         torch.cat(parts, out=self.grad)
         if grads is None:
             for p in self.params:
@@ -51,7 +76,12 @@ class FlatState:
 
     def broadcast(self, src=0):
         if dist.is_initialized() and dist.get_world_size() > 1:
-            dist.broadcast(self.flat, src)
+            if dist.get_backend() == "gloo" and self.flat.is_cuda:
+                h = self.flat.cpu()
+                dist.broadcast(h, src)
+                self.flat.copy_(h)
+            else:
+                dist.broadcast(self.flat, src)
 
     # ---- checkpoint compatibility with the reference drivers, which save `torch.optim.Adam(model.parameters())
     #      .state_dict()` as ADAM.pt (UCIExperiments.py:216-220, ImageExperiments.py:251-253)
@@ -60,7 +90,7 @@ class FlatState:
         state, o = {}, 0
         for p in self.params:
             k = p.numel()
-            if self.t > 0:
+            if self.t > 0 and id(p) in index:
                 state[index[id(p)]] = {"step": torch.tensor(float(self.t)),
                                        "exp_avg": self.m[o:o + k].view_as(p).clone(),
                                        "exp_avg_sq": self.v[o:o + k].view_as(p).clone()}
@@ -75,7 +105,7 @@ class FlatState:
         o = 0
         for p in self.params:
             k = p.numel()
-            st = sd["state"].get(index[id(p)])
+            st = sd["state"].get(index.get(id(p)))
             if st is not None:
                 self.m[o:o + k].copy_(st["exp_avg"].reshape(-1))
                 self.v[o:o + k].copy_(st["exp_avg_sq"].reshape(-1))
@@ -85,8 +115,55 @@ class FlatState:
 
 def hip_adam(state, lr, weight_decay, grad_scale):
     from . import ops
-    ops.adam_step(state.flat, state.grad, state.m, state.v, state.t, lr=lr, weight_decay=weight_decay,
-                  grad_scale=grad_scale)
+    for o, k in state.active_runs:                  # one launch unless some parameter is frozen mid-buffer
+        ops.adam_step(state.flat[o:o + k], state.grad[o:o + k], state.m[o:o + k], state.v[o:o + k], state.t, lr=lr,
+                      weight_decay=weight_decay, grad_scale=grad_scale)
+
+
+def gate_seed(rank, k, base=0x9E3779B97F4A7C15):
+    """Philox key of conditioner k on rank `rank` (splitmix64 of the pair): replicas draw different gate noise per
+    shard like nn.DataParallel's replicas, and the steps of one flow draw independent noise like the reference's
+    per-call torch.rand (DAGConditioner.py:99-100)."""
+    m = (1 << 64) - 1
+    z = (base + 0xBF58476D1CE4E5B9 * (rank + 1) + 0x94D049BB133111EB * (k + 1)) & m
+    z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & m
+    z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & m
+    return (z ^ (z >> 31)) & ((1 << 62) - 1)
+
+
+def seed_gates(flow, rank):
+    for k, c in enumerate(flow.getConditioners()):
+        if hasattr(c, "gate_seed"):
+            c.gate_seed = gate_seed(rank, k)
+
+
+def all_reduce_sum(t):
+    """the step's collective: RCCL all-reduce in place; under the gloo backend (CPU transport, used only to exercise
+    the N>1 path on boxes with one GPU) the buffer is staged through host memory."""
+    if dist.get_backend() == "gloo" and t.is_cuda:
+        h = t.cpu()
+        dist.all_reduce(h)
+        t.copy_(h)
+    else:
+        dist.all_reduce(t)
+
+
+def replicas_identical(state, module=None):
+    """True when every rank holds bit-identical parameters (and, given the module, buffers -- the DAG dual variables
+    live there): an order-independent integer checksum of the raw fp32 bits, all-gathered."""
+    bits = state.flat.view(torch.int32).to(torch.int64).sum()
+    if module is not None:
+        for b in module.buffers():
+            if b.dtype == torch.float32 and b.numel():
+                bits = bits + b.detach().contiguous().view(torch.int32).to(torch.int64).sum().to(bits.device) * 31
+    if not (dist.is_initialized() and dist.get_world_size() > 1):
+        return True
+    mine = bits.reshape(1)
+    if dist.get_backend() == "gloo":
+        mine = mine.cpu()
+    all_ = [torch.zeros_like(mine) for _ in range(dist.get_world_size())]
+    dist.all_gather(all_, mine)
+    return all(int(a.item()) == int(all_[0].item()) for a in all_)
 
 
 def train_step(flow, state, x_shard, lr=1e-3, weight_decay=1e-5, optimizer=hip_adam):
@@ -98,33 +175,63 @@ def train_step(flow, state, x_shard, lr=1e-3, weight_decay=1e-5, optimizer=hip_a
     loss.backward()
     state.pack_grads()
     if world > 1:
-        dist.all_reduce(state.grad)                 # the step's only collective
+        all_reduce_sum(state.grad)                  # the step's only collective
     state.t += 1
     optimizer(state, lr, weight_decay, 1. / world)
     return loss
 
 
 class GraphedStep:
-    """The whole optimisation step (fwd + log|det J| + NLL + bwd + gradient pack + Adam) captured ONCE into a hipGraph
-    and replayed: for the launch-bound configurations (toy d=2, MADE at B=100: ~100 launches of a few microseconds,
-    host enqueue ~0.8 ms per step) the replay removes the per-launch host cost.  Single-GPU only (the all-reduce stays
+    """The whole optimisation step (fwd + log|det J| + NLL + bwd + gradient pack + Adam) captured into a hipGraph and
+    replayed: for the launch-bound configurations (toy d=2, MADE at B=100: ~100 launches of a few microseconds, host
+    enqueue ~0.8 ms per step) the replay removes the per-launch host cost.  Single-GPU only (the all-reduce stays
     eager); nothing step-dependent may be passed to a kernel by value, so Adam's step count lives in device memory
     (gnf_adam_step_dev).  Flows whose conditioner draws Philox noise from a host-side call counter (stochastic DAG
     gate) would replay the same noise: they are refused.
 
+    Host-side state that a captured step bakes in BY VALUE -- a DAG conditioner's matrix-power exponent and gate
+    flags, which `model.step()` / `update_dual_param()` / `post_process()` change at epoch level, whether A is
+    trainable, a Monotonic normalizer's node count, the batch shape -- is fingerprinted; when the fingerprint differs
+    from the captured one the step is re-captured (the dual variables themselves are device buffers updated in place,
+    so a replay reads their current values).
+
     Construction runs `warmup` real steps on x_example (they count as training steps), then captures."""
 
     def __init__(self, flow, state, x_example, lr=1e-3, weight_decay=1e-5, warmup=3):
-        from . import ops
         if dist.is_initialized() and dist.get_world_size() > 1:
             raise RuntimeError("GraphedStep is single-process; use train_step under torchrun")
+        self.state, self.flow = state, flow
+        self.lr, self.weight_decay = lr, weight_decay
+        self.x = x_example.clone()
+        self.step_dev = torch.full((1,), state.t, dtype=torch.int32, device=self.x.device)
+        self.captures = 0
+        self._capture(max(warmup, 1))
+
+    @staticmethod
+    def graphable(flow):
         for c in flow.getConditioners():
             if getattr(c, "stoch_gate", False) or getattr(c, "noise_gate", False):
                 if getattr(c, "h_thresh", 0) > 0 or getattr(c, "s_thresh", False):
-                    raise RuntimeError("a stochastic DAG gate draws its noise from a host-side counter: not graphable")
-        self.state, self.flow = state, flow
-        self.x = x_example.clone()
-        self.step_dev = torch.full((1,), state.t, dtype=torch.int32, device=self.x.device)
+                    return False
+        return True
+
+    def _fingerprint(self):
+        fp = [tuple(self.x.shape)]
+        for c in self.flow.getConditioners():
+            fp.append((getattr(c, "exponent", None), getattr(c, "stoch_gate", None), getattr(c, "noise_gate", None),
+                       getattr(c, "s_thresh", None), float(getattr(c, "h_thresh", 0.)), getattr(c, "alpha_factor", None),
+                       tuple((id(b), ) for b in c.buffers(recurse=False))))
+        for nrm in self.flow.getNormalizers():
+            fp.append(getattr(nrm, "nb_steps", None))
+        fp.append(tuple(p.requires_grad for p in self.state.params))
+        return tuple(fp)
+
+    def _capture(self, warmup):
+        from . import ops
+        flow, state = self.flow, self.state
+        if not self.graphable(flow):
+            raise RuntimeError("a stochastic DAG gate draws its noise from a host-side counter: not graphable")
+        lr, weight_decay = self.lr, self.weight_decay
 
         # The captured step differentiates w.r.t. FRESH leaves aliasing the parameters (torch.func.functional_call), not
         # the nn.Parameters themselves: a Parameter's gradient accumulator remembers the stream it was created on and is
@@ -142,29 +249,44 @@ class GraphedStep:
         wrapper = _Loss(flow)
         name_of = {id(p): n for n, p in wrapper.named_parameters()}
         names = [name_of[id(p)] for p in state.params]
+        live = [i for i, p in enumerate(state.params) if p.requires_grad]     # a frozen A stays out of the backward
 
         def body():
-            leaves = [p.detach().requires_grad_() for p in state.params]
+            leaves = [p.detach().requires_grad_(i in live) for i, p in enumerate(state.params)]
             loss = torch.func.functional_call(wrapper, dict(zip(names, leaves)), (self.x,))
-            state.pack_grads(torch.autograd.grad(loss, leaves, allow_unused=True))
-            ops.adam_step_dev(state.flat, state.grad, state.m, state.v, self.step_dev, lr=lr,
-                              weight_decay=weight_decay)
+            got = torch.autograd.grad(loss, [leaves[i] for i in live], allow_unused=True)
+            grads = [None] * len(leaves)
+            for i, g in zip(live, got):
+                grads[i] = g
+            state.pack_grads(grads)
+            runs = state.active_runs
+            for k, (o, n) in enumerate(runs):       # the device-side counter is advanced by the last launch only
+                last = k == len(runs) - 1
+                ops.adam_step_dev(state.flat[o:o + n], state.grad[o:o + n], state.m[o:o + n], state.v[o:o + n],
+                                  self.step_dev, lr=lr, weight_decay=weight_decay, advance=last)
             return loss.detach()
 
+        self.step_dev.fill_(state.t)
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
-            for _ in range(max(warmup, 1)):
+            for _ in range(warmup):
                 body()
                 state.t += 1
         torch.cuda.current_stream().wait_stream(side)
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph):
             self.loss = body()
+        self._captured = self._fingerprint()
+        self.captures += 1
 
     def __call__(self, x):
-        self.x.copy_(x, non_blocking=True)
+        if tuple(x.shape) != tuple(self.x.shape):
+            self.x = x.clone()
+        else:
+            self.x.copy_(x, non_blocking=True)
+        if self._fingerprint() != self._captured:
+            self._capture(1)                        # one eager step on x (counted), then a fresh capture
         self.graph.replay()
         self.state.t += 1
         return self.loss
-

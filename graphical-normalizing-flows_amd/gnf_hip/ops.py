@@ -506,12 +506,13 @@ def adam_step(p, g, m, v, step, lr=1e-3, betas=(.9, .999), eps=1e-8, weight_deca
          grad_scale, int(step), stream())
 
 
-def adam_step_dev(p, g, m, v, step_dev, lr=1e-3, betas=(.9, .999), eps=1e-8, weight_decay=0., grad_scale=1.):
+def adam_step_dev(p, g, m, v, step_dev, lr=1e-3, betas=(.9, .999), eps=1e-8, weight_decay=0., grad_scale=1.,
+                  advance=True):
     """Adam with the step counter in device memory (int32 tensor, incremented by the call): graph-capturable."""
     if step_dev.dtype != torch.int32 or not step_dev.is_cuda:
         raise abi.GnfError("step_dev must be an int32 HIP tensor")
     call("gnf_adam_step_dev", ptr(p), ptr(g), ptr(m), ptr(v), p.numel(), lr, betas[0], betas[1], eps, weight_decay,
-         grad_scale, abi.rawptr(step_dev), stream())
+         grad_scale, abi.rawptr(step_dev), int(bool(advance)), stream())
 
 
 class PowerTraceFn(torch.autograd.Function):

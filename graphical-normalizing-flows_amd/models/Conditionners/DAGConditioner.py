@@ -218,9 +218,12 @@ class DAGConditioner(Conditioner):
         self.noise_gate = False
         self.s_thresh = False
         self.h_thresh = 0.
-        self.A.data = (self.soft_thresholded_A().data.clone().abs() > zero_threshold).float()
+        # written INTO A's storage (the reference rebinds A.data, :88): A may be a view of a flat parameter buffer
+        # (gnf_hip.dp.FlatState) and of a captured hipGraph, both of which must keep seeing it
+        with torch.no_grad():
+            self.A.copy_((self.soft_thresholded_A().abs() > zero_threshold).float()
+                         * (1. - torch.eye(self.in_size, device=self.A.device)))
         self.A.requires_grad = False
-        self.A *= 1. - torch.eye(self.in_size, device=self.A.device)
         self.A.grad = None
 
     def _reopen(self, A=None):
@@ -229,11 +232,23 @@ class DAGConditioner(Conditioner):
         self.s_thresh = True
         self.h_thresh = 0.
         if A is not None:
-            self.A = nn.Parameter(A)
+            # the reference installs a NEW nn.Parameter here (:224), which its optimiser never sees (it keeps stepping
+            # the old object): A silently stops training after a failed post-processing.  Here the saved values go back
+            # into the same storage, so the optimiser (flat buffer or torch.optim) keeps updating A.
+            with torch.no_grad():
+                self.A.copy_(A)
         self.A.requires_grad = True
-        self.A.grad = self.A.detach().clone()
-        self.alpha = self.getAlpha().to(self.A.device)
-        self.prev_trace = self.get_power_trace().detach()
+        self.A.grad = None               # the reference parks A.clone() here until its next zero_grad() (:226,244)
+        self._set("alpha", self.getAlpha())
+        self._set("prev_trace", self.get_power_trace().detach())
+
+    def _set(self, name, value):
+        """buffer <- value IN PLACE (the reference rebinds new tensors, e.g. `self.lambd = self.lambd + ...`): device
+        addresses stay valid for captured hipGraphs, and the value lands on A's device (the reference leaves CPU scalars
+        `torch.tensor(1.)` behind, :231,233-234)."""
+        buf = getattr(self, name)
+        with torch.no_grad():
+            buf.copy_(torch.as_tensor(value, dtype=buf.dtype, device=buf.device))
 
     def update_dual_param(self):
         """Augmented-Lagrangian update of (lambd, c) / post-processing (:196-260)."""
@@ -243,29 +258,29 @@ class DAGConditioner(Conditioner):
                 self.exponent += 50
                 lag_const = self.get_power_trace()
             if self.dag_const > 0. and lag_const > self.tol:
-                self.lambd = self.lambd + self.c * lag_const
+                self._set("lambd", self.lambd + self.c * lag_const)
                 if lag_const.abs() > self.gamma * self.prev_trace.abs():
                     self.c *= self.eta
-                self.prev_trace = lag_const
+                self._set("prev_trace", lag_const)
             elif self.dag_const > 0.:
                 A_before = self.A.detach().clone()
                 self.post_process()
-                self.alpha = self.getAlpha().to(self.A.device)
+                self._set("alpha", self.getAlpha())
                 lag_const = self.get_power_trace()
                 if lag_const > 0.:
                     self._reopen(A_before)
                     self.c *= 1 / self.eta
-                    self.lambd = self.lambd + self.c * lag_const
-                    self.dag_const = torch.tensor(1., device=self.A.device)
+                    self._set("lambd", self.lambd + self.c * lag_const)
+                    self._set("dag_const", 1.)
                 else:
-                    self.dag_const = torch.tensor(0., device=self.A.device)
-                    self.l1_weight = torch.tensor(0., device=self.A.device)
+                    self._set("dag_const", 0.)
+                    self._set("l1_weight", 0.)
             else:
                 G = _digraph(self.A.detach().cpu().numpy() ** 2)
                 try:
                     nx.find_cycle(G)
                     self._reopen()
-                    self.dag_const = torch.tensor(1., device=self.A.device)
+                    self._set("dag_const", 1.)
                 except nx.NetworkXNoCycle:
                     self.is_invertible = True
         return lag_const

@@ -9,6 +9,7 @@ either side can resume the other's run."""
 import argparse
 import math
 import os
+import re
 import sys
 import time
 
@@ -42,6 +43,21 @@ def batches(X, b, shuffle, gen):
         yield X[idx[i:i + b].to(X.device)]
 
 
+def shard_batches(n, b, rank, world, gen):
+    """Index tensors of this rank's share of every global minibatch of one epoch.  The permutation is drawn from `gen`,
+    which every rank seeds identically, so all ranks cut the SAME global batches; each batch is trimmed to a multiple
+    of `world` rows and dealt round-robin, so every rank runs the same number of steps with the same shard size (no rank
+    is left waiting in the per-step all-reduce, and the mean of the rank means is the global batch mean)."""
+    idx = torch.randperm(n, generator=gen)
+    out = []
+    for i in range(0, n, b):
+        cur = idx[i:i + b]
+        keep = cur.numel() // world * world
+        if keep:
+            out.append(cur[:keep][rank::world])
+    return out
+
+
 def build(args, dim):
     cond_t, norm_t = COND[args.conditioner], NORM[args.normalizer]
     cargs = {"in_size": dim, "hidden": args.emb_net[:-1], "out_size": args.emb_net[-1]}
@@ -70,13 +86,20 @@ def train(args):
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("train_uci.py needs an MI355X (the flow kernels have no CPU fallback)")
+    backend = os.environ.get("GNF_DIST_BACKEND", "nccl")     # "nccl" is RCCL; "gloo" only to exercise N>1 on a 1-GPU box
+    ndev = torch.cuda.device_count()
+    if backend == "nccl" and local >= ndev:
+        raise SystemExit("rank %d has no GPU (%d visible)" % (local, ndev))
+    local %= max(ndev, 1)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
     trn, val, tst = [t.to(dev) for t in load_split(args.data, args.dataset)]
-    trn = trn[rank::world]                                   # each rank trains on its shard of every batch
     torch.manual_seed(0)
     model, cond_t, norm_t = build(args, trn.shape[1])
     os.makedirs(args.folder, exist_ok=True)
@@ -84,8 +107,7 @@ def train(args):
     if args.load:
         model.load_state_dict(torch.load(os.path.join(args.folder, "model%s.pt" % tag), map_location="cpu"))
     model.to(dev)
-    for c in model.getConditioners():
-        c.gate_seed = 1000003 * (rank + 1) if hasattr(c, "gate_seed") else None
+    dp.seed_gates(model, rank)                               # independent gate noise per rank and per flow step
     state = dp.FlatState(model)
     state.broadcast(0)
     adam_file = os.path.join(args.folder, "ADAM%s.pt" % tag)
@@ -102,7 +124,6 @@ def train(args):
             log.flush()
 
     say(str(vars(args)))
-    b_local = max(args.b_size // world, 1)
     for epoch in range(args.nb_epoch):
         t0 = time.perf_counter()
         if cond_t is DAGConditioner:
@@ -111,20 +132,28 @@ def train(args):
                     c.constrainA(zero_threshold=0.)
         ll_tot, n = torch.zeros((), device=dev), 0
         if not args.test:
-            for cur in batches(trn, b_local, True, gen):
+            for rows in shard_batches(trn.shape[0], max(args.b_size, world), rank, world, gen):
                 if norm_t is MonotonicNormalizer:            # node-count jitter of the reference (:131-133)
                     k = args.nb_steps + int(torch.randint(0, 10, [1], generator=gen))
                     for nrm in model.getNormalizers():
                         nrm.nb_steps = k
-                loss = dp.train_step(model, state, cur, lr=args.learning_rate, weight_decay=args.weight_decay)
+                loss = dp.train_step(model, state, trn[rows.to(dev)], lr=args.learning_rate,
+                                     weight_decay=args.weight_decay)
                 ll_tot += loss.detach()
                 n += 1
             ll_tot /= max(n, 1)
+            if world > 1:
+                # model.step() decides the dual update / post-processing from this value (DAGConditioner.step): every
+                # replica must take the same branch, so they all see the mean over ranks
+                dp.all_reduce_sum(ll_tot)
+                ll_tot /= world
             if not torch.isfinite(ll_tot):
                 if rank == 0:
                     torch.save(model.state_dict(), os.path.join(args.folder, "NANmodel.pt"))
                 raise SystemExit("non-finite loss")
             model.step(epoch, ll_tot)
+            if not dp.replicas_identical(state, model):
+                raise SystemExit("data-parallel replicas diverged in epoch %d" % epoch)
         if norm_t is MonotonicNormalizer:
             for nrm in model.getNormalizers():
                 nrm.nb_steps = args.nb_steps + 20
@@ -145,6 +174,20 @@ def train(args):
     if world > 1:
         dist.destroy_process_group()
     return model
+
+
+_SCI = re.compile(r"[-+]?(\d[\d_]*\.?[\d_]*|\.[\d_]+)([eE][-+]?\d+)?")
+
+
+def _yml_number(v):
+    """PyYAML reads `1e-3` and `.5e1` as strings (YAML 1.1 wants a dot AND a signed exponent); the reference installs a
+    YAML 1.2 float resolver so that its configuration file's `weight_decay: 1e-3` arrives as a float
+    (UCIExperiments.py:258-269, UCIExperimentsConfigurations.yml:84).  Same outcome: plain-number strings -> float."""
+    if isinstance(v, str) and _SCI.fullmatch(v.strip()):
+        return float(v.replace("_", ""))
+    if isinstance(v, list):
+        return [_yml_number(e) for e in v]
+    return v
 
 
 def parse(argv=None):
@@ -176,7 +219,7 @@ def parse(argv=None):
         with open(args.config_file) as f:
             cfg = yaml.safe_load(f)[args.load_config]
         for k, v in cfg.items():
-            setattr(args, k, float(v) if isinstance(v, str) and k in ("l1", "gumble_T") else v)
+            setattr(args, k, _yml_number(v))
     if args.dataset is None:
         ap.error("-dataset (or a -load_config entry naming one) is required")
     if not args.folder:

@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define GNF_ABI_VERSION 1
+#define GNF_ABI_VERSION 2
 #define GNF_EINVAL (-1)   /* bad argument (null pointer, negative size, ...)          */
 #define GNF_ESHAPE (-2)   /* shape not supported by any compiled kernel instantiation */
 #define GNF_EWS    (-3)   /* workspace too small                                      */
@@ -231,12 +231,13 @@ int gnf_adam_step(float* p, const float* g, float* m, float* v, int64_t n,
                   float grad_scale, int step, gnf_stream_t stream);
 
 /* Same update (torch.optim.Adam at ImageExperiments.py:173 / UCIExperiments.py:97), with the step count in device
- * memory (*step_dev = number of steps already taken; incremented by the call):
+ * memory (*step_dev = number of steps already taken; incremented by the call when advance != 0 -- a step over
+ * several disjoint runs of the flat buffer, e.g. around a frozen parameter, advances on its last launch only):
  * nothing step-dependent is passed by value, so a captured hipGraph of a whole training step can be replayed
  * (gnf_hip.dp.GraphedStep -- the launch-bound configurations). */
 int gnf_adam_step_dev(float* p, const float* g, float* m, float* v, int64_t n,
                       float lr, float beta1, float beta2, float eps, float weight_decay,
-                      float grad_scale, int* step_dev, gnf_stream_t stream);
+                      float grad_scale, int* step_dev, int advance, gnf_stream_t stream);
 
 /* ---- device-ceiling probes (measurement aids for bench.py) ---------------
  * gnf_probe_mfma_f32 launches `blocks` workgroups of 8 wavefronts that do nothing but

@@ -55,3 +55,18 @@ def rel_err(a, b):
     a = a.double()
     b = b.double()
     return ((a - b).abs().max() / b.abs().max().clamp_min(1e-30)).item()
+
+
+def assert_close(a, b, rtol=1e-5, atol=1e-6, what=""):
+    """element-wise |a-b| <= atol + rtol*|b| (the per-entry form of north_star's 1e-5 relative fp32; rel_err above is
+    the infinity-norm form and leaves small entries unconstrained)."""
+    a = a.detach().double().cpu()
+    b = b.detach().double().cpu()
+    assert a.shape == b.shape, (what, tuple(a.shape), tuple(b.shape))
+    excess = (a - b).abs() - (atol + rtol * b.abs())
+    if excess.numel() and excess.max().item() > 0:
+        k = int(excess.argmax())
+        raise AssertionError("%s: entry %d differs: %.9g vs %.9g (|diff| %.3g > %.3g); %d of %d entries out of tolerance"
+                             % (what, k, a.reshape(-1)[k].item(), b.reshape(-1)[k].item(),
+                                (a - b).abs().reshape(-1)[k].item(), (atol + rtol * b.abs()).reshape(-1)[k].item(),
+                                int((excess > 0).sum()), excess.numel()))

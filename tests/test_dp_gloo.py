@@ -114,3 +114,85 @@ def test_adam_checkpoint_round_trips_through_torch_optim():
     assert state2.t == 4
     assert torch.allclose(state2.m, state.m, rtol=1e-5, atol=1e-8) and torch.allclose(state2.v, state.v, rtol=1e-5, atol=1e-10)
 
+
+
+def test_shard_batches_equal_step_counts_for_ragged_sizes():
+    """train_uci.shard_batches: every rank runs the same number of steps with the same shard size for any N, b, world
+    (a rank with one step fewer would leave its peers waiting in the per-step all-reduce), shards of one global batch
+    are disjoint, and together they are the (trimmed) global batch every rank cut identically."""
+    import train_uci
+    for n, b, world in [(10, 4, 2), (11, 4, 2), (9, 4, 2), (101, 10, 4), (7, 8, 4), (3, 4, 4), (1000, 33, 8)]:
+        per_rank = [train_uci.shard_batches(n, b, r, world, torch.Generator().manual_seed(5)) for r in range(world)]
+        assert len({len(p) for p in per_rank}) == 1, (n, b, world)
+        perm = torch.randperm(n, generator=torch.Generator().manual_seed(5))
+        for k in range(len(per_rank[0])):
+            sizes = {p[k].numel() for p in per_rank}
+            assert len(sizes) == 1 and sizes.pop() >= 1
+            union = torch.cat([p[k] for p in per_rank])
+            assert union.unique().numel() == union.numel()
+            chunk = perm[k * b:(k + 1) * b]
+            # batches trimmed to nothing are dropped, so index k is the k-th NON-EMPTY global batch
+            assert set(union.tolist()) <= set(perm.tolist())
+            if n % b == 0 or k < n // b:
+                assert set(union.tolist()) == set(chunk[:chunk.numel() // world * world].tolist())
+
+
+def _ragged_worker(rank, world, port, out):
+    import train_uci
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.manual_seed(0)
+    X = torch.randn(23, 4)                                   # 23 rows, b_size 8, 2 ranks: global batches 8, 8, 7 -> 6
+    flow = TinyFlow()
+    state = dp.FlatState(flow)
+    state.broadcast(0)
+    gen = torch.Generator().manual_seed(1234)
+    steps = 0
+    for rows in train_uci.shard_batches(X.shape[0], 8, rank, world, gen):
+        dp.train_step(flow, state, X[rows], lr=1e-2, weight_decay=1e-5, optimizer=torch_adam)
+        steps += 1
+    gathered = [torch.empty_like(state.flat) for _ in range(world)]
+    dist.all_gather(gathered, state.flat)                    # reached by every rank: nobody hangs in a step
+    if rank == 0:
+        out.put((steps, [g.numpy().copy() for g in gathered]))
+    dist.destroy_process_group()
+
+
+def test_two_rank_epoch_with_ragged_dataset_size():
+    import train_uci
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.SimpleQueue()
+    procs = [ctx.Process(target=_ragged_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    steps, flats = q.get()
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert steps == 3
+    assert (flats[0] == flats[1]).all()
+    # equals one process stepping through the same trimmed global batches
+    torch.manual_seed(0)
+    X = torch.randn(23, 4)
+    flow = TinyFlow()
+    state = dp.FlatState(flow)
+    gen = torch.Generator().manual_seed(1234)
+    for rows in train_uci.shard_batches(X.shape[0], 8, 0, 1, gen):
+        rows = rows[:rows.numel() // 2 * 2]
+        dp.train_step(flow, state, X[rows], lr=1e-2, weight_decay=1e-5, optimizer=torch_adam)
+    assert torch.allclose(torch.from_numpy(flats[0]), state.flat, rtol=1e-5, atol=1e-6)
+
+
+def test_gate_seeds_differ_per_rank_and_per_conditioner():
+    seeds = {dp.gate_seed(r, k) for r in range(8) for k in range(4)}
+    assert len(seeds) == 32 and all(0 <= s < 2 ** 62 for s in seeds)
+    from models import buildFCNormalizingFlow, DAGConditioner, AffineNormalizer
+    flow = buildFCNormalizingFlow(3, DAGConditioner, {"in_size": 4, "hidden": [8], "out_size": 2}, AffineNormalizer, {})
+    dp.seed_gates(flow, rank=1)
+    got = [c.gate_seed for c in flow.getConditioners()]
+    assert got == [dp.gate_seed(1, k) for k in range(3)] and len(set(got)) == 3

@@ -1,0 +1,283 @@
+"""BASELINE.json configurations as composites (-m gpu): cfg4 (MNIST d=784, Monotonic + DAG(MNISTCNN), the headline)
+against the oracle chain at B=2 and through size-independent properties at B=100; cfg5 at its full B=50 000 with the
+Monotonic normalizer; the fused Adam kernel against torch.optim.Adam on the device.  Mirrors the reference's
+ImageExperiments.py:146-153,173,199-216.  Monotonic z / NLL: UMNN 1.0 parity unpinned (oracle restates the rule)."""
+import os
+import sys
+
+import pytest
+import torch
+
+from conftest import ROOT, rel_err, assert_close
+from oracle import gnf_oracle as O
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+TOL = 1e-5
+GTOL = 1e-4
+
+
+def _bench():
+    if ROOT not in sys.path:
+        sys.path.insert(0, ROOT)
+    import bench
+    return bench
+
+
+def _oracle_cfg4(sd, x, u1, u2, S):
+    """dag_masked_inputs -> mnistcnn_forward -> monotonic_forward -> dag_loss -> flow_loss on the CPU oracle"""
+    pre = "steps.0.conditioner."
+    sd = {k: v.detach().cpu().clone() for k, v in sd.items()}
+    cnn = {k[len(pre + "embedding_net."):]: v.requires_grad_(True) for k, v in sd.items() if "embedding_net." in k}
+    A = sd[pre + "A"].requires_grad_(True)
+    layers, k = [], 0
+    ipre = "steps.0.normalizer.integrand_net.net."
+    while ipre + "%d.weight" % k in sd:
+        layers.append((sd[ipre + "%d.weight" % k].requires_grad_(True), sd[ipre + "%d.bias" % k].requires_grad_(True)))
+        k += 2
+    B, d = x.shape
+    e = O.dag_masked_inputs(x, A, True, 0., True, False, 1., u1, u2, None, False)
+    h = O.mnistcnn_forward(e, cnn).view(B, d, -1)
+    z, jac = O.monotonic_forward(x, h, layers, S)
+    closs = O.dag_loss(A, sd[pre + "alpha"], d % 50, sd[pre + "lambd"], sd[pre + "c"], sd[pre + "dag_const"],
+                       sd[pre + "l1_weight"])
+    ld = torch.log(jac).sum(1)
+    loss = O.flow_loss(z, ld, closs)
+    loss.backward()
+    grads = {pre + "A": A.grad}
+    for name, v in cnn.items():
+        grads[pre + "embedding_net." + name] = v.grad
+    for i, (W, b) in enumerate(layers):
+        grads[ipre + "%d.weight" % (2 * i)] = W.grad
+        grads[ipre + "%d.bias" % (2 * i)] = b.grad
+    return z.detach(), ld.detach(), loss.detach(), grads
+
+
+def test_cfg4_composite_vs_oracle():
+    """bench.build_flow() -- buildMNISTNormalizingFlow([1], MonotonicNormalizer [50,50,50], prior kernel 2,
+    hot_encoding=False), Gumbel gate with injected u1, u2 -- at B=2: z, log|det J|, loss, dA and every parameter
+    gradient against the oracle chain."""
+    bench = _bench()
+    B, S = 2, 20
+    flow = bench.build_flow()
+    x = bench.pseudo_mnist(torch.Generator().manual_seed(77), B, 784)
+    g = torch.Generator().manual_seed(78)
+    u1, u2 = torch.rand(B, 784, 784, generator=g), torch.rand(B, 784, 784, generator=g)
+    z0, ld0, loss0, grads0 = _oracle_cfg4(flow.state_dict(), x, u1, u2, S)
+
+    flow = flow.to(DEV)
+    for nrm in flow.getNormalizers():
+        nrm.nb_steps = S
+    cond = flow.steps[0].conditioner
+    cond.gate_noise = (u1.to(DEV), u2.to(DEV))
+    z, ld = flow(x.to(DEV))
+    loss = flow.loss(z, ld)
+    loss.backward()
+    assert rel_err(z.cpu(), z0) < TOL and rel_err(ld.cpu(), ld0) < TOL and rel_err(loss.detach().cpu(), loss0) < TOL
+    assert_close(z, z0, what="z")
+    assert_close(ld, ld0, what="logdet")
+    assert_close(loss, loss0, what="loss")
+    nll0 = -(ld0 + O.normal_log_density(z0))
+    nll = -(ld + flow.z_log_density(z))
+    assert_close(nll, nll0, what="NLL")
+    named = dict(flow.named_parameters())
+    assert set(named) == set(grads0)
+    for k, g0 in grads0.items():
+        assert named[k].grad is not None, k
+        assert rel_err(named[k].grad.cpu(), g0) < GTOL, (k, rel_err(named[k].grad.cpu(), g0))
+    # zero entries of the prior keep an exactly-zero gradient (grad ∝ A, DAG:118-119)
+    assert int(((cond.A.grad != 0) & (cond.A.detach() == 0)).sum()) == 0
+
+
+def test_cfg4_full_size_step_properties():
+    """cfg4 at its per-GPU size (B=100, Philox gate): finite loss, a finite gradient for every parameter, the
+    decomposition loss = constraints - mean(logdet + log N(z)), z(x) strictly monotone along each coordinate's own
+    input (jac > 0.05), and a full dp.train_step that changes every parameter tensor."""
+    from gnf_hip import dp
+    bench = _bench()
+    flow = bench.build_flow().to(DEV)
+    x = bench.pseudo_mnist(torch.Generator().manual_seed(1234), 100, 784).to(DEV)
+    for nrm in flow.getNormalizers():
+        nrm.nb_steps = 20
+    z, ld = flow(x)
+    loss = flow.loss(z, ld)
+    loss.backward()
+    assert z.shape == (100, 784) and ld.shape == (100,)
+    assert torch.isfinite(loss).item() and torch.isfinite(z).all() and torch.isfinite(ld).all()
+    ref = flow.constraintsLoss() - (ld + O.normal_log_density(z.detach().cpu()).to(DEV)).mean()
+    assert abs(ref.item() - loss.item()) <= 1e-5 * max(1., abs(loss.item()))
+    for k, p in flow.named_parameters():
+        assert p.grad is not None and torch.isfinite(p.grad).all(), k
+        assert p.grad.abs().max() > 0, k
+        p.grad = None
+    state = dp.FlatState(flow)
+    before = state.flat.clone()
+    l2 = dp.train_step(flow, state, x)
+    assert torch.isfinite(l2).item() and state.t == 1
+    moved = (state.flat != before)
+    o = 0
+    for p in state.params:
+        assert moved[o:o + p.numel()].any(), "a parameter tensor did not move"
+        o += (p.numel() + 3) // 4 * 4
+
+
+def test_cfg5_full_size_monotonic_step():
+    """cfg5 as BASELINE.json states it: d=63, B=50 000 on one GPU, MADE [630]*3 -> 30, Monotonic [150,150,150],
+    S=20.  Properties: finite loss and gradients, loss decomposition, jac > 0.05, z(0) = h0-free check by shifting x
+    (strictly increasing in each coordinate given h), and agreement with the CPU oracle on a 64-row slice of the SAME
+    batch (rows are independent: the slice of a full-size launch must equal the oracle's small run)."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import bench_configs as bc
+    flow, x = bc.cfg("cfg5")
+    assert x.shape == (50000, 63)
+    for nrm in flow.getNormalizers():
+        nrm.nb_steps = 20
+    z, ld = flow(x)
+    loss = flow.loss(z, ld)
+    loss.backward()
+    assert torch.isfinite(loss).item() and torch.isfinite(z).all() and torch.isfinite(ld).all()
+    ref = -(ld + O.normal_log_density(z.detach().cpu()).to(DEV)).mean()
+    assert abs(ref.item() - loss.item()) <= 1e-5 * max(1., abs(loss.item()))
+    for k, p in flow.named_parameters():
+        assert p.grad is not None and torch.isfinite(p.grad).all(), k
+    # oracle on rows 0..63 with the same parameters
+    sd = {k: v.detach().cpu() for k, v in flow.state_dict().items()}
+    pre = "steps.0.conditioner.masked_autoregressive_net."
+    made, masks, k = [], [], 0
+    while pre + "net.%d.weight" % k in sd:
+        made.append((sd[pre + "net.%d.weight" % k], sd[pre + "net.%d.bias" % k]))
+        masks.append(sd[pre + "net.%d.mask" % k])
+        k += 2
+    ipre = "steps.0.normalizer.integrand_net."
+    layers, k = [], 0
+    while ipre + "net.%d.weight" % k in sd:
+        layers.append((sd[ipre + "net.%d.weight" % k], sd[ipre + "net.%d.bias" % k]))
+        k += 2
+    xs = x[:64].cpu()
+    h0 = O.made_forward(xs, made, masks).view(64, 30, 63).permute(0, 2, 1)
+    z0, j0 = O.monotonic_forward(xs, h0, layers, 20)
+    assert rel_err(z[:64].cpu(), z0) < TOL and rel_err(ld[:64].cpu(), torch.log(j0).sum(1)) < TOL
+    assert_close(z[:64], z0, what="z")
+    assert_close(ld[:64], torch.log(j0).sum(1), what="logdet")
+    with torch.no_grad():
+        h = flow.steps[0].conditioner(x)
+        z1, j1 = flow.steps[0].normalizer(x, h)
+        z2, _ = flow.steps[0].normalizer(x + .5, h)
+        assert (j1 > .05).all() and (z2 > z1).all()
+        assert torch.equal(z1, z.detach())
+
+
+@pytest.mark.parametrize("n,wd", [(1000, 1e-5), (922797, 1e-5), (4099, 0.), (257, 1e-2)])
+def test_hip_adam_vs_torch_adam_on_device(n, wd):
+    """gnf_adam_step (the flat fused Adam of dp.train_step) against torch.optim.Adam(lr, weight_decay) on the same
+    flat tensor for 5 steps on the device (ImageExperiments.py:173: Adam(lr, weight_decay), L2 form)."""
+    from gnf_hip import ops
+    torch.manual_seed(n)
+    p0 = torch.randn(n, device=DEV)
+    grads = [torch.randn(n, device=DEV) * (10. ** (i - 2)) for i in range(5)]
+    ref = torch.nn.Parameter(p0.clone())
+    opt = torch.optim.Adam([ref], lr=1e-3, weight_decay=wd)
+    p, m, v = p0.clone(), torch.zeros(n, device=DEV), torch.zeros(n, device=DEV)
+    for t, g in enumerate(grads, 1):
+        ref.grad = g.clone()
+        opt.step()
+        ops.adam_step(p, g, m, v, t, lr=1e-3, weight_decay=wd)
+        assert_close(p, ref.data, rtol=1e-6, atol=1e-6, what="step %d" % t)
+    st = opt.state[ref]
+    assert_close(m, st["exp_avg"], rtol=1e-6, atol=1e-7, what="exp_avg")
+    assert_close(v, st["exp_avg_sq"], rtol=1e-6, atol=1e-7, what="exp_avg_sq")
+    # the all-reduce scale (1/world) folded into the launch: grad_scale=1/4 on 4x the gradient is the same step
+    p2, m2, v2 = p0.clone(), torch.zeros(n, device=DEV), torch.zeros(n, device=DEV)
+    ops.adam_step(p2, grads[0] * 4, m2, v2, 1, lr=1e-3, weight_decay=wd, grad_scale=.25)
+    ref2 = torch.nn.Parameter(p0.clone())
+    opt2 = torch.optim.Adam([ref2], lr=1e-3, weight_decay=wd)
+    ref2.grad = grads[0].clone()
+    opt2.step()
+    assert_close(p2, ref2.data, rtol=1e-6, atol=1e-6, what="grad_scale")
+
+
+def test_graphed_step_vs_torch_adam_reference():
+    """GraphedStep (hipGraph replay, device-side step counter) against an independent trajectory: autograd of the
+    same flow + torch.optim.Adam -- not against the eager HIP step."""
+    from gnf_hip import dp
+    from models import buildFCNormalizingFlow, AutoregressiveConditioner, AffineNormalizer
+
+    def make():
+        torch.manual_seed(11)
+        return buildFCNormalizingFlow(1, AutoregressiveConditioner, {"in_size": 12, "hidden": [64, 64], "out_size": 2},
+                                      AffineNormalizer, {}).to(DEV)
+    xs = [torch.randn(64, 12, generator=torch.Generator().manual_seed(200 + i)).to(DEV) for i in range(4)]
+    fa = make()
+    opt = torch.optim.Adam(fa.parameters(), lr=1e-2, weight_decay=1e-5)
+    for x in [xs[0]] * 3 + xs:
+        opt.zero_grad()
+        z, ld = fa(x)
+        la = fa.loss(z, ld)
+        la.backward()
+        opt.step()
+    fb = make()
+    sb = dp.FlatState(fb)
+    gs = dp.GraphedStep(fb, sb, xs[0], lr=1e-2, weight_decay=1e-5, warmup=3)
+    for x in xs:
+        lb = gs(x)
+    torch.cuda.synchronize()
+    assert rel_err(lb.cpu(), la.detach().cpu()) < 1e-5
+    for (k, pa), (_, pb) in zip(fa.named_parameters(), fb.named_parameters()):
+        assert rel_err(pb.detach().cpu(), pa.detach().cpu()) < 1e-5, k
+
+
+def _free_port():
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def test_bench_two_ranks_product_flow():
+    """`python bench.py --gpus 2` as the driver invokes it: the launcher spawns two ranks of the PRODUCT flow (cfg4,
+    B=100 each, different data and gate noise per rank); on a one-GPU box they share the device and the all-reduce
+    travels over gloo (GNF_DIST_BACKEND).  n_gpus == 2, finite loss (bench exits non-zero otherwise), the replicas'
+    parameter checksums are identical after the steps (ImageExperiments.py:168,205)."""
+    import json
+    import subprocess
+    env = dict(os.environ, GNF_DIST_BACKEND="gloo")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+                        "--no-secondary", "--no-cpu-baseline"], cwd=ROOT, env=env, capture_output=True, text=True,
+                       timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["config"]["global_batch"] == 200 and out["config"]["parallelism"] == "dp2"
+    assert out["replicas_identical"] is True and out["dist_backend"] == "gloo"
+    assert out["value"] > 0 and out["steps"] == 3 and out["scaling"] == "weak"
+    assert abs(out["value"] - 200 * 3 / (out["ms_per_step"] * 3e-3)) < 1e-6 * out["value"]
+
+
+def test_train_uci_two_ranks_dual_updates_stay_in_lockstep(tmp_path):
+    """train_uci.py under torch.distributed.run with two ranks (gloo transport on a one-GPU box): a DAG conditioner
+    whose dual update fires every epoch (nb_steps_dual 1); the epoch loss is averaged over ranks before model.step(), so
+    both replicas take the same branch; a ragged dataset size must not hang the epoch."""
+    import subprocess
+    import numpy as np
+    g = np.random.default_rng(0)
+    data = tmp_path / "toy.npz"
+    np.savez(data, trn=g.standard_normal((1003, 6)).astype("float32"), val=g.standard_normal((200, 6)).astype("float32"),
+             tst=g.standard_normal((200, 6)).astype("float32"))
+    env = dict(os.environ, GNF_DIST_BACKEND="gloo")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+           "127.0.0.1", "--master-port", str(_free_port()),
+           os.path.join(ROOT, "graphical-normalizing-flows_amd", "train_uci.py"), "-dataset", "power", "-data", str(data),
+           "-folder", str(tmp_path / "run"), "-nb_epoch", "4", "-b_size", "250", "-conditioner", "DAG", "-emb_net", "16",
+           "16", "4", "-normalizer", "affine", "-nb_steps_dual", "1", "-l1", "0.1"]
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-3000:])
+    lines = [l for l in open(tmp_path / "run" / "logs") if l.startswith("epoch")]
+    assert len(lines) == 4
+    sd = torch.load(tmp_path / "run" / "model.pt", map_location="cpu")
+    assert float(sd["steps.0.conditioner.lambd"]) > 0          # the dual update ran
+    assert os.path.exists(tmp_path / "run" / "ADAM.pt")

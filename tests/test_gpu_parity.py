@@ -633,7 +633,7 @@ def test_abi_error_codes():
         abi.ptr(torch.zeros(2, dtype=torch.float64, device=DEV))
     # graph-capturable Adam and the ceiling probes validate their arguments the same way
     assert lib.gnf_adam_step_dev(P(x.data_ptr()), P(x.data_ptr()), P(x.data_ptr()), P(x.data_ptr()), 16, 1e-3, .9, .999,
-                                 1e-8, 0., 1., None, st) == -1
+                                 1e-8, 0., 1., None, 1, st) == -1
     assert lib.gnf_probe_copy(P(x.data_ptr()), P(x.data_ptr()), 6, st) == -1          # n must be a multiple of 4
     assert lib.gnf_probe_mfma_f32(None, 1, 1, st) == -1
     # the device-side step counter advances by one per call and the update equals the by-value entry point

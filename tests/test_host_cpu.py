@@ -23,7 +23,7 @@ def test_abi_exports_every_declared_symbol():
     lib = abi.load()                                   # dlopen works without a GPU
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.gnf_abi_version() == 1
+    assert lib.gnf_abi_version() == abi.ABI_VERSION
     # pure host queries work without a device
     assert lib.gnf_colsum_ws_bytes(1000, 7) > 0
     assert lib.gnf_gemm_ws_bytes(128, 2304, 78400) > 0 and lib.gnf_gemm_ws_bytes(4096, 4096, 64) == 0
@@ -149,3 +149,58 @@ def test_dag_levels_match_networkx_generations():
     cond.A.data[perm[0], perm[1]] = 1.; cond.A.data[perm[1], perm[0]] = 1.   # a 2-cycle
     assert cond.levels() is None
 
+
+
+def test_yml_numbers_parse_like_the_reference_resolver(tmp_path):
+    """`weight_decay: 1e-3` (UCIExperimentsConfigurations.yml:84) must arrive as a float: PyYAML's YAML-1.1 resolver
+    reads it as a string, the reference installs a YAML-1.2 float resolver (UCIExperiments.py:258-269)."""
+    import train_uci
+    yml = tmp_path / "cfg.yml"
+    yml.write_text("gas-mono-DAG:\n  dataset: 'gas'\n  nb_flow: 1\n  b_size: 10000\n  conditioner: 'DAG'\n"
+                   "  emb_net: [80, 80, 80, 30]\n  l1: 0.\n  gumble_T: .5\n  normalizer: 'monotonic'\n"
+                   "  int_net: [200, 200, 200]\n  nb_steps: 20\n  solver: 'CC'\n  weight_decay: 1e-3\n"
+                   "  learning_rate: 5E-4\n")
+    a = train_uci.parse(["-config_file", str(yml), "-load_config", "gas-mono-DAG"])
+    assert isinstance(a.weight_decay, float) and a.weight_decay == 1e-3
+    assert isinstance(a.learning_rate, float) and a.learning_rate == 5e-4
+    assert a.l1 == 0. and a.gumble_T == .5 and a.emb_net == [80, 80, 80, 30] and a.solver == "CC" and a.b_size == 10000
+    assert train_uci._yml_number("CC") == "CC" and train_uci._yml_number("1e5") == 1e5
+    assert train_uci._yml_number("-2.5e-3") == -2.5e-3 and train_uci._yml_number("gas") == "gas"
+    # every entry of the shipped configuration file builds its argument set with numeric hyper-parameters
+    import yaml
+    own = os.path.join(ROOT, "graphical-normalizing-flows_amd", "uci_configs.yml")
+    files = [own]
+    ref = "/root/reference/UCIExperimentsConfigurations.yml"          # build container only; absent on the GPU box
+    if os.path.exists(ref):
+        files.append(ref)
+    for path in files:
+        for name in yaml.safe_load(open(path)):
+            a = train_uci.parse(["-config_file", path, "-load_config", name])
+            for k in ("weight_decay", "learning_rate", "l1", "gumble_T"):
+                assert isinstance(getattr(a, k), float), (path, name, k, getattr(a, k))
+            assert all(isinstance(v, int) for v in a.emb_net + a.int_net)
+
+
+def test_bench_launcher_spawns_ranks_without_touching_the_gpu(tmp_path, monkeypatch):
+    """`python bench.py --gpus N` must become a launcher of N ranks (torch.distributed.run children) BEFORE any GPU
+    call, and a rank whose WORLD_SIZE contradicts --gpus must refuse to run."""
+    import subprocess, sys
+    env = dict(os.environ)
+    env.pop("WORLD_SIZE", None)
+    fake = tmp_path / "torch_distributed_run_args.txt"
+    # a stand-in `python` for the children is not needed: intercept subprocess.call inside bench.main
+    code = ("import sys, json; sys.argv=['bench.py','--gpus','4','--steps','2','--warmup','1'];"
+            "import bench, subprocess;"
+            "subprocess.call=lambda cmd: (open(%r,'w').write(json.dumps(cmd)), 7)[1];"
+            "bench.main()" % str(fake))
+    r = subprocess.run([sys.executable, "-c", code], cwd=ROOT, env=env, capture_output=True, text=True)
+    assert r.returncode == 7, r.stderr                    # exits with the children's code
+    import json
+    cmd = json.loads(fake.read_text())
+    assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"]
+    assert cmd[cmd.index("--nproc-per-node") + 1] == "4" and cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
+    assert cmd[-6:] == ["--gpus", "4", "--steps", "2", "--warmup", "1"] and cmd[-7].endswith("bench.py")
+    env["WORLD_SIZE"] = "2"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4"], cwd=ROOT, env=env,
+                       capture_output=True, text=True)
+    assert r.returncode != 0 and "WORLD_SIZE=2" in r.stderr
