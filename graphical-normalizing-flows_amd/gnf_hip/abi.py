@@ -15,6 +15,7 @@ c_f = ctypes.c_void_p            # device float*
 c_i64 = ctypes.c_int64
 c_int = ctypes.c_int
 c_float = ctypes.c_float
+c_double = ctypes.c_double
 c_u64 = ctypes.c_uint64
 c_stream = ctypes.c_void_p
 
@@ -63,7 +64,7 @@ SIGNATURES = {
     "gnf_dag_loss_prep": (c_int, [c_f, c_f, c_float, c_f, c_i64, c_stream]),
     "gnf_dag_loss_value": (c_int, [c_f, c_f, c_f, c_f, c_float, c_f, c_f, c_f, c_f, c_int, c_f, c_f, c_i64, c_stream]),
     "gnf_dag_loss_bwd": (c_int, [c_f, c_f, c_f, c_f, c_f, c_i64, c_stream]),
-    "gnf_mnistcnn_conv_fwd": (c_int, [c_f, c_f, c_f, c_f, c_f, c_f, ctypes.c_void_p, c_i64, c_stream]),
+    "gnf_mnistcnn_conv_fwd": (c_int, [c_f, c_f, c_f, c_f, c_f, c_f, ctypes.c_void_p, c_i64, c_int, c_stream]),
     "gnf_mnistcnn_conv_bwd_ws_bytes": (c_i64, [c_i64]),
     "gnf_mnistcnn_conv_bwd": (c_int, [c_f, c_f, c_f, c_f, c_f, ctypes.c_void_p, c_f, c_f, c_f, c_f, c_f,
                                       ctypes.c_void_p, c_i64, c_i64, c_stream]),
@@ -76,9 +77,9 @@ SIGNATURES = {
                                         ctypes.c_void_p, c_i64, ctypes.c_void_p, c_f, c_f, c_f,
                                         c_f, c_f, c_i64, c_f, ctypes.c_void_p, c_f, c_f, c_f, c_f, c_f, c_f, c_f,
                                         ctypes.c_void_p, c_i64, c_stream]),
-    "gnf_adam_step": (c_int, [c_f, c_f, c_f, c_f, c_i64, c_float, c_float, c_float, c_float, c_float, c_float, c_int,
+    "gnf_adam_step": (c_int, [c_f, c_f, c_f, c_f, c_i64, c_double, c_double, c_double, c_double, c_double, c_double, c_int,
                               c_stream]),
-    "gnf_adam_step_dev": (c_int, [c_f, c_f, c_f, c_f, c_i64, c_float, c_float, c_float, c_float, c_float, c_float,
+    "gnf_adam_step_dev": (c_int, [c_f, c_f, c_f, c_f, c_i64, c_double, c_double, c_double, c_double, c_double, c_double,
                                   ctypes.c_void_p, c_int, c_stream]),
     "gnf_probe_mfma_f32": (c_i64, [c_f, c_int, c_int, c_stream]),
     "gnf_probe_copy": (c_int, [c_f, c_f, c_i64, c_stream]),

@@ -1117,23 +1117,23 @@ int gnf_debug_fwd_timing(float* host64) { return (int)hipMemcpyFromSymbol(host64
 #endif
 
 int gnf_mnistcnn_conv_fwd(const float* e, const float* W1, const float* b1, const float* W2, const float* b2,
-                          float* pooled, unsigned char* argmax, int64_t n_img, gnf_stream_t stream) {
+                          float* pooled, unsigned char* argmax, int64_t n_img, int exact_ties, gnf_stream_t stream) {
   if (!e || !W1 || !b1 || !W2 || !b2 || !pooled || !argmax || n_img < 0) return GNF_EINVAL;
   if (n_img == 0) return 0;
   CnnArgs a{};
   a.e = e; a.W1 = W1; a.b1 = b1; a.W2 = W2; a.b2 = b2; a.pooled = pooled; a.arg = argmax; a.n = n_img;
-#ifdef GNF_CNN_DIRECT_FWD
-  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&cnn_fwd_k), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)kFwdLds);
-  const unsigned grid = n_img < kFwdGrid ? (unsigned)n_img : kFwdGrid;
-  hipLaunchKernelGGL(cnn_fwd_k, dim3(grid), dim3(64 * FWD_WAVES), kFwdLds, (hipStream_t)stream, a);
-#else
-  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&cnn_fwd_wino_k),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)kWinoLds);
-  const int64_t npair = (n_img + 1) / 2;
-  const unsigned grid = npair < kWinoGrid ? (unsigned)npair : kWinoGrid;
-  hipLaunchKernelGGL(cnn_fwd_wino_k, dim3(grid), dim3(64 * FWD_WAVES), kWinoLds, (hipStream_t)stream, a);
-#endif
+  if (exact_ties) {                                 // direct implicit GEMM: bit-equal outputs for equal patches
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&cnn_fwd_k), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)kFwdLds);
+    const unsigned grid = n_img < kFwdGrid ? (unsigned)n_img : kFwdGrid;
+    hipLaunchKernelGGL(cnn_fwd_k, dim3(grid), dim3(64 * FWD_WAVES), kFwdLds, (hipStream_t)stream, a);
+  } else {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&cnn_fwd_wino_k),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)kWinoLds);
+    const int64_t npair = (n_img + 1) / 2;
+    const unsigned grid = npair < kWinoGrid ? (unsigned)npair : kWinoGrid;
+    hipLaunchKernelGGL(cnn_fwd_wino_k, dim3(grid), dim3(64 * FWD_WAVES), kWinoLds, (hipStream_t)stream, a);
+  }
   GNF_LAUNCH_CHECK();
   return 0;
 }

@@ -214,37 +214,51 @@ __global__ void colsum_stage2_k(const float* __restrict__ ws, float* __restrict_
 }
 
 // ------------------------------------------------------------------ Adam (L2 decay, bias-corrected)
-__global__ void adam_k(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
-                       float* __restrict__ v, int64_t n, float lr, float b1, float b2, float eps, float wd,
-                       float gscale, float bc1, float bc2_sqrt) {
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-    const float pi = p[i];
-    const float gi = fmaf(wd, pi, g[i] * gscale);
-    const float mi = fmaf(b1, m[i], (1.f - b1) * gi);
-    const float vi = fmaf(b2, v[i], (1.f - b2) * gi * gi);
-    m[i] = mi;
-    v[i] = vi;
-    // torch.optim.Adam: denom = sqrt(v)/sqrt(bc2) + eps; p -= lr/bc1 * m/denom
-    p[i] = pi - (lr / bc1) * (mi / (sqrtf(vi) / bc2_sqrt + eps));
+// Hyper-parameters arrive as doubles and every derived constant (1-beta, lr / bias-correction, sqrt of the second
+// bias-correction) is formed in double and rounded ONCE, as torch.optim.Adam does on the host: 1.f - 0.999f is
+// 1.3e-5 away from (float)(1 - 0.999), which shows in exp_avg_sq after a single step.
+struct AdamC { float b1, b2, omb1, omb2, eps, wd, gscale; };
+
+__device__ __forceinline__ void adam_elem(float& p, float g, float& m, float& v, const AdamC& c, float step_size,
+                                          float bc2_sqrt) {
+  const float gi = fmaf(c.wd, p, g * c.gscale);
+  m = fmaf(c.b1, m, c.omb1 * gi);
+  v = fmaf(c.b2, v, c.omb2 * gi * gi);
+  // torch.optim.Adam: denom = sqrt(v)/sqrt(bc2) + eps; p -= lr/bc1 * m/denom
+  p = p - step_size * (m / (sqrtf(v) / bc2_sqrt + c.eps));
+}
+
+// n4 float4 groups + a scalar tail; 16-B alignment of the four buffers is checked by the launcher
+__device__ __forceinline__ void adam_body(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                          float* __restrict__ v, int64_t n, bool vec, const AdamC& c, float step_size,
+                                          float bc2_sqrt) {
+  const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, nth = (int64_t)gridDim.x * blockDim.x;
+  const int64_t n4 = vec ? n >> 2 : 0;
+  for (int64_t i = tid; i < n4; i += nth) {
+    float4 pp = reinterpret_cast<float4*>(p)[i], mm = reinterpret_cast<float4*>(m)[i], vv = reinterpret_cast<float4*>(v)[i];
+    const float4 gg = reinterpret_cast<const float4*>(g)[i];
+    adam_elem(pp.x, gg.x, mm.x, vv.x, c, step_size, bc2_sqrt);
+    adam_elem(pp.y, gg.y, mm.y, vv.y, c, step_size, bc2_sqrt);
+    adam_elem(pp.z, gg.z, mm.z, vv.z, c, step_size, bc2_sqrt);
+    adam_elem(pp.w, gg.w, mm.w, vv.w, c, step_size, bc2_sqrt);
+    reinterpret_cast<float4*>(p)[i] = pp; reinterpret_cast<float4*>(m)[i] = mm; reinterpret_cast<float4*>(v)[i] = vv;
   }
+  for (int64_t i = 4 * n4 + tid; i < n; i += nth) adam_elem(p[i], g[i], m[i], v[i], c, step_size, bc2_sqrt);
+}
+
+__global__ void adam_k(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                       float* __restrict__ v, int64_t n, int vec, AdamC c, float step_size, float bc2_sqrt) {
+  adam_body(p, g, m, v, n, vec != 0, c, step_size, bc2_sqrt);
 }
 
 // Same update with the step count in device memory, so that a captured hipGraph of the whole training step can be
 // replayed: the bias corrections are recomputed on the device from *step_dev + 1; adam_bump_k then advances it.
 __global__ void adam_dev_k(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
-                           float* __restrict__ v, int64_t n, float lr, float b1, float b2, float eps, float wd,
-                           float gscale, const int* __restrict__ step_dev) {
-  const float t = (float)(*step_dev + 1);
-  const float bc1 = 1.f - powf(b1, t), bc2_sqrt = sqrtf(1.f - powf(b2, t));
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-    const float pi = p[i];
-    const float gi = fmaf(wd, pi, g[i] * gscale);
-    const float mi = fmaf(b1, m[i], (1.f - b1) * gi);
-    const float vi = fmaf(b2, v[i], (1.f - b2) * gi * gi);
-    m[i] = mi;
-    v[i] = vi;
-    p[i] = pi - (lr / bc1) * (mi / (sqrtf(vi) / bc2_sqrt + eps));
-  }
+                           float* __restrict__ v, int64_t n, int vec, AdamC c, double lr, double b1, double b2,
+                           const int* __restrict__ step_dev) {
+  const double t = (double)(*step_dev + 1);
+  const float step_size = (float)(lr / (1.0 - pow(b1, t))), bc2_sqrt = (float)sqrt(1.0 - pow(b2, t));
+  adam_body(p, g, m, v, n, vec != 0, c, step_size, bc2_sqrt);
 }
 __global__ void adam_bump_k(int* step_dev) { *step_dev += 1; }
 
@@ -403,25 +417,38 @@ int gnf_colsum(const float* a, int64_t lda, float* out, int64_t M, int64_t N, fl
   return 0;
 }
 
-int gnf_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
-                  float eps, float weight_decay, float grad_scale, int step, gnf_stream_t stream) {
+static AdamC adam_consts(double beta1, double beta2, double eps, double weight_decay, double grad_scale) {
+  AdamC c;
+  c.b1 = (float)beta1; c.b2 = (float)beta2; c.omb1 = (float)(1.0 - beta1); c.omb2 = (float)(1.0 - beta2);
+  c.eps = (float)eps; c.wd = (float)weight_decay; c.gscale = (float)grad_scale;
+  return c;
+}
+static int adam_vec_ok(const float* p, const float* g, const float* m, const float* v) {
+  return ((((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15u) == 0) ? 1 : 0;
+}
+
+int gnf_adam_step(float* p, const float* g, float* m, float* v, int64_t n, double lr, double beta1, double beta2,
+                  double eps, double weight_decay, double grad_scale, int step, gnf_stream_t stream) {
   if (!p || !g || !m || !v || n < 0 || step < 1) return GNF_EINVAL;
   if (n == 0) return 0;
-  const float bc1 = 1.f - powf(beta1, (float)step);
-  const float bc2s = sqrtf(1.f - powf(beta2, (float)step));
-  hipLaunchKernelGGL(adam_k, dim3(grid_1d(n)), dim3(kBlock), 0, (hipStream_t)stream, p, g, m, v, n, lr, beta1, beta2,
-                     eps, weight_decay, grad_scale, bc1, bc2s);
+  const float step_size = (float)(lr / (1.0 - pow(beta1, (double)step)));
+  const float bc2s = (float)sqrt(1.0 - pow(beta2, (double)step));
+  const int vec = adam_vec_ok(p, g, m, v);
+  hipLaunchKernelGGL(adam_k, dim3(grid_1d(vec ? (n + 3) / 4 : n)), dim3(kBlock), 0, (hipStream_t)stream, p, g, m, v, n,
+                     vec, adam_consts(beta1, beta2, eps, weight_decay, grad_scale), step_size, bc2s);
   GNF_LAUNCH_CHECK();
   return 0;
 }
 
-int gnf_adam_step_dev(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
-                      float eps, float weight_decay, float grad_scale, int* step_dev, int advance,
+int gnf_adam_step_dev(float* p, const float* g, float* m, float* v, int64_t n, double lr, double beta1, double beta2,
+                      double eps, double weight_decay, double grad_scale, int* step_dev, int advance,
                       gnf_stream_t stream) {
   if (!p || !g || !m || !v || !step_dev || n < 0) return GNF_EINVAL;
   if (n == 0) return 0;
-  hipLaunchKernelGGL(adam_dev_k, dim3(grid_1d(n)), dim3(kBlock), 0, (hipStream_t)stream, p, g, m, v, n, lr, beta1,
-                     beta2, eps, weight_decay, grad_scale, (const int*)step_dev);
+  const int vec = adam_vec_ok(p, g, m, v);
+  hipLaunchKernelGGL(adam_dev_k, dim3(grid_1d(vec ? (n + 3) / 4 : n)), dim3(kBlock), 0, (hipStream_t)stream, p, g, m, v,
+                     n, vec, adam_consts(beta1, beta2, eps, weight_decay, grad_scale), lr, beta1, beta2,
+                     (const int*)step_dev);
   if (advance) hipLaunchKernelGGL(adam_bump_k, dim3(1), dim3(1), 0, (hipStream_t)stream, step_dev);
   GNF_LAUNCH_CHECK();
   return 0;

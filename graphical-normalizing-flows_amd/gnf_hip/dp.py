@@ -166,10 +166,25 @@ def replicas_identical(state, module=None):
     return all(int(a.item()) == int(all_[0].item()) for a in all_)
 
 
-def train_step(flow, state, x_shard, lr=1e-3, weight_decay=1e-5, optimizer=hip_adam):
+GRAPH_MAX_ELEMS = 1 << 18               # auto-replay only steps small enough to be launch-bound (cfg1: 1 Ki, cfg3: 77 Ki
+                                        # elements; cfg5's 3.1 M-element step is GPU-bound and stages GiBs per capture)
+
+
+def train_step(flow, state, x_shard, lr=1e-3, weight_decay=1e-5, optimizer=hip_adam, graph="auto"):
     """fwd + log|det J| + NLL (+ constraints) + bwd on the local shard, one all-reduce, Adam.
-    loss_rank = constraints - mean_local(log p); averaging over ranks gives the global mean."""
+    loss_rank = constraints - mean_local(log p); averaging over ranks gives the global mean.
+
+    graph="auto": single-process steps of gate-free (graphable) flows on small batches are captured once per variant and
+    replayed as a hipGraph (GraphedStep: cfg1 0.68 -> 0.16 ms, cfg3 0.72 -> 0.27 ms per step); graph=False forces the
+    launch-by-launch path.  The returned loss tensor of a replayed step is reused by the next replay."""
     world = dist.get_world_size() if dist.is_initialized() else 1
+    if (graph and world == 1 and optimizer is hip_adam and x_shard.is_cuda and x_shard.numel() <= GRAPH_MAX_ELEMS
+            and torch.is_grad_enabled() and GraphedStep.graphable(flow)):
+        gs = getattr(state, "_graphed", None)
+        if gs is None or gs.flow is not flow or (gs.lr, gs.weight_decay) != (lr, weight_decay):
+            state._graphed = gs = GraphedStep(flow, state, x_shard, lr=lr, weight_decay=weight_decay, warmup=1)
+            return gs.loss
+        return gs(x_shard)
     z, logdet = flow(x_shard)
     loss = flow.loss(z, logdet)
     loss.backward()
@@ -197,15 +212,17 @@ class GraphedStep:
 
     Construction runs `warmup` real steps on x_example (they count as training steps), then captures."""
 
+    MAX_GRAPHS = 16                      # captured variants kept (node-count jitter 20..29 of the drivers = 10)
+
     def __init__(self, flow, state, x_example, lr=1e-3, weight_decay=1e-5, warmup=3):
         if dist.is_initialized() and dist.get_world_size() > 1:
             raise RuntimeError("GraphedStep is single-process; use train_step under torchrun")
         self.state, self.flow = state, flow
         self.lr, self.weight_decay = lr, weight_decay
-        self.x = x_example.clone()
-        self.step_dev = torch.full((1,), state.t, dtype=torch.int32, device=self.x.device)
+        self.step_dev = torch.full((1,), state.t, dtype=torch.int32, device=x_example.device)
         self.captures = 0
-        self._capture(max(warmup, 1))
+        self._graphs = {}                    # fingerprint -> (graph, loss tensor, input buffer)
+        self.loss = self._capture(x_example, max(warmup, 1))
 
     @staticmethod
     def graphable(flow):
@@ -215,23 +232,26 @@ class GraphedStep:
                     return False
         return True
 
-    def _fingerprint(self):
-        fp = [tuple(self.x.shape)]
+    def _fingerprint(self, shape):
+        fp = [tuple(shape)]
         for c in self.flow.getConditioners():
             fp.append((getattr(c, "exponent", None), getattr(c, "stoch_gate", None), getattr(c, "noise_gate", None),
                        getattr(c, "s_thresh", None), float(getattr(c, "h_thresh", 0.)), getattr(c, "alpha_factor", None),
-                       tuple((id(b), ) for b in c.buffers(recurse=False))))
+                       tuple(id(b) for b in c.buffers(recurse=False))))
         for nrm in self.flow.getNormalizers():
             fp.append(getattr(nrm, "nb_steps", None))
         fp.append(tuple(p.requires_grad for p in self.state.params))
         return tuple(fp)
 
-    def _capture(self, warmup):
+    def _capture(self, x, warmup):
+        """`warmup` eager steps on x (real, counted training steps; the loss of the last one is returned), then the
+        capture of one more step for this fingerprint"""
         from . import ops
         flow, state = self.flow, self.state
         if not self.graphable(flow):
             raise RuntimeError("a stochastic DAG gate draws its noise from a host-side counter: not graphable")
         lr, weight_decay = self.lr, self.weight_decay
+        xbuf = x.clone()
 
         # The captured step differentiates w.r.t. FRESH leaves aliasing the parameters (torch.func.functional_call), not
         # the nn.Parameters themselves: a Parameter's gradient accumulator remembers the stream it was created on and is
@@ -253,7 +273,7 @@ class GraphedStep:
 
         def body():
             leaves = [p.detach().requires_grad_(i in live) for i, p in enumerate(state.params)]
-            loss = torch.func.functional_call(wrapper, dict(zip(names, leaves)), (self.x,))
+            loss = torch.func.functional_call(wrapper, dict(zip(names, leaves)), (xbuf,))
             got = torch.autograd.grad(loss, [leaves[i] for i in live], allow_unused=True)
             grads = [None] * len(leaves)
             for i, g in zip(live, got):
@@ -261,9 +281,8 @@ class GraphedStep:
             state.pack_grads(grads)
             runs = state.active_runs
             for k, (o, n) in enumerate(runs):       # the device-side counter is advanced by the last launch only
-                last = k == len(runs) - 1
                 ops.adam_step_dev(state.flat[o:o + n], state.grad[o:o + n], state.m[o:o + n], state.v[o:o + n],
-                                  self.step_dev, lr=lr, weight_decay=weight_decay, advance=last)
+                                  self.step_dev, lr=lr, weight_decay=weight_decay, advance=(k == len(runs) - 1))
             return loss.detach()
 
         self.step_dev.fill_(state.t)
@@ -271,22 +290,28 @@ class GraphedStep:
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
             for _ in range(warmup):
-                body()
+                last = body().clone()
                 state.t += 1
         torch.cuda.current_stream().wait_stream(side)
-        self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
-            self.loss = body()
-        self._captured = self._fingerprint()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            loss = body()
+        if len(self._graphs) >= self.MAX_GRAPHS:
+            self._graphs.pop(next(iter(self._graphs)))
+        self._graphs[self._fingerprint(x.shape)] = (graph, loss, xbuf)
         self.captures += 1
+        return last
 
     def __call__(self, x):
-        if tuple(x.shape) != tuple(self.x.shape):
-            self.x = x.clone()
-        else:
-            self.x.copy_(x, non_blocking=True)
-        if self._fingerprint() != self._captured:
-            self._capture(1)                        # one eager step on x (counted), then a fresh capture
-        self.graph.replay()
+        entry = self._graphs.get(self._fingerprint(x.shape))
+        if entry is None:
+            # something a captured step bakes in by value changed (or a new batch shape / node count): this call's step
+            # runs eagerly and a graph for the new variant is captured behind it
+            self.loss = self._capture(x, 1)
+            return self.loss
+        graph, loss, xbuf = entry
+        xbuf.copy_(x, non_blocking=True)
+        graph.replay()
         self.state.t += 1
-        return self.loss
+        self.loss = loss
+        return loss

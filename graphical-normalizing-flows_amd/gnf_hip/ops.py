@@ -204,14 +204,16 @@ class MnistConvFn(torch.autograd.Function):
     (models/MLP.py:36-43), fused in LDS; backward recomputes conv1 in-kernel."""
 
     @staticmethod
-    def forward(ctx, e, W1, b1, W2, b2):
+    def forward(ctx, e, W1, b1, W2, b2, exact_ties=False):
+        """exact_ties: direct-convolution forward whose pool argmax follows torch's first-maximum rule on exactly tied
+        windows (include/gnf_hip.h); the Winograd forward otherwise"""
         e = e.contiguous()
         n = e.shape[0]
         W1c, b1c, W2c, b2c = W1.contiguous(), b1.contiguous(), W2.contiguous(), b2.contiguous()
         pooled = _empty((n, 2304), e)
         arg = torch.empty((n, 2304), dtype=torch.uint8, device=e.device)
         call("gnf_mnistcnn_conv_fwd", ptr(e), ptr(W1c), ptr(b1c), ptr(W2c), ptr(b2c), ptr(pooled), abi.rawptr(arg), n,
-             stream())
+             int(bool(exact_ties)), stream())
         ctx.save_for_backward(e, W1c, b1c, W2c, arg)
         return pooled
 
@@ -226,7 +228,7 @@ class MnistConvFn(torch.autograd.Function):
         ws = _ws(nws, e)
         call("gnf_mnistcnn_conv_bwd", ptr(e), ptr(W1), ptr(b1), ptr(W2), ptr(gp), abi.rawptr(arg), ptr(ge), ptr(gW1),
              ptr(gb1), ptr(gW2), ptr(gb2), abi.rawptr(ws), nws, n, stream())
-        return ge, gW1, gb1, gW2, gb2
+        return ge, gW1, gb1, gW2, gb2, None
 
 
 def crop_origin(p):
@@ -498,6 +500,74 @@ def monotonic_inverse(z, h, nb_steps, params):
     call("gnf_monotonic_inv", ptr(pack), ctypes.byref(net), ptr(z), ptr(h), h.stride(0), h.stride(1), h.stride(2),
          ptr(w), ptr(t), int(nb_steps), ptr(x), B, d, stream())
     return x
+
+
+class ModuleIntegralFn(torch.autograd.Function):
+    """z = int_0^x f(t; h) dt for a USER-SUPPLIED integrand module (MonotonicNormalizer(integrand_net=<nn.Module>),
+    reference MonotonicNormalizer.py:44-48,51-63): the module is honoured as it is and evaluated through PyTorch-ROCm
+    on the device, at all Clenshaw-Curtis nodes in one batch ("CCParallel" form; "CC" gives the same numbers up to
+    summation order).  Only the reference's own IntegrandNet architecture is fused into the gfx950 kernel.
+
+    Same conventions as the fused kernel / UMNN's NeuralIntegral (restated, parity unpinned): forward without a graph;
+    backward re-evaluates the integrand at the nodes to get d/d(theta) and d/dh by the same quadrature weighted by
+    grad * x / 2, and uses the Leibniz rule for the upper limit, dz/dx = f(x; h)."""
+
+    @staticmethod
+    def forward(ctx, x, hflat, module, nb_steps, *params):
+        w, t = cc_rule(nb_steps, x.device)
+        S1 = w.numel()
+        B, d = x.shape
+        with torch.no_grad():
+            nodes = (x.unsqueeze(0) * ((t.view(S1, 1, 1) + 1.) * .5)).reshape(S1 * B, d)
+            f = module(nodes, hflat.unsqueeze(0).expand(S1, B, -1).reshape(S1 * B, -1)).view(S1, B, d)
+            z = (f * w.view(S1, 1, 1)).sum(0) * x * .5
+        ctx.module, ctx.S = module, int(nb_steps)
+        ctx.save_for_backward(x, hflat)
+        return z
+
+    @staticmethod
+    def backward(ctx, gz):
+        x, hflat = ctx.saved_tensors
+        module = ctx.module
+        w, t = cc_rule(ctx.S, x.device)
+        S1 = w.numel()
+        B, d = x.shape
+        params = [p for p in module.parameters() if p.requires_grad]
+        with torch.enable_grad():
+            hr = hflat.detach().requires_grad_(True)
+            nodes = (x.detach().unsqueeze(0) * ((t.view(S1, 1, 1) + 1.) * .5)).reshape(S1 * B, d)
+            f = module(nodes, hr.unsqueeze(0).expand(S1, B, -1).reshape(S1 * B, -1)).view(S1, B, d)
+            weight = (gz * x.detach() * .5).unsqueeze(0) * w.view(S1, 1, 1)
+            grads = torch.autograd.grad((f * weight).sum(), [hr] + params, allow_unused=True)
+            fx = module(x.detach(), hflat.detach())
+        gx = gz * fx.detach() if ctx.needs_input_grad[0] else None
+        return (gx, grads[0], None, None, *grads[1:])
+
+
+def module_monotonic(x, h, module, nb_steps):
+    """(z, jac) of MonotonicNormalizer.forward for a custom integrand module; h: [B, d, c]"""
+    B, d = x.shape
+    hflat = h.permute(0, 2, 1).contiguous().view(B, -1)          # cond-major, as the reference passes it (:55)
+    params = [p for p in module.parameters() if p.requires_grad]
+    z = ModuleIntegralFn.apply(x, hflat, module, int(nb_steps), *params) + h[:, :, 0]
+    return z, module(x, hflat)
+
+
+def module_monotonic_inverse(z, h, module, nb_steps):
+    """the reference's bisection (MonotonicNormalizer.py:69-83): 20 halvings of [-20, 20], midpoint returned"""
+    B, d = z.shape
+    hflat = h.permute(0, 2, 1).contiguous().view(B, -1)
+    lo = torch.full_like(z, -20.)
+    hi = torch.full_like(z, 20.)
+    h0 = h[:, :, 0]
+    with torch.no_grad():
+        for _ in range(20):
+            mid = (lo + hi) * .5
+            zm = ModuleIntegralFn.apply(mid, hflat, module, int(nb_steps)) + h0
+            left = zm > z                                     # (:76-79) solution lies left of the midpoint
+            hi = torch.where(left, mid, hi)
+            lo = torch.where(left, lo, mid)
+    return (lo + hi) * .5
 
 
 # ----------------------------------------------------------------------------- Adam on a flat buffer

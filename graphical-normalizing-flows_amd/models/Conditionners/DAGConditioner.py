@@ -112,9 +112,6 @@ class DAGConditioner(Conditioner):
         else:
             return ops.IMP_RAW, ops.GATE_DET
         if self.stoch_gate:
-            if not self.gumble:
-                raise NotImplementedError("only the Gumbel-softmax stochastic gate is implemented "
-                                          "(`gumble` is always True in the reference)")
             return imp, ops.GATE_GUMBEL
         if self.noise_gate:
             return imp, ops.GATE_NOISE
@@ -123,12 +120,29 @@ class DAGConditioner(Conditioner):
     def masked_inputs(self, x):
         """e: [B*d, d (+d one-hot)] -- rows are the masked copies of each sample."""
         imp, gate = self._modes()
+        if gate == ops.GATE_GUMBEL and not self.gumble:
+            return self._clipped_normal_gate(x)
         u1 = u2 = None
         if self.gate_noise is not None and gate != ops.GATE_DET:
             u1, u2 = self.gate_noise
         self._gate_calls += 1
         return ops.DagGateFn.apply(x, self.A, imp, gate, float(self.h_thresh), float(self.gumble_T),
                                    bool(self.hot_encoding), u1, u2, self.gate_seed, self._gate_calls)
+
+    def _clipped_normal_gate(self, x):
+        """`gumble = False` branch of the reference's stochastic_gate (:105-111): gate = relu(min(n * sigma + p + .25, 1)),
+        sigma = 3 / (1 + 10 |p - .5|), n ~ N(0,1) per (b, i, j).  No driver of the reference ever clears `gumble`, so
+        this branch is not fused: it is evaluated with torch ops on the device (autograd through them).
+        `gate_noise = (n,)` injects the normal samples."""
+        B, d = x.shape
+        p = self.hard_thresholded_A() if self.h_thresh > 0 else self.soft_thresholded_A()
+        n = self.gate_noise[0] if self.gate_noise is not None else torch.randn(B, d, d, device=x.device)
+        sigma = 3. / (1. + 10. * torch.sqrt((p - .5) ** 2.))
+        gate = torch.relu((n * sigma + p + .25).clamp_max(1.))
+        e = (x.unsqueeze(1) * gate).reshape(B * d, d)
+        if self.hot_encoding:
+            e = torch.cat((e, torch.eye(d, device=x.device).repeat(B, 1)), 1)
+        return e
 
     def _sparse_plan(self, x, rows, P):
         """gnf_hip.ops.SparseRows when the sparse masked-image front applies -- an MNISTCNN embedding net on the GPU, no
@@ -167,6 +181,10 @@ class DAGConditioner(Conditioner):
             plan = self._sparse_plan(x, None, P)
             if plan is not None:
                 return self.embedding_net.sparse_rows(x, P, plan)
+        if hasattr(self.embedding_net, "exact_pool_ties"):
+            # deterministic gate on the dense kernels (trainable A, or a gradient wanted for x): the masked copies
+            # have exactly-constant regions, so the embedding net must break pool ties the way torch does
+            self.embedding_net.exact_pool_ties = P is not None
         e = self.masked_inputs(x)
         return self.embedding_net(e).view(x.shape[0], self.in_size, -1)
 
@@ -333,6 +351,8 @@ class DAGConditioner(Conditioner):
         plan = self._sparse_plan(x, rows.tolist() if host_rows is None else host_rows, P)
         if plan is not None:
             return self.embedding_net.sparse_rows(x, P, plan)
+        if hasattr(self.embedding_net, "exact_pool_ties"):
+            self.embedding_net.exact_pool_ties = True                    # deterministic gate by construction
         e = x.unsqueeze(1) * P[rows].unsqueeze(0)                        # [B, R, d]
         if self.hot_encoding:
             hot = torch.zeros(R, self.in_size, device=x.device, dtype=x.dtype)

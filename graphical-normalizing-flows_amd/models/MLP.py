@@ -59,6 +59,10 @@ class MNISTCNN(nn.Module):
         self.dropout1, self.dropout2 = nn.Dropout2d(0.25), nn.Dropout2d(0.5)
         self.fc1 = nn.Linear(fc_l[0], fc_l[1])
         self.fc2 = nn.Linear(fc_l[1], out_d)
+        # max-pool windows whose four values are exactly equal (constant image regions) follow torch's first-maximum rule
+        # only on the direct-convolution forward; DAGConditioner sets this for deterministic gates (their masked copies
+        # are exactly zero outside the allowed inputs), the stochastic gate's copies have no exact ties
+        self.exact_pool_ties = False
 
     def _fused_front(self, x):
         """the Winograd/MFMA kernels cover exactly the 1 x 28 x 28 -> 16 x 12 x 12 case on the GPU"""
@@ -89,7 +93,7 @@ class MNISTCNN(nn.Module):
         rows = x.shape[0]
         if self._fused_front(x):
             feat = ops.MnistConvFn.apply(x.view(-1, 784), self.conv1.weight, self.conv1.bias, self.conv2.weight,
-                                         self.conv2.bias)
+                                         self.conv2.bias, self.exact_pool_ties)
         elif self._embeddable(x):
             # the 14x14 / 7x7 scales of the multi-scale factory: the image sits in the top-left corner of a zero 28x28
             # one.  Valid convolutions never look across the corner's edge for the output positions that exist in the
@@ -97,7 +101,8 @@ class MNISTCNN(nn.Module):
             # necessary area, still several times cheaper than an im2col round trip through HBM)
             _, h, w = self.size_img
             big = F.pad(x.view(-1, 1, h, w), (0, 28 - w, 0, 28 - h)).view(-1, 784)
-            pooled = ops.MnistConvFn.apply(big, self.conv1.weight, self.conv1.bias, self.conv2.weight, self.conv2.bias)
+            pooled = ops.MnistConvFn.apply(big, self.conv1.weight, self.conv1.bias, self.conv2.weight, self.conv2.bias,
+                                           self.exact_pool_ties)
             feat = pooled.view(-1, 16, 12, 12)[:, :, :(h - 4) // 2, :(w - 4) // 2].reshape(rows, -1)
         else:
             # any other geometry: batched im2col + MFMA GEMM (no MIOpen: its find step costs minutes on this stack)

@@ -62,10 +62,12 @@ class MonotonicNormalizer(Normalizer):
         self.solver = solver
         self.nb_steps = nb_steps
 
+    def _fused(self):
+        """the reference's IntegrandNet architecture (list of hidden sizes) is fused into the gfx950 quadrature kernel;
+        any other module passed as `integrand_net` (reference :44-48) is evaluated through PyTorch on the device"""
+        return type(self.integrand_net) is IntegrandNet
+
     def _params(self):
-        if not isinstance(self.integrand_net, IntegrandNet):
-            raise NotImplementedError("only the reference IntegrandNet architecture (list of hidden sizes) is "
-                                      "fused into the gfx950 quadrature kernel")
         return self.integrand_net.flat_params()
 
     def forward(self, x, h, context=None):
@@ -73,8 +75,12 @@ class MonotonicNormalizer(Normalizer):
         # summation order; both map to the one fused kernel.  Unknown solver -> None (:64-65).
         if self.solver not in ("CC", "CCParallel"):
             return None
+        if not self._fused():
+            return ops.module_monotonic(x, h, self.integrand_net, int(self.nb_steps))
         return ops.MonotonicFn.apply(x, h, int(self.nb_steps), *self._params())
 
     def inverse_transform(self, z, h, context=None):
         with torch.no_grad():
+            if not self._fused():
+                return ops.module_monotonic_inverse(z, h, self.integrand_net, int(self.nb_steps))
             return ops.monotonic_inverse(z, h, int(self.nb_steps), self._params())

@@ -174,9 +174,14 @@ int gnf_monotonic_bwd(const float* pack, const gnf_mono_net* net,
  * e: [n_img, 784] masked images; W1 [16,1,3,3], b1 [16], W2 [16,16,3,3], b2 [16].
  * pooled: [n_img, 2304] = flatten(maxpool2(conv2(relu(conv1(e))))) in [16,12,12] order;
  * argmax: [n_img, 2304] bytes, index 0..3 of the first maximum of each 2x2 window in scan
- * order (what torch's max_pool2d records), consumed by the backward. */
+ * order (what torch's max_pool2d records), consumed by the backward.
+ * exact_ties = 0: conv2 in the Winograd F(2x2,3x3) domain (2.25x fewer MFMAs); pool windows whose four values are
+ *   EXACTLY equal in exact arithmetic (constant image regions: a deterministic gate on a windowed A) are then decided
+ *   by rounding noise of the transforms -- an equally valid subgradient, not torch's.
+ * exact_ties = 1: conv2 as the direct implicit GEMM: equal patches give bit-equal outputs, the first maximum wins as
+ *   in torch.  models.DAGConditioner selects it for deterministic gates that cannot use the sparse front. */
 int gnf_mnistcnn_conv_fwd(const float* e, const float* W1, const float* b1, const float* W2, const float* b2,
-                          float* pooled, unsigned char* argmax, int64_t n_img, gnf_stream_t stream);
+                          float* pooled, unsigned char* argmax, int64_t n_img, int exact_ties, gnf_stream_t stream);
 /* Backward: recomputes conv1, writes ge [n_img,784] and the parameter gradients (written,
  * not accumulated).  ws: >= gnf_mnistcnn_conv_bwd_ws_bytes(n_img) bytes. */
 int64_t gnf_mnistcnn_conv_bwd_ws_bytes(int64_t n_img);
@@ -225,10 +230,12 @@ int gnf_mnistcnn_sparse_bwd(const float* x, int64_t B, const float* P, const int
 
 /* ---- Adam on one flat fp32 buffer (torch.optim.Adam semantics, L2 weight decay) --------
  * ImageExperiments.py:173 / UCIExperiments.py:97; used by the data-parallel harness after
- * the single RCCL all-reduce.  grad_scale multiplies the (summed) gradient first. */
+ * the single RCCL all-reduce.  grad_scale multiplies the (summed) gradient first.  Hyper-parameters are doubles:
+ * 1-beta, lr/(1-beta1^t) and sqrt(1-beta2^t) are formed in double and rounded once, as torch.optim.Adam forms them
+ * (tested against it on the device, 1e-6). */
 int gnf_adam_step(float* p, const float* g, float* m, float* v, int64_t n,
-                  float lr, float beta1, float beta2, float eps, float weight_decay,
-                  float grad_scale, int step, gnf_stream_t stream);
+                  double lr, double beta1, double beta2, double eps, double weight_decay,
+                  double grad_scale, int step, gnf_stream_t stream);
 
 /* Same update (torch.optim.Adam at ImageExperiments.py:173 / UCIExperiments.py:97), with the step count in device
  * memory (*step_dev = number of steps already taken; incremented by the call when advance != 0 -- a step over
@@ -236,8 +243,8 @@ int gnf_adam_step(float* p, const float* g, float* m, float* v, int64_t n,
  * nothing step-dependent is passed by value, so a captured hipGraph of a whole training step can be replayed
  * (gnf_hip.dp.GraphedStep -- the launch-bound configurations). */
 int gnf_adam_step_dev(float* p, const float* g, float* m, float* v, int64_t n,
-                      float lr, float beta1, float beta2, float eps, float weight_decay,
-                      float grad_scale, int* step_dev, int advance, gnf_stream_t stream);
+                      double lr, double beta1, double beta2, double eps, double weight_decay,
+                      double grad_scale, int* step_dev, int advance, gnf_stream_t stream);
 
 /* ---- device-ceiling probes (measurement aids for bench.py) ---------------
  * gnf_probe_mfma_f32 launches `blocks` workgroups of 8 wavefronts that do nothing but

@@ -154,7 +154,7 @@ def test_cfg5_full_size_monotonic_step():
         layers.append((sd[ipre + "net.%d.weight" % k], sd[ipre + "net.%d.bias" % k]))
         k += 2
     xs = x[:64].cpu()
-    h0 = O.made_forward(xs, made, masks).view(64, 30, 63).permute(0, 2, 1)
+    h0 = O.made_forward(xs, made, masks)                 # [64, 63, 30] view, component-major chunks
     z0, j0 = O.monotonic_forward(xs, h0, layers, 20)
     assert rel_err(z[:64].cpu(), z0) < TOL and rel_err(ld[:64].cpu(), torch.log(j0).sum(1)) < TOL
     assert_close(z[:64], z0, what="z")
@@ -281,3 +281,130 @@ def test_train_uci_two_ranks_dual_updates_stay_in_lockstep(tmp_path):
     sd = torch.load(tmp_path / "run" / "model.pt", map_location="cpu")
     assert float(sd["steps.0.conditioner.lambd"]) > 0          # the dual update ran
     assert os.path.exists(tmp_path / "run" / "ADAM.pt")
+
+
+def test_dag_clipped_normal_gate_golden():
+    """`gumble = False` branch of the reference's stochastic gate (DAGConditioner.py:104-111) with the reference's
+    own N(0,1) samples: h and every gradient against fixtures generated from the reference."""
+    from conftest import load_golden
+    from models import DAGConditioner
+    g = load_golden("dag_clipped_normal")
+    for tag in ("soft", "hard_hot"):
+        h_thresh, hot = g[tag + ".cfg"].tolist()
+        c = DAGConditioner(7, [12, 12], 3, hot_encoding=bool(hot))
+        c.load_state_dict({k[len(tag) + 3:]: v for k, v in g.items() if k.startswith(tag + ".p.")})
+        c = c.to(DEV)
+        c.h_thresh, c.gumble = h_thresh, False
+        c.gate_noise = (g[tag + ".n"].to(DEV),)
+        x = g[tag + ".x"].to(DEV).requires_grad_(True)
+        h = c(x)
+        assert rel_err(h.cpu(), g[tag + ".h"]) < TOL
+        (h * g[tag + ".gh"].to(DEV)).sum().backward()
+        assert rel_err(x.grad.cpu(), g[tag + ".gx"]) < GTOL and rel_err(c.A.grad.cpu(), g[tag + ".gA"]) < GTOL
+        for k, p in c.named_parameters():
+            if k != "A":
+                assert rel_err(p.grad.cpu(), g[tag + ".g." + k]) < GTOL, (tag, k)
+
+
+def test_custom_integrand_module_matches_fused_kernel():
+    """MonotonicNormalizer(integrand_net=<nn.Module>) (reference MonotonicNormalizer.py:44-48): a user module is
+    evaluated through PyTorch on the device.  Given a module with the arithmetic of the reference's IntegrandNet, the
+    torch-op quadrature and the fused gfx950 kernel are two independent evaluations of the same rule: z, jac, every
+    gradient and the bisection inverse agree."""
+    from models import MonotonicNormalizer
+
+    class Custom(torch.nn.Module):                     # same function as IntegrandNet, different module type
+        def __init__(self, hidden, c):
+            super().__init__()
+            dims = [1 + c] + hidden + [1]
+            self.lin = torch.nn.ModuleList(torch.nn.Linear(a, b) for a, b in zip(dims[:-1], dims[1:]))
+
+        def forward(self, x, h):                       # x [B', d], h [B', c*d] cond-major (reference :33-38)
+            B, d = x.shape
+            a = torch.cat((x.unsqueeze(2), h.view(B, -1, d).permute(0, 2, 1)), 2).reshape(B * d, -1)
+            for k, lin in enumerate(self.lin):
+                a = lin(a)
+                if k < len(self.lin) - 1:
+                    a = torch.relu(a)
+            return (torch.nn.functional.elu(a) + 1.05).view(B, d)
+
+    torch.manual_seed(8)
+    B, d, c, S = 6, 5, 30, 20
+    fused = MonotonicNormalizer([50, 50, 50], c, nb_steps=S).to(DEV)
+    mod = Custom([50, 50, 50], c).to(DEV)
+    with torch.no_grad():
+        for lin, (W, b) in zip(mod.lin, zip(fused.integrand_net.flat_params()[0::2], fused.integrand_net.flat_params()[1::2])):
+            lin.weight.copy_(W)
+            lin.bias.copy_(b)
+    custom = MonotonicNormalizer(mod, c, nb_steps=S)
+    assert not custom._fused() and fused._fused()
+    x0, h0 = torch.randn(B, d, device=DEV) * 1.5, torch.randn(B, d, c, device=DEV)
+    gz, gj = torch.randn(B, d, device=DEV), torch.randn(B, d, device=DEV)
+    res = []
+    for norm in (fused, custom):
+        x, h = x0.clone().requires_grad_(True), h0.clone().requires_grad_(True)
+        z, jac = norm(x, h)
+        ((z * gz).sum() + (torch.log(jac) * gj).sum()).backward()
+        res.append((z.detach(), jac.detach(), x.grad, h.grad))
+    for a, b, tol in zip(res[0], res[1], (TOL, TOL, GTOL, GTOL)):
+        assert rel_err(a.cpu(), b.cpu()) < tol
+    assert_close(res[0][0], res[1][0], what="z")
+    for lin, (W, b) in zip(mod.lin, zip(fused.integrand_net.flat_params()[0::2], fused.integrand_net.flat_params()[1::2])):
+        assert rel_err(lin.weight.grad.cpu(), W.grad.cpu()) < GTOL and rel_err(lin.bias.grad.cpu(), b.grad.cpu()) < GTOL
+    xi_f = fused.inverse_transform(res[0][0], h0)
+    xi_c = custom.inverse_transform(res[0][0], h0)
+    assert (xi_f - xi_c).abs().max() <= 40. / 2 ** 20 + 1e-6 and (xi_c - x0).abs().max() < 1e-3
+
+
+def test_train_step_auto_graph_follows_epoch_level_changes():
+    """dp.train_step replays gate-free steps from a hipGraph by default.  Host-side state a captured step bakes in by
+    value (Monotonic node count, batch shape, a DAG conditioner's exponent / gate flags / frozen A) is fingerprinted:
+    changing it captures a new variant instead of replaying stale values.  Trajectory == launch-by-launch steps."""
+    from gnf_hip import dp
+    from models import buildFCNormalizingFlow, AutoregressiveConditioner, MonotonicNormalizer, DAGConditioner, AffineNormalizer
+
+    def make():
+        torch.manual_seed(21)
+        return buildFCNormalizingFlow(1, AutoregressiveConditioner, {"in_size": 6, "hidden": [32, 32], "out_size": 8},
+                                      MonotonicNormalizer, {"integrand_net": [16, 16], "cond_size": 8, "nb_steps": 20,
+                                                            "solver": "CC"}).to(DEV)
+    xs = [torch.randn(48 if i != 3 else 40, 6, generator=torch.Generator().manual_seed(300 + i)).to(DEV) for i in range(6)]
+    nodes = [20, 20, 23, 23, 20, 27]
+    fa, fb = make(), make()
+    sa, sb = dp.FlatState(fa), dp.FlatState(fb)
+    for x, S in zip(xs, nodes):
+        for f in (fa, fb):
+            f.getNormalizers()[0].nb_steps = S
+        la = dp.train_step(fa, sa, x, lr=1e-2, graph=False)
+        lb = dp.train_step(fb, sb, x, lr=1e-2)
+        assert rel_err(lb.cpu(), la.detach().cpu()) < 1e-5, S
+    gs = sb._graphed
+    assert gs.captures == 4 and sb.t == sa.t == 6          # (48,S=20) (48,23) (40,23) (48,27); (48,20) replayed
+    assert rel_err(sb.flat.cpu(), sa.flat.cpu()) < 1e-5
+
+    # DAG flow with a deterministic gate: the dual update rewrites lambd / c IN PLACE (replay reads the new values) and
+    # changes `exponent`, post_process() freezes A (one fewer live leaf): both must show in the replayed trajectory
+    def make_dag():
+        torch.manual_seed(22)
+        f = buildFCNormalizingFlow(1, DAGConditioner, {"in_size": 8, "hidden": [16], "out_size": 2, "l1": .1},
+                                   AffineNormalizer, {}).to(DEV)
+        f.getConditioners()[0].stoch_gate = False
+        return f
+    ga, gb = make_dag(), make_dag()
+    ta, tb = dp.FlatState(ga), dp.FlatState(gb)
+    x = torch.randn(64, 8, device=DEV)
+    for phase in range(3):
+        for _ in range(2):
+            la = dp.train_step(ga, ta, x, lr=1e-2, graph=False)
+            lb = dp.train_step(gb, tb, x, lr=1e-2)
+            assert rel_err(lb.cpu(), la.detach().cpu()) < 1e-5, phase
+        for f in (ga, gb):
+            c = f.getConditioners()[0]
+            if phase == 0:
+                c.update_dual_param()                        # lambd += c h, maybe c *= eta; exponent may move
+                c.exponent = 5
+            elif phase == 1:
+                with torch.no_grad():
+                    c.post_process(.1)
+    assert rel_err(tb.flat.cpu(), ta.flat.cpu()) < 1e-5
+    assert tb._graphed.captures == 3

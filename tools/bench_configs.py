@@ -115,11 +115,11 @@ def main():
             del loss                                   # GraphedStep needs the eager graphs gone
             state = dp.FlatState(flow)
             for _ in range(3):
-                dp.train_step(flow, state, x)
+                dp.train_step(flow, state, x, graph=False)
             torch.cuda.synchronize()
             t0 = time.perf_counter()
             for _ in range(50):
-                dp.train_step(flow, state, x)
+                dp.train_step(flow, state, x, graph=False)
             torch.cuda.synchronize()
             t_eager = (time.perf_counter() - t0) / 50
             gs = dp.GraphedStep(flow, state, x)

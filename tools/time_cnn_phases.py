@@ -18,7 +18,7 @@ pooled = torch.empty(n, 2304, device=dev); arg = torch.empty(n, 2304, dtype=torc
 P = ctypes.c_void_p
 st = P(torch.cuda.current_stream().cuda_stream)
 lib.gnf_mnistcnn_conv_bwd_ws_bytes.restype = ctypes.c_int64
-rc = lib.gnf_mnistcnn_conv_fwd(P(e.data_ptr()), P(W1.data_ptr()), P(b1.data_ptr()), P(W2.data_ptr()), P(b2.data_ptr()), P(pooled.data_ptr()), P(arg.data_ptr()), ctypes.c_int64(n), st)
+rc = lib.gnf_mnistcnn_conv_fwd(P(e.data_ptr()), P(W1.data_ptr()), P(b1.data_ptr()), P(W2.data_ptr()), P(b2.data_ptr()), P(pooled.data_ptr()), P(arg.data_ptr()), ctypes.c_int64(n), ctypes.c_int(0), st)
 nws = lib.gnf_mnistcnn_conv_bwd_ws_bytes(ctypes.c_int64(n))
 ws = torch.zeros(nws // 4, device=dev)
 gp = torch.randn(n, 2304, device=dev); ge = torch.empty(n, 784, device=dev)
@@ -38,7 +38,7 @@ for w in range(8):
 # forward phases (the timing build writes them through CnnArgs.part, which the fwd entry leaves NULL: use a raw launch)
 buf = (ctypes.c_float * 64)()
 for _ in range(2):
-    lib.gnf_mnistcnn_conv_fwd(P(e.data_ptr()), P(W1.data_ptr()), P(b1.data_ptr()), P(W2.data_ptr()), P(b2.data_ptr()), P(pooled.data_ptr()), P(arg.data_ptr()), ctypes.c_int64(n), st)
+    lib.gnf_mnistcnn_conv_fwd(P(e.data_ptr()), P(W1.data_ptr()), P(b1.data_ptr()), P(W2.data_ptr()), P(b2.data_ptr()), P(pooled.data_ptr()), P(arg.data_ptr()), ctypes.c_int64(n), ctypes.c_int(0), st)
 torch.cuda.synchronize()
 lib.gnf_debug_fwd_timing(buf)
 imgs_f = (n - 7 + 511) // 512
