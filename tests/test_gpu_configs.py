@@ -184,8 +184,10 @@ def test_hip_adam_vs_torch_adam_on_device(n, wd):
         ops.adam_step(p, g, m, v, t, lr=1e-3, weight_decay=wd)
         assert_close(p, ref.data, rtol=1e-6, atol=1e-6, what="step %d" % t)
     st = opt.state[ref]
-    assert_close(m, st["exp_avg"], rtol=1e-6, atol=1e-7, what="exp_avg")
-    assert_close(v, st["exp_avg_sq"], rtol=1e-6, atol=1e-7, what="exp_avg_sq")
+    # moments: torch forms exp_avg with lerp (m + (g - m) w), the kernel with fma(b1, m, w g): a few ulp of the largest
+    # term apart; the gradients here span 1e-2 .. 1e2, so an ulp of the largest one is ~1e-5 absolute
+    assert_close(m, st["exp_avg"], rtol=2e-6, atol=2e-5, what="exp_avg")
+    assert_close(v, st["exp_avg_sq"], rtol=2e-6, atol=2e-5, what="exp_avg_sq")
     # the all-reduce scale (1/world) folded into the launch: grad_scale=1/4 on 4x the gradient is the same step
     p2, m2, v2 = p0.clone(), torch.zeros(n, device=DEV), torch.zeros(n, device=DEV)
     ops.adam_step(p2, grads[0] * 4, m2, v2, 1, lr=1e-3, weight_decay=wd, grad_scale=.25)

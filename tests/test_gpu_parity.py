@@ -793,6 +793,34 @@ def _windowed_conditioner(seed, post_processed):
     return cond
 
 
+def _knife_edge_windows(cond, x):
+    """Pool windows of the dense (tie-exact) forward whose recorded argmax differs from torch-CPU's on the same masked
+    copies.  Exact ties are decided identically (first maximum); what remains are windows whose two largest values are
+    EQUAL IN EXACT ARITHMETIC but come from different patches, so that each fp32 evaluation order rounds them apart by
+    an ulp its own way -- no implementation can follow another's choice there.  Returns their number after checking
+    that every one of them is such a near-tie (top two values within 4 ulp in torch's own evaluation)."""
+    import torch.nn.functional as F
+    from gnf_hip import abi
+    net = cond.embedding_net
+    B = x.shape[0]
+    e = (x.cpu().unsqueeze(1) * cond.deterministic_importance().detach().cpu().unsqueeze(0)).reshape(B * 784, 784)
+    W1, b1, W2, b2 = [t.detach().cpu() for t in (net.conv1.weight, net.conv1.bias, net.conv2.weight, net.conv2.bias)]
+    c2 = F.conv2d(torch.relu(F.conv2d(e.view(-1, 1, 28, 28), W1, b1)), W2, b2)
+    _, idx = F.max_pool2d(c2, 2, return_indices=True)
+    ref = (((idx // 24) % 2) * 2 + (idx % 24) % 2).flatten(1)
+    dev = [t.to(DEV).contiguous() for t in (e, W1, b1, W2, b2)]
+    pooled = torch.empty(B * 784, 2304, device=DEV)
+    arg = torch.empty(B * 784, 2304, dtype=torch.uint8, device=DEV)
+    abi.call("gnf_mnistcnn_conv_fwd", *[abi.ptr(t) for t in dev], abi.ptr(pooled), abi.rawptr(arg), B * 784, 1,
+             abi.stream())
+    flips = (arg.cpu().long() != ref).nonzero()
+    win = c2.view(-1, 16, 12, 2, 12, 2).permute(0, 1, 2, 4, 3, 5).reshape(-1, 2304, 4)
+    for i, p in flips.tolist():
+        top = win[i, p].sort(descending=True).values
+        assert (top[0] - top[1]).abs() <= 4 * torch.finfo(torch.float32).eps * top[0].abs(), (i, p, top.tolist())
+    return flips.shape[0]
+
+
 @pytest.mark.parametrize("post_processed", [False, True])
 def test_sparse_front_matches_oracle_and_dense(post_processed):
     """forward of the conditioner under a deterministic gate: sparse crop path == CPU oracle on the explicit
@@ -864,6 +892,8 @@ def test_sparse_front_parameter_gradients(B):
     cond.sparse_front = False
     (cond(cu(x)) * cu(gh)).sum().backward()
     dense = {k: p.grad.clone() for k, p in net.named_parameters()}
+    flips = _knife_edge_windows(cond, x)
+    assert flips <= 1 + B                              # a handful per million windows
     # CPU oracle
     params = {k: v.detach().cpu().clone().requires_grad_(True) for k, v in net.named_parameters()}
     e = (x.unsqueeze(1) * cond.A.detach().cpu().unsqueeze(0)).reshape(B * 784, 784)
@@ -871,8 +901,11 @@ def test_sparse_front_parameter_gradients(B):
     for k in got:
         assert rel_err(got[k].cpu(), params[k].grad) < GTOL, (k, rel_err(got[k].cpu(), params[k].grad))
         # dense path under a deterministic gate = the tie-exact direct forward (DAGConditioner sets exact_pool_ties): the
-        # exact max-pool ties of the constant background follow torch's first-maximum rule there too
-        assert rel_err(dense[k].cpu(), params[k].grad) < GTOL, (k, rel_err(dense[k].cpu(), params[k].grad))
+        # exact max-pool ties of the constant background follow torch's first-maximum rule there too.  A knife-edge
+        # window (see _knife_edge_windows) moves one cotangent entry to a neighbouring position: with so few images
+        # that is visible in the conv gradients, so the bound is loosened only when such windows were counted
+        tol = GTOL if (flips == 0 or not k.startswith("conv")) else 5e-3
+        assert rel_err(dense[k].cpu(), params[k].grad) < tol, (k, flips, rel_err(dense[k].cpu(), params[k].grad))
 
 
 @pytest.mark.parametrize("B,rows", [(1, [391]), (1, None), (33, [0, 783]), (130, [5, 6, 7, 300])])
@@ -898,8 +931,10 @@ def test_sparse_front_edge_sizes(B, rows):
             p.grad = None
         (cond.forward_rows(x, r, P) * gh).sum().backward()
         grads.append([p.grad.clone() for p in cond.embedding_net.parameters()])
+    flips = _knife_edge_windows(cond, x.cpu()) if rows is None else 0      # counted on the full set of masked copies
     for a, b, (k, _) in zip(grads[0], grads[1], cond.embedding_net.named_parameters()):
-        assert rel_err(a.cpu(), b.cpu()) < GTOL, (k, rel_err(a.cpu(), b.cpu()))
+        tol = 5e-3 if (flips > 0 and k.startswith("conv")) else GTOL
+        assert rel_err(a.cpu(), b.cpu()) < tol, (k, flips, rel_err(a.cpu(), b.cpu()))
 
 
 def test_sparse_front_reference_golden():
