@@ -146,7 +146,7 @@ def measured_peaks(dev):
     torch.cuda.synchronize()
     return {"mfma_f32_TFLOPs": round(flops / (ev[0].elapsed_time(ev[1]) * 1e-3) / 1e12, 1),
             "stream_copy_GBps": round(10 * 2 * 4 * n / (ev[2].elapsed_time(ev[3]) * 1e-3) / 1e9, 1),
-            "note": "pure-MFMA kernel (8 independent 16x16x4 f32 chains/wave, 2 waves/SIMD) and 1 GiB float4 copy"}
+            "note": "pure-MFMA kernel (8 independent 16x16x4 f32 chains/wave, 2 waves/SIMD) and a 1 GiB float4 copy (contiguous chunk per workgroup, 8 non-temporal 16-B loads in flight per lane: best of tools/copy_probe.hip)"}
 
 
 def main():

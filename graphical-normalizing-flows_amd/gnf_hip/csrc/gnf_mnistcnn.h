@@ -1,0 +1,99 @@
+// Shared pieces of the MNISTCNN convolutional front kernels (gnf_mnistcnn_fwd.hip / gnf_mnistcnn.hip): geometry of the
+// LDS images, the MFMA / packed-VALU helpers, the Winograd input transform and the conv1 tile routine.
+#pragma once
+#include "gnf_common.h"
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int IMG = 28, C1 = 26, C2 = 24, PO = 12, NCH = 16;
+constexpr int ROWE = 36, ESZ = IMG * ROWE;            // padded input image
+constexpr int ROW = 40, CH = C1 * ROW;                // conv1 activations: [16][26][40], CH = 1040 == 16 mod 32
+constexpr int ROWD = 40, CHD = 28 * ROWD + 16;        // dY2 with a 2-wide zero border: [16][28][40], CHD = 1136 == 16 mod 32
+constexpr int CS = 688;                               // per-tap planes T: [9][688] flat 26x26 positions
+constexpr int NPOOL = NCH * PO * PO;                  // 2304
+constexpr int FWD_WAVES = 8, BWD_WAVES = 8;
+constexpr int PROW = NCH * 144 + NCH * 16 + NCH;      // per-wave gradient partial row: dW2 | dW1+db1 | db2
+
+static_assert(CH % 32 == 16 && CHD % 32 == 16, "channel strides must sit 16 banks apart");
+
+__device__ __forceinline__ f32x4 mfma(float a, float b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+
+// Packed fp32 VALU (2 flops per lane per op) for the Winograd transforms.  One row (t0,t1,t2,t3) of B^T d held as
+// A = (t0,t1), B = (t2,t3) gives the four outputs of (B^T d) B in two instructions:
+//   A - B                       = (t0 - t2, t1 - t3) = (v0, v3)
+//   (A.hi + B.lo, -A.hi + B.lo) = (t1 + t2, t2 - t1) = (v1, v2)      [op_sel picks the halves, neg_hi negates src0]
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2 pk_v12(f32x2 a, f32x2 b) {
+  f32x2 r;
+  asm("v_pk_add_f32 %0, %1, %2 op_sel:[1,0] op_sel_hi:[1,0] neg_hi:[1,0]" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+// B^T d B of a 4x4 patch given as 4 rows x 2 column pairs; out[xi = 4*xi_y + xi_x]
+__device__ __forceinline__ void wino_in(const f32x2 (&lo)[4], const f32x2 (&hi)[4], float (&v)[16]) {
+  f32x2 tl[4], th[4];                                 // B^T d: rows d0-d2, d1+d2, d2-d1, d1-d3
+  tl[0] = lo[0] - lo[2]; th[0] = hi[0] - hi[2];
+  tl[1] = lo[1] + lo[2]; th[1] = hi[1] + hi[2];
+  tl[2] = lo[2] - lo[1]; th[2] = hi[2] - hi[1];
+  tl[3] = lo[1] - lo[3]; th[3] = hi[1] - hi[3];
+#pragma unroll
+  for (int rr = 0; rr < 4; ++rr) {
+    const f32x2 v03 = tl[rr] - th[rr], v12 = pk_v12(tl[rr], th[rr]);
+    v[4 * rr + 0] = v03.x; v[4 * rr + 1] = v12.x; v[4 * rr + 2] = v12.y; v[4 * rr + 3] = v03.y;
+  }
+}
+
+// lane^1 (quad_perm [1,0,3,2]) and lane^8 (row_ror:8 inside a 16-lane row) without touching LDS
+__device__ __forceinline__ float dpp_xor1(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, false));
+}
+__device__ __forceinline__ float dpp_xor8(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x128, 0xF, 0xF, false));
+}
+
+struct CnnArgs {
+  const float* e; const float* W1; const float* b1; const float* W2; const float* b2;
+  float* pooled; unsigned char* arg;                                // forward outputs
+  const float* gp; const unsigned char* argin; float* ge; float* part;   // backward
+  int64_t n;
+};
+
+// conv1 + ReLU of the image in e_s into a1_s; 43 tiles of 16 consecutive positions of the 26x26 grid.
+// All operand reads of a wave's (up to 6) tiles are issued first, then 6 independent 3-step MFMA chains,
+// then the stores: the phase is latency-bound, so nothing may serialise behind a single chain.
+template <int NW>
+__device__ __forceinline__ void conv1_tiles(const float* e_s, float* a1_s, const float (&w1f)[3], const int (&off1)[3],
+                                            const f32x4& b1v, int wave, int q, int j) {
+  constexpr int NTL = (43 + NW - 1) / NW, NB = NTL;           // tiles per wave, processed NB at a time
+#pragma unroll
+  for (int k0 = 0; k0 < NTL; k0 += NB) {
+    int po[NB];
+    f32x4 acc[NB];
+    float ev[NB][3];
+#pragma unroll
+    for (int k = 0; k < NB; ++k) {
+      const int pos = 16 * (wave + NW * (k0 + k)) + j;
+      const int pc = pos < C1 * C1 ? pos : 0;
+      const int y = pc / C1, x = pc - y * C1;
+      po[k] = pos < C1 * C1 ? y * ROW + x : -1;
+#pragma unroll
+      for (int s = 0; s < 3; ++s) ev[k][s] = e_s[y * ROWE + x + off1[s]];
+      acc[k] = b1v;
+    }
+#pragma unroll
+    for (int s = 0; s < 3; ++s)
+#pragma unroll
+      for (int k = 0; k < NB; ++k) acc[k] = mfma(w1f[s], ev[k][s], acc[k]);
+#pragma unroll
+    for (int k = 0; k < NB; ++k)
+      if (po[k] >= 0) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) a1_s[(4 * q + r) * CH + po[k]] = fmaxf(acc[k][r], 0.f);
+      }
+  }
+}
+
+}  // namespace

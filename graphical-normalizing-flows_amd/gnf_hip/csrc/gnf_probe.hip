@@ -26,21 +26,22 @@ __global__ __launch_bounds__(512) void probe_mfma_k(float* out, int iters) {
   if (s == 12345.678f) out[0] = s;   // keep the chain alive; practically never true
 }
 
-// STREAM copy: dst[i] = src[i].  128-bit accesses, FOUR independent loads in flight per lane per trip (one 16-B load
-// per lane per trip leaves the memory pipeline latency-bound: 4.6 TB/s where MI355X_MICROARCH.md measures 6.29),
-// non-temporal loads and stores (each byte is touched once), grid = CUs x 8 resident workgroups.
+// STREAM copy: dst[i] = src[i].  Every workgroup owns ONE CONTIGUOUS chunk (DRAM page locality), 128-bit accesses,
+// EIGHT independent loads in flight per lane per trip, non-temporal loads and stores (each byte is touched once),
+// 16 workgroups per CU: the best of the 35 launch shapes of tools/copy_probe.hip on this part (5.6 TB/s; the first
+// version -- grid-strided, one load in flight -- reached 4.6; MI355X_MICROARCH.md quotes 6.29 for its float4 copy).
 __global__ __launch_bounds__(256) void probe_copy_k(f32x4* __restrict__ dst, const f32x4* __restrict__ src, int64_t n4) {
-  const int64_t stride = (int64_t)gridDim.x * 256;
-  int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  for (; i + 3 * stride < n4; i += 4 * stride) {
-    const f32x4 a = __builtin_nontemporal_load(src + i), b = __builtin_nontemporal_load(src + i + stride);
-    const f32x4 c = __builtin_nontemporal_load(src + i + 2 * stride), d = __builtin_nontemporal_load(src + i + 3 * stride);
-    __builtin_nontemporal_store(a, dst + i);
-    __builtin_nontemporal_store(b, dst + i + stride);
-    __builtin_nontemporal_store(c, dst + i + 2 * stride);
-    __builtin_nontemporal_store(d, dst + i + 3 * stride);
+  const int64_t per = (n4 + gridDim.x - 1) / gridDim.x;
+  const int64_t b0 = per * blockIdx.x, b1 = b0 + per < n4 ? b0 + per : n4;
+  int64_t i = b0 + threadIdx.x;
+  for (; i + 7 * 256 < b1; i += 8 * 256) {
+    f32x4 v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = __builtin_nontemporal_load(src + i + u * 256);
+#pragma unroll
+    for (int u = 0; u < 8; ++u) __builtin_nontemporal_store(v[u], dst + i + u * 256);
   }
-  for (; i < n4; i += stride) __builtin_nontemporal_store(__builtin_nontemporal_load(src + i), dst + i);
+  for (; i < b1; i += 256) __builtin_nontemporal_store(__builtin_nontemporal_load(src + i), dst + i);
 }
 
 }  // namespace
@@ -57,7 +58,7 @@ extern "C" int64_t gnf_probe_mfma_f32(float* out, int iters, int blocks, gnf_str
 extern "C" int gnf_probe_copy(float* dst, const float* src, int64_t n, gnf_stream_t stream) {
   if (!dst || !src || n < 0 || (n & 3)) return GNF_EINVAL;
   if (n == 0) return 0;
-  hipLaunchKernelGGL(probe_copy_k, dim3(256 * 8), dim3(256), 0, (hipStream_t)stream, (f32x4*)dst, (const f32x4*)src,
+  hipLaunchKernelGGL(probe_copy_k, dim3(256 * 16), dim3(256), 0, (hipStream_t)stream, (f32x4*)dst, (const f32x4*)src,
                      n / 4);
   GNF_LAUNCH_CHECK();
   return 0;
