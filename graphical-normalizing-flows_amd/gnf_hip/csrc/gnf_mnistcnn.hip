@@ -56,7 +56,7 @@ __global__ __launch_bounds__(64 * BWD_WAVES) void cnn_bwd_wino_k(CnnArgs a) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   constexpr int NW = BWD_WAVES, NT = 64 * BWD_WAVES;
   static_assert((ESZ % 4 == 0) && ((NCH * CHB) % 4 == 0) && (DSZW % 4 == 0), "u_s must be 16-B aligned");
-  static_assert(9 * CS + 64 <= NCH * CHB, "T planes alias the a1 region");
+  static_assert(10 * CS <= NCH * CHB, "T planes (9 taps + a dump plane) alias the a1 region");
 
   float w1f[3];
   int off1[3];
@@ -185,15 +185,27 @@ __global__ __launch_bounds__(64 * BWD_WAVES) void cnn_bwd_wino_k(CnnArgs a) {
         for (int s = 0; s < 3; ++s)
 #pragma unroll
           for (int p = 0; p < 4; ++p) acc[p] = mfma(w1f[s], ev[p][s], acc[p]);
+        // ReLU + gate bits.  Bit of value (k, p, r) ends up at 31 - (16k + 4p + r): each value shifts the sign of
+        // 0 - relu(acc) in from the right (two full-rate ops per value instead of compare + select + or)
+        float a1v[4][4];
+#pragma unroll
+        for (int p = 0; p < 4; ++p)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            a1v[p][r] = fmaxf(acc[p][r], 0.f);
+            gate = __builtin_amdgcn_alignbit(gate, __float_as_uint(0.f - a1v[p][r]), 31);
+          }
         if (ok) {
 #pragma unroll
           for (int p = 0; p < 4; ++p)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-              a1_s[(4 * q + r) * CHB + (2 * ty + (p >> 1)) * ROWB + 2 * tx + (p & 1)] = fmaxf(acc[p][r], 0.f);
-              if (acc[p][r] > 0.f) gate |= 1u << (16 * k + 4 * p + r);
-            }
+            for (int r = 0; r < 4; ++r)
+              a1_s[(4 * q + r) * CHB + (2 * ty + (p >> 1)) * ROWB + 2 * tx + (p & 1)] = a1v[p][r];
+        } else {
+          gate &= 0xFFFF0000u;                                    // a lane without a tile gates everything off
         }
+      } else {
+        gate <<= 16;
       }
     }
     __syncthreads();
@@ -272,6 +284,7 @@ __global__ __launch_bounds__(64 * BWD_WAVES) void cnn_bwd_wino_k(CnnArgs a) {
           for (int xi = 0; xi < 16; ++xi) m[xi] = mfma(uf[xi >> 2][xi & 3], vv[xi], m[xi]);
           __builtin_amdgcn_sched_barrier(0);
         }
+        TSTAMP(3);                                              // (timing build) P4a: the 64 Winograd MFMAs + transforms
         f32x4 dp[4];                                            // dpre1 at sub-position p, channels 4q+r
 #pragma unroll
         for (int r = 0; r < 4; ++r) {                           // A^T M A, A^T = [[1,1,1,0],[0,1,-1,-1]]
@@ -283,12 +296,14 @@ __global__ __launch_bounds__(64 * BWD_WAVES) void cnn_bwd_wino_k(CnnArgs a) {
           }
           const float y00 = s0[0] + s0[1] + s0[2], y01 = s0[1] - s0[2] - s0[3];
           const float y10 = s1[0] + s1[1] + s1[2], y11 = s1[1] - s1[2] - s1[3];
-          const unsigned gb = ok ? (gate >> (16 * k + r)) : 0u;
-          dp[0][r] = (gb & 1u) ? y00 : 0.f;
-          dp[1][r] = (gb & 16u) ? y01 : 0.f;
-          dp[2][r] = (gb & 256u) ? y10 : 0.f;
-          dp[3][r] = (gb & 4096u) ? y11 : 0.f;
+          // gate bit -> all-ones / all-zeros mask (v_bfe_i32) -> and: two full-rate ops per value
+          const int b0 = 31 - (16 * k + r);
+          dp[0][r] = __int_as_float(__float_as_int(y00) & __builtin_amdgcn_sbfe((int)gate, b0, 1));
+          dp[1][r] = __int_as_float(__float_as_int(y01) & __builtin_amdgcn_sbfe((int)gate, b0 - 4, 1));
+          dp[2][r] = __int_as_float(__float_as_int(y10) & __builtin_amdgcn_sbfe((int)gate, b0 - 8, 1));
+          dp[3][r] = __int_as_float(__float_as_int(y11) & __builtin_amdgcn_sbfe((int)gate, b0 - 12, 1));
         }
+        TSTAMP(5);                                              // P4b: output transform + gate
         // dW1 / db1 partials against the 4x4 image patch of this tile
         float ep[4][4];
         {
@@ -300,6 +315,21 @@ __global__ __launch_bounds__(64 * BWD_WAVES) void cnn_bwd_wino_k(CnnArgs a) {
             ep[rr][0] = lo.x; ep[rr][1] = lo.y; ep[rr][2] = hi.x; ep[rr][3] = hi.y;
           }
         }
+#ifdef GNF_DW1_SCALAR
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {                           // scalar v_fma chain per (channel, tap)
+          float* gw = reinterpret_cast<float*>(&gW1p[r >> 1][0]) + (r & 1);
+          gw[2 * 9] += (dp[0][r] + dp[1][r]) + (dp[2][r] + dp[3][r]);
+#pragma unroll
+          for (int tap = 0; tap < 9; ++tap) {
+            const int ky = tap / 3, kx = tap % 3;
+            float acc = gw[2 * tap];
+#pragma unroll
+            for (int p = 0; p < 4; ++p) acc = fmaf(dp[p][r], ep[(p >> 1) + ky][(p & 1) + kx], acc);
+            gw[2 * tap] = acc;
+          }
+        }
+#else
 #pragma unroll
         for (int h = 0; h < 2; ++h) {                           // packed over the channel pair (2 flops per lane per op)
           f32x2 d2[4];
@@ -318,6 +348,8 @@ __global__ __launch_bounds__(64 * BWD_WAVES) void cnn_bwd_wino_k(CnnArgs a) {
             gW1p[h][tap] = acc;
           }
         }
+#endif
+        TSTAMP(6);                                              // P4c: dW1 / db1 partials
         // T[tap][pos] = sum_oc W1[oc][tap] dpre1[oc][pos]: dpre1 in the C/D layout IS the B operand
         f32x4 tq[4];
 #pragma unroll
@@ -326,16 +358,22 @@ __global__ __launch_bounds__(64 * BWD_WAVES) void cnn_bwd_wino_k(CnnArgs a) {
         for (int r = 0; r < 4; ++r)
 #pragma unroll
           for (int p = 0; p < 4; ++p) tq[p] = mfma(w1t[r], dp[p][r], tq[p]);
+        // plane of tap 4q+r, or the dump plane 9 (taps >= 9, lanes without a tile): one base per r, the four
+        // sub-positions are immediate offsets of the stores
+        {
+          const int pos0 = 2 * ty * C1 + 2 * tx;
 #pragma unroll
-        for (int p = 0; p < 4; ++p) {
-          const int pos = (2 * ty + (p >> 1)) * C1 + 2 * tx + (p & 1);
-#pragma unroll
-          for (int r = 0; r < 4; ++r) T_s[(ok && 4 * q + r < 9) ? (4 * q + r) * CS + pos : 9 * CS + lane] = tq[p][r];
+          for (int r = 0; r < 4; ++r) {
+            const int plane = (ok && 4 * q + r < 9) ? 4 * q + r : 9;
+            float* tp = T_s + plane * CS + pos0;
+            tp[0] = tq[0][r]; tp[1] = tq[1][r]; tp[C1] = tq[2][r]; tp[C1 + 1] = tq[3][r];
+          }
         }
       }
     }
+    TSTAMP(7);                                                  // P4d: T planes
     __syncthreads();
-    TSTAMP(3);
+    TSTAMP(3);                                                  // barrier wait counts as P4a
     // ---- de[y][x] = sum_tap T[tap][y-ky][x-kx]
     for (int i = tid; i < IMG * IMG; i += NT) {
       const int y = i / IMG, x = i - y * IMG;
@@ -353,7 +391,7 @@ __global__ __launch_bounds__(64 * BWD_WAVES) void cnn_bwd_wino_k(CnnArgs a) {
   }
 #ifdef GNF_CNN_TIMING
   if (blockIdx.x == 7 && (tid & 63) == 0)
-    for (int k = 0; k < 6; ++k) a.part[((int64_t)gridDim.x * NW + 1) * PROW + wave * 8 + k] = (float)tacc[k];
+    for (int k = 0; k < 8; ++k) a.part[((int64_t)gridDim.x * NW + 1) * PROW + wave * 8 + k] = (float)tacc[k];
 #endif
 
   // ---- per-wave partial row: dW2 [16][144] | dW1+db1 [16][16] | db2 [16]

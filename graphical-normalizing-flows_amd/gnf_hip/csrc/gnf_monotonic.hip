@@ -43,6 +43,8 @@ constexpr int kMaxNH = GNF_MONO_MAX_LAYERS - 1;
 // ---------------------------------------------------------------------------------------
 struct MonoLayout {
   int HT, HP, NH, c, CP, LDH, LDW;
+  int HM, EX;                         // "peeled" narrow nets (all hidden widths H, H mod 16 in {1,2,3}): HM = H / 16 full
+                                      // tiles on the MFMA, EX = H mod 16 units on the VALU (0, 0 otherwise)
   int o_w1x, o_b1, o_wL, o_bL, o_W1h;
   int o_W[kMaxNH], o_b[kMaxNH];       // hidden->hidden layers l = 1..NH-1
   int fwd_floats;                     // prefix used by forward / inverse
@@ -52,7 +54,7 @@ struct MonoLayout {
 
 __host__ __device__ inline MonoLayout make_layout(int HT, int NH, int c) {
   MonoLayout L;
-  L.HT = HT; L.HP = 16 * HT; L.NH = NH; L.c = c;
+  L.HT = HT; L.HP = 16 * HT; L.NH = NH; L.c = c; L.HM = 0; L.EX = 0;
   L.CP = (c + 15) / 16 * 16; L.LDH = L.CP + 4; L.LDW = L.HP + 4;
   int o = 0;
   L.o_w1x = o; o += L.HP;
@@ -137,10 +139,21 @@ __device__ __forceinline__ void glds16(const float* g, float* l) {
 __device__ __forceinline__ f32x4 mfma(float a, float b, f32x4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }
-__device__ __forceinline__ float qsum(float v) {   // sum over the 4 lane-slots q (lanes j, j+16, j+32, j+48)
+// sum over the 4 lane-slots q (lanes j, j+16, j+32, j+48), result in all of them.  gfx950's v_permlane16_swap /
+// v_permlane32_swap exchange 16- / 32-lane rows between two registers on the VALU: swapping a value with its own copy
+// leaves (row, neighbour row) side by side, one add finishes the level -- no trip through the LDS crossbar
+// (ds_bpermute, ~100 cycles of latency per level in the dependent chain of every node evaluation).
+__device__ __forceinline__ float qsum(float v) {
+#ifdef GNF_QSUM_BPERMUTE
   v += __shfl_xor(v, 16, 64);
   v += __shfl_xor(v, 32, 64);
   return v;
+#else
+  auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  v = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+  r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+#endif
 }
 __device__ __forceinline__ float jsum(float v) {   // sum over the 16 elements of a lane-slot
   v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 8, 64);
@@ -241,6 +254,197 @@ __device__ __forceinline__ float quadrature(const float* wp, const MonoLayout& L
     }
   }
   return acc;
+}
+
+// ---------------------------------------------------------------------------------------
+// Peeled forward.  H = 50 (the reference's default integrand net) padded to 4 tiles of 16 spends a quarter of every
+// hidden layer's MFMAs on a tile that holds TWO real units (and a quarter of the K steps likewise).  Here the HM = H/16
+// full tiles stay on the MFMA (9 instead of 16 tile products per layer) and the EX = H mod 16 leftover units are
+// carried as plain per-element scalars, replicated over the four q-lanes of an element: their contribution to the main
+// units is a rank-EX update (W[:, U] from the padded image, one b128 per row), their own pre-activations are per-lane
+// partial dot products over the lane's 4 HM units + a q-sum.  The pack (HP = 64 image) is unchanged.
+// ---------------------------------------------------------------------------------------
+template <int HM, int EX, class GetW>
+__device__ __forceinline__ void eval2x(const float* wp, const MonoLayout& L, const f32x4 (&c1)[HM], const float (&c1x)[EX],
+                                       float xa, float xb, int q, int j, float& fa, float& fb, GetW&& getW) {
+  constexpr int U0 = 16 * HM;                  // first peeled unit
+  f32x4 a0[HM], a1[HM];
+  float x0[EX], x1[EX];
+#pragma unroll
+  for (int t = 0; t < HM; ++t) {
+    const f32x4 wx = ld4(wp + L.o_w1x + 16 * t + 4 * q);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      a0[t][r] = fmaxf(fmaf(wx[r], xa, c1[t][r]), 0.f);
+      a1[t][r] = fmaxf(fmaf(wx[r], xb, c1[t][r]), 0.f);
+    }
+  }
+  {
+    const f32x4 wx = ld4(wp + L.o_w1x + U0);
+#pragma unroll
+    for (int e = 0; e < EX; ++e) {
+      x0[e] = fmaxf(fmaf(wx[e], xa, c1x[e]), 0.f);
+      x1[e] = fmaxf(fmaf(wx[e], xb, c1x[e]), 0.f);
+    }
+  }
+  for (int l = 1; l < L.NH; ++l) {
+    const float* W = getW(l);
+    // every weight fragment of the peeled part is requested BEFORE the MFMA block, so that the LDS latency of these
+    // 21 b128 reads hides under the 72 MFMAs instead of stalling the VALU tail read by read
+    f32x4 wr[EX][HM], wxr[EX], wc[HM][4];
+    const f32x4 bx = ld4(wp + L.o_b[l] + U0);
+#pragma unroll
+    for (int e = 0; e < EX; ++e) {
+#pragma unroll
+      for (int t = 0; t < HM; ++t) wr[e][t] = ld4(W + (U0 + e) * L.LDW + 16 * t + 4 * q);
+      wxr[e] = ld4(W + (U0 + e) * L.LDW + U0);
+    }
+#pragma unroll
+    for (int mt = 0; mt < HM; ++mt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) wc[mt][r] = ld4(W + (16 * mt + 4 * q + r) * L.LDW + U0);
+    f32x4 o0[HM], o1[HM];
+#pragma unroll
+    for (int mt = 0; mt < HM; ++mt) { o0[mt] = ld4(wp + L.o_b[l] + 16 * mt + 4 * q); o1[mt] = o0[mt]; }
+    __builtin_amdgcn_sched_barrier(0);           // keep the requests above the MFMA block (the scheduler would sink them)
+#pragma unroll
+    for (int t = 0; t < HM; ++t) {
+#pragma unroll
+      for (int mt = 0; mt < HM; ++mt) {
+        const f32x4 A = ld4(W + (16 * mt + j) * L.LDW + 16 * t + 4 * q);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          o0[mt] = mfma(A[r], a0[t][r], o0[mt]);
+          o1[mt] = mfma(A[r], a1[t][r], o1[mt]);
+        }
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);           // ... and the VALU tail below it (VALU between MFMAs costs issue slots)
+    // the peeled units' own pre-activations (from the OLD a / x), then their rank-EX contribution to the main units
+    float y0[EX], y1[EX];
+#pragma unroll
+    for (int e = 0; e < EX; ++e) {
+      float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+      for (int t = 0; t < HM; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { s0 = fmaf(wr[e][t][r], a0[t][r], s0); s1 = fmaf(wr[e][t][r], a1[t][r], s1); }
+      float k0 = bx[e], k1 = bx[e];
+#pragma unroll
+      for (int e2 = 0; e2 < EX; ++e2) { k0 = fmaf(wxr[e][e2], x0[e2], k0); k1 = fmaf(wxr[e][e2], x1[e2], k1); }
+      y0[e] = fmaxf(qsum(s0) + k0, 0.f);
+      y1[e] = fmaxf(qsum(s1) + k1, 0.f);
+    }
+#pragma unroll
+    for (int mt = 0; mt < HM; ++mt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float v0 = o0[mt][r], v1 = o1[mt][r];
+#pragma unroll
+        for (int e = 0; e < EX; ++e) { v0 = fmaf(wc[mt][r][e], x0[e], v0); v1 = fmaf(wc[mt][r][e], x1[e], v1); }
+        a0[mt][r] = fmaxf(v0, 0.f);
+        a1[mt][r] = fmaxf(v1, 0.f);
+      }
+#pragma unroll
+    for (int e = 0; e < EX; ++e) { x0[e] = y0[e]; x1[e] = y1[e]; }
+  }
+  float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+  for (int t = 0; t < HM; ++t) {
+    const f32x4 wl = ld4(wp + L.o_wL + 16 * t + 4 * q);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { s0 = fmaf(wl[r], a0[t][r], s0); s1 = fmaf(wl[r], a1[t][r], s1); }
+  }
+  const f32x4 wlx = ld4(wp + L.o_wL + U0);
+  float t0 = wp[L.o_bL], t1 = t0;
+#pragma unroll
+  for (int e = 0; e < EX; ++e) { t0 = fmaf(wlx[e], x0[e], t0); t1 = fmaf(wlx[e], x1[e], t1); }
+  fa = elu_plus(qsum(s0) + t0);
+  fb = elu_plus(qsum(s1) + t1);
+}
+
+// first-layer pre-activations without the x term: HM main tiles + EX peeled scalars (the once-per-group MFMA runs
+// over HM + 1 tiles; the peeled rows sit in lanes q = 0 of the last tile and are broadcast to the element's other lanes)
+template <int HM, int EX>
+__device__ __forceinline__ void cond_bias_x(const float* wp, const MonoLayout& L, const float* __restrict__ h,
+                                            int64_t hbase, int64_t h_sc, int q, int j, f32x4 (&c1)[HM],
+                                            float (&c1x)[EX]) {
+  f32x4 full[HM + 1];
+  cond_bias<HM + 1>(wp, L, h, hbase, h_sc, q, j, full);
+#pragma unroll
+  for (int t = 0; t < HM; ++t) c1[t] = full[t];
+#pragma unroll
+  for (int e = 0; e < EX; ++e) c1x[e] = __shfl(full[HM][e], j, 64);
+}
+
+template <int HM, int EX, int WM, bool INV>
+__global__ __launch_bounds__(64 * kWaves) void mono_fwd_x_k(MonoArgs a) {
+  static_assert(WM == 0 || WM == 1, "peeled nets are narrow: the forward image is resident (1) or cached (0)");
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const MonoLayout& L = a.L;
+  const float* wp = a.pack;
+  if (WM == 1) {
+    for (int i = threadIdx.x * 4; i < L.fwd_floats; i += blockDim.x * 4)
+      *reinterpret_cast<f32x4*>(smem + i) = ld4(a.pack + i);
+    __syncthreads();
+    wp = smem;
+  }
+  auto getW = [&](int l) -> const float* { return wp + L.o_W[l]; };
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int q = lane >> 4, j = lane & 15;
+  const int64_t ngroups = (a.n + 15) / 16;
+  const float fS = (float)a.S;
+  for (int64_t grp = (int64_t)blockIdx.x * kWaves + wave; grp < ngroups; grp += (int64_t)gridDim.x * kWaves) {
+    const int64_t e = grp * 16 + j;
+    const bool valid = e < a.n;
+    const int64_t ec = valid ? e : a.n - 1;
+    const int64_t b = ec / a.d, i = ec - b * a.d;
+    const int64_t hbase = b * a.h_sb + i * a.h_sd;
+    f32x4 c1[HM];
+    float c1x[EX];
+    cond_bias_x<HM, EX>(wp, L, a.h, hbase, a.h_sc, q, j, c1, c1x);
+    const float h0 = a.h[hbase];
+    auto quad = [&](float xT, float xj, bool with_jac, float& fjac) {
+      float acc = 0.f;
+      const int total = a.S + 1 + (with_jac ? 1 : 0);
+      for (int k = 0; k < total; k += 2) {
+        const int k1 = k + 1;
+        const float wa = k <= a.S ? a.ccw[k] : 0.f;
+        const float wb = k1 <= a.S ? a.ccw[k1] : 0.f;
+        const float xa = k <= a.S ? xT * (a.cct[k] + 1.f) * .5f : xj;
+        const float xb = k1 <= a.S ? xT * (a.cct[k1] + 1.f) * .5f : xj;
+        float fa, fb;
+        eval2x<HM, EX>(wp, L, c1, c1x, xa, xb, q, j, fa, fb, getW);
+        acc = fmaf(wa, fa, acc);
+        acc = fmaf(wb, fb, acc);
+        if (with_jac) {
+          if (k == a.S + 1) fjac = fa;
+          if (k1 == a.S + 1) fjac = fb;
+        }
+      }
+      return acc;
+    };
+    float fj = 0.f;
+    if (!INV) {
+      const float xv = a.x[ec];
+      const float xT = fS * (xv / fS);                 // xT = x0 + nb_steps*step, x0 = 0
+      const float zs = quad(xT, xv, true, fj);
+      if (valid && q == 0) {
+        a.z[e] = zs * xT * .5f + h0;
+        a.jac[e] = fj;
+      }
+    } else {
+      const float zt = a.zt[ec];
+      float xmax = 20.f, xmin = -20.f;
+      for (int it = 0; it < 20; ++it) {
+        const float xm = (xmax + xmin) * .5f;
+        const float xT = fS * (xm / fS);
+        const float zm = quad(xT, 0.f, false, fj) * xT * .5f + h0;
+        if (zm > zt) xmax = xm; else xmin = xm;
+      }
+      if (valid && q == 0) a.xo[e] = (xmax + xmin) * .5f;
+    }
+  }
 }
 
 // WM 0: weight fragments from L1/L2.  1: the forward part of the pack LDS-resident (H <= 112).  2: wide nets -- one
@@ -1012,6 +1216,411 @@ __global__ __launch_bounds__(64 * kWaves, 1) void mono_bwd_pair_k(MonoArgs a) {
         for (int r = 0; r < 4; ++r) wrow[l * HP * HP + (16 * ti + 4 * q + r) * HP + 16 * tn + j] = accW[l][ti][tn][r];
 }
 
+// ---------------------------------------------------------------------------------------
+// Two-node backward of a PEELED narrow net (see eval2x): the HM full tiles run on the MFMA exactly as in
+// mono_bwd_pair_k with HT = HM (9 instead of 16 tile products per layer in each of the three contractions), the EX
+// leftover units U = 16 HM + e are per-element scalars replicated over the four q-lanes:
+//   forward      pre[U] = b + q-sum of the lane's partial dot with the main inputs + W[U][U'] x[U'];  main outputs get the
+//                rank-EX update W[:, U] x[U]
+//   dW, db       stay on the MFMA in the padded 4-tile form (K = the 16 elements: nothing to skip there, and per-lane
+//                partial accumulators for the peeled rows / columns / biases would cost 132 registers: measured, they
+//                spill); the peeled units and the constant 1 of the bias column are written into the fourth tile
+//   da           main inputs: W^T on the MFMA + rank-EX update W[U][:] dpre[U];  inputs U: q-sum of the lane's partial dot
+//                of W[:, U] with the main dpre + the corner
+// The pack, the LDS image, the per-wavefront element-major tiles and every output (accumulator rows in the padded
+// [HP][HP] form with the bias gradient in column HP-1, Dsum, the partial vector row) are those of mono_bwd_pair_k.
+// ---------------------------------------------------------------------------------------
+template <int HM, int NH, int EX>
+__global__ __launch_bounds__(64 * kWaves, 1) void mono_bwd_pair_x_k(MonoArgs a) {
+  static_assert(HM >= 1 && HM <= 3 && NH >= 2 && EX >= 1 && EX <= 3, "peeled narrow nets");
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const MonoLayout& L = a.L;
+  constexpr int HT = HM + 1, HP = 16 * HT, LDW = HP + 4, U0 = 16 * HM;
+  constexpr int matf = HP * LDW;
+  const int small = L.o_W1h;
+  float* sW = smem + small;                      // W_l at sW + (l-1) * (matf + HP), b_l right behind it
+  float* sWT = sW + (NH - 1) * (matf + HP);      // W_l^T at sWT + (l-1) * matf
+  for (int i = threadIdx.x * 4; i < small; i += blockDim.x * 4) *reinterpret_cast<f32x4*>(smem + i) = ld4(a.pack + i);
+  for (int l = 1; l < NH; ++l) {
+    for (int i = threadIdx.x * 4; i < matf + HP; i += blockDim.x * 4)
+      *reinterpret_cast<f32x4*>(sW + (l - 1) * (matf + HP) + i) = ld4(a.pack + L.o_W[l] + i);
+    for (int i = threadIdx.x * 4; i < matf; i += blockDim.x * 4)
+      *reinterpret_cast<f32x4*>(sWT + (l - 1) * matf + i) = ld4(a.pack + L.o_WT[l] + i);
+  }
+  __syncthreads();
+  const float* wp = smem;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int q = lane >> 4, j = lane & 15;
+  constexpr int NT = 2 * (NH - 1) + 1;           // tiles per wavefront: layer inputs of node 0 / node 1, one dpre tile
+  float* tiles = sWT + (NH - 1) * matf + wave * (NT * 16 * kTS);
+  for (int i = lane; i < NT * 16 * kTS; i += 64) tiles[i] = 0.f;
+  float* td = tiles + (NT - 1) * 16 * kTS;
+  const int64_t ngroups = (a.ecount + 15) / 16;
+  const float fS = (float)a.S;
+
+  f32x4 p_wL[HM], p_w1x[HM], accW[NH - 1][HT][HT];      // dW_l in the padded form (the weight gradient keeps all 4 tiles)
+  float p_wLx[EX], p_w1xx[EX];                            // d wL[U], d w1x[U] (same value in all q lanes)
+  float p_bL = 0.f;
+  const f32x4 z4 = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int t = 0; t < HM; ++t) { p_wL[t] = z4; p_w1x[t] = z4; }
+#pragma unroll
+  for (int e = 0; e < EX; ++e) { p_wLx[e] = 0.f; p_w1xx[e] = 0.f; }
+#pragma unroll
+  for (int l = 0; l < NH - 1; ++l)
+#pragma unroll
+    for (int ti = 0; ti < HT; ++ti)
+#pragma unroll
+      for (int tn = 0; tn < HT; ++tn) accW[l][ti][tn] = z4;
+
+  for (int64_t grp = (int64_t)blockIdx.x * kWaves + wave; grp < ngroups; grp += (int64_t)gridDim.x * kWaves) {
+    const int64_t el = grp * 16 + j;
+    const bool valid = el < a.ecount;
+    const int64_t e = a.e0 + (valid ? el : a.ecount - 1);
+    const int64_t b = e / a.d, i = e - b * a.d;
+    const int64_t hbase = b * a.h_sb + i * a.h_sd;
+    f32x4 c1[HM];
+    float c1x[EX];
+    cond_bias_x<HM, EX>(a.pack, L, a.h, hbase, a.h_sc, q, j, c1, c1x);     // W1h from L2 (once per group)
+    const float xv = a.x[e];
+    const float xT = fS * (xv / fS);
+    const float g_z = valid ? a.gz[e] : 0.f;
+    const float g_j = (valid && a.gjac) ? a.gjac[e] : 0.f;
+    const float cotq = g_z * xT * .5f;
+    f32x4 Ds[HM];
+    float Dsx[EX];
+#pragma unroll
+    for (int t = 0; t < HM; ++t) Ds[t] = z4;
+#pragma unroll
+    for (int ee = 0; ee < EX; ++ee) Dsx[ee] = 0.f;
+    float dx = 0.f;
+
+    for (int k = 0; k < a.NK; k += 2) {
+      float xk[2], cot[2];
+      bool isj[2];
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int ku = k + u;
+        const bool isq = ku <= a.S;
+        isj[u] = ku == a.S + 1;
+        xk[u] = isq ? xT * (a.cct[ku] + 1.f) * .5f : xv;
+        cot[u] = isq ? a.ccw[ku] * cotq : (isj[u] ? g_j : 0.f);
+      }
+      // ---- forward recompute of both nodes
+      f32x4 act[2][HM];
+      float ax[2][EX], axin[NH - 1][2][EX];          // axin[l-1]: peeled inputs of hidden layer l (for gates and dW)
+#pragma unroll
+      for (int t = 0; t < HM; ++t) {
+        const f32x4 wx = ld4(wp + L.o_w1x + 16 * t + 4 * q);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          act[0][t][r] = fmaxf(fmaf(wx[r], xk[0], c1[t][r]), 0.f);
+          act[1][t][r] = fmaxf(fmaf(wx[r], xk[1], c1[t][r]), 0.f);
+        }
+      }
+      {
+        const f32x4 wx = ld4(wp + L.o_w1x + U0);
+#pragma unroll
+        for (int ee = 0; ee < EX; ++ee) {
+          ax[0][ee] = fmaxf(fmaf(wx[ee], xk[0], c1x[ee]), 0.f);
+          ax[1][ee] = fmaxf(fmaf(wx[ee], xk[1], c1x[ee]), 0.f);
+        }
+      }
+#pragma unroll
+      for (int l = 1; l < NH; ++l) {
+        const float* W = sW + (l - 1) * (matf + HP);
+        const float* WTf = sWT + (l - 1) * matf;
+        f32x4 wr[EX][HM], wxr[EX], wc[EX][HM];      // W[U][k] (k = lane's units), W[U][U'], W[o][U] (o = lane's units)
+        const f32x4 bx = ld4(W + matf + U0);
+#pragma unroll
+        for (int ee = 0; ee < EX; ++ee) {
+#pragma unroll
+          for (int t = 0; t < HM; ++t) {
+            wr[ee][t] = ld4(W + (U0 + ee) * LDW + 16 * t + 4 * q);
+            wc[ee][t] = ld4(WTf + (U0 + ee) * LDW + 16 * t + 4 * q);
+          }
+          wxr[ee] = ld4(W + (U0 + ee) * LDW + U0);
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          float* ta = tiles + (2 * (l - 1) + u) * 16 * kTS;
+#pragma unroll
+          for (int t = 0; t < HM; ++t) *reinterpret_cast<f32x4*>(ta + tile_w(j, t, q)) = act[u][t];
+          f32x4 vx = z4;                                       // tile HM: the peeled units (lanes q = 0), column HP-1 = 1
+#pragma unroll
+          for (int ee = 0; ee < EX; ++ee) { vx[ee] = q == 0 ? ax[u][ee] : 0.f; axin[l - 1][u][ee] = ax[u][ee]; }
+          if (q == 3) vx[3] = 1.f;
+          *reinterpret_cast<f32x4*>(ta + tile_w(j, HM, q)) = vx;
+        }
+        f32x4 o[2][HM];
+#pragma unroll
+        for (int mt = 0; mt < HM; ++mt) { o[0][mt] = ld4(W + matf + 16 * mt + 4 * q); o[1][mt] = o[0][mt]; }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int t = 0; t < HM; ++t)
+#pragma unroll
+          for (int mt = 0; mt < HM; ++mt) {
+            const f32x4 A = ld4(W + (16 * mt + j) * LDW + 16 * t + 4 * q);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              o[0][mt] = mfma(A[r], act[0][t][r], o[0][mt]);
+              o[1][mt] = mfma(A[r], act[1][t][r], o[1][mt]);
+            }
+          }
+        __builtin_amdgcn_sched_barrier(0);
+        float y[2][EX];
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+          for (int ee = 0; ee < EX; ++ee) {
+            float sdot = 0.f;
+#pragma unroll
+            for (int t = 0; t < HM; ++t)
+#pragma unroll
+              for (int r = 0; r < 4; ++r) sdot = fmaf(wr[ee][t][r], act[u][t][r], sdot);
+            float kk = bx[ee];
+#pragma unroll
+            for (int e2 = 0; e2 < EX; ++e2) kk = fmaf(wxr[ee][e2], ax[u][e2], kk);
+            y[u][ee] = fmaxf(qsum(sdot) + kk, 0.f);
+          }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+#pragma unroll
+          for (int mt = 0; mt < HM; ++mt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              float v = o[u][mt][r];
+#pragma unroll
+              for (int ee = 0; ee < EX; ++ee) v = fmaf(wc[ee][mt][r], ax[u][ee], v);
+              act[u][mt][r] = fmaxf(v, 0.f);
+            }
+#pragma unroll
+          for (int ee = 0; ee < EX; ++ee) ax[u][ee] = y[u][ee];
+        }
+      }
+      float sv[2], dpl[2];
+      {
+        float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+        for (int t = 0; t < HM; ++t) {
+          const f32x4 wl = ld4(wp + L.o_wL + 16 * t + 4 * q);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) { s0 = fmaf(wl[r], act[0][t][r], s0); s1 = fmaf(wl[r], act[1][t][r], s1); }
+        }
+        const f32x4 wlx = ld4(wp + L.o_wL + U0);
+        float t0 = wp[L.o_bL], t1 = t0;
+#pragma unroll
+        for (int ee = 0; ee < EX; ++ee) { t0 = fmaf(wlx[ee], ax[0][ee], t0); t1 = fmaf(wlx[ee], ax[1][ee], t1); }
+        sv[0] = qsum(s0) + t0;
+        sv[1] = qsum(s1) + t1;
+      }
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        if (isj[u]) dx = g_z * elu_plus(sv[u]);                  // Leibniz rule: dz/dx = f(x;h)
+        dpl[u] = cot[u] * (sv[u] > 0.f ? 1.f : expf(sv[u]));
+        if (q == 0) p_bL += dpl[u];
+      }
+      // ---- backward through the last layer
+      f32x4 dp[2][HM];
+      float dpx[2][EX];
+#pragma unroll
+      for (int t = 0; t < HM; ++t) {
+        const f32x4 wl = ld4(wp + L.o_wL + 16 * t + 4 * q);
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+          for (int u = 0; u < 2; ++u) {
+            p_wL[t][r] = fmaf(dpl[u], act[u][t][r], p_wL[t][r]);
+            dp[u][t][r] = act[u][t][r] > 0.f ? wl[r] * dpl[u] : 0.f;
+          }
+      }
+      {
+        const f32x4 wlx = ld4(wp + L.o_wL + U0);
+#pragma unroll
+        for (int ee = 0; ee < EX; ++ee)
+#pragma unroll
+          for (int u = 0; u < 2; ++u) {
+            p_wLx[ee] = fmaf(dpl[u], ax[u][ee], p_wLx[ee]);
+            dpx[u][ee] = ax[u][ee] > 0.f ? wlx[ee] * dpl[u] : 0.f;
+          }
+      }
+      // ---- hidden->hidden layers, top down
+#pragma unroll
+      for (int l = NH - 1; l >= 1; --l) {
+        const float* W = sW + (l - 1) * (matf + HP);
+        const float* WT = sWT + (l - 1) * matf;
+        // dW_l main block += dpre_l^T * input_l, K = the 16 elements, node by node through the one dpre tile
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+#pragma unroll
+          for (int t = 0; t < HM; ++t) *reinterpret_cast<f32x4*>(td + tile_w(j, t, q)) = dp[u][t];
+          f32x4 vx = z4;
+#pragma unroll
+          for (int ee = 0; ee < EX; ++ee) vx[ee] = q == 0 ? dpx[u][ee] : 0.f;
+          *reinterpret_cast<f32x4*>(td + tile_w(j, HM, q)) = vx;
+          const float* ta = tiles + (2 * (l - 1) + u) * 16 * kTS;
+#pragma unroll
+          for (int sK = 0; sK < 4; ++sK) {
+            float fa[HT], fb[HT];
+#pragma unroll
+            for (int t = 0; t < HT; ++t) { fa[t] = td[tile_r(sK, q, t, j)]; fb[t] = ta[tile_r(sK, q, t, j)]; }
+#pragma unroll
+            for (int ti = 0; ti < HT; ++ti)
+#pragma unroll
+              for (int tn = 0; tn < HT; ++tn) accW[l - 1][ti][tn] = mfma(fa[ti], fb[tn], accW[l - 1][ti][tn]);
+          }
+        }
+        f32x4 da[2][HM];
+#pragma unroll
+        for (int mt = 0; mt < HM; ++mt) { da[0][mt] = z4; da[1][mt] = z4; }
+#pragma unroll
+        for (int t = 0; t < HM; ++t)
+#pragma unroll
+          for (int mt = 0; mt < HM; ++mt) {
+            const f32x4 A = ld4(WT + (16 * mt + j) * LDW + 16 * t + 4 * q);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              da[0][mt] = mfma(A[r], dp[0][t][r], da[0][mt]);
+              da[1][mt] = mfma(A[r], dp[1][t][r], da[1][mt]);
+            }
+          }
+        // peeled parts of da: the main inputs get a rank-EX update, the peeled inputs a q-summed partial dot
+        f32x4 wr[EX][HM], wcT[EX][HM], wxr[EX];
+#pragma unroll
+        for (int ee = 0; ee < EX; ++ee) {
+#pragma unroll
+          for (int t = 0; t < HM; ++t) {
+            wr[ee][t] = ld4(W + (U0 + ee) * LDW + 16 * t + 4 * q);       // W[U][k],  k = the lane's main units
+            wcT[ee][t] = ld4(WT + (U0 + ee) * LDW + 16 * t + 4 * q);     // W[o][U],  o = the lane's main units
+          }
+          wxr[ee] = ld4(W + (U0 + ee) * LDW + U0);                        // W[U][U']
+        }
+        float dax[2][EX];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          f32x4 ain[HM];                               // main inputs of layer l, back from the tile they were saved in
+          const float* tg = tiles + (2 * (l - 1) + u) * 16 * kTS;
+#pragma unroll
+          for (int t = 0; t < HM; ++t) ain[t] = *reinterpret_cast<const f32x4*>(tg + tile_w(j, t, q));
+          // da of the peeled inputs U' = sum_o W[o][U'] dp[o] + sum_U W[U][U'] dpx[U]
+#pragma unroll
+          for (int e2 = 0; e2 < EX; ++e2) {
+            float sdot = 0.f;
+#pragma unroll
+            for (int t = 0; t < HM; ++t)
+#pragma unroll
+              for (int r = 0; r < 4; ++r) sdot = fmaf(wcT[e2][t][r], dp[u][t][r], sdot);
+            float kk = 0.f;
+#pragma unroll
+            for (int ee = 0; ee < EX; ++ee) kk = fmaf(wxr[ee][e2], dpx[u][ee], kk);
+            dax[u][e2] = qsum(sdot) + kk;
+          }
+          // main inputs: MFMA result + rank-EX update, gated by (input > 0)
+#pragma unroll
+          for (int t = 0; t < HM; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              float v = da[u][t][r];
+#pragma unroll
+              for (int ee = 0; ee < EX; ++ee) v = fmaf(wr[ee][t][r], dpx[u][ee], v);
+              dp[u][t][r] = ain[t][r] > 0.f ? v : 0.f;
+            }
+#pragma unroll
+          for (int e2 = 0; e2 < EX; ++e2) dpx[u][e2] = axin[l - 1][u][e2] > 0.f ? dax[u][e2] : 0.f;
+        }
+      }
+      // ---- first layer: rank-1 in x_k, node-independent in h
+      float sx0 = 0.f, sx1 = 0.f;
+#pragma unroll
+      for (int t = 0; t < HM; ++t) {
+        const f32x4 wx = ld4(wp + L.o_w1x + 16 * t + 4 * q);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          Ds[t][r] += dp[0][t][r] + dp[1][t][r];
+          p_w1x[t][r] = fmaf(dp[0][t][r], xk[0], p_w1x[t][r]);
+          p_w1x[t][r] = fmaf(dp[1][t][r], xk[1], p_w1x[t][r]);
+          sx0 = fmaf(wx[r], dp[0][t][r], sx0);
+          sx1 = fmaf(wx[r], dp[1][t][r], sx1);
+        }
+      }
+      {
+        const f32x4 wx = ld4(wp + L.o_w1x + U0);
+        float tx0 = 0.f, tx1 = 0.f;
+#pragma unroll
+        for (int ee = 0; ee < EX; ++ee) {
+          Dsx[ee] += dpx[0][ee] + dpx[1][ee];
+          p_w1xx[ee] = fmaf(dpx[0][ee], xk[0], p_w1xx[ee]);
+          p_w1xx[ee] = fmaf(dpx[1][ee], xk[1], p_w1xx[ee]);
+          tx0 = fmaf(wx[ee], dpx[0][ee], tx0);
+          tx1 = fmaf(wx[ee], dpx[1][ee], tx1);
+        }
+        if (isj[0]) dx += qsum(sx0) + tx0;                       // gjac * df/dx(x;h)
+        if (isj[1]) dx += qsum(sx1) + tx1;
+      }
+    }
+
+    // ---- per-group epilogue: staged Dsum (for d W1h and d b_0), dh, dx.  The peeled units form the tile HM of the
+    //      padded Dsum row: lanes q = 0 hold them (columns U0..U0+3), the other lanes of the tile are zero
+    f32x4 DsF[HT];
+#pragma unroll
+    for (int t = 0; t < HM; ++t) DsF[t] = Ds[t];
+    DsF[HM] = z4;
+#pragma unroll
+    for (int ee = 0; ee < EX; ++ee) DsF[HM][ee] = q == 0 ? Dsx[ee] : 0.f;
+    float* ds = a.Dsum + (grp * 16 + j) * HP + 4 * q;
+#pragma unroll
+    for (int t = 0; t < HT; ++t) *reinterpret_cast<f32x4*>(ds + 16 * t) = DsF[t];
+    if (valid && q == 0 && a.gx) a.gx[e] = dx;
+    const int64_t gbase = b * a.g_sb + i * a.g_sd;
+    for (int mt = 0; mt < L.CP / 16; ++mt) {
+      f32x4 o = z4;
+#pragma unroll
+      for (int t = 0; t < HT; ++t) {
+        const f32x4 A = ld4(a.pack + L.o_W1hT + (16 * mt + j) * LDW + 16 * t + 4 * q);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o = mfma(A[r], DsF[t][r], o);
+      }
+      if (valid) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int cc = 16 * mt + 4 * q + r;
+          if (cc < L.c) a.gh[gbase + cc * a.g_sc] = o[r] + (cc == 0 ? g_z : 0.f);
+        }
+      }
+    }
+  }
+
+  // ---- partial vector row: d wL | d w1x | (hidden biases: zero here, they ride column HP-1 of the weight rows) | d bL
+  float* prow = a.part + ((int64_t)blockIdx.x * kWaves + wave) * ((NH + 2) * HP + 4);
+#pragma unroll
+  for (int t = 0; t < HT; ++t)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int hid = 16 * t + 4 * q + r;
+      float v0 = 0.f, v1 = 0.f;
+      if (t < HM) { v0 = jsum(p_wL[t < HM ? t : 0][r]); v1 = jsum(p_w1x[t < HM ? t : 0][r]); }
+      else if (r < EX) { v0 = jsum(p_wLx[r < EX ? r : 0]); v1 = jsum(p_w1xx[r < EX ? r : 0]); if (q != 0) { v0 = 0.f; v1 = 0.f; } }
+      if (j == 0) {
+        prow[hid] = v0;
+        prow[HP + hid] = v1;
+#pragma unroll
+        for (int l = 0; l < NH; ++l) prow[(2 + l) * HP + hid] = 0.f;
+      }
+    }
+  const float vbl = jsum(p_bL);
+  if (lane == 0) { prow[(NH + 2) * HP] = vbl; prow[(NH + 2) * HP + 1] = 0.f; prow[(NH + 2) * HP + 2] = 0.f; prow[(NH + 2) * HP + 3] = 0.f; }
+  // ---- accumulator rows in the padded [HP][HP] form (row = out unit, column = in unit, column HP-1 = bias gradient)
+  float* wrow = a.wpart + ((int64_t)blockIdx.x * kWaves + wave) * ((NH - 1) * HP * HP);
+#pragma unroll
+  for (int l = 0; l < NH - 1; ++l)
+#pragma unroll
+    for (int ti = 0; ti < HT; ++ti)
+#pragma unroll
+      for (int tn = 0; tn < HT; ++tn)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) wrow[l * HP * HP + (16 * ti + 4 * q + r) * HP + 16 * tn + j] = accW[l][ti][tn][r];
+}
+
 struct UnpackArgs {
   gnf_mono_net net; MonoLayout L;
   float* gW[GNF_MONO_MAX_LAYERS]; float* gb[GNF_MONO_MAX_LAYERS];
@@ -1057,6 +1666,20 @@ int pick_ht(const gnf_mono_net* net) {
 
 constexpr int kLdsBudget = 160 * 1024;
 
+// layout of a net's pack + whether its kernels peel the leftover units of the last tile (all hidden widths H with
+// H / 16 == 3 and H mod 16 in {1, 2, 3}: the reference's default [50, 50, 50]); GNF_MONO_PEEL=0 keeps the padded form
+MonoLayout net_layout(const gnf_mono_net* net, int HT) {
+  MonoLayout L = make_layout(HT, net->nl - 1, net->dims[0] - 1);
+  static const bool enabled = [] { const char* e = std::getenv("GNF_MONO_PEEL"); return !(e && e[0] == '0'); }();
+  if (enabled && HT == 4) {
+    const int H = net->dims[1];
+    bool same = true;
+    for (int l = 1; l < net->nl; ++l) same = same && net->dims[l] == H;
+    if (same && H / 16 == 3 && H % 16 >= 1 && H % 16 <= 3) { L.HM = 3; L.EX = H % 16; }
+  }
+  return L;
+}
+
 template <bool INV>
 int launch_fwd(const MonoArgs& a, hipStream_t s) {
   const int HT = a.L.HT;
@@ -1091,6 +1714,20 @@ int launch_fwd(const MonoArgs& a, hipStream_t s) {
   }
   const int64_t per_cu = ((wlds && lds > (size_t)kLdsBudget / 2) || swap) ? 1 : 2;   // resident workgroups per CU
   if (grid > 256 * per_cu) grid = 256 * per_cu;                      // persistent
+  if (a.L.EX > 0 && !swap) {                                          // peeled narrow net (HM = 3: H in {49, 50, 51})
+#define GNF_FWDX(EX_)                                                                                          \
+    if (wlds) {                                                                                                \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mono_fwd_x_k<3, EX_, 1, INV>),                  \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                         \
+      hipLaunchKernelGGL((mono_fwd_x_k<3, EX_, 1, INV>), dim3((unsigned)grid), dim3(64 * kWaves), lds, s, a);  \
+    } else {                                                                                                   \
+      hipLaunchKernelGGL((mono_fwd_x_k<3, EX_, 0, INV>), dim3((unsigned)grid), dim3(64 * kWaves), 0, s, a);    \
+    }
+    if (a.L.EX <= 2) { GNF_FWDX(2) } else { GNF_FWDX(3) }
+#undef GNF_FWDX
+    GNF_LAUNCH_CHECK();
+    return 0;
+  }
 #define GNF_FWD_CASE(HT_)                                                                                     \
   case HT_:                                                                                                  \
     if (wlds) {                                                                                              \
@@ -1122,6 +1759,21 @@ int launch_bwd_one(const MonoArgs& a, unsigned grid, hipStream_t s) {
     if (a.indw == 2) {                          // two nodes per pass, image without W1h / W1h^T, 5 tiles per wavefront
       const size_t lds_pair = ((size_t)a.L.o_W1h + (size_t)(NH - 1) * (2 * a.L.HP * a.L.LDW + a.L.HP) +
                                (size_t)kWaves * (2 * (NH - 1) + 1) * 16 * kTS) * sizeof(float);
+      if constexpr (HT == 4) {
+        if (a.L.EX > 0) {                       // peeled: 3 tiles on the MFMA, the H mod 16 leftover units on the VALU
+          if (a.L.EX <= 2) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mono_bwd_pair_x_k<3, NH, 2>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_pair);
+            hipLaunchKernelGGL((mono_bwd_pair_x_k<3, NH, 2>), dim3(grid), dim3(64 * kWaves), lds_pair, s, a);
+          } else {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mono_bwd_pair_x_k<3, NH, 3>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_pair);
+            hipLaunchKernelGGL((mono_bwd_pair_x_k<3, NH, 3>), dim3(grid), dim3(64 * kWaves), lds_pair, s, a);
+          }
+          GNF_LAUNCH_CHECK();
+          return 0;
+        }
+      }
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mono_bwd_pair_k<HT, NH>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_pair);
       hipLaunchKernelGGL((mono_bwd_pair_k<HT, NH>), dim3(grid), dim3(64 * kWaves), lds_pair, s, a);
@@ -1353,7 +2005,7 @@ extern "C" {
 int64_t gnf_monotonic_pack_floats(const gnf_mono_net* net) {
   const int HT = pick_ht(net);
   if (HT < 0) return GNF_ESHAPE;
-  return make_layout(HT, net->nl - 1, net->dims[0] - 1).total_floats;
+  return net_layout(net, HT).total_floats;
 }
 
 int gnf_monotonic_pack(const gnf_mono_net* net, float* pack, gnf_stream_t stream) {
@@ -1362,7 +2014,7 @@ int gnf_monotonic_pack(const gnf_mono_net* net, float* pack, gnf_stream_t stream
   if (!pack) return GNF_EINVAL;
   PackArgs a;
   a.net = *net;
-  a.L = make_layout(HT, net->nl - 1, net->dims[0] - 1);
+  a.L = net_layout(net, HT);
   hipLaunchKernelGGL(mono_pack_k, dim3((a.L.total_floats + 255) / 256), dim3(256), 0, (hipStream_t)stream, a, pack);
   GNF_LAUNCH_CHECK();
   return 0;
@@ -1376,7 +2028,7 @@ int gnf_monotonic_fwd(const float* pack, const gnf_mono_net* net, const float* x
   if (!pack || !x || !h || !cc_w || !cc_t || !z || !jac || S < 1 || B < 0 || d <= 0) return GNF_EINVAL;
   if (B == 0) return 0;
   MonoArgs a{};
-  a.pack = pack; a.L = make_layout(HT, net->nl - 1, net->dims[0] - 1);
+  a.pack = pack; a.L = net_layout(net, HT);
   a.x = x; a.h = h; a.h_sb = h_sb; a.h_sd = h_sd; a.h_sc = h_sc;
   a.ccw = cc_w; a.cct = cc_t; a.S = S; a.z = z; a.jac = jac; a.n = B * d; a.d = d;
   return launch_fwd<false>(a, (hipStream_t)stream);
@@ -1390,7 +2042,7 @@ int gnf_monotonic_inv(const float* pack, const gnf_mono_net* net, const float* z
   if (!pack || !z || !h || !cc_w || !cc_t || !x || S < 1 || B < 0 || d <= 0) return GNF_EINVAL;
   if (B == 0) return 0;
   MonoArgs a{};
-  a.pack = pack; a.L = make_layout(HT, net->nl - 1, net->dims[0] - 1);
+  a.pack = pack; a.L = net_layout(net, HT);
   a.h = h; a.h_sb = h_sb; a.h_sd = h_sd; a.h_sc = h_sc;
   a.ccw = cc_w; a.cct = cc_t; a.S = S; a.zt = z; a.xo = x; a.n = B * d; a.d = d;
   return launch_fwd<true>(a, (hipStream_t)stream);
@@ -1399,7 +2051,7 @@ int gnf_monotonic_inv(const float* pack, const gnf_mono_net* net, const float* z
 int64_t gnf_monotonic_bwd_ws_bytes(const gnf_mono_net* net, int S, int64_t B, int64_t d) {
   const int HT = pick_ht(net);
   if (HT < 0) return GNF_ESHAPE;
-  const MonoLayout L = make_layout(HT, net->nl - 1, net->dims[0] - 1);
+  const MonoLayout L = net_layout(net, HT);
   const bool indw = use_indw(net, L);
   const BwdPlan full = plan_bwd(L, S, B * d, 0, indw);
   const int64_t want = full.total_floats * (int64_t)sizeof(float);
@@ -1423,7 +2075,7 @@ int gnf_monotonic_bwd(const float* pack, const gnf_mono_net* net, const float* x
   if (NH > 4) return GNF_ESHAPE;
   if (h_sb != d * h_sd) return GNF_ESHAPE;   // element stride must collapse (caller makes h contiguous)
   hipStream_t s = (hipStream_t)stream;
-  const MonoLayout L = make_layout(HT, NH, net->dims[0] - 1);
+  const MonoLayout L = net_layout(net, HT);
   const int64_t n = B * d;
   const bool indw = use_indw(net, L);
   const BwdPlan P = plan_bwd(L, S, n, ws_bytes / (int64_t)sizeof(float), indw);

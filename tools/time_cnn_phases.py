@@ -29,29 +29,9 @@ for _ in range(2):
 torch.cuda.synchronize()
 PROW = 16 * 144 + 256 + 16
 t = ws[(256 * 8 + 1) * PROW:(256 * 8 + 1) * PROW + 64].view(8, 8).cpu()
-names = ["P0 load+scatter", "P1 conv1", "P3 dW2", "P4 da1", "P5 dW1+T", "de+zero"]
+names = ["P0 load+scatter", "P1 conv1", "P3 dW2", "P4a mfma(+barrier)", "de", "P4b outT+gate", "P4c dW1", "P4d T"]
 imgs = (n - 7 + 255) // 256
 print("rc", rc, "images per WG", imgs)
 for w in range(8):
-    print("wave", w, {names[k]: int(t[w, k].item() / imgs) for k in range(6)}, "total/img", int(t[w, :6].sum().item() / imgs))
+    print("wave", w, {names[k]: int(t[w, k].item() / imgs) for k in range(8)}, "total/img", int(t[w, :8].sum().item() / imgs))
 
-# forward phases (the timing build writes them through CnnArgs.part, which the fwd entry leaves NULL: use a raw launch)
-buf = (ctypes.c_float * 64)()
-for _ in range(2):
-    lib.gnf_mnistcnn_conv_fwd(P(e.data_ptr()), P(W1.data_ptr()), P(b1.data_ptr()), P(W2.data_ptr()), P(b2.data_ptr()), P(pooled.data_ptr()), P(arg.data_ptr()), ctypes.c_int64(n), ctypes.c_int(0), st)
-torch.cuda.synchronize()
-lib.gnf_debug_fwd_timing(buf)
-imgs_f = (n - 7 + 511) // 512
-for w in (0, 7):
-    print("fwd wave", w, {nm: int(buf[w * 8 + k] / imgs_f) for k, nm in enumerate(["load+store e", "conv1", "conv2+pool"])})
-print("occupancy API blocks/CU: fwd", lib.gnf_debug_occupancy(0), "bwd", lib.gnf_debug_occupancy(1))
-props = torch.cuda.get_device_properties(0)
-print("sharedMemPerBlock", getattr(props, "shared_memory_per_block", None), "per multiprocessor", getattr(props, "shared_memory_per_multiprocessor", None))
-print("fwd occupancy vs LDS bytes:", {k: lib.gnf_debug_occupancy_lds(k * 1024) for k in (16, 32, 40, 48, 52, 56, 60, 64, 68, 72, 80)})
-st64 = (ctypes.c_longlong * 1024)()
-lib.gnf_debug_fwd_start(st64)
-import numpy as np
-stt = np.array(st64[:512], dtype=np.float64); en = np.array(st64[512:], dtype=np.float64)
-t0 = stt.min()
-print("fwd WG start (cycles after first): quartiles", np.percentile(stt - t0, [0, 25, 50, 75, 100]).astype(int).tolist(),
-      " end: ", np.percentile(en - t0, [0, 50, 100]).astype(int).tolist())
