@@ -52,46 +52,76 @@ __global__ void dag_gate_tab_k(const float* __restrict__ A, float* __restrict__ 
   tab[3 * dd + ij] = (1.f / pa + 1.f / pb) / T;
 }
 
-struct Noise { float a, b; };
+// Noise of the FOUR adjacent columns 4 jq .. 4 jq + 3 of row (b*d + i), one value per column:
+//   gate_mode 1 (Gumbel-softmax): v = exp(g2 - g1) = E1 / E2, the ratio of two independent Exp(1) variates.
+//     * injected uniforms (parity tests, the reference's draw order u1 then u2):  v = ln u1 / ln u2;
+//     * Philox:  E1 / (E1 + E2) is EXACTLY uniform on (0,1), so v = V / (1 - V) with ONE uniform V has exactly the law of
+//       the reference's ratio -- one 32-bit word and one division per element instead of two words and two logarithms.
+//       One Philox4x32-10 call (the dominant VALU cost of these kernels: 40 quarter-rate integer multiplies) then serves
+//       four columns: the counter is the column QUAD (row * ceil(d/4) + jq).
+//   gate_mode 2 (noise gate): one standard normal per column; Philox: both Box-Muller outputs of each uniform pair.
+// Forward and backward use the same mapping, so the backward regenerates the forward's noise.
+struct Draw4 { float v[4]; };
 
-// Noise of the two adjacent columns 2 jp, 2 jp + 1 of row (b*d + i).  gate_mode 1: two uniforms in (0,1) each;
-// gate_mode 2: one standard normal each (Box-Muller on a Philox pair).  One Philox4x32-10 call -- the dominant VALU
-// cost of these kernels -- yields four 32-bit words = exactly what two columns need, so the counter is the column
-// PAIR (row * ceil(d/2) + jp); forward and backward use the same mapping.
-__device__ __forceinline__ void draw2(int gate_mode, const float* u1, const float* u2, uint64_t seed, uint64_t offset,
-                                      int64_t row, int64_t jp, int64_t d, Noise (&n)[2]) {
-  n[0] = Noise{0.f, 0.f};
-  n[1] = n[0];
-  if (gate_mode == 0) return;
-  const int64_t j0 = 2 * jp;
+__device__ __forceinline__ float u01_open(uint32_t w) {      // 24-bit uniform centred in its cell: never exactly 0 or 1
+  return ((float)(w >> 8) + .5f) * (1.0f / 16777216.0f);
+}
+
+__device__ __forceinline__ Draw4 draw4(int gate_mode, const float* u1, const float* u2, uint64_t seed, uint64_t offset,
+                                       int64_t row, int64_t jq, int64_t d) {
+  Draw4 n;
+#pragma unroll
+  for (int h = 0; h < 4; ++h) n.v[h] = 0.f;
+  if (gate_mode == 0) return n;
+  const int64_t j0 = 4 * jq;
   if (u1) {
 #pragma unroll
-    for (int h = 0; h < 2; ++h)
+    for (int h = 0; h < 4; ++h)
       if (j0 + h < d) {
-        n[h].a = u1[row * d + j0 + h];
-        n[h].b = (gate_mode == 1) ? u2[row * d + j0 + h] : 0.f;
+        const float a = u1[row * d + j0 + h];
+        n.v[h] = gate_mode == 1 ? log2f(a) / log2f(u2[row * d + j0 + h]) : a;      // ln u1 / ln u2 = exp(g2 - g1)
       }
-    return;
+    return n;
   }
-  const uint64_t idx = (uint64_t)(row * ((d + 1) / 2) + jp);
+  const uint64_t idx = (uint64_t)(row * ((d + 3) / 4) + jq);
   uint32_t r[4];
   philox4x32_10((uint32_t)idx, (uint32_t)(idx >> 32), (uint32_t)offset, (uint32_t)(offset >> 32),
                 (uint32_t)seed, (uint32_t)(seed >> 32), r);
+  if (gate_mode == 1) {
 #pragma unroll
-  for (int h = 0; h < 2; ++h) {
-    // 24-bit uniforms centred in their cell: never exactly 0 or 1
-    const float ua = ((float)(r[2 * h] >> 8) + .5f) * (1.0f / 16777216.0f);
-    const float ub = ((float)(r[2 * h + 1] >> 8) + .5f) * (1.0f / 16777216.0f);
-    if (gate_mode == 1) { n[h].a = ua; n[h].b = ub; }
-    else n[h].a = sqrtf(-2.f * logf(ua)) * cosf(6.283185307179586f * ub);
+    for (int h = 0; h < 4; ++h) {
+      const float V = u01_open(r[h]);
+      n.v[h] = V / (1.f - V);
+    }
+  } else {
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const float rad = sqrtf(-2.f * logf(u01_open(r[2 * h]))), ang = 6.283185307179586f * u01_open(r[2 * h + 1]);
+      n.v[2 * h] = rad * cosf(ang);
+      n.v[2 * h + 1] = rad * sinf(ang);
+    }
   }
+  return n;
 }
 
-// Gumbel-softmax gate from the table entry ET and the two uniforms
-__device__ __forceinline__ float gumbel_gate(float ET, Noise n, float T) {
-  const float r = log2f(n.a) / log2f(n.b);            // = ln u1 / ln u2 = exp(g2 - g1)
-  const float rT = T == 1.f ? r : (T == .5f ? r * r : exp2f(log2f(r) / T));
-  return 1.f / (1.f + ET * rT);                       // u1 -> 0: gate 0;  u2 -> 0: gate 1 (as the reference)
+// four consecutive floats: one 16-B load when the quad is whole and 16-B aligned (vec), scalar loads otherwise
+__device__ __forceinline__ void load4(const float* __restrict__ p, int nv, bool vec, float (&o)[4]) {
+  if (vec && nv == 4) {
+    const float4 t = *reinterpret_cast<const float4*>(p);
+    o[0] = t.x; o[1] = t.y; o[2] = t.z; o[3] = t.w;
+  } else {
+#pragma unroll
+    for (int h = 0; h < 4; ++h) o[h] = h < nv ? p[h] : 0.f;
+  }
+}
+__device__ __forceinline__ bool quad_aligned(const float* base, int64_t ld) {
+  return ((ld | (int64_t)(reinterpret_cast<uintptr_t>(base) >> 2)) & 3) == 0;
+}
+
+// Gumbel-softmax gate z1/(z1+z2) = 1/(1 + ET * v^(1/T)) from the table entry ET and the ratio v
+__device__ __forceinline__ float gumbel_gate(float ET, float v, float T) {
+  const float vT = T == 1.f ? v : (T == .5f ? v * v : exp2f(log2f(v) / T));
+  return 1.f / (1.f + ET * vT);                       // u1 -> 0: gate 0;  u2 -> 0: gate 1 (as the reference)
 }
 
 struct GateArgs {
@@ -100,66 +130,89 @@ struct GateArgs {
   float* ws; float* gA; float* gx; int64_t B, d, chunk;
 };
 
-// one workgroup row per (b,i): blockIdx.x = b*d + i, blockIdx.y tiles the ceil(d/2) column pairs
+// One thread per (i, column quad), looping over the samples of its chunk (blockIdx.y): the table entries of the quad are
+// read once, every iteration is one Philox call + four gates + one 16-B store.  (One tiny thread per (b, i, quad)
+// -- 78 400 workgroups at cfg4 -- spent its time on the dependent table loads: 0.17 ms; this form 0.06.)
 __global__ void dag_gate_fwd_k(GateArgs a) {
-  const int64_t bi = blockIdx.x;
-  const int64_t jp = (int64_t)blockIdx.y * blockDim.x + threadIdx.x;
-  if (2 * jp >= a.d) return;
-  const int64_t b = bi / a.d, i = bi - b * a.d, dd = a.d * a.d;
-  Noise n[2];
-  draw2(a.gate_mode, a.u1, a.u2, a.seed, a.offset, bi, jp, a.d, n);
+  const int64_t d = a.d, dd = d * d, dq = (d + 3) / 4;
+  const int64_t ip = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (ip >= d * dq) return;
+  const int64_t i = ip / dq, jq = ip - i * dq, j0 = 4 * jq;
+  const int nv = d - j0 < 4 ? (int)(d - j0) : 4;
+  const bool vt = quad_aligned(a.tab, d), vx = quad_aligned(a.x, d), ve = quad_aligned(a.e, a.ld_e);
+  float p4[4], et4[4] = {0.f, 0.f, 0.f, 0.f};
+  load4(a.tab + i * d + j0, nv, vt, p4);
+  if (a.gate_mode == 1) load4(a.tab + 2 * dd + i * d + j0, nv, vt, et4);
+  const int64_t b0 = (int64_t)blockIdx.y * a.chunk;
+  const int64_t b1 = b0 + a.chunk < a.B ? b0 + a.chunk : a.B;
+  for (int64_t b = b0; b < b1; ++b) {
+    const int64_t bi = b * d + i;
+    const Draw4 n = draw4(a.gate_mode, a.u1, a.u2, a.seed, a.offset, bi, jq, d);
+    float out[4], x4[4];
+    load4(a.x + b * d + j0, nv, vx, x4);
 #pragma unroll
-  for (int h = 0; h < 2; ++h) {
-    const int64_t j = 2 * jp + h;
-    if (j >= a.d) break;
-    const int64_t ij = i * a.d + j;
-    const float p = a.tab[ij];
-    const float xv = a.x[b * a.d + j];
-    float out;
-    if (a.gate_mode == 0) out = xv * p;
-    else out = a.gate_mode == 1 ? xv * gumbel_gate(a.tab[2 * dd + ij], n[h], a.T) : p * (xv + n[h].a * fabsf(1.f - p));
-    a.e[bi * a.ld_e + j] = out;
-    if (a.hot) a.e[bi * a.ld_e + a.d + j] = (j == i) ? 1.f : 0.f;
+    for (int h = 0; h < 4; ++h) {
+      const float p = p4[h], xv = x4[h];
+      if (a.gate_mode == 0) out[h] = xv * p;
+      else out[h] = a.gate_mode == 1 ? xv * gumbel_gate(et4[h], n.v[h], a.T) : p * (xv + n.v[h] * fabsf(1.f - p));
+    }
+    float* erow = a.e + bi * a.ld_e + j0;
+    if (nv == 4 && ve) {
+      *reinterpret_cast<float4*>(erow) = make_float4(out[0], out[1], out[2], out[3]);
+    } else {
+#pragma unroll
+      for (int h = 0; h < 4; ++h)
+        if (h < nv) erow[h] = out[h];
+    }
+    if (a.hot) {
+#pragma unroll
+      for (int h = 0; h < 4; ++h)
+        if (h < nv) erow[d + h] = (j0 + h == i) ? 1.f : 0.f;
+    }
   }
 }
 
-// dL/dp partial sums over a chunk of b:  ws[chunk][i*d+j] = sum_b ge[b,i,j] * de/dp[b,i,j];  one thread per (i, column pair)
+// dL/dp partial sums over a chunk of b:  ws[chunk][i*d+j] = sum_b ge[b,i,j] * de/dp[b,i,j];  one thread per (i, column quad)
 __global__ void dag_gate_bwd_dp_k(GateArgs a) {
-  const int64_t d = a.d, dd = d * d, dh = (d + 1) / 2;
+  const int64_t d = a.d, dd = d * d, dq = (d + 3) / 4;
   const int64_t ip = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (ip >= d * dh) return;
-  const int64_t i = ip / dh, jp = ip - i * dh, j0 = 2 * jp;
-  const bool two = j0 + 1 < d;
-  float p[2], ET[2], Q[2], acc[2] = {0.f, 0.f};
+  if (ip >= d * dq) return;
+  const int64_t i = ip / dq, jq = ip - i * dq, j0 = 4 * jq;
+  const int nv = d - j0 < 4 ? (int)(d - j0) : 4;
+  float p[4], ET[4], Q[4], acc[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-  for (int h = 0; h < 2; ++h) {
-    const int64_t ij = i * d + j0 + (two ? h : 0);
+  for (int h = 0; h < 4; ++h) {
+    const int64_t ij = i * d + j0 + (h < nv ? h : 0);
     p[h] = a.tab[ij]; ET[h] = a.tab[2 * dd + ij]; Q[h] = a.tab[3 * dd + ij];
   }
   const int64_t b0 = (int64_t)blockIdx.y * a.chunk;
   const int64_t b1 = b0 + a.chunk < a.B ? b0 + a.chunk : a.B;
+  const bool vg = quad_aligned(a.ge, a.ld_e), vx = quad_aligned(a.x, d);
   for (int64_t b = b0; b < b1; ++b) {
-    Noise n[2];
-    draw2(a.gate_mode, a.u1, a.u2, a.seed, a.offset, b * d + i, jp, d, n);
+    const Draw4 n = draw4(a.gate_mode, a.u1, a.u2, a.seed, a.offset, b * d + i, jq, d);
+    float g4[4], x4[4];
+    load4(a.ge + (b * d + i) * a.ld_e + j0, nv, vg, g4);
+    load4(a.x + b * d + j0, nv, vx, x4);
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      if (h == 1 && !two) break;
-      const float g = a.ge[(b * d + i) * a.ld_e + j0 + h];
-      const float xv = a.x[b * d + j0 + h];
+    for (int h = 0; h < 4; ++h) {
+      if (h >= nv) break;
+      const float g = g4[h];
+      const float xv = x4[h];
       if (a.gate_mode == 0) {
         acc[h] = fmaf(g, xv, acc[h]);
       } else if (a.gate_mode == 1) {
-        const float s = gumbel_gate(ET[h], n[h], a.T);
+        const float s = gumbel_gate(ET[h], n.v[h], a.T);
         acc[h] = fmaf(g * xv, s * (1.f - s) * Q[h], acc[h]);
       } else {
         const float om = 1.f - p[h];
         const float sgn = om > 0.f ? 1.f : (om < 0.f ? -1.f : 0.f);
-        acc[h] = fmaf(g, xv + n[h].a * fabsf(om) - p[h] * n[h].a * sgn, acc[h]);
+        acc[h] = fmaf(g, xv + n.v[h] * fabsf(om) - p[h] * n.v[h] * sgn, acc[h]);
       }
     }
   }
-  a.ws[(int64_t)blockIdx.y * dd + i * d + j0] = acc[0];
-  if (two) a.ws[(int64_t)blockIdx.y * dd + i * d + j0 + 1] = acc[1];
+#pragma unroll
+  for (int h = 0; h < 4; ++h)
+    if (h < nv) a.ws[(int64_t)blockIdx.y * dd + i * d + j0 + h] = acc[h];
 }
 
 // gA = (sum over the batch chunks, taken by the shared deterministic row-sum kernel) * dP/dA
@@ -170,35 +223,53 @@ __global__ void dag_gate_bwd_dA_k(const float* __restrict__ tab, const float* __
   gA[ij] = sums[ij] * tab[dd + ij];
 }
 
-// gx[b,j] = sum_i ge[b,i,j] * de/dx[b,i,j];  one thread per (b, column pair)
+// gx partial sums over a chunk of i (blockIdx.y):  out[chunk][b,j] = sum_{i in chunk} ge[b,i,j] * de/dx[b,i,j];  one thread
+// per (b, column quad).  (B * d / 4 threads alone are 77 workgroups at cfg4: the i loop is split to fill the chip; the
+// chunk partials are added by the deterministic row-sum kernel.)
 __global__ void dag_gate_bwd_dx_k(GateArgs a) {
-  const int64_t d = a.d, dd = d * d, dh = (d + 1) / 2, n = a.B * dh;
+  const int64_t d = a.d, dd = d * d, dq = (d + 3) / 4, n = a.B * dq;
+  const int64_t i0 = (int64_t)blockIdx.y * a.chunk, i1 = i0 + a.chunk < d ? i0 + a.chunk : d;
+  float* out = a.gx + (int64_t)blockIdx.y * a.B * d;
   for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x) {
-    const int64_t b = e / dh, jp = e - b * dh, j0 = 2 * jp;
-    const bool two = j0 + 1 < d;
-    float acc[2] = {0.f, 0.f};
-    for (int64_t i = 0; i < d; ++i) {
-      Noise nz[2];
-      if (a.gate_mode == 1) draw2(1, a.u1, a.u2, a.seed, a.offset, b * d + i, jp, d, nz);
+    const int64_t b = e / dq, jq = e - b * dq, j0 = 4 * jq;
+    const int nv = d - j0 < 4 ? (int)(d - j0) : 4;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    const bool vg = quad_aligned(a.ge, a.ld_e), vt = quad_aligned(a.tab, d);
+    for (int64_t i = i0; i < i1; ++i) {
+      Draw4 nz;
+      if (a.gate_mode == 1) nz = draw4(1, a.u1, a.u2, a.seed, a.offset, b * d + i, jq, d);
+      float g4[4], t4[4];
+      load4(a.ge + (b * d + i) * a.ld_e + j0, nv, vg, g4);
+      load4(a.tab + (a.gate_mode == 1 ? 2 * dd : 0) + i * d + j0, nv, vt, t4);   // ET (Gumbel) or the importance itself
 #pragma unroll
-      for (int h = 0; h < 2; ++h) {
-        if (h == 1 && !two) break;
-        const int64_t j = j0 + h;
-        float gate = a.tab[i * d + j];
-        if (a.gate_mode == 1) gate = gumbel_gate(a.tab[2 * dd + i * d + j], nz[h], a.T);
-        acc[h] = fmaf(a.ge[(b * d + i) * a.ld_e + j], gate, acc[h]);
+      for (int h = 0; h < 4; ++h) {
+        if (h >= nv) break;
+        const float gate = a.gate_mode == 1 ? gumbel_gate(t4[h], nz.v[h], a.T) : t4[h];
+        acc[h] = fmaf(g4[h], gate, acc[h]);
       }
     }
-    a.gx[b * d + j0] = acc[0];
-    if (two) a.gx[b * d + j0 + 1] = acc[1];
+#pragma unroll
+    for (int h = 0; h < 4; ++h)
+      if (h < nv) out[b * d + j0 + h] = acc[h];
   }
 }
 
+// chunks of the sample loop of the (i, quad)-threaded kernels: enough workgroups to fill the chip (16 per CU)
 inline int64_t bwd_chunks(int64_t B, int64_t d) {
-  const int64_t nblk = (d * d + kBlock - 1) / kBlock;
-  int64_t nc = 2048 / nblk;
-  if (nc < 1) nc = 1;
+  const int64_t nblk = (d * ((d + 3) / 4) + kBlock - 1) / kBlock;
+  int64_t nc = (4096 + nblk - 1) / nblk;
+  if (nc > 2048) nc = 2048;
   if (nc > B) nc = B;
+  if (nc < 1) nc = 1;
+  return nc;
+}
+
+// chunks of the i loop of the (b, quad)-threaded dx kernel
+inline int64_t dx_chunks(int64_t B, int64_t d) {
+  const int64_t nblk = (B * ((d + 3) / 4) + kBlock - 1) / kBlock;
+  int64_t nc = (4096 + nblk - 1) / nblk;
+  if (nc > d) nc = d;
+  if (nc > 64) nc = 64;
   if (nc < 1) nc = 1;
   return nc;
 }
@@ -344,15 +415,17 @@ int gnf_dag_gate_fwd(const float* x, const float* A, float* e, int64_t ld_e, int
   GateArgs a{};
   a.x = x; a.tab = ws; a.e = e; a.ld_e = ld_e; a.gate_mode = gate_mode; a.T = temperature; a.u1 = u1; a.u2 = u2;
   a.seed = seed; a.offset = offset; a.hot = hot; a.B = B; a.d = d;
-  const int64_t dh = (d + 1) / 2;                     // column pairs
-  const int bs = dh >= 256 ? 256 : (dh >= 128 ? 128 : 64);
-  hipLaunchKernelGGL(dag_gate_fwd_k, dim3((unsigned)(B * d), (unsigned)((dh + bs - 1) / bs)), dim3(bs), 0, s, a);
+  const int64_t nc = bwd_chunks(B, d);
+  a.chunk = (B + nc - 1) / nc;
+  const unsigned gxp = (unsigned)((d * ((d + 3) / 4) + kBlock - 1) / kBlock);
+  hipLaunchKernelGGL(dag_gate_fwd_k, dim3(gxp, (unsigned)nc), dim3(kBlock), 0, s, a);
   GNF_LAUNCH_CHECK();
   return 0;
 }
 
 int64_t gnf_dag_gate_bwd_ws_bytes(int64_t B, int64_t d) {
-  return (bwd_chunks(B, d) + 5) * d * d * (int64_t)sizeof(float);
+  // table [4 d^2] | dp chunk partials [nc d^2] | their sum [d^2] | dx chunk partials [nci B d]
+  return ((bwd_chunks(B, d) + 5) * d * d + dx_chunks(B, d) * B * d) * (int64_t)sizeof(float);
 }
 
 int gnf_dag_gate_bwd(const float* x, const float* A, const float* ge, int64_t ld_e, int imp_mode, int gate_mode,
@@ -373,7 +446,7 @@ int gnf_dag_gate_bwd(const float* x, const float* A, const float* ge, int64_t ld
     const int64_t nc = bwd_chunks(B, d);
     a.chunk = B > 0 ? (B + nc - 1) / nc : 1;
     const unsigned gxd = (unsigned)((d * d + kBlock - 1) / kBlock);
-    const unsigned gxp = (unsigned)((d * ((d + 1) / 2) + kBlock - 1) / kBlock);
+    const unsigned gxp = (unsigned)((d * ((d + 3) / 4) + kBlock - 1) / kBlock);
     hipLaunchKernelGGL(dag_gate_bwd_dp_k, dim3(gxp, (unsigned)nc), dim3(kBlock), 0, s, a);
     GNF_LAUNCH_CHECK();
     // second stage: a small-d / large-B call (POWER: d = 6, B = 10000) has 2048 chunk rows of only 36 columns; one thread
@@ -388,8 +461,16 @@ int gnf_dag_gate_bwd(const float* x, const float* A, const float* ge, int64_t ld
     GNF_LAUNCH_CHECK();
   }
   if (gx && B > 0) {
-    hipLaunchKernelGGL(dag_gate_bwd_dx_k, dim3(grid_1d(B * ((d + 1) / 2))), dim3(kBlock), 0, s, a);
+    const int64_t nci = dx_chunks(B, d);
+    a.chunk = (d + nci - 1) / nci;
+    float* part = ws + (bwd_chunks(B, d) + 5) * d * d;
+    a.gx = nci > 1 ? part : gx;                            // a single chunk writes gx directly
+    hipLaunchKernelGGL(dag_gate_bwd_dx_k, dim3(grid_1d(B * ((d + 3) / 4)), (unsigned)nci), dim3(kBlock), 0, s, a);
     GNF_LAUNCH_CHECK();
+    if (nci > 1) {
+      rc = gnf_rowsum_launch(part, gx, nci, B * d, 0, s);
+      if (rc) return rc;
+    }
   }
   return 0;
 }

@@ -217,6 +217,29 @@ def test_dag_gate_philox_statistics_and_determinism():
     assert abs(fd.item() - gA[3, 5].item()) < 2e-2 * max(1., abs(fd.item()))
 
 
+def test_dag_gate_single_uniform_sampler_has_the_reference_law():
+    """The Philox path draws ONE uniform V per element and uses exp(g2 - g1) = V / (1 - V): E1 / (E1 + E2) of two
+    independent Exp(1) variates is exactly uniform, so this is the law of the reference's two-uniform Gumbel ratio
+    (DAGConditioner.py:99-103).  Checked empirically against the kernel fed with torch.rand u1, u2 (the parity path)
+    at several importances and temperatures: the empirical CDFs of the gate agree within sampling error."""
+    from gnf_hip import ops
+    torch.manual_seed(3)
+    B, d = 512, 16
+    x = torch.ones(B, d, device=DEV)
+    A = torch.linspace(.05, 1.6, d * d, device=DEV).view(d, d).contiguous()
+    for T in (1., .5, .7):
+        fast = torch.cat([ops.DagGateFn.apply(x, A, ops.IMP_SOFT, ops.GATE_GUMBEL, 0., T, False, None, None, 4242, k)
+                          .view(B, d, d) for k in range(8)])                       # 4096 draws per entry
+        ref = torch.cat([ops.DagGateFn.apply(x, A, ops.IMP_SOFT, ops.GATE_GUMBEL, 0., T, False,
+                                             torch.rand(B, d, d, device=DEV), torch.rand(B, d, d, device=DEV), 0, 0)
+                         .view(B, d, d) for _ in range(8)])
+        for thr in (.05, .25, .5, .75, .95):
+            cf, cr = (fast < thr).float().mean(0), (ref < thr).float().mean(0)
+            # two binomial proportions of 4096 draws each: sigma of the difference <= sqrt(2 * .25 / 4096) = .011
+            assert (cf - cr).abs().max() < .055, (T, thr, (cf - cr).abs().max().item())
+        assert (fast.mean(0) - ref.mean(0)).abs().max() < .03
+
+
 def test_mnistcnn_golden():
     from models.MLP import MNISTCNN
     g = load_golden("mnistcnn")
