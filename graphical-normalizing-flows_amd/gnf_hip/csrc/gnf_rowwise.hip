@@ -139,6 +139,174 @@ __global__ void affine_bwd_k(const float* __restrict__ x, const float* __restric
   }
 }
 
+// ---- "flat" variants for short rows (d <= 64) in the contiguous [B,d,2] layout, the shape of the tabular configurations
+// (cfg5: d = 63).  A wavefront owns RW consecutive rows with (RW d) % 4 == 0 (RW = 4 / gcd(d, 4)), i.e. a 16-B aligned
+// span of RW d <= 256 floats: every lane moves ONE float4 of x / z and TWO of h (the row-per-lane-group kernels above
+// move 4 B and 8 B per lane and reach 46-48 % of the HBM peak where a float4 copy reaches 70 %); U spans are in flight
+// per wavefront.  The row sums of the log-Jacobian are RW masked wave reductions in a fixed order (deterministic).
+typedef float f32x4r __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, GNF_WAVE);
+  return v;
+}
+
+template <int RW, int U>
+__global__ __launch_bounds__(kBlock) void affine_fwd_flat_k(const float* __restrict__ x, const float* __restrict__ h,
+                                                            float* __restrict__ z, float* __restrict__ jac,
+                                                            float* __restrict__ logdet, int64_t B, int d) {
+  const int lane = threadIdx.x & 63;
+  const int64_t gw = (int64_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6), nw = (int64_t)gridDim.x * (kBlock / 64);
+  const int64_t nspan = (B + RW - 1) / RW;
+  int rid[4];                                        // row (inside the span) of this lane's four elements
+#pragma unroll
+  for (int c = 0; c < 4; ++c) rid[c] = (4 * lane + c) / d;
+  for (int64_t sp0 = gw * U; sp0 < nspan; sp0 += nw * U) {
+    f32x4r xv[U], ha[U], hb[U];
+    int ne[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int64_t sp = sp0 + u, row0 = sp * RW;
+      const int nrows = sp < nspan ? (int)(B - row0 < RW ? B - row0 : RW) : 0;
+      ne[u] = nrows * d;
+      const int64_t base = row0 * d + 4 * lane;
+      if (4 * lane + 3 < ne[u]) {
+        xv[u] = __builtin_nontemporal_load(reinterpret_cast<const f32x4r*>(x + base));
+        ha[u] = __builtin_nontemporal_load(reinterpret_cast<const f32x4r*>(h + 2 * base));
+        hb[u] = __builtin_nontemporal_load(reinterpret_cast<const f32x4r*>(h + 2 * base + 4));
+      } else {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const bool ok = 4 * lane + c < ne[u];
+          xv[u][c] = ok ? x[base + c] : 0.f;
+          const float a0 = ok ? h[2 * (base + c)] : 0.f, a1 = ok ? h[2 * (base + c) + 1] : 0.f;
+          if (c < 2) { ha[u][2 * c] = a0; ha[u][2 * c + 1] = a1; } else { hb[u][2 * c - 4] = a0; hb[u][2 * c - 3] = a1; }
+        }
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      if (ne[u] == 0) continue;
+      const int64_t row0 = (sp0 + u) * RW, base = row0 * d + 4 * lane;
+      const float h0[4] = {ha[u][0], ha[u][2], hb[u][0], hb[u][2]}, h1[4] = {ha[u][1], ha[u][3], hb[u][1], hb[u][3]};
+      f32x4r zv, jv;
+      float ls[4];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const float mu = clampf(h0[c], -5.f, 5.f);
+        ls[c] = clampf(h1[c], -5.f, 2.f);
+        const float sg = expf(ls[c]);
+        zv[c] = fmaf(xv[u][c], sg, mu);
+        jv[c] = sg;
+        if (4 * lane + c >= ne[u]) ls[c] = 0.f;
+      }
+      if (4 * lane + 3 < ne[u]) {
+        __builtin_nontemporal_store(zv, reinterpret_cast<f32x4r*>(z + base));
+        if (jac) __builtin_nontemporal_store(jv, reinterpret_cast<f32x4r*>(jac + base));
+      } else {
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+          if (4 * lane + c < ne[u]) { z[base + c] = zv[c]; if (jac) jac[base + c] = jv[c]; }
+      }
+      if (logdet) {
+#pragma unroll
+        for (int rr = 0; rr < RW; ++rr) {
+          float sv = 0.f;
+#pragma unroll
+          for (int c = 0; c < 4; ++c) sv += rid[c] == rr ? ls[c] : 0.f;
+          sv = wave_sum(sv);
+          if (lane == 0 && row0 + rr < B) logdet[row0 + rr] = sv;
+        }
+      }
+    }
+  }
+}
+
+template <int RW, int U>
+__global__ __launch_bounds__(kBlock) void affine_bwd_flat_k(const float* __restrict__ x, const float* __restrict__ h,
+                                                            const float* __restrict__ gz, const float* __restrict__ gjac,
+                                                            const float* __restrict__ glogdet, float* __restrict__ gx,
+                                                            float* __restrict__ gh, int64_t B, int d) {
+  const int lane = threadIdx.x & 63;
+  const int64_t gw = (int64_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6), nw = (int64_t)gridDim.x * (kBlock / 64);
+  const int64_t nspan = (B + RW - 1) / RW;
+  int rid[4];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) rid[c] = (4 * lane + c) / d;
+  for (int64_t sp0 = gw * U; sp0 < nspan; sp0 += nw * U) {
+    f32x4r xv[U], ha[U], hb[U], gv[U], jv[U];
+    int ne[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int64_t sp = sp0 + u, row0 = sp * RW;
+      const int nrows = sp < nspan ? (int)(B - row0 < RW ? B - row0 : RW) : 0;
+      ne[u] = nrows * d;
+      const int64_t base = row0 * d + 4 * lane;
+      gv[u] = f32x4r{0.f, 0.f, 0.f, 0.f};
+      jv[u] = gv[u];
+      if (4 * lane + 3 < ne[u]) {
+        xv[u] = __builtin_nontemporal_load(reinterpret_cast<const f32x4r*>(x + base));
+        ha[u] = __builtin_nontemporal_load(reinterpret_cast<const f32x4r*>(h + 2 * base));
+        hb[u] = __builtin_nontemporal_load(reinterpret_cast<const f32x4r*>(h + 2 * base + 4));
+        if (gz) gv[u] = __builtin_nontemporal_load(reinterpret_cast<const f32x4r*>(gz + base));
+        if (gjac) jv[u] = __builtin_nontemporal_load(reinterpret_cast<const f32x4r*>(gjac + base));
+      } else {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const bool ok = 4 * lane + c < ne[u];
+          xv[u][c] = ok ? x[base + c] : 0.f;
+          const float a0 = ok ? h[2 * (base + c)] : 0.f, a1 = ok ? h[2 * (base + c) + 1] : 0.f;
+          if (c < 2) { ha[u][2 * c] = a0; ha[u][2 * c + 1] = a1; } else { hb[u][2 * c - 4] = a0; hb[u][2 * c - 3] = a1; }
+          if (ok && gz) gv[u][c] = gz[base + c];
+          if (ok && gjac) jv[u][c] = gjac[base + c];
+        }
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      if (ne[u] == 0) continue;
+      const int64_t row0 = (sp0 + u) * RW, base = row0 * d + 4 * lane;
+      const float h0[4] = {ha[u][0], ha[u][2], hb[u][0], hb[u][2]}, h1[4] = {ha[u][1], ha[u][3], hb[u][1], hb[u][3]};
+      f32x4r ox, oa, ob;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const bool ok = 4 * lane + c < ne[u];
+        const float gl = (glogdet && ok) ? glogdet[row0 + rid[c]] : 0.f;
+        // torch clamp backward passes the gradient where min <= v <= max (boundaries included)
+        const float m0 = (h0[c] >= -5.f && h0[c] <= 5.f) ? 1.f : 0.f;
+        const float m1 = (h1[c] >= -5.f && h1[c] <= 2.f) ? 1.f : 0.f;
+        const float sg = expf(clampf(h1[c], -5.f, 2.f));
+        ox[c] = gv[u][c] * sg;
+        const float o0 = gv[u][c] * m0, o1 = (fmaf(gv[u][c] * xv[u][c], sg, jv[u][c] * sg) + gl) * m1;
+        if (c < 2) { oa[2 * c] = o0; oa[2 * c + 1] = o1; } else { ob[2 * c - 4] = o0; ob[2 * c - 3] = o1; }
+      }
+      if (4 * lane + 3 < ne[u]) {
+        if (gx) __builtin_nontemporal_store(ox, reinterpret_cast<f32x4r*>(gx + base));
+        __builtin_nontemporal_store(oa, reinterpret_cast<f32x4r*>(gh + 2 * base));
+        __builtin_nontemporal_store(ob, reinterpret_cast<f32x4r*>(gh + 2 * base + 4));
+      } else {
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+          if (4 * lane + c < ne[u]) {
+            if (gx) gx[base + c] = ox[c];
+            gh[2 * (base + c)] = c < 2 ? oa[2 * c] : ob[2 * c - 4];
+            gh[2 * (base + c) + 1] = c < 2 ? oa[2 * c + 1] : ob[2 * c - 3];
+          }
+      }
+    }
+  }
+}
+
+// rows per wavefront span of the flat variants, 0 when they do not apply
+inline int affine_flat_rw(int64_t h_sb, int64_t h_sd, int64_t h_sc, int64_t B, int64_t d, const void* a, const void* b,
+                          const void* c) {
+  if (!(h_sc == 1 && h_sd == 2 && h_sb == 2 * d) || d > 64 || B * d < (1 << 18)) return 0;
+  if ((((uintptr_t)a | (uintptr_t)b | (uintptr_t)c) & 15) != 0) return 0;
+  const int rw = (d % 4 == 0) ? 1 : ((d % 2 == 0) ? 2 : 4);
+  return rw * d <= 256 ? rw : 0;
+}
+
 __global__ void affine_inv_k(const float* __restrict__ z, const float* __restrict__ h, int64_t h_sb, int64_t h_sd,
                              int64_t h_sc, float* __restrict__ x, int64_t B, int64_t d) {
   const int64_t n = B * d;
@@ -333,6 +501,19 @@ int gnf_affine_fwd(const float* x, float* h, int64_t h_sb, int64_t h_sd, int64_t
   if (!x || !h || !z || B < 0 || d <= 0) return GNF_EINVAL;
   if (B == 0) return 0;
   const int G = gnf_pow2_ge(d, 64);
+  if (const int rw = clamp_inplace ? 0 : affine_flat_rw(h_sb, h_sd, h_sc, B, d, x, h, z)) {
+    if (!jac || ((uintptr_t)jac & 15) == 0) {
+      const int64_t nspan = (B + rw - 1) / rw;
+      int64_t grid = (nspan + 2 * (kBlock / 64) - 1) / (2 * (kBlock / 64));
+      if (grid > 256 * 16) grid = 256 * 16;
+      hipStream_t s = (hipStream_t)stream;
+      if (rw == 4) hipLaunchKernelGGL((affine_fwd_flat_k<4, 2>), dim3((unsigned)grid), dim3(kBlock), 0, s, x, h, z, jac, logdet, B, (int)d);
+      else if (rw == 2) hipLaunchKernelGGL((affine_fwd_flat_k<2, 2>), dim3((unsigned)grid), dim3(kBlock), 0, s, x, h, z, jac, logdet, B, (int)d);
+      else hipLaunchKernelGGL((affine_fwd_flat_k<1, 2>), dim3((unsigned)grid), dim3(kBlock), 0, s, x, h, z, jac, logdet, B, (int)d);
+      GNF_LAUNCH_CHECK();
+      return 0;
+    }
+  }
   if (B * d >= (1 << 20)) GNF_DISPATCH_GR(G, 4, affine_fwd_k, B, x, h, h_sb, h_sd, h_sc, z, jac, logdet, clamp_inplace, B, d);
   else GNF_DISPATCH_GR(G, 1, affine_fwd_k, B, x, h, h_sb, h_sd, h_sc, z, jac, logdet, clamp_inplace, B, d);
   GNF_LAUNCH_CHECK();
@@ -345,6 +526,19 @@ int gnf_affine_bwd(const float* x, const float* h, int64_t h_sb, int64_t h_sd, i
   if (!x || !h || !gh || B < 0 || d <= 0) return GNF_EINVAL;
   if (B == 0) return 0;
   const int G = gnf_pow2_ge(d, 64);
+  if (const int rw = (g_sc == 1 && g_sd == 2 && g_sb == 2 * d) ? affine_flat_rw(h_sb, h_sd, h_sc, B, d, x, h, gh) : 0) {
+    if ((((uintptr_t)gz | (uintptr_t)gjac | (uintptr_t)gx) & 15) == 0) {
+      const int64_t nspan = (B + rw - 1) / rw;
+      int64_t grid = (nspan + 2 * (kBlock / 64) - 1) / (2 * (kBlock / 64));
+      if (grid > 256 * 16) grid = 256 * 16;
+      hipStream_t s = (hipStream_t)stream;
+      if (rw == 4) hipLaunchKernelGGL((affine_bwd_flat_k<4, 2>), dim3((unsigned)grid), dim3(kBlock), 0, s, x, h, gz, gjac, glogdet, gx, gh, B, (int)d);
+      else if (rw == 2) hipLaunchKernelGGL((affine_bwd_flat_k<2, 2>), dim3((unsigned)grid), dim3(kBlock), 0, s, x, h, gz, gjac, glogdet, gx, gh, B, (int)d);
+      else hipLaunchKernelGGL((affine_bwd_flat_k<1, 2>), dim3((unsigned)grid), dim3(kBlock), 0, s, x, h, gz, gjac, glogdet, gx, gh, B, (int)d);
+      GNF_LAUNCH_CHECK();
+      return 0;
+    }
+  }
   if (B * d >= (1 << 20)) GNF_DISPATCH_GR(G, 4, affine_bwd_k, B, x, h, h_sb, h_sd, h_sc, gz, gjac, glogdet, gx, gh, g_sb, g_sd, g_sc, B, d);
   else GNF_DISPATCH_GR(G, 1, affine_bwd_k, B, x, h, h_sb, h_sd, h_sc, gz, gjac, glogdet, gx, gh, g_sb, g_sd, g_sc, B, d);
   GNF_LAUNCH_CHECK();

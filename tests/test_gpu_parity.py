@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import load_golden, params_of, linear_layers, rel_err
+from conftest import load_golden, params_of, linear_layers, rel_err, assert_close
 from oracle import gnf_oracle as O
 
 pytestmark = pytest.mark.gpu
@@ -84,6 +84,33 @@ def test_affine_strided_h_and_large():
     zr, jr = O.affine_forward(xr, hr.view(B, 2, d).permute(0, 2, 1))
     (zr.sum() + torch.log(jr).sum()).backward()
     assert rel_err(xg.grad.cpu(), xr.grad) < TOL and rel_err(hg.grad.cpu(), hr.grad) < TOL
+
+
+@pytest.mark.parametrize("B,d", [(4163, 63), (20001, 63), (4500, 62), (4100, 64), (50003, 6), (70001, 5), (300001, 1)])
+def test_affine_flat_vectorised_path_vs_oracle(B, d):
+    """short rows in the contiguous [B,d,2] layout (tabular configurations, cfg5: d = 63) take the span-per-wavefront
+    kernels with 16-B accesses: every row count modulo the span, odd / even / multiple-of-4 widths, ragged last span"""
+    from gnf_hip import ops
+    assert B * d >= 1 << 18
+    torch.manual_seed(B + d)
+    x, h = torch.randn(B, d), torch.randn(B, d, 2) * 3
+    z0, j0 = O.affine_forward(x, h)
+    xg, hg = req(x), req(h)
+    z, jac, ld = ops.AffineFn.apply(xg, hg)
+    assert rel_err(z.cpu(), z0) < TOL and rel_err(jac.cpu(), j0) < TOL
+    assert rel_err(ld.cpu(), torch.log(j0).sum(1)) < TOL
+    assert_close(ld, torch.log(j0).sum(1), atol=2e-6 * d ** .5, what="logdet")
+    gz, gj, gl = torch.randn(B, d), torch.randn(B, d), torch.randn(B)
+    ((z * cu(gz)).sum() + (jac * cu(gj)).sum() + (ld * cu(gl)).sum()).backward()
+    xr, hr = x.clone().requires_grad_(True), h.clone().requires_grad_(True)
+    zr, jr = O.affine_forward(xr, hr)
+    ((zr * gz).sum() + (jr * gj).sum() + (torch.log(jr).sum(1) * gl).sum()).backward()
+    assert rel_err(xg.grad.cpu(), xr.grad) < TOL and rel_err(hg.grad.cpu(), hr.grad) < TOL
+    # the fused step's variant (no jac output) and determinism
+    with torch.no_grad():
+        z2, _, ld2 = ops.AffineFn.apply(cu(x), cu(h), False, False)
+        z3, _, ld3 = ops.AffineFn.apply(cu(x), cu(h), False, False)
+    assert torch.equal(z2, z.detach()) and torch.equal(ld2, ld3) and rel_err(ld2.cpu(), ld.detach().cpu()) < 1e-6
 
 
 def test_normal_log_density_and_logsum():
