@@ -292,8 +292,10 @@ def main():
             "gnf_mnistcnn_conv_bwd": ("cnn_bwd_wino_k (conv backward: dW2 and da1 as Winograd F(2x2,3x3) on MFMA, dW1, de; conv1 recomputed)",
                                       2. * (2 * CONV2 + 2 * CONV1) * n_elem),
             "gnf_mnistcnn_conv_fwd": ("cnn_fwd_wino_k (conv1+ReLU, conv2 as Winograd F(2x2,3x3) on MFMA, maxpool)", 2. * (CONV1 + CONV2) * n_elem),
-            "gnf_monotonic_fwd": ("mono_fwd_k<HT=4> (Clenshaw-Curtis quadrature)", 2. * macs * (S_NODES + 2) * n_elem),
-            "gnf_monotonic_bwd": ("mono_bwd_k<4,3> (weight gradients accumulated in-kernel) + unpack", 4. * macs * (S_NODES + 2) * n_elem),
+            "gnf_monotonic_fwd": ("mono_fwd_x_k<3,2> (Clenshaw-Curtis quadrature; 3 tiles on MFMA, units 48-49 peeled onto the VALU)",
+                                  2. * macs * (S_NODES + 2) * n_elem),
+            "gnf_monotonic_bwd": ("mono_bwd_pair_x_k<3,3,2> (two nodes per pass, weight gradients in-kernel) + unpack",
+                                  4. * macs * (S_NODES + 2) * n_elem),
         }
         kern = {}
         for k, (label, fl) in work.items():
@@ -323,20 +325,27 @@ def main():
             "ops_ms": {k: round(v, 4) for k, v in prof.items()},
         }
         # HBM bytes per launch of the dominant kernel: PMC counters cannot be read from inside this process, so the
-        # figure is the one rocprofv3 measured for the same kernel at the same per-GPU size (profiles/r01_conv_hbm.json:
+        # figure is the one rocprofv3 measured for the same kernel at the same per-GPU size (profiles/r02_conv_hbm.json:
         # 2 x FETCH_SIZE + WRITE_SIZE, separate --pmc passes), next to the algorithmic bytes; null for any other size
-        hbm = {"gnf_mnistcnn_conv_bwd": (1421.7e6, n_elem * (784 * 4 + 2304 * 5 + 784 * 4)),
-               "gnf_mnistcnn_conv_fwd": (1149.1e6, n_elem * (784 * 4 + 2304 * 5))}
+        hbm = {"gnf_mnistcnn_conv_bwd": (1421.5e6, n_elem * (784 * 4 + 2304 * 5 + 784 * 4)),
+               "gnf_mnistcnn_conv_fwd": (1149.3e6, n_elem * (784 * 4 + 2304 * 5))}
         if dom in hbm and n_elem == 78400:
             out["roofline"]["traffic"] = hbm[dom][0]
             out["roofline"]["traffic_algorithmic"] = float(hbm[dom][1])
-            out["roofline"]["traffic_source"] = "profiles/r01_conv_hbm.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE)"
+            out["roofline"]["traffic_source"] = "profiles/r02_conv_hbm.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE)"
         # MFMA issue slots used by the dominant kernel: v_mfma_f32_16x16x4_f32 issued per image (Winograd form, incl.
         # padding and the conv1 recompute) x 2048 flop / time / peak -- the head-room left, see DESIGN.md section 4
         issued = {"gnf_mnistcnn_conv_bwd": 11 * 12 + 36 * 16 + 11 * 64 + 11 * 16, "gnf_mnistcnn_conv_fwd": 129 + 9 * 64}
         if dom in issued:
             out["roofline"]["mfma_issue_frac"] = round(issued[dom] * 2048. * n_elem / (prof[dom] * 1e-3) / 1e12
                                                        / PEAK_F32_TFLOPS, 4)
+            # f32 MFMA and the other VALU instructions share one ALU per SIMD on gfx950 (tools/mfma_pipe.hip, valu_cost.hip:
+            # 32.5 cycles per v_mfma_f32_16x16x4_f32 + ~3 per VALU instruction, additive at 2, 3 and 4 wavefronts per SIMD),
+            # so with V other VALU instructions per MFMA the issue fraction cannot exceed 32.5 / (32.5 + 3 V);
+            # V from profiles/r02_cnn_pmc.json (SQ_INSTS_VALU - SQ_INSTS_MFMA) / SQ_INSTS_MFMA
+            v_per_mfma = {"gnf_mnistcnn_conv_bwd": 4.64, "gnf_mnistcnn_conv_fwd": 3.77}[dom]
+            out["roofline"]["valu_per_mfma"] = v_per_mfma
+            out["roofline"]["issue_frac_ceiling_shared_alu"] = round(32.5 / (32.5 + 3. * v_per_mfma), 3)
         out["secondary"] = {"fwd_bwd_only_samples_per_s": round(B_PER_GPU * world / t_fb, 1) if t_fb else None,
                             "full_step_S_mix_20_29_samples_per_s": round(B_PER_GPU * world / t_mix, 1) if t_mix else None,
                             "full_step_frozen_deterministic_gate_samples_per_s":
