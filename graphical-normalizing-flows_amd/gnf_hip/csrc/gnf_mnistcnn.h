@@ -11,7 +11,7 @@ constexpr int IMG = 28, C1 = 26, C2 = 24, PO = 12, NCH = 16;
 constexpr int ROWE = 36, ESZ = IMG * ROWE;            // padded input image
 constexpr int ROW = 40, CH = C1 * ROW;                // conv1 activations: [16][26][40], CH = 1040 == 16 mod 32
 constexpr int ROWD = 40, CHD = 28 * ROWD + 16;        // dY2 with a 2-wide zero border: [16][28][40], CHD = 1136 == 16 mod 32
-constexpr int CS = 688;                               // per-tap planes T: [9][688] flat 26x26 positions
+constexpr int CS = 676;                               // per-tap planes T: [9][26 x 26] flat positions
 constexpr int NPOOL = NCH * PO * PO;                  // 2304
 constexpr int FWD_WAVES = 8, BWD_WAVES = 8;
 constexpr int PROW = NCH * 144 + NCH * 16 + NCH;      // per-wave gradient partial row: dW2 | dW1+db1 | db2

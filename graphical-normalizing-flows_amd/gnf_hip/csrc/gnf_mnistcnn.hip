@@ -36,9 +36,13 @@ constexpr int USZ = 16 * 4 * 64;                     // U' as [xi_y][g][lane][xi
 //     the tile-row wrap TRD - 24 == 2 (mod 64), the two channels of a pair CHDW == 32 (mod 64) apart; channel pairs
 //     PSD == 2 (mod 64) apart keep the 16-channel Z read of dW2 conflict-free too.
 constexpr int ROWB = 28, CHB = 730;
+#ifdef GNF_DS_WIDE      // round-1 layout: one channel per [14][90] block, 84 KB
 constexpr int TRD = 90, ROD = 44, CHDW = 1312, PSD = 2 * CHDW + 2, DSZW = (NCH / 2) * PSD;
+#else                   // the two channels of a pair share a tile row: [row 2t | row 2t+1 | 40 free | row 2t | row 2t+1 | 2], 70 KB
+constexpr int TRD = 154, ROD = 28, CHDW = 96, PSD = 14 * TRD + 22, DSZW = (NCH / 2) * PSD;
+#endif
 static_assert(CHB >= C1 * ROWB && (CHB % 4) == 2, "a1 channel stride");
-static_assert((TRD - 24) % 64 == 2 && CHDW % 64 == 32 && PSD % 64 == 2 && 13 * TRD + ROD + 28 <= CHDW, "dY2 layout");
+static_assert((TRD - 24) % 64 == 2 && CHDW % 64 == 32 && PSD % 64 == 2 && 14 * TRD <= PSD + 2 && ROD >= 28, "dY2 layout");
 __device__ __forceinline__ int dofs(int c) { return (c >> 1) * PSD + (c & 1) * CHDW; }
 
 __global__ __launch_bounds__(64 * BWD_WAVES) void cnn_bwd_wino_k(CnnArgs a) {
@@ -48,15 +52,20 @@ __global__ __launch_bounds__(64 * BWD_WAVES) void cnn_bwd_wino_k(CnnArgs a) {
 #endif
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* e_s = smem;
-  float* a1_s = smem + ESZ;                 // conv1 activations; reused for the per-tap planes T after dW2
+  float* a1_s = smem + ESZ;                 // conv1 activations
   float* d_s = a1_s + NCH * CHB;            // dY2 with a 2-wide zero border, tile-row layout
+#ifdef GNF_BWD_T_ALIAS
   float* u_s = d_s + DSZW;                  // U' as [g][xi_y][lane][xi_x]
-  float* T_s = a1_s;
+  float* T_s = a1_s;                        // (round 1) per-tap planes in the a1 region: a barrier between dW2 and da1
+#else
+  float* T_s = d_s + DSZW;                  // per-tap planes T [9][26 x 26], their own region: dW2 and da1 share one phase
+  float* u_s = T_s + 9 * CS;                // U' as [g][xi_y][lane][xi_x]
+#endif
   const int tid = threadIdx.x, lane = tid & 63, q = lane >> 4, j = lane & 15;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   constexpr int NW = BWD_WAVES, NT = 64 * BWD_WAVES;
   static_assert((ESZ % 4 == 0) && ((NCH * CHB) % 4 == 0) && (DSZW % 4 == 0), "u_s must be 16-B aligned");
-  static_assert(10 * CS <= NCH * CHB, "T planes (9 taps + a dump plane) alias the a1 region");
+  static_assert((9 * CS) % 4 == 0 && 9 * CS <= NCH * CHB, "T planes");
 
   float w1f[3];
   int off1[3];
@@ -164,7 +173,8 @@ __global__ __launch_bounds__(64 * BWD_WAVES) void cnn_bwd_wino_k(CnnArgs a) {
     __syncthreads();
     prefetch(img + gridDim.x);
     TSTAMP(0);
-    // ---- P1: conv1 + ReLU in the 2x2-tile layout: group grp = wave + 8k, 4 sub-positions = 4 MFMA chains
+#ifdef GNF_BWD_T_ALIAS
+    // ---- P1 (round 1): conv1 + ReLU in the 2x2-tile layout of da1 so that the ReLU gate bits stay in a register
     unsigned gate = 0u;
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
@@ -185,8 +195,6 @@ __global__ __launch_bounds__(64 * BWD_WAVES) void cnn_bwd_wino_k(CnnArgs a) {
         for (int s = 0; s < 3; ++s)
 #pragma unroll
           for (int p = 0; p < 4; ++p) acc[p] = mfma(w1f[s], ev[p][s], acc[p]);
-        // ReLU + gate bits.  Bit of value (k, p, r) ends up at 31 - (16k + 4p + r): each value shifts the sign of
-        // 0 - relu(acc) in from the right (two full-rate ops per value instead of compare + select + or)
         float a1v[4][4];
 #pragma unroll
         for (int p = 0; p < 4; ++p)
@@ -208,13 +216,53 @@ __global__ __launch_bounds__(64 * BWD_WAVES) void cnn_bwd_wino_k(CnnArgs a) {
         gate <<= 16;
       }
     }
+#else
+    // ---- P1: conv1 + ReLU, 43 tiles of 16 consecutive positions of the 26 x 26 grid dealt over the 8 wavefronts
+    //      (6 / 5 each).  a1 stays intact until the end of the image (the T planes have their own region), so da1 reads
+    //      its ReLU gates back from a1 itself and this phase no longer has to follow da1's 11-groups-over-8 layout
+    {
+      constexpr int NTL = (43 + NW - 1) / NW;
+      int po[NTL];
+      f32x4 acc[NTL];
+      float ev[NTL][3];
+#pragma unroll
+      for (int k = 0; k < NTL; ++k) {
+        const int pos = 16 * (wave + NW * k) + j;
+        const int pc = pos < C1 * C1 ? pos : 0;
+        const int y = pc / C1, x = pc - y * C1;
+        po[k] = pos < C1 * C1 ? y * ROWB + x : -1;
+#pragma unroll
+        for (int s = 0; s < 3; ++s) ev[k][s] = e_s[y * ROWE + x + off1[s]];
+        acc[k] = b1v;
+      }
+#pragma unroll
+      for (int s = 0; s < 3; ++s)
+#pragma unroll
+        for (int k = 0; k < NTL; ++k) acc[k] = mfma(w1f[s], ev[k][s], acc[k]);
+#pragma unroll
+      for (int k = 0; k < NTL; ++k)
+        if (po[k] >= 0) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) a1_s[(4 * q + r) * CHB + po[k]] = fmaxf(acc[k][r], 0.f);
+        }
+    }
+#endif
     __syncthreads();
     TSTAMP(1);
     // ---- P3: dU_xi[o][c] += sum_tiles Z_xi[o][tile] V_xi[c][tile]; K-step s = 4 tiles; this wavefront's xi_y half.
     //      Z = A dY A^T from the 2x2 window of dY2 in LDS (A = [[1,0],[1,1],[1,-1],[0,-1]]); V = B^T d B needs the
     //      patch rows hy..hy+2 only: xi_y 0,1 = d0-d2, d1+d2;  xi_y 2,3 = d2-d1, d1-d3
+    // K-steps of this wavefront.  With dW2 and da1 in ONE barrier interval the wavefronts that own two da1 groups
+    // (0-2) take fewer dW2 steps: per SIMD 360 / 360 / 360 / 376 MFMAs instead of (72 + 72) + (240 | 160)
+#ifdef GNF_BWD_T_ALIAS
+    const int s_first = wave & 3, s_step = 4, s_last = 36;
+#else
+    const int s_step = 1;
+    const int s_first = hy == 0 ? (wave < 3 ? 6 * wave : 18) : 9 * (wave - 4);
+    const int s_last = hy == 0 ? (wave < 3 ? 6 * wave + 6 : 36) : 9 * (wave - 4) + 9;
+#endif
 #pragma nounroll
-    for (int s = wave & 3; s < 36; s += 4) {
+    for (int s = s_first; s < s_last; s += s_step) {
       const int T = 4 * s + q, ty = T / 12, tx = T - 12 * ty;
       const float* p = a1_s + j * CHB + (2 * ty + hy) * ROWB + 2 * tx;
       const float* pz = d_s + dofs(j) + (ty + 1) * TRD + 2 * tx + 2;
@@ -250,7 +298,9 @@ __global__ __launch_bounds__(64 * BWD_WAVES) void cnn_bwd_wino_k(CnnArgs a) {
       for (int xi = 0; xi < 8; ++xi) dU[xi] = mfma(zz[xi], vv[xi], dU[xi]);
       __builtin_amdgcn_sched_barrier(0);
     }
+#ifdef GNF_BWD_T_ALIAS
     __syncthreads();                                           // a1 as dW2 operand is done: region becomes T
+#endif
     TSTAMP(2);
     // ---- P4: dpre1 = conv2^T(dY2) * gate on 2x2 tiles: per 4 input channels (g) 16 operands, then 16 MFMAs
 #pragma nounroll
@@ -296,12 +346,22 @@ __global__ __launch_bounds__(64 * BWD_WAVES) void cnn_bwd_wino_k(CnnArgs a) {
           }
           const float y00 = s0[0] + s0[1] + s0[2], y01 = s0[1] - s0[2] - s0[3];
           const float y10 = s1[0] + s1[1] + s1[2], y11 = s1[1] - s1[2] - s1[3];
+#ifdef GNF_BWD_T_ALIAS
           // gate bit -> all-ones / all-zeros mask (v_bfe_i32) -> and: two full-rate ops per value
           const int b0 = 31 - (16 * k + r);
           dp[0][r] = __int_as_float(__float_as_int(y00) & __builtin_amdgcn_sbfe((int)gate, b0, 1));
           dp[1][r] = __int_as_float(__float_as_int(y01) & __builtin_amdgcn_sbfe((int)gate, b0 - 4, 1));
           dp[2][r] = __int_as_float(__float_as_int(y10) & __builtin_amdgcn_sbfe((int)gate, b0 - 8, 1));
           dp[3][r] = __int_as_float(__float_as_int(y11) & __builtin_amdgcn_sbfe((int)gate, b0 - 12, 1));
+#else
+          // ReLU gate = (a1 > 0), read back from the a1 image (two ds_read_b64 per channel: the tile's two rows)
+          const float* pa = a1_s + (4 * q + r) * CHB + 2 * ty * ROWB + 2 * tx;
+          const float2 g0 = *reinterpret_cast<const float2*>(pa), g1 = *reinterpret_cast<const float2*>(pa + ROWB);
+          dp[0][r] = (ok && g0.x > 0.f) ? y00 : 0.f;
+          dp[1][r] = (ok && g0.y > 0.f) ? y01 : 0.f;
+          dp[2][r] = (ok && g1.x > 0.f) ? y10 : 0.f;
+          dp[3][r] = (ok && g1.y > 0.f) ? y11 : 0.f;
+#endif
         }
         TSTAMP(5);                                              // P4b: output transform + gate
         // dW1 / db1 partials against the 4x4 image patch of this tile
@@ -363,11 +423,11 @@ __global__ __launch_bounds__(64 * BWD_WAVES) void cnn_bwd_wino_k(CnnArgs a) {
         {
           const int pos0 = 2 * ty * C1 + 2 * tx;
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const int plane = (ok && 4 * q + r < 9) ? 4 * q + r : 9;
-            float* tp = T_s + plane * CS + pos0;
-            tp[0] = tq[0][r]; tp[1] = tq[1][r]; tp[C1] = tq[2][r]; tp[C1 + 1] = tq[3][r];
-          }
+          for (int r = 0; r < 4; ++r)
+            if (ok && 4 * q + r < 9) {                           // taps 9..15 of the MFMA tile and idle lanes: nothing to store
+              float* tp = T_s + (4 * q + r) * CS + pos0;
+              tp[0] = tq[0][r]; tp[1] = tq[1][r]; tp[C1] = tq[2][r]; tp[C1 + 1] = tq[3][r];
+            }
         }
       }
     }
@@ -446,7 +506,12 @@ __global__ void cnn_unpack_k(const float* __restrict__ vec, float* gW1, float* g
   } else gb2[n - NCH * 144 - NCH * 16] = s;
 }
 
+#ifdef GNF_BWD_T_ALIAS
 constexpr size_t kBwdWinoLds = (size_t)(ESZ + NCH * CHB + DSZW + USZ) * sizeof(float);
+#else
+constexpr size_t kBwdWinoLds = (size_t)(ESZ + NCH * CHB + DSZW + 9 * CS + USZ) * sizeof(float);
+static_assert(kBwdWinoLds <= 160 * 1024, "conv backward LDS image");
+#endif
 // one 8-wave workgroup per CU: at its 256 VGPRs a second one is not admitted
 constexpr unsigned kBwdGrid = 256;
 
