@@ -346,8 +346,11 @@ def test_flow_golden(name):
     x = req(g["x"])
     z, ld = flow(x)
     assert rel_err(z.cpu(), g["z"]) < TOL and rel_err(ld.cpu(), g["logdet"]) < TOL
+    assert_close(z, g["z"], what="z")                      # element-wise: |a-b| <= 1e-6 + 1e-5 |b|
+    assert_close(ld, g["logdet"], what="logdet")
     loss = flow.loss(z, ld)
     assert rel_err(loss.detach().cpu(), g["loss"]) < TOL
+    assert_close(loss, g["loss"], what="loss")
     loss.backward()
     assert rel_err(x.grad.cpu(), g["gx"]) < GTOL
     grads_match(flow, g)
@@ -389,6 +392,8 @@ def test_mnist_affine_dag_flow_golden():
     cond.gate_noise = (cu(u1), cu(u2))
     z, ld = flow(cu(g["x"]))
     assert rel_err(z.cpu(), g["z"]) < TOL and rel_err(ld.cpu(), g["logdet"]) < TOL
+    assert_close(z, g["z"], atol=2e-6, what="z")
+    assert_close(ld, g["logdet"], what="logdet")
     loss = flow.loss(z, ld)
     assert rel_err(loss.detach().cpu(), g["loss"]) < TOL
     loss.backward()
@@ -535,6 +540,9 @@ def test_monotonic_forward_backward_vs_oracle(hidden, S, layout):
     z, jac = norm(xg, hgv)
     assert rel_err(z.cpu(), z0.detach()) < TOL, rel_err(z.cpu(), z0.detach())
     assert rel_err(jac.cpu(), j0.detach()) < TOL
+    assert_close(z, z0, atol=2e-6, what="z")               # element-wise (the integral sums ~20 terms of O(1))
+    assert_close(jac, j0, what="jac")
+    assert_close(torch.log(jac).sum(1), torch.log(j0.detach()).sum(1), what="logdet")
     ((z * cu(gz)).sum() + (torch.log(jac) * cu(gj)).sum()).backward()
     assert rel_err(xg.grad.cpu(), xr.grad) < GTOL
     assert rel_err(hg.grad.cpu(), hr.grad) < GTOL
