@@ -31,16 +31,14 @@ constexpr int USZ = 16 * 4 * 64;                     // U' as [xi_y][g][lane][xi
 // and both phases LDS-bound (measured: 4.4k of 11.5k and ~5k of 17k cycles per image).
 //  a1 [16][26][ROWB]: the dW2 gather reads 16 CHANNELS x one column pair per 16-lane group -> CHB*j mod 64 must be
 //     16 distinct even banks (CHB = 2 * odd).
-//  dY2 (zero-bordered 28x28) per channel as [14 tile rows][TRD] with the odd image row at +ROD: the da1 gather reads
-//     16 consecutive 2x2 TILES (13 per tile row) of 2 channels per 32-lane group -> consecutive tiles are +2 dwords,
-//     the tile-row wrap TRD - 24 == 2 (mod 64), the two channels of a pair CHDW == 32 (mod 64) apart; channel pairs
-//     PSD == 2 (mod 64) apart keep the 16-channel Z read of dW2 conflict-free too.
+//  dY2 (zero-bordered 28x28): the two channels of a PAIR share [14 tile rows][TRD = 154]: image rows 2t / 2t+1 of the even
+//     channel at +0 / +ROD, of the odd channel at +CHDW / +CHDW+ROD (40 floats of each tile row stay unused).  The da1
+//     gather reads 16 consecutive 2x2 TILES (13 per tile row) of 2 channels per 32-lane group -> consecutive tiles are
+//     +2 dwords, the tile-row wrap TRD - 24 == 2 (mod 64), the two channels of a pair CHDW == 32 (mod 64) apart;
+//     channel pairs PSD == 2 (mod 64) apart keep the 16-channel Z read of dW2 conflict-free too.  70 KB; round 1 gave
+//     every channel its own [14][90] block (84 KB, same timings) -- the 14 KB are what lets the T planes leave the a1 region.
 constexpr int ROWB = 28, CHB = 730;
-#ifdef GNF_DS_WIDE      // round-1 layout: one channel per [14][90] block, 84 KB
-constexpr int TRD = 90, ROD = 44, CHDW = 1312, PSD = 2 * CHDW + 2, DSZW = (NCH / 2) * PSD;
-#else                   // the two channels of a pair share a tile row: [row 2t | row 2t+1 | 40 free | row 2t | row 2t+1 | 2], 70 KB
 constexpr int TRD = 154, ROD = 28, CHDW = 96, PSD = 14 * TRD + 22, DSZW = (NCH / 2) * PSD;
-#endif
 static_assert(CHB >= C1 * ROWB && (CHB % 4) == 2, "a1 channel stride");
 static_assert((TRD - 24) % 64 == 2 && CHDW % 64 == 32 && PSD % 64 == 2 && 14 * TRD <= PSD + 2 && ROD >= 28, "dY2 layout");
 __device__ __forceinline__ int dofs(int c) { return (c >> 1) * PSD + (c & 1) * CHDW; }
@@ -54,13 +52,8 @@ __global__ __launch_bounds__(64 * BWD_WAVES) void cnn_bwd_wino_k(CnnArgs a) {
   float* e_s = smem;
   float* a1_s = smem + ESZ;                 // conv1 activations
   float* d_s = a1_s + NCH * CHB;            // dY2 with a 2-wide zero border, tile-row layout
-#ifdef GNF_BWD_T_ALIAS
-  float* u_s = d_s + DSZW;                  // U' as [g][xi_y][lane][xi_x]
-  float* T_s = a1_s;                        // (round 1) per-tap planes in the a1 region: a barrier between dW2 and da1
-#else
   float* T_s = d_s + DSZW;                  // per-tap planes T [9][26 x 26], their own region: dW2 and da1 share one phase
   float* u_s = T_s + 9 * CS;                // U' as [g][xi_y][lane][xi_x]
-#endif
   const int tid = threadIdx.x, lane = tid & 63, q = lane >> 4, j = lane & 15;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   constexpr int NW = BWD_WAVES, NT = 64 * BWD_WAVES;
@@ -173,50 +166,6 @@ __global__ __launch_bounds__(64 * BWD_WAVES) void cnn_bwd_wino_k(CnnArgs a) {
     __syncthreads();
     prefetch(img + gridDim.x);
     TSTAMP(0);
-#ifdef GNF_BWD_T_ALIAS
-    // ---- P1 (round 1): conv1 + ReLU in the 2x2-tile layout of da1 so that the ReLU gate bits stay in a register
-    unsigned gate = 0u;
-#pragma unroll
-    for (int k = 0; k < 2; ++k) {
-      const int grp = wave + NW * k;                            // wave-uniform
-      if (grp < NG4) {
-        const int t = 16 * grp + j;
-        const bool ok = t < 169;
-        const int tc = ok ? t : 0, ty = tc / 13, tx = tc - 13 * ty;
-        f32x4 acc[4];
-        float ev[4][3];
-#pragma unroll
-        for (int p = 0; p < 4; ++p) {
-#pragma unroll
-          for (int s = 0; s < 3; ++s) ev[p][s] = e_s[(2 * ty + (p >> 1)) * ROWE + 2 * tx + (p & 1) + off1[s]];
-          acc[p] = b1v;
-        }
-#pragma unroll
-        for (int s = 0; s < 3; ++s)
-#pragma unroll
-          for (int p = 0; p < 4; ++p) acc[p] = mfma(w1f[s], ev[p][s], acc[p]);
-        float a1v[4][4];
-#pragma unroll
-        for (int p = 0; p < 4; ++p)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            a1v[p][r] = fmaxf(acc[p][r], 0.f);
-            gate = __builtin_amdgcn_alignbit(gate, __float_as_uint(0.f - a1v[p][r]), 31);
-          }
-        if (ok) {
-#pragma unroll
-          for (int p = 0; p < 4; ++p)
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-              a1_s[(4 * q + r) * CHB + (2 * ty + (p >> 1)) * ROWB + 2 * tx + (p & 1)] = a1v[p][r];
-        } else {
-          gate &= 0xFFFF0000u;                                    // a lane without a tile gates everything off
-        }
-      } else {
-        gate <<= 16;
-      }
-    }
-#else
     // ---- P1: conv1 + ReLU, 43 tiles of 16 consecutive positions of the 26 x 26 grid dealt over the 8 wavefronts
     //      (6 / 5 each).  a1 stays intact until the end of the image (the T planes have their own region), so da1 reads
     //      its ReLU gates back from a1 itself and this phase no longer has to follow da1's 11-groups-over-8 layout
@@ -246,7 +195,6 @@ __global__ __launch_bounds__(64 * BWD_WAVES) void cnn_bwd_wino_k(CnnArgs a) {
           for (int r = 0; r < 4; ++r) a1_s[(4 * q + r) * CHB + po[k]] = fmaxf(acc[k][r], 0.f);
         }
     }
-#endif
     __syncthreads();
     TSTAMP(1);
     // ---- P3: dU_xi[o][c] += sum_tiles Z_xi[o][tile] V_xi[c][tile]; K-step s = 4 tiles; this wavefront's xi_y half.
@@ -254,13 +202,9 @@ __global__ __launch_bounds__(64 * BWD_WAVES) void cnn_bwd_wino_k(CnnArgs a) {
     //      patch rows hy..hy+2 only: xi_y 0,1 = d0-d2, d1+d2;  xi_y 2,3 = d2-d1, d1-d3
     // K-steps of this wavefront.  With dW2 and da1 in ONE barrier interval the wavefronts that own two da1 groups
     // (0-2) take fewer dW2 steps: per SIMD 360 / 360 / 360 / 376 MFMAs instead of (72 + 72) + (240 | 160)
-#ifdef GNF_BWD_T_ALIAS
-    const int s_first = wave & 3, s_step = 4, s_last = 36;
-#else
     const int s_step = 1;
     const int s_first = hy == 0 ? (wave < 3 ? 6 * wave : 18) : 9 * (wave - 4);
     const int s_last = hy == 0 ? (wave < 3 ? 6 * wave + 6 : 36) : 9 * (wave - 4) + 9;
-#endif
 #pragma nounroll
     for (int s = s_first; s < s_last; s += s_step) {
       const int T = 4 * s + q, ty = T / 12, tx = T - 12 * ty;
@@ -298,9 +242,6 @@ __global__ __launch_bounds__(64 * BWD_WAVES) void cnn_bwd_wino_k(CnnArgs a) {
       for (int xi = 0; xi < 8; ++xi) dU[xi] = mfma(zz[xi], vv[xi], dU[xi]);
       __builtin_amdgcn_sched_barrier(0);
     }
-#ifdef GNF_BWD_T_ALIAS
-    __syncthreads();                                           // a1 as dW2 operand is done: region becomes T
-#endif
     TSTAMP(2);
     // ---- P4: dpre1 = conv2^T(dY2) * gate on 2x2 tiles: per 4 input channels (g) 16 operands, then 16 MFMAs
 #pragma nounroll
@@ -346,14 +287,6 @@ __global__ __launch_bounds__(64 * BWD_WAVES) void cnn_bwd_wino_k(CnnArgs a) {
           }
           const float y00 = s0[0] + s0[1] + s0[2], y01 = s0[1] - s0[2] - s0[3];
           const float y10 = s1[0] + s1[1] + s1[2], y11 = s1[1] - s1[2] - s1[3];
-#ifdef GNF_BWD_T_ALIAS
-          // gate bit -> all-ones / all-zeros mask (v_bfe_i32) -> and: two full-rate ops per value
-          const int b0 = 31 - (16 * k + r);
-          dp[0][r] = __int_as_float(__float_as_int(y00) & __builtin_amdgcn_sbfe((int)gate, b0, 1));
-          dp[1][r] = __int_as_float(__float_as_int(y01) & __builtin_amdgcn_sbfe((int)gate, b0 - 4, 1));
-          dp[2][r] = __int_as_float(__float_as_int(y10) & __builtin_amdgcn_sbfe((int)gate, b0 - 8, 1));
-          dp[3][r] = __int_as_float(__float_as_int(y11) & __builtin_amdgcn_sbfe((int)gate, b0 - 12, 1));
-#else
           // ReLU gate = (a1 > 0), read back from the a1 image (two ds_read_b64 per channel: the tile's two rows)
           const float* pa = a1_s + (4 * q + r) * CHB + 2 * ty * ROWB + 2 * tx;
           const float2 g0 = *reinterpret_cast<const float2*>(pa), g1 = *reinterpret_cast<const float2*>(pa + ROWB);
@@ -361,7 +294,6 @@ __global__ __launch_bounds__(64 * BWD_WAVES) void cnn_bwd_wino_k(CnnArgs a) {
           dp[1][r] = (ok && g0.y > 0.f) ? y01 : 0.f;
           dp[2][r] = (ok && g1.x > 0.f) ? y10 : 0.f;
           dp[3][r] = (ok && g1.y > 0.f) ? y11 : 0.f;
-#endif
         }
         TSTAMP(5);                                              // P4b: output transform + gate
         // dW1 / db1 partials against the 4x4 image patch of this tile
@@ -375,21 +307,6 @@ __global__ __launch_bounds__(64 * BWD_WAVES) void cnn_bwd_wino_k(CnnArgs a) {
             ep[rr][0] = lo.x; ep[rr][1] = lo.y; ep[rr][2] = hi.x; ep[rr][3] = hi.y;
           }
         }
-#ifdef GNF_DW1_SCALAR
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {                           // scalar v_fma chain per (channel, tap)
-          float* gw = reinterpret_cast<float*>(&gW1p[r >> 1][0]) + (r & 1);
-          gw[2 * 9] += (dp[0][r] + dp[1][r]) + (dp[2][r] + dp[3][r]);
-#pragma unroll
-          for (int tap = 0; tap < 9; ++tap) {
-            const int ky = tap / 3, kx = tap % 3;
-            float acc = gw[2 * tap];
-#pragma unroll
-            for (int p = 0; p < 4; ++p) acc = fmaf(dp[p][r], ep[(p >> 1) + ky][(p & 1) + kx], acc);
-            gw[2 * tap] = acc;
-          }
-        }
-#else
 #pragma unroll
         for (int h = 0; h < 2; ++h) {                           // packed over the channel pair (2 flops per lane per op)
           f32x2 d2[4];
@@ -408,7 +325,6 @@ __global__ __launch_bounds__(64 * BWD_WAVES) void cnn_bwd_wino_k(CnnArgs a) {
             gW1p[h][tap] = acc;
           }
         }
-#endif
         TSTAMP(6);                                              // P4c: dW1 / db1 partials
         // T[tap][pos] = sum_oc W1[oc][tap] dpre1[oc][pos]: dpre1 in the C/D layout IS the B operand
         f32x4 tq[4];
@@ -506,12 +422,8 @@ __global__ void cnn_unpack_k(const float* __restrict__ vec, float* gW1, float* g
   } else gb2[n - NCH * 144 - NCH * 16] = s;
 }
 
-#ifdef GNF_BWD_T_ALIAS
-constexpr size_t kBwdWinoLds = (size_t)(ESZ + NCH * CHB + DSZW + USZ) * sizeof(float);
-#else
 constexpr size_t kBwdWinoLds = (size_t)(ESZ + NCH * CHB + DSZW + 9 * CS + USZ) * sizeof(float);
 static_assert(kBwdWinoLds <= 160 * 1024, "conv backward LDS image");
-#endif
 // one 8-wave workgroup per CU: at its 256 VGPRs a second one is not admitted
 constexpr unsigned kBwdGrid = 256;
 

@@ -144,16 +144,10 @@ __device__ __forceinline__ f32x4 mfma(float a, float b, f32x4 c) {
 // leaves (row, neighbour row) side by side, one add finishes the level -- no trip through the LDS crossbar
 // (ds_bpermute, ~100 cycles of latency per level in the dependent chain of every node evaluation).
 __device__ __forceinline__ float qsum(float v) {
-#ifdef GNF_QSUM_BPERMUTE
-  v += __shfl_xor(v, 16, 64);
-  v += __shfl_xor(v, 32, 64);
-  return v;
-#else
   auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
   v = __uint_as_float(r[0]) + __uint_as_float(r[1]);
   r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
   return __uint_as_float(r[0]) + __uint_as_float(r[1]);
-#endif
 }
 __device__ __forceinline__ float jsum(float v) {   // sum over the 16 elements of a lane-slot
   v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 8, 64);
