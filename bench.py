@@ -327,7 +327,7 @@ def main():
         # HBM bytes per launch of the dominant kernel: PMC counters cannot be read from inside this process, so the
         # figure is the one rocprofv3 measured for the same kernel at the same per-GPU size (profiles/r02_conv_hbm.json:
         # 2 x FETCH_SIZE + WRITE_SIZE, separate --pmc passes), next to the algorithmic bytes; null for any other size
-        hbm = {"gnf_mnistcnn_conv_bwd": (1421.5e6, n_elem * (784 * 4 + 2304 * 5 + 784 * 4)),
+        hbm = {"gnf_mnistcnn_conv_bwd": (1427.2e6, n_elem * (784 * 4 + 2304 * 5 + 784 * 4)),
                "gnf_mnistcnn_conv_fwd": (1149.3e6, n_elem * (784 * 4 + 2304 * 5))}
         if dom in hbm and n_elem == 78400:
             out["roofline"]["traffic"] = hbm[dom][0]
@@ -335,7 +335,7 @@ def main():
             out["roofline"]["traffic_source"] = "profiles/r02_conv_hbm.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE)"
         # MFMA issue slots used by the dominant kernel: v_mfma_f32_16x16x4_f32 issued per image (Winograd form, incl.
         # padding and the conv1 recompute) x 2048 flop / time / peak -- the head-room left, see DESIGN.md section 4
-        issued = {"gnf_mnistcnn_conv_bwd": 11 * 12 + 36 * 16 + 11 * 64 + 11 * 16, "gnf_mnistcnn_conv_fwd": 129 + 9 * 64}
+        issued = {"gnf_mnistcnn_conv_bwd": 8 * 6 * 3 + 36 * 16 + 11 * 64 + 11 * 16, "gnf_mnistcnn_conv_fwd": 129 + 9 * 64}
         if dom in issued:
             out["roofline"]["mfma_issue_frac"] = round(issued[dom] * 2048. * n_elem / (prof[dom] * 1e-3) / 1e12
                                                        / PEAK_F32_TFLOPS, 4)
@@ -343,7 +343,7 @@ def main():
             # 32.5 cycles per v_mfma_f32_16x16x4_f32 + ~3 per VALU instruction, additive at 2, 3 and 4 wavefronts per SIMD),
             # so with V other VALU instructions per MFMA the issue fraction cannot exceed 32.5 / (32.5 + 3 V);
             # V from profiles/r02_cnn_pmc.json (SQ_INSTS_VALU - SQ_INSTS_MFMA) / SQ_INSTS_MFMA
-            v_per_mfma = {"gnf_mnistcnn_conv_bwd": 4.64, "gnf_mnistcnn_conv_fwd": 3.77}[dom]
+            v_per_mfma = {"gnf_mnistcnn_conv_bwd": 4.39, "gnf_mnistcnn_conv_fwd": 3.77}[dom]
             out["roofline"]["valu_per_mfma"] = v_per_mfma
             out["roofline"]["issue_frac_ceiling_shared_alu"] = round(32.5 / (32.5 + 3. * v_per_mfma), 3)
         out["secondary"] = {"fwd_bwd_only_samples_per_s": round(B_PER_GPU * world / t_fb, 1) if t_fb else None,
