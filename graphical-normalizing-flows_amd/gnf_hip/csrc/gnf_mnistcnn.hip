@@ -157,11 +157,9 @@ __global__ __launch_bounds__(64 * BWD_WAVES) void cnn_bwd_wino_k(CnnArgs a) {
         const float g = gpre[k];
         const int am = (int)apre[k];
         gb2 += g;
-        float* p = d_s + woff[k];
-        p[0] = am == 0 ? g : 0.f;
-        p[1] = am == 1 ? g : 0.f;
-        p[ROD] = am == 2 ? g : 0.f;
-        p[ROD + 1] = am == 3 ? g : 0.f;
+        float* p = d_s + woff[k];                                 // even offset: the two rows of the window as 8-B stores
+        *reinterpret_cast<float2*>(p) = make_float2(am == 0 ? g : 0.f, am == 1 ? g : 0.f);
+        *reinterpret_cast<float2*>(p + ROD) = make_float2(am == 2 ? g : 0.f, am == 3 ? g : 0.f);
       }
     __syncthreads();
     prefetch(img + gridDim.x);
