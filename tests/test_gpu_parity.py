@@ -159,6 +159,25 @@ def test_gemm_shapes(M, N, K):
     assert rel_err(C3.cpu(), ref3) < 2e-6
 
 
+@pytest.mark.parametrize("M,N", [(4096, 512), (5003, 644), (78400, 2304)])
+def test_gemm_wide_short_k_path(M, N):
+    """C = A[M x 128] * B[128 x N], A k-contiguous, B n-contiguous, no epilogue options (the fc1 data gradient of the
+    MNISTCNN): the persistent unit-range kernel (gemm_wide_k), ragged row blocks and N tiles included"""
+    from gnf_hip import ops
+    torch.manual_seed(M + N)
+    K = 128
+    A, B = torch.randn(M, K, device=DEV), torch.randn(K, N, device=DEV)
+    C = torch.full((M, N), float("nan"), device=DEV)
+    ops.gemm(A, (K, 1), B, (N, 1), C, (N, 1), M, N, K)
+    ref = (A.double() @ B.double())
+    assert rel_err(C.cpu(), ref.cpu()) < 2e-6
+    assert not torch.isnan(C).any()
+    # strided rows of A and C (views into wider buffers)
+    Aw, Cw = torch.randn(M, K + 8, device=DEV), torch.zeros(M, N + 12, device=DEV)
+    ops.gemm(Aw, (K + 8, 1), B, (N, 1), Cw, (N + 12, 1), M, N, K)
+    assert rel_err(Cw[:, :N].cpu(), (Aw[:, :K].double() @ B.double()).cpu()) < 2e-6 and float(Cw[:, N:].abs().max()) == 0.
+
+
 def test_colsum():
     from gnf_hip import ops
     for M, N in [(1, 1), (513, 7), (5000, 300)]:
