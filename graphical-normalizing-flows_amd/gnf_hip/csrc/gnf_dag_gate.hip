@@ -266,7 +266,8 @@ inline int64_t bwd_chunks(int64_t B, int64_t d) {
 
 // chunks of the i loop of the (b, quad)-threaded dx kernel
 inline int64_t dx_chunks(int64_t B, int64_t d) {
-  const int64_t nblk = (B * ((d + 3) / 4) + kBlock - 1) / kBlock;
+  int64_t nblk = (B * ((d + 3) / 4) + kBlock - 1) / kBlock;
+  if (nblk < 1) nblk = 1;                    // empty batch
   int64_t nc = (4096 + nblk - 1) / nblk;
   if (nc > d) nc = d;
   if (nc > 64) nc = 64;
@@ -403,8 +404,9 @@ int64_t gnf_dag_gate_fwd_ws_bytes(int64_t d) { return 4 * d * d * (int64_t)sizeo
 int gnf_dag_gate_fwd(const float* x, const float* A, float* e, int64_t ld_e, int imp_mode, int gate_mode,
                      float h_thresh, float temperature, const float* u1, const float* u2, uint64_t seed,
                      uint64_t offset, int hot, float* ws, int64_t B, int64_t d, gnf_stream_t stream) {
-  if (!x || !A || !e || !ws || B < 0 || d <= 0 || imp_mode < 0 || imp_mode > 3 || gate_mode < 0 || gate_mode > 2)
-    return GNF_EINVAL;
+  if (((!x || !e) && B > 0) || !A || !ws || B < 0 || d <= 0 || imp_mode < 0 || imp_mode > 3 || gate_mode < 0 ||
+      gate_mode > 2)
+    return GNF_EINVAL;                // batch-sized arrays may be NULL for an empty batch
   if (ld_e < (hot ? 2 * d : d)) return GNF_EINVAL;
   if (gate_mode == 1 && u1 && !u2) return GNF_EINVAL;
   if (imp_mode == 0) gate_mode = 0;   // DAG:151-153: raw A, no gate
@@ -431,8 +433,9 @@ int64_t gnf_dag_gate_bwd_ws_bytes(int64_t B, int64_t d) {
 int gnf_dag_gate_bwd(const float* x, const float* A, const float* ge, int64_t ld_e, int imp_mode, int gate_mode,
                      float h_thresh, float temperature, const float* u1, const float* u2, uint64_t seed,
                      uint64_t offset, float* gA, float* gx, float* ws, int64_t B, int64_t d, gnf_stream_t stream) {
-  if (!x || !A || !ge || !ws || B < 0 || d <= 0 || imp_mode < 0 || imp_mode > 3 || gate_mode < 0 || gate_mode > 2)
-    return GNF_EINVAL;
+  if (((!x || !ge) && B > 0) || !A || !ws || B < 0 || d <= 0 || imp_mode < 0 || imp_mode > 3 || gate_mode < 0 ||
+      gate_mode > 2)
+    return GNF_EINVAL;                // empty batch: gA = 0 through the same kernels
   if (gate_mode == 1 && u1 && !u2) return GNF_EINVAL;
   if (imp_mode == 0) gate_mode = 0;
   hipStream_t s = (hipStream_t)stream;

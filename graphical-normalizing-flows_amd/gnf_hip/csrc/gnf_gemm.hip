@@ -556,6 +556,7 @@ int gnf_gemm_grouped_launch(GemmArgs g, int ngroups, hipStream_t s) {
 
 // split-K plan of the public entry: few output tiles and a long K -> spread K over the chip
 static int plan_splits(int64_t M, int64_t N, int64_t K) {
+  if (M <= 0 || N <= 0 || K <= 0) return 1;  // empty operands (a zero-row batch): nothing to split
   // Fewer 64x64 output tiles than ~3/4 of the CUs: split K until the chip is covered, at least 128 of K per split.
   // (The MADE layers at B = 100 are 2 x 16 tiles with K = 1024: unsplit they ran on 32 of the 256 CUs.)
   const int64_t tiles = ((M + 63) / 64) * ((N + 63) / 64);
@@ -584,8 +585,9 @@ extern "C" int gnf_gemm(const float* A, int64_t sam, int64_t sak, const float* B
                         int64_t sbn, float* C, int64_t scm, int64_t scn, const float* bias, const float* Cmask,
                         int64_t scmm, int64_t scmn, const float* gate, int64_t sgm, int64_t sgn, int flags,
                         int64_t M, int64_t N, int64_t K, float* ws, int64_t ws_bytes, gnf_stream_t stream) {
-  if (!A || !B || !C || M < 0 || N < 0 || K < 0) return GNF_EINVAL;
-  if (M == 0 || N == 0) return 0;
+  if (M < 0 || N < 0 || K < 0) return GNF_EINVAL;
+  if (M == 0 || N == 0) return 0;          // nothing to write; operands may be NULL
+  if (!C || ((!A || !B) && K > 0)) return GNF_EINVAL;   // K == 0 (an empty batch as the contraction): C = epilogue(0)
   GemmArgs g{A, sam, sak, B, Bmask, sbk, sbn, C, scm, scn, bias, Cmask, scmm, scmn, gate, sgm, sgn,
              flags & GNF_GEMM_RELU, M, N, K, 0, 0};
   const int splits = plan_splits(M, N, K);

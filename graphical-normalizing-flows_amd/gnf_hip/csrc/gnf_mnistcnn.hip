@@ -437,8 +437,9 @@ int64_t gnf_mnistcnn_conv_bwd_ws_bytes(int64_t n_img) {
 int gnf_mnistcnn_conv_bwd(const float* e, const float* W1, const float* b1, const float* W2, const float* g_pooled,
                           const unsigned char* argmax, float* ge, float* gW1, float* gb1, float* gW2, float* gb2,
                           void* ws, int64_t ws_bytes, int64_t n_img, gnf_stream_t stream) {
-  if (!e || !W1 || !b1 || !W2 || !g_pooled || !argmax || !ge || !gW1 || !gb1 || !gW2 || !gb2 || !ws || n_img < 0)
-    return GNF_EINVAL;
+  if (((!e || !g_pooled || !argmax || !ge) && n_img > 0) || !W1 || !b1 || !W2 || !gW1 || !gb1 || !gW2 || !gb2 || !ws ||
+      n_img < 0)
+    return GNF_EINVAL;                       // empty batch: zero weight gradients through the same kernels
   if (ws_bytes < gnf_mnistcnn_conv_bwd_ws_bytes(n_img)) return GNF_EWS;
   CnnArgs a{};
   a.e = e; a.W1 = W1; a.b1 = b1; a.W2 = W2; a.gp = g_pooled; a.argin = argmax; a.ge = ge; a.part = (float*)ws;

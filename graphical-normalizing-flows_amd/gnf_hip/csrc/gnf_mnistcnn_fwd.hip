@@ -332,8 +332,9 @@ extern "C" {
 
 int gnf_mnistcnn_conv_fwd(const float* e, const float* W1, const float* b1, const float* W2, const float* b2,
                           float* pooled, unsigned char* argmax, int64_t n_img, int exact_ties, gnf_stream_t stream) {
-  if (!e || !W1 || !b1 || !W2 || !b2 || !pooled || !argmax || n_img < 0) return GNF_EINVAL;
-  if (n_img == 0) return 0;
+  if (!W1 || !b1 || !W2 || !b2 || n_img < 0) return GNF_EINVAL;
+  if (n_img == 0) return 0;                // image-sized arrays may be NULL for an empty batch
+  if (!e || !pooled || !argmax) return GNF_EINVAL;
   CnnArgs a{};
   a.e = e; a.W1 = W1; a.b1 = b1; a.W2 = W2; a.b2 = b2; a.pooled = pooled; a.arg = argmax; a.n = n_img;
   if (exact_ties) {                                 // direct implicit GEMM: bit-equal outputs for equal patches

@@ -504,12 +504,13 @@ int gnf_mnistcnn_sparse_fwd(const float* x, int64_t B, const float* P, const int
                             const float* Wfc1, const float* bfc1, int64_t F,
                             float* h1, float* pd_save, unsigned char* argmax_save,
                             void* ws, int64_t ws_bytes, gnf_stream_t stream) {
-  if (!x || !P || !pix || !groups || !W1 || !b1 || !W2 || !b2 || !Wfc1 || !bfc1 || !h1 || B < 0 || R < 0 || F <= 0 ||
+  if (!W1 || !b1 || !W2 || !b2 || !Wfc1 || !bfc1 || B < 0 || R < 0 || F <= 0 ||
       (pd_save == nullptr) != (argmax_save == nullptr))
     return GNF_EINVAL;
   if (F % 4 || F > 65535 * 64) return GNF_ESHAPE;
   const int64_t items = R * B;
-  if (items == 0) return 0;
+  if (items == 0) return 0;                // batch- and row-sized arrays may be NULL for an empty call
+  if (!x || !P || !pix || !groups || !h1) return GNF_EINVAL;
   if (!ws || ws_bytes < gnf_mnistcnn_sparse_ws_bytes(items, F) || max_group_rows <= 0 || max_group_rows > items)
     return GNF_EINVAL;
   hipStream_t s = (hipStream_t)stream;
@@ -561,10 +562,11 @@ int gnf_mnistcnn_sparse_bwd(const float* x, int64_t B, const float* P, const int
                             const float* pd, const unsigned char* argmax, const float* g_h1,
                             float* gW1, float* gb1, float* gW2, float* gb2, float* gWfc1, float* gbfc1,
                             void* ws, int64_t ws_bytes, gnf_stream_t stream) {
-  if (!kgroups || !origin_chunks || n_kgroups < 0 || n_kgroups > 65535) return GNF_EINVAL;
-  if (!x || !P || !pix || !groups || !W1 || !b1 || !W2 || !b2 || !Wfc1 || !pd || !argmax || !g_h1 || !gW1 || !gb1 ||
-      !gW2 || !gb2 || !gWfc1 || !gbfc1 || B < 0 || R < 0 || F <= 0)
+  if (n_kgroups < 0 || n_kgroups > 65535) return GNF_EINVAL;
+  if (!W1 || !b1 || !W2 || !b2 || !Wfc1 || !gW1 || !gb1 || !gW2 || !gb2 || !gWfc1 || !gbfc1 || B < 0 || R < 0 || F <= 0)
     return GNF_EINVAL;
+  if (R * B > 0 && (!kgroups || !origin_chunks || !x || !P || !pix || !groups || !pd || !argmax || !g_h1))
+    return GNF_EINVAL;                       // an empty call only zeroes the weight gradients
   if (F % 4 || F > 65535 * 64) return GNF_ESHAPE;
   const int64_t items = R * B;
   hipStream_t s = (hipStream_t)stream;

@@ -2019,8 +2019,9 @@ int gnf_monotonic_fwd(const float* pack, const gnf_mono_net* net, const float* x
                       float* jac, int64_t B, int64_t d, gnf_stream_t stream) {
   const int HT = pick_ht(net);
   if (HT < 0) return GNF_ESHAPE;
-  if (!pack || !x || !h || !cc_w || !cc_t || !z || !jac || S < 1 || B < 0 || d <= 0) return GNF_EINVAL;
-  if (B == 0) return 0;
+  if (!pack || !cc_w || !cc_t || S < 1 || B < 0 || d <= 0) return GNF_EINVAL;
+  if (B == 0) return 0;                    // batch-sized arrays may be NULL for an empty batch
+  if (!x || !h || !z || !jac) return GNF_EINVAL;
   MonoArgs a{};
   a.pack = pack; a.L = net_layout(net, HT);
   a.x = x; a.h = h; a.h_sb = h_sb; a.h_sd = h_sd; a.h_sc = h_sc;
@@ -2033,8 +2034,9 @@ int gnf_monotonic_inv(const float* pack, const gnf_mono_net* net, const float* z
                       int64_t d, gnf_stream_t stream) {
   const int HT = pick_ht(net);
   if (HT < 0) return GNF_ESHAPE;
-  if (!pack || !z || !h || !cc_w || !cc_t || !x || S < 1 || B < 0 || d <= 0) return GNF_EINVAL;
+  if (!pack || !cc_w || !cc_t || S < 1 || B < 0 || d <= 0) return GNF_EINVAL;
   if (B == 0) return 0;
+  if (!z || !h || !x) return GNF_EINVAL;
   MonoArgs a{};
   a.pack = pack; a.L = net_layout(net, HT);
   a.h = h; a.h_sb = h_sb; a.h_sd = h_sd; a.h_sc = h_sc;
@@ -2047,6 +2049,7 @@ int64_t gnf_monotonic_bwd_ws_bytes(const gnf_mono_net* net, int S, int64_t B, in
   if (HT < 0) return GNF_ESHAPE;
   const MonoLayout L = net_layout(net, HT);
   const bool indw = use_indw(net, L);
+  if (B < 1) B = 1;                          // an empty batch needs no workspace; keep the plan arithmetic away from 0
   const BwdPlan full = plan_bwd(L, S, B * d, 0, indw);
   const int64_t want = full.total_floats * (int64_t)sizeof(float);
   if (want <= kWsTarget) return want;
@@ -2063,10 +2066,19 @@ int gnf_monotonic_bwd(const float* pack, const gnf_mono_net* net, const float* x
                       gnf_stream_t stream) {
   const int HT = pick_ht(net);
   if (HT < 0) return GNF_ESHAPE;
-  if (!pack || !x || !h || !cc_w || !cc_t || !gz || !gh || !gW || !gb || !ws || S < 1 || B < 0 || d <= 0)
-    return GNF_EINVAL;
+  if (!pack || !cc_w || !cc_t || !gW || !gb || S < 1 || B < 0 || d <= 0) return GNF_EINVAL;
   const int NH = net->nl - 1;
   if (NH > 4) return GNF_ESHAPE;
+  if (B == 0) {                              // empty batch: zero parameter gradients, nothing else to write
+    for (int l = 0; l <= NH; ++l) {
+      if (!gW[l] || !gb[l]) return GNF_EINVAL;
+      if (hipMemsetAsync(gW[l], 0, sizeof(float) * net->dims[l] * net->dims[l + 1], (hipStream_t)stream) != hipSuccess ||
+          hipMemsetAsync(gb[l], 0, sizeof(float) * net->dims[l + 1], (hipStream_t)stream) != hipSuccess)
+        return GNF_EINVAL;
+    }
+    return 0;
+  }
+  if (!x || !h || !gz || !gh || !ws) return GNF_EINVAL;
   if (h_sb != d * h_sd) return GNF_ESHAPE;   // element stride must collapse (caller makes h contiguous)
   hipStream_t s = (hipStream_t)stream;
   const MonoLayout L = net_layout(net, HT);

@@ -498,8 +498,9 @@ int gnf_abi_version(void) { return GNF_ABI_VERSION; }
 
 int gnf_affine_fwd(const float* x, float* h, int64_t h_sb, int64_t h_sd, int64_t h_sc, float* z, float* jac,
                    float* logdet, int clamp_inplace, int64_t B, int64_t d, gnf_stream_t stream) {
-  if (!x || !h || !z || B < 0 || d <= 0) return GNF_EINVAL;
-  if (B == 0) return 0;
+  if (B < 0 || d <= 0) return GNF_EINVAL;
+  if (B == 0) return 0;                    // batch-sized arrays may be NULL for an empty batch
+  if (!x || !h || !z) return GNF_EINVAL;
   const int G = gnf_pow2_ge(d, 64);
   if (const int rw = clamp_inplace ? 0 : affine_flat_rw(h_sb, h_sd, h_sc, B, d, x, h, z)) {
     if (!jac || ((uintptr_t)jac & 15) == 0) {
@@ -523,8 +524,9 @@ int gnf_affine_fwd(const float* x, float* h, int64_t h_sb, int64_t h_sd, int64_t
 int gnf_affine_bwd(const float* x, const float* h, int64_t h_sb, int64_t h_sd, int64_t h_sc, const float* gz,
                    const float* gjac, const float* glogdet, float* gx, float* gh, int64_t g_sb, int64_t g_sd,
                    int64_t g_sc, int64_t B, int64_t d, gnf_stream_t stream) {
-  if (!x || !h || !gh || B < 0 || d <= 0) return GNF_EINVAL;
+  if (B < 0 || d <= 0) return GNF_EINVAL;
   if (B == 0) return 0;
+  if (!x || !h || !gh) return GNF_EINVAL;
   const int G = gnf_pow2_ge(d, 64);
   if (const int rw = (g_sc == 1 && g_sd == 2 && g_sb == 2 * d) ? affine_flat_rw(h_sb, h_sd, h_sc, B, d, x, h, gh) : 0) {
     if ((((uintptr_t)gz | (uintptr_t)gjac | (uintptr_t)gx) & 15) == 0) {
@@ -547,8 +549,9 @@ int gnf_affine_bwd(const float* x, const float* h, int64_t h_sb, int64_t h_sd, i
 
 int gnf_affine_inv(const float* z, const float* h, int64_t h_sb, int64_t h_sd, int64_t h_sc, float* x, int64_t B,
                    int64_t d, gnf_stream_t stream) {
-  if (!z || !h || !x || B < 0 || d <= 0) return GNF_EINVAL;
+  if (B < 0 || d <= 0) return GNF_EINVAL;
   if (B == 0) return 0;
+  if (!z || !h || !x) return GNF_EINVAL;
   hipLaunchKernelGGL(affine_inv_k, dim3(grid_1d(B * d)), dim3(kBlock), 0, (hipStream_t)stream, z, h, h_sb, h_sd,
                      h_sc, x, B, d);
   GNF_LAUNCH_CHECK();
@@ -556,8 +559,9 @@ int gnf_affine_inv(const float* z, const float* h, int64_t h_sb, int64_t h_sd, i
 }
 
 int gnf_logsum_rows_fwd(const float* jac, float* out, int64_t B, int64_t d, gnf_stream_t stream) {
-  if (!jac || !out || B < 0 || d <= 0) return GNF_EINVAL;
+  if (B < 0 || d <= 0) return GNF_EINVAL;
   if (B == 0) return 0;
+  if (!jac || !out) return GNF_EINVAL;
   const int G = gnf_pow2_ge(d, 64);
   GNF_DISPATCH_G(G, logsum_rows_k, B, jac, out, B, d);
   GNF_LAUNCH_CHECK();
@@ -565,8 +569,9 @@ int gnf_logsum_rows_fwd(const float* jac, float* out, int64_t B, int64_t d, gnf_
 }
 
 int gnf_logsum_rows_bwd(const float* jac, const float* g, float* gjac, int64_t B, int64_t d, gnf_stream_t stream) {
-  if (!jac || !g || !gjac || B < 0 || d <= 0) return GNF_EINVAL;
+  if (B < 0 || d <= 0) return GNF_EINVAL;
   if (B == 0) return 0;
+  if (!jac || !g || !gjac) return GNF_EINVAL;
   hipLaunchKernelGGL(logsum_rows_bwd_k, dim3(grid_1d(B * d)), dim3(kBlock), 0, (hipStream_t)stream, jac, g, gjac, B,
                      d);
   GNF_LAUNCH_CHECK();
@@ -574,8 +579,9 @@ int gnf_logsum_rows_bwd(const float* jac, const float* g, float* gjac, int64_t B
 }
 
 int gnf_normal_logdensity_fwd(const float* z, float* out, int64_t B, int64_t d, gnf_stream_t stream) {
-  if (!z || !out || B < 0 || d <= 0) return GNF_EINVAL;
+  if (B < 0 || d <= 0) return GNF_EINVAL;
   if (B == 0) return 0;
+  if (!z || !out) return GNF_EINVAL;
   const int G = gnf_pow2_ge(d, 64);
   GNF_DISPATCH_G(G, normal_ld_rows_k, B, z, out, B, d);
   GNF_LAUNCH_CHECK();
@@ -583,8 +589,9 @@ int gnf_normal_logdensity_fwd(const float* z, float* out, int64_t B, int64_t d, 
 }
 
 int gnf_normal_logdensity_bwd(const float* z, const float* g, float* gz, int64_t B, int64_t d, gnf_stream_t stream) {
-  if (!z || !g || !gz || B < 0 || d <= 0) return GNF_EINVAL;
+  if (B < 0 || d <= 0) return GNF_EINVAL;
   if (B == 0) return 0;
+  if (!z || !g || !gz) return GNF_EINVAL;
   hipLaunchKernelGGL(normal_ld_bwd_k, dim3(grid_1d(B * d)), dim3(kBlock), 0, (hipStream_t)stream, z, g, gz, B, d);
   GNF_LAUNCH_CHECK();
   return 0;
@@ -596,7 +603,7 @@ int64_t gnf_colsum_ws_bytes(int64_t M, int64_t N) {
 }
 
 int gnf_colsum(const float* a, int64_t lda, float* out, int64_t M, int64_t N, float* ws, gnf_stream_t stream) {
-  if (!a || !out || !ws || M < 0 || N <= 0) return GNF_EINVAL;
+  if ((!a && M > 0) || !out || !ws || M < 0 || N <= 0) return GNF_EINVAL;   // M == 0: out = 0
   if (lda == N) return gnf_rowsum_tall_launch(a, out, M, N, 0, ws, (hipStream_t)stream);
   // strided rows: generic two-stage kernels
   const int64_t P = (M + kColRows - 1) / kColRows;
@@ -623,8 +630,9 @@ static int adam_vec_ok(const float* p, const float* g, const float* m, const flo
 
 int gnf_adam_step(float* p, const float* g, float* m, float* v, int64_t n, double lr, double beta1, double beta2,
                   double eps, double weight_decay, double grad_scale, int step, gnf_stream_t stream) {
-  if (!p || !g || !m || !v || n < 0 || step < 1) return GNF_EINVAL;
+  if (n < 0 || step < 1) return GNF_EINVAL;
   if (n == 0) return 0;
+  if (!p || !g || !m || !v) return GNF_EINVAL;
   const float step_size = (float)(lr / (1.0 - pow(beta1, (double)step)));
   const float bc2s = (float)sqrt(1.0 - pow(beta2, (double)step));
   const int vec = adam_vec_ok(p, g, m, v);
@@ -637,8 +645,9 @@ int gnf_adam_step(float* p, const float* g, float* m, float* v, int64_t n, doubl
 int gnf_adam_step_dev(float* p, const float* g, float* m, float* v, int64_t n, double lr, double beta1, double beta2,
                       double eps, double weight_decay, double grad_scale, int* step_dev, int advance,
                       gnf_stream_t stream) {
-  if (!p || !g || !m || !v || !step_dev || n < 0) return GNF_EINVAL;
+  if (!step_dev || n < 0) return GNF_EINVAL;
   if (n == 0) return 0;
+  if (!p || !g || !m || !v) return GNF_EINVAL;
   const int vec = adam_vec_ok(p, g, m, v);
   hipLaunchKernelGGL(adam_dev_k, dim3(grid_1d(vec ? (n + 3) / 4 : n)), dim3(kBlock), 0, (hipStream_t)stream, p, g, m, v,
                      n, vec, adam_consts(beta1, beta2, eps, weight_decay, grad_scale), lr, beta1, beta2,

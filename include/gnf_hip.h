@@ -13,7 +13,11 @@
  *     hipError_t from the launch; never throws, never allocates, never synchronises;
  *   - the caller owns and sizes every buffer, including workspaces (gnf_*_ws_bytes);
  *   - no global mutable state: safe for one process per GPU and for several streams;
- *   - strides are in ELEMENTS, not bytes.
+ *   - strides are in ELEMENTS, not bytes;
+ *   - an EMPTY batch (B, n_img, M or the row count = 0) is a valid call, as it is in the
+ *     reference (torch ops on [0, d] tensors): arrays sized by the batch may then be NULL
+ *     (torch hands out a null data_ptr for them), nothing is launched over them, and the
+ *     backward entry points still write ZERO parameter gradients.
  */
 #ifndef GNF_HIP_H
 #define GNF_HIP_H
