@@ -38,6 +38,9 @@ constexpr int USZ = 16 * 4 * 64;                     // U' as [xi_y][g][lane][xi
 //     channel pairs PSD == 2 (mod 64) apart keep the 16-channel Z read of dW2 conflict-free too.  70 KB; round 1 gave
 //     every channel its own [14][90] block (84 KB, same timings) -- the 14 KB are what lets the T planes leave the a1 region.
 constexpr int ROWB = 28, CHB = 730;
+// the input image, unpadded rows (no read leaves a row: conv1 x+kx <= 27, the dW1 patches 2tx+3 <= 27), TWO buffers:
+// image n+1 is staged while image n is still being read, which removes the staging barrier interval
+constexpr int ROWEB = IMG, ESZB = IMG * IMG;
 constexpr int TRD = 154, ROD = 28, CHDW = 96, PSD = 14 * TRD + 22, DSZW = (NCH / 2) * PSD;
 static_assert(CHB >= C1 * ROWB && (CHB % 4) == 2, "a1 channel stride");
 static_assert((TRD - 24) % 64 == 2 && CHDW % 64 == 32 && PSD % 64 == 2 && 14 * TRD <= PSD + 2 && ROD >= 28, "dY2 layout");
@@ -49,15 +52,14 @@ __global__ __launch_bounds__(64 * BWD_WAVES) void cnn_bwd_wino_k(CnnArgs a) {
   long long tlast = __builtin_readcyclecounter();
 #endif
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* e_s = smem;
-  float* a1_s = smem + ESZ;                 // conv1 activations
+  float* a1_s = smem + 2 * ESZB;            // conv1 activations (the two input-image buffers sit in front)
   float* d_s = a1_s + NCH * CHB;            // dY2 with a 2-wide zero border, tile-row layout
   float* T_s = d_s + DSZW;                  // per-tap planes T [9][26 x 26], their own region: dW2 and da1 share one phase
   float* u_s = T_s + 9 * CS;                // U' as [g][xi_y][lane][xi_x]
   const int tid = threadIdx.x, lane = tid & 63, q = lane >> 4, j = lane & 15;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   constexpr int NW = BWD_WAVES, NT = 64 * BWD_WAVES;
-  static_assert((ESZ % 4 == 0) && ((NCH * CHB) % 4 == 0) && (DSZW % 4 == 0), "u_s must be 16-B aligned");
+  static_assert(((2 * ESZB) % 4 == 0) && ((NCH * CHB) % 4 == 0) && (DSZW % 4 == 0), "u_s must be 16-B aligned");
   static_assert((9 * CS) % 4 == 0 && 9 * CS <= NCH * CHB, "T planes");
 
   float w1f[3];
@@ -67,7 +69,7 @@ __global__ __launch_bounds__(64 * BWD_WAVES) void cnn_bwd_wino_k(CnnArgs a) {
     const int tap = 4 * s + q;
     w1f[s] = tap < 9 ? a.W1[j * 9 + tap] : 0.f;
     const int tt = tap < 9 ? tap : 0;
-    off1[s] = (tt / 3) * ROWE + tt % 3;
+    off1[s] = (tt / 3) * ROWEB + tt % 3;
   }
   f32x4 b1v;
 #pragma unroll
@@ -111,7 +113,6 @@ __global__ __launch_bounds__(64 * BWD_WAVES) void cnn_bwd_wino_k(CnnArgs a) {
     for (int k = 0; k < 10; ++k) gW1p[h][k] = f32x2{0.f, 0.f};
   float gb2 = 0.f;                           // thread tid accumulates channel tid/32
 
-  for (int i = tid; i < ESZ; i += NT) e_s[i] = 0.f;
   for (int i = tid; i < DSZW; i += NT) d_s[i] = 0.f;
 
   constexpr int EPT = (IMG * IMG + NT - 1) / NT, WPT = (PO * PO + 31) / 32;
@@ -143,14 +144,51 @@ __global__ __launch_bounds__(64 * BWD_WAVES) void cnn_bwd_wino_k(CnnArgs a) {
     woff[k] = w < PO * PO ? dwin + (w / PO) * TRD + 2 * (w % PO) : -1;
   }
 
-  for (int64_t img = blockIdx.x; img < a.n; img += gridDim.x) {
-    __syncthreads();
-    // ---- P0: image, and dY2 = pool-backward scatter of g_pooled (one write per conv2 position)
+  // ---- de[y][x] = sum_tap T[tap][y-ky][x-kx] of a finished image.  Branch-free: the nine reads are immediate offsets
+  //      from ONE base and always land inside the T region (largest: 27*26+27 + 8*CS - 2*C1 - 2 = 9*CS - 1), taps that
+  //      fall off the 26 x 26 plane are dropped by a select AFTER the read -- the bounds-checked form compiled into nine
+  //      dependent branch / ds_read / s_waitcnt rounds per pixel (2.3 k of 27 k cycles per image)
+  static_assert(27 * C1 + 27 + 8 * CS - 2 * C1 - 2 < 9 * CS, "de gather stays inside the T planes");
+  auto de_gather = [&](int64_t im) {
+#pragma unroll
+    for (int k = 0; k < (IMG * IMG + NT - 1) / NT; ++k) {
+      if (k * NT + 64 * wave < IMG * IMG) {                      // wave-uniform
+        const int i = tid + k * NT;
+        const bool on = i < IMG * IMG;
+        const int ic = on ? i : 0, y = ic / IMG, x = ic - IMG * y;
+        const float* tp = T_s + y * C1 + x;
+        float t[9];
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) t[tap] = tp[tap * CS - (tap / 3) * C1 - tap % 3];
+        float s = 0.f;
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+          const bool v = (unsigned)(y - tap / 3) < (unsigned)C1 && (unsigned)(x - tap % 3) < (unsigned)C1;
+          s += v ? t[tap] : 0.f;
+        }
+        if (on) a.ge[im * (IMG * IMG) + i] = s;
+      }
+    }
+  };
+
+  auto stage_e = [&](float* dst) {                               // the prefetched image into an input buffer
 #pragma unroll
     for (int k = 0; k < EPT; ++k) {
       const int i = tid + k * NT;
-      if (i < IMG * IMG) e_s[(i / IMG) * ROWE + i % IMG] = epre[k];
+      if (i < IMG * IMG) dst[i] = epre[k];
     }
+  };
+  stage_e(smem);
+
+  // TWO barrier intervals per image: {dY2 scatter, the PREVIOUS image's de gather, conv1 recompute} | {dW2, da1, staging
+  // of the NEXT image into the other input buffer}.  de sits in the first interval so that its LDS latency overlaps the
+  // conv1 MFMAs and nothing waits on vmcnt right behind its global stores (at the end of the loop body the compiler's
+  // s_waitcnt vmcnt(0) for the prefetched bytes of the next image also waited for the store acknowledgements).
+  int par = 0;                                                   // input buffer of this image (wave-uniform)
+  for (int64_t img = blockIdx.x; img < a.n; img += gridDim.x, par ^= 1) {
+    const float* e_rd = smem + par * ESZB;
+    __syncthreads();                                             // previous image done: dY2, a1 free, T complete; e staged
+    // ---- dY2 = pool-backward scatter of g_pooled (one write per conv2 position)
 #pragma unroll
     for (int k = 0; k < WPT; ++k)
       if (woff[k] >= 0) {
@@ -161,9 +199,10 @@ __global__ __launch_bounds__(64 * BWD_WAVES) void cnn_bwd_wino_k(CnnArgs a) {
         *reinterpret_cast<float2*>(p) = make_float2(am == 0 ? g : 0.f, am == 1 ? g : 0.f);
         *reinterpret_cast<float2*>(p + ROD) = make_float2(am == 2 ? g : 0.f, am == 3 ? g : 0.f);
       }
-    __syncthreads();
     prefetch(img + gridDim.x);
     TSTAMP(0);
+    if (img != (int64_t)blockIdx.x) de_gather(img - gridDim.x);
+    TSTAMP(4);
     // ---- P1: conv1 + ReLU, 43 tiles of 16 consecutive positions of the 26 x 26 grid dealt over the 8 wavefronts
     //      (6 / 5 each).  a1 stays intact until the end of the image (the T planes have their own region), so da1 reads
     //      its ReLU gates back from a1 itself and this phase no longer has to follow da1's 11-groups-over-8 layout
@@ -179,7 +218,7 @@ __global__ __launch_bounds__(64 * BWD_WAVES) void cnn_bwd_wino_k(CnnArgs a) {
         const int y = pc / C1, x = pc - y * C1;
         po[k] = pos < C1 * C1 ? y * ROWB + x : -1;
 #pragma unroll
-        for (int s = 0; s < 3; ++s) ev[k][s] = e_s[y * ROWE + x + off1[s]];
+        for (int s = 0; s < 3; ++s) ev[k][s] = e_rd[y * ROWEB + x + off1[s]];
         acc[k] = b1v;
       }
 #pragma unroll
@@ -199,10 +238,16 @@ __global__ __launch_bounds__(64 * BWD_WAVES) void cnn_bwd_wino_k(CnnArgs a) {
     //      Z = A dY A^T from the 2x2 window of dY2 in LDS (A = [[1,0],[1,1],[1,-1],[0,-1]]); V = B^T d B needs the
     //      patch rows hy..hy+2 only: xi_y 0,1 = d0-d2, d1+d2;  xi_y 2,3 = d2-d1, d1-d3
     // K-steps of this wavefront.  With dW2 and da1 in ONE barrier interval the wavefronts that own two da1 groups
-    // (0-2) take fewer dW2 steps: per SIMD 360 / 360 / 360 / 376 MFMAs instead of (72 + 72) + (240 | 160)
+    // (0-2) take fewer dW2 steps
     const int s_step = 1;
-    const int s_first = hy == 0 ? (wave < 3 ? 6 * wave : 18) : 9 * (wave - 4);
-    const int s_last = hy == 0 ? (wave < 3 ? 6 * wave + 6 : 36) : 9 * (wave - 4) + 9;
+    // K-steps of the last wavefront of each half (3 and 7: one da1 group and SIMD 3 to themselves).  Measured sweep
+    // (tools/bench_cnn.py, same box): (18,9) 3.32 ms, (17,9) 3.22, (16,9) 3.20, (15,9) 3.23, (14,9) 3.25, (18,6) 3.24,
+    // (16,8) 3.23, (15,6) 3.28 -- equal MFMA counts per SIMD (18,9) is not equal time: a dW2 step carries more VALU
+    // and LDS latency per MFMA than a da1 group
+    constexpr int KL = 16, KH = 9;
+    const int wq = wave & 3, kl = hy == 0 ? KL : KH, kb = (36 - kl) / 3, kr = (36 - kl) % 3;
+    const int s_first = wq < 3 ? wq * kb + (wq < kr ? wq : kr) : 36 - kl;
+    const int s_last = wq < 3 ? s_first + kb + (wq < kr ? 1 : 0) : 36;
 #pragma nounroll
     for (int s = s_first; s < s_last; s += s_step) {
       const int T = 4 * s + q, ty = T / 12, tx = T - 12 * ty;
@@ -297,11 +342,11 @@ __global__ __launch_bounds__(64 * BWD_WAVES) void cnn_bwd_wino_k(CnnArgs a) {
         // dW1 / db1 partials against the 4x4 image patch of this tile
         float ep[4][4];
         {
-          const float* pe = e_s + 2 * ty * ROWE + 2 * tx;
+          const float* pe = e_rd + 2 * ty * ROWEB + 2 * tx;
 #pragma unroll
           for (int rr = 0; rr < 4; ++rr) {
-            const float2 lo = *reinterpret_cast<const float2*>(pe + rr * ROWE);
-            const float2 hi = *reinterpret_cast<const float2*>(pe + rr * ROWE + 2);
+            const float2 lo = *reinterpret_cast<const float2*>(pe + rr * ROWEB);
+            const float2 hi = *reinterpret_cast<const float2*>(pe + rr * ROWEB + 2);
             ep[rr][0] = lo.x; ep[rr][1] = lo.y; ep[rr][2] = hi.x; ep[rr][3] = hi.y;
           }
         }
@@ -346,23 +391,10 @@ __global__ __launch_bounds__(64 * BWD_WAVES) void cnn_bwd_wino_k(CnnArgs a) {
       }
     }
     TSTAMP(7);                                                  // P4d: T planes
-    __syncthreads();
-    TSTAMP(3);                                                  // barrier wait counts as P4a
-    // ---- de[y][x] = sum_tap T[tap][y-ky][x-kx]
-    for (int i = tid; i < IMG * IMG; i += NT) {
-      const int y = i / IMG, x = i - y * IMG;
-      float s = 0.f;
-#pragma unroll
-      for (int ky = 0; ky < 3; ++ky)
-#pragma unroll
-        for (int kx = 0; kx < 3; ++kx) {
-          const int yy = y - ky, xx = x - kx;
-          if (yy >= 0 && yy < C1 && xx >= 0 && xx < C1) s += T_s[(ky * 3 + kx) * CS + yy * C1 + xx];
-        }
-      a.ge[img * (IMG * IMG) + i] = s;
-    }
-    TSTAMP(4);
+    stage_e(smem + (par ^ 1) * ESZB);                           // the next image (zeros behind the last one)
   }
+  __syncthreads();
+  if ((int64_t)blockIdx.x < a.n) de_gather(blockIdx.x + (a.n - 1 - blockIdx.x) / gridDim.x * gridDim.x);   // the last image
 #ifdef GNF_CNN_TIMING
   if (blockIdx.x == 7 && (tid & 63) == 0)
     for (int k = 0; k < 8; ++k) a.part[((int64_t)gridDim.x * NW + 1) * PROW + wave * 8 + k] = (float)tacc[k];
@@ -420,7 +452,7 @@ __global__ void cnn_unpack_k(const float* __restrict__ vec, float* gW1, float* g
   } else gb2[n - NCH * 144 - NCH * 16] = s;
 }
 
-constexpr size_t kBwdWinoLds = (size_t)(ESZ + NCH * CHB + DSZW + 9 * CS + USZ) * sizeof(float);
+constexpr size_t kBwdWinoLds = (size_t)(2 * ESZB + NCH * CHB + DSZW + 9 * CS + USZ) * sizeof(float);
 static_assert(kBwdWinoLds <= 160 * 1024, "conv backward LDS image");
 // one 8-wave workgroup per CU: at its 256 VGPRs a second one is not admitted
 constexpr unsigned kBwdGrid = 256;

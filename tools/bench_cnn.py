@@ -11,9 +11,10 @@ so = '/tmp/libgnf_cnn_ab_%d.so' % os.getpid()
 sys.path.insert(0, ROOT + '/graphical-normalizing-flows_amd')
 from gnf_hip.build import EXTRA_FLAGS   # the product's per-file flags apply here too
 objs = []
-for f in ('gnf_mnistcnn_fwd.hip', 'gnf_mnistcnn.hip', 'gnf_rowwise.hip'):
+for f in (os.environ.get('GNF_CNN_FWD_SRC', 'gnf_mnistcnn_fwd.hip'), os.environ.get('GNF_CNN_BWD_SRC', 'gnf_mnistcnn.hip'),
+          'gnf_rowwise.hip'):                                       # A/B against other sources in csrc/
     o = '/tmp/cnn_ab_%d_%s.o' % (os.getpid(), f)
-    subprocess.run(['hipcc', '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-Wno-unused-value'] + EXTRA_FLAGS.get(f, []) + flags +
+    subprocess.run(['hipcc', '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-Wno-unused-value'] + EXTRA_FLAGS.get(f, EXTRA_FLAGS.get('gnf_mnistcnn_fwd.hip', []) if 'fwd' in f else []) + flags +
                    ['-I' + ROOT + '/include', '-I' + src, '-c', src + f, '-o', o], check=True)
     objs.append(o)
 subprocess.run(['hipcc', '--offload-arch=gfx950', '-shared', '-fPIC', '-o', so] + objs, check=True)

@@ -1,4 +1,4 @@
-"""Debug: per-phase cycle counts of cnn_bwd_k (build with -DGNF_CNN_TIMING)."""
+"""Debug: per-phase cycle counts of cnn_bwd_wino_k (build with -DGNF_CNN_TIMING)."""
 import ctypes, subprocess, sys, os
 import torch
 ROOT = '/root/repo'
@@ -29,7 +29,7 @@ for _ in range(2):
 torch.cuda.synchronize()
 PROW = 16 * 144 + 256 + 16
 t = ws[(256 * 8 + 1) * PROW:(256 * 8 + 1) * PROW + 64].view(8, 8).cpu()
-names = ["P0 load+scatter", "P1 conv1", "P3 dW2", "P4a mfma(+barrier)", "de", "P4b outT+gate", "P4c dW1", "P4d T"]
+names = ["stage e(next) + barrier A + dY2 scatter", "P1 conv1 + barrier B", "P3 dW2", "P4a mfma", "de(prev)", "P4b outT+gate", "P4c dW1", "P4d T"]
 imgs = (n - 7 + 255) // 256
 print("rc", rc, "images per WG", imgs)
 for w in range(8):
