@@ -4,6 +4,8 @@ import sys, os, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, ROOT + '/graphical-normalizing-flows_amd']
 from gnf_hip import abi
+if os.environ.get('GNF_AB_LIB'):                      # A/B against another build of the library (tools/*.bin)
+    abi.LIB_PATH = os.path.join(ROOT, os.environ['GNF_AB_LIB'])
 from models import MonotonicNormalizer
 dev = 'cuda:0'
 for H in [int(a) for a in sys.argv[1:]] or [50]:

@@ -4,6 +4,10 @@ Usage: python tools/bench_sampling.py"""
 import sys, time, torch
 sys.path[:0] = ['/root/repo', '/root/repo/graphical-normalizing-flows_amd']
 import bench
+import os
+if os.environ.get('GNF_AB_LIB'):                      # A/B against another build of the library (tools/*.bin)
+    from gnf_hip import abi
+    abi.LIB_PATH = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), os.environ['GNF_AB_LIB'])
 DEV = "cuda:0"
 flow = bench.build_flow().to(DEV)
 cond = flow.getConditioners()[0]
