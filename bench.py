@@ -343,7 +343,7 @@ def main():
             # 32.5 cycles per v_mfma_f32_16x16x4_f32 + ~3 per VALU instruction, additive at 2, 3 and 4 wavefronts per SIMD),
             # so with V other VALU instructions per MFMA the issue fraction cannot exceed 32.5 / (32.5 + 3 V);
             # V from profiles/r02_cnn_pmc.json (SQ_INSTS_VALU - SQ_INSTS_MFMA) / SQ_INSTS_MFMA
-            v_per_mfma = {"gnf_mnistcnn_conv_bwd": 4.39, "gnf_mnistcnn_conv_fwd": 3.77}[dom]
+            v_per_mfma = {"gnf_mnistcnn_conv_bwd": 4.30, "gnf_mnistcnn_conv_fwd": 3.77}[dom]
             out["roofline"]["valu_per_mfma"] = v_per_mfma
             out["roofline"]["issue_frac_ceiling_shared_alu"] = round(32.5 / (32.5 + 3. * v_per_mfma), 3)
         out["secondary"] = {"fwd_bwd_only_samples_per_s": round(B_PER_GPU * world / t_fb, 1) if t_fb else None,
