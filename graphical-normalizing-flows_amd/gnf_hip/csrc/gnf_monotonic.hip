@@ -610,6 +610,12 @@ __global__ __launch_bounds__(64 * kWaves, (ONES && !INDW) ? 2 : 1) void mono_bwd
   // 4: the forward part of the pack (small vectors, W1h, the untransposed hidden matrices) plus W1h^T resident, W^T read
   //    out of the untransposed matrices as in 3 (54 KB at H <= 64 instead of 89 KB: two workgroups per CU)
   constexpr bool WLDS = WMODE == 1, SWAP = WMODE == 2, RES = WMODE == 3, FRES = WMODE == 4, UNT = SWAP || RES || FRES;
+  // hand-pipelined weight fragments for 6 <= HT <= 8 (H = 81..128, one wavefront per SIMD, both matrices resident): cfg2's
+  // backward 2.38 -> 2.30 ms.  At HT = 10 the second fragment buffer spills (5 -> 65 registers) and buys nothing: that
+  // kernel is bound by its staging traffic, not by LDS latency
+  constexpr bool PIPE = (SWAP || RES) && HT >= 6 && HT <= 8;
+  constexpr int HB = (HT + 1) / 2;                           // fragments per pipeline stage
+  constexpr int NUT = (HT + HB - 1) / HB;                    // stages per k-tile
   const MonoLayout& L = a.L;
   const float* wp = a.pack;
   if (WLDS) {
@@ -752,6 +758,32 @@ __global__ __launch_bounds__(64 * kWaves, (ONES && !INDW) ? 2 : 1) void mono_bwd
         f32x4 o[HT];
 #pragma unroll
         for (int mt = 0; mt < HT; ++mt) o[mt] = ld4(wp + L.o_b[l] + 16 * mt + 4 * q);
+        if constexpr (PIPE) {
+          // wide nets, ONE wavefront per SIMD: nothing hides an LDS round trip, so the weight fragments are double-buffered
+          // by hand in half rows of tiles -- the reads of half row u+1 are issued in front of the MFMAs of half row u
+          // (2 x HB fragments live = the HT of the block-at-a-time form it replaces, which exposed every block's latency)
+          f32x4 Af[2][HB];
+          auto loadA = [&](int u, f32x4 (&dst)[HB]) {
+            const int t = u / NUT, m0 = (u % NUT) * HB;
+#pragma unroll
+            for (int i = 0; i < HB; ++i)
+              if (m0 + i < HT) dst[i] = ld4(W + (16 * (m0 + i) + j) * L.LDW + 16 * t + 4 * q);
+          };
+          loadA(0, Af[0]);
+#pragma unroll
+          for (int u = 0; u < NUT * HT; ++u) {
+            if (u + 1 < NUT * HT) loadA(u + 1, Af[(u + 1) & 1]);
+            __builtin_amdgcn_sched_barrier(0);
+            const int t = u / NUT, m0 = (u % NUT) * HB;
+#pragma unroll
+            for (int i = 0; i < HB; ++i)
+              if (m0 + i < HT) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) o[m0 + i] = mfma(Af[u & 1][i][r], act[t][r], o[m0 + i]);
+              }
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        } else {
 #pragma unroll
         for (int t = 0; t < HT; ++t) {
 #pragma unroll
@@ -762,6 +794,7 @@ __global__ __launch_bounds__(64 * kWaves, (ONES && !INDW) ? 2 : 1) void mono_bwd
           }
           // wide nets: keep the scheduler from hoisting all HT^2 weight fragments (400+ VGPRs) at once
           if constexpr (WMODE != 0) __builtin_amdgcn_sched_barrier(0);   // LDS weights: bound the fragment hoisting (no spills)
+        }
         }
         msk[l] = 0ull;
 #pragma unroll
@@ -835,6 +868,32 @@ __global__ __launch_bounds__(64 * kWaves, (ONES && !INDW) ? 2 : 1) void mono_bwd
         f32x4 da[HT];
 #pragma unroll
         for (int mt = 0; mt < HT; ++mt) da[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if constexpr (PIPE) {
+          f32x4 Af[2][HB];
+          auto loadT = [&](int u, f32x4 (&dst)[HB]) {
+            const int t = u / NUT, m0 = (u % NUT) * HB;
+#pragma unroll
+            for (int i = 0; i < HB; ++i)
+              if (m0 + i < HT) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) dst[i][r] = WT[(16 * t + 4 * q + r) * L.LDW + 16 * (m0 + i) + j];
+              }
+          };
+          loadT(0, Af[0]);
+#pragma unroll
+          for (int u = 0; u < NUT * HT; ++u) {
+            if (u + 1 < NUT * HT) loadT(u + 1, Af[(u + 1) & 1]);
+            __builtin_amdgcn_sched_barrier(0);
+            const int t = u / NUT, m0 = (u % NUT) * HB;
+#pragma unroll
+            for (int i = 0; i < HB; ++i)
+              if (m0 + i < HT) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) da[m0 + i] = mfma(Af[u & 1][i][r], dp[t][r], da[m0 + i]);
+              }
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        } else {
 #pragma unroll
         for (int t = 0; t < HT; ++t) {
 #pragma unroll
@@ -850,6 +909,7 @@ __global__ __launch_bounds__(64 * kWaves, (ONES && !INDW) ? 2 : 1) void mono_bwd
             for (int r = 0; r < 4; ++r) da[mt] = mfma(A[r], dp[t][r], da[mt]);
           }
           if constexpr (WMODE != 0) __builtin_amdgcn_sched_barrier(0);   // LDS weights: bound the fragment hoisting (no spills)
+        }
         }
 #pragma unroll
         for (int t = 0; t < HT; ++t)

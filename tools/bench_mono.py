@@ -1,5 +1,5 @@
-"""Monotonic normalizer kernels at the cfg4 element count (100 x 784, c = 30, S = 20): forward / backward entry-point
-times for a list of hidden widths.    python tools/bench_mono.py 48 50 64"""
+"""Monotonic normalizer kernels at the cfg4 element count (100 x 784, c = 30, S = 20; GNF_MONO_SHAPE=B,d,c,S for others):
+forward / backward entry-point times for a list of hidden widths.    python tools/bench_mono.py 48 50 64"""
 import sys, os, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, ROOT + '/graphical-normalizing-flows_amd']
@@ -10,8 +10,8 @@ from models import MonotonicNormalizer
 dev = 'cuda:0'
 for H in [int(a) for a in sys.argv[1:]] or [50]:
     torch.manual_seed(0)
-    B, d, c = 100, 784, 30
-    norm = MonotonicNormalizer([H, H, H], c, nb_steps=20).to(dev)
+    B, d, c, S = [int(v) for v in os.environ.get('GNF_MONO_SHAPE', '100,784,30,20').split(',')]   # cfg5: 50000,63,30,20
+    norm = MonotonicNormalizer([H, H, H], c, nb_steps=S).to(dev)
     x = torch.randn(B, d, device=dev, requires_grad=True); h = torch.randn(B, d, c, device=dev, requires_grad=True)
     def step():
         for p in norm.parameters(): p.grad = None
