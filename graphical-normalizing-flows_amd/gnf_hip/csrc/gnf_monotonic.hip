@@ -735,6 +735,9 @@ __global__ __launch_bounds__(64 * kWaves, (ONES && !INDW) ? 2 : 1) void mono_bwd
       }
 #pragma unroll
       for (int l = 1; l < NH; ++l) {
+        // the matrix first, the staging stores behind it: a swap ends in s_waitcnt vmcnt(0), which would also wait for
+        // the acknowledgement of stores issued just in front of it (the layer input stays in registers as the B operand)
+        const float* W = UNT ? get_mat(l) : wp + L.o_W[l];
         if constexpr (INDW) {                   // layer input, element-major, into this wavefront's LDS tile
           float* ta = tiles + (l - 1) * 16 * kTS;
 #pragma unroll
@@ -754,7 +757,6 @@ __global__ __launch_bounds__(64 * kWaves, (ONES && !INDW) ? 2 : 1) void mono_bwd
             }
           }
         }
-        const float* W = UNT ? get_mat(l) : wp + L.o_W[l];
         f32x4 o[HT];
 #pragma unroll
         for (int mt = 0; mt < HT; ++mt) o[mt] = ld4(wp + L.o_b[l] + 16 * mt + 4 * q);
@@ -835,6 +837,7 @@ __global__ __launch_bounds__(64 * kWaves, (ONES && !INDW) ? 2 : 1) void mono_bwd
       // ---- hidden->hidden layers, top down
 #pragma unroll
       for (int l = NH - 1; l >= 1; --l) {
+        const float* WT = UNT ? get_mat(l) : wp + L.o_WT[l];      // UNT: the untransposed matrix, read transposed below
         if constexpr (INDW) {
           // dW_l[out][in] += sum over the 16 elements of dpre_l[elem][out] * input_l[elem][in]: K = elements, both
           // operands read back element-major (lane (q, j): element 4 s + q, unit 16 tile + j).  A wave re-running the
@@ -864,7 +867,6 @@ __global__ __launch_bounds__(64 * kWaves, (ONES && !INDW) ? 2 : 1) void mono_bwd
             if constexpr (BREG) p_b[l][t] += dp[t];
           }
         }
-        const float* WT = UNT ? get_mat(l) : wp + L.o_WT[l];      // UNT: the untransposed matrix, read transposed below
         f32x4 da[HT];
 #pragma unroll
         for (int mt = 0; mt < HT; ++mt) da[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
