@@ -185,15 +185,31 @@ def train_step(flow, state, x_shard, lr=1e-3, weight_decay=1e-5, optimizer=hip_a
             state._graphed = gs = GraphedStep(flow, state, x_shard, lr=lr, weight_decay=weight_decay, warmup=1)
             return gs.loss
         return gs(x_shard)
+    loss = accumulate(flow, x_shard)
+    apply_step(state, lr, weight_decay, optimizer)
+    return loss
+
+
+def accumulate(flow, x_shard, scale=1.):
+    """fwd + log|det J| + NLL (+ constraints) + bwd of ONE micro-batch; gradients add up in `.grad` until apply_step().
+    The image driver's gradient accumulation (ImageExperiments.py:205-213: loss / batch_per_optim_step, backward on
+    every batch, optimiser every k-th) is k calls with scale = 1/k followed by one apply_step."""
     z, logdet = flow(x_shard)
     loss = flow.loss(z, logdet)
+    if scale != 1.:
+        loss = loss * scale
     loss.backward()
+    return loss
+
+
+def apply_step(state, lr=1e-3, weight_decay=1e-5, optimizer=hip_adam):
+    """the accumulated gradients into the flat buffer, ONE all-reduce, Adam"""
+    world = dist.get_world_size() if dist.is_initialized() else 1
     state.pack_grads()
     if world > 1:
         all_reduce_sum(state.grad)                  # the step's only collective
     state.t += 1
     optimizer(state, lr, weight_decay, 1. / world)
-    return loss
 
 
 class GraphedStep:
