@@ -573,6 +573,70 @@ __global__ __launch_bounds__(64 * kSplitWaves) void mono_inv_split_k(MonoArgs a)
   }
 }
 
+// The same for the peeled narrow nets (H in {49, 50, 51}: three MFMA tiles + EX units on the VALU, eval2x) with up to
+// TWELVE wavefronts per group: at S = 20 the 11 node pairs get a wavefront each, so a bisection step is ONE pair
+// evaluation (144 MFMAs) instead of two of the padded form (2 x 256) -- the level kernel of MNIST sampling 256 -> see
+// DESIGN.md section 6.  The partial sums are added in the fixed order of the wavefronts, as above.
+constexpr int kSplitWavesX = 12;     // 3 wavefronts per SIMD: 168 registers (at 16 / 128 registers eval2x spills)
+template <int HM, int EX, int WM>
+__global__ __launch_bounds__(64 * kSplitWavesX) void mono_inv_split_x_k(MonoArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const MonoLayout& L = a.L;
+  const float* wp = a.pack;
+  float* psum = smem;                            // [2][nw][16]
+  const int nw = blockDim.x >> 6;                // wavefronts sharing the group (<= kSplitWavesX)
+  if (WM == 1) {
+    for (int i = threadIdx.x * 4; i < L.fwd_floats; i += blockDim.x * 4)
+      *reinterpret_cast<f32x4*>(smem + i) = ld4(a.pack + i);
+    __syncthreads();
+    wp = smem;
+    psum = smem + L.fwd_floats;
+  }
+  auto getW = [&](int l) -> const float* { return wp + L.o_W[l]; };
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int q = lane >> 4, j = lane & 15;
+  const int64_t ngroups = (a.n + 15) / 16;
+  const float fS = (float)a.S;
+  int buf = 0;
+  for (int64_t grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
+    const int64_t e = grp * 16 + j;
+    const bool valid = e < a.n;
+    const int64_t ec = valid ? e : a.n - 1;
+    const int64_t b = ec / a.d, i = ec - b * a.d;
+    const int64_t hbase = b * a.h_sb + i * a.h_sd;
+    f32x4 c1[HM];
+    float c1x[EX];
+    cond_bias_x<HM, EX>(wp, L, a.h, hbase, a.h_sc, q, j, c1, c1x);
+    const float h0 = a.h[hbase];
+    const float zt = a.zt[ec];
+    float xmax = 20.f, xmin = -20.f;
+    for (int it = 0; it < 20; ++it) {
+      const float xm = (xmax + xmin) * .5f;
+      const float xT = fS * (xm / fS);
+      float acc = 0.f;
+      for (int k = 2 * wave; k <= a.S; k += 2 * nw) {
+        const int k1 = k + 1;
+        const float wb = k1 <= a.S ? a.ccw[k1] : 0.f;
+        const float xa = xT * (a.cct[k] + 1.f) * .5f;
+        const float xb = k1 <= a.S ? xT * (a.cct[k1] + 1.f) * .5f : xa;
+        float fa, fb;
+        eval2x<HM, EX>(wp, L, c1, c1x, xa, xb, q, j, fa, fb, getW);
+        acc = fmaf(a.ccw[k], fa, acc);
+        acc = fmaf(wb, fb, acc);
+      }
+      if (q == 0) psum[(buf * nw + wave) * 16 + j] = acc;
+      __syncthreads();
+      const float* ps = psum + buf * nw * 16 + j;
+      float tot = ps[0];
+      for (int w = 1; w < nw; ++w) tot += ps[16 * w];
+      const float zm = tot * xT * .5f + h0;
+      buf ^= 1;
+      if (zm > zt) xmax = xm; else xmin = xm;
+    }
+    if (valid && q == 0 && wave == 0) a.xo[e] = (xmax + xmin) * .5f;
+  }
+}
+
 // ---------------------------------------------------------------------------------------
 // Backward chain kernel.  Vector gradients kept as per-lane partials over the wave's whole
 // persistent loop:  slot 0: d wL, 1: d w1x, 2+l: d b_l (l = 0..NH-1);  + scalar d bL.
@@ -1748,6 +1812,22 @@ int launch_fwd(const MonoArgs& a, hipStream_t s) {
   if (INV && !swap && ngroups <= 512 && a.S >= 7) {
     // fewer groups than a resident wave of workgroups: split the quadrature nodes over the workgroup's wavefronts
     const int pairs = (a.S + 2) / 2;
+    if (a.L.EX > 0) {                                                 // peeled narrow net: up to 16 wavefronts per group
+      const int nwx = pairs < kSplitWavesX ? pairs : kSplitWavesX;
+      const size_t lds_x = (wlds ? lds : 0) + 2 * nwx * 16 * sizeof(float);
+#define GNF_INVX(EX_)                                                                                          \
+      if (wlds) {                                                                                              \
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mono_inv_split_x_k<3, EX_, 1>),               \
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_x);                     \
+        hipLaunchKernelGGL((mono_inv_split_x_k<3, EX_, 1>), dim3((unsigned)ngroups), dim3(64 * nwx), lds_x, s, a); \
+      } else {                                                                                                 \
+        hipLaunchKernelGGL((mono_inv_split_x_k<3, EX_, 0>), dim3((unsigned)ngroups), dim3(64 * nwx), lds_x, s, a); \
+      }
+      if (a.L.EX <= 2) { GNF_INVX(2) } else { GNF_INVX(3) }
+#undef GNF_INVX
+      GNF_LAUNCH_CHECK();
+      return 0;
+    }
     const int nw = pairs < kSplitWaves ? pairs : kSplitWaves;
     const size_t lds_split = (wlds ? lds : 0) + 2 * nw * 16 * sizeof(float);
 #define GNF_INV_CASE(HT_)                                                                                      \
