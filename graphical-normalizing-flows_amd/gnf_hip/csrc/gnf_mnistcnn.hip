@@ -14,15 +14,16 @@ namespace {
 // Backward with both conv2-sized contractions in the Winograd F(2x2,3x3) domain (2.25x fewer MFMAs):
 //   forward   Y = A^T [ sum_c U[o][c] (.) V[c] ] A,  U = G w G^T,  V = B^T d B   (d = 4x4 patch of a1)
 //   dW2:      dU[o][c] = sum_tiles (A dY A^T)[o] (.) V[c],  dw = G^T dU G once at the end of the kernel.
-//             The 2x2 output tile is the pool window, so dY has ONE non-zero g at the saved argmax (py,px):
-//             A dY A^T = g * alpha_py alpha_px^T with alpha_0 = (1,1,1,0), alpha_1 = (0,1,-1,-1) -- read
-//             straight from g_pooled/argmax, no transform.  GEMM per xi: M = o, N = c, K = tiles (144/image).
+//             The 2x2 output tile is the pool window, so dY has ONE non-zero g at the saved argmax (py,px) and
+//             Z = A dY A^T = g * alpha_py alpha_px^T with alpha_0 = (1,1,1,0), alpha_1 = (0,1,-1,-1): a few adds on the
+//             window of the dY2 image in LDS.  GEMM per xi: M = o, N = c, K = tiles (144/image).
 //   da1:      a 3x3 valid correlation of the zero-bordered dY2 (28x28) with the flipped kernel
 //             w'[c][o][a][b] = W2[o][c][2-a][2-b] -> 13x13 tiles of 2x2; U' = G w' G^T lives in LDS (A operand),
 //             the lane transforms its own dY2 patch (B operand); the output transform, ReLU gate, dW1/db1
 //             partials and the per-tap planes T are lane-local as in the direct kernel.
-// conv1 is recomputed in the same tile -> lane mapping (lane (q,j): channels 4q..4q+3 of tile j, 4 sub-positions),
-// so its ReLU gate bits stay in registers for da1.
+// conv1 is recomputed per image as 43 flat tiles of 16 positions dealt over the wavefronts; da1 reads its ReLU gates
+// back from the a1 image.  Per image: {dY2 scatter, de gather of the previous image, conv1} | barrier | {dW2, da1,
+// staging of the next input image} | barrier.
 // ---------------------------------------------------------------------------------------------
 constexpr int NG4 = 11;                              // groups of 16 da1 tiles (13 x 13 = 169 tiles of 2x2)
 constexpr int USZ = 16 * 4 * 64;                     // U' as [xi_y][g][lane][xi_x]
