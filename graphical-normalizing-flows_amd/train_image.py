@@ -104,7 +104,7 @@ def dequantise(u8, alpha, gen):
     noise is drawn anew every time a batch is read."""
     y = (u8.to(torch.float32) + torch.rand(u8.shape, device=u8.device, generator=gen)) / 256.
     y = alpha + (1. - 2. * alpha) * y
-    return torch.log(y) - torch.log1p(-y)
+    return torch.log(y) - torch.log(1. - y)                 # the reference's expression, term by term (fp32)
 
 
 def logit_back(x, alpha):
