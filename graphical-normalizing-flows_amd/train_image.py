@@ -336,35 +336,35 @@ def sample_grids(model, dev, alpha, epoch, folder, say, n_images=16):
         write_pgm(os.path.join(folder, "images_%d_%f.pgm" % (epoch, T)), logit_back(x, alpha))
 
 
+# (flag, default, type / None for a switch, nargs, choices): names and defaults of the reference's driver
+_ARGS = (
+    ("load", False, None, None, None), ("folder", "", str, None, None), ("nb_steps_dual", 100, int, None, None),
+    ("l1", 10., float, None, None), ("nb_epoch", 10000, int, None, None), ("b_size", 1, int, None, None),
+    ("int_net", [50, 50, 50], int, "+", None), ("nb_steps", 20, int, None, None), ("f_number", None, str, None, None),
+    ("solver", "CC", str, None, ["CC", "CCParallel"]), ("nb_flow", [1], int, "+", None), ("test", False, None, None, None),
+    ("weight_decay", 1e-5, float, None, None), ("learning_rate", 1e-3, float, None, None),
+    ("batch_per_optim_step", 1, int, None, None), ("nb_gpus", 1, int, None, None),
+    ("dataset", "MNIST", str, None, ["MNIST", "CIFAR10"] + ["MNIST%d" % k for k in range(10)]),
+    ("normalizer", "Affine", str, None, ["Affine", "Monotonic"]), ("no_hot_encoding", False, None, None, None),
+    ("prior_A_kernel", None, int, None, None), ("conditioner", "DAG", str, None, sorted(COND)),
+    ("emb_net", [100, 100, 100, 10], int, "+", None),
+    # additions of this driver
+    ("max_batches", 0, int, None, None),      # stop an epoch after this many batches (smoke runs; 0: all)
+    ("data_root", ".", str, None, None),      # directory holding MNIST/raw/*-ubyte(.gz), or `synthetic`
+)
+
+
 def parse(argv=None):
-    ap = argparse.ArgumentParser(description="Image density estimation with graphical normalizing flows on MI355X")
-    ap.add_argument("-load", default=False, action="store_true", help="Load a model ?")
-    ap.add_argument("-folder", default="", help="Folder")
-    ap.add_argument("-nb_steps_dual", default=100, type=int,
-                    help="number of step between updating Acyclicity constraint and sparsity constraint")
-    ap.add_argument("-l1", default=10., type=float, help="Maximum weight for l1 regularization")
-    ap.add_argument("-nb_epoch", default=10000, type=int, help="Number of epochs")
-    ap.add_argument("-b_size", default=1, type=int, help="Batch size (rows per GPU)")
-    ap.add_argument("-int_net", default=[50, 50, 50], nargs="+", type=int, help="NN hidden layers of UMNN")
-    ap.add_argument("-nb_steps", default=20, type=int, help="Number of integration steps.")
-    ap.add_argument("-f_number", default=None, type=str, help="Checkpoint suffix to load")
-    ap.add_argument("-solver", default="CC", type=str, choices=["CC", "CCParallel"])
-    ap.add_argument("-nb_flow", default=[1], nargs="+", type=int, help="Number of steps in the flow.")
-    ap.add_argument("-test", default=False, action="store_true")
-    ap.add_argument("-weight_decay", default=1e-5, type=float)
-    ap.add_argument("-learning_rate", default=1e-3, type=float)
-    ap.add_argument("-batch_per_optim_step", default=1, type=int, help="Number of batch to accumulate")
-    ap.add_argument("-nb_gpus", default=1, type=int, help="ignored: the world size comes from torchrun")
-    ap.add_argument("-dataset", default="MNIST", type=str,
-                    choices=["MNIST", "CIFAR10"] + ["MNIST%d" % k for k in range(10)])
-    ap.add_argument("-normalizer", default="Affine", type=str, choices=["Affine", "Monotonic"])
-    ap.add_argument("-no_hot_encoding", default=False, action="store_true")
-    ap.add_argument("-prior_A_kernel", default=None, type=int)
-    ap.add_argument("-conditioner", default="DAG", choices=sorted(COND), type=str)
-    ap.add_argument("-emb_net", default=[100, 100, 100, 10], nargs="+", type=int, help="NN layers of embedding")
-    ap.add_argument("-max_batches", default=0, type=int, help="stop an epoch after this many batches (smoke runs; 0: all)")
-    ap.add_argument("-data_root", default=".", type=str,
-                    help="directory holding MNIST/raw/*-ubyte(.gz) (torchvision layout), or `synthetic`")
+    ap = argparse.ArgumentParser(description="image density estimation with graphical normalizing flows on MI355X "
+                                             "(b_size = rows per GPU; nb_gpus is ignored, the launcher sets the world size)")
+    for name, default, typ, nargs, choices in _ARGS:
+        if typ is None:
+            ap.add_argument("-" + name, default=default, action="store_true")
+        else:
+            kw = {"nargs": nargs} if nargs else {}
+            if choices:
+                kw["choices"] = choices
+            ap.add_argument("-" + name, default=default, type=typ, **kw)
     args = ap.parse_args(argv)
     if not args.folder:
         args.folder = os.path.join(args.dataset, time.strftime("%m_%d_%Y_%H_%M_%S"))
