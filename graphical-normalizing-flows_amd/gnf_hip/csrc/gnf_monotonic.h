@@ -1,0 +1,110 @@
+// Internal (not part of the C ABI): layout of the padded weight image, argument block and device helpers shared by
+// the Monotonic-normalizer translation units (gnf_monotonic.hip, gnf_monotonic_wide.hip).
+#pragma once
+#include "gnf_common.h"
+
+namespace gnfmono {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int kWaves = 4;          // wavefronts per workgroup
+constexpr int kMaxNH = GNF_MONO_MAX_LAYERS - 1;
+
+// ---------------------------------------------------------------------------------------
+// Padded weight image ("pack"): every matrix row-major with leading dimension LD = pad+4
+// floats (keeps float4 fragment reads 16-B aligned and staggers LDS banks).
+// ---------------------------------------------------------------------------------------
+struct MonoLayout {
+  int HT, HP, NH, c, CP, LDH, LDW;
+  int HM, EX;                         // "peeled" narrow nets (all hidden widths H, H mod 16 in {1,2,3}): HM = H / 16 full
+                                      // tiles on the MFMA, EX = H mod 16 units on the VALU (0, 0 otherwise)
+  int o_w1x, o_b1, o_wL, o_bL, o_W1h;
+  int o_W[kMaxNH], o_b[kMaxNH];       // hidden->hidden layers l = 1..NH-1
+  int fwd_floats;                     // prefix used by forward / inverse
+  int o_WT[kMaxNH], o_W1hT;           // transposes, backward only
+  int total_floats;                   // end of the row-major image (what the LDS-resident kernels copy)
+  // Fragment-major copies of the hidden->hidden matrices for the kernels that stream weights from L2 as MFMA A operands
+  // (gnf_monotonic_wide.hip; HT >= 7 only): fragment (mt, t) = 256 consecutive floats, lane (q, j) owns floats 4 lane .. +3
+  //   Wf [l][mt][t][lane][r] = W_l[16 mt + j][16 t + 4 q + r]       (forward:   out tile mt, k tile t)
+  //   WTf[l][mt][t][lane][r] = W_l[16 t + 4 q + r][16 mt + j]       (backward:  in tile mt,  k tile t over the out units)
+  // so that one global_load_dwordx4 per lane fetches a whole fragment as 1 KB of consecutive bytes.
+  int o_Wf[kMaxNH], o_WTf[kMaxNH];
+  int pack_floats;                    // size of the whole pack
+};
+
+__host__ __device__ inline MonoLayout make_layout(int HT, int NH, int c) {
+  MonoLayout L;
+  L.HT = HT; L.HP = 16 * HT; L.NH = NH; L.c = c; L.HM = 0; L.EX = 0;
+  L.CP = (c + 15) / 16 * 16; L.LDH = L.CP + 4; L.LDW = L.HP + 4;
+  int o = 0;
+  L.o_w1x = o; o += L.HP;
+  L.o_b1 = o; o += L.HP;
+  L.o_wL = o; o += L.HP;
+  L.o_bL = o; o += 4;
+  L.o_W1h = o; o += L.HP * L.LDH;
+  for (int l = 1; l < NH; ++l) { L.o_W[l] = o; o += L.HP * L.LDW; L.o_b[l] = o; o += L.HP; }
+  L.fwd_floats = o;
+  for (int l = 1; l < NH; ++l) { L.o_WT[l] = o; o += L.HP * L.LDW; }
+  L.o_W1hT = o; o += L.CP * L.LDW;
+  L.total_floats = o;
+  for (int l = 1; l < NH; ++l) { L.o_Wf[l] = 0; L.o_WTf[l] = 0; }
+  if (HT >= 7) {
+    for (int l = 1; l < NH; ++l) { L.o_Wf[l] = o; o += L.HP * L.HP; L.o_WTf[l] = o; o += L.HP * L.HP; }
+  }
+  L.pack_floats = o;
+  return L;
+}
+
+struct MonoArgs {
+  const float* pack; MonoLayout L;
+  const float* x; const float* h; int64_t h_sb, h_sd, h_sc;
+  const float* ccw; const float* cct; int S;
+  float* z; float* jac;                 // forward outputs
+  const float* zt; float* xo;           // inverse: target z, output x
+  int64_t n, d;                         // n = B*d elements
+  // backward
+  const float* gz; const float* gjac; float* gx; float* gh; int64_t g_sb, g_sd, g_sc;
+  float* SA[kMaxNH]; float* SD[kMaxNH]; float* Dsum; float* part;
+  int64_t e0, ecount;                   // element chunk [e0, e0+ecount)
+  int NK;                               // node slots per group (S+2 rounded up to even)
+  int ones;                             // backward: bias gradients of the hidden layers via a ones column (see mono_bwd_k)
+  int indw;                             // backward: weight gradients accumulated in the chain kernel (1, 2: narrow nets;
+                                        // 3: wide nets, gnf_monotonic_wide.hip)
+  float* wpart;                         // [workgroups * kWaves][(NH-1) * HP * HP] accumulator rows of that variant
+                                        // (indw = 3: one row per workgroup)
+};
+
+__device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+// 16 B per lane global -> LDS without passing through registers (global_load_lds_dwordx4): the LDS destination of a
+// wave-instruction is lane-linear, which a contiguous copy is.  Completion: s_waitcnt vmcnt(0) before the barrier.
+__device__ __forceinline__ void glds16(const float* g, float* l) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                   (__attribute__((address_space(3))) void*)l, 16, 0, 0);
+}
+__device__ __forceinline__ f32x4 mfma(float a, float b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+// sum over the 4 lane-slots q (lanes j, j+16, j+32, j+48), result in all of them.  gfx950's v_permlane16_swap /
+// v_permlane32_swap exchange 16- / 32-lane rows between two registers on the VALU: swapping a value with its own copy
+// leaves (row, neighbour row) side by side, one add finishes the level -- no trip through the LDS crossbar
+// (ds_bpermute, ~100 cycles of latency per level in the dependent chain of every node evaluation).
+__device__ __forceinline__ float qsum(float v) {
+  auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  v = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+  r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+__device__ __forceinline__ float jsum(float v) {   // sum over the 16 elements of a lane-slot
+  v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 8, 64);
+  return v;
+}
+__device__ __forceinline__ float elu_plus(float s) { return (s > 0.f ? s : expm1f(s)) + 1.05f; }
+
+}  // namespace gnfmono
+
+// gnf_monotonic_wide.hip: backward of wide integrand nets (H = 97..160) with the hidden state of a batch of (element, node)
+// pairs in LDS, the output units split over the wavefronts and every weight gradient accumulated in registers.
+// ok(): the net's shape has an instantiation and its LDS plan fits.  grid(): persistent workgroups (= rows of a.wpart).
+bool gnf_mono_bwd_wide_ok(const gnfmono::MonoLayout& L);
+unsigned gnf_mono_bwd_wide_grid(const gnfmono::MonoLayout& L, int64_t n);
+int gnf_mono_bwd_wide_launch(const gnfmono::MonoArgs& a, unsigned grid, hipStream_t s);

@@ -28,47 +28,12 @@
 // the split-K fp32 MFMA GEMM (gnf_gemm.hip) contracts them, chunk by chunk.
 #include "gnf_common.h"
 #include "gnf_gemm.h"
+#include "gnf_monotonic.h"
 #include <cstdlib>
 
 namespace {
 
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-
-constexpr int kWaves = 4;          // wavefronts per workgroup
-constexpr int kMaxNH = GNF_MONO_MAX_LAYERS - 1;
-
-// ---------------------------------------------------------------------------------------
-// Padded weight image ("pack"): every matrix row-major with leading dimension LD = pad+4
-// floats (keeps float4 fragment reads 16-B aligned and staggers LDS banks).
-// ---------------------------------------------------------------------------------------
-struct MonoLayout {
-  int HT, HP, NH, c, CP, LDH, LDW;
-  int HM, EX;                         // "peeled" narrow nets (all hidden widths H, H mod 16 in {1,2,3}): HM = H / 16 full
-                                      // tiles on the MFMA, EX = H mod 16 units on the VALU (0, 0 otherwise)
-  int o_w1x, o_b1, o_wL, o_bL, o_W1h;
-  int o_W[kMaxNH], o_b[kMaxNH];       // hidden->hidden layers l = 1..NH-1
-  int fwd_floats;                     // prefix used by forward / inverse
-  int o_WT[kMaxNH], o_W1hT;           // transposes, backward only
-  int total_floats;
-};
-
-__host__ __device__ inline MonoLayout make_layout(int HT, int NH, int c) {
-  MonoLayout L;
-  L.HT = HT; L.HP = 16 * HT; L.NH = NH; L.c = c; L.HM = 0; L.EX = 0;
-  L.CP = (c + 15) / 16 * 16; L.LDH = L.CP + 4; L.LDW = L.HP + 4;
-  int o = 0;
-  L.o_w1x = o; o += L.HP;
-  L.o_b1 = o; o += L.HP;
-  L.o_wL = o; o += L.HP;
-  L.o_bL = o; o += 4;
-  L.o_W1h = o; o += L.HP * L.LDH;
-  for (int l = 1; l < NH; ++l) { L.o_W[l] = o; o += L.HP * L.LDW; L.o_b[l] = o; o += L.HP; }
-  L.fwd_floats = o;
-  for (int l = 1; l < NH; ++l) { L.o_WT[l] = o; o += L.HP * L.LDW; }
-  L.o_W1hT = o; o += L.CP * L.LDW;
-  L.total_floats = o;
-  return L;
-}
+using namespace gnfmono;
 
 struct PackArgs {
   gnf_mono_net net;
@@ -79,8 +44,23 @@ __global__ void mono_pack_k(PackArgs a, float* __restrict__ pack) {
   const MonoLayout& L = a.L;
   const gnf_mono_net& N = a.net;
   const int H0 = N.dims[1];
-  for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < L.total_floats; idx += gridDim.x * blockDim.x) {
+  for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < L.pack_floats; idx += gridDim.x * blockDim.x) {
     float v = 0.f;
+    if (idx >= L.total_floats) {                  // fragment-major copies of the hidden->hidden matrices (see MonoLayout)
+      for (int l = 1; l < L.NH; ++l) {
+        const bool tr = idx >= L.o_WTf[l];
+        const int k = idx - (tr ? L.o_WTf[l] : L.o_Wf[l]);
+        if (k < 0 || k >= L.HP * L.HP) continue;
+        const int frag = k >> 8, lane = (k >> 2) & 63, r = k & 3, mt = frag / L.HT, t = frag - mt * L.HT;
+        const int q = lane >> 4, j = lane & 15;
+        const int row = tr ? 16 * t + 4 * q + r : 16 * mt + j;     // out unit
+        const int col = tr ? 16 * mt + j : 16 * t + 4 * q + r;     // in unit
+        if (row < N.dims[l + 1] && col < N.dims[l]) v = N.W[l][(int64_t)row * N.dims[l] + col];
+        break;
+      }
+      pack[idx] = v;
+      continue;
+    }
     if (idx < L.o_b1) { const int k = idx - L.o_w1x; if (k < H0) v = N.W[0][(int64_t)k * N.dims[0]]; }
     else if (idx < L.o_wL) { const int k = idx - L.o_b1; if (k < H0) v = N.b[0][k]; }
     else if (idx < L.o_bL) { const int k = idx - L.o_wL; if (k < N.dims[L.NH]) v = N.W[L.NH][k]; }
@@ -111,49 +91,6 @@ __global__ void mono_pack_k(PackArgs a, float* __restrict__ pack) {
     pack[idx] = v;
   }
 }
-
-struct MonoArgs {
-  const float* pack; MonoLayout L;
-  const float* x; const float* h; int64_t h_sb, h_sd, h_sc;
-  const float* ccw; const float* cct; int S;
-  float* z; float* jac;                 // forward outputs
-  const float* zt; float* xo;           // inverse: target z, output x
-  int64_t n, d;                         // n = B*d elements
-  // backward
-  const float* gz; const float* gjac; float* gx; float* gh; int64_t g_sb, g_sd, g_sc;
-  float* SA[kMaxNH]; float* SD[kMaxNH]; float* Dsum; float* part;
-  int64_t e0, ecount;                   // element chunk [e0, e0+ecount)
-  int NK;                               // node slots per group (S+2 rounded up to even)
-  int ones;                             // backward: bias gradients of the hidden layers via a ones column (see mono_bwd_k)
-  int indw;                             // backward: weight gradients accumulated in the chain kernel (narrow nets)
-  float* wpart;                         // [workgroups * kWaves][(NH-1) * HP * HP] accumulator rows of that variant
-};
-
-__device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
-// 16 B per lane global -> LDS without passing through registers (global_load_lds_dwordx4): the LDS destination of a
-// wave-instruction is lane-linear, which a contiguous copy is.  Completion: s_waitcnt vmcnt(0) before the barrier.
-__device__ __forceinline__ void glds16(const float* g, float* l) {
-  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
-                                   (__attribute__((address_space(3))) void*)l, 16, 0, 0);
-}
-__device__ __forceinline__ f32x4 mfma(float a, float b, f32x4 c) {
-  return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
-}
-// sum over the 4 lane-slots q (lanes j, j+16, j+32, j+48), result in all of them.  gfx950's v_permlane16_swap /
-// v_permlane32_swap exchange 16- / 32-lane rows between two registers on the VALU: swapping a value with its own copy
-// leaves (row, neighbour row) side by side, one add finishes the level -- no trip through the LDS crossbar
-// (ds_bpermute, ~100 cycles of latency per level in the dependent chain of every node evaluation).
-__device__ __forceinline__ float qsum(float v) {
-  auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
-  v = __uint_as_float(r[0]) + __uint_as_float(r[1]);
-  r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
-  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
-}
-__device__ __forceinline__ float jsum(float v) {   // sum over the 16 elements of a lane-slot
-  v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 8, 64);
-  return v;
-}
-__device__ __forceinline__ float elu_plus(float s) { return (s > 0.f ? s : expm1f(s)) + 1.05f; }
 
 // c1[t][r] = b1[hid] + sum_cc W1h[hid][cc] * h[elem][cc],  hid = 16t+4q+r   (MFMA, once per group)
 template <int HT>
@@ -2100,7 +2037,9 @@ bool use_indw(const gnf_mono_net* net, const MonoLayout& L) {
 }
 constexpr unsigned kInDwGrid = 256;           // one workgroup per CU (512 registers per wavefront)
 
-BwdPlan plan_bwd(const MonoLayout& L, int S, int64_t n, int64_t ws_floats, bool indw = false) {
+// indw: 0 staged weight gradients; 1 narrow in-kernel (one accumulator row per wavefront); 2 wide in-kernel
+// (gnf_monotonic_wide.hip: one accumulator row per workgroup)
+BwdPlan plan_bwd(const MonoLayout& L, int S, int64_t n, int64_t ws_floats, int indw = 0) {
   BwdPlan P;
   const int64_t HP = L.HP, NK = (S + 2 + 1) / 2 * 2;
   const int64_t vecw = (L.NH + 2) * HP + 4;
@@ -2115,7 +2054,7 @@ BwdPlan plan_bwd(const MonoLayout& L, int S, int64_t n, int64_t ws_floats, bool 
   P.o_vec = fixed; fixed += vecw;
   P.o_rs = fixed; fixed += (int64_t)kRowsumChunks * HP;     // scratch of the tall row-sums (bias gradients)
   P.o_wpart = fixed;
-  if (indw) fixed += (int64_t)kInDwGrid * kWaves * (L.NH - 1) * HP * HP;
+  if (indw) fixed += (int64_t)kInDwGrid * (indw == 2 ? 1 : kWaves) * (L.NH - 1) * HP * HP;
   const int64_t per_elem = indw ? HP : (int64_t)(L.NH - 1) * 2 * NK * HP + HP;     // SA+SD per hidden layer, Dsum
   int64_t ce = (n + 15) / 16 * 16;
   if (ws_floats > 0) {
@@ -2141,7 +2080,7 @@ extern "C" {
 int64_t gnf_monotonic_pack_floats(const gnf_mono_net* net) {
   const int HT = pick_ht(net);
   if (HT < 0) return GNF_ESHAPE;
-  return net_layout(net, HT).total_floats;
+  return net_layout(net, HT).pack_floats;
 }
 
 int gnf_monotonic_pack(const gnf_mono_net* net, float* pack, gnf_stream_t stream) {
@@ -2151,7 +2090,7 @@ int gnf_monotonic_pack(const gnf_mono_net* net, float* pack, gnf_stream_t stream
   PackArgs a;
   a.net = *net;
   a.L = net_layout(net, HT);
-  hipLaunchKernelGGL(mono_pack_k, dim3((a.L.total_floats + 255) / 256), dim3(256), 0, (hipStream_t)stream, a, pack);
+  hipLaunchKernelGGL(mono_pack_k, dim3((a.L.pack_floats + 255) / 256), dim3(256), 0, (hipStream_t)stream, a, pack);
   GNF_LAUNCH_CHECK();
   return 0;
 }
@@ -2190,7 +2129,7 @@ int64_t gnf_monotonic_bwd_ws_bytes(const gnf_mono_net* net, int S, int64_t B, in
   const int HT = pick_ht(net);
   if (HT < 0) return GNF_ESHAPE;
   const MonoLayout L = net_layout(net, HT);
-  const bool indw = use_indw(net, L);
+  const int indw = use_indw(net, L) ? 1 : (gnf_mono_bwd_wide_ok(L) ? 2 : 0);
   if (B < 1) B = 1;                          // an empty batch needs no workspace; keep the plan arithmetic away from 0
   const BwdPlan full = plan_bwd(L, S, B * d, 0, indw);
   const int64_t want = full.total_floats * (int64_t)sizeof(float);
@@ -2225,8 +2164,9 @@ int gnf_monotonic_bwd(const float* pack, const gnf_mono_net* net, const float* x
   hipStream_t s = (hipStream_t)stream;
   const MonoLayout L = net_layout(net, HT);
   const int64_t n = B * d;
-  const bool indw = use_indw(net, L);
-  const BwdPlan P = plan_bwd(L, S, n, ws_bytes / (int64_t)sizeof(float), indw);
+  const bool wide = gnf_mono_bwd_wide_ok(L);       // wide nets: hidden state in LDS, weight gradients in registers
+  const bool indw = use_indw(net, L) || wide;
+  const BwdPlan P = plan_bwd(L, S, n, ws_bytes / (int64_t)sizeof(float), wide ? 2 : (indw ? 1 : 0));
   if (P.chunk_elems < 16) return GNF_EWS;
   float* w = (float*)ws;
   const int64_t HP = L.HP, NK = (S + 2 + 1) / 2 * 2;
@@ -2240,33 +2180,38 @@ int gnf_monotonic_bwd(const float* pack, const gnf_mono_net* net, const float* x
   a.Dsum = w + P.o_Dsum; a.part = w + P.o_part; a.NK = (int)NK;
   a.ones = HT <= 4 && NH > 1;
   for (int l = 1; l < NH; ++l) a.ones = a.ones && net->dims[l] < HP;
-  a.indw = indw;
-  if (indw) {                                     // the two-node kernel when its LDS plan fits (A/B: GNF_MONO_INDW=1 keeps one node)
+  a.indw = wide ? 3 : (int)indw;
+  if (indw && !wide) {                            // the two-node kernel when its LDS plan fits (A/B: GNF_MONO_INDW=1 keeps one node)
     const size_t lds_pair = ((size_t)L.o_W1h + (size_t)(NH - 1) * (2 * L.HP * L.LDW + L.HP) +
                              (size_t)kWaves * (2 * (NH - 1) + 1) * 16 * kTS) * sizeof(float);
     static const bool one = getenv("GNF_MONO_INDW") && getenv("GNF_MONO_INDW")[0] == '1';
     if (lds_pair <= (size_t)160 * 1024 && !one) a.indw = 2;
   }
   a.wpart = w + P.o_wpart;
-  const unsigned bwd_grid = indw ? kInDwGrid : kBwdGrid;
+  const unsigned bwd_grid = wide ? gnf_mono_bwd_wide_grid(L, n < P.chunk_elems ? n : P.chunk_elems)
+                                 : (indw ? kInDwGrid : kBwdGrid);
 
   auto rowsum = [&](const float* src, float* out, int64_t Pn, int64_t N, int acc) -> int {
     return gnf_rowsum_launch(src, out, Pn, N, acc, s);
   };
   const int64_t nchunks = (n + P.chunk_elems - 1) / P.chunk_elems;
   const int64_t part_rows = (int64_t)bwd_grid * kWaves;
+  const int64_t wpart_rows = wide ? (int64_t)bwd_grid : part_rows;
   int64_t nsp_w = 1, nsp_h = 1;
   int rc = 0;
   for (int64_t ck = 0; ck < nchunks; ++ck) {
     a.e0 = ck * P.chunk_elems;
     a.ecount = n - a.e0 < P.chunk_elems ? n - a.e0 : P.chunk_elems;
-    if ((rc = launch_bwd(a, bwd_grid, s))) return rc;
+    if (wide) {                        // its wavefronts write only their own half of the partial rows
+      if (hipMemsetAsync(a.part, 0, sizeof(float) * part_rows * vecw, s) != hipSuccess) return GNF_EINVAL;
+      if ((rc = gnf_mono_bwd_wide_launch(a, bwd_grid, s))) return rc;
+    } else if ((rc = launch_bwd(a, bwd_grid, s))) return rc;
     const int64_t groups = (a.ecount + 15) / 16;
     const int64_t rows = groups * NK * 16;
     const int accum = ck > 0 ? GNF_GEMM_ACCUM : 0;     // chunk 0 is the largest: it defines the split count
     // d W_l (+)= dpre_l^T * act_{l-1}   (split-K partials, accumulated across chunks)
     if (indw) {                        // the chain kernel's accumulator rows -> dW (accumulated across chunks)
-      if ((rc = rowsum(a.wpart, w + P.o_dW[1], part_rows, (int64_t)(NH - 1) * HP * HP, ck > 0))) return rc;
+      if ((rc = rowsum(a.wpart, w + P.o_dW[1], wpart_rows, (int64_t)(NH - 1) * HP * HP, ck > 0))) return rc;
     }
     for (int l = 1; l < NH && !indw; ++l) {
       if (HT == 7 || HT == 10) {       // wide nets: one pass over the staged rows, bias gradient fused
@@ -2305,7 +2250,7 @@ int gnf_monotonic_bwd(const float* pack, const gnf_mono_net* net, const float* x
           if ((rc = gnf_rowsum_tall_launch(a.SD[l], w + P.o_vec + (2 + l) * HP, rows, HP, 1, w + P.o_rs, s))) return rc;
     }
   }
-  if (HT == 7 || HT == 10)             // bias gradients of the hidden->hidden layers: partial column sums of mono_dw_k
+  if ((HT == 7 || HT == 10) && !wide)  // bias gradients of the hidden->hidden layers: partial column sums of mono_dw_k
     for (int l = 1; l < NH; ++l)
       if ((rc = rowsum(w + P.o_bpart[l], w + P.o_vec + (2 + l) * HP, kDwGrid, HP, 1))) return rc;
   UnpackArgs u{};

@@ -1,0 +1,522 @@
+// Monotonic (UMNN) normalizer, backward of WIDE integrand nets (hidden widths 113..160, e.g. BASELINE cfg5's
+// [150,150,150]): models/Normalizers/MonotonicNormalizer.py:21-66 + the UMNN 1.0 backward (Leibniz rule for x, quadrature
+// of df/dh and df/dtheta), restated in oracle/gnf_oracle.py.
+//
+// Why a second formulation.  gnf_monotonic.hip gives every wavefront 16 elements and chains the hidden state of ONE
+// quadrature node through the MFMA C/D registers.  At H = 150 that costs 484 registers, the two 105 KB hidden matrices
+// must be swapped through LDS twice per node (four workgroup barriers), and the hidden->hidden weight gradients do not
+// fit anywhere: layer inputs and dpre were staged to HBM (2 560 B per (element, node), 177 GB per cfg5 step) and
+// contracted by a second kernel -- 354 GB of traffic for 0.8 GB of algorithmic bytes.
+//
+// Here the roles are turned around:
+//  * A workgroup (4 wavefronts, one per SIMD, one workgroup per CU) walks groups of 32 elements and, per step, a BATCH
+//    of 64 (element, node) pairs = 32 elements x 2 quadrature nodes.  The hidden state of the batch lives in LDS,
+//    pair-major ([64][HP + 4] floats per layer): exactly the B operand a layer needs (one ds_read_b128 = 4 K-steps).
+//  * A layer is out[HP x 64] = W[HP x HP] act[HP x 64].  The OUTPUT units are split over the wavefronts: wavefront
+//    (mh, nh) owns HT/2 of the HT out tiles and the 32 pairs of node nh, so every weight fragment it fetches feeds 8
+//    MFMAs and every activation read 20.  Weights are never LDS-resident: they stream from L2 as ready-made A fragments
+//    (1 KB of consecutive bytes per wave-instruction, MonoLayout::o_Wf / o_WTf), double-buffered in registers under the
+//    40 MFMAs of the previous k-tile -- with the state in LDS there are registers to spare for that.
+//  * dW_l = sum over pairs of dpre_l (x) input_l is an MFMA contraction with K = the 64 pairs of the batch, both operands
+//    read back from the same LDS buffers (ds_read_b32, transposed view).  The HT x HT accumulator tiles of a layer are
+//    dealt over the four wavefronts ((HT/2)^2 tiles = 100 registers per layer and wavefront at HT = 10) and stay in
+//    registers for the whole persistent loop.  NOTHING per (element, node) goes to HBM.
+//  * Bias / first / last layer gradients: per-lane partials; the first layer's dpre summed over the nodes (Dsum, per
+//    element) is written once per element for the d W1h GEMM of the caller, as in gnf_monotonic.hip.
+// Work per batch and wavefront at H = 150, 3 hidden layers: 2 400 MFMAs (recompute 800, data gradient 800, weight
+// gradient 800), 7 workgroup barriers, ~200 global fragment loads, ~500 LDS accesses.
+#include "gnf_common.h"
+#include "gnf_monotonic.h"
+#include <cstdlib>
+
+namespace {
+
+using namespace gnfmono;
+
+constexpr int kGE = 32;            // elements per group
+constexpr int kNP = 64;            // (element, node) pairs per batch: node slot nh = pair / 32, element = pair % 32
+
+// LDS plan (floats)
+template <int HT, int NH>
+struct WidePlan {
+  static constexpr int HP = 16 * HT, P = HP + 4;           // P: row pitch of the pair-major buffers
+  static constexpr int o_w1x = 0, o_wL = HP, o_b = 2 * HP;  // b_l at o_b + (l-1) HP, l = 1..NH-1
+  static constexpr int o_bL = o_b + (NH - 1) * HP;
+  static constexpr int o_c1 = o_bL + 4;                     // [32][P]  W1h h + b1 of the group's elements
+  static constexpr int o_act = o_c1 + kGE * P;              // input of hidden layer l at o_act + (l-1) 64 P
+  static constexpr int o_dp = o_act + (NH - 1) * kNP * P;   // [64][P]  dpre of the layer being back-propagated
+  static constexpr int o_sred = o_dp + kNP * P;             // [2][64]  last-layer partial dot products per out half
+  static constexpr int o_sx = o_sred + 2 * kNP;             // [2][32]  df/dx partials of the Jacobian node
+  static constexpr int total = o_sx + 2 * kGE;
+};
+
+// A fragment of the pack through a buffer descriptor: descriptor and fragment offset (soff, bytes) in SGPRs, 16 lane
+// bytes in ONE VGPR -- no 64-bit per-lane addresses (flat loads reach +-4 KB by immediate, a matrix is 100 KB: hipcc
+// hoisted two dozen address pairs per matrix out of the node loop and spilled them)
+// Values the compiler must not recognise as loop-invariant: everything derived from them (fragment offsets, the small
+// vectors w1x / wL / b_l in LDS) would otherwise be hoisted out of the node loop and held in registers -- 80 VGPRs of
+// hoisted LDS reads and 200 SGPR offsets in the first build of this kernel, spilled in turn.
+__device__ __forceinline__ int opaque_v(int x) { asm volatile("" : "+v"(x)); return x; }
+__device__ __forceinline__ int opaque_s(int x) { asm volatile("" : "+s"(x)); return x; }
+typedef __amdgpu_buffer_rsrc_t rsrc_t;
+__device__ __forceinline__ f32x4 ldfrag(rsrc_t rs, int voff, int soff) {
+  typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+  const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, soff, 0);
+  return __builtin_bit_cast(f32x4, v);
+}
+
+// One pass over a hidden->hidden matrix: acc[mi][s] += sum_k A(m0 + mi, k) B(k, the wavefront's 16 pairs of node slot s).
+//   rs, voff, soff : fragment (m0, 0) of the matrix (global, L2); fragment (mi, t) sits (mi HT + t) KB further
+//   bsrc : LDS address of (pair (slot 0, element j), unit 4 q); slot 1 adds 32 P, k-tile t adds 16
+// Fragments of k-tile t+1 are requested in front of the MFMAs of k-tile t.
+template <int HT, int MC, int P>
+__device__ __forceinline__ void layer_pass(rsrc_t rs, int voff, int soff, const float* bsrc, f32x4 (&acc)[MC][2]) {
+  f32x4 A[2][MC], B[2][2];
+#pragma unroll
+  for (int mi = 0; mi < MC; ++mi) A[0][mi] = ldfrag(rs, voff, soff + (mi * HT) * 1024);
+#pragma unroll
+  for (int sl = 0; sl < 2; ++sl) B[0][sl] = ld4(bsrc + sl * kGE * P);
+#pragma unroll
+  for (int t = 0; t < HT; ++t) {
+    if (t + 1 < HT) {
+#pragma unroll
+      for (int mi = 0; mi < MC; ++mi) A[(t + 1) & 1][mi] = ldfrag(rs, voff, soff + (mi * HT + t + 1) * 1024);
+#pragma unroll
+      for (int sl = 0; sl < 2; ++sl) B[(t + 1) & 1][sl] = ld4(bsrc + sl * kGE * P + 16 * (t + 1));
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int mi = 0; mi < MC; ++mi)
+#pragma unroll
+        for (int sl = 0; sl < 2; ++sl) acc[mi][sl] = mfma(A[t & 1][mi][r], B[t & 1][sl][r], acc[mi][sl]);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
+// In-place MFMA for the long-lived weight-gradient accumulators.  The builtin leaves vdst and srcC untied; with 200 of the
+// 256 registers holding accumulators the allocator then splits their live ranges (v_mov chains through the whole tile
+// set and scratch spills in the first build of the role).  Tied through the "+v" constraint every tile stays where it is.
+// Nothing reads a tile between its MFMAs except other MFMAs on it (the hardware interlocks those); the stores at the
+// end of the kernel sit behind workgroup barriers.
+__device__ __forceinline__ void mfma_acc(float a, float b, f32x4& c) {
+  asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b));
+}
+
+// Weight-gradient tiles of one layer: accW[a][b] += sum over the 64 pairs of dpre[pair][16 (ti0+a) + .] (x) in[pair][16 (tn0+b) + .]
+//   dsrc : dp buffer  + q P + 16 ti0 + j   (lane (q, j) reads pair 4 s + q of K-step s)
+//   asrc : act buffer + q P + 16 tn0 + j
+// pb[a] += the dpre operands themselves: summed over the K-steps here and over q by the caller they are the column sums of
+// dpre, i.e. the bias gradient of the tiles' out units.
+template <int TI, int TN, int P>
+__device__ __forceinline__ void dw_pass(const float* dsrc, const float* asrc, f32x4 (&accW)[TI][TN], float (&pb)[TI]) {
+  float fa[2][TI], fb[2][TN];
+#pragma unroll
+  for (int a = 0; a < TI; ++a) fa[0][a] = dsrc[16 * a];
+#pragma unroll
+  for (int b = 0; b < TN; ++b) fb[0][b] = asrc[16 * b];
+#pragma unroll
+  for (int s = 0; s < kNP / 4; ++s) {
+    if (s + 1 < kNP / 4) {
+#pragma unroll
+      for (int a = 0; a < TI; ++a) fa[(s + 1) & 1][a] = dsrc[4 * (s + 1) * P + 16 * a];
+#pragma unroll
+      for (int b = 0; b < TN; ++b) fb[(s + 1) & 1][b] = asrc[4 * (s + 1) * P + 16 * b];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int a = 0; a < TI; ++a)
+#pragma unroll
+      for (int b = 0; b < TN; ++b) mfma_acc(fa[s & 1][a], fb[s & 1][b], accW[a][b]);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int a = 0; a < TI; ++a)                      // volatile: left to itself the compiler sinks all 80 additions of a pass
+      asm volatile("v_add_f32 %0, %0, %1" : "+v"(pb[a]) : "v"(fa[s & 1][a]));   // to its end and spills their operands
+  }
+}
+
+constexpr int kWideWaves = 8;      // 4 chain wavefronts + 4 weight-gradient wavefronts: two per SIMD, 256 registers each
+
+// Every wavefront of the workgroup passes the same sequence of workgroup barriers (the two roles execute different
+// s_barrier instructions; the hardware counts arrivals):
+//   group:   [c1 written]  batches ...  [Ds written]
+//   batch:   [input of layer 1 written] ([input of layer l+1 written]) x (NH-2)  [last-layer partial dots written]
+//            then for l = NH-1 .. 1:  [dpre_l written]  [dpre_l and input_l no longer read]
+__device__ __forceinline__ void wg_barrier() { __syncthreads(); }
+
+template <int HT, int NH>
+__global__ __launch_bounds__(64 * kWideWaves, 1) void mono_bwd_wide_k(MonoArgs a) {
+  static_assert(HT % 2 == 0 && NH >= 2, "even tile count (out tiles split in halves), at least one hidden->hidden layer");
+  using PL = WidePlan<HT, NH>;
+  constexpr int HP = PL::HP, P = PL::P, MC = HT / 2, TI = HT / 2, TN = HT / 2;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const MonoLayout& L = a.L;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int q = lane >> 4, j = lane & 15;
+
+  float* const c1buf = smem + PL::o_c1;
+  float* const dpbuf = smem + PL::o_dp;
+  float* const sred = smem + PL::o_sred;
+  float* const sxbuf = smem + PL::o_sx;
+  auto actbuf = [&](int l) -> float* { return smem + PL::o_act + (l - 1) * kNP * P; };   // input of hidden layer l
+
+  for (int i = threadIdx.x; i < HP; i += blockDim.x) {
+    smem[PL::o_w1x + i] = a.pack[L.o_w1x + i];
+    smem[PL::o_wL + i] = a.pack[L.o_wL + i];
+#pragma unroll
+    for (int l = 1; l < NH; ++l) smem[PL::o_b + (l - 1) * HP + i] = a.pack[L.o_b[l] + i];
+  }
+  if (threadIdx.x == 0) smem[PL::o_bL] = a.pack[L.o_bL];
+  // (the first barrier of the group loop orders these stores before their readers)
+
+  const int64_t ngroups = (a.ecount + kGE - 1) / kGE;
+  const int64_t erows = (a.ecount + 15) / 16 * 16;    // Dsum rows the caller's column sums read
+  const int64_t vecw = (NH + 2) * HP + 4;
+  float* const prow_g = a.part + ((int64_t)blockIdx.x * kWaves + (wave & 3)) * vecw;   // one row per role pair of wavefronts
+
+  // shared by both roles: the per-group epilogue after the [Ds written] barrier -- Dsum rows (for d W1h, d b1) and dh
+  auto group_epilogue = [&](int64_t grp) {
+    const float* d0 = actbuf(1);                      // rows 0..31: Ds of the group's elements
+    constexpr int C4 = HP / 4;
+    for (int idx = threadIdx.x; idx < kGE * C4; idx += blockDim.x) {
+      const int el = idx / C4, c4 = idx - el * C4;
+      const int64_t row = grp * kGE + el;
+      if (row < erows) *reinterpret_cast<f32x4*>(a.Dsum + row * HP + 4 * c4) = ld4(d0 + el * P + 4 * c4);
+    }
+    // dh[el][cc] = sum_u W1h[u][cc] Ds[el][u]: (c tile, element half) pairs dealt over the wavefronts
+    for (int idx = wave; idx < 2 * (L.CP / 16); idx += kWideWaves) {
+      const int ct = idx >> 1, eh = idx & 1;
+      f32x4 o = f32x4{0.f, 0.f, 0.f, 0.f};
+      const float* dr = d0 + (16 * eh + j) * P + 4 * q;
+#pragma unroll
+      for (int t = 0; t < HT; ++t) {
+        const f32x4 A = ld4(a.pack + L.o_W1hT + (16 * ct + j) * L.LDW + 16 * t + 4 * q);
+        const f32x4 Bv = ld4(dr + 16 * t);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o = mfma(A[r], Bv[r], o);
+      }
+      const int64_t el = grp * kGE + 16 * eh + j;
+      if (el < a.ecount) {
+        const int64_t e = a.e0 + el;
+        const int64_t b = e / a.d, i = e - b * a.d;
+        const int64_t gbase = b * a.g_sb + i * a.g_sd;
+        const float gz = a.gz[e];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int cc = 16 * ct + 4 * q + r;
+          if (cc < L.c) a.gh[gbase + cc * a.g_sc] = o[r] + (cc == 0 ? gz : 0.f);   // + gz: the "+ z0" term
+        }
+      }
+    }
+  };
+
+  if (wave >= 4) {
+    // =====================================================================================================================
+    // weight-gradient role: wavefront w owns the TI x TN block (w & 1, w >> 1) of every layer's HT x HT accumulator tiles
+    // =====================================================================================================================
+    const int w = wave - 4;
+    const int ti0 = (w & 1) * TI, tn0 = (w >> 1) * TN;
+    f32x4 accW[NH - 1][TI][TN];
+    float p_b[NH - 1][TI];                            // lane (q, j): share of d b_l[16 (ti0 + a) + j] (pairs = q mod 4)
+#pragma unroll
+    for (int l = 0; l < NH - 1; ++l)
+#pragma unroll
+      for (int ta = 0; ta < TI; ++ta) {
+        p_b[l][ta] = 0.f;
+#pragma unroll
+        for (int tb = 0; tb < TN; ++tb) accW[l][ta][tb] = f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+    const int droff = q * P + 16 * ti0 + j, aroff = q * P + 16 * tn0 + j;
+    for (int64_t grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
+      wg_barrier();                                   // c1 written
+      for (int k0 = 0; k0 < a.NK; k0 += 2) {
+#pragma unroll
+        for (int l = 0; l < NH; ++l) wg_barrier();    // layer inputs 1..NH-1, last-layer partial dots
+#pragma unroll
+        for (int l = NH - 1; l >= 1; --l) {
+          wg_barrier();                               // dpre_l written
+          dw_pass<TI, TN, P>(dpbuf + droff, actbuf(l) + aroff, accW[l - 1], p_b[l - 1]);
+          wg_barrier();                               // dpre_l, input_l no longer read
+        }
+      }
+      wg_barrier();                                   // Ds written
+      group_epilogue(grp);
+    }
+    if (tn0 == 0) {                                   // both column blocks of a row block read the same dpre operands
+#pragma unroll
+      for (int l = 1; l < NH; ++l)
+#pragma unroll
+        for (int ta = 0; ta < TI; ++ta) {
+          const float v = qsum(p_b[l - 1][ta]);
+          if (q == 0) prow_g[(2 + l) * HP + 16 * (ti0 + ta) + j] = v;
+        }
+    }
+    float* wrow = a.wpart + (int64_t)blockIdx.x * ((NH - 1) * HP * HP);
+#pragma unroll
+    for (int l = 0; l < NH - 1; ++l)
+#pragma unroll
+      for (int ta = 0; ta < TI; ++ta)
+#pragma unroll
+        for (int tb = 0; tb < TN; ++tb)
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            wrow[l * HP * HP + (16 * (ti0 + ta) + 4 * q + r) * HP + 16 * (tn0 + tb) + j] = accW[l][ta][tb][r];
+    return;
+  }
+
+  // =======================================================================================================================
+  // chain role: wavefront (mh, nh) owns out tiles m0 .. m0 + MC - 1 of every layer and, in both node slots of a batch, the
+  // elements 16 nh + j of the group: its 32 pairs are rows 32 s + 16 nh + j (s = node slot) of the batch buffers
+  // =======================================================================================================================
+  const int mh = wave & 1, nh = wave >> 1;
+  const int m0 = mh * MC;
+  const rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.pack), 0, L.pack_floats * 4, 0x00020000);
+  const int prow = (16 * nh + j) * P;                 // slot 0 row of this lane's element (slot 1: + 32 P)
+  const int ucol_c = 16 * m0 + 4 * q;                 // own unit column of out tile m0 (tile mi adds 16)
+
+  f32x4 p_wL[MC], p_w1x[MC];
+  float p_bL = 0.f;
+#pragma unroll
+  for (int mi = 0; mi < MC; ++mi) {
+    p_wL[mi] = f32x4{0.f, 0.f, 0.f, 0.f};
+    p_w1x[mi] = p_wL[mi];
+  }
+  const float fS = (float)a.S;
+
+  for (int64_t grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
+    // ---- the lane's element
+    const int64_t el = grp * kGE + 16 * nh + j;
+    const bool valid = el < a.ecount;
+    const int64_t e = a.e0 + (valid ? el : a.ecount - 1);
+    const float xv = a.x[e];
+    const float xT = fS * (xv / fS);                  // xT = x0 + nb_steps * step, x0 = 0
+    const float gz = valid ? a.gz[e] : 0.f;
+    const float gj = (valid && a.gjac) ? a.gjac[e] : 0.f;
+    const float cotq = gz * xT * .5f;                 // grad_out (xT - x0) / 2
+    // ---- c1 = b1 + W1h h of the element, out tiles m0.. (MFMA, K = c)
+    {
+      const int64_t b = e / a.d, i = e - b * a.d;
+      const int64_t hbase = b * a.h_sb + i * a.h_sd;
+      f32x4 c[MC];
+#pragma unroll
+      for (int mi = 0; mi < MC; ++mi) c[mi] = ld4(a.pack + L.o_b1 + 16 * (m0 + mi) + 4 * q);
+      for (int s = 0; s < L.CP / 16; ++s) {
+        float hv[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int cc = 16 * s + 4 * q + r;
+          hv[r] = cc < L.c ? a.h[hbase + cc * a.h_sc] : 0.f;
+        }
+#pragma unroll
+        for (int mi = 0; mi < MC; ++mi) {
+          const f32x4 A = ld4(a.pack + L.o_W1h + (16 * (m0 + mi) + j) * L.LDH + 16 * s + 4 * q);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) c[mi] = mfma(A[r], hv[r], c[mi]);
+        }
+      }
+#pragma unroll
+      for (int mi = 0; mi < MC; ++mi) *reinterpret_cast<f32x4*>(c1buf + prow + ucol_c + 16 * mi) = c[mi];
+    }
+    wg_barrier();                                     // c1 written
+
+    f32x4 Ds[MC];
+#pragma unroll
+    for (int mi = 0; mi < MC; ++mi) Ds[mi] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float fjac = 0.f;
+
+    for (int k0 = 0; k0 < a.NK; k0 += 2) {
+      const int ucol = opaque_v(ucol_c);              // (see opaque_v)
+      float xk[2], cot[2];
+      bool isj[2];
+#pragma unroll
+      for (int sl = 0; sl < 2; ++sl) {
+        const int k = k0 + sl;
+        const bool isq = k <= a.S;
+        isj[sl] = k == a.S + 1;
+        const float wk = isq ? a.ccw[k] : 0.f, tk = isq ? a.cct[k] : 0.f;
+        xk[sl] = isq ? xT * (tk + 1.f) * .5f : xv;
+        cot[sl] = isq ? wk * cotq : (isj[sl] ? gj : 0.f);
+      }
+      // ---- layer 0 (rank-1 in x_k): input of hidden layer 1
+      {
+        float* a1 = actbuf(1) + prow + ucol;
+#pragma unroll
+        for (int mi = 0; mi < MC; ++mi) {
+          const f32x4 wx = ld4(smem + PL::o_w1x + ucol + 16 * mi);
+          const f32x4 c = ld4(c1buf + prow + ucol + 16 * mi);
+#pragma unroll
+          for (int sl = 0; sl < 2; ++sl) {
+            f32x4 v;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = fmaxf(fmaf(wx[r], xk[sl], c[r]), 0.f);
+            *reinterpret_cast<f32x4*>(a1 + sl * kGE * P + 16 * mi) = v;
+          }
+        }
+      }
+      wg_barrier();                                   // input of layer 1 written
+      // ---- hidden layers 1..NH-1, forward
+      f32x4 acc[MC][2];                               // pre-activation -> activation -> dpre of this wavefront's (units, pairs)
+#pragma unroll
+      for (int l = 1; l < NH; ++l) {
+#pragma unroll
+        for (int mi = 0; mi < MC; ++mi) {
+          acc[mi][0] = ld4(smem + PL::o_b + (l - 1) * HP + ucol + 16 * mi);
+          acc[mi][1] = acc[mi][0];
+        }
+        layer_pass<HT, MC, P>(rs, 16 * lane, opaque_s(4 * (L.o_Wf[l] + m0 * HT * 256)), actbuf(l) + prow + 4 * q, acc);
+#pragma unroll
+        for (int mi = 0; mi < MC; ++mi)
+#pragma unroll
+          for (int sl = 0; sl < 2; ++sl)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[mi][sl][r] = fmaxf(acc[mi][sl][r], 0.f);
+        if (l < NH - 1) {
+          float* an = actbuf(l + 1) + prow + ucol;
+#pragma unroll
+          for (int mi = 0; mi < MC; ++mi)
+#pragma unroll
+            for (int sl = 0; sl < 2; ++sl) *reinterpret_cast<f32x4*>(an + sl * kGE * P + 16 * mi) = acc[mi][sl];
+          wg_barrier();                               // input of layer l+1 written
+        }
+      }
+      // ---- last layer (H -> 1): partial dot over this wavefront's units, the two out halves meet in LDS
+      {
+        float sp[2] = {0.f, 0.f};
+#pragma unroll
+        for (int mi = 0; mi < MC; ++mi) {
+          const f32x4 wl = ld4(smem + PL::o_wL + ucol + 16 * mi);
+#pragma unroll
+          for (int sl = 0; sl < 2; ++sl)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) sp[sl] = fmaf(wl[r], acc[mi][sl][r], sp[sl]);
+        }
+#pragma unroll
+        for (int sl = 0; sl < 2; ++sl) {
+          sp[sl] = qsum(sp[sl]);
+          if (q == 0) sred[mh * kNP + kGE * sl + 16 * nh + j] = sp[sl];
+        }
+      }
+      wg_barrier();                                   // last-layer partial dots written
+      float dpl[2];
+#pragma unroll
+      for (int sl = 0; sl < 2; ++sl) {
+        const float s = (sred[kGE * sl + 16 * nh + j] + sred[kNP + kGE * sl + 16 * nh + j]) + smem[PL::o_bL];
+        if (isj[sl]) fjac = elu_plus(s);
+        dpl[sl] = cot[sl] * (s > 0.f ? 1.f : expf(s));
+      }
+      if (mh == 0 && q == 0) p_bL += dpl[0] + dpl[1];
+      // ---- backward through the last layer: d wL partials, dpre of hidden layer NH-1
+#pragma unroll
+      for (int mi = 0; mi < MC; ++mi) {
+        const f32x4 wl = ld4(smem + PL::o_wL + ucol + 16 * mi);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          p_wL[mi][r] = fmaf(dpl[0], acc[mi][0][r], fmaf(dpl[1], acc[mi][1][r], p_wL[mi][r]));
+#pragma unroll
+          for (int sl = 0; sl < 2; ++sl) acc[mi][sl][r] = acc[mi][sl][r] > 0.f ? wl[r] * dpl[sl] : 0.f;
+        }
+      }
+      // ---- hidden layers, top down
+#pragma unroll
+      for (int l = NH - 1; l >= 1; --l) {
+        // acc = dpre of layer l for this wavefront's (units, pairs): into the dp buffer for everybody
+#pragma unroll
+        for (int mi = 0; mi < MC; ++mi)
+#pragma unroll
+          for (int sl = 0; sl < 2; ++sl) *reinterpret_cast<f32x4*>(dpbuf + prow + ucol + sl * kGE * P + 16 * mi) = acc[mi][sl];
+        wg_barrier();                                 // dpre_l written
+        // d input_l = W_l^T dpre_l, gated by input_l > 0 (for l = 1 that is the first layer's dpre)
+#pragma unroll
+        for (int mi = 0; mi < MC; ++mi) { acc[mi][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[mi][1] = acc[mi][0]; }
+        layer_pass<HT, MC, P>(rs, 16 * lane, opaque_s(4 * (L.o_WTf[l] + m0 * HT * 256)), dpbuf + prow + 4 * q, acc);
+        const float* ag = actbuf(l) + prow + ucol;
+#pragma unroll
+        for (int mi = 0; mi < MC; ++mi)
+#pragma unroll
+          for (int sl = 0; sl < 2; ++sl) {
+            const f32x4 g = ld4(ag + sl * kGE * P + 16 * mi);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[mi][sl][r] = g[r] > 0.f ? acc[mi][sl][r] : 0.f;
+          }
+        wg_barrier();                                 // every reader of the dp buffer (and of input_l) is done
+      }
+      // ---- first layer: rank-1 in x_k, node-independent in h
+      float sx[2] = {0.f, 0.f};
+#pragma unroll
+      for (int mi = 0; mi < MC; ++mi) {
+        const f32x4 wx = ld4(smem + PL::o_w1x + ucol + 16 * mi);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          p_w1x[mi][r] = fmaf(acc[mi][0][r], xk[0], fmaf(acc[mi][1][r], xk[1], p_w1x[mi][r]));
+          Ds[mi][r] += acc[mi][0][r] + acc[mi][1][r];
+#pragma unroll
+          for (int sl = 0; sl < 2; ++sl) sx[sl] = fmaf(wx[r], acc[mi][sl][r], sx[sl]);
+        }
+      }
+      if (isj[0] || isj[1]) {                         // Jacobian node: this out half's share of df/dx
+        const float v = qsum(isj[0] ? sx[0] : sx[1]);
+        if (q == 0) sxbuf[mh * kGE + 16 * nh + j] = v;
+      }
+    }
+
+    // ---- per-group epilogue: Ds rows of the group's elements into the (free) input-1 buffer, then Dsum / dh / dx
+    {
+      float* d1 = actbuf(1) + prow + ucol_c;
+#pragma unroll
+      for (int mi = 0; mi < MC; ++mi) *reinterpret_cast<f32x4*>(d1 + 16 * mi) = Ds[mi];
+    }
+    wg_barrier();                                     // Ds written
+    group_epilogue(grp);
+    if (mh == 0 && q == 0 && valid && a.gx)           // Leibniz rule: dz/dx = f(x; h);  + gjac df/dx(x; h) (its cotangent was gjac)
+      a.gx[e] = gz * fjac + (sxbuf[16 * nh + j] + sxbuf[kGE + 16 * nh + j]);
+    // (the [c1 written] barrier of the next group orders these reads before the next writes of the buffers)
+  }
+
+  // ---- per-lane partials -> the wavefront's share of its partial row (the caller zeroes the rows)
+#pragma unroll
+  for (int mi = 0; mi < MC; ++mi)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int hid = 16 * (m0 + mi) + 4 * q + r;
+      float v = jsum(p_wL[mi][r]);
+      if (j == 0) prow_g[hid] = v;
+      v = jsum(p_w1x[mi][r]);
+      if (j == 0) prow_g[HP + hid] = v;
+    }
+  const float vbl = jsum(p_bL);
+  if (lane == 0 && mh == 0) prow_g[(NH + 2) * HP] = vbl;
+}
+
+template <int HT, int NH>
+int launch_wide(const MonoArgs& a, unsigned grid, hipStream_t s) {
+  const size_t lds = (size_t)WidePlan<HT, NH>::total * sizeof(float);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mono_bwd_wide_k<HT, NH>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipLaunchKernelGGL((mono_bwd_wide_k<HT, NH>), dim3(grid), dim3(64 * kWideWaves), lds, s, a);
+  GNF_LAUNCH_CHECK();
+  return 0;
+}
+
+constexpr size_t kLds = 160 * 1024;
+
+}  // namespace
+
+bool gnf_mono_bwd_wide_ok(const gnfmono::MonoLayout& L) {
+  static const bool off = getenv("GNF_MONO_WIDE") && getenv("GNF_MONO_WIDE")[0] == '0';   // A/B switch (measurement)
+  if (off || L.c > 32) return false;
+  if (L.HT == 10 && L.NH == 2) return WidePlan<10, 2>::total * sizeof(float) <= kLds;
+  if (L.HT == 10 && L.NH == 3) return WidePlan<10, 3>::total * sizeof(float) <= kLds;
+  return false;
+}
+
+unsigned gnf_mono_bwd_wide_grid(const gnfmono::MonoLayout&, int64_t n) {
+  const int64_t groups = (n + kGE - 1) / kGE;
+  return (unsigned)(groups < 256 ? groups : 256);     // one workgroup per CU, persistent
+}
+
+int gnf_mono_bwd_wide_launch(const gnfmono::MonoArgs& a, unsigned grid, hipStream_t s) {
+  if (a.L.HT == 10 && a.L.NH == 2) return launch_wide<10, 2>(a, grid, s);
+  if (a.L.HT == 10 && a.L.NH == 3) return launch_wide<10, 3>(a, grid, s);
+  return GNF_ESHAPE;
+}
