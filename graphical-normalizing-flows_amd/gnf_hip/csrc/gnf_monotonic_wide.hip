@@ -65,32 +65,40 @@ __device__ __forceinline__ f32x4 ldfrag(rsrc_t rs, int voff, int soff) {
   return __builtin_bit_cast(f32x4, v);
 }
 
-// One pass over a hidden->hidden matrix: acc[mi][s] += sum_k A(m0 + mi, k) B(k, the wavefront's 16 pairs of node slot s).
-//   rs, voff, soff : fragment (m0, 0) of the matrix (global, L2); fragment (mi, t) sits (mi HT + t) KB further
-//   bsrc : LDS address of (pair (slot 0, element j), unit 4 q); slot 1 adds 32 P, k-tile t adds 16
+// One pass over a hidden->hidden matrix for a chain wavefront: MF full out tiles (both node slots) and, for an odd tile
+// count, the shared middle tile for ONE node slot (the other out half takes the other slot, so both halves carry
+// HT/2 tile products per k-tile):
+//   acc[mi][sl] += sum_k A(full tile mi, k) B(k, the wavefront's 16 pairs of node slot sl),   acc[MF][0] likewise for
+//   (shared tile, own slot).
+//   rs, voff, soff : fragment (first full tile, 0) of the matrix (global, L2); fragment (mi, t) sits (mi HT + t) KB further;
+//   soffx : fragment (shared tile, 0);  bsrc : LDS address of (pair (slot 0, element j), unit 4 q), slot 1 adds 32 P,
+//   k-tile t adds 16;  bsrcx : the same for the shared tile's slot.
 // Fragments of k-tile t+1 are requested in front of the MFMAs of k-tile t.
-template <int HT, int MC, int P>
-__device__ __forceinline__ void layer_pass(rsrc_t rs, int voff, int soff, const float* bsrc, f32x4 (&acc)[MC][2]) {
-  f32x4 A[2][MC], B[2][2];
+template <int HT, int MF, int XT, int P>
+__device__ __forceinline__ void layer_pass(rsrc_t rs, int voff, int soff, int soffx, const float* bsrc, const float* bsrcx,
+                                           f32x4 (&acc)[MF + XT][2]) {
+  f32x4 A[2][MF + XT], B[2][2 + XT];
+  auto fetch = [&](int t, f32x4 (&Ad)[MF + XT], f32x4 (&Bd)[2 + XT]) {
 #pragma unroll
-  for (int mi = 0; mi < MC; ++mi) A[0][mi] = ldfrag(rs, voff, soff + (mi * HT) * 1024);
+    for (int mi = 0; mi < MF; ++mi) Ad[mi] = ldfrag(rs, voff, soff + (mi * HT + t) * 1024);
+    if constexpr (XT) Ad[MF] = ldfrag(rs, voff, soffx + t * 1024);
 #pragma unroll
-  for (int sl = 0; sl < 2; ++sl) B[0][sl] = ld4(bsrc + sl * kGE * P);
+    for (int sl = 0; sl < 2; ++sl) Bd[sl] = ld4(bsrc + sl * kGE * P + 16 * t);
+    if constexpr (XT) Bd[2] = ld4(bsrcx + 16 * t);
+  };
+  fetch(0, A[0], B[0]);
 #pragma unroll
   for (int t = 0; t < HT; ++t) {
-    if (t + 1 < HT) {
-#pragma unroll
-      for (int mi = 0; mi < MC; ++mi) A[(t + 1) & 1][mi] = ldfrag(rs, voff, soff + (mi * HT + t + 1) * 1024);
-#pragma unroll
-      for (int sl = 0; sl < 2; ++sl) B[(t + 1) & 1][sl] = ld4(bsrc + sl * kGE * P + 16 * (t + 1));
-    }
+    if (t + 1 < HT) fetch(t + 1, A[(t + 1) & 1], B[(t + 1) & 1]);
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int r = 0; r < 4; ++r)
+    for (int r = 0; r < 4; ++r) {
 #pragma unroll
-      for (int mi = 0; mi < MC; ++mi)
+      for (int mi = 0; mi < MF; ++mi)
 #pragma unroll
         for (int sl = 0; sl < 2; ++sl) acc[mi][sl] = mfma(A[t & 1][mi][r], B[t & 1][sl][r], acc[mi][sl]);
+      if constexpr (XT) acc[MF][0] = mfma(A[t & 1][MF][r], B[t & 1][2][r], acc[MF][0]);
+    }
     __builtin_amdgcn_sched_barrier(0);
   }
 }
@@ -104,35 +112,60 @@ __device__ __forceinline__ void mfma_acc(float a, float b, f32x4& c) {
   asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b));
 }
 
-// Weight-gradient tiles of one layer: accW[a][b] += sum over the 64 pairs of dpre[pair][16 (ti0+a) + .] (x) in[pair][16 (tn0+b) + .]
+// How the HT x HT accumulator tiles of a layer are dealt over the four weight-gradient wavefronts.
+//   even HT: wavefront w owns the (HT/2) x (HT/2) block (w & 1, w >> 1): one code path, block origin at run time
+//   odd  HT: wavefront W owns the row-major tile range [HT^2 W / 4, HT^2 (W+1) / 4): 12-13 tiles of 2-3 rows at HT = 7,
+//            one code path per wavefront (W at compile time)
+template <int HT, int W>
+struct DwDeal {
+  static constexpr int lo = HT * HT * W / 4, hi = HT * HT * (W + 1) / 4, NT = hi - lo;
+  static constexpr int r0 = lo / HT, NR = (hi - 1) / HT - r0 + 1, NC = HT;
+  static constexpr int lrow(int i) { return (lo + i) / HT - r0; }
+  static constexpr int lcol(int i) { return (lo + i) % HT; }
+  static constexpr bool bias_row(int r) { return (r0 + r) * HT >= lo && (r0 + r) * HT < hi; }   // owns tile (row, 0)
+  __device__ static int ti0(int) { return r0; }
+  __device__ static int tn0(int) { return 0; }
+  __device__ static bool bias_rt(int) { return true; }
+};
+template <int HT>
+struct DwDeal<HT, -1> {
+  static constexpr int NR = HT / 2, NC = HT / 2, NT = NR * NC;
+  static constexpr int lrow(int i) { return i / NC; }
+  static constexpr int lcol(int i) { return i % NC; }
+  static constexpr bool bias_row(int) { return true; }
+  __device__ static int ti0(int w) { return (w & 1) * NR; }
+  __device__ static int tn0(int w) { return (w >> 1) * NC; }
+  __device__ static bool bias_rt(int w) { return (w >> 1) == 0; }    // both column blocks of a row block read the same dpre
+};
+
+// Weight-gradient tiles of one layer: accW[i] += sum over the 64 pairs of dpre[pair][16 row(i) + .] (x) in[pair][16 col(i) + .]
 //   dsrc : dp buffer  + q P + 16 ti0 + j   (lane (q, j) reads pair 4 s + q of K-step s)
 //   asrc : act buffer + q P + 16 tn0 + j
-// pb[a] += the dpre operands themselves: summed over the K-steps here and over q by the caller they are the column sums of
-// dpre, i.e. the bias gradient of the tiles' out units.
-template <int TI, int TN, int P>
-__device__ __forceinline__ void dw_pass(const float* dsrc, const float* asrc, f32x4 (&accW)[TI][TN], float (&pb)[TI]) {
-  float fa[2][TI], fb[2][TN];
+// pb[r] += the dpre operands themselves: summed over the K-steps here and over q by the caller they are the column sums of
+// dpre, i.e. the bias gradient of the rows' out units.
+template <class D, int P>
+__device__ __forceinline__ void dw_pass(const float* dsrc, const float* asrc, f32x4 (&accW)[D::NT], float (&pb)[D::NR]) {
+  float fa[2][D::NR], fb[2][D::NC];
 #pragma unroll
-  for (int a = 0; a < TI; ++a) fa[0][a] = dsrc[16 * a];
+  for (int a = 0; a < D::NR; ++a) fa[0][a] = dsrc[16 * a];
 #pragma unroll
-  for (int b = 0; b < TN; ++b) fb[0][b] = asrc[16 * b];
+  for (int b = 0; b < D::NC; ++b) fb[0][b] = asrc[16 * b];
 #pragma unroll
   for (int s = 0; s < kNP / 4; ++s) {
     if (s + 1 < kNP / 4) {
 #pragma unroll
-      for (int a = 0; a < TI; ++a) fa[(s + 1) & 1][a] = dsrc[4 * (s + 1) * P + 16 * a];
+      for (int a = 0; a < D::NR; ++a) fa[(s + 1) & 1][a] = dsrc[4 * (s + 1) * P + 16 * a];
 #pragma unroll
-      for (int b = 0; b < TN; ++b) fb[(s + 1) & 1][b] = asrc[4 * (s + 1) * P + 16 * b];
+      for (int b = 0; b < D::NC; ++b) fb[(s + 1) & 1][b] = asrc[4 * (s + 1) * P + 16 * b];
     }
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int a = 0; a < TI; ++a)
-#pragma unroll
-      for (int b = 0; b < TN; ++b) mfma_acc(fa[s & 1][a], fb[s & 1][b], accW[a][b]);
+    for (int i = 0; i < D::NT; ++i) mfma_acc(fa[s & 1][D::lrow(i)], fb[s & 1][D::lcol(i)], accW[i]);
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int a = 0; a < TI; ++a)                      // volatile: left to itself the compiler sinks all 80 additions of a pass
-      asm volatile("v_add_f32 %0, %0, %1" : "+v"(pb[a]) : "v"(fa[s & 1][a]));   // to its end and spills their operands
+    for (int a = 0; a < D::NR; ++a)                   // volatile: left to itself the compiler sinks all additions of a pass
+      if (D::bias_row(a))                             // to its end and spills their operands
+        asm volatile("v_add_f32 %0, %0, %1" : "+v"(pb[a]) : "v"(fa[s & 1][a]));
   }
 }
 
@@ -140,16 +173,128 @@ constexpr int kWideWaves = 8;      // 4 chain wavefronts + 4 weight-gradient wav
 
 // Every wavefront of the workgroup passes the same sequence of workgroup barriers (the two roles execute different
 // s_barrier instructions; the hardware counts arrivals):
-//   group:   [c1 written]  batches ...  [Ds written]
+//   group:   [c1 written]  batches ...  [Ds written] ([shared tile's Ds halves added], odd HT)
 //   batch:   [input of layer 1 written] ([input of layer l+1 written]) x (NH-2)  [last-layer partial dots written]
 //            then for l = NH-1 .. 1:  [dpre_l written]  [dpre_l and input_l no longer read]
 __device__ __forceinline__ void wg_barrier() { __syncthreads(); }
 
 template <int HT, int NH>
-__global__ __launch_bounds__(64 * kWideWaves, 1) void mono_bwd_wide_k(MonoArgs a) {
-  static_assert(HT % 2 == 0 && NH >= 2, "even tile count (out tiles split in halves), at least one hidden->hidden layer");
+struct WideCtx {                    // what both roles need
   using PL = WidePlan<HT, NH>;
-  constexpr int HP = PL::HP, P = PL::P, MC = HT / 2, TI = HT / 2, TN = HT / 2;
+  static constexpr int HP = PL::HP, P = PL::P;
+};
+
+// Per-group epilogue, all 8 wavefronts, behind the [Ds written] barrier: rows 0..31 of the input-1 buffer hold Ds (the
+// first layer's dpre summed over the nodes) of the group's elements -> Dsum rows (for d W1h, d b1) and dh
+template <int HT, int NH>
+__device__ __forceinline__ void group_epilogue(const MonoArgs& a, float* smem, int64_t grp, int64_t erows, int wave, int q, int j) {
+  using PL = WidePlan<HT, NH>;
+  constexpr int HP = PL::HP, P = PL::P, MF = HT / 2, XT = HT & 1;
+  const MonoLayout& L = a.L;
+  float* d0 = smem + PL::o_act;
+  if constexpr (XT) {               // the shared middle tile: each out half summed its own node slot; slot-1 half in rows 32..
+    if (threadIdx.x < kGE * 4) {
+      const int el = threadIdx.x >> 2, c4 = threadIdx.x & 3;
+      float* p0 = d0 + el * P + 16 * MF + 4 * c4;
+      *reinterpret_cast<f32x4*>(p0) = ld4(p0) + ld4(p0 + kGE * P);
+    }
+    wg_barrier();
+  }
+  constexpr int C4 = HP / 4;
+  for (int idx = threadIdx.x; idx < kGE * C4; idx += blockDim.x) {
+    const int el = idx / C4, c4 = idx - el * C4;
+    const int64_t row = grp * kGE + el;
+    if (row < erows) *reinterpret_cast<f32x4*>(a.Dsum + row * HP + 4 * c4) = ld4(d0 + el * P + 4 * c4);
+  }
+  // dh[el][cc] = sum_u W1h[u][cc] Ds[el][u]: (c tile, element half) pairs dealt over the wavefronts
+  for (int idx = wave; idx < 2 * (L.CP / 16); idx += kWideWaves) {
+    const int ct = idx >> 1, eh = idx & 1;
+    f32x4 o = f32x4{0.f, 0.f, 0.f, 0.f};
+    const float* dr = d0 + (16 * eh + j) * P + 4 * q;
+#pragma unroll
+    for (int t = 0; t < HT; ++t) {
+      const f32x4 A = ld4(a.pack + L.o_W1hT + (16 * ct + j) * L.LDW + 16 * t + 4 * q);
+      const f32x4 Bv = ld4(dr + 16 * t);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) o = mfma(A[r], Bv[r], o);
+    }
+    const int64_t el = grp * kGE + 16 * eh + j;
+    if (el < a.ecount) {
+      const int64_t e = a.e0 + el;
+      const int64_t b = e / a.d, i = e - b * a.d;
+      const int64_t gbase = b * a.g_sb + i * a.g_sd;
+      const float gz = a.gz[e];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int cc = 16 * ct + 4 * q + r;
+        if (cc < L.c) a.gh[gbase + cc * a.g_sc] = o[r] + (cc == 0 ? gz : 0.f);   // + gz: the "+ z0" term
+      }
+    }
+  }
+}
+
+// =========================================================================================================================
+// weight-gradient role (wavefronts 4..7): accumulator tiles per DwDeal, all layers, for the whole persistent loop
+// =========================================================================================================================
+template <int HT, int NH, int W>
+__device__ __forceinline__ void dw_role(const MonoArgs& a, float* smem, int w, int64_t ngroups, int64_t erows, int wave,
+                                        int q, int j, float* prow_g) {
+  using PL = WidePlan<HT, NH>;
+  using D = DwDeal<HT, W>;
+  constexpr int HP = PL::HP, P = PL::P;
+  const int ti0 = D::ti0(w), tn0 = D::tn0(w);
+  f32x4 accW[NH - 1][D::NT];
+  float p_b[NH - 1][D::NR];         // lane (q, j): share of d b_l[16 (ti0 + r) + j] (pairs = q mod 4)
+#pragma unroll
+  for (int l = 0; l < NH - 1; ++l) {
+#pragma unroll
+    for (int r = 0; r < D::NR; ++r) p_b[l][r] = 0.f;
+#pragma unroll
+    for (int i = 0; i < D::NT; ++i) accW[l][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  const float* dsrc = smem + PL::o_dp + q * P + 16 * ti0 + j;
+  const int aroff = q * P + 16 * tn0 + j;
+  for (int64_t grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
+    wg_barrier();                                     // c1 written
+    for (int k0 = 0; k0 < a.NK; k0 += 2) {
+#pragma unroll
+      for (int l = 0; l < NH; ++l) wg_barrier();      // layer inputs 1..NH-1, last-layer partial dots
+#pragma unroll
+      for (int l = NH - 1; l >= 1; --l) {
+        wg_barrier();                                 // dpre_l written
+        dw_pass<D, P>(dsrc, smem + PL::o_act + (l - 1) * kNP * P + aroff, accW[l - 1], p_b[l - 1]);
+        wg_barrier();                                 // dpre_l, input_l no longer read
+      }
+    }
+    wg_barrier();                                     // Ds written
+    group_epilogue<HT, NH>(a, smem, grp, erows, wave, q, j);
+  }
+  if (D::bias_rt(w)) {
+#pragma unroll
+    for (int l = 1; l < NH; ++l)
+#pragma unroll
+      for (int r = 0; r < D::NR; ++r)
+        if (D::bias_row(r)) {
+          const float v = qsum(p_b[l - 1][r]);
+          if (q == 0) prow_g[(2 + l) * HP + 16 * (ti0 + r) + j] = v;
+        }
+  }
+  float* wrow = a.wpart + (int64_t)blockIdx.x * ((NH - 1) * HP * HP);
+#pragma unroll
+  for (int l = 0; l < NH - 1; ++l)
+#pragma unroll
+    for (int i = 0; i < D::NT; ++i)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        wrow[l * HP * HP + (16 * (ti0 + D::lrow(i)) + 4 * q + r) * HP + 16 * (tn0 + D::lcol(i)) + j] = accW[l][i][r];
+}
+
+template <int HT, int NH>
+__global__ __launch_bounds__(64 * kWideWaves, 1) void mono_bwd_wide_k(MonoArgs a) {
+  static_assert(NH >= 2, "at least one hidden->hidden layer");
+  using PL = WidePlan<HT, NH>;
+  constexpr int HP = PL::HP, P = PL::P;
+  constexpr int MF = HT / 2, XT = HT & 1, MT = MF + XT;     // full out tiles per chain wavefront, shared middle tile, local tiles
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const MonoLayout& L = a.L;
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -173,112 +318,42 @@ __global__ __launch_bounds__(64 * kWideWaves, 1) void mono_bwd_wide_k(MonoArgs a
   const int64_t ngroups = (a.ecount + kGE - 1) / kGE;
   const int64_t erows = (a.ecount + 15) / 16 * 16;    // Dsum rows the caller's column sums read
   const int64_t vecw = (NH + 2) * HP + 4;
-  float* const prow_g = a.part + ((int64_t)blockIdx.x * kWaves + (wave & 3)) * vecw;   // one row per role pair of wavefronts
-
-  // shared by both roles: the per-group epilogue after the [Ds written] barrier -- Dsum rows (for d W1h, d b1) and dh
-  auto group_epilogue = [&](int64_t grp) {
-    const float* d0 = actbuf(1);                      // rows 0..31: Ds of the group's elements
-    constexpr int C4 = HP / 4;
-    for (int idx = threadIdx.x; idx < kGE * C4; idx += blockDim.x) {
-      const int el = idx / C4, c4 = idx - el * C4;
-      const int64_t row = grp * kGE + el;
-      if (row < erows) *reinterpret_cast<f32x4*>(a.Dsum + row * HP + 4 * c4) = ld4(d0 + el * P + 4 * c4);
-    }
-    // dh[el][cc] = sum_u W1h[u][cc] Ds[el][u]: (c tile, element half) pairs dealt over the wavefronts
-    for (int idx = wave; idx < 2 * (L.CP / 16); idx += kWideWaves) {
-      const int ct = idx >> 1, eh = idx & 1;
-      f32x4 o = f32x4{0.f, 0.f, 0.f, 0.f};
-      const float* dr = d0 + (16 * eh + j) * P + 4 * q;
-#pragma unroll
-      for (int t = 0; t < HT; ++t) {
-        const f32x4 A = ld4(a.pack + L.o_W1hT + (16 * ct + j) * L.LDW + 16 * t + 4 * q);
-        const f32x4 Bv = ld4(dr + 16 * t);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) o = mfma(A[r], Bv[r], o);
-      }
-      const int64_t el = grp * kGE + 16 * eh + j;
-      if (el < a.ecount) {
-        const int64_t e = a.e0 + el;
-        const int64_t b = e / a.d, i = e - b * a.d;
-        const int64_t gbase = b * a.g_sb + i * a.g_sd;
-        const float gz = a.gz[e];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int cc = 16 * ct + 4 * q + r;
-          if (cc < L.c) a.gh[gbase + cc * a.g_sc] = o[r] + (cc == 0 ? gz : 0.f);   // + gz: the "+ z0" term
-        }
-      }
-    }
-  };
+  float* const prow_g = a.part + ((int64_t)blockIdx.x * kWaves + (wave & 3)) * vecw;   // one row per pair of wavefronts
 
   if (wave >= 4) {
-    // =====================================================================================================================
-    // weight-gradient role: wavefront w owns the TI x TN block (w & 1, w >> 1) of every layer's HT x HT accumulator tiles
-    // =====================================================================================================================
     const int w = wave - 4;
-    const int ti0 = (w & 1) * TI, tn0 = (w >> 1) * TN;
-    f32x4 accW[NH - 1][TI][TN];
-    float p_b[NH - 1][TI];                            // lane (q, j): share of d b_l[16 (ti0 + a) + j] (pairs = q mod 4)
-#pragma unroll
-    for (int l = 0; l < NH - 1; ++l)
-#pragma unroll
-      for (int ta = 0; ta < TI; ++ta) {
-        p_b[l][ta] = 0.f;
-#pragma unroll
-        for (int tb = 0; tb < TN; ++tb) accW[l][ta][tb] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if constexpr (XT == 0) {
+      dw_role<HT, NH, -1>(a, smem, w, ngroups, erows, wave, q, j, prow_g);
+    } else {
+      switch (w) {
+        case 0: dw_role<HT, NH, 0>(a, smem, w, ngroups, erows, wave, q, j, prow_g); break;
+        case 1: dw_role<HT, NH, 1>(a, smem, w, ngroups, erows, wave, q, j, prow_g); break;
+        case 2: dw_role<HT, NH, 2>(a, smem, w, ngroups, erows, wave, q, j, prow_g); break;
+        default: dw_role<HT, NH, 3>(a, smem, w, ngroups, erows, wave, q, j, prow_g); break;
       }
-    const int droff = q * P + 16 * ti0 + j, aroff = q * P + 16 * tn0 + j;
-    for (int64_t grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
-      wg_barrier();                                   // c1 written
-      for (int k0 = 0; k0 < a.NK; k0 += 2) {
-#pragma unroll
-        for (int l = 0; l < NH; ++l) wg_barrier();    // layer inputs 1..NH-1, last-layer partial dots
-#pragma unroll
-        for (int l = NH - 1; l >= 1; --l) {
-          wg_barrier();                               // dpre_l written
-          dw_pass<TI, TN, P>(dpbuf + droff, actbuf(l) + aroff, accW[l - 1], p_b[l - 1]);
-          wg_barrier();                               // dpre_l, input_l no longer read
-        }
-      }
-      wg_barrier();                                   // Ds written
-      group_epilogue(grp);
     }
-    if (tn0 == 0) {                                   // both column blocks of a row block read the same dpre operands
-#pragma unroll
-      for (int l = 1; l < NH; ++l)
-#pragma unroll
-        for (int ta = 0; ta < TI; ++ta) {
-          const float v = qsum(p_b[l - 1][ta]);
-          if (q == 0) prow_g[(2 + l) * HP + 16 * (ti0 + ta) + j] = v;
-        }
-    }
-    float* wrow = a.wpart + (int64_t)blockIdx.x * ((NH - 1) * HP * HP);
-#pragma unroll
-    for (int l = 0; l < NH - 1; ++l)
-#pragma unroll
-      for (int ta = 0; ta < TI; ++ta)
-#pragma unroll
-        for (int tb = 0; tb < TN; ++tb)
-#pragma unroll
-          for (int r = 0; r < 4; ++r)
-            wrow[l * HP * HP + (16 * (ti0 + ta) + 4 * q + r) * HP + 16 * (tn0 + tb) + j] = accW[l][ta][tb][r];
     return;
   }
 
   // =======================================================================================================================
-  // chain role: wavefront (mh, nh) owns out tiles m0 .. m0 + MC - 1 of every layer and, in both node slots of a batch, the
-  // elements 16 nh + j of the group: its 32 pairs are rows 32 s + 16 nh + j (s = node slot) of the batch buffers
+  // chain role: wavefront (mh, nh) owns MF full out tiles of every layer (mh = 0: tiles 0.., mh = 1: the last MF) for both
+  // node slots of a batch and, for odd HT, the middle tile for node slot mh; its elements are 16 nh + j of the group, i.e.
+  // rows 32 s + 16 nh + j (s = node slot) of the batch buffers.  Local tile mi < MF: full; mi = MF: the shared one.
   // =======================================================================================================================
   const int mh = wave & 1, nh = wave >> 1;
-  const int m0 = mh * MC;
+  const int m0 = mh * (MF + XT);
   const rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.pack), 0, L.pack_floats * 4, 0x00020000);
   const int prow = (16 * nh + j) * P;                 // slot 0 row of this lane's element (slot 1: + 32 P)
-  const int ucol_c = 16 * m0 + 4 * q;                 // own unit column of out tile m0 (tile mi adds 16)
+  const int xrow = prow + mh * kGE * P;               // row of the shared tile's slot
+  const int ucol_c = 16 * m0 + 4 * q;                 // own unit column of the first full tile (tile mi adds 16)
+  const int xcol_c = 16 * MF + 4 * q;                 // ... of the shared tile
+  // column of local tile mi relative to the laundered bases (uc, xc)
+  auto col = [&](int mi, int uc, int xc) { return mi < MF ? uc + 16 * mi : xc; };
 
-  f32x4 p_wL[MC], p_w1x[MC];
+  f32x4 p_wL[MT], p_w1x[MT];
   float p_bL = 0.f;
 #pragma unroll
-  for (int mi = 0; mi < MC; ++mi) {
+  for (int mi = 0; mi < MT; ++mi) {
     p_wL[mi] = f32x4{0.f, 0.f, 0.f, 0.f};
     p_w1x[mi] = p_wL[mi];
   }
@@ -294,13 +369,13 @@ __global__ __launch_bounds__(64 * kWideWaves, 1) void mono_bwd_wide_k(MonoArgs a
     const float gz = valid ? a.gz[e] : 0.f;
     const float gj = (valid && a.gjac) ? a.gjac[e] : 0.f;
     const float cotq = gz * xT * .5f;                 // grad_out (xT - x0) / 2
-    // ---- c1 = b1 + W1h h of the element, out tiles m0.. (MFMA, K = c)
+    // ---- c1 = b1 + W1h h of the element, own out tiles (MFMA, K = c); the shared tile is computed by both out halves
     {
       const int64_t b = e / a.d, i = e - b * a.d;
       const int64_t hbase = b * a.h_sb + i * a.h_sd;
-      f32x4 c[MC];
+      f32x4 c[MT];
 #pragma unroll
-      for (int mi = 0; mi < MC; ++mi) c[mi] = ld4(a.pack + L.o_b1 + 16 * (m0 + mi) + 4 * q);
+      for (int mi = 0; mi < MT; ++mi) c[mi] = ld4(a.pack + L.o_b1 + col(mi, ucol_c, xcol_c));
       for (int s = 0; s < L.CP / 16; ++s) {
         float hv[4];
 #pragma unroll
@@ -309,24 +384,25 @@ __global__ __launch_bounds__(64 * kWideWaves, 1) void mono_bwd_wide_k(MonoArgs a
           hv[r] = cc < L.c ? a.h[hbase + cc * a.h_sc] : 0.f;
         }
 #pragma unroll
-        for (int mi = 0; mi < MC; ++mi) {
-          const f32x4 A = ld4(a.pack + L.o_W1h + (16 * (m0 + mi) + j) * L.LDH + 16 * s + 4 * q);
+        for (int mi = 0; mi < MT; ++mi) {
+          const int tile = mi < MF ? m0 + mi : MF;
+          const f32x4 A = ld4(a.pack + L.o_W1h + (16 * tile + j) * L.LDH + 16 * s + 4 * q);
 #pragma unroll
           for (int r = 0; r < 4; ++r) c[mi] = mfma(A[r], hv[r], c[mi]);
         }
       }
 #pragma unroll
-      for (int mi = 0; mi < MC; ++mi) *reinterpret_cast<f32x4*>(c1buf + prow + ucol_c + 16 * mi) = c[mi];
+      for (int mi = 0; mi < MT; ++mi) *reinterpret_cast<f32x4*>(c1buf + prow + col(mi, ucol_c, xcol_c)) = c[mi];
     }
     wg_barrier();                                     // c1 written
 
-    f32x4 Ds[MC];
+    f32x4 Ds[MT];
 #pragma unroll
-    for (int mi = 0; mi < MC; ++mi) Ds[mi] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int mi = 0; mi < MT; ++mi) Ds[mi] = f32x4{0.f, 0.f, 0.f, 0.f};
     float fjac = 0.f;
 
     for (int k0 = 0; k0 < a.NK; k0 += 2) {
-      const int ucol = opaque_v(ucol_c);              // (see opaque_v)
+      const int ucol = opaque_v(ucol_c), xcol = opaque_v(xcol_c);   // (see opaque_v)
       float xk[2], cot[2];
       bool isj[2];
 #pragma unroll
@@ -338,59 +414,71 @@ __global__ __launch_bounds__(64 * kWideWaves, 1) void mono_bwd_wide_k(MonoArgs a
         xk[sl] = isq ? xT * (tk + 1.f) * .5f : xv;
         cot[sl] = isq ? wk * cotq : (isj[sl] ? gj : 0.f);
       }
+      const float xkx = mh ? xk[1] : xk[0];           // the shared tile's node slot
       // ---- layer 0 (rank-1 in x_k): input of hidden layer 1
       {
-        float* a1 = actbuf(1) + prow + ucol;
+        float* a1 = actbuf(1);
 #pragma unroll
-        for (int mi = 0; mi < MC; ++mi) {
-          const f32x4 wx = ld4(smem + PL::o_w1x + ucol + 16 * mi);
-          const f32x4 c = ld4(c1buf + prow + ucol + 16 * mi);
+        for (int mi = 0; mi < MT; ++mi) {
+          const int cm = col(mi, ucol, xcol);
+          const f32x4 wx = ld4(smem + PL::o_w1x + cm);
+          const f32x4 c = ld4(c1buf + prow + cm);
 #pragma unroll
-          for (int sl = 0; sl < 2; ++sl) {
+          for (int sl = 0; sl < (mi < MF ? 2 : 1); ++sl) {
+            const float xs = mi < MF ? xk[sl] : xkx;
             f32x4 v;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] = fmaxf(fmaf(wx[r], xk[sl], c[r]), 0.f);
-            *reinterpret_cast<f32x4*>(a1 + sl * kGE * P + 16 * mi) = v;
+            for (int r = 0; r < 4; ++r) v[r] = fmaxf(fmaf(wx[r], xs, c[r]), 0.f);
+            *reinterpret_cast<f32x4*>(a1 + (mi < MF ? prow + sl * kGE * P : xrow) + cm) = v;
           }
         }
       }
       wg_barrier();                                   // input of layer 1 written
       // ---- hidden layers 1..NH-1, forward
-      f32x4 acc[MC][2];                               // pre-activation -> activation -> dpre of this wavefront's (units, pairs)
+      f32x4 acc[MT][2];                               // pre-activation -> activation -> dpre of this wavefront's (units, pairs)
 #pragma unroll
       for (int l = 1; l < NH; ++l) {
 #pragma unroll
-        for (int mi = 0; mi < MC; ++mi) {
-          acc[mi][0] = ld4(smem + PL::o_b + (l - 1) * HP + ucol + 16 * mi);
+        for (int mi = 0; mi < MT; ++mi) {
+          acc[mi][0] = ld4(smem + PL::o_b + (l - 1) * HP + col(mi, ucol, xcol));
           acc[mi][1] = acc[mi][0];
         }
-        layer_pass<HT, MC, P>(rs, 16 * lane, opaque_s(4 * (L.o_Wf[l] + m0 * HT * 256)), actbuf(l) + prow + 4 * q, acc);
+        layer_pass<HT, MF, XT, P>(rs, 16 * lane, opaque_s(4 * (L.o_Wf[l] + m0 * HT * 256)),
+                                  opaque_s(4 * (L.o_Wf[l] + MF * HT * 256)), actbuf(l) + prow + 4 * q,
+                                  actbuf(l) + xrow + 4 * q, acc);
 #pragma unroll
-        for (int mi = 0; mi < MC; ++mi)
+        for (int mi = 0; mi < MT; ++mi)
 #pragma unroll
-          for (int sl = 0; sl < 2; ++sl)
+          for (int sl = 0; sl < (mi < MF ? 2 : 1); ++sl)
 #pragma unroll
             for (int r = 0; r < 4; ++r) acc[mi][sl][r] = fmaxf(acc[mi][sl][r], 0.f);
         if (l < NH - 1) {
-          float* an = actbuf(l + 1) + prow + ucol;
+          float* an = actbuf(l + 1);
 #pragma unroll
-          for (int mi = 0; mi < MC; ++mi)
+          for (int mi = 0; mi < MT; ++mi)
 #pragma unroll
-            for (int sl = 0; sl < 2; ++sl) *reinterpret_cast<f32x4*>(an + sl * kGE * P + 16 * mi) = acc[mi][sl];
+            for (int sl = 0; sl < (mi < MF ? 2 : 1); ++sl)
+              *reinterpret_cast<f32x4*>(an + (mi < MF ? prow + sl * kGE * P : xrow) + col(mi, ucol, xcol)) = acc[mi][sl];
           wg_barrier();                               // input of layer l+1 written
         }
       }
       // ---- last layer (H -> 1): partial dot over this wavefront's units, the two out halves meet in LDS
       {
-        float sp[2] = {0.f, 0.f};
+        float sp[2] = {0.f, 0.f}, spx = 0.f;
 #pragma unroll
-        for (int mi = 0; mi < MC; ++mi) {
-          const f32x4 wl = ld4(smem + PL::o_wL + ucol + 16 * mi);
+        for (int mi = 0; mi < MT; ++mi) {
+          const f32x4 wl = ld4(smem + PL::o_wL + col(mi, ucol, xcol));
 #pragma unroll
-          for (int sl = 0; sl < 2; ++sl)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) sp[sl] = fmaf(wl[r], acc[mi][sl][r], sp[sl]);
+          for (int r = 0; r < 4; ++r) {
+            if (mi < MF) {
+              sp[0] = fmaf(wl[r], acc[mi][0][r], sp[0]);
+              sp[1] = fmaf(wl[r], acc[mi][1][r], sp[1]);
+            } else {
+              spx = fmaf(wl[r], acc[mi][0][r], spx);
+            }
+          }
         }
+        if constexpr (XT) { sp[0] += mh ? 0.f : spx; sp[1] += mh ? spx : 0.f; }
 #pragma unroll
         for (int sl = 0; sl < 2; ++sl) {
           sp[sl] = qsum(sp[sl]);
@@ -405,16 +493,22 @@ __global__ __launch_bounds__(64 * kWideWaves, 1) void mono_bwd_wide_k(MonoArgs a
         if (isj[sl]) fjac = elu_plus(s);
         dpl[sl] = cot[sl] * (s > 0.f ? 1.f : expf(s));
       }
+      const float dplx = mh ? dpl[1] : dpl[0];
       if (mh == 0 && q == 0) p_bL += dpl[0] + dpl[1];
       // ---- backward through the last layer: d wL partials, dpre of hidden layer NH-1
 #pragma unroll
-      for (int mi = 0; mi < MC; ++mi) {
-        const f32x4 wl = ld4(smem + PL::o_wL + ucol + 16 * mi);
+      for (int mi = 0; mi < MT; ++mi) {
+        const f32x4 wl = ld4(smem + PL::o_wL + col(mi, ucol, xcol));
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          p_wL[mi][r] = fmaf(dpl[0], acc[mi][0][r], fmaf(dpl[1], acc[mi][1][r], p_wL[mi][r]));
+          if (mi < MF) {
+            p_wL[mi][r] = fmaf(dpl[0], acc[mi][0][r], fmaf(dpl[1], acc[mi][1][r], p_wL[mi][r]));
 #pragma unroll
-          for (int sl = 0; sl < 2; ++sl) acc[mi][sl][r] = acc[mi][sl][r] > 0.f ? wl[r] * dpl[sl] : 0.f;
+            for (int sl = 0; sl < 2; ++sl) acc[mi][sl][r] = acc[mi][sl][r] > 0.f ? wl[r] * dpl[sl] : 0.f;
+          } else {
+            p_wL[mi][r] = fmaf(dplx, acc[mi][0][r], p_wL[mi][r]);
+            acc[mi][0][r] = acc[mi][0][r] > 0.f ? wl[r] * dplx : 0.f;
+          }
         }
       }
       // ---- hidden layers, top down
@@ -422,63 +516,75 @@ __global__ __launch_bounds__(64 * kWideWaves, 1) void mono_bwd_wide_k(MonoArgs a
       for (int l = NH - 1; l >= 1; --l) {
         // acc = dpre of layer l for this wavefront's (units, pairs): into the dp buffer for everybody
 #pragma unroll
-        for (int mi = 0; mi < MC; ++mi)
+        for (int mi = 0; mi < MT; ++mi)
 #pragma unroll
-          for (int sl = 0; sl < 2; ++sl) *reinterpret_cast<f32x4*>(dpbuf + prow + ucol + sl * kGE * P + 16 * mi) = acc[mi][sl];
+          for (int sl = 0; sl < (mi < MF ? 2 : 1); ++sl)
+            *reinterpret_cast<f32x4*>(dpbuf + (mi < MF ? prow + sl * kGE * P : xrow) + col(mi, ucol, xcol)) = acc[mi][sl];
         wg_barrier();                                 // dpre_l written
         // d input_l = W_l^T dpre_l, gated by input_l > 0 (for l = 1 that is the first layer's dpre)
 #pragma unroll
-        for (int mi = 0; mi < MC; ++mi) { acc[mi][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[mi][1] = acc[mi][0]; }
-        layer_pass<HT, MC, P>(rs, 16 * lane, opaque_s(4 * (L.o_WTf[l] + m0 * HT * 256)), dpbuf + prow + 4 * q, acc);
-        const float* ag = actbuf(l) + prow + ucol;
+        for (int mi = 0; mi < MT; ++mi) { acc[mi][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[mi][1] = acc[mi][0]; }
+        layer_pass<HT, MF, XT, P>(rs, 16 * lane, opaque_s(4 * (L.o_WTf[l] + m0 * HT * 256)),
+                                  opaque_s(4 * (L.o_WTf[l] + MF * HT * 256)), dpbuf + prow + 4 * q, dpbuf + xrow + 4 * q, acc);
+        const float* ag = actbuf(l);
 #pragma unroll
-        for (int mi = 0; mi < MC; ++mi)
+        for (int mi = 0; mi < MT; ++mi)
 #pragma unroll
-          for (int sl = 0; sl < 2; ++sl) {
-            const f32x4 g = ld4(ag + sl * kGE * P + 16 * mi);
+          for (int sl = 0; sl < (mi < MF ? 2 : 1); ++sl) {
+            const f32x4 g = ld4(ag + (mi < MF ? prow + sl * kGE * P : xrow) + col(mi, ucol, xcol));
 #pragma unroll
             for (int r = 0; r < 4; ++r) acc[mi][sl][r] = g[r] > 0.f ? acc[mi][sl][r] : 0.f;
           }
         wg_barrier();                                 // every reader of the dp buffer (and of input_l) is done
       }
       // ---- first layer: rank-1 in x_k, node-independent in h
-      float sx[2] = {0.f, 0.f};
+      float sx[2] = {0.f, 0.f}, sxx = 0.f;
 #pragma unroll
-      for (int mi = 0; mi < MC; ++mi) {
-        const f32x4 wx = ld4(smem + PL::o_w1x + ucol + 16 * mi);
+      for (int mi = 0; mi < MT; ++mi) {
+        const f32x4 wx = ld4(smem + PL::o_w1x + col(mi, ucol, xcol));
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          p_w1x[mi][r] = fmaf(acc[mi][0][r], xk[0], fmaf(acc[mi][1][r], xk[1], p_w1x[mi][r]));
-          Ds[mi][r] += acc[mi][0][r] + acc[mi][1][r];
+          if (mi < MF) {
+            p_w1x[mi][r] = fmaf(acc[mi][0][r], xk[0], fmaf(acc[mi][1][r], xk[1], p_w1x[mi][r]));
+            Ds[mi][r] += acc[mi][0][r] + acc[mi][1][r];
 #pragma unroll
-          for (int sl = 0; sl < 2; ++sl) sx[sl] = fmaf(wx[r], acc[mi][sl][r], sx[sl]);
+            for (int sl = 0; sl < 2; ++sl) sx[sl] = fmaf(wx[r], acc[mi][sl][r], sx[sl]);
+          } else {
+            p_w1x[mi][r] = fmaf(acc[mi][0][r], xkx, p_w1x[mi][r]);
+            Ds[mi][r] += acc[mi][0][r];
+            sxx = fmaf(wx[r], acc[mi][0][r], sxx);
+          }
         }
       }
       if (isj[0] || isj[1]) {                         // Jacobian node: this out half's share of df/dx
-        const float v = qsum(isj[0] ? sx[0] : sx[1]);
+        float v = isj[0] ? sx[0] : sx[1];
+        if (XT && (mh ? isj[1] : isj[0])) v += sxx;
+        v = qsum(v);
         if (q == 0) sxbuf[mh * kGE + 16 * nh + j] = v;
       }
     }
 
     // ---- per-group epilogue: Ds rows of the group's elements into the (free) input-1 buffer, then Dsum / dh / dx
     {
-      float* d1 = actbuf(1) + prow + ucol_c;
+      float* d1 = actbuf(1);
 #pragma unroll
-      for (int mi = 0; mi < MC; ++mi) *reinterpret_cast<f32x4*>(d1 + 16 * mi) = Ds[mi];
+      for (int mi = 0; mi < MT; ++mi)
+        *reinterpret_cast<f32x4*>(d1 + (mi < MF ? prow : xrow) + col(mi, ucol_c, xcol_c)) = Ds[mi];
     }
     wg_barrier();                                     // Ds written
-    group_epilogue(grp);
+    group_epilogue<HT, NH>(a, smem, grp, erows, wave, q, j);
     if (mh == 0 && q == 0 && valid && a.gx)           // Leibniz rule: dz/dx = f(x; h);  + gjac df/dx(x; h) (its cotangent was gjac)
       a.gx[e] = gz * fjac + (sxbuf[16 * nh + j] + sxbuf[kGE + 16 * nh + j]);
     // (the [c1 written] barrier of the next group orders these reads before the next writes of the buffers)
   }
 
-  // ---- per-lane partials -> the wavefront's share of its partial row (the caller zeroes the rows)
+  // ---- per-lane partials -> the wavefront's share of its partial row (the caller zeroes the rows; the shared tile's
+  //      entries are written by both out halves, each into its own row)
 #pragma unroll
-  for (int mi = 0; mi < MC; ++mi)
+  for (int mi = 0; mi < MT; ++mi)
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const int hid = 16 * (m0 + mi) + 4 * q + r;
+      const int hid = (mi < MF ? 16 * (m0 + mi) : 16 * MF) + 4 * q + r;
       float v = jsum(p_wL[mi][r]);
       if (j == 0) prow_g[hid] = v;
       v = jsum(p_w1x[mi][r]);
@@ -505,8 +611,10 @@ constexpr size_t kLds = 160 * 1024;
 bool gnf_mono_bwd_wide_ok(const gnfmono::MonoLayout& L) {
   static const bool off = getenv("GNF_MONO_WIDE") && getenv("GNF_MONO_WIDE")[0] == '0';   // A/B switch (measurement)
   if (off || L.c > 32) return false;
-  if (L.HT == 10 && L.NH == 2) return WidePlan<10, 2>::total * sizeof(float) <= kLds;
-  if (L.HT == 10 && L.NH == 3) return WidePlan<10, 3>::total * sizeof(float) <= kLds;
+#define GNF_WIDE_CASE(HT_, NH_) \
+  if (L.HT == HT_ && L.NH == NH_) return WidePlan<HT_, NH_>::total * sizeof(float) <= kLds;
+  GNF_WIDE_CASE(7, 2) GNF_WIDE_CASE(7, 3) GNF_WIDE_CASE(7, 4) GNF_WIDE_CASE(10, 2) GNF_WIDE_CASE(10, 3)
+#undef GNF_WIDE_CASE
   return false;
 }
 
@@ -516,7 +624,9 @@ unsigned gnf_mono_bwd_wide_grid(const gnfmono::MonoLayout&, int64_t n) {
 }
 
 int gnf_mono_bwd_wide_launch(const gnfmono::MonoArgs& a, unsigned grid, hipStream_t s) {
-  if (a.L.HT == 10 && a.L.NH == 2) return launch_wide<10, 2>(a, grid, s);
-  if (a.L.HT == 10 && a.L.NH == 3) return launch_wide<10, 3>(a, grid, s);
+#define GNF_WIDE_CASE(HT_, NH_) \
+  if (a.L.HT == HT_ && a.L.NH == NH_) return launch_wide<HT_, NH_>(a, grid, s);
+  GNF_WIDE_CASE(7, 2) GNF_WIDE_CASE(7, 3) GNF_WIDE_CASE(7, 4) GNF_WIDE_CASE(10, 2) GNF_WIDE_CASE(10, 3)
+#undef GNF_WIDE_CASE
   return GNF_ESHAPE;
 }
