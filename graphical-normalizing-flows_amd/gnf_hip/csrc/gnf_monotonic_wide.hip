@@ -58,6 +58,9 @@ struct WidePlan {
 // hoisted LDS reads and 200 SGPR offsets in the first build of this kernel, spilled in turn.
 __device__ __forceinline__ int opaque_v(int x) { asm volatile("" : "+v"(x)); return x; }
 __device__ __forceinline__ int opaque_s(int x) { asm volatile("" : "+s"(x)); return x; }
+// max(x, 0) as ONE v_max_f32: fmaxf() is compiled into a canonicalising v_max(x, x) plus the maximum (NaN quieting the
+// kernels do not need: a NaN pre-activation stays a NaN either way)
+__device__ __forceinline__ float relu1(float x) { float y; asm("v_max_f32 %0, 0, %1" : "=v"(y) : "v"(x)); return y; }
 typedef __amdgpu_buffer_rsrc_t rsrc_t;
 __device__ __forceinline__ f32x4 ldfrag(rsrc_t rs, int voff, int soff) {
   typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
@@ -73,34 +76,60 @@ __device__ __forceinline__ f32x4 ldfrag(rsrc_t rs, int voff, int soff) {
 //   rs, voff, soff : fragment (first full tile, 0) of the matrix (global, L2); fragment (mi, t) sits (mi HT + t) KB further;
 //   soffx : fragment (shared tile, 0);  bsrc : LDS address of (pair (slot 0, element j), unit 4 q), slot 1 adds 32 P,
 //   k-tile t adds 16;  bsrcx : the same for the shared tile's slot.
-// Fragments of k-tile t+1 are requested in front of the MFMAs of k-tile t.
+// Fragments of k-tile t+1 are requested in front of the MFMAs of k-tile t; those of k-tile 0 (A0) were requested by the
+// caller (frag_prefetch) in front of whatever serial section and barrier precede the pass, so that their L2 latency
+// is not exposed at the head of every pass.
+template <int HT, int MF, int XT>
+__device__ __forceinline__ void frag_prefetch(rsrc_t rs, int voff, int soff, int soffx, f32x4 (&A0)[MF + XT]) {
+#pragma unroll
+  for (int mi = 0; mi < MF; ++mi) A0[mi] = ldfrag(rs, voff, soff + (mi * HT) * 1024);
+  if constexpr (XT) A0[MF] = ldfrag(rs, voff, soffx);
+}
 template <int HT, int MF, int XT, int P>
 __device__ __forceinline__ void layer_pass(rsrc_t rs, int voff, int soff, int soffx, const float* bsrc, const float* bsrcx,
-                                           f32x4 (&acc)[MF + XT][2]) {
+                                           const f32x4 (&A0)[MF + XT], f32x4 (&acc)[MF + XT][2]) {
   f32x4 A[2][MF + XT], B[2][2 + XT];
-  auto fetch = [&](int t, f32x4 (&Ad)[MF + XT], f32x4 (&Bd)[2 + XT]) {
+  constexpr int MT = MF + XT, AH = (MT + 1) / 2;
+  // the requests for k-tile t+1 ride in the shadow of the MFMAs of k-tile t, a few at a time: issued as one block between
+  // two k-tiles they take ~100 issue cycles during which the matrix pipe runs dry (one wavefront per SIMD feeds it in the
+  // forward passes): weight fragments behind the MFMAs of r = 0 and r = 1 (longest latency first), LDS reads behind r = 2
+  auto fetch_part = [&](int part, int t, f32x4 (&Ad)[MF + XT], f32x4 (&Bd)[2 + XT]) {
 #pragma unroll
-    for (int mi = 0; mi < MF; ++mi) Ad[mi] = ldfrag(rs, voff, soff + (mi * HT + t) * 1024);
-    if constexpr (XT) Ad[MF] = ldfrag(rs, voff, soffx + t * 1024);
+    for (int mi = 0; mi < MT; ++mi) {
+      if ((part == 0 && mi < AH) || (part == 1 && mi >= AH)) {
+#ifdef GNF_WIDE_EXP_L1       // measurement only: every fragment from the same KB (L1 hits; wrong results)
+        Ad[mi] = ldfrag(rs, voff, opaque_s(mi < MF ? soff : soffx));                    // opaque: no CSE of the MFMAs
+#else
+        Ad[mi] = mi < MF ? ldfrag(rs, voff, soff + (mi * HT + t) * 1024) : ldfrag(rs, voff, soffx + t * 1024);
+#endif
+      }
+    }
+    if (part == 2) {
 #pragma unroll
-    for (int sl = 0; sl < 2; ++sl) Bd[sl] = ld4(bsrc + sl * kGE * P + 16 * t);
-    if constexpr (XT) Bd[2] = ld4(bsrcx + 16 * t);
+      for (int sl = 0; sl < 2; ++sl) Bd[sl] = ld4(bsrc + sl * kGE * P + 16 * t);
+      if constexpr (XT) Bd[2] = ld4(bsrcx + 16 * t);
+    }
   };
-  fetch(0, A[0], B[0]);
+#pragma unroll
+  for (int mi = 0; mi < MF + XT; ++mi) A[0][mi] = A0[mi];
+#pragma unroll
+  for (int sl = 0; sl < 2; ++sl) B[0][sl] = ld4(bsrc + sl * kGE * P);
+  if constexpr (XT) B[0][2] = ld4(bsrcx);
 #pragma unroll
   for (int t = 0; t < HT; ++t) {
-    if (t + 1 < HT) fetch(t + 1, A[(t + 1) & 1], B[(t + 1) & 1]);
-    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int mi = 0; mi < MF; ++mi)
 #pragma unroll
         for (int sl = 0; sl < 2; ++sl) acc[mi][sl] = mfma(A[t & 1][mi][r], B[t & 1][sl][r], acc[mi][sl]);
       if constexpr (XT) acc[MF][0] = mfma(A[t & 1][MF][r], B[t & 1][2][r], acc[MF][0]);
+      __builtin_amdgcn_sched_barrier(0);
+      if (t + 1 < HT) fetch_part(r, t + 1, A[(t + 1) & 1], B[(t + 1) & 1]);
     }
-    __builtin_amdgcn_sched_barrier(0);
   }
+  __builtin_amdgcn_sched_barrier(0);
 }
 
 // In-place MFMA for the long-lived weight-gradient accumulators.  The builtin leaves vdst and srcC untied; with 200 of the
@@ -150,24 +179,44 @@ __device__ __forceinline__ void dw_pass(const float* dsrc, const float* asrc, f3
   for (int a = 0; a < D::NR; ++a) fa[0][a] = dsrc[16 * a];
 #pragma unroll
   for (int b = 0; b < D::NC; ++b) fb[0][b] = asrc[16 * b];
+  // the tiles of a K-step in chunks; behind each chunk a share of the next K-step's operand reads and of this one's bias
+  // additions (as one block between two K-steps they leave the matrix pipe idle whenever the chain wavefront of the SIMD
+  // is not issuing)
+  constexpr int NCH = 4, CH = (D::NT + NCH - 1) / NCH, NRD = D::NR + D::NC, RCH = (NRD + NCH - 1) / NCH;
 #pragma unroll
   for (int s = 0; s < kNP / 4; ++s) {
-    if (s + 1 < kNP / 4) {
 #pragma unroll
-      for (int a = 0; a < D::NR; ++a) fa[(s + 1) & 1][a] = dsrc[4 * (s + 1) * P + 16 * a];
+    for (int ch = 0; ch < NCH; ++ch) {
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int b = 0; b < D::NC; ++b) fb[(s + 1) & 1][b] = asrc[4 * (s + 1) * P + 16 * b];
+      for (int i = ch * CH; i < (ch + 1) * CH && i < D::NT; ++i)
+        mfma_acc(fa[s & 1][D::lrow(i)], fb[s & 1][D::lcol(i)], accW[i]);
+      __builtin_amdgcn_sched_barrier(0);
+      if (s + 1 < kNP / 4) {
+#pragma unroll
+        for (int i = ch * RCH; i < (ch + 1) * RCH && i < NRD; ++i) {
+          if (i < D::NR) fa[(s + 1) & 1][i] = dsrc[4 * (s + 1) * P + 16 * i];
+          else fb[(s + 1) & 1][i - D::NR] = asrc[4 * (s + 1) * P + 16 * (i - D::NR)];
+        }
+      }
+#pragma unroll
+      for (int a = ch; a < D::NR; a += NCH)           // volatile: left to itself the compiler sinks all additions of a pass
+        if (D::bias_row(a))                           // to its end and spills their operands
+          asm volatile("v_add_f32 %0, %0, %1" : "+v"(pb[a]) : "v"(fa[s & 1][a]));
     }
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int i = 0; i < D::NT; ++i) mfma_acc(fa[s & 1][D::lrow(i)], fb[s & 1][D::lcol(i)], accW[i]);
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int a = 0; a < D::NR; ++a)                   // volatile: left to itself the compiler sinks all additions of a pass
-      if (D::bias_row(a))                             // to its end and spills their operands
-        asm volatile("v_add_f32 %0, %0, %1" : "+v"(pb[a]) : "v"(fa[s & 1][a]));
   }
+  __builtin_amdgcn_sched_barrier(0);
 }
+
+#ifdef GNF_WIDE_TIMING        // measurement only (tools/time_wide_phases.py): s_memtime stamps of ONE batch of workgroup 0
+__device__ unsigned long long gnf_wide_stamps[8 * 32];
+__device__ int gnf_wide_stamp_on;
+#define STAMP(i) do { if (gnf_wide_stamp_on_l) gnf_wide_stamps[wave * 32 + (i)] = __builtin_readcyclecounter(); } while (0)
+#define STAMP_SEL(grp, k0) const bool gnf_wide_stamp_on_l = gnf_wide_stamp_on && blockIdx.x == 0 && (grp) == (int64_t)gridDim.x * 2 && (k0) == 6 && lane == 0
+#else
+#define STAMP(i) do {} while (0)
+#define STAMP_SEL(grp, k0) do {} while (0)
+#endif
 
 constexpr int kWideWaves = 8;      // 4 chain wavefronts + 4 weight-gradient wavefronts: two per SIMD, 256 registers each
 
@@ -176,7 +225,11 @@ constexpr int kWideWaves = 8;      // 4 chain wavefronts + 4 weight-gradient wav
 //   group:   [c1 written]  batches ...  [Ds written] ([shared tile's Ds halves added], odd HT)
 //   batch:   [input of layer 1 written] ([input of layer l+1 written]) x (NH-2)  [last-layer partial dots written]
 //            then for l = NH-1 .. 1:  [dpre_l written]  [dpre_l and input_l no longer read]
+#ifdef GNF_WIDE_EXP_NOBAR     // measurement only: no workgroup barriers (wrong results)
+__device__ __forceinline__ void wg_barrier() {}
+#else
 __device__ __forceinline__ void wg_barrier() { __syncthreads(); }
+#endif
 
 template <int HT, int NH>
 struct WideCtx {                    // what both roles need
@@ -257,13 +310,19 @@ __device__ __forceinline__ void dw_role(const MonoArgs& a, float* smem, int w, i
   for (int64_t grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
     wg_barrier();                                     // c1 written
     for (int k0 = 0; k0 < a.NK; k0 += 2) {
+      const int lane = threadIdx.x & 63;
+      STAMP_SEL(grp, k0);
+      STAMP(0);
 #pragma unroll
-      for (int l = 0; l < NH; ++l) wg_barrier();      // layer inputs 1..NH-1, last-layer partial dots
+      for (int l = 0; l < NH; ++l) { wg_barrier(); STAMP(1 + l); }   // layer inputs 1..NH-1, last-layer partial dots
 #pragma unroll
       for (int l = NH - 1; l >= 1; --l) {
         wg_barrier();                                 // dpre_l written
+        STAMP(8 + 3 * (NH - 1 - l));
         dw_pass<D, P>(dsrc, smem + PL::o_act + (l - 1) * kNP * P + aroff, accW[l - 1], p_b[l - 1]);
+        STAMP(9 + 3 * (NH - 1 - l));
         wg_barrier();                                 // dpre_l, input_l no longer read
+        STAMP(10 + 3 * (NH - 1 - l));
       }
     }
     wg_barrier();                                     // Ds written
@@ -401,10 +460,14 @@ __global__ __launch_bounds__(64 * kWideWaves, 1) void mono_bwd_wide_k(MonoArgs a
     for (int mi = 0; mi < MT; ++mi) Ds[mi] = f32x4{0.f, 0.f, 0.f, 0.f};
     float fjac = 0.f;
 
-    for (int k0 = 0; k0 < a.NK; k0 += 2) {
-      const int ucol = opaque_v(ucol_c), xcol = opaque_v(xcol_c);   // (see opaque_v)
-      float xk[2], cot[2];
-      bool isj[2];
+    // The node loop is software-pipelined by one serial section: the input of hidden layer 1 (rank-1 in x_k) of batch
+    // k0 + 2 is computed at the END of batch k0 -- in front of the barrier at which the chain wavefronts wait for the
+    // weight-gradient wavefronts anyway -- and only stored behind it.
+    float xk[2], cot[2];
+    bool isj[2];
+    f32x4 acc[MT][2];                                 // layer-1 input -> pre-activation -> activation -> dpre of (own units, own pairs)
+    f32x4 Apre[MT];                                   // first weight fragments of the next pass
+    auto node_params = [&](int k0) {
 #pragma unroll
       for (int sl = 0; sl < 2; ++sl) {
         const int k = k0 + sl;
@@ -414,28 +477,44 @@ __global__ __launch_bounds__(64 * kWideWaves, 1) void mono_bwd_wide_k(MonoArgs a
         xk[sl] = isq ? xT * (tk + 1.f) * .5f : xv;
         cot[sl] = isq ? wk * cotq : (isj[sl] ? gj : 0.f);
       }
+    };
+    auto layer0 = [&](int ucol, int xcol) {           // acc = relu(c1 + w1x x_k) for the own (units, pairs)
       const float xkx = mh ? xk[1] : xk[0];           // the shared tile's node slot
-      // ---- layer 0 (rank-1 in x_k): input of hidden layer 1
+#pragma unroll
+      for (int mi = 0; mi < MT; ++mi) {
+        const int cm = col(mi, ucol, xcol);
+        const f32x4 wx = ld4(smem + PL::o_w1x + cm);
+        const f32x4 c = ld4(c1buf + prow + cm);
+#pragma unroll
+        for (int sl = 0; sl < (mi < MF ? 2 : 1); ++sl) {
+          const float xs = mi < MF ? xk[sl] : xkx;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) acc[mi][sl][r] = relu1(fmaf(wx[r], xs, c[r]));
+        }
+      }
+    };
+    node_params(0);
+    layer0(opaque_v(ucol_c), opaque_v(xcol_c));
+    frag_prefetch<HT, MF, XT>(rs, 16 * lane, opaque_s(4 * (L.o_Wf[1] + m0 * HT * 256)), opaque_s(4 * (L.o_Wf[1] + MF * HT * 256)), Apre);
+
+    for (int k0 = 0; k0 < a.NK; k0 += 2) {
+      const int ucol = opaque_v(ucol_c), xcol = opaque_v(xcol_c);   // (see opaque_v)
+      STAMP_SEL(grp, k0);
+      STAMP(0);
+      const float xkx = mh ? xk[1] : xk[0];           // the shared tile's node slot
+      // ---- input of hidden layer 1 (computed ahead, see above)
       {
         float* a1 = actbuf(1);
 #pragma unroll
-        for (int mi = 0; mi < MT; ++mi) {
-          const int cm = col(mi, ucol, xcol);
-          const f32x4 wx = ld4(smem + PL::o_w1x + cm);
-          const f32x4 c = ld4(c1buf + prow + cm);
+        for (int mi = 0; mi < MT; ++mi)
 #pragma unroll
-          for (int sl = 0; sl < (mi < MF ? 2 : 1); ++sl) {
-            const float xs = mi < MF ? xk[sl] : xkx;
-            f32x4 v;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] = fmaxf(fmaf(wx[r], xs, c[r]), 0.f);
-            *reinterpret_cast<f32x4*>(a1 + (mi < MF ? prow + sl * kGE * P : xrow) + cm) = v;
-          }
-        }
+          for (int sl = 0; sl < (mi < MF ? 2 : 1); ++sl)
+            *reinterpret_cast<f32x4*>(a1 + (mi < MF ? prow + sl * kGE * P : xrow) + col(mi, ucol, xcol)) = acc[mi][sl];
       }
+      STAMP(1);
       wg_barrier();                                   // input of layer 1 written
+      STAMP(2);
       // ---- hidden layers 1..NH-1, forward
-      f32x4 acc[MT][2];                               // pre-activation -> activation -> dpre of this wavefront's (units, pairs)
 #pragma unroll
       for (int l = 1; l < NH; ++l) {
 #pragma unroll
@@ -445,13 +524,18 @@ __global__ __launch_bounds__(64 * kWideWaves, 1) void mono_bwd_wide_k(MonoArgs a
         }
         layer_pass<HT, MF, XT, P>(rs, 16 * lane, opaque_s(4 * (L.o_Wf[l] + m0 * HT * 256)),
                                   opaque_s(4 * (L.o_Wf[l] + MF * HT * 256)), actbuf(l) + prow + 4 * q,
-                                  actbuf(l) + xrow + 4 * q, acc);
+                                  actbuf(l) + xrow + 4 * q, Apre, acc);
+        {                                             // next pass: the next layer, or the top layer's transpose
+          const int on = l < NH - 1 ? L.o_Wf[l < NH - 1 ? l + 1 : l] : L.o_WTf[NH - 1];
+          frag_prefetch<HT, MF, XT>(rs, 16 * lane, opaque_s(4 * (on + m0 * HT * 256)), opaque_s(4 * (on + MF * HT * 256)), Apre);
+        }
+        STAMP(3 + 3 * (l - 1));
 #pragma unroll
         for (int mi = 0; mi < MT; ++mi)
 #pragma unroll
           for (int sl = 0; sl < (mi < MF ? 2 : 1); ++sl)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) acc[mi][sl][r] = fmaxf(acc[mi][sl][r], 0.f);
+            for (int r = 0; r < 4; ++r) acc[mi][sl][r] = relu1(acc[mi][sl][r]);
         if (l < NH - 1) {
           float* an = actbuf(l + 1);
 #pragma unroll
@@ -459,7 +543,9 @@ __global__ __launch_bounds__(64 * kWideWaves, 1) void mono_bwd_wide_k(MonoArgs a
 #pragma unroll
             for (int sl = 0; sl < (mi < MF ? 2 : 1); ++sl)
               *reinterpret_cast<f32x4*>(an + (mi < MF ? prow + sl * kGE * P : xrow) + col(mi, ucol, xcol)) = acc[mi][sl];
+          STAMP(4 + 3 * (l - 1));
           wg_barrier();                               // input of layer l+1 written
+          STAMP(5 + 3 * (l - 1));
         }
       }
       // ---- last layer (H -> 1): partial dot over this wavefront's units, the two out halves meet in LDS
@@ -485,7 +571,9 @@ __global__ __launch_bounds__(64 * kWideWaves, 1) void mono_bwd_wide_k(MonoArgs a
           if (q == 0) sred[mh * kNP + kGE * sl + 16 * nh + j] = sp[sl];
         }
       }
+      STAMP(12);
       wg_barrier();                                   // last-layer partial dots written
+      STAMP(13);
       float dpl[2];
 #pragma unroll
       for (int sl = 0; sl < 2; ++sl) {
@@ -520,12 +608,19 @@ __global__ __launch_bounds__(64 * kWideWaves, 1) void mono_bwd_wide_k(MonoArgs a
 #pragma unroll
           for (int sl = 0; sl < (mi < MF ? 2 : 1); ++sl)
             *reinterpret_cast<f32x4*>(dpbuf + (mi < MF ? prow + sl * kGE * P : xrow) + col(mi, ucol, xcol)) = acc[mi][sl];
+        STAMP(14 + 5 * (NH - 1 - l));
         wg_barrier();                                 // dpre_l written
+        STAMP(15 + 5 * (NH - 1 - l));
         // d input_l = W_l^T dpre_l, gated by input_l > 0 (for l = 1 that is the first layer's dpre)
 #pragma unroll
         for (int mi = 0; mi < MT; ++mi) { acc[mi][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[mi][1] = acc[mi][0]; }
         layer_pass<HT, MF, XT, P>(rs, 16 * lane, opaque_s(4 * (L.o_WTf[l] + m0 * HT * 256)),
-                                  opaque_s(4 * (L.o_WTf[l] + MF * HT * 256)), dpbuf + prow + 4 * q, dpbuf + xrow + 4 * q, acc);
+                                  opaque_s(4 * (L.o_WTf[l] + MF * HT * 256)), dpbuf + prow + 4 * q, dpbuf + xrow + 4 * q, Apre, acc);
+        {                                             // next pass: the layer below, or layer 1 of the next batch
+          const int on = l > 1 ? L.o_WTf[l > 1 ? l - 1 : l] : L.o_Wf[1];
+          frag_prefetch<HT, MF, XT>(rs, 16 * lane, opaque_s(4 * (on + m0 * HT * 256)), opaque_s(4 * (on + MF * HT * 256)), Apre);
+        }
+        STAMP(16 + 5 * (NH - 1 - l));
         const float* ag = actbuf(l);
 #pragma unroll
         for (int mi = 0; mi < MT; ++mi)
@@ -535,7 +630,11 @@ __global__ __launch_bounds__(64 * kWideWaves, 1) void mono_bwd_wide_k(MonoArgs a
 #pragma unroll
             for (int r = 0; r < 4; ++r) acc[mi][sl][r] = g[r] > 0.f ? acc[mi][sl][r] : 0.f;
           }
-        wg_barrier();                                 // every reader of the dp buffer (and of input_l) is done
+        STAMP(17 + 5 * (NH - 1 - l));
+        if (l > 1) {
+          wg_barrier();                               // every reader of the dp buffer (and of input_l) is done
+          STAMP(18 + 5 * (NH - 1 - l));
+        }                                             // (l = 1: behind the first-layer section below)
       }
       // ---- first layer: rank-1 in x_k, node-independent in h
       float sx[2] = {0.f, 0.f}, sxx = 0.f;
@@ -562,6 +661,13 @@ __global__ __launch_bounds__(64 * kWideWaves, 1) void mono_bwd_wide_k(MonoArgs a
         v = qsum(v);
         if (q == 0) sxbuf[mh * kGE + 16 * nh + j] = v;
       }
+      if (k0 + 2 < a.NK) {                            // layer-1 input of the next batch, stored at the top of the loop
+        node_params(k0 + 2);
+        layer0(ucol, xcol);
+      }
+      STAMP(30);
+      wg_barrier();                                   // every reader of the dp buffer and of the layer inputs is done
+      STAMP(31);
     }
 
     // ---- per-group epilogue: Ds rows of the group's elements into the (free) input-1 buffer, then Dsum / dh / dx
@@ -622,6 +728,13 @@ unsigned gnf_mono_bwd_wide_grid(const gnfmono::MonoLayout&, int64_t n) {
   const int64_t groups = (n + kGE - 1) / kGE;
   return (unsigned)(groups < 256 ? groups : 256);     // one workgroup per CU, persistent
 }
+
+#ifdef GNF_WIDE_TIMING
+extern "C" int gnf_debug_wide_stamps(unsigned long long* host, int enable) {
+  if (enable >= 0) return (int)hipMemcpyToSymbol(HIP_SYMBOL(gnf_wide_stamp_on), &enable, sizeof(int));
+  return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(gnf_wide_stamps), sizeof(unsigned long long) * 8 * 32);
+}
+#endif
 
 int gnf_mono_bwd_wide_launch(const gnfmono::MonoArgs& a, unsigned grid, hipStream_t s) {
 #define GNF_WIDE_CASE(HT_, NH_) \

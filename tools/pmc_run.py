@@ -6,7 +6,12 @@ regex, out = sys.argv[1], sys.argv[2]
 cmd = [os.path.abspath(a) if os.path.exists(a) else a for a in sys.argv[sys.argv.index("--") + 1:]]   # rocprofv3 runs from /tmp
 PASSES = ["SQ_BUSY_CU_CYCLES SQ_VALU_MFMA_BUSY_CYCLES", "SQ_INSTS_MFMA SQ_INSTS_VALU", "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE",
           "SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS", "SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU", "SQ_WAIT_ANY SQ_ACTIVE_INST_ANY",
-          "SQ_WAVE_CYCLES SQ_BUSY_CYCLES", "SQ_INSTS_LDS SQ_INSTS_SALU"]
+          "SQ_WAVE_CYCLES SQ_BUSY_CYCLES", "SQ_INSTS_LDS SQ_INSTS_SALU",
+          # clock (GRBM_GUI_ACTIVE / kernel duration) and HBM bytes: FETCH_SIZE and WRITE_SIZE in their own passes
+          # (MI355X_MICROARCH.md: TCC slots; FETCH_SIZE counts 64 B per 128-B request of wide streaming reads -> doubled below)
+          "GRBM_GUI_ACTIVE", "FETCH_SIZE", "WRITE_SIZE"]
+if os.environ.get("PMC_PASSES"):                      # e.g. PMC_PASSES="GRBM_GUI_ACTIVE;FETCH_SIZE;WRITE_SIZE"
+    PASSES = [p.replace(",", " ") for p in os.environ["PMC_PASSES"].split(";")]
 env = dict(os.environ, TMPDIR="/tmp")
 acc = collections.defaultdict(lambda: collections.defaultdict(list))
 for i, counters in enumerate(PASSES):
@@ -21,7 +26,10 @@ for i, counters in enumerate(PASSES):
     for f in files:
         for row in csv.DictReader(open(f)):
             m = re.search(r"([A-Za-z_0-9]+_k)(<[^>]*>)?", row["Kernel_Name"])
-            acc[m.group(0) if m else row["Kernel_Name"]][row["Counter_Name"]].append(float(row["Counter_Value"]))
+            key = m.group(0) if m else row["Kernel_Name"]
+            acc[key][row["Counter_Name"]].append(float(row["Counter_Value"]))
+            if row["Counter_Name"] == "GRBM_GUI_ACTIVE" and row.get("Start_Timestamp") and row.get("End_Timestamp"):
+                acc[key]["_duration_ns_grbm_pass"].append(float(row["End_Timestamp"]) - float(row["Start_Timestamp"]))
 res = {"how": "rocprofv3 --pmc <2 counters per pass> --kernel-include-regex %s -- %s ; per-launch averages, chip totals" % (regex, " ".join(cmd)),
        "kernels": {}}
 for k, cs in acc.items():
@@ -34,6 +42,12 @@ for k, cs in acc.items():
     if "SQ_LDS_IDX_ACTIVE" in c and "SQ_BUSY_CU_CYCLES" in c and c["SQ_BUSY_CU_CYCLES"]:
         d["lds_active_frac_of_cu_cycles"] = round(c["SQ_LDS_IDX_ACTIVE"] / c["SQ_BUSY_CU_CYCLES"], 4)
         d["lds_bank_conflict_frac_of_cu_cycles"] = round(c.get("SQ_LDS_BANK_CONFLICT", 0) / c["SQ_BUSY_CU_CYCLES"], 4)
+    if "GRBM_GUI_ACTIVE" in c and c.get("_duration_ns_grbm_pass"):
+        d["effective_clock_GHz"] = round(c["GRBM_GUI_ACTIVE"] / c["_duration_ns_grbm_pass"], 3)
+    if "FETCH_SIZE" in c:                             # KB units
+        d["hbm_fetch_GB_doubled"] = round(2 * c["FETCH_SIZE"] * 1024 / 1e9, 3)
+    if "WRITE_SIZE" in c:
+        d["hbm_write_GB"] = round(c["WRITE_SIZE"] * 1024 / 1e9, 3)
     res["kernels"][k] = {"counters": {n: round(v, 1) for n, v in c.items()}, "derived": d}
 os.makedirs(os.path.dirname(os.path.abspath(out)), exist_ok=True)
 json.dump(res, open(out, "w"), indent=1)
