@@ -108,3 +108,6 @@ __device__ __forceinline__ float elu_plus(float s) { return (s > 0.f ? s : expm1
 bool gnf_mono_bwd_wide_ok(const gnfmono::MonoLayout& L);
 unsigned gnf_mono_bwd_wide_grid(const gnfmono::MonoLayout& L, int64_t n);
 int gnf_mono_bwd_wide_launch(const gnfmono::MonoArgs& a, unsigned grid, hipStream_t s);
+// forward (z, jac) of the same nets in the same formulation, two workgroups per CU
+bool gnf_mono_fwd_wide_ok(const gnfmono::MonoLayout& L);
+int gnf_mono_fwd_wide_launch(const gnfmono::MonoArgs& a, hipStream_t s);

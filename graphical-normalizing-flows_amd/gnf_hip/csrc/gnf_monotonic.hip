@@ -2107,6 +2107,7 @@ int gnf_monotonic_fwd(const float* pack, const gnf_mono_net* net, const float* x
   a.pack = pack; a.L = net_layout(net, HT);
   a.x = x; a.h = h; a.h_sb = h_sb; a.h_sd = h_sd; a.h_sc = h_sc;
   a.ccw = cc_w; a.cct = cc_t; a.S = S; a.z = z; a.jac = jac; a.n = B * d; a.d = d;
+  if (gnf_mono_fwd_wide_ok(a.L)) return gnf_mono_fwd_wide_launch(a, (hipStream_t)stream);
   return launch_fwd<false>(a, (hipStream_t)stream);
 }
 

@@ -700,6 +700,212 @@ __global__ __launch_bounds__(64 * kWideWaves, 1) void mono_bwd_wide_k(MonoArgs a
   if (lane == 0 && mh == 0) prow_g[(NH + 2) * HP] = vbl;
 }
 
+// =========================================================================================================================
+// Forward (z, jac) of wide nets in the same formulation: chain wavefronts only.  Nothing has to be kept for a backward,
+// so ONE pair-major buffer is enough (a layer's outputs wait in registers until every wavefront has read its inputs):
+// 66 KB of LDS at HT = 10 and 4 wavefronts of <= 256 registers per workgroup, i.e. TWO independent workgroups per CU --
+// the serial sections of one (layer-0 inputs, ReLU + stores, the last-layer exchange, barriers) sit under the MFMAs of
+// the other.  z = sum_k w_k f(x_k) * xT/2 + h0 accumulates per lane over the batches of the element's group.
+// =========================================================================================================================
+template <int HT, int NH>
+struct WidePlanF {
+  static constexpr int HP = 16 * HT, P = HP + 4;
+  static constexpr int o_w1x = 0, o_wL = HP, o_b = 2 * HP;
+  static constexpr int o_bL = o_b + (NH - 1) * HP;
+  static constexpr int o_c1 = o_bL + 4;                     // [32][P]
+  static constexpr int o_act = o_c1 + kGE * P;              // [64][P]  input of the layer being evaluated
+  static constexpr int o_sred = o_act + kNP * P;            // [2][64]
+  static constexpr int total = o_sred + 2 * kNP;
+};
+
+template <int HT, int NH>
+__global__ __launch_bounds__(64 * kWaves, 2) void mono_fwd_wide_k(MonoArgs a) {
+  using PL = WidePlanF<HT, NH>;
+  constexpr int HP = PL::HP, P = PL::P;
+  constexpr int MF = HT / 2, XT = HT & 1, MT = MF + XT;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const MonoLayout& L = a.L;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int q = lane >> 4, j = lane & 15;
+  float* const c1buf = smem + PL::o_c1;
+  float* const act = smem + PL::o_act;
+  float* const sred = smem + PL::o_sred;
+  for (int i = threadIdx.x; i < HP; i += blockDim.x) {
+    smem[PL::o_w1x + i] = a.pack[L.o_w1x + i];
+    smem[PL::o_wL + i] = a.pack[L.o_wL + i];
+#pragma unroll
+    for (int l = 1; l < NH; ++l) smem[PL::o_b + (l - 1) * HP + i] = a.pack[L.o_b[l] + i];
+  }
+  if (threadIdx.x == 0) smem[PL::o_bL] = a.pack[L.o_bL];
+
+  const int mh = wave & 1, nh = wave >> 1;            // as in the backward's chain role
+  const int m0 = mh * (MF + XT);
+  const rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.pack), 0, L.pack_floats * 4, 0x00020000);
+  const int prow = (16 * nh + j) * P, xrow = prow + mh * kGE * P;
+  const int ucol_c = 16 * m0 + 4 * q, xcol_c = 16 * MF + 4 * q;
+  auto col = [&](int mi, int uc, int xc) { return mi < MF ? uc + 16 * mi : xc; };
+  const int64_t ngroups = (a.n + kGE - 1) / kGE;
+  const float fS = (float)a.S;
+  const int NK = (a.S + 2 + 1) / 2 * 2;
+
+  for (int64_t grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
+    const int64_t el = grp * kGE + 16 * nh + j;
+    const bool valid = el < a.n;
+    const int64_t e = valid ? el : a.n - 1;
+    const int64_t b = e / a.d, i = e - b * a.d;
+    const int64_t hbase = b * a.h_sb + i * a.h_sd;
+    const float xv = a.x[e];
+    const float xT = fS * (xv / fS);                  // xT = x0 + nb_steps * step, x0 = 0
+    const float h0 = a.h[hbase];
+    {
+      f32x4 c[MT];
+#pragma unroll
+      for (int mi = 0; mi < MT; ++mi) c[mi] = ld4(a.pack + L.o_b1 + col(mi, ucol_c, xcol_c));
+      for (int s = 0; s < L.CP / 16; ++s) {
+        float hv[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int cc = 16 * s + 4 * q + r;
+          hv[r] = cc < L.c ? a.h[hbase + cc * a.h_sc] : 0.f;
+        }
+#pragma unroll
+        for (int mi = 0; mi < MT; ++mi) {
+          const int tile = mi < MF ? m0 + mi : MF;
+          const f32x4 A = ld4(a.pack + L.o_W1h + (16 * tile + j) * L.LDH + 16 * s + 4 * q);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) c[mi] = mfma(A[r], hv[r], c[mi]);
+        }
+      }
+      __syncthreads();                                // the previous group's c1 / act / sred are no longer read
+#pragma unroll
+      for (int mi = 0; mi < MT; ++mi) *reinterpret_cast<f32x4*>(c1buf + prow + col(mi, ucol_c, xcol_c)) = c[mi];
+    }
+    __syncthreads();                                  // c1 written
+
+    float xk[2], wq[2];
+    bool isj[2];
+    f32x4 acc[MT][2], Apre[MT];
+    auto node_params = [&](int k0) {
+#pragma unroll
+      for (int sl = 0; sl < 2; ++sl) {
+        const int k = k0 + sl;
+        const bool isq = k <= a.S;
+        isj[sl] = k == a.S + 1;
+        wq[sl] = isq ? a.ccw[k] : 0.f;
+        xk[sl] = isq ? xT * (a.cct[isq ? k : 0] + 1.f) * .5f : xv;
+      }
+    };
+    auto layer0 = [&](int ucol, int xcol) {
+      const float xkx = mh ? xk[1] : xk[0];
+#pragma unroll
+      for (int mi = 0; mi < MT; ++mi) {
+        const int cm = col(mi, ucol, xcol);
+        const f32x4 wx = ld4(smem + PL::o_w1x + cm);
+        const f32x4 c = ld4(c1buf + prow + cm);
+#pragma unroll
+        for (int sl = 0; sl < (mi < MF ? 2 : 1); ++sl) {
+          const float xs = mi < MF ? xk[sl] : xkx;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) acc[mi][sl][r] = relu1(fmaf(wx[r], xs, c[r]));
+        }
+      }
+    };
+    auto store_act = [&](int ucol, int xcol) {
+#pragma unroll
+      for (int mi = 0; mi < MT; ++mi)
+#pragma unroll
+        for (int sl = 0; sl < (mi < MF ? 2 : 1); ++sl)
+          *reinterpret_cast<f32x4*>(act + (mi < MF ? prow + sl * kGE * P : xrow) + col(mi, ucol, xcol)) = acc[mi][sl];
+    };
+    node_params(0);
+    layer0(opaque_v(ucol_c), opaque_v(xcol_c));
+    frag_prefetch<HT, MF, XT>(rs, 16 * lane, opaque_s(4 * (L.o_Wf[1] + m0 * HT * 256)), opaque_s(4 * (L.o_Wf[1] + MF * HT * 256)), Apre);
+    float zacc = 0.f, fjac = 0.f;
+
+    for (int k0 = 0; k0 < NK; k0 += 2) {
+      const int ucol = opaque_v(ucol_c), xcol = opaque_v(xcol_c);
+      store_act(ucol, xcol);                          // input of hidden layer 1 (computed ahead)
+      __syncthreads();
+#pragma unroll
+      for (int l = 1; l < NH; ++l) {
+#pragma unroll
+        for (int mi = 0; mi < MT; ++mi) {
+          acc[mi][0] = ld4(smem + PL::o_b + (l - 1) * HP + col(mi, ucol, xcol));
+          acc[mi][1] = acc[mi][0];
+        }
+        layer_pass<HT, MF, XT, P>(rs, 16 * lane, opaque_s(4 * (L.o_Wf[l] + m0 * HT * 256)),
+                                  opaque_s(4 * (L.o_Wf[l] + MF * HT * 256)), act + prow + 4 * q, act + xrow + 4 * q, Apre, acc);
+        {
+          const int on = L.o_Wf[l < NH - 1 ? l + 1 : 1];
+          frag_prefetch<HT, MF, XT>(rs, 16 * lane, opaque_s(4 * (on + m0 * HT * 256)), opaque_s(4 * (on + MF * HT * 256)), Apre);
+        }
+#pragma unroll
+        for (int mi = 0; mi < MT; ++mi)
+#pragma unroll
+          for (int sl = 0; sl < (mi < MF ? 2 : 1); ++sl)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[mi][sl][r] = relu1(acc[mi][sl][r]);
+        if (l < NH - 1) {
+          __syncthreads();                            // every wavefront has read the layer's inputs
+          store_act(ucol, xcol);
+          __syncthreads();
+        }
+      }
+      {
+        float sp[2] = {0.f, 0.f}, spx = 0.f;
+#pragma unroll
+        for (int mi = 0; mi < MT; ++mi) {
+          const f32x4 wl = ld4(smem + PL::o_wL + col(mi, ucol, xcol));
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            if (mi < MF) {
+              sp[0] = fmaf(wl[r], acc[mi][0][r], sp[0]);
+              sp[1] = fmaf(wl[r], acc[mi][1][r], sp[1]);
+            } else {
+              spx = fmaf(wl[r], acc[mi][0][r], spx);
+            }
+          }
+        }
+        if constexpr (XT) { sp[0] += mh ? 0.f : spx; sp[1] += mh ? spx : 0.f; }
+#pragma unroll
+        for (int sl = 0; sl < 2; ++sl) {
+          sp[sl] = qsum(sp[sl]);
+          if (q == 0) sred[mh * kNP + kGE * sl + 16 * nh + j] = sp[sl];
+        }
+      }
+      __syncthreads();                                // partial dots written (and the layer inputs no longer read)
+#pragma unroll
+      for (int sl = 0; sl < 2; ++sl) {
+        const float s = (sred[kGE * sl + 16 * nh + j] + sred[kNP + kGE * sl + 16 * nh + j]) + smem[PL::o_bL];
+        const float f = elu_plus(s);
+        zacc = fmaf(wq[sl], f, zacc);
+        if (isj[sl]) fjac = f;
+      }
+      if (k0 + 2 < NK) {
+        node_params(k0 + 2);
+        layer0(ucol, xcol);
+      }
+    }
+    if (valid && mh == 0 && q == 0) {
+      a.z[el] = zacc * xT * .5f + h0;
+      a.jac[el] = fjac;
+    }
+  }
+}
+
+template <int HT, int NH>
+int launch_wide_fwd(const MonoArgs& a, hipStream_t s) {
+  const size_t lds = (size_t)WidePlanF<HT, NH>::total * sizeof(float);
+  const int64_t groups = (a.n + kGE - 1) / kGE;
+  const int per_cu = lds * 3 <= (size_t)160 * 1024 ? 3 : 2;          // workgroups per CU (140 registers: up to 3 per SIMD)
+  const unsigned grid = (unsigned)(groups < 256 * per_cu ? groups : 256 * per_cu);   // persistent
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mono_fwd_wide_k<HT, NH>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipLaunchKernelGGL((mono_fwd_wide_k<HT, NH>), dim3(grid), dim3(64 * kWaves), lds, s, a);
+  GNF_LAUNCH_CHECK();
+  return 0;
+}
+
 template <int HT, int NH>
 int launch_wide(const MonoArgs& a, unsigned grid, hipStream_t s) {
   const size_t lds = (size_t)WidePlan<HT, NH>::total * sizeof(float);
@@ -740,6 +946,20 @@ int gnf_mono_bwd_wide_launch(const gnfmono::MonoArgs& a, unsigned grid, hipStrea
 #define GNF_WIDE_CASE(HT_, NH_) \
   if (a.L.HT == HT_ && a.L.NH == NH_) return launch_wide<HT_, NH_>(a, grid, s);
   GNF_WIDE_CASE(7, 2) GNF_WIDE_CASE(7, 3) GNF_WIDE_CASE(7, 4) GNF_WIDE_CASE(10, 2) GNF_WIDE_CASE(10, 3)
+#undef GNF_WIDE_CASE
+  return GNF_ESHAPE;
+}
+
+bool gnf_mono_fwd_wide_ok(const gnfmono::MonoLayout& L) {
+  static const bool off = getenv("GNF_MONO_WIDE_FWD") && getenv("GNF_MONO_WIDE_FWD")[0] == '0';   // A/B switch (measurement)
+  if (off || L.c > 32 || L.NH < 2 || L.NH > 4) return false;
+  return L.HT == 7 || L.HT == 10;
+}
+
+int gnf_mono_fwd_wide_launch(const gnfmono::MonoArgs& a, hipStream_t s) {
+#define GNF_WIDE_CASE(HT_, NH_) \
+  if (a.L.HT == HT_ && a.L.NH == NH_) return launch_wide_fwd<HT_, NH_>(a, s);
+  GNF_WIDE_CASE(7, 2) GNF_WIDE_CASE(7, 3) GNF_WIDE_CASE(7, 4) GNF_WIDE_CASE(10, 2) GNF_WIDE_CASE(10, 3) GNF_WIDE_CASE(10, 4)
 #undef GNF_WIDE_CASE
   return GNF_ESHAPE;
 }
