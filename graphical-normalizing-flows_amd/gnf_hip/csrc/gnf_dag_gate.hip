@@ -63,8 +63,11 @@ __global__ void dag_gate_tab_k(const float* __restrict__ A, float* __restrict__ 
 // Forward and backward use the same mapping, so the backward regenerates the forward's noise.
 struct Draw4 { float v[4]; };
 
-__device__ __forceinline__ float u01_open(uint32_t w) {      // 24-bit uniform centred in its cell: never exactly 0 or 1
-  return ((float)(w >> 8) + .5f) * (1.0f / 16777216.0f);
+// 23-bit uniform centred in its cell: never exactly 0 or 1.  (With 24 bits the + .5f is a rounding tie for words >= 2^23 and
+// rounds to even: 16777215.5 -> 16777216, i.e. V = 1.0f about four times per cfg4 step and V / (1 - V) = inf in the
+// single-uniform Gumbel ratio.  With 23 bits k + .5 is exactly representable for every k < 2^23.)
+__device__ __forceinline__ float u01_open(uint32_t w) {
+  return ((float)(w >> 9) + .5f) * (1.0f / 8388608.0f);
 }
 
 __device__ __forceinline__ Draw4 draw4(int gate_mode, const float* u1, const float* u2, uint64_t seed, uint64_t offset,

@@ -40,16 +40,6 @@ class FlatState:
             o += pad4(q.numel())
         self.active_runs = [(0, n)]                # [(offset, length)] of the flat buffer Adam steps; see pack_grads
 
-    def rebind(self):
-        """Re-alias every parameter to its slice of the flat buffer, keeping the parameter's CURRENT values -- for host
-        code that rebinds `p.data` (the reference's post_process does, DAGConditioner.py:88; this package's does not)."""
-        for q, o in zip(self.params, self._offsets):
-            k = q.numel()
-            view = self.flat[o:o + k].view_as(q)
-            if q.data.data_ptr() != view.data_ptr():
-                view.copy_(q.data)
-                q.data = view
-
     def pack_grads(self, grads=None):
         """flat gradient buffer <- the .grad tensors autograd just produced (or the given list, in self.params order),
         in ONE concatenation launch.  (.grad views into the flat buffer would cost a zero-fill plus one accumulate
@@ -316,6 +306,7 @@ class GraphedStep:
             self._graphs.pop(next(iter(self._graphs)))
         self._graphs[self._fingerprint(x.shape)] = (graph, loss, xbuf)
         self.captures += 1
+        self._dev_t = state.t                   # host mirror of step_dev (a capture itself executes nothing)
         return last
 
     def __call__(self, x):
@@ -327,7 +318,13 @@ class GraphedStep:
             return self.loss
         graph, loss, xbuf = entry
         xbuf.copy_(x, non_blocking=True)
+        if getattr(self, "_dev_t", None) != self.state.t:
+            # eager steps in between (graph=False, a batch above GRAPH_MAX_ELEMS, a variant that was briefly not
+            # graphable) advanced state.t but not the device-side counter the replayed Adam launches read: re-sync it
+            # with a plain launch outside the graph, or the bias corrections lr/(1-b1^t), sqrt(1-b2^t) go stale
+            self.step_dev.fill_(self.state.t)
         graph.replay()
         self.state.t += 1
+        self._dev_t = self.state.t
         self.loss = loss
         return loss

@@ -220,7 +220,7 @@ def train(args):
     if args.load:                                            # reference :186-188
         for c in model.getConditioners():
             if hasattr(c, "getAlpha"):
-                c.alpha = c.getAlpha()
+                c._set("alpha", c.getAlpha())     # in place: the buffer keeps its device address
     log = open(os.path.join(args.folder, "logs"), "a") if rank == 0 else None
 
     def say(msg):
@@ -242,6 +242,9 @@ def train(args):
             shards = [r for r in shard_batches(trn.shape[0], b * world, rank, world, host_gen) if r.numel() == b]
             if args.max_batches:
                 shards = shards[:args.max_batches]
+            if k_acc > 1:                                    # micro-batch gradients left over from an epoch whose batch
+                for p in state.params:                       # count is no multiple of k are dropped, as the reference's
+                    p.grad = None                            # zero_grad() at batch_idx % k == 0 does (:210-211)
             for n, rows in enumerate(shards, 1):
                 if norm_t is MonotonicNormalizer:            # node-count jitter (:201-203)
                     k = args.nb_steps + int(torch.randint(0, 10, [1], generator=host_gen))

@@ -65,6 +65,28 @@ def test_dual_update_trajectories_gpu(name):
         assert c._constraints_off() and float(c.loss()) == 0.
 
 
+def test_A_keeps_training_after_a_failed_post_processing():
+    """Deliberate divergence: the reference re-opens the gate by installing a NEW nn.Parameter
+    (DAGConditioner.py:224) that its optimiser never steps, so A silently freezes; here the saved values go back into the
+    same Parameter and an optimiser built before the failure keeps updating it."""
+    from models import DAGConditioner
+    g = load_golden("dag_dual")
+    d, l1, nbu, th, off = [float(v) for v in g["failure.cfg"]]
+    torch.manual_seed(0)
+    c = DAGConditioner(int(d), [8], 2, l1=l1, nb_epoch_update=int(nbu), A_prior=g["failure.A0"].clone())
+    opt = torch.optim.SGD(c.parameters(), lr=.1)      # built BEFORE the failed post-processing, like a driver's
+    pp = c.post_process
+    c.post_process = lambda zero_threshold=None: pp(th)
+    for epoch, loss_avg in g["failure.calls"].tolist():
+        c.step(int(epoch), torch.tensor(loss_avg))
+    assert c.A.requires_grad and c.stoch_gate and c.A.grad is None
+    before = c.A.detach().clone()
+    opt.zero_grad()
+    c.loss().backward()
+    opt.step()
+    assert (c.A.detach() != before).any()
+
+
 def test_post_process_auto_threshold_loop():
     """post_process(None) raises the threshold from .1 in steps of .05 until the kept edges are acyclic
     (reference :76-92): a 3-cycle whose weakest edge has soft-thresholded weight ~.31 needs 5 increments."""

@@ -228,6 +228,37 @@ def test_graphed_step_vs_torch_adam_reference():
         assert rel_err(pb.detach().cpu(), pa.detach().cpu()) < 1e-5, k
 
 
+def test_graph_replay_after_eager_steps_keeps_the_adam_step_count():
+    """train_step(graph='auto') interleaved with eager steps (graph=False): the eager ones advance state.t but not the
+    device-side counter of the captured Adam launches; a later replay must see the right count (bias corrections).
+    Reference trajectory: torch.optim.Adam on the same flow."""
+    from gnf_hip import dp
+    from models import buildFCNormalizingFlow, AutoregressiveConditioner, AffineNormalizer
+
+    def make():
+        torch.manual_seed(13)
+        return buildFCNormalizingFlow(1, AutoregressiveConditioner, {"in_size": 10, "hidden": [48, 48], "out_size": 2},
+                                      AffineNormalizer, {}).to(DEV)
+    xs = [torch.randn(32, 10, generator=torch.Generator().manual_seed(300 + i)).to(DEV) for i in range(9)]
+    modes = ["auto", "auto", False, False, False, "auto", False, "auto", "auto"]     # replays behind eager steps
+    fa = make()
+    opt = torch.optim.Adam(fa.parameters(), lr=1e-2, weight_decay=1e-5)
+    for x in xs:
+        opt.zero_grad()
+        z, ld = fa(x)
+        fa.loss(z, ld).backward()
+        opt.step()
+    fb = make()
+    sb = dp.FlatState(fb)
+    for x, mode in zip(xs, modes):
+        dp.train_step(fb, sb, x, lr=1e-2, weight_decay=1e-5, graph=mode)
+    torch.cuda.synchronize()
+    assert sb.t == len(xs)
+    assert int(sb._graphed.step_dev.item()) == sb.t
+    for (k, pa), (_, pb) in zip(fa.named_parameters(), fb.named_parameters()):
+        assert rel_err(pb.detach().cpu(), pa.detach().cpu()) < 1e-5, k
+
+
 def _free_port():
     import socket
     with socket.socket() as s:
