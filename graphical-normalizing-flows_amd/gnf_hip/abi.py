@@ -20,7 +20,7 @@ c_u64 = ctypes.c_uint64
 c_stream = ctypes.c_void_p
 
 MONO_MAX_LAYERS = 8
-ABI_VERSION = 2           # GNF_ABI_VERSION of include/gnf_hip.h this binding was written against
+ABI_VERSION = 3           # GNF_ABI_VERSION of include/gnf_hip.h this binding was written against
 
 
 class MonoNet(ctypes.Structure):
@@ -32,14 +32,16 @@ class MonoNet(ctypes.Structure):
 # name -> (restype, argtypes); must list every symbol include/gnf_hip.h declares
 SIGNATURES = {
     "gnf_abi_version": (c_int, []),
-    "gnf_affine_fwd": (c_int, [c_f, c_f, c_i64, c_i64, c_i64, c_f, c_f, c_f, c_int, c_i64, c_i64, c_stream]),
-    "gnf_affine_bwd": (c_int, [c_f, c_f, c_i64, c_i64, c_i64, c_f, c_f, c_f, c_f, c_f, c_i64, c_i64, c_i64, c_i64,
+    "gnf_affine_fwd": (c_int, [c_f, c_f, c_i64, c_i64, c_i64, c_f, c_f, c_f, c_f, c_int, c_i64, c_i64, c_stream]),
+    "gnf_affine_bwd": (c_int, [c_f, c_f, c_i64, c_i64, c_i64, c_f, c_f, c_f, c_f, c_f, c_f, c_i64, c_i64, c_i64, c_i64,
                                c_i64, c_stream]),
     "gnf_affine_inv": (c_int, [c_f, c_f, c_i64, c_i64, c_i64, c_f, c_i64, c_i64, c_stream]),
     "gnf_logsum_rows_fwd": (c_int, [c_f, c_f, c_i64, c_i64, c_stream]),
     "gnf_logsum_rows_bwd": (c_int, [c_f, c_f, c_f, c_i64, c_i64, c_stream]),
     "gnf_normal_logdensity_fwd": (c_int, [c_f, c_f, c_i64, c_i64, c_stream]),
     "gnf_normal_logdensity_bwd": (c_int, [c_f, c_f, c_f, c_i64, c_i64, c_stream]),
+    "gnf_nll_reduce_fwd": (c_int, [c_f, c_f, c_f, c_f, c_i64, c_i64, c_stream]),
+    "gnf_nll_reduce_bwd": (c_int, [c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_i64, c_i64, c_stream]),
     "gnf_colsum_ws_bytes": (c_i64, [c_i64, c_i64]),
     "gnf_colsum": (c_int, [c_f, c_i64, c_f, c_i64, c_i64, c_f, c_stream]),
     "gnf_gemm_ws_bytes": (c_i64, [c_i64, c_i64, c_i64]),

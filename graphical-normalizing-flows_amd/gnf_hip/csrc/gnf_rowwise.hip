@@ -45,6 +45,7 @@ constexpr int kBlock = 256;
   } while (0)
 
 __device__ __forceinline__ float clampf(float v, float lo, float hi) { return fminf(fmaxf(v, lo), hi); }
+constexpr float kLog2Pi = 1.8378770664093453f;     // log(2 pi): summed per element with z^2, like the reference does
 
 // ------------------------------------------------------------------ Affine normalizer
 // R rows per lane group per pass: R independent load streams per lane hide the HBM latency at large B; when h is the
@@ -52,13 +53,14 @@ __device__ __forceinline__ float clampf(float v, float lo, float hi) { return fm
 template <int G, int R>
 __global__ void affine_fwd_k(const float* __restrict__ x, float* __restrict__ h, int64_t h_sb, int64_t h_sd,
                              int64_t h_sc, float* __restrict__ z, float* __restrict__ jac,
-                             float* __restrict__ logdet, int clamp_inplace, int64_t B, int64_t d) {
+                             float* __restrict__ logdet, float* __restrict__ logn, int clamp_inplace, int64_t B,
+                             int64_t d) {
   const int64_t row0 = ((int64_t)blockIdx.x * (kBlock / G) + threadIdx.x / G) * R;
   const int g = threadIdx.x % G;
   const bool pair = (h_sc == 1 && h_sd == 2 && (h_sb & 1) == 0);
-  float ld[R];
+  float ld[R], ln[R];
 #pragma unroll
-  for (int k = 0; k < R; ++k) ld[k] = 0.f;
+  for (int k = 0; k < R; ++k) { ld[k] = 0.f; ln[k] = 0.f; }
   for (int64_t i = g; i < d; i += G) {
     float h0[R], h1[R], xv[R];
 #pragma unroll
@@ -81,24 +83,31 @@ __global__ void affine_fwd_k(const float* __restrict__ x, float* __restrict__ h,
       const float ls = clampf(h1[k], -5.f, 2.f);
       const float sg = expf(ls);
       const int64_t e = row * d + i;
-      z[e] = fmaf(xv[k], sg, mu);
+      const float zv = fmaf(xv[k], sg, mu);
+      z[e] = zv;
       if (jac) jac[e] = sg;
       if (clamp_inplace) { const int64_t hi = row * h_sb + i * h_sd; h[hi] = mu; h[hi + h_sc] = ls; }
       ld[k] += ls;
+      ln[k] += kLog2Pi + zv * zv;
     }
   }
 #pragma unroll
   for (int k = 0; k < R; ++k) {
     const float s = group_sum<G>(ld[k]);
     if (logdet && row0 + k < B && g == 0) logdet[row0 + k] = s;
+    if (logn) {                                      // Normal log-density of the row (NormalizingFlowFactories.py:15-16)
+      const float t = group_sum<G>(ln[k]);
+      if (row0 + k < B && g == 0) logn[row0 + k] = -0.5f * t;
+    }
   }
 }
 
 template <int G, int R>
 __global__ void affine_bwd_k(const float* __restrict__ x, const float* __restrict__ h, int64_t h_sb, int64_t h_sd,
                              int64_t h_sc, const float* __restrict__ gz, const float* __restrict__ gjac,
-                             const float* __restrict__ glogdet, float* __restrict__ gx, float* __restrict__ gh,
-                             int64_t g_sb, int64_t g_sd, int64_t g_sc, int64_t B, int64_t d) {
+                             const float* __restrict__ glogdet, const float* __restrict__ glogn,
+                             float* __restrict__ gx, float* __restrict__ gh, int64_t g_sb, int64_t g_sd, int64_t g_sc,
+                             int64_t B, int64_t d) {
   const int64_t row0 = ((int64_t)blockIdx.x * (kBlock / G) + threadIdx.x / G) * R;
   const int g = threadIdx.x % G;
   const bool pair = (h_sc == 1 && h_sd == 2 && (h_sb & 1) == 0);
@@ -130,9 +139,11 @@ __global__ void affine_bwd_k(const float* __restrict__ x, const float* __restric
       const float m1 = (h1[k] >= -5.f && h1[k] <= 2.f) ? 1.f : 0.f;
       const float sg = expf(clampf(h1[k], -5.f, 2.f));
       const int64_t e = row * d + i;
-      if (gx) gx[e] = gzv[k] * sg;
+      // cotangent of z: what came in, plus the Normal log-density's -z * g when that reduction was fused into the forward
+      const float gze = glogn ? fmaf(-fmaf(xv[k], sg, clampf(h0[k], -5.f, 5.f)), glogn[row], gzv[k]) : gzv[k];
+      if (gx) gx[e] = gze * sg;
       const int64_t gi = row * g_sb + i * g_sd;
-      const float o0 = gzv[k] * m0, o1 = (fmaf(gzv[k] * xv[k], sg, gjv[k] * sg) + gl) * m1;
+      const float o0 = gze * m0, o1 = (fmaf(gze * xv[k], sg, gjv[k] * sg) + gl) * m1;
       if (gpair) *reinterpret_cast<float2*>(gh + gi) = make_float2(o0, o1);
       else { gh[gi] = o0; gh[gi + g_sc] = o1; }
     }
@@ -155,7 +166,8 @@ __device__ __forceinline__ float wave_sum(float v) {
 template <int RW, int U>
 __global__ __launch_bounds__(kBlock) void affine_fwd_flat_k(const float* __restrict__ x, const float* __restrict__ h,
                                                             float* __restrict__ z, float* __restrict__ jac,
-                                                            float* __restrict__ logdet, int64_t B, int d) {
+                                                            float* __restrict__ logdet, float* __restrict__ logn,
+                                                            int64_t B, int d) {
   const int lane = threadIdx.x & 63;
   const int64_t gw = (int64_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6), nw = (int64_t)gridDim.x * (kBlock / 64);
   const int64_t nspan = (B + RW - 1) / RW;
@@ -191,7 +203,7 @@ __global__ __launch_bounds__(kBlock) void affine_fwd_flat_k(const float* __restr
       const int64_t row0 = (sp0 + u) * RW, base = row0 * d + 4 * lane;
       const float h0[4] = {ha[u][0], ha[u][2], hb[u][0], hb[u][2]}, h1[4] = {ha[u][1], ha[u][3], hb[u][1], hb[u][3]};
       f32x4r zv, jv;
-      float ls[4];
+      float ls[4], lq[4];
 #pragma unroll
       for (int c = 0; c < 4; ++c) {
         const float mu = clampf(h0[c], -5.f, 5.f);
@@ -199,7 +211,8 @@ __global__ __launch_bounds__(kBlock) void affine_fwd_flat_k(const float* __restr
         const float sg = expf(ls[c]);
         zv[c] = fmaf(xv[u][c], sg, mu);
         jv[c] = sg;
-        if (4 * lane + c >= ne[u]) ls[c] = 0.f;
+        lq[c] = kLog2Pi + zv[c] * zv[c];
+        if (4 * lane + c >= ne[u]) { ls[c] = 0.f; lq[c] = 0.f; }
       }
       if (4 * lane + 3 < ne[u]) {
         __builtin_nontemporal_store(zv, reinterpret_cast<f32x4r*>(z + base));
@@ -219,6 +232,16 @@ __global__ __launch_bounds__(kBlock) void affine_fwd_flat_k(const float* __restr
           if (lane == 0 && row0 + rr < B) logdet[row0 + rr] = sv;
         }
       }
+      if (logn) {
+#pragma unroll
+        for (int rr = 0; rr < RW; ++rr) {
+          float sv = 0.f;
+#pragma unroll
+          for (int c = 0; c < 4; ++c) sv += rid[c] == rr ? lq[c] : 0.f;
+          sv = wave_sum(sv);
+          if (lane == 0 && row0 + rr < B) logn[row0 + rr] = -0.5f * sv;
+        }
+      }
     }
   }
 }
@@ -226,7 +249,8 @@ __global__ __launch_bounds__(kBlock) void affine_fwd_flat_k(const float* __restr
 template <int RW, int U>
 __global__ __launch_bounds__(kBlock) void affine_bwd_flat_k(const float* __restrict__ x, const float* __restrict__ h,
                                                             const float* __restrict__ gz, const float* __restrict__ gjac,
-                                                            const float* __restrict__ glogdet, float* __restrict__ gx,
+                                                            const float* __restrict__ glogdet,
+                                                            const float* __restrict__ glogn, float* __restrict__ gx,
                                                             float* __restrict__ gh, int64_t B, int d) {
   const int lane = threadIdx.x & 63;
   const int64_t gw = (int64_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6), nw = (int64_t)gridDim.x * (kBlock / 64);
@@ -277,8 +301,10 @@ __global__ __launch_bounds__(kBlock) void affine_bwd_flat_k(const float* __restr
         const float m0 = (h0[c] >= -5.f && h0[c] <= 5.f) ? 1.f : 0.f;
         const float m1 = (h1[c] >= -5.f && h1[c] <= 2.f) ? 1.f : 0.f;
         const float sg = expf(clampf(h1[c], -5.f, 2.f));
-        ox[c] = gv[u][c] * sg;
-        const float o0 = gv[u][c] * m0, o1 = (fmaf(gv[u][c] * xv[u][c], sg, jv[u][c] * sg) + gl) * m1;
+        const float gn = (glogn && ok) ? glogn[row0 + rid[c]] : 0.f;
+        const float gze = fmaf(-fmaf(xv[u][c], sg, clampf(h0[c], -5.f, 5.f)), gn, gv[u][c]);   // + d logN / dz = -z
+        ox[c] = gze * sg;
+        const float o0 = gze * m0, o1 = (fmaf(gze * xv[u][c], sg, jv[u][c] * sg) + gl) * m1;
         if (c < 2) { oa[2 * c] = o0; oa[2 * c + 1] = o1; } else { ob[2 * c - 4] = o0; ob[2 * c - 3] = o1; }
       }
       if (4 * lane + 3 < ne[u]) {
@@ -320,43 +346,414 @@ __global__ void affine_inv_k(const float* __restrict__ z, const float* __restric
 }
 
 // ------------------------------------------------------------------ row reductions
+// log|det J| = sum_d log jac (NormalizingFlow.py:70) and the Normal log-density -1/2 sum_d (log 2 pi + z^2)
+// (NormalizingFlowFactories.py:15-16) of a row in ONE pass over z and jac; either output may be absent (jac == NULL: only
+// the density; logn == NULL: only the log-determinant).  G lanes per row.
 template <int G>
-__global__ void logsum_rows_k(const float* __restrict__ jac, float* __restrict__ out, int64_t B, int64_t d) {
+__global__ void nll_rows_k(const float* __restrict__ z, const float* __restrict__ jac, float* __restrict__ logdet,
+                           float* __restrict__ logn, int64_t B, int64_t d) {
   const int64_t row = (int64_t)blockIdx.x * (kBlock / G) + threadIdx.x / G;
   const int g = threadIdx.x % G;
-  float s = 0.f;
-  if (row < B)
-    for (int64_t i = g; i < d; i += G) s += logf(jac[row * d + i]);
-  s = group_sum<G>(s);
-  if (row < B && g == 0) out[row] = s;
-}
-
-template <int G>
-__global__ void normal_ld_rows_k(const float* __restrict__ z, float* __restrict__ out, int64_t B, int64_t d) {
-  const int64_t row = (int64_t)blockIdx.x * (kBlock / G) + threadIdx.x / G;
-  const int g = threadIdx.x % G;
-  float s = 0.f;
+  float sl = 0.f, sn = 0.f;
   if (row < B)
     for (int64_t i = g; i < d; i += G) {
-      const float v = z[row * d + i];
-      s += 1.8378770664093453f + v * v;  // log(2 pi) + z^2, summed like the reference does
+      if (jac) sl += logf(jac[row * d + i]);
+      if (logn) { const float v = z[row * d + i]; sn += kLog2Pi + v * v; }
     }
-  s = group_sum<G>(s);
-  if (row < B && g == 0) out[row] = -0.5f * s;
+  if (jac) { sl = group_sum<G>(sl); if (row < B && g == 0) logdet[row] = sl; }
+  if (logn) { sn = group_sum<G>(sn); if (row < B && g == 0) logn[row] = -0.5f * sn; }
 }
 
-__global__ void logsum_rows_bwd_k(const float* __restrict__ jac, const float* __restrict__ g, float* __restrict__ gj,
-                                  int64_t B, int64_t d) {
-  const int64_t n = B * d;
-  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x)
-    gj[e] = g[e / d] / jac[e];
+// backward of both: gz = gz_in - z * glogn[row], gjac = glogdet[row] / jac (no integer division per element: rows are
+// dealt to lane groups as in the forward)
+template <int G>
+__global__ void nll_rows_bwd_k(const float* __restrict__ z, const float* __restrict__ jac, const float* __restrict__ glogdet,
+                               const float* __restrict__ glogn, const float* __restrict__ gz_in, float* __restrict__ gz,
+                               float* __restrict__ gjac, int64_t B, int64_t d) {
+  const int64_t row = (int64_t)blockIdx.x * (kBlock / G) + threadIdx.x / G;
+  const int g = threadIdx.x % G;
+  if (row >= B) return;
+  const float gl = glogdet ? glogdet[row] : 0.f, gn = glogn ? glogn[row] : 0.f;
+  for (int64_t i = g; i < d; i += G) {
+    const int64_t e = row * d + i;
+    if (gz) gz[e] = fmaf(-z[e], gn, gz_in ? gz_in[e] : 0.f);
+    if (gjac) gjac[e] = gl / jac[e];
+  }
 }
 
-__global__ void normal_ld_bwd_k(const float* __restrict__ z, const float* __restrict__ g, float* __restrict__ gz,
-                                int64_t B, int64_t d) {
-  const int64_t n = B * d;
-  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x)
-    gz[e] = -z[e] * g[e / d];
+// Short rows (d <= 64, contiguous, 16-B aligned): the span-per-wavefront scheme of the flat Affine kernels -- one float4 of
+// z and of jac per lane and span, U spans in flight, masked wave reductions per row.
+template <int RW, int U>
+__global__ __launch_bounds__(kBlock) void nll_rows_flat_k(const float* __restrict__ z, const float* __restrict__ jac,
+                                                          float* __restrict__ logdet, float* __restrict__ logn,
+                                                          int64_t B, int d) {
+  const int lane = threadIdx.x & 63;
+  const int64_t gw = (int64_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6), nw = (int64_t)gridDim.x * (kBlock / 64);
+  const int64_t nspan = (B + RW - 1) / RW;
+  int rid[4];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) rid[c] = (4 * lane + c) / d;
+  for (int64_t sp0 = gw * U; sp0 < nspan; sp0 += nw * U) {
+    f32x4r zv[U], jv[U];
+    int ne[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int64_t sp = sp0 + u, row0 = sp * RW;
+      const int nrows = sp < nspan ? (int)(B - row0 < RW ? B - row0 : RW) : 0;
+      ne[u] = nrows * d;
+      const int64_t base = row0 * d + 4 * lane;
+      zv[u] = f32x4r{0.f, 0.f, 0.f, 0.f};
+      jv[u] = f32x4r{1.f, 1.f, 1.f, 1.f};
+      if (4 * lane + 3 < ne[u]) {
+        if (logn) zv[u] = __builtin_nontemporal_load(reinterpret_cast<const f32x4r*>(z + base));
+        if (jac) jv[u] = __builtin_nontemporal_load(reinterpret_cast<const f32x4r*>(jac + base));
+      } else {
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+          if (4 * lane + c < ne[u]) {
+            if (logn) zv[u][c] = z[base + c];
+            if (jac) jv[u][c] = jac[base + c];
+          }
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      if (ne[u] == 0) continue;
+      const int64_t row0 = (sp0 + u) * RW;
+      float lj[4], lq[4];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const bool ok = 4 * lane + c < ne[u];
+        lj[c] = (jac && ok) ? logf(jv[u][c]) : 0.f;
+        lq[c] = ok ? kLog2Pi + zv[u][c] * zv[u][c] : 0.f;
+      }
+#pragma unroll
+      for (int rr = 0; rr < RW; ++rr) {
+        if (jac) {
+          float sv = 0.f;
+#pragma unroll
+          for (int c = 0; c < 4; ++c) sv += rid[c] == rr ? lj[c] : 0.f;
+          sv = wave_sum(sv);
+          if (lane == 0 && row0 + rr < B) logdet[row0 + rr] = sv;
+        }
+        if (logn) {
+          float sv = 0.f;
+#pragma unroll
+          for (int c = 0; c < 4; ++c) sv += rid[c] == rr ? lq[c] : 0.f;
+          sv = wave_sum(sv);
+          if (lane == 0 && row0 + rr < B) logn[row0 + rr] = -0.5f * sv;
+        }
+      }
+    }
+  }
+}
+
+template <int RW, int U>
+__global__ __launch_bounds__(kBlock) void nll_rows_bwd_flat_k(const float* __restrict__ z, const float* __restrict__ jac,
+                                                              const float* __restrict__ glogdet,
+                                                              const float* __restrict__ glogn,
+                                                              const float* __restrict__ gz_in, float* __restrict__ gz,
+                                                              float* __restrict__ gjac, int64_t B, int d) {
+  const int lane = threadIdx.x & 63;
+  const int64_t gw = (int64_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6), nw = (int64_t)gridDim.x * (kBlock / 64);
+  const int64_t nspan = (B + RW - 1) / RW;
+  int rid[4];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) rid[c] = (4 * lane + c) / d;
+  for (int64_t sp0 = gw * U; sp0 < nspan; sp0 += nw * U) {
+    f32x4r zv[U], jv[U], gv[U];
+    int ne[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int64_t sp = sp0 + u, row0 = sp * RW;
+      const int nrows = sp < nspan ? (int)(B - row0 < RW ? B - row0 : RW) : 0;
+      ne[u] = nrows * d;
+      const int64_t base = row0 * d + 4 * lane;
+      zv[u] = f32x4r{0.f, 0.f, 0.f, 0.f};
+      gv[u] = zv[u];
+      jv[u] = f32x4r{1.f, 1.f, 1.f, 1.f};
+      if (4 * lane + 3 < ne[u]) {
+        if (gz) zv[u] = __builtin_nontemporal_load(reinterpret_cast<const f32x4r*>(z + base));
+        if (gz_in) gv[u] = __builtin_nontemporal_load(reinterpret_cast<const f32x4r*>(gz_in + base));
+        if (gjac) jv[u] = __builtin_nontemporal_load(reinterpret_cast<const f32x4r*>(jac + base));
+      } else {
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+          if (4 * lane + c < ne[u]) {
+            if (gz) zv[u][c] = z[base + c];
+            if (gz_in) gv[u][c] = gz_in[base + c];
+            if (gjac) jv[u][c] = jac[base + c];
+          }
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      if (ne[u] == 0) continue;
+      const int64_t row0 = (sp0 + u) * RW, base = row0 * d + 4 * lane;
+      f32x4r oz, oj;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const bool ok = 4 * lane + c < ne[u];
+        const float gn = (glogn && ok) ? glogn[row0 + rid[c]] : 0.f, gl = (glogdet && ok) ? glogdet[row0 + rid[c]] : 0.f;
+        oz[c] = fmaf(-zv[u][c], gn, gv[u][c]);
+        oj[c] = gl / jv[u][c];
+      }
+      if (4 * lane + 3 < ne[u]) {
+        if (gz) __builtin_nontemporal_store(oz, reinterpret_cast<f32x4r*>(gz + base));
+        if (gjac) __builtin_nontemporal_store(oj, reinterpret_cast<f32x4r*>(gjac + base));
+      } else {
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+          if (4 * lane + c < ne[u]) { if (gz) gz[base + c] = oz[c]; if (gjac) gjac[base + c] = oj[c]; }
+      }
+    }
+  }
+}
+
+// Short rows, forward: ONE ROW PER 16-LANE GROUP.  The span kernels above pay RW full-wave reductions (ds_bpermute
+// butterflies) per 252 elements, which is what bounds a kernel that only READS 4-8 B per element (22 % of the HBM peak for
+// the density alone).  Here lane g of a group loads elements 4 g .. 4 g + 3 of its row with ONE dwordx4 (gfx950 executes
+// global_load_dwordx4 at any dword address; rows of 63 floats are only dword aligned) and the row sum is four DPP adds
+// inside the hardware's 16-lane row: quad_perm xor 1, xor 2, row_half_mirror, row_mirror -- VALU only, no LDS crossbar.
+// A wavefront covers 4 rows per load instruction and keeps U of them in flight.
+typedef float f32x4ru __attribute__((ext_vector_type(4), aligned(4)));
+__device__ __forceinline__ float row16_sum(float v) {
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xf, 0xf, true));   // quad_perm [1,0,3,2]
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xf, 0xf, true));   // quad_perm [2,3,0,1]
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xf, 0xf, true));  // row_half_mirror
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xf, 0xf, true));  // row_mirror
+  return v;
+}
+
+template <int U>
+__global__ __launch_bounds__(kBlock) void nll_rows_g16_k(const float* __restrict__ z, const float* __restrict__ jac,
+                                                         float* __restrict__ logdet, float* __restrict__ logn,
+                                                         int64_t B, int d) {
+  const int lane = threadIdx.x & 63, g = lane & 15, grp = lane >> 4;
+  const int64_t gw = (int64_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6), nw = (int64_t)gridDim.x * (kBlock / 64);
+  const int nel = d - 4 * g;                           // elements of the row this lane holds: min(4, nel), <= 0: none
+  for (int64_t r0 = gw * (4 * U); r0 < B; r0 += nw * (4 * U)) {
+    f32x4ru zv[U], jv[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int64_t row = r0 + 4 * u + grp;
+      const int64_t base = row * d + 4 * g;
+      zv[u] = f32x4ru{0.f, 0.f, 0.f, 0.f};
+      jv[u] = f32x4ru{1.f, 1.f, 1.f, 1.f};
+      // the last lanes of the LAST row must not read past the array; everywhere else the float4 may run into the next row
+      // (masked below), which keeps every lane's load a single dwordx4
+      const bool full = row < B && nel > 0 && (nel >= 4 || row + 1 < B);
+      if (full) {
+        if (logn) zv[u] = __builtin_nontemporal_load(reinterpret_cast<const f32x4ru*>(z + base));
+        if (jac) jv[u] = __builtin_nontemporal_load(reinterpret_cast<const f32x4ru*>(jac + base));
+      } else if (row < B && nel > 0) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+          if (c < nel) { if (logn) zv[u][c] = z[base + c]; if (jac) jv[u][c] = jac[base + c]; }
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int64_t row = r0 + 4 * u + grp;
+      float sl = 0.f, sn = 0.f;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const bool ok = c < nel;
+        if (jac) sl += ok ? logf(jv[u][c]) : 0.f;
+        sn += ok ? kLog2Pi + zv[u][c] * zv[u][c] : 0.f;
+      }
+      if (jac) { sl = row16_sum(sl); if (g == 0 && row < B) logdet[row] = sl; }
+      if (logn) { sn = row16_sum(sn); if (g == 0 && row < B) logn[row] = -0.5f * sn; }
+    }
+  }
+}
+
+// The Affine forward on the same row-per-16-lane-group scheme (contiguous [B,d,2] conditioner output, d <= 64, dword
+// alignment only): x / z one dwordx4 per lane, h two; log|det J| and the Normal log-density of the row are two DPP sums.
+template <int U>
+__global__ __launch_bounds__(kBlock) void affine_fwd_g16_k(const float* __restrict__ x, const float* __restrict__ h,
+                                                           float* __restrict__ z, float* __restrict__ jac,
+                                                           float* __restrict__ logdet, float* __restrict__ logn,
+                                                           int64_t B, int d) {
+  const int lane = threadIdx.x & 63, g = lane & 15, grp = lane >> 4;
+  const int64_t gw = (int64_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6), nw = (int64_t)gridDim.x * (kBlock / 64);
+  const int nel = d - 4 * g;
+  for (int64_t r0 = gw * (4 * U); r0 < B; r0 += nw * (4 * U)) {
+    f32x4ru xv[U], ha[U], hb[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int64_t row = r0 + 4 * u + grp;
+      const int64_t base = row * d + 4 * g;
+      xv[u] = f32x4ru{0.f, 0.f, 0.f, 0.f};
+      ha[u] = xv[u]; hb[u] = xv[u];
+      const bool full = row < B && nel > 0 && (nel >= 4 || row + 1 < B);
+      if (full) {
+        xv[u] = __builtin_nontemporal_load(reinterpret_cast<const f32x4ru*>(x + base));
+        ha[u] = __builtin_nontemporal_load(reinterpret_cast<const f32x4ru*>(h + 2 * base));
+        hb[u] = __builtin_nontemporal_load(reinterpret_cast<const f32x4ru*>(h + 2 * base + 4));
+      } else if (row < B && nel > 0) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+          if (c < nel) {
+            xv[u][c] = x[base + c];
+            const float a0 = h[2 * (base + c)], a1 = h[2 * (base + c) + 1];
+            if (c < 2) { ha[u][2 * c] = a0; ha[u][2 * c + 1] = a1; } else { hb[u][2 * c - 4] = a0; hb[u][2 * c - 3] = a1; }
+          }
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int64_t row = r0 + 4 * u + grp;
+      const int64_t base = row * d + 4 * g;
+      const float h0[4] = {ha[u][0], ha[u][2], hb[u][0], hb[u][2]}, h1[4] = {ha[u][1], ha[u][3], hb[u][1], hb[u][3]};
+      f32x4ru zv, jv;
+      float sl = 0.f, sn = 0.f;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const float mu = clampf(h0[c], -5.f, 5.f), ls = clampf(h1[c], -5.f, 2.f);
+        const float sg = expf(ls);
+        zv[c] = fmaf(xv[u][c], sg, mu);
+        jv[c] = sg;
+        if (c < nel) { sl += ls; sn += kLog2Pi + zv[c] * zv[c]; }
+      }
+      if (row < B && nel >= 4) {
+        __builtin_nontemporal_store(zv, reinterpret_cast<f32x4ru*>(z + base));
+        if (jac) __builtin_nontemporal_store(jv, reinterpret_cast<f32x4ru*>(jac + base));
+      } else if (row < B) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+          if (c < nel) { z[base + c] = zv[c]; if (jac) jac[base + c] = jv[c]; }
+      }
+      if (logdet) { sl = row16_sum(sl); if (g == 0 && row < B) logdet[row] = sl; }
+      if (logn) { sn = row16_sum(sn); if (g == 0 && row < B) logn[row] = -0.5f * sn; }
+    }
+  }
+}
+
+// ... and its backward: a lane's four elements belong to ONE row, so the per-row cotangents glogdet[row] / glogn[row] are
+// one load per lane (the span kernel gathers them per element through its element -> row table).
+template <int U>
+__global__ __launch_bounds__(kBlock) void affine_bwd_g16_k(const float* __restrict__ x, const float* __restrict__ h,
+                                                           const float* __restrict__ gz, const float* __restrict__ gjac,
+                                                           const float* __restrict__ glogdet,
+                                                           const float* __restrict__ glogn, float* __restrict__ gx,
+                                                           float* __restrict__ gh, int64_t B, int d) {
+  const int lane = threadIdx.x & 63, g = lane & 15, grp = lane >> 4;
+  const int64_t gw = (int64_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6), nw = (int64_t)gridDim.x * (kBlock / 64);
+  const int nel = d - 4 * g;
+  for (int64_t r0 = gw * (4 * U); r0 < B; r0 += nw * (4 * U)) {
+    f32x4ru xv[U], ha[U], hb[U], gv[U], jv[U];
+    float gl[U], gn[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int64_t row = r0 + 4 * u + grp;
+      const int64_t base = row * d + 4 * g;
+      xv[u] = f32x4ru{0.f, 0.f, 0.f, 0.f};
+      ha[u] = xv[u]; hb[u] = xv[u]; gv[u] = xv[u]; jv[u] = xv[u];
+      gl[u] = (glogdet && row < B) ? glogdet[row] : 0.f;
+      gn[u] = (glogn && row < B) ? glogn[row] : 0.f;
+      const bool full = row < B && nel > 0 && (nel >= 4 || row + 1 < B);
+      if (full) {
+        xv[u] = __builtin_nontemporal_load(reinterpret_cast<const f32x4ru*>(x + base));
+        ha[u] = __builtin_nontemporal_load(reinterpret_cast<const f32x4ru*>(h + 2 * base));
+        hb[u] = __builtin_nontemporal_load(reinterpret_cast<const f32x4ru*>(h + 2 * base + 4));
+        if (gz) gv[u] = __builtin_nontemporal_load(reinterpret_cast<const f32x4ru*>(gz + base));
+        if (gjac) jv[u] = __builtin_nontemporal_load(reinterpret_cast<const f32x4ru*>(gjac + base));
+      } else if (row < B && nel > 0) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+          if (c < nel) {
+            xv[u][c] = x[base + c];
+            const float a0 = h[2 * (base + c)], a1 = h[2 * (base + c) + 1];
+            if (c < 2) { ha[u][2 * c] = a0; ha[u][2 * c + 1] = a1; } else { hb[u][2 * c - 4] = a0; hb[u][2 * c - 3] = a1; }
+            if (gz) gv[u][c] = gz[base + c];
+            if (gjac) jv[u][c] = gjac[base + c];
+          }
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int64_t row = r0 + 4 * u + grp;
+      if (row >= B || nel <= 0) continue;
+      const int64_t base = row * d + 4 * g;
+      const float h0[4] = {ha[u][0], ha[u][2], hb[u][0], hb[u][2]}, h1[4] = {ha[u][1], ha[u][3], hb[u][1], hb[u][3]};
+      f32x4ru ox, oa, ob;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        // torch clamp backward passes the gradient where min <= v <= max (boundaries included)
+        const float m0 = (h0[c] >= -5.f && h0[c] <= 5.f) ? 1.f : 0.f;
+        const float m1 = (h1[c] >= -5.f && h1[c] <= 2.f) ? 1.f : 0.f;
+        const float sg = expf(clampf(h1[c], -5.f, 2.f));
+        const float gze = fmaf(-fmaf(xv[u][c], sg, clampf(h0[c], -5.f, 5.f)), gn[u], gv[u][c]);   // + d logN / dz = -z
+        ox[c] = gze * sg;
+        const float o0 = gze * m0, o1 = (fmaf(gze * xv[u][c], sg, jv[u][c] * sg) + gl[u]) * m1;
+        if (c < 2) { oa[2 * c] = o0; oa[2 * c + 1] = o1; } else { ob[2 * c - 4] = o0; ob[2 * c - 3] = o1; }
+      }
+      if (nel >= 4) {
+        if (gx) __builtin_nontemporal_store(ox, reinterpret_cast<f32x4ru*>(gx + base));
+        __builtin_nontemporal_store(oa, reinterpret_cast<f32x4ru*>(gh + 2 * base));
+        __builtin_nontemporal_store(ob, reinterpret_cast<f32x4ru*>(gh + 2 * base + 4));
+      } else {
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+          if (c < nel) {
+            if (gx) gx[base + c] = ox[c];
+            gh[2 * (base + c)] = c < 2 ? oa[2 * c] : ob[2 * c - 4];
+            gh[2 * (base + c) + 1] = c < 2 ? oa[2 * c + 1] : ob[2 * c - 3];
+          }
+      }
+    }
+  }
+}
+
+// rows per wavefront span of the flat row kernels (contiguous [B,d] arrays, d <= 64, all pointers 16-B aligned), else 0
+inline int rows_flat_rw(int64_t B, int64_t d, uintptr_t ptr_bits) {
+  if (d > 64 || B * d < (1 << 18) || (ptr_bits & 15) != 0) return 0;
+  const int rw = (d % 4 == 0) ? 1 : ((d % 2 == 0) ? 2 : 4);
+  return rw * d <= 256 ? rw : 0;
+}
+
+int nll_rows_launch(const float* z, const float* jac, float* logdet, float* logn, int64_t B, int64_t d, hipStream_t s) {
+  void* stream = (void*)s;
+  if (d <= 64 && B * d >= (1 << 16)) {                 // short rows: a row per 16-lane group
+    constexpr int U = 4;
+    const int64_t per_block = (int64_t)(kBlock / 64) * 4 * U;
+    int64_t grid = (B + per_block - 1) / per_block;
+    if (grid > 256 * 8) grid = 256 * 8;
+    hipLaunchKernelGGL((nll_rows_g16_k<U>), dim3((unsigned)grid), dim3(kBlock), 0, s, z, jac, logdet, logn, B, (int)d);
+  } else if (const int rw = rows_flat_rw(B, d, (uintptr_t)z | (uintptr_t)jac)) {
+    constexpr int U = 4;
+    const int64_t nspan = (B + rw - 1) / rw;
+    int64_t grid = (nspan + U * (kBlock / 64) - 1) / (U * (kBlock / 64));
+    if (grid > 256 * 8) grid = 256 * 8;
+    if (rw == 4) hipLaunchKernelGGL((nll_rows_flat_k<4, U>), dim3((unsigned)grid), dim3(kBlock), 0, s, z, jac, logdet, logn, B, (int)d);
+    else if (rw == 2) hipLaunchKernelGGL((nll_rows_flat_k<2, U>), dim3((unsigned)grid), dim3(kBlock), 0, s, z, jac, logdet, logn, B, (int)d);
+    else hipLaunchKernelGGL((nll_rows_flat_k<1, U>), dim3((unsigned)grid), dim3(kBlock), 0, s, z, jac, logdet, logn, B, (int)d);
+  } else {
+    const int G = gnf_pow2_ge(d, 64);
+    GNF_DISPATCH_G(G, nll_rows_k, B, z, jac, logdet, logn, B, d);
+  }
+  GNF_LAUNCH_CHECK();
+  return 0;
+}
+
+int nll_rows_bwd_launch(const float* z, const float* jac, const float* glogdet, const float* glogn, const float* gz_in,
+                        float* gz, float* gjac, int64_t B, int64_t d, hipStream_t s) {
+  void* stream = (void*)s;
+  if (const int rw = rows_flat_rw(B, d, (uintptr_t)z | (uintptr_t)jac | (uintptr_t)gz_in | (uintptr_t)gz | (uintptr_t)gjac)) {
+    constexpr int U = 2;
+    const int64_t nspan = (B + rw - 1) / rw;
+    int64_t grid = (nspan + U * (kBlock / 64) - 1) / (U * (kBlock / 64));
+    if (grid > 256 * 16) grid = 256 * 16;
+    if (rw == 4) hipLaunchKernelGGL((nll_rows_bwd_flat_k<4, U>), dim3((unsigned)grid), dim3(kBlock), 0, s, z, jac, glogdet, glogn, gz_in, gz, gjac, B, (int)d);
+    else if (rw == 2) hipLaunchKernelGGL((nll_rows_bwd_flat_k<2, U>), dim3((unsigned)grid), dim3(kBlock), 0, s, z, jac, glogdet, glogn, gz_in, gz, gjac, B, (int)d);
+    else hipLaunchKernelGGL((nll_rows_bwd_flat_k<1, U>), dim3((unsigned)grid), dim3(kBlock), 0, s, z, jac, glogdet, glogn, gz_in, gz, gjac, B, (int)d);
+  } else {
+    const int G = gnf_pow2_ge(d, 64);
+    GNF_DISPATCH_G(G, nll_rows_bwd_k, B, z, jac, glogdet, glogn, gz_in, gz, gjac, B, d);
+  }
+  GNF_LAUNCH_CHECK();
+  return 0;
 }
 
 // ------------------------------------------------------------------ column sums
@@ -497,52 +894,72 @@ extern "C" {
 int gnf_abi_version(void) { return GNF_ABI_VERSION; }
 
 int gnf_affine_fwd(const float* x, float* h, int64_t h_sb, int64_t h_sd, int64_t h_sc, float* z, float* jac,
-                   float* logdet, int clamp_inplace, int64_t B, int64_t d, gnf_stream_t stream) {
+                   float* logdet, float* logn, int clamp_inplace, int64_t B, int64_t d, gnf_stream_t stream) {
   if (B < 0 || d <= 0) return GNF_EINVAL;
   if (B == 0) return 0;                    // batch-sized arrays may be NULL for an empty batch
   if (!x || !h || !z) return GNF_EINVAL;
   const int G = gnf_pow2_ge(d, 64);
+  if (!clamp_inplace && h_sc == 1 && h_sd == 2 && h_sb == 2 * d && d <= 64 && B * d >= (1 << 16)) {
+    constexpr int U = 2;                   // short rows in the contiguous [B,d,2] layout: a row per 16-lane group
+    const int64_t per_block = (int64_t)(kBlock / 64) * 4 * U;
+    int64_t grid = (B + per_block - 1) / per_block;
+    if (grid > 256 * 16) grid = 256 * 16;
+    hipLaunchKernelGGL((affine_fwd_g16_k<U>), dim3((unsigned)grid), dim3(kBlock), 0, (hipStream_t)stream, x, h, z, jac,
+                       logdet, logn, B, (int)d);
+    GNF_LAUNCH_CHECK();
+    return 0;
+  }
   if (const int rw = clamp_inplace ? 0 : affine_flat_rw(h_sb, h_sd, h_sc, B, d, x, h, z)) {
     if (!jac || ((uintptr_t)jac & 15) == 0) {
       const int64_t nspan = (B + rw - 1) / rw;
       int64_t grid = (nspan + 2 * (kBlock / 64) - 1) / (2 * (kBlock / 64));
       if (grid > 256 * 16) grid = 256 * 16;
       hipStream_t s = (hipStream_t)stream;
-      if (rw == 4) hipLaunchKernelGGL((affine_fwd_flat_k<4, 2>), dim3((unsigned)grid), dim3(kBlock), 0, s, x, h, z, jac, logdet, B, (int)d);
-      else if (rw == 2) hipLaunchKernelGGL((affine_fwd_flat_k<2, 2>), dim3((unsigned)grid), dim3(kBlock), 0, s, x, h, z, jac, logdet, B, (int)d);
-      else hipLaunchKernelGGL((affine_fwd_flat_k<1, 2>), dim3((unsigned)grid), dim3(kBlock), 0, s, x, h, z, jac, logdet, B, (int)d);
+      if (rw == 4) hipLaunchKernelGGL((affine_fwd_flat_k<4, 2>), dim3((unsigned)grid), dim3(kBlock), 0, s, x, h, z, jac, logdet, logn, B, (int)d);
+      else if (rw == 2) hipLaunchKernelGGL((affine_fwd_flat_k<2, 2>), dim3((unsigned)grid), dim3(kBlock), 0, s, x, h, z, jac, logdet, logn, B, (int)d);
+      else hipLaunchKernelGGL((affine_fwd_flat_k<1, 2>), dim3((unsigned)grid), dim3(kBlock), 0, s, x, h, z, jac, logdet, logn, B, (int)d);
       GNF_LAUNCH_CHECK();
       return 0;
     }
   }
-  if (B * d >= (1 << 20)) GNF_DISPATCH_GR(G, 4, affine_fwd_k, B, x, h, h_sb, h_sd, h_sc, z, jac, logdet, clamp_inplace, B, d);
-  else GNF_DISPATCH_GR(G, 1, affine_fwd_k, B, x, h, h_sb, h_sd, h_sc, z, jac, logdet, clamp_inplace, B, d);
+  if (B * d >= (1 << 20)) GNF_DISPATCH_GR(G, 4, affine_fwd_k, B, x, h, h_sb, h_sd, h_sc, z, jac, logdet, logn, clamp_inplace, B, d);
+  else GNF_DISPATCH_GR(G, 1, affine_fwd_k, B, x, h, h_sb, h_sd, h_sc, z, jac, logdet, logn, clamp_inplace, B, d);
   GNF_LAUNCH_CHECK();
   return 0;
 }
 
 int gnf_affine_bwd(const float* x, const float* h, int64_t h_sb, int64_t h_sd, int64_t h_sc, const float* gz,
-                   const float* gjac, const float* glogdet, float* gx, float* gh, int64_t g_sb, int64_t g_sd,
-                   int64_t g_sc, int64_t B, int64_t d, gnf_stream_t stream) {
+                   const float* gjac, const float* glogdet, const float* glogn, float* gx, float* gh, int64_t g_sb,
+                   int64_t g_sd, int64_t g_sc, int64_t B, int64_t d, gnf_stream_t stream) {
   if (B < 0 || d <= 0) return GNF_EINVAL;
   if (B == 0) return 0;
   if (!x || !h || !gh) return GNF_EINVAL;
   const int G = gnf_pow2_ge(d, 64);
+  if (g_sc == 1 && g_sd == 2 && g_sb == 2 * d && h_sc == 1 && h_sd == 2 && h_sb == 2 * d && d <= 64 && B * d >= (1 << 16)) {
+    constexpr int U = 2;                   // short rows, contiguous [B,d,2] h and gh: a row per 16-lane group
+    const int64_t per_block = (int64_t)(kBlock / 64) * 4 * U;
+    int64_t grid = (B + per_block - 1) / per_block;
+    if (grid > 256 * 16) grid = 256 * 16;
+    hipLaunchKernelGGL((affine_bwd_g16_k<U>), dim3((unsigned)grid), dim3(kBlock), 0, (hipStream_t)stream, x, h, gz, gjac,
+                       glogdet, glogn, gx, gh, B, (int)d);
+    GNF_LAUNCH_CHECK();
+    return 0;
+  }
   if (const int rw = (g_sc == 1 && g_sd == 2 && g_sb == 2 * d) ? affine_flat_rw(h_sb, h_sd, h_sc, B, d, x, h, gh) : 0) {
     if ((((uintptr_t)gz | (uintptr_t)gjac | (uintptr_t)gx) & 15) == 0) {
       const int64_t nspan = (B + rw - 1) / rw;
       int64_t grid = (nspan + 2 * (kBlock / 64) - 1) / (2 * (kBlock / 64));
       if (grid > 256 * 16) grid = 256 * 16;
       hipStream_t s = (hipStream_t)stream;
-      if (rw == 4) hipLaunchKernelGGL((affine_bwd_flat_k<4, 2>), dim3((unsigned)grid), dim3(kBlock), 0, s, x, h, gz, gjac, glogdet, gx, gh, B, (int)d);
-      else if (rw == 2) hipLaunchKernelGGL((affine_bwd_flat_k<2, 2>), dim3((unsigned)grid), dim3(kBlock), 0, s, x, h, gz, gjac, glogdet, gx, gh, B, (int)d);
-      else hipLaunchKernelGGL((affine_bwd_flat_k<1, 2>), dim3((unsigned)grid), dim3(kBlock), 0, s, x, h, gz, gjac, glogdet, gx, gh, B, (int)d);
+      if (rw == 4) hipLaunchKernelGGL((affine_bwd_flat_k<4, 2>), dim3((unsigned)grid), dim3(kBlock), 0, s, x, h, gz, gjac, glogdet, glogn, gx, gh, B, (int)d);
+      else if (rw == 2) hipLaunchKernelGGL((affine_bwd_flat_k<2, 2>), dim3((unsigned)grid), dim3(kBlock), 0, s, x, h, gz, gjac, glogdet, glogn, gx, gh, B, (int)d);
+      else hipLaunchKernelGGL((affine_bwd_flat_k<1, 2>), dim3((unsigned)grid), dim3(kBlock), 0, s, x, h, gz, gjac, glogdet, glogn, gx, gh, B, (int)d);
       GNF_LAUNCH_CHECK();
       return 0;
     }
   }
-  if (B * d >= (1 << 20)) GNF_DISPATCH_GR(G, 4, affine_bwd_k, B, x, h, h_sb, h_sd, h_sc, gz, gjac, glogdet, gx, gh, g_sb, g_sd, g_sc, B, d);
-  else GNF_DISPATCH_GR(G, 1, affine_bwd_k, B, x, h, h_sb, h_sd, h_sc, gz, gjac, glogdet, gx, gh, g_sb, g_sd, g_sc, B, d);
+  if (B * d >= (1 << 20)) GNF_DISPATCH_GR(G, 4, affine_bwd_k, B, x, h, h_sb, h_sd, h_sc, gz, gjac, glogdet, glogn, gx, gh, g_sb, g_sd, g_sc, B, d);
+  else GNF_DISPATCH_GR(G, 1, affine_bwd_k, B, x, h, h_sb, h_sd, h_sc, gz, gjac, glogdet, glogn, gx, gh, g_sb, g_sd, g_sc, B, d);
   GNF_LAUNCH_CHECK();
   return 0;
 }
@@ -562,39 +979,44 @@ int gnf_logsum_rows_fwd(const float* jac, float* out, int64_t B, int64_t d, gnf_
   if (B < 0 || d <= 0) return GNF_EINVAL;
   if (B == 0) return 0;
   if (!jac || !out) return GNF_EINVAL;
-  const int G = gnf_pow2_ge(d, 64);
-  GNF_DISPATCH_G(G, logsum_rows_k, B, jac, out, B, d);
-  GNF_LAUNCH_CHECK();
-  return 0;
+  return nll_rows_launch(nullptr, jac, out, nullptr, B, d, (hipStream_t)stream);
 }
 
 int gnf_logsum_rows_bwd(const float* jac, const float* g, float* gjac, int64_t B, int64_t d, gnf_stream_t stream) {
   if (B < 0 || d <= 0) return GNF_EINVAL;
   if (B == 0) return 0;
   if (!jac || !g || !gjac) return GNF_EINVAL;
-  hipLaunchKernelGGL(logsum_rows_bwd_k, dim3(grid_1d(B * d)), dim3(kBlock), 0, (hipStream_t)stream, jac, g, gjac, B,
-                     d);
-  GNF_LAUNCH_CHECK();
-  return 0;
+  return nll_rows_bwd_launch(nullptr, jac, g, nullptr, nullptr, nullptr, gjac, B, d, (hipStream_t)stream);
 }
 
 int gnf_normal_logdensity_fwd(const float* z, float* out, int64_t B, int64_t d, gnf_stream_t stream) {
   if (B < 0 || d <= 0) return GNF_EINVAL;
   if (B == 0) return 0;
   if (!z || !out) return GNF_EINVAL;
-  const int G = gnf_pow2_ge(d, 64);
-  GNF_DISPATCH_G(G, normal_ld_rows_k, B, z, out, B, d);
-  GNF_LAUNCH_CHECK();
-  return 0;
+  return nll_rows_launch(z, nullptr, nullptr, out, B, d, (hipStream_t)stream);
 }
 
 int gnf_normal_logdensity_bwd(const float* z, const float* g, float* gz, int64_t B, int64_t d, gnf_stream_t stream) {
   if (B < 0 || d <= 0) return GNF_EINVAL;
   if (B == 0) return 0;
   if (!z || !g || !gz) return GNF_EINVAL;
-  hipLaunchKernelGGL(normal_ld_bwd_k, dim3(grid_1d(B * d)), dim3(kBlock), 0, (hipStream_t)stream, z, g, gz, B, d);
-  GNF_LAUNCH_CHECK();
-  return 0;
+  return nll_rows_bwd_launch(z, nullptr, nullptr, g, nullptr, gz, nullptr, B, d, (hipStream_t)stream);
+}
+
+int gnf_nll_reduce_fwd(const float* z, const float* jac, float* logdet, float* logn, int64_t B, int64_t d,
+                       gnf_stream_t stream) {
+  if (B < 0 || d <= 0) return GNF_EINVAL;
+  if (B == 0) return 0;
+  if (!z || !jac || !logdet || !logn) return GNF_EINVAL;
+  return nll_rows_launch(z, jac, logdet, logn, B, d, (hipStream_t)stream);
+}
+
+int gnf_nll_reduce_bwd(const float* z, const float* jac, const float* glogdet, const float* glogn, const float* gz_in,
+                       float* gz, float* gjac, int64_t B, int64_t d, gnf_stream_t stream) {
+  if (B < 0 || d <= 0) return GNF_EINVAL;
+  if (B == 0) return 0;
+  if (!z || !jac || !gz || !gjac) return GNF_EINVAL;
+  return nll_rows_bwd_launch(z, jac, glogdet, glogn, gz_in, gz, gjac, B, d, (hipStream_t)stream);
 }
 
 int64_t gnf_colsum_ws_bytes(int64_t M, int64_t N) {

@@ -22,27 +22,32 @@ def _ws(nbytes, like):
 
 # ----------------------------------------------------------------------------- Affine normalizer
 class AffineFn(torch.autograd.Function):
-    """(z, jac, logdet) of models/Normalizers/AffineNormalizer.py:9-12 fused with the
-    log|det J| row reduction of models/NormalizingFlow.py:70."""
+    """(z, jac, logdet, logn) of models/Normalizers/AffineNormalizer.py:9-12 fused with the log|det J| row reduction of
+    models/NormalizingFlow.py:70 and (want_logn) the Normal log-density of z (NormalizingFlowFactories.py:15-16): the
+    pass that produces z also reduces it, and the backward recomputes z instead of reading it."""
 
     @staticmethod
-    def forward(ctx, x, h, clamp_inplace=False, want_jac=True):
+    def forward(ctx, x, h, clamp_inplace=False, want_jac=True, want_logn=False):
         x = x.contiguous()
         B, d = x.shape
         z, logdet = _empty((B, d), x), _empty((B,), x)
         jac = _empty((B, d), x) if want_jac else None       # the fused step only needs log|det J|: 4 B/elem less traffic
+        logn = _empty((B,), x) if want_logn else None
         h_bwd = h.detach().clone() if clamp_inplace else h
         call("gnf_affine_fwd", ptr(x), ptr(h), h.stride(0), h.stride(1), h.stride(2), ptr(z), ptr(jac), ptr(logdet),
-             int(bool(clamp_inplace)), B, d, stream())
+             ptr(logn), int(bool(clamp_inplace)), B, d, stream())
         ctx.save_for_backward(x, h_bwd)
         ctx.hshape = tuple(h.shape)
         if jac is None:
             jac = z.new_empty(0)
             ctx.mark_non_differentiable(jac)
-        return z, jac, logdet
+        if logn is None:
+            logn = z.new_empty(0)
+            ctx.mark_non_differentiable(logn)
+        return z, jac, logdet, logn
 
     @staticmethod
-    def backward(ctx, gz, gjac, glogdet):
+    def backward(ctx, gz, gjac, glogdet, glogn=None):
         x, h = ctx.saved_tensors
         B, d = x.shape
         hs = ctx.hshape[2]
@@ -53,8 +58,9 @@ class AffineFn(torch.autograd.Function):
              ptr(gz.contiguous()) if gz is not None else None,
              ptr(gjac.contiguous()) if (gjac is not None and gjac.numel() > 0) else None,
              ptr(glogdet.contiguous()) if glogdet is not None else None,
+             ptr(glogn.contiguous()) if (glogn is not None and glogn.numel() > 0) else None,
              ptr(gx), ptr(gh), gh.stride(0), gh.stride(1), gh.stride(2), B, d, stream())
-        return gx, gh, None, None
+        return gx, gh, None, None, None
 
 
 def affine_inverse(z, h):
@@ -107,6 +113,41 @@ class NormalLogDensityFn(torch.autograd.Function):
         gz = _empty((B, d), z)
         call("gnf_normal_logdensity_bwd", ptr(z), ptr(g.contiguous()), ptr(gz), B, d, stream())
         return gz
+
+
+class NllReduceFn(torch.autograd.Function):
+    """(log(jac).sum(1), -.5*(log(2 pi) + z**2).sum(1)): the two row reductions of a flow step's tail
+    (models/NormalizingFlow.py:70, NormalizingFlowFactories.py:15-16) in one pass over z and jac, and one backward
+    launch producing both cotangents (the Monotonic normalizer's kernels cannot reduce over a row themselves)."""
+
+    @staticmethod
+    def forward(ctx, z, jac):
+        z, jac = z.contiguous(), jac.contiguous()
+        B, d = z.shape
+        logdet, logn = _empty((B,), z), _empty((B,), z)
+        call("gnf_nll_reduce_fwd", ptr(z), ptr(jac), ptr(logdet), ptr(logn), B, d, stream())
+        ctx.save_for_backward(z, jac)
+        return logdet, logn
+
+    @staticmethod
+    def backward(ctx, glogdet, glogn):
+        z, jac = ctx.saved_tensors
+        B, d = z.shape
+        gz, gjac = _empty((B, d), z), _empty((B, d), z)
+        call("gnf_nll_reduce_bwd", ptr(z), ptr(jac), ptr(glogdet.contiguous()) if glogdet is not None else None,
+             ptr(glogn.contiguous()) if glogn is not None else None, None, ptr(gz), ptr(gjac), B, d, stream())
+        return gz, gjac
+
+
+def stash_logn(z, logn):
+    """remember the Normal log-density that was reduced in the pass producing z; NormalLogDensity picks it up when it is
+    handed the very same tensor (flow.loss(z, logdet) right after flow(x)) instead of reading z again"""
+    z._gnf_logn = logn
+    return z
+
+
+def cached_logn(z):
+    return getattr(z, "_gnf_logn", None)
 
 
 def colsum(a):

@@ -15,13 +15,14 @@ class AffineNormalizer(Normalizer):
         self.inplace_clamp = False
 
     def forward(self, x, h, context=None):
-        z, jac, _ = ops.AffineFn.apply(x, h, self.inplace_clamp)
+        z, jac, _, _ = ops.AffineFn.apply(x, h, self.inplace_clamp)
         return z, jac
 
     def forward_logdet(self, x, h, context=None):
-        """(z, log|det J|) with the row reduction fused (used by NormalizingFlowStep)."""
-        z, _, logdet = ops.AffineFn.apply(x, h, self.inplace_clamp, False)
-        return z, logdet
+        """(z, log|det J|) with the row reduction fused (used by NormalizingFlowStep); the same pass also reduces the Normal
+        log-density of z, which NormalLogDensity picks up when flow.loss() hands it this z (ops.stash_logn)."""
+        z, _, logdet, logn = ops.AffineFn.apply(x, h, self.inplace_clamp, False, True)
+        return ops.stash_logn(z, logn), logdet
 
     def inverse_transform(self, z, h, context=None):
         return ops.affine_inverse(z, h)

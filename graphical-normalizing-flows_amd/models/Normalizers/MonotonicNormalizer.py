@@ -79,6 +79,18 @@ class MonotonicNormalizer(Normalizer):
             return ops.module_monotonic(x, h, self.integrand_net, int(self.nb_steps))
         return ops.MonotonicFn.apply(x, h, int(self.nb_steps), *self._params())
 
+    def forward_logdet(self, x, h, context=None):
+        """(z, log|det J|) for NormalizingFlowStep: the integrand kernels emit z and jac per element (a row's elements are
+        spread over wavefronts and workgroups), so the step's tail -- log(jac).sum(1) and the Normal log-density of z --
+        is ONE reduction pass over both (gnf_nll_reduce) instead of two kernels re-reading jac and z; the density is
+        handed to NormalLogDensity through ops.stash_logn."""
+        out = self.forward(x, h, context)
+        if out is None:
+            return None
+        z, jac = out
+        logdet, logn = ops.NllReduceFn.apply(z, jac)
+        return ops.stash_logn(z, logn), logdet
+
     def inverse_transform(self, z, h, context=None):
         with torch.no_grad():
             if not self._fused():

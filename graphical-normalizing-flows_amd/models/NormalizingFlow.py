@@ -55,9 +55,10 @@ class NormalizingFlow(nn.Module):
 
 
 class NormalizingFlowStep(NormalizingFlow):
-    """One autoregressive-style transformation.  A normalizer that offers `forward_logdet` (both built-in ones do)
-    returns the row-summed log-Jacobian from its own kernel; any other Normalizer plug-in goes through the
-    log + row-sum reduction kernel."""
+    """One autoregressive-style transformation.  A normalizer that offers `forward_logdet` returns the row-summed
+    log-Jacobian itself: the Affine normalizer from the kernel that computes z (log-det and Normal log-density reduced
+    in the same pass), the Monotonic one from a single fused reduction pass over its (z, jac) (its integrand kernels
+    spread a row over many wavefronts); any other Normalizer plug-in goes through the log + row-sum reduction kernel."""
 
     def __init__(self, conditioner: Conditioner, normalizer: Normalizer):
         super().__init__()

@@ -23,7 +23,8 @@ class NormalLogDensity(nn.Module):
         self.register_buffer("pi", torch.tensor(math.pi))
 
     def forward(self, z):
-        return ops.NormalLogDensityFn.apply(z)
+        logn = ops.cached_logn(z)                # reduced by the kernel that produced this very z (forward_logdet)
+        return logn if logn is not None else ops.NormalLogDensityFn.apply(z)
 
 
 def buildFCNormalizingFlow(nb_steps, conditioner_type, conditioner_args, normalizer_type, normalizer_args):

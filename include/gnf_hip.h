@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define GNF_ABI_VERSION 2
+#define GNF_ABI_VERSION 3
 #define GNF_EINVAL (-1)   /* bad argument (null pointer, negative size, ...)          */
 #define GNF_ESHAPE (-2)   /* shape not supported by any compiled kernel instantiation */
 #define GNF_EWS    (-3)   /* workspace too small                                      */
@@ -38,17 +38,19 @@ int gnf_abi_version(void);
 /* ---- Affine normalizer: models/Normalizers/AffineNormalizer.py:9-17 -------------------
  * mu = clamp(h[..,0],-5,5); sigma = exp(clamp(h[..,1],-5,2)); z = x*sigma + mu.
  * x,z,jac: [B,d] contiguous.  h[b,i,c] at b*h_sb + i*h_sd + c*h_sc (MADE hands over a
- * permuted view).  jac (= sigma) and logdet (= sum_i log sigma = sum_i clamp(h1)) may be
- * NULL.  clamp_inplace != 0 writes the clamped values back into h like the reference's
- * clamp_ does. */
+ * permuted view).  jac (= sigma), logdet (= sum_i log sigma = sum_i clamp(h1)) and logn
+ * (= -0.5 sum_i (log 2pi + z^2), the NormalLogDensity of NormalizingFlowFactories.py:15-16
+ * fused into the pass that produces z) may be NULL.  clamp_inplace != 0 writes the clamped
+ * values back into h like the reference's clamp_ does. */
 int gnf_affine_fwd(const float* x, float* h, int64_t h_sb, int64_t h_sd, int64_t h_sc,
-                   float* z, float* jac, float* logdet, int clamp_inplace,
+                   float* z, float* jac, float* logdet, float* logn, int clamp_inplace,
                    int64_t B, int64_t d, gnf_stream_t stream);
-/* Backward of the above.  gz: [B,d]; gjac: [B,d] or NULL; glogdet: [B] or NULL.
+/* Backward of the above.  gz: [B,d] or NULL; gjac: [B,d] or NULL; glogdet, glogn: [B] or
+ * NULL (glogn: z's cotangent gains -z*glogn[b], z recomputed in the kernel).
  * gx: [B,d] or NULL.  gh[b,i,c] at b*g_sb + i*g_sd + c*g_sc receives components 0,1
  * (components >= 2 are never read by the normalizer: caller zero-fills them). */
 int gnf_affine_bwd(const float* x, const float* h, int64_t h_sb, int64_t h_sd, int64_t h_sc,
-                   const float* gz, const float* gjac, const float* glogdet,
+                   const float* gz, const float* gjac, const float* glogdet, const float* glogn,
                    float* gx, float* gh, int64_t g_sb, int64_t g_sd, int64_t g_sc,
                    int64_t B, int64_t d, gnf_stream_t stream);
 /* x = (z - mu)/sigma  (AffineNormalizer.py:14-17). */
@@ -62,6 +64,15 @@ int gnf_logsum_rows_fwd(const float* jac, float* out, int64_t B, int64_t d, gnf_
 int gnf_logsum_rows_bwd(const float* jac, const float* g, float* gjac, int64_t B, int64_t d, gnf_stream_t stream);
 int gnf_normal_logdensity_fwd(const float* z, float* out, int64_t B, int64_t d, gnf_stream_t stream);
 int gnf_normal_logdensity_bwd(const float* z, const float* g, float* gz, int64_t B, int64_t d, gnf_stream_t stream);
+/* Both reductions of a flow step's tail in ONE pass over z and jac (the "gnf_nll_reduce" of SURVEY.md 8b; used behind
+ * normalizers whose kernel cannot reduce over a row itself, i.e. the Monotonic one):
+ *   logdet[b] = sum_i log(jac[b,i])   logn[b] = -0.5*sum_i(log(2pi)+z[b,i]^2)
+ * bwd: gz[b,i] = (gz_in ? gz_in[b,i] : 0) - z[b,i]*glogn[b],  gjac[b,i] = glogdet[b]/jac[b,i]
+ *      (glogdet / glogn / gz_in may be NULL = zero). */
+int gnf_nll_reduce_fwd(const float* z, const float* jac, float* logdet, float* logn, int64_t B, int64_t d,
+                       gnf_stream_t stream);
+int gnf_nll_reduce_bwd(const float* z, const float* jac, const float* glogdet, const float* glogn, const float* gz_in,
+                       float* gz, float* gjac, int64_t B, int64_t d, gnf_stream_t stream);
 /* out[n] = sum_m a[m*lda + n]  (bias gradients; deterministic two-level reduction).
  * ws: >= gnf_colsum_ws_bytes(M,N) bytes. */
 int64_t gnf_colsum_ws_bytes(int64_t M, int64_t N);

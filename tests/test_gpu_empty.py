@@ -60,7 +60,7 @@ def test_empty_batch_through_every_autograd_function():
 
     # Affine (+ inverse, + the row reductions of the loss)
     h = torch.zeros(0, d, 2, device=DEV, requires_grad=True)
-    z, jac, ld = ops.AffineFn.apply(x, h)
+    z, jac, ld, _ = ops.AffineFn.apply(x, h)
     assert z.shape == (0, d) and jac.shape == (0, d) and ld.shape == (0,)
     (z.sum() + jac.sum() + ld.sum()).backward()
     assert x.grad.shape == (0, d) and h.grad.shape == (0, d, 2)

@@ -76,7 +76,7 @@ def test_affine_strided_h_and_large():
     h = hraw.view(B, 2, d).permute(0, 2, 1)          # MADE layout: strides (2d, 1, d)
     z0, j0 = O.affine_forward(x, h)
     xg, hg = req(x), cu(hraw).requires_grad_(True)
-    z, jac, ld = ops.AffineFn.apply(xg, hg.view(B, 2, d).permute(0, 2, 1))
+    z, jac, ld, _ = ops.AffineFn.apply(xg, hg.view(B, 2, d).permute(0, 2, 1))
     assert rel_err(z.cpu(), z0) < TOL and rel_err(jac.cpu(), j0) < TOL
     assert rel_err(ld.cpu(), torch.log(j0).sum(1)) < TOL
     (z.sum() + ld.sum()).backward()
@@ -96,7 +96,7 @@ def test_affine_flat_vectorised_path_vs_oracle(B, d):
     x, h = torch.randn(B, d), torch.randn(B, d, 2) * 3
     z0, j0 = O.affine_forward(x, h)
     xg, hg = req(x), req(h)
-    z, jac, ld = ops.AffineFn.apply(xg, hg)
+    z, jac, ld, _ = ops.AffineFn.apply(xg, hg)
     assert rel_err(z.cpu(), z0) < TOL and rel_err(jac.cpu(), j0) < TOL
     assert rel_err(ld.cpu(), torch.log(j0).sum(1)) < TOL
     assert_close(ld, torch.log(j0).sum(1), atol=2e-6 * d ** .5, what="logdet")
@@ -108,8 +108,8 @@ def test_affine_flat_vectorised_path_vs_oracle(B, d):
     assert rel_err(xg.grad.cpu(), xr.grad) < TOL and rel_err(hg.grad.cpu(), hr.grad) < TOL
     # the fused step's variant (no jac output) and determinism
     with torch.no_grad():
-        z2, _, ld2 = ops.AffineFn.apply(cu(x), cu(h), False, False)
-        z3, _, ld3 = ops.AffineFn.apply(cu(x), cu(h), False, False)
+        z2, _, ld2, _ = ops.AffineFn.apply(cu(x), cu(h), False, False)
+        z3, _, ld3, _ = ops.AffineFn.apply(cu(x), cu(h), False, False)
     assert torch.equal(z2, z.detach()) and torch.equal(ld2, ld3) and rel_err(ld2.cpu(), ld.detach().cpu()) < 1e-6
 
 
@@ -511,6 +511,84 @@ def test_dag_level_schedule_inversion_equals_fixed_point(normalizer):
     with torch.no_grad():
         zz, _ = flow(x_lvl)
     assert rel_err(zz.cpu(), z.cpu()) < (1e-4 if normalizer == "affine" else 2e-3)   # bisection resolution 1.9e-5 abs
+
+
+# --------------------------------------------------------------------------------- fused tail of a flow step
+@pytest.mark.parametrize("B,d", [(7, 5), (33, 63), (5000, 63), (4200, 64), (9000, 30), (400, 784), (3, 1)])
+def test_nll_reduce_vs_torch(B, d):
+    """gnf_nll_reduce (log(jac).sum(1) and the Normal log-density in one pass; models/NormalizingFlow.py:70,
+    NormalizingFlowFactories.py:15-16) and its one-launch backward, on the row-group and the span-per-wavefront kernels
+    (B d >= 2^18, d <= 64: d = 63 -> 4 rows per span, 30 -> 2, 64 -> 1)."""
+    from gnf_hip import ops
+    g = torch.Generator().manual_seed(B + d)
+    z = torch.randn(B, d, generator=g)
+    jac = torch.rand(B, d, generator=g) * 3 + .05
+    gl, gn = torch.randn(B, generator=g), torch.randn(B, generator=g)
+    zr, jr = z.clone().double().requires_grad_(True), jac.clone().double().requires_grad_(True)
+    ld0 = torch.log(jr).sum(1)
+    ln0 = O.normal_log_density(zr)
+    ((ld0 * gl.double()).sum() + (ln0 * gn.double()).sum()).backward()
+    zg, jg = req(z), req(jac)
+    ld, ln = ops.NllReduceFn.apply(zg, jg)
+    assert_close(ld, ld0.detach().float(), rtol=2e-6, atol=1e-5 * d ** .5, what="logdet")
+    assert_close(ln, ln0.detach().float(), rtol=2e-6, atol=1e-5 * d ** .5, what="logN")
+    ((ld * cu(gl)).sum() + (ln * cu(gn)).sum()).backward()
+    assert_close(zg.grad, zr.grad.float(), rtol=1e-6, atol=1e-7, what="gz")
+    assert_close(jg.grad, jr.grad.float(), rtol=2e-6, atol=1e-7, what="gjac")
+    # the stand-alone entry points run on the same kernels
+    assert torch.equal(ops.NormalLogDensityFn.apply(cu(z)), ln.detach())
+    assert torch.equal(ops.LogSumRowsFn.apply(cu(jac)), ld.detach())
+
+
+@pytest.mark.parametrize("B,d,layout", [(9, 7, "contig"), (6000, 63, "contig"), (64, 40, "made")])
+def test_affine_fused_normal_log_density(B, d, layout):
+    """AffineFn with the Normal log-density of z reduced in the same pass (want_logn) and its cotangent folded into
+    the backward (z recomputed): against plain torch on the CPU."""
+    from gnf_hip import ops
+    g = torch.Generator().manual_seed(17 * B + d)
+    x = torch.randn(B, d, generator=g)
+    hraw = torch.randn(B, 2 * d, generator=g) * 2.5 if layout == "made" else torch.randn(B, d, 2, generator=g) * 2.5
+    gzv, gl, gn = torch.randn(B, d, generator=g), torch.randn(B, generator=g), torch.randn(B, generator=g)
+    xr, hr = x.clone().requires_grad_(True), hraw.clone().requires_grad_(True)
+    hv = hr.view(B, 2, d).permute(0, 2, 1) if layout == "made" else hr
+    mu, ls = torch.clamp(hv[:, :, 0], -5., 5.), torch.clamp(hv[:, :, 1], -5., 2.)
+    z0 = xr * torch.exp(ls) + mu
+    ld0, ln0 = ls.sum(1), O.normal_log_density(z0)
+    ((z0 * gzv).sum() + (ld0 * gl).sum() + (ln0 * gn).sum()).backward()
+    xg, hg = req(x), req(hraw)
+    hgv = hg.view(B, 2, d).permute(0, 2, 1) if layout == "made" else hg
+    z, _, ld, ln = ops.AffineFn.apply(xg, hgv, False, False, True)
+    assert_close(z, z0, what="z")
+    assert_close(ld, ld0, atol=1e-5, what="logdet")
+    assert_close(ln, ln0, rtol=2e-6, atol=1e-4, what="logN")
+    ((z * cu(gzv)).sum() + (ld * cu(gl)).sum() + (ln * cu(gn)).sum()).backward()
+    assert rel_err(xg.grad.cpu(), xr.grad) < GTOL and rel_err(hg.grad.cpu(), hr.grad) < GTOL
+
+
+def test_flow_loss_uses_the_density_reduced_with_z():
+    """flow(x) stashes the Normal log-density on the z it returns; flow.loss(z, logdet) picks it up (no second pass
+    over z) and gives the value and gradients of the separate evaluation."""
+    from models import buildFCNormalizingFlow, AutoregressiveConditioner, AffineNormalizer, MonotonicNormalizer
+    from gnf_hip import ops
+    for norm_t, args in ((AffineNormalizer, {}), (MonotonicNormalizer, {"integrand_net": [16, 16], "cond_size": 6})):
+        torch.manual_seed(5)
+        hs = 2 if norm_t is AffineNormalizer else 6
+        flow = buildFCNormalizingFlow(2, AutoregressiveConditioner, {"in_size": 9, "hidden": [32, 32], "out_size": hs},
+                                      norm_t, args).to(DEV)
+        x = torch.randn(21, 9, device=DEV)
+        z, ld = flow(x)
+        assert ops.cached_logn(z) is not None
+        loss = flow.loss(z, ld)
+        fresh = flow.constraintsLoss() - (ld + ops.NormalLogDensityFn.apply(z.detach())).mean()
+        assert abs(loss.item() - fresh.item()) <= 1e-6 * max(1., abs(fresh.item()))
+        loss.backward()
+        g1 = [p.grad.clone() for p in flow.parameters()]
+        for p in flow.parameters():
+            p.grad = None
+        z2, ld2 = flow(x)
+        (flow.constraintsLoss() - (ld2 + ops.NormalLogDensityFn.apply(z2)).mean()).backward()
+        for a, b in zip(g1, (p.grad for p in flow.parameters())):
+            assert rel_err(a.cpu(), b.cpu()) < 1e-5
 
 
 # --------------------------------------------------------------------------------- Monotonic vs oracle

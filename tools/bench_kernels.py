@@ -6,8 +6,10 @@ import sys
 
 import torch
 
-sys.path[:0] = ['/root/repo', '/root/repo/graphical-normalizing-flows_amd']
-from gnf_hip import ops  # noqa: E402
+import os
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, ROOT + '/graphical-normalizing-flows_amd']
+from gnf_hip import abi, ops  # noqa: E402
 from models import MonotonicNormalizer  # noqa: E402
 
 DEV = "cuda:0"
@@ -30,6 +32,17 @@ def timeit(fn, n=20, warm=3):
     return ts[len(ts) // 2]
 
 
+def time_entry(name, fn, n=20, warm=3):
+    """median-free mean of the HIP events gnf_hip.abi records around the NAMED C-ABI entry point (on its launch stream):
+    the kernel(s) of that entry point alone, without autograd bookkeeping, output allocation or other launches"""
+    for _ in range(warm):
+        fn()
+    abi.profile_enable((name,))
+    for _ in range(n):
+        fn()
+    return abi.profile_collect()[name]
+
+
 rows = []
 
 
@@ -48,17 +61,22 @@ def mfma(name, shape, ms, flops):
 def main():
     torch.manual_seed(0)
     # ---- Affine normalizer (16 B/elem fwd, 28 B/elem bwd)
-    for B, d in [(100, 784), (50000, 63), (1000000, 63)]:
+    for B, d in [(100, 784), (50000, 63), (1000000, 63), (4000000, 63)]:     # the last one: 1 GB per array, beyond the 256 MB Infinity Cache
         x = torch.randn(B, d, device=DEV, requires_grad=True)
         h = torch.randn(B, d, 2, device=DEV, requires_grad=True)
         with torch.no_grad():
-            hbm("affine_fwd(z,logdet)", [B, d], timeit(lambda: ops.AffineFn.apply(x, h, False, False)), 16. * B * d + 4 * B)
-        z, jac, ld = ops.AffineFn.apply(x, h)
+            hbm("affine_fwd(z,logdet)", [B, d], time_entry("gnf_affine_fwd", lambda: ops.AffineFn.apply(x, h, False, False)), 16. * B * d + 4 * B)
+            hbm("affine_fwd(z,logdet,logN)", [B, d], time_entry("gnf_affine_fwd", lambda: ops.AffineFn.apply(x, h, False, False, True)), 16. * B * d + 8 * B)
+        z, jac, ld, _ = ops.AffineFn.apply(x, h)
         gz, gl = torch.randn_like(z), torch.randn_like(ld)
-        hbm("affine_bwd", [B, d], timeit(lambda: torch.autograd.grad((z, ld), (x, h), (gz, gl), retain_graph=True)),
+        hbm("affine_bwd", [B, d], time_entry("gnf_affine_bwd", lambda: torch.autograd.grad((z, ld), (x, h), (gz, gl), retain_graph=True)),
+            28. * B * d + 4 * B)
+        hbm("affine_bwd (through autograd)", [B, d], timeit(lambda: torch.autograd.grad((z, ld), (x, h), (gz, gl), retain_graph=True)),
             28. * B * d + 4 * B)
         with torch.no_grad():
-            hbm("normal_logdensity_fwd", [B, d], timeit(lambda: ops.NormalLogDensityFn.apply(x)), 4. * B * d)
+            hbm("normal_logdensity_fwd", [B, d], time_entry("gnf_normal_logdensity_fwd", lambda: ops.NormalLogDensityFn.apply(x)), 4. * B * d)
+            jj = torch.rand(B, d, device=DEV) + .1
+            hbm("nll_reduce_fwd(logdet,logN)", [B, d], time_entry("gnf_nll_reduce_fwd", lambda: ops.NllReduceFn.apply(x, jj)), 8. * B * d)
     # ---- DAG gate (writes 4 B per (b,i,j))
     for B, d in [(100, 784), (10000, 6)]:
         x = torch.randn(B, d, device=DEV)

@@ -9,7 +9,7 @@ B, d = 1000000, 63
 x = torch.randn(B, d, device=dev, requires_grad=True)
 h = torch.randn(B, d, 2, device=dev, requires_grad=True)
 for _ in range(3):
-    z, _, ld = ops.AffineFn.apply(x, h, False, False)
+    z, _, ld, _ = ops.AffineFn.apply(x, h, False, False)
     torch.autograd.grad((z, ld), (x, h), (torch.ones_like(z), torch.ones_like(ld)))
 xx = torch.randn(100, 784, device=dev)
 A = torch.rand(784, 784, device=dev)
