@@ -176,30 +176,41 @@ class MLPFn(torch.autograd.Function):
     (CouplingConditioner.py:6-19), DAGMLP (DAGConditioner.py:7-20), MADE's masked linears
     (AutoregressiveConditioner.py:14-25, mask fused into the weight load instead of a
     mask*weight product per forward), MNISTCNN.fc1/fc2 (MLP.py:44-47).  The backward fuses the
-    ReLU gate into the epilogue of the data-gradient GEMM and the mask into the
-    weight-gradient GEMM."""
+    ReLU gate into the epilogue of the data-gradient kernel, the mask into the weight-gradient
+    one and the bias gradient (column sums) into the same launch.  Every layer goes through the
+    gnf_linear_* entry points: small batches run on weight-streaming kernels that evaluate a
+    degree-structured mask (`degs[i] = (deg_out, deg_in, strict)`) instead of reading it."""
 
     @staticmethod
-    def forward(ctx, x, masks, relu_in, *params):
+    def _spec(ctx, li):
+        mk = ctx.masks[li] if ctx.masks is not None else None
+        dg = ctx.degs[li] if ctx.degs is not None else None
+        if dg is None:
+            return ptr(mk), None, None, 0
+        return ptr(mk), ptr(dg[0]), ptr(dg[1]), int(dg[2])
+
+    @staticmethod
+    def forward(ctx, x, masks, relu_in, degs, *params):
         """relu_in: x is itself the output of a ReLU (e.g. fc1 of the sparse embedding front): its gradient leaves this
-        Function already gated by x > 0, fused into the data-gradient GEMM's epilogue."""
+        Function already gated by x > 0, fused into the data-gradient kernel's epilogue."""
         x = x.contiguous()
         n = len(params) // 2
+        ctx.masks, ctx.degs, ctx.n, ctx.relu_in = masks, degs, n, bool(relu_in)
         acts = [x]
         a = x
         for li in range(n):
             W, b = params[2 * li].contiguous(), params[2 * li + 1]
-            mk = masks[li] if masks is not None else None
             out_f, in_f = W.shape
             M = a.shape[0]
             y = _empty((M, out_f), x)
-            gemm(a, (in_f, 1), W, (1, in_f), y, (out_f, 1), M, out_f, in_f, Bmask=mk, bias=b, relu=(li < n - 1))
+            nws = abi.load().gnf_linear_ws_bytes(M, out_f, in_f)
+            ws = _ws(nws, x) if nws > 0 else None
+            mk, do, di, st = MLPFn._spec(ctx, li)
+            call("gnf_linear_fwd", ptr(a), ptr(W), ptr(b), mk, do, di, st, 1 if li < n - 1 else 0, ptr(y), M, out_f, in_f,
+                 ptr(ws), nws, stream())
             a = y
             if li < n - 1:
                 acts.append(y)
-        ctx.masks = masks
-        ctx.n = n
-        ctx.relu_in = bool(relu_in)
         ctx.save_for_backward(*acts, *params)
         return a
 
@@ -213,30 +224,39 @@ class MLPFn(torch.autograd.Function):
         gx = None
         for li in range(n - 1, -1, -1):
             W = params[2 * li].contiguous()
-            mk = ctx.masks[li] if ctx.masks is not None else None
             out_f, in_f = W.shape
             a = acts[li]
             M = a.shape[0]
-            if ctx.needs_input_grad[3 + 2 * li]:
+            nws = abi.load().gnf_linear_ws_bytes(M, out_f, in_f)
+            ws = _ws(nws, W) if nws > 0 else None
+            mk, do, di, st = MLPFn._spec(ctx, li)
+            want_w, want_b = ctx.needs_input_grad[4 + 2 * li], ctx.needs_input_grad[5 + 2 * li]
+            if want_w:
                 gW = _empty((out_f, in_f), W)
-                gemm(g, (1, out_f), a, (in_f, 1), gW, (in_f, 1), out_f, in_f, M, Cmask=mk, cm_strides=(in_f, 1))
+                gb = _empty((out_f,), W) if want_b else None
+                call("gnf_linear_bwd_w", ptr(g), ptr(a), mk, do, di, st, ptr(gW), ptr(gb), M, out_f, in_f, ptr(ws), nws,
+                     stream())
                 grads[2 * li] = gW
-            if ctx.needs_input_grad[4 + 2 * li]:
+                grads[2 * li + 1] = gb
+            elif want_b:
                 grads[2 * li + 1] = colsum(g)
             if li > 0 or ctx.needs_input_grad[0]:
                 ga = _empty((M, in_f), W)
-                gemm(g, (out_f, 1), W, (in_f, 1), ga, (in_f, 1), M, in_f, out_f, Bmask=mk,
-                     gate=(a if (li > 0 or ctx.relu_in) else None), g_strides=(in_f, 1))
+                gate = a if (li > 0 or ctx.relu_in) else None
+                call("gnf_linear_bwd_x", ptr(g), ptr(W), mk, do, di, st, ptr(gate), ptr(ga), M, out_f, in_f, ptr(ws), nws,
+                     stream())
                 g = ga
                 if li == 0:
                     gx = ga
-        return (gx, None, None, *grads)
+        return (gx, None, None, None, *grads)
 
 
-def mlp(x, layers, masks=None, relu_in=False):
-    """layers: list of (weight, bias) parameter pairs."""
+def mlp(x, layers, masks=None, relu_in=False, degs=None):
+    """layers: list of (weight, bias) parameter pairs; masks: per-layer [out, in] 0/1 tensors (or None); degs: per-layer
+    (deg_out [out], deg_in [in], strict) with mask[o][i] = deg_in[i] <= deg_out[o] (strict: <) where the caller has
+    verified that the mask tensor has that structure, else None."""
     flat = [p for Wb in layers for p in Wb]
-    return MLPFn.apply(x, masks, relu_in, *flat)
+    return MLPFn.apply(x, masks, relu_in, degs, *flat)
 
 
 # ----------------------------------------------------------------------------- MNISTCNN conv front

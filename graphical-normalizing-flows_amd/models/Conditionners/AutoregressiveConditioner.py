@@ -14,12 +14,34 @@ class MaskedLinear(nn.Linear):
     def __init__(self, in_features, out_features, bias=True):
         super().__init__(in_features, out_features, bias)
         self.register_buffer('mask', torch.ones(out_features, in_features))
+        # the degrees the mask was built from (not part of the reference's state_dict): mask[o][i] = deg_in[i] <= deg_out[o]
+        # (strict: <).  The small-batch kernels evaluate that rule instead of streaming the fp32 mask next to the weights.
+        self.register_buffer('deg_out', torch.zeros(out_features), persistent=False)
+        self.register_buffer('deg_in', torch.zeros(in_features), persistent=False)
+        self.deg_strict = False
+        self._deg_checked = None           # (mask version, deg versions) of the last verification, and its verdict
+        self._deg_ok = False
 
-    def set_mask(self, mask):
+    def set_mask(self, mask, deg_out=None, deg_in=None, strict=False):
         self.mask.data.copy_(torch.from_numpy(mask.astype(np.uint8).T))
+        if deg_out is not None:
+            self.deg_out.data.copy_(torch.as_tensor(np.asarray(deg_out), dtype=torch.float32))
+            self.deg_in.data.copy_(torch.as_tensor(np.asarray(deg_in), dtype=torch.float32))
+            self.deg_strict = bool(strict)
+        self._deg_checked = None
+
+    def degree_spec(self):
+        """(deg_out, deg_in, strict) if the mask buffer IS the degree rule (checked once per change of the buffers -- a
+        loaded checkpoint or a user's set_mask may carry any 0/1 pattern), else None: the kernels then read the mask."""
+        key = (self.mask._version, self.deg_out._version, self.deg_in._version, self.mask.data_ptr(), self.deg_strict)
+        if self._deg_checked != key:
+            cmp = torch.lt if self.deg_strict else torch.le
+            self._deg_ok = bool(torch.equal(self.mask, cmp(self.deg_in[None, :], self.deg_out[:, None]).to(self.mask.dtype)))
+            self._deg_checked = key
+        return (self.deg_out, self.deg_in, self.deg_strict) if self._deg_ok else None
 
     def forward(self, input):
-        return ops.mlp(input, [(self.weight, self.bias)], [self.mask])
+        return ops.mlp(input, [(self.weight, self.bias)], [self.mask], degs=[self.degree_spec()])
 
 
 def made_degrees(nin, hidden_sizes):
@@ -63,10 +85,14 @@ class MADE(nn.Module):
         self.m = made_degrees(self.nin, self.hidden_sizes)
         masks = [self.m[l - 1][:, None] <= self.m[l][None, :] for l in range(L)]
         masks.append(self.m[L - 1][:, None] < self.m[-1][None, :])
+        degs = [(self.m[l], self.m[l - 1], False) for l in range(L)]
+        deg_last = self.m[-1]
         if self.nout > self.nin:
             masks[-1] = np.concatenate([masks[-1]] * int(self.nout / self.nin), axis=1)
-        for layer, mk in zip(self.masked_layers(), masks):
-            layer.set_mask(mk)
+            deg_last = np.concatenate([deg_last] * int(self.nout / self.nin))
+        degs.append((deg_last, self.m[L - 1], True))
+        for layer, mk, (do, di, strict) in zip(self.masked_layers(), masks, degs):
+            layer.set_mask(mk, do, di, strict)
         self.i_map = self.m[-1].copy()
         for k in range(len(self.m[-1])):
             self.i_map[self.m[-1][k]] = k
@@ -76,7 +102,7 @@ class MADE(nn.Module):
 
     def forward(self, x):
         ls = self.masked_layers()
-        y = ops.mlp(x, [(l.weight, l.bias) for l in ls], [l.mask for l in ls])
+        y = ops.mlp(x, [(l.weight, l.bias) for l in ls], [l.mask for l in ls], degs=[l.degree_spec() for l in ls])
         return y.view(x.shape[0], -1, x.shape[1]).permute(0, 2, 1)
 
 

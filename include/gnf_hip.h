@@ -78,6 +78,28 @@ int gnf_nll_reduce_bwd(const float* z, const float* jac, const float* glogdet, c
 int64_t gnf_colsum_ws_bytes(int64_t M, int64_t N);
 int gnf_colsum(const float* a, int64_t lda, float* out, int64_t M, int64_t N, float* ws, gnf_stream_t stream);
 
+/* ---- Linear / masked-Linear layers of the conditioner MLPs ----------------------------------------------------------
+ * MADE's MaskedLinear (models/Conditionners/AutoregressiveConditioner.py:14-25: F.linear(x, mask * W, b)) and the plain
+ * Linear + ReLU chains of CouplingMLP / DAGMLP, forward and autograd.  x: [M,K], W: [N,K] (nn.Linear layout), y: [M,N],
+ * all contiguous.  The mask is either `mask` ([N,K], 0/1, may be NULL = none) or, when deg_out / deg_in are given, the
+ * degree rule mask[o][i] = deg_in[i] <= deg_out[o] (strict != 0: <) of AutoregressiveConditioner.py:85-96 evaluated in
+ * the kernel -- the caller guarantees that `mask` (still needed by the large-batch path) equals it.  M <= 128 rows run on
+ * the weight-streaming kernels of gnf_linear.hip (no mask stream, no split-K partials), anything else on the tiled GEMM.
+ *   fwd:    y  = act(x (W o mask)^T + b)                       relu != 0: act = ReLU
+ *   bwd_x:  gx = (g (W o mask)) o [gate > 0]                   g: [M,N]; gate: [M,K] (the layer's input) or NULL
+ *   bwd_w:  gW = (g^T a) o mask, gb = column sums of g         a: [M,K]; gb: [N] or NULL
+ * ws: >= gnf_linear_ws_bytes(M,N,K) bytes. */
+int64_t gnf_linear_ws_bytes(int64_t M, int64_t N, int64_t K);
+int gnf_linear_fwd(const float* x, const float* W, const float* b, const float* mask, const float* deg_out,
+                   const float* deg_in, int strict, int relu, float* y, int64_t M, int64_t N, int64_t K,
+                   float* ws, int64_t ws_bytes, gnf_stream_t stream);
+int gnf_linear_bwd_x(const float* g, const float* W, const float* mask, const float* deg_out, const float* deg_in,
+                     int strict, const float* gate, float* gx, int64_t M, int64_t N, int64_t K,
+                     float* ws, int64_t ws_bytes, gnf_stream_t stream);
+int gnf_linear_bwd_w(const float* g, const float* a, const float* mask, const float* deg_out, const float* deg_in,
+                     int strict, float* gW, float* gb, int64_t M, int64_t N, int64_t K,
+                     float* ws, int64_t ws_bytes, gnf_stream_t stream);
+
 /* ---- fp32 MFMA GEMM with fused masks / bias / ReLU ------------------------------------
  * Replaces F.linear(input, mask*weight, bias) (AutoregressiveConditioner.py:24-25), the
  * nn.Linear+ReLU chains of CouplingMLP / DAGMLP / MNISTCNN.fc* and their autograd

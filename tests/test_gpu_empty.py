@@ -86,7 +86,7 @@ def test_empty_batch_through_every_autograd_function():
         for p in (W1, b1, W2, b2):
             p.grad = None
         x3 = torch.zeros(0, d, device=DEV, requires_grad=True)
-        y = ops.MLPFn.apply(x3, masks, False, W1, b1, W2, b2)
+        y = ops.MLPFn.apply(x3, masks, False, None, W1, b1, W2, b2)
         assert y.shape == (0, 4)
         y.sum().backward()
         _zero(W1.grad, b1.grad, W2.grad, b2.grad)

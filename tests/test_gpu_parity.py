@@ -513,6 +513,76 @@ def test_dag_level_schedule_inversion_equals_fixed_point(normalizer):
     assert rel_err(zz.cpu(), z.cpu()) < (1e-4 if normalizer == "affine" else 2e-3)   # bisection resolution 1.9e-5 abs
 
 
+# --------------------------------------------------------------------------------- small-batch Linear kernels
+@pytest.mark.parametrize("M,N,K", [(1, 16, 16), (7, 40, 48), (100, 1024, 784), (100, 1568, 1024), (128, 96, 160),
+                                   (37, 150, 2), (129, 64, 64), (100, 30, 50)])
+@pytest.mark.parametrize("mask_kind", ["none", "full", "deg", "deg_strict"])
+def test_linear_layer_kernels_vs_torch(M, N, K, mask_kind):
+    """gnf_linear_fwd / _bwd_x / _bwd_w (gnf_linear.hip: weight-streaming kernels for M <= 128 with the MADE mask as a
+    degree rule or as a tensor; the tiled GEMM otherwise, e.g. M = 129 or K = 50) against F.linear(x, mask * W, b) and its
+    autograd on the CPU (AutoregressiveConditioner.py:24-25)."""
+    from gnf_hip import ops
+    g = torch.Generator().manual_seed(M * 1000 + N + K)
+    x = torch.randn(M, K, generator=g)
+    W, b = torch.randn(N, K, generator=g) / K ** .5, torch.randn(N, generator=g) * .1
+    W2, b2 = torch.randn(N, N, generator=g) / N ** .5, torch.randn(N, generator=g) * .1
+    gy = torch.randn(M, N, generator=g)
+    masks = degs = None
+    m1 = m2 = None
+    if mask_kind != "none":
+        strict = mask_kind == "deg_strict"
+        do1, di1 = torch.randint(0, 9, (N,), generator=g).float(), torch.randint(0, 9, (K,), generator=g).float()
+        do2, di2 = torch.randint(0, 9, (N,), generator=g).float(), do1
+        cmp = torch.lt if strict else torch.le
+        m1, m2 = cmp(di1[None, :], do1[:, None]).float(), cmp(di2[None, :], do2[:, None]).float()
+        if mask_kind == "full":                            # an arbitrary 0/1 pattern: no degree structure
+            m1 = (torch.rand(N, K, generator=g) < .6).float()
+            m2 = (torch.rand(N, N, generator=g) < .6).float()
+        else:
+            degs = [(cu(do1), cu(di1), strict), (cu(do2), cu(di2), strict)]
+        masks = [cu(m1), cu(m2)]
+    # two layers: the first one's backward exercises the gated data gradient of the second
+    xr, Wr, br, W2r, b2r = (t.clone().requires_grad_(True) for t in (x, W, b, W2, b2))
+    h = torch.relu(torch.nn.functional.linear(xr, Wr * m1 if m1 is not None else Wr, br))
+    y0 = torch.nn.functional.linear(h, W2r * m2 if m2 is not None else W2r, b2r)
+    (y0 * gy).sum().backward()
+    xg, Wg, bg, W2g, b2g = (req(t) for t in (x, W, b, W2, b2))
+    y = ops.mlp(xg, [(Wg, bg), (W2g, b2g)], masks, degs=degs)
+    assert_close(y, y0, rtol=1e-5, atol=2e-5, what="y")
+    (y * cu(gy)).sum().backward()
+    for name, a, r in (("gx", xg, xr), ("gW1", Wg, Wr), ("gb1", bg, br), ("gW2", W2g, W2r), ("gb2", b2g, b2r)):
+        assert rel_err(a.grad.cpu(), r.grad) < GTOL, (name, rel_err(a.grad.cpu(), r.grad))
+        if name.startswith("gW") and m1 is not None:       # masked-out weights get an exactly-zero gradient
+            mk = m1 if name == "gW1" else m2
+            assert int(((a.grad.cpu() != 0) & (mk == 0)).sum()) == 0
+
+
+def test_made_degree_rule_is_verified_against_the_mask_buffer():
+    """MaskedLinear hands the kernels its degree vectors only while the mask buffer equals the degree rule; a mask that
+    was overwritten (a checkpoint, a user's own pattern) is read as a tensor again, and the result follows it."""
+    from models import AutoregressiveConditioner
+    torch.manual_seed(3)
+    cond = AutoregressiveConditioner(12, [32, 32], 2).to(DEV)
+    layers = cond.masked_autoregressive_net.masked_layers()
+    assert all(l.degree_spec() is not None for l in layers)
+    sd = cond.state_dict()
+    assert not any("deg_" in k for k in sd)                   # the reference's checkpoint keys, nothing more
+    x = torch.randn(9, 12, device=DEV)
+    h0 = cond(x)
+    with torch.no_grad():
+        layers[1].mask.copy_((torch.rand_like(layers[1].mask) < .5).float())
+    assert layers[1].degree_spec() is None and layers[0].degree_spec() is not None
+    h1 = cond(x)
+    ref = x
+    for k, l in enumerate(layers):
+        ref = torch.nn.functional.linear(ref, l.weight * l.mask, l.bias)
+        if k < len(layers) - 1:
+            ref = torch.relu(ref)
+    ref = ref.view(9, -1, 12).permute(0, 2, 1)
+    assert_close(h1, ref, rtol=1e-5, atol=1e-5, what="h with an arbitrary mask")
+    assert (h1 - h0).abs().max() > 1e-3
+
+
 # --------------------------------------------------------------------------------- fused tail of a flow step
 @pytest.mark.parametrize("B,d", [(7, 5), (33, 63), (5000, 63), (4200, 64), (9000, 30), (400, 784), (3, 1)])
 def test_nll_reduce_vs_torch(B, d):
@@ -776,7 +846,10 @@ def test_abi_error_codes():
     st = abi.stream()
     x = torch.zeros(4, 4, device=DEV)
     P = ctypes.c_void_p
-    assert lib.gnf_affine_fwd(None, P(x.data_ptr()), 8, 2, 1, P(x.data_ptr()), None, None, 0, 2, 2, st) == -1
+    assert lib.gnf_affine_fwd(None, P(x.data_ptr()), 8, 2, 1, P(x.data_ptr()), None, None, None, 0, 2, 2, st) == -1
+    # a degree rule needs both vectors; the small-batch Linear entry points validate like the others
+    assert lib.gnf_linear_fwd(P(x.data_ptr()), P(x.data_ptr()), None, None, P(x.data_ptr()), None, 0, 0,
+                              P(x.data_ptr()), 4, 4, 4, None, 0, st) == -1
     assert lib.gnf_gemm(P(x.data_ptr()), 4, 1, None, None, 1, 4, P(x.data_ptr()), 4, 1, None, None, 0, 0, None, 0, 0, 0,
                         4, 4, 4, None, 0, st) == -1
     net = abi.MonoNet()
