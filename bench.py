@@ -37,22 +37,15 @@ PEAK_F32_TFLOPS = 157.3          # MI355X fp32 MFMA/vector peak (MI355X_MICROARC
 
 
 def pseudo_mnist(gen, B, d):
-    """logit-space pseudo-MNIST: reference transform (lib/transform.py:5-20) applied to a
-    synthetic pixel law (p=0 w.p. 0.8 else U{1..255}) -- real MNIST is not available."""
-    p = torch.where(torch.rand(B, d, generator=gen) < .8, torch.zeros(B, d),
-                    torch.randint(1, 256, (B, d), generator=gen).float())
-    y = (p + torch.rand(B, d, generator=gen)) / 256.
-    y = 1e-6 + (1 - 2e-6) * y
-    return torch.log(y) - torch.log(1 - y)
+    from gnf_hip import configs
+    return configs.pseudo_mnist(gen, B, d)
 
 
 def build_flow():
-    from models import MonotonicNormalizer
-    from models.NormalizingFlowFactories import buildMNISTNormalizingFlow
-    torch.manual_seed(0)
-    return buildMNISTNormalizingFlow([1], MonotonicNormalizer,
-                                     {"integrand_net": INT_NET, "nb_steps": 15, "solver": "CC"}, l1=0.,
-                                     nb_epoch_update=10, hot_encoding=False, prior_kernel=2)
+    """cfg4 of BASELINE.json: buildMNISTNormalizingFlow([1], MonotonicNormalizer [50,50,50], prior kernel 2,
+    hot_encoding=False) -- gnf_hip.configs holds the builders of all five configurations"""
+    from gnf_hip import configs
+    return configs.build_cfg4_flow()
 
 
 def train_step(flow, state, x):
@@ -82,8 +75,6 @@ def cpu_baseline():
     Bc = 2
     x = pseudo_mnist(torch.Generator().manual_seed(1234), Bc, D)
     ncpu = os.cpu_count() or 1
-    cores = min(ncpu, 32)                    # more threads only add contention at this size
-    torch.set_num_threads(cores)
     model = "unknown"
     try:
         with open("/proc/cpuinfo") as f:
@@ -102,10 +93,21 @@ def cpu_baseline():
         closs = O.dag_loss(A, sd[pre + "alpha"], D % 50, sd[pre + "lambd"], sd[pre + "c"], sd[pre + "dag_const"],
                            sd[pre + "l1_weight"])
         O.flow_loss(z, torch.log(jac).sum(1), closs).backward()
-    step()                                   # warm-up
+    # SURVEY.md 8(d) asks for all physical cores; measured, not assumed: a short sweep over thread counts up to the
+    # physical core count (os.cpu_count() counts SMT siblings) picks the fastest setting, the sweep is reported
+    phys = max(1, ncpu // 2) if ncpu >= 16 else ncpu
+    sweep = {}
+    for th in sorted({min(32, phys), min(64, phys), phys}):
+        torch.set_num_threads(th)
+        step()                               # warm-up at this setting
+        t0 = time.perf_counter()
+        step(); step()
+        sweep[th] = Bc / ((time.perf_counter() - t0) / 2)
+    cores = max(sweep, key=sweep.get)
+    torch.set_num_threads(cores)
     t0 = time.perf_counter()
     n = 0
-    while n < 1 or (time.perf_counter() - t0 < 12. and n < 40):     # a bounded sample: ~12 s of host work
+    while n < 1 or (time.perf_counter() - t0 < 10. and n < 40):     # a bounded sample: ~10 s of host work
         step()
         n += 1
     dt = (time.perf_counter() - t0) / n
@@ -115,7 +117,8 @@ def cpu_baseline():
     dt1 = time.perf_counter() - t0
     torch.set_num_threads(cores)
     return {"value": Bc / dt, "unit": "samples/s", "cores": cores, "kind": "port",
-            "os_cpu_count": ncpu, "cpu_model": model, "threads": cores,
+            "os_cpu_count": ncpu, "physical_cores_assumed": phys, "cpu_model": model, "threads": cores,
+            "threads_sweep_samples_per_s": {str(k): round(v, 2) for k, v in sweep.items()},
             "sample": "%d steps of B=%d (same d=784 model, S=20), fwd+logdet+NLL+bwd, torch %d threads"
                       % (n, Bc, cores),
             "value_1thread": Bc / dt1}
@@ -183,12 +186,18 @@ def main():
     local = local % max(ndev, 1)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if world > 1:
+    force = os.environ.get("GNF_FORCE_DIST") == "1"          # world size 1 with the collective path on (dp.collective_on)
+    if world > 1 or force:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if world == 1:
+            os.environ.setdefault("MASTER_PORT", str(29500 + os.getpid() % 2000))
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
         if backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)
+            dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)
         else:
-            dist.init_process_group(backend)
+            dist.init_process_group(backend, rank=rank, world_size=world)
+    collective = world > 1 or force
 
     from gnf_hip import abi, ops
     abi.load()
@@ -200,7 +209,7 @@ def main():
     x = pseudo_mnist(torch.Generator().manual_seed(1234 + rank), B_PER_GPU, D).to(dev)
 
     def fence():
-        if world > 1:
+        if collective:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -209,12 +218,14 @@ def main():
     fence()
     abi.profile_enable(("gnf_mnistcnn_conv_fwd", "gnf_mnistcnn_conv_bwd", "gnf_monotonic_fwd", "gnf_monotonic_bwd",
                         "gnf_dag_gate_fwd", "gnf_dag_gate_bwd", "gnf_gemm"))
+    dp.comm_profile(True)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = train_step(flow, state, x)
     fence()
     dt = time.perf_counter() - t0
     prof = abi.profile_collect()
+    allreduce_ms = dp.comm_profile(False)                    # HIP events around the step's one collective
     if not torch.isfinite(loss).item():
         raise SystemExit("non-finite loss")
 
@@ -272,14 +283,19 @@ def main():
         t_det, det_error = None, repr(exc)
     # max over ranks of every timing (a missing secondary figure travels as -1); replicas must have stayed identical:
     # compare an order-independent bit checksum of the flat parameter buffer across ranks
-    tmax = torch.tensor([dt, t_fb or -1., t_mix or -1., t_det or -1.], dtype=torch.float64)
+    tmax = torch.tensor([dt, t_fb or -1., t_mix or -1., t_det or -1., allreduce_ms or -1.], dtype=torch.float64)
     replicas_identical = dp.replicas_identical(state, flow)
-    if world > 1:
+    per_rank_ms = [dt / args.steps * 1e3]
+    if collective:
         cdev = dev if backend == "nccl" else torch.device("cpu")     # RCCL moves device buffers, gloo host buffers
+        mine = torch.tensor([dt / args.steps * 1e3], dtype=torch.float64, device=cdev)
+        gathered = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(gathered, mine)                      # per-rank step time: the spread the max hides
+        per_rank_ms = [float(g.item()) for g in gathered]
         tmax = tmax.to(cdev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         tmax = tmax.cpu()
-    dt, t_fb, t_mix, t_det = [v if v > 0 else None for v in tmax.tolist()]
+    dt, t_fb, t_mix, t_det, allreduce_ms = [v if v > 0 else None for v in tmax.tolist()]
     if not replicas_identical:
         raise SystemExit("data-parallel replicas diverged (parameter checksums differ across ranks)")
 
@@ -313,7 +329,10 @@ def main():
             "parity_note": "UMNN 1.0 parity unpinned: the Clenshaw-Curtis integral of the Monotonic normalizer is "
                            "checked against this repo's own restatement + mathematics, not against the absent package; "
                            "everything else on the path is pinned by reference-generated fixtures",
-            "replicas_identical": replicas_identical, "dist_backend": backend if world > 1 else None,
+            "replicas_identical": replicas_identical, "dist_backend": backend if collective else None,
+            "collective_forced_at_world_1": bool(force and world == 1),
+            "allreduce_ms_per_step": round(allreduce_ms, 4) if allreduce_ms else None,
+            "ms_per_step_per_rank": [round(v, 4) for v in per_rank_ms],
             "config": {"workload": "cfg4: MNIST d=784, MonotonicNormalizer[50,50,50] cond 30 S=20 + DAGConditioner("
                                    "MNISTCNN->30, prior_A_kernel=2, hot_encoding=False, Gumbel gate T=1), "
                                    "b_size=100 per GPU; step = fwd+logdet+NLL+bwd+allreduce+Adam",
@@ -324,27 +343,33 @@ def main():
             "roofline_other": [v for k, v in kern.items() if k != dom],
             "ops_ms": {k: round(v, 4) for k, v in prof.items()},
         }
-        # HBM bytes per launch of the dominant kernel: PMC counters cannot be read from inside this process, so the
-        # figure is the one rocprofv3 measured for the same kernel at the same per-GPU size (profiles/r02_conv_hbm.json:
-        # 2 x FETCH_SIZE + WRITE_SIZE, separate --pmc passes), next to the algorithmic bytes; null for any other size
-        hbm = {"gnf_mnistcnn_conv_bwd": (1427.2e6, n_elem * (784 * 4 + 2304 * 5 + 784 * 4)),
-               "gnf_mnistcnn_conv_fwd": (1149.3e6, n_elem * (784 * 4 + 2304 * 5))}
-        if dom in hbm and n_elem == 78400:
-            out["roofline"]["traffic"] = hbm[dom][0]
-            out["roofline"]["traffic_algorithmic"] = float(hbm[dom][1])
-            out["roofline"]["traffic_source"] = "profiles/r02_conv_hbm.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE)"
-        # MFMA issue slots used by the dominant kernel: v_mfma_f32_16x16x4_f32 issued per image (Winograd form, incl.
-        # padding and the conv1 recompute) x 2048 flop / time / peak -- the head-room left, see DESIGN.md section 4
-        issued = {"gnf_mnistcnn_conv_bwd": 8 * 6 * 3 + 36 * 16 + 11 * 64 + 11 * 16, "gnf_mnistcnn_conv_fwd": 129 + 9 * 64}
-        if dom in issued:
-            out["roofline"]["mfma_issue_frac"] = round(issued[dom] * 2048. * n_elem / (prof[dom] * 1e-3) / 1e12
+        # PMC counters cannot be read from inside this process: HBM bytes per launch, MFMA instructions per image and other
+        # VALU instructions per MFMA of the conv pair are READ from profiles/r03_bench_inputs.json, which
+        # tools/make_bench_inputs.py writes from rocprofv3 --pmc passes over the same kernels at the same per-GPU size
+        # (null when the file is missing or the size differs)
+        pmc = {}
+        try:
+            with open(os.path.join(ROOT, "profiles", "r03_bench_inputs.json")) as f:
+                pmc_file = json.load(f)
+            if pmc_file.get("n_images") == n_elem:
+                pmc = pmc_file["kernels"]
+                out["roofline"]["pmc_source"] = "profiles/r03_bench_inputs.json (" + pmc_file["how"][:60] + "...)"
+        except (OSError, ValueError, KeyError):
+            pass
+        alg_bytes = {"gnf_mnistcnn_conv_bwd": n_elem * (784 * 4 + 2304 * 5 + 784 * 4),
+                     "gnf_mnistcnn_conv_fwd": n_elem * (784 * 4 + 2304 * 5)}
+        if dom in pmc:
+            out["roofline"]["traffic"] = pmc[dom]["hbm_bytes_per_launch"]
+            out["roofline"]["traffic_algorithmic"] = float(alg_bytes[dom])
+            # MFMA issue slots used by the dominant kernel: v_mfma_f32_16x16x4_f32 issued per image (Winograd form, incl.
+            # padding and the conv1 recompute) x 2048 flop / time / peak -- the head-room left, see DESIGN.md section 4
+            out["roofline"]["mfma_issue_frac"] = round(pmc[dom]["mfma_per_image"] * 2048. * n_elem / (prof[dom] * 1e-3) / 1e12
                                                        / PEAK_F32_TFLOPS, 4)
             # f32 MFMA and the other VALU instructions share one ALU per SIMD on gfx950 (tools/mfma_pipe.hip, valu_cost.hip:
             # 32.5 cycles per v_mfma_f32_16x16x4_f32 + ~3 per VALU instruction, additive at 2, 3 and 4 wavefronts per SIMD),
-            # so with V other VALU instructions per MFMA the issue fraction cannot exceed 32.5 / (32.5 + 3 V);
-            # V from profiles/r02_cnn_pmc.json (SQ_INSTS_VALU - SQ_INSTS_MFMA) / SQ_INSTS_MFMA
-            v_per_mfma = {"gnf_mnistcnn_conv_bwd": 4.30, "gnf_mnistcnn_conv_fwd": 3.77}[dom]
-            out["roofline"]["valu_per_mfma"] = v_per_mfma
+            # so with V other VALU instructions per MFMA the issue fraction cannot exceed 32.5 / (32.5 + 3 V)
+            v_per_mfma = pmc[dom]["valu_per_mfma"]
+            out["roofline"]["valu_per_mfma"] = round(v_per_mfma, 3)
             out["roofline"]["issue_frac_ceiling_shared_alu"] = round(32.5 / (32.5 + 3. * v_per_mfma), 3)
         out["secondary"] = {"fwd_bwd_only_samples_per_s": round(B_PER_GPU * world / t_fb, 1) if t_fb else None,
                             "full_step_S_mix_20_29_samples_per_s": round(B_PER_GPU * world / t_mix, 1) if t_mix else None,
@@ -357,7 +382,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if collective:
         dist.destroy_process_group()
 
 

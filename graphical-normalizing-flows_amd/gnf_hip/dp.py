@@ -7,6 +7,8 @@ ONE collective -- an all-reduce(sum) of the flat gradient buffer over RCCL/xGMI 
 by one fused Adam launch.  The DAG acyclicity term depends on parameters only: every rank
 computes it redundantly, so after averaging it is counted once, like the reference where it is
 added once on GPU 0."""
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -65,7 +67,7 @@ class FlatState:
                 p.grad = None
 
     def broadcast(self, src=0):
-        if dist.is_initialized() and dist.get_world_size() > 1:
+        if collective_on():
             if dist.get_backend() == "gloo" and self.flat.is_cuda:
                 h = self.flat.cpu()
                 dist.broadcast(h, src)
@@ -127,15 +129,47 @@ def seed_gates(flow, rank):
             c.gate_seed = gate_seed(rank, k)
 
 
+def collective_on():
+    """the gradient all-reduce runs when there is more than one rank -- or when GNF_FORCE_DIST=1 asks for it at world
+    size 1, so that the RCCL branch (process group on the device, in-place device all-reduce, device all-gather of the
+    replica checksums, barrier) can be executed and timed on a box with ONE GPU"""
+    if not dist.is_initialized():
+        return False
+    return dist.get_world_size() > 1 or os.environ.get("GNF_FORCE_DIST") == "1"
+
+
+comm_events = None      # [(start, end)] HIP events around the step's all-reduce while bench.py has profiling on
+
+
+def comm_profile(enable):
+    """start / stop recording the all-reduce time; stop returns the mean milliseconds per call (None without calls)"""
+    global comm_events
+    if enable:
+        comm_events = []
+        return None
+    evs, comm_events = comm_events, None
+    if not evs:
+        return None
+    torch.cuda.synchronize()
+    return sum(a.elapsed_time(b) for a, b in evs) / len(evs)
+
+
 def all_reduce_sum(t):
     """the step's collective: RCCL all-reduce in place; under the gloo backend (CPU transport, used only to exercise
     the N>1 path on boxes with one GPU) the buffer is staged through host memory."""
+    ev = None
+    if comm_events is not None and t.is_cuda:
+        ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+        ev[0].record()
     if dist.get_backend() == "gloo" and t.is_cuda:
         h = t.cpu()
         dist.all_reduce(h)
         t.copy_(h)
     else:
         dist.all_reduce(t)
+    if ev is not None:
+        ev[1].record()
+        comm_events.append(ev)
 
 
 def replicas_identical(state, module=None):
@@ -146,7 +180,7 @@ def replicas_identical(state, module=None):
         for b in module.buffers():
             if b.dtype == torch.float32 and b.numel():
                 bits = bits + b.detach().contiguous().view(torch.int32).to(torch.int64).sum().to(bits.device) * 31
-    if not (dist.is_initialized() and dist.get_world_size() > 1):
+    if not collective_on():
         return True
     mine = bits.reshape(1)
     if dist.get_backend() == "gloo":
@@ -168,8 +202,8 @@ def train_step(flow, state, x_shard, lr=1e-3, weight_decay=1e-5, optimizer=hip_a
     replayed as a hipGraph (GraphedStep: cfg1 0.68 -> 0.16 ms, cfg3 0.72 -> 0.27 ms per step); graph=False forces the
     launch-by-launch path.  The returned loss tensor of a replayed step is reused by the next replay."""
     world = dist.get_world_size() if dist.is_initialized() else 1
-    if (graph and world == 1 and optimizer is hip_adam and x_shard.is_cuda and x_shard.numel() <= GRAPH_MAX_ELEMS
-            and torch.is_grad_enabled() and GraphedStep.graphable(flow)):
+    if (graph and world == 1 and not collective_on() and optimizer is hip_adam and x_shard.is_cuda
+            and x_shard.numel() <= GRAPH_MAX_ELEMS and torch.is_grad_enabled() and GraphedStep.graphable(flow)):
         gs = getattr(state, "_graphed", None)
         if gs is None or gs.flow is not flow or (gs.lr, gs.weight_decay) != (lr, weight_decay):
             state._graphed = gs = GraphedStep(flow, state, x_shard, lr=lr, weight_decay=weight_decay, warmup=1)
@@ -196,7 +230,7 @@ def apply_step(state, lr=1e-3, weight_decay=1e-5, optimizer=hip_adam):
     """the accumulated gradients into the flat buffer, ONE all-reduce, Adam"""
     world = dist.get_world_size() if dist.is_initialized() else 1
     state.pack_grads()
-    if world > 1:
+    if collective_on():
         all_reduce_sum(state.grad)                  # the step's only collective
     state.t += 1
     optimizer(state, lr, weight_decay, 1. / world)

@@ -126,9 +126,8 @@ def test_cfg5_full_size_monotonic_step():
     S=20.  Properties: finite loss and gradients, loss decomposition, jac > 0.05, z(0) = h0-free check by shifting x
     (strictly increasing in each coordinate given h), and agreement with the CPU oracle on a 64-row slice of the SAME
     batch (rows are independent: the slice of a full-size launch must equal the oracle's small run)."""
-    sys.path.insert(0, os.path.join(ROOT, "tools"))
-    import bench_configs as bc
-    flow, x = bc.cfg("cfg5")
+    from gnf_hip.configs import baseline_config
+    flow, x = baseline_config("cfg5")
     assert x.shape == (50000, 63)
     for nrm in flow.getNormalizers():
         nrm.nb_steps = 20
@@ -287,6 +286,31 @@ def test_bench_two_ranks_product_flow():
     assert out["replicas_identical"] is True and out["dist_backend"] == "gloo"
     assert out["value"] > 0 and out["steps"] == 3 and out["scaling"] == "weak"
     assert abs(out["value"] - 200 * 3 / (out["ms_per_step"] * 3e-3)) < 1e-6 * out["value"]
+    # communication time of the step's one collective and the per-rank step times travel in the line
+    assert out["allreduce_ms_per_step"] is not None and out["allreduce_ms_per_step"] > 0
+    assert len(out["ms_per_step_per_rank"]) == 2 and max(out["ms_per_step_per_rank"]) <= out["ms_per_step"] * 1.0001
+
+
+def test_bench_rccl_branch_at_world_size_one():
+    """The RCCL code path itself on the ONE GPU of this box (GNF_FORCE_DIST=1): init_process_group("nccl", device_id=...)
+    with world size 1, the in-place device all-reduce of the flat gradient buffer inside every step, the device
+    all-gather of the replica checksums and of the per-rank step times, dist.barrier() -- in a child process started
+    before anything touches the GPU (the reference's nn.DataParallel call site is ImageExperiments.py:168)."""
+    import json
+    import subprocess
+    env = dict(os.environ, GNF_FORCE_DIST="1")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "GNF_DIST_BACKEND"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1", "--no-secondary",
+                        "--no-cpu-baseline"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 1 and out["dist_backend"] == "nccl" and out["collective_forced_at_world_1"] is True
+    assert out["replicas_identical"] is True
+    assert out["allreduce_ms_per_step"] is not None and 0 < out["allreduce_ms_per_step"] < 50
+    assert len(out["ms_per_step_per_rank"]) == 1
 
 
 def test_train_uci_two_ranks_dual_updates_stay_in_lockstep(tmp_path):

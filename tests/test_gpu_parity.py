@@ -883,10 +883,8 @@ def test_baseline_configs_train_step(name, B):
     """every BASELINE.json configuration (cfg4 is the bench itself; cfg5 at a reduced batch to bound the test time):
     a full fwd + log|det J| + NLL + bwd step runs, the loss is finite, every parameter gets a finite gradient,
     and the log-likelihood decomposition loss = constraints - mean(logdet + logN(z)) holds."""
-    import sys
-    sys.path.insert(0, str(__import__("pathlib").Path(__file__).resolve().parents[1] / "tools"))
-    import bench_configs as bc
-    flow, x = bc.cfg(name)
+    from gnf_hip.configs import baseline_config
+    flow, x = baseline_config(name)
     x = x[:B]
     for nrm in flow.getNormalizers():
         if hasattr(nrm, "nb_steps"):

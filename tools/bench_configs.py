@@ -7,63 +7,16 @@ import time
 
 import torch
 
-sys.path[:0] = ['/root/repo', '/root/repo/graphical-normalizing-flows_amd']
+import os
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, ROOT + '/graphical-normalizing-flows_amd']
 from gnf_hip import abi  # noqa: E402
-from models import (buildFCNormalizingFlow, CouplingConditioner, AutoregressiveConditioner, DAGConditioner,  # noqa: E402
-                    AffineNormalizer, MonotonicNormalizer)
-from models.NormalizingFlowFactories import buildMNISTNormalizingFlow  # noqa: E402
-import bench  # noqa: E402
+from models import MonotonicNormalizer  # noqa: E402
 
 DEV = "cuda:0"
 
 
-def cfg(name):
-    g = torch.Generator().manual_seed(1234)
-    torch.manual_seed(0)
-    if name == "cfg1":      # toy 8gaussians (lib/toy_data.py:81-98 restated), Affine+Coupling
-        B = 512
-        ang = torch.randint(0, 8, (B,), generator=g).float() * (3.141592653589793 / 4)
-        x = (torch.stack((torch.cos(ang), torch.sin(ang)), 1) * 4 + torch.randn(B, 2, generator=g) * .5) / 1.414
-        f = buildFCNormalizingFlow(1, CouplingConditioner, {"in_size": 2, "hidden": [150, 150], "out_size": 150},
-                                   AffineNormalizer, {})
-    elif name == "cfg2":    # POWER d=6 Monotonic+DAG (UCIExperimentsConfigurations.yml:1-14, UCI:83-93)
-        x = torch.randn(10000, 6, generator=g)
-        f = buildFCNormalizingFlow(1, DAGConditioner, {"in_size": 6, "hidden": [60, 60, 60], "out_size": 30, "l1": 0.,
-                                                       "gumble_T": .5, "nb_epoch_update": 30, "hot_encoding": True},
-                                   MonotonicNormalizer, {"integrand_net": [100, 100, 100], "cond_size": 30,
-                                                         "nb_steps": 20, "solver": "CC"})
-    elif name == "cfg3":    # MNIST d=784 Affine+Autoregressive 1024^3
-        x = bench.pseudo_mnist(g, 100, 784)
-        f = buildFCNormalizingFlow(1, AutoregressiveConditioner, {"in_size": 784, "hidden": [1024] * 3, "out_size": 2},
-                                   AffineNormalizer, {})
-    elif name == "cfg4":
-        x = bench.pseudo_mnist(g, 100, 784)
-        f = bench.build_flow()
-    elif name == "cfg4det":  # cfg4 after the DAG phase: post_process() froze a binary A, the gate is deterministic
-        x = bench.pseudo_mnist(g, 100, 784)
-        f = bench.build_flow()
-        for c in f.getConditioners():
-            with torch.no_grad():
-                c.post_process(zero_threshold=.1)
-    elif name == "cfg4dag":  # the state update_dual_param() ends in: an acyclic binary A (window parents that precede the
-        x = bench.pseudo_mnist(g, 100, 784)          # pixel in raster order), post-processed, dag_const = l1 = 0
-        f = bench.build_flow()
-        for c in f.getConditioners():
-            with torch.no_grad():
-                idx = torch.arange(784)
-                c.A.mul_((idx[None, :] < idx[:, None]).float())
-                c.post_process(zero_threshold=.1)
-                c.dag_const = torch.tensor(0.)
-                c.l1_weight = torch.tensor(0.)
-                c.is_invertible = True
-    elif name == "cfg5":    # BSDS300 d=63 synthetic (yml:347-358), B=50000
-        x = torch.randn(50000, 63, generator=g)
-        f = buildFCNormalizingFlow(1, AutoregressiveConditioner, {"in_size": 63, "hidden": [630] * 3, "out_size": 30},
-                                   MonotonicNormalizer, {"integrand_net": [150, 150, 150], "cond_size": 30,
-                                                         "nb_steps": 20, "solver": "CCParallel"})
-    else:
-        raise KeyError(name)
-    return f.to(DEV), x.to(DEV)
+from gnf_hip.configs import baseline_config as cfg  # noqa: E402  (the builders live in the package)
 
 
 def main():

@@ -2,7 +2,9 @@
 window pixels preceding a pixel in raster order (109 levels), sparse vs dense embedding front.
 Usage: python tools/bench_sampling.py"""
 import sys, time, torch
-sys.path[:0] = ['/root/repo', '/root/repo/graphical-normalizing-flows_amd']
+import os
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, ROOT + '/graphical-normalizing-flows_amd']
 import bench
 import os
 if os.environ.get('GNF_AB_LIB'):                      # A/B against another build of the library (tools/*.bin)

@@ -7,7 +7,9 @@ import sys
 
 import torch
 
-sys.path[:0] = ['/root/repo', '/root/repo/graphical-normalizing-flows_amd']
+import os
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, ROOT + '/graphical-normalizing-flows_amd']
 from gnf_hip import abi  # noqa: E402
 from models import DAGConditioner  # noqa: E402
 from models.MLP import MNISTCNN  # noqa: E402

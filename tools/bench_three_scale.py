@@ -2,7 +2,9 @@
 kernel-2 priors, B = 100) with the Affine and the Monotonic normalizer.
 Usage: python tools/bench_three_scale.py"""
 import sys, time, torch
-sys.path[:0] = ['/root/repo', '/root/repo/graphical-normalizing-flows_amd']
+import os
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, ROOT + '/graphical-normalizing-flows_amd']
 import bench
 from models import MonotonicNormalizer, AffineNormalizer
 from models.NormalizingFlowFactories import buildMNISTNormalizingFlow

@@ -1,5 +1,7 @@
 import sys, torch
-sys.path[:0] = ['/root/repo', '/root/repo/graphical-normalizing-flows_amd']
+import os
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, ROOT + '/graphical-normalizing-flows_amd']
 import torch.nn.functional as F
 from gnf_hip import ops
 torch.manual_seed(700)

@@ -1,5 +1,6 @@
 import sys, torch
-sys.path[:0]=['/root/repo','/root/repo/graphical-normalizing-flows_amd','/root/repo/tests']
+R=__import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__)))
+sys.path[:0]=[R,R+'/graphical-normalizing-flows_amd',R+'/tests']
 import torch.nn.functional as F
 from gnf_hip import ops, abi
 from test_gpu_parity import _windowed_conditioner

@@ -1,6 +1,8 @@
 """How long does the HOST take to enqueue one cfg4 training step (Python + ctypes + torch autograd)?"""
 import sys, time, torch
-sys.path[:0] = ['/root/repo', '/root/repo/graphical-normalizing-flows_amd']
+import os
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, ROOT + '/graphical-normalizing-flows_amd']
 import bench
 from gnf_hip import dp
 flow = bench.build_flow().to("cuda:0")

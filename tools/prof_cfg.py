@@ -1,8 +1,10 @@
 import sys, torch
-sys.path[:0] = ['/root/repo', '/root/repo/graphical-normalizing-flows_amd', '/root/repo/tools']
-import bench_configs as bc
+import os
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, ROOT + '/graphical-normalizing-flows_amd']
+from gnf_hip.configs import baseline_config
 name = sys.argv[1]
-flow, x = bc.cfg(name)
+flow, x = baseline_config(name)
 for nrm in flow.getNormalizers():
     if hasattr(nrm, "nb_steps"): nrm.nb_steps = 20
 for _ in range(3):

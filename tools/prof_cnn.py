@@ -2,7 +2,9 @@
 normalizer (fwd+bwd) at the cfg4 size (78 400 masked images / elements)."""
 import sys
 import torch
-sys.path[:0] = ['/root/repo', '/root/repo/graphical-normalizing-flows_amd']
+import os
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, ROOT + '/graphical-normalizing-flows_amd']
 from gnf_hip import ops
 which = sys.argv[1] if len(sys.argv) > 1 else "cnn"
 iters = int(sys.argv[2]) if len(sys.argv) > 2 else 3

@@ -1,6 +1,8 @@
 """Micro-driver for rocprofv3: the three fc1 GEMM shapes of cfg4 through gnf_gemm."""
 import sys, torch
-sys.path[:0] = ['/root/repo', '/root/repo/graphical-normalizing-flows_amd']
+import os
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, ROOT + '/graphical-normalizing-flows_amd']
 from gnf_hip import ops
 dev = "cuda:0"
 torch.manual_seed(0)

@@ -1,7 +1,9 @@
 """Micro-driver for rocprofv3 --pmc: the HBM-bound kernels (fused affine fwd/bwd at 1e6 x 63, DAG gate fwd at cfg4)."""
 import sys
 import torch
-sys.path[:0] = ['/root/repo', '/root/repo/graphical-normalizing-flows_amd']
+import os
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, ROOT + '/graphical-normalizing-flows_amd']
 from gnf_hip import ops
 dev = "cuda:0"
 torch.manual_seed(0)

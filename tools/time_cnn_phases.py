@@ -1,7 +1,7 @@
 """Debug: per-phase cycle counts of cnn_bwd_wino_k (build with -DGNF_CNN_TIMING)."""
 import ctypes, subprocess, sys, os
 import torch
-ROOT = '/root/repo'
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, ROOT + '/graphical-normalizing-flows_amd']
 src = ROOT + '/graphical-normalizing-flows_amd/gnf_hip/csrc/'
 so = '/tmp/libgnf_timing.so'
