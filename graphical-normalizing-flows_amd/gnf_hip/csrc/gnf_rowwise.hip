@@ -50,8 +50,11 @@ constexpr float kLog2Pi = 1.8378770664093453f;     // log(2 pi): summed per elem
 // ------------------------------------------------------------------ Affine normalizer
 // R rows per lane group per pass: R independent load streams per lane hide the HBM latency at large B; when h is the
 // contiguous [B,d,2] layout its two components are one 8-byte load / store.
-template <int G, int R>
-__global__ void affine_fwd_k(const float* __restrict__ x, float* __restrict__ h, int64_t h_sb, int64_t h_sd,
+// (CLAMP: the reference's in-place clamp_ of h is a separate instantiation, so that the common one never stores to h and the
+// loads of the unrolled column loop can all be issued ahead of the arithmetic -- at B = 100, d = 784 the kernel is a chain of
+// d / G = 13 dependent load rounds otherwise)
+template <int G, int R, bool CLAMP>
+__device__ __forceinline__ void affine_fwd_body(const float* __restrict__ x, float* __restrict__ h, int64_t h_sb, int64_t h_sd,
                              int64_t h_sc, float* __restrict__ z, float* __restrict__ jac,
                              float* __restrict__ logdet, float* __restrict__ logn, int clamp_inplace, int64_t B,
                              int64_t d) {
@@ -61,6 +64,7 @@ __global__ void affine_fwd_k(const float* __restrict__ x, float* __restrict__ h,
   float ld[R], ln[R];
 #pragma unroll
   for (int k = 0; k < R; ++k) { ld[k] = 0.f; ln[k] = 0.f; }
+#pragma unroll 4
   for (int64_t i = g; i < d; i += G) {
     float h0[R], h1[R], xv[R];
 #pragma unroll
@@ -86,7 +90,7 @@ __global__ void affine_fwd_k(const float* __restrict__ x, float* __restrict__ h,
       const float zv = fmaf(xv[k], sg, mu);
       z[e] = zv;
       if (jac) jac[e] = sg;
-      if (clamp_inplace) { const int64_t hi = row * h_sb + i * h_sd; h[hi] = mu; h[hi + h_sc] = ls; }
+      if (CLAMP && clamp_inplace) { const int64_t hi = row * h_sb + i * h_sd; h[hi] = mu; h[hi + h_sc] = ls; }
       ld[k] += ls;
       ln[k] += kLog2Pi + zv * zv;
     }
@@ -103,6 +107,19 @@ __global__ void affine_fwd_k(const float* __restrict__ x, float* __restrict__ h,
 }
 
 template <int G, int R>
+__global__ void affine_fwd_plain_k(const float* __restrict__ x, float* __restrict__ h, int64_t h_sb, int64_t h_sd, int64_t h_sc,
+                                   float* __restrict__ z, float* __restrict__ jac, float* __restrict__ logdet,
+                                   float* __restrict__ logn, int clamp_inplace, int64_t B, int64_t d) {
+  affine_fwd_body<G, R, false>(x, h, h_sb, h_sd, h_sc, z, jac, logdet, logn, clamp_inplace, B, d);
+}
+template <int G, int R>
+__global__ void affine_fwd_clamp_k(const float* __restrict__ x, float* __restrict__ h, int64_t h_sb, int64_t h_sd, int64_t h_sc,
+                                   float* __restrict__ z, float* __restrict__ jac, float* __restrict__ logdet,
+                                   float* __restrict__ logn, int clamp_inplace, int64_t B, int64_t d) {
+  affine_fwd_body<G, R, true>(x, h, h_sb, h_sd, h_sc, z, jac, logdet, logn, clamp_inplace, B, d);
+}
+
+template <int G, int R>
 __global__ void affine_bwd_k(const float* __restrict__ x, const float* __restrict__ h, int64_t h_sb, int64_t h_sd,
                              int64_t h_sc, const float* __restrict__ gz, const float* __restrict__ gjac,
                              const float* __restrict__ glogdet, const float* __restrict__ glogn,
@@ -112,6 +129,7 @@ __global__ void affine_bwd_k(const float* __restrict__ x, const float* __restric
   const int g = threadIdx.x % G;
   const bool pair = (h_sc == 1 && h_sd == 2 && (h_sb & 1) == 0);
   const bool gpair = (g_sc == 1 && g_sd == 2 && (g_sb & 1) == 0);
+#pragma unroll 4
   for (int64_t i = g; i < d; i += G) {
     float h0[R], h1[R], xv[R], gzv[R], gjv[R];
 #pragma unroll
@@ -148,6 +166,62 @@ __global__ void affine_bwd_k(const float* __restrict__ x, const float* __restric
       else { gh[gi] = o0; gh[gi + g_sc] = o1; }
     }
   }
+}
+
+// ---- FEW LONG rows (the image configurations: B = 100, d = 784): the row-per-lane-group kernels above put four rows on a
+// workgroup, i.e. 25 workgroups walking 13 dependent column rounds each (9-11 us for 1.2 MB).  Here a row gets a whole
+// workgroup in the forward (4 column rounds; the two row sums meet in LDS) and the backward, which has no reduction, is one
+// thread per element.  Any strides of h / gh.
+__global__ __launch_bounds__(kBlock) void affine_fwd_rowblock_k(const float* __restrict__ x, const float* __restrict__ h,
+                                                                int64_t h_sb, int64_t h_sd, int64_t h_sc,
+                                                                float* __restrict__ z, float* __restrict__ jac,
+                                                                float* __restrict__ logdet, float* __restrict__ logn, int d) {
+  __shared__ float red[2][kBlock / 64];
+  const int row = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float sl = 0.f, sn = 0.f;
+#pragma unroll 4
+  for (int i = threadIdx.x; i < d; i += kBlock) {
+    const int64_t hi = row * h_sb + i * h_sd, e = (int64_t)row * d + i;
+    const float mu = clampf(h[hi], -5.f, 5.f), ls = clampf(h[hi + h_sc], -5.f, 2.f);
+    const float sg = expf(ls), zv = fmaf(x[e], sg, mu);
+    z[e] = zv;
+    if (jac) jac[e] = sg;
+    sl += ls;
+    sn += kLog2Pi + zv * zv;
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) { sl += __shfl_xor(sl, off, GNF_WAVE); sn += __shfl_xor(sn, off, GNF_WAVE); }
+  if (lane == 0) { red[0][wave] = sl; red[1][wave] = sn; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float a = 0.f, b = 0.f;
+#pragma unroll
+    for (int w = 0; w < kBlock / 64; ++w) { a += red[0][w]; b += red[1][w]; }
+    if (logdet) logdet[row] = a;
+    if (logn) logn[row] = -0.5f * b;
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void affine_bwd_elem_k(const float* __restrict__ x, const float* __restrict__ h, int64_t h_sb,
+                                                            int64_t h_sd, int64_t h_sc, const float* __restrict__ gz,
+                                                            const float* __restrict__ gjac, const float* __restrict__ glogdet,
+                                                            const float* __restrict__ glogn, float* __restrict__ gx,
+                                                            float* __restrict__ gh, int64_t g_sb, int64_t g_sd, int64_t g_sc,
+                                                            int n, int d) {
+  const int e = blockIdx.x * kBlock + threadIdx.x;
+  if (e >= n) return;
+  const int row = e / d, i = e - row * d;
+  const int64_t hi = row * h_sb + i * h_sd;
+  const float h0 = h[hi], h1 = h[hi + h_sc];
+  // torch clamp backward passes the gradient where min <= v <= max (boundaries included)
+  const float m0 = (h0 >= -5.f && h0 <= 5.f) ? 1.f : 0.f, m1 = (h1 >= -5.f && h1 <= 2.f) ? 1.f : 0.f;
+  const float sg = expf(clampf(h1, -5.f, 2.f)), xv = x[e];
+  const float gzv = gz ? gz[e] : 0.f, gjv = gjac ? gjac[e] : 0.f;
+  const float gze = glogn ? fmaf(-fmaf(xv, sg, clampf(h0, -5.f, 5.f)), glogn[row], gzv) : gzv;
+  if (gx) gx[e] = gze * sg;
+  const int64_t gi = row * g_sb + i * g_sd;
+  gh[gi] = gze * m0;
+  gh[gi + g_sc] = (fmaf(gze * xv, sg, gjv * sg) + (glogdet ? glogdet[row] : 0.f)) * m1;
 }
 
 // ---- "flat" variants for short rows (d <= 64) in the contiguous [B,d,2] layout, the shape of the tabular configurations
@@ -356,6 +430,7 @@ __global__ void nll_rows_k(const float* __restrict__ z, const float* __restrict_
   const int g = threadIdx.x % G;
   float sl = 0.f, sn = 0.f;
   if (row < B)
+#pragma unroll 4
     for (int64_t i = g; i < d; i += G) {
       if (jac) sl += logf(jac[row * d + i]);
       if (logn) { const float v = z[row * d + i]; sn += kLog2Pi + v * v; }
@@ -374,11 +449,49 @@ __global__ void nll_rows_bwd_k(const float* __restrict__ z, const float* __restr
   const int g = threadIdx.x % G;
   if (row >= B) return;
   const float gl = glogdet ? glogdet[row] : 0.f, gn = glogn ? glogn[row] : 0.f;
+#pragma unroll 4
   for (int64_t i = g; i < d; i += G) {
     const int64_t e = row * d + i;
     if (gz) gz[e] = fmaf(-z[e], gn, gz_in ? gz_in[e] : 0.f);
     if (gjac) gjac[e] = gl / jac[e];
   }
+}
+
+// Few long rows (B = 100, d = 784): a workgroup per row in the forward, a thread per element in the backward (see the Affine
+// kernels of the same names)
+__global__ __launch_bounds__(kBlock) void nll_rows_rowblock_k(const float* __restrict__ z, const float* __restrict__ jac,
+                                                              float* __restrict__ logdet, float* __restrict__ logn, int d) {
+  __shared__ float red[2][kBlock / 64];
+  const int row = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float sl = 0.f, sn = 0.f;
+#pragma unroll 4
+  for (int i = threadIdx.x; i < d; i += kBlock) {
+    const int64_t e = (int64_t)row * d + i;
+    if (jac) sl += logf(jac[e]);
+    if (logn) { const float v = z[e]; sn += kLog2Pi + v * v; }
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) { sl += __shfl_xor(sl, off, GNF_WAVE); sn += __shfl_xor(sn, off, GNF_WAVE); }
+  if (lane == 0) { red[0][wave] = sl; red[1][wave] = sn; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float a = 0.f, b = 0.f;
+#pragma unroll
+    for (int w = 0; w < kBlock / 64; ++w) { a += red[0][w]; b += red[1][w]; }
+    if (jac) logdet[row] = a;
+    if (logn) logn[row] = -0.5f * b;
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void nll_rows_bwd_elem_k(const float* __restrict__ z, const float* __restrict__ jac,
+                                                              const float* __restrict__ glogdet, const float* __restrict__ glogn,
+                                                              const float* __restrict__ gz_in, float* __restrict__ gz,
+                                                              float* __restrict__ gjac, int n, int d) {
+  const int e = blockIdx.x * kBlock + threadIdx.x;
+  if (e >= n) return;
+  const int row = e / d;
+  if (gz) gz[e] = fmaf(-z[e], glogn ? glogn[row] : 0.f, gz_in ? gz_in[e] : 0.f);
+  if (gjac) gjac[e] = (glogdet ? glogdet[row] : 0.f) / jac[e];
 }
 
 // Short rows (d <= 64, contiguous, 16-B aligned): the span-per-wavefront scheme of the flat Affine kernels -- one float4 of
@@ -715,7 +828,9 @@ inline int rows_flat_rw(int64_t B, int64_t d, uintptr_t ptr_bits) {
 
 int nll_rows_launch(const float* z, const float* jac, float* logdet, float* logn, int64_t B, int64_t d, hipStream_t s) {
   void* stream = (void*)s;
-  if (d <= 64 && B * d >= (1 << 16)) {                 // short rows: a row per 16-lane group
+  if (d >= 256 && B <= 4096) {                          // few long rows: a workgroup per row
+    hipLaunchKernelGGL(nll_rows_rowblock_k, dim3((unsigned)B), dim3(kBlock), 0, s, z, jac, logdet, logn, (int)d);
+  } else if (d <= 64 && B * d >= (1 << 16)) {          // short rows: a row per 16-lane group
     constexpr int U = 4;
     const int64_t per_block = (int64_t)(kBlock / 64) * 4 * U;
     int64_t grid = (B + per_block - 1) / per_block;
@@ -740,7 +855,11 @@ int nll_rows_launch(const float* z, const float* jac, float* logdet, float* logn
 int nll_rows_bwd_launch(const float* z, const float* jac, const float* glogdet, const float* glogn, const float* gz_in,
                         float* gz, float* gjac, int64_t B, int64_t d, hipStream_t s) {
   void* stream = (void*)s;
-  if (const int rw = rows_flat_rw(B, d, (uintptr_t)z | (uintptr_t)jac | (uintptr_t)gz_in | (uintptr_t)gz | (uintptr_t)gjac)) {
+  if (d >= 256 && B * d <= (1 << 22)) {                 // few long rows: a thread per element
+    const int n = (int)(B * d);
+    hipLaunchKernelGGL(nll_rows_bwd_elem_k, dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, s, z, jac, glogdet, glogn,
+                       gz_in, gz, gjac, n, (int)d);
+  } else if (const int rw = rows_flat_rw(B, d, (uintptr_t)z | (uintptr_t)jac | (uintptr_t)gz_in | (uintptr_t)gz | (uintptr_t)gjac)) {
     constexpr int U = 2;
     const int64_t nspan = (B + rw - 1) / rw;
     int64_t grid = (nspan + U * (kBlock / 64) - 1) / (U * (kBlock / 64));
@@ -922,8 +1041,19 @@ int gnf_affine_fwd(const float* x, float* h, int64_t h_sb, int64_t h_sd, int64_t
       return 0;
     }
   }
-  if (B * d >= (1 << 20)) GNF_DISPATCH_GR(G, 4, affine_fwd_k, B, x, h, h_sb, h_sd, h_sc, z, jac, logdet, logn, clamp_inplace, B, d);
-  else GNF_DISPATCH_GR(G, 1, affine_fwd_k, B, x, h, h_sb, h_sd, h_sc, z, jac, logdet, logn, clamp_inplace, B, d);
+  if (!clamp_inplace && d >= 256 && B <= 4096) {         // few long rows: a workgroup per row
+    hipLaunchKernelGGL(affine_fwd_rowblock_k, dim3((unsigned)B), dim3(kBlock), 0, (hipStream_t)stream, x, h, h_sb, h_sd, h_sc,
+                       z, jac, logdet, logn, (int)d);
+    GNF_LAUNCH_CHECK();
+    return 0;
+  }
+  if (clamp_inplace) {
+    if (B * d >= (1 << 20)) GNF_DISPATCH_GR(G, 4, affine_fwd_clamp_k, B, x, h, h_sb, h_sd, h_sc, z, jac, logdet, logn, clamp_inplace, B, d);
+    else GNF_DISPATCH_GR(G, 1, affine_fwd_clamp_k, B, x, h, h_sb, h_sd, h_sc, z, jac, logdet, logn, clamp_inplace, B, d);
+  } else {
+    if (B * d >= (1 << 20)) GNF_DISPATCH_GR(G, 4, affine_fwd_plain_k, B, x, h, h_sb, h_sd, h_sc, z, jac, logdet, logn, clamp_inplace, B, d);
+    else GNF_DISPATCH_GR(G, 1, affine_fwd_plain_k, B, x, h, h_sb, h_sd, h_sc, z, jac, logdet, logn, clamp_inplace, B, d);
+  }
   GNF_LAUNCH_CHECK();
   return 0;
 }
@@ -957,6 +1087,13 @@ int gnf_affine_bwd(const float* x, const float* h, int64_t h_sb, int64_t h_sd, i
       GNF_LAUNCH_CHECK();
       return 0;
     }
+  }
+  if (d >= 256 && B * d <= (1 << 22)) {                  // few long rows: a thread per element
+    const int n = (int)(B * d);
+    hipLaunchKernelGGL(affine_bwd_elem_k, dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, (hipStream_t)stream, x, h,
+                       h_sb, h_sd, h_sc, gz, gjac, glogdet, glogn, gx, gh, g_sb, g_sd, g_sc, n, (int)d);
+    GNF_LAUNCH_CHECK();
+    return 0;
   }
   if (B * d >= (1 << 20)) GNF_DISPATCH_GR(G, 4, affine_bwd_k, B, x, h, h_sb, h_sd, h_sc, gz, gjac, glogdet, glogn, gx, gh, g_sb, g_sd, g_sc, B, d);
   else GNF_DISPATCH_GR(G, 1, affine_bwd_k, B, x, h, h_sb, h_sd, h_sc, gz, gjac, glogdet, glogn, gx, gh, g_sb, g_sd, g_sc, B, d);

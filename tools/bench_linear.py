@@ -15,7 +15,8 @@ W = (torch.randn(N, K, device=dev) / K ** .5).requires_grad_(True)
 b = torch.zeros(N, device=dev, requires_grad=True)
 W2 = (torch.randn(N, N, device=dev) / N ** .5).requires_grad_(True)
 b2 = torch.zeros(N, device=dev, requires_grad=True)
-do, di = torch.randint(0, 784, (N,), device=dev).float(), torch.randint(0, 784, (K,), device=dev).float()
+# MADE's natural-ordering degrees (AutoregressiveConditioner.py:85-87): hidden unit k has degree 783 - (k mod 784)
+do, di = (783 - torch.arange(N, device=dev) % 784).float(), (783 - torch.arange(K, device=dev) % 784).float()
 mask = (di[None, :] <= do[:, None]).float()
 mask2 = (do[None, :] <= do[:, None]).float()
 names = ("gnf_linear_fwd", "gnf_linear_bwd_x", "gnf_linear_bwd_w")
