@@ -875,6 +875,35 @@ int nll_rows_bwd_launch(const float* z, const float* jac, const float* glogdet, 
   return 0;
 }
 
+// ------------------------------------------------------------------ batch mean of the log-likelihood
+// out = -mean_b(logdet[b] + logn[b]): the data term of FCNormalizingFlow.loss (models/NormalizingFlow.py:144-146) in one
+// launch (torch: add, mean, neg + their backward = 8 launches of a step that has ~40).  One workgroup, fixed summation
+// order: per-thread strided partials, butterfly per wavefront, the 16 wavefront sums in order.
+__global__ __launch_bounds__(1024) void nll_mean_k(const float* __restrict__ logdet, const float* __restrict__ logn,
+                                                   float* __restrict__ out, int64_t B) {
+  __shared__ float red[16];
+  float s = 0.f;
+  for (int64_t b = threadIdx.x; b < B; b += 1024) s += logdet[b] + logn[b];
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, GNF_WAVE);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float t = 0.f;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) t += red[w];
+    out[0] = -t / (float)B;
+  }
+}
+// both cotangents of the above: glogdet[b] = glogn[b] = -g / B (g: device scalar)
+__global__ void nll_mean_bwd_k(const float* __restrict__ g, float* __restrict__ glogdet, float* __restrict__ glogn, int64_t B) {
+  const float v = -g[0] / (float)B;
+  for (int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; b < B; b += (int64_t)gridDim.x * blockDim.x) {
+    glogdet[b] = v;
+    glogn[b] = v;
+  }
+}
+
 // ------------------------------------------------------------------ column sums
 // stage 1: block (bx, by) sums rows [by*R, by*R+R) of column tile bx into ws[by][n];
 // stage 2: sums the gridDim.y partials.  Fixed order -> bit-reproducible.
@@ -1154,6 +1183,22 @@ int gnf_nll_reduce_bwd(const float* z, const float* jac, const float* glogdet, c
   if (B == 0) return 0;
   if (!z || !jac || !gz || !gjac) return GNF_EINVAL;
   return nll_rows_bwd_launch(z, jac, glogdet, glogn, gz_in, gz, gjac, B, d, (hipStream_t)stream);
+}
+
+int gnf_nll_mean_fwd(const float* logdet, const float* logn, float* out, int64_t B, gnf_stream_t stream) {
+  if (B <= 0 || !logdet || !logn || !out) return GNF_EINVAL;
+  hipLaunchKernelGGL(nll_mean_k, dim3(1), dim3(1024), 0, (hipStream_t)stream, logdet, logn, out, B);
+  GNF_LAUNCH_CHECK();
+  return 0;
+}
+
+int gnf_nll_mean_bwd(const float* g, float* glogdet, float* glogn, int64_t B, gnf_stream_t stream) {
+  if (B <= 0 || !g || !glogdet || !glogn) return GNF_EINVAL;
+  int64_t grid = (B + kBlock - 1) / kBlock;
+  if (grid > 1024) grid = 1024;
+  hipLaunchKernelGGL(nll_mean_bwd_k, dim3((unsigned)grid), dim3(kBlock), 0, (hipStream_t)stream, g, glogdet, glogn, B);
+  GNF_LAUNCH_CHECK();
+  return 0;
 }
 
 int64_t gnf_colsum_ws_bytes(int64_t M, int64_t N) {

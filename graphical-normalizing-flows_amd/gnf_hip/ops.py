@@ -139,6 +139,26 @@ class NllReduceFn(torch.autograd.Function):
         return gz, gjac
 
 
+class NllMeanFn(torch.autograd.Function):
+    """-(logdet + logn).mean(): the data term of FCNormalizingFlow.loss (models/NormalizingFlow.py:144-146) and both of its
+    cotangents in one launch each."""
+
+    @staticmethod
+    def forward(ctx, logdet, logn):
+        logdet, logn = logdet.contiguous(), logn.contiguous()
+        out = _empty((), logdet)
+        call("gnf_nll_mean_fwd", ptr(logdet), ptr(logn), ptr(out), logdet.shape[0], stream())
+        ctx.B = logdet.shape[0]
+        ctx.like = logdet
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        gl, gn = _empty((ctx.B,), ctx.like), _empty((ctx.B,), ctx.like)
+        call("gnf_nll_mean_bwd", ptr(g.contiguous()), ptr(gl), ptr(gn), ctx.B, stream())
+        return gl, gn
+
+
 def stash_logn(z, logn):
     """remember the Normal log-density that was reduced in the pass producing z; NormalLogDensity picks it up when it is
     handed the very same tensor (flow.loss(z, logdet) right after flow(x)) instead of reading z again"""

@@ -139,7 +139,13 @@ class FCNormalizingFlow(NormalizingFlow):
         return z, logdet                         # the last step's z is returned un-flipped (:126)
 
     def loss(self, z, jac):
-        return self.constraintsLoss() - (jac + self.z_log_density(z)).mean()
+        logn = self.z_log_density(z)
+        if (jac.is_cuda and jac.dim() == 1 and logn.shape == jac.shape and jac.shape[0] > 0
+                and jac.dtype == torch.float32 and logn.dtype == torch.float32):
+            nll = ops.NllMeanFn.apply(jac, logn)                                 # -(jac + logn).mean(), one launch
+            c = self.constraintsLoss()
+            return nll if (isinstance(c, float) and c == 0.) else c + nll
+        return self.constraintsLoss() - (jac + logn).mean()
 
     def invert(self, z, context=None):
         """Exact inverse of forward for any number of steps.  The reference (:166-169) visits steps[-0] == steps[0]
