@@ -92,6 +92,24 @@ def main():
         C = torch.empty(M, N, device=DEV)
         mfma("gemm " + what, [M, N, K], timeit(lambda: ops.gemm(Am, (K, 1), Bm, (1, K), C, (N, 1), M, N, K)),
              2. * M * N * K)
+    # ---- small-batch masked Linear (cfg3's MADE hidden layer, mask as degree vectors): weights streamed once (4 N K bytes)
+    M, N, K = 100, 1024, 1024
+    xl = torch.randn(M, K, device=DEV, requires_grad=True)
+    Wl, bl = (torch.randn(N, K, device=DEV) / 32).requires_grad_(True), torch.zeros(N, device=DEV, requires_grad=True)
+    W2l, b2l = (torch.randn(N, N, device=DEV) / 32).requires_grad_(True), torch.zeros(N, device=DEV, requires_grad=True)
+    dg = (783 - torch.arange(N, device=DEV) % 784).float()
+    mk = (dg[None, :] <= dg[:, None]).float()
+
+    def lin_step():
+        for t in (xl, Wl, bl, W2l, b2l):
+            t.grad = None
+        ops.mlp(xl, [(Wl, bl), (W2l, b2l)], [mk, mk], degs=[(dg, dg, False), (dg, dg, False)]).sum().backward()
+    for entry in ("gnf_linear_fwd", "gnf_linear_bwd_x", "gnf_linear_bwd_w"):
+        ms = time_entry(entry, lin_step)
+        rows.append({"kernel": entry + " (MADE mask as degrees)", "shape": [M, N, K], "ms": round(ms, 4), "bound": "hbm (weights once)",
+                     "achieved_GBps": round(4. * N * K / ms / 1e6, 1), "frac_of_8TBps": round(4. * N * K / ms / 1e6 / HBM_PEAK, 3),
+                     "achieved_TFLOPs": round(2. * M * N * K / ms / 1e9, 1),
+                     "note": "HIP events around ONE launch on an idle stream: includes ~3 us of dispatch; rocprofv3 kernel durations in profiles/r03_linear_kernels.txt"})
     # ---- Monotonic quadrature, forward: 2*M*(S+2) flop per element
     for (B, d, c, hid, tag) in [(100, 784, 30, [50, 50, 50], "cfg4"), (10000, 6, 30, [100, 100, 100], "cfg2"),
                                 (50000, 63, 30, [150, 150, 150], "cfg5")]:
@@ -101,13 +119,13 @@ def main():
         dims = [1 + c] + hid + [1]
         macs = sum(a * b for a, b in zip(dims[:-1], dims[1:]))
         with torch.no_grad():
-            mfma("monotonic_fwd " + tag, [B, d, hid[0]], timeit(lambda: norm(x, h), n=10), 2. * macs * (S + 2) * B * d)
+            mfma("monotonic_fwd " + tag, [B, d, hid[0]], time_entry("gnf_monotonic_fwd", lambda: norm(x, h), n=10), 2. * macs * (S + 2) * B * d)
         xg, hg = x.clone().requires_grad_(True), h.clone().requires_grad_(True)
         z, jac = norm(xg, hg)
         gz = torch.randn_like(z)
         ps = list(norm.parameters())
         mfma("monotonic_bwd " + tag, [B, d, hid[0]],
-             timeit(lambda: torch.autograd.grad((z, jac), [xg, hg] + ps, (gz, gz), retain_graph=True), n=5, warm=1),
+             time_entry("gnf_monotonic_bwd", lambda: torch.autograd.grad((z, jac), [xg, hg] + ps, (gz, gz), retain_graph=True), n=5, warm=1),
              4. * macs * (S + 2) * B * d)
     # ---- MNISTCNN conv front at cfg4 (78 400 images)
     n = 78400
@@ -115,13 +133,13 @@ def main():
     W1, b1 = torch.randn(16, 1, 3, 3, device=DEV, requires_grad=True), torch.randn(16, device=DEV, requires_grad=True)
     W2, b2 = torch.randn(16, 16, 3, 3, device=DEV, requires_grad=True), torch.randn(16, device=DEV, requires_grad=True)
     with torch.no_grad():
-        mfma("mnistcnn_conv_fwd", [n, 784], timeit(lambda: ops.MnistConvFn.apply(e, W1, b1, W2, b2), n=10),
+        mfma("mnistcnn_conv_fwd", [n, 784], time_entry("gnf_mnistcnn_conv_fwd", lambda: ops.MnistConvFn.apply(e, W1, b1, W2, b2), n=10),
              2. * (97344 + 1327104) * n)
     out = ops.MnistConvFn.apply(e, W1, b1, W2, b2)
     gp = torch.randn_like(out)
     # dW2 + da1 (2 x conv2 MACs) + conv1 recompute + dW1 + de (3 x conv1 MACs)
     mfma("mnistcnn_conv_bwd", [n, 784],
-         timeit(lambda: torch.autograd.grad(out, (e, W1, b1, W2, b2), gp, retain_graph=True), n=10),
+         time_entry("gnf_mnistcnn_conv_bwd", lambda: torch.autograd.grad(out, (e, W1, b1, W2, b2), gp, retain_graph=True), n=10),
          2. * (2 * 1327104 + 3 * 97344) * n)
     for r in rows:
         print(json.dumps(r))
