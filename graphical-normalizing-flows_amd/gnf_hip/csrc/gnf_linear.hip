@@ -54,46 +54,60 @@ __device__ __forceinline__ float deg_keep(float dc, float dr, int strict) { retu
 constexpr int MK_NONE = 0, MK_FULL = 1, MK_DEG = 2;
 
 // ------------------------------------------------------------------------------------------------------------- forward
-// Workgroup (nt, mt): y[16 mt .., 16 nt ..] over the whole K; wavefront w of NW contracts the 16-wide chunks [c0, c1) of
-// its share.  CB chunks are requested in one round (x, W and mask/degree fragments: 3 CB dwordx4 per lane in flight) --
-// with K / (16 NW) <= CB the whole kernel is ONE memory latency plus 4 CB MFMAs per wavefront.
-template <int NW, int MK, int CB>
+// Workgroup (nt, mp): y[16 TM mp .. +16 TM, 16 nt .. +16] over the whole K -- TM batch tiles per workgroup, so that a
+// weight fragment feeds TM MFMAs and the weight stream through the CU's L1 return path (what bounds these kernels:
+// 64 B/clk, every workgroup pulls its own operand slabs from L2) shrinks by TM.  A 16-wavefront workgroup is alone on its
+// CU: TM is chosen so that the grid is one round of the 256 CUs.  Wavefront w of NW contracts the 16-wide chunks [c0, c1)
+// of its share; CB chunks are requested in one round -- with K / (16 NW) <= CB the whole kernel is ONE memory latency plus
+// 8 CB MFMAs per wavefront.
+// Degree masks: the 16 deg_in values of a chunk are wave-uniform -> SCALAR loads (s_load_dwordx16 through the constant
+// cache, no vector-memory traffic at all; as a dwordx4 per lane this stream cost as much as the weights), the lane's four
+// (slot q) picked with three selects each.
+template <int NW, int MK, int CB, int TM>
 __global__ __launch_bounds__(64 * NW) void lin_fwd_skinny_k(const float* __restrict__ x, const float* __restrict__ W, LinMask mk,
                                                             const float* __restrict__ bias, int relu, float* __restrict__ y,
                                                             int M, int N, int K) {
-  __shared__ f32x4 red[NW][64];
+  __shared__ f32x4 red[NW][TM][64];
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int q = lane >> 4, j = lane & 15;
-  const int nt = blockIdx.x, mt = blockIdx.y;
+  const int nt = blockIdx.x, mp = blockIdx.y;
   const int nchunks = K / 16;
   const int c0 = nchunks * wave / NW, c1 = nchunks * (wave + 1) / NW;
-  const int m = 16 * mt + j, n = 16 * nt + j;
-  const bool mok = m < M, nok = n < N;
-  const float* xr = x + (int64_t)(mok ? m : 0) * K + 4 * q;
+  const int n = 16 * nt + j;
+  const bool nok = n < N;
+  const float* xr[TM];
+  bool mok[TM];
+  f32x4 acc[TM];
+#pragma unroll
+  for (int t = 0; t < TM; ++t) {
+    const int m = 16 * (TM * mp + t) + j;
+    mok[t] = m < M;
+    xr[t] = x + (int64_t)(mok[t] ? m : 0) * K + 4 * q;
+    acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
   const float* wr = W + (int64_t)(nok ? n : 0) * K + 4 * q;
-  const float* fr = MK == MK_FULL ? mk.full + (int64_t)(nok ? n : 0) * K + 4 * q : (MK == MK_DEG ? mk.dcol + 4 * q : nullptr);
-  const float dr = MK == MK_DEG ? mk.drow[nok ? n : 0] : 0.f;
-  f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
-#ifdef GNF_LIN_EXP_EMPTY
-  if (K > 0) { red[wave][lane] = acc; __syncthreads(); if (wave == 0 && nok && mok) y[(int64_t)m * N + n] = dr; return; }
-#endif
+  const float* fr = MK == MK_FULL ? mk.full + (int64_t)(nok ? n : 0) * K + 4 * q : nullptr;
+  const float* __restrict__ dcol = mk.dcol;
+  float dr = 0.f;
   for (int cb = c0; cb < c1; cb += CB) {
-    f32x4 a[CB], b[CB], d[MK == MK_NONE ? 1 : CB];
+    f32x4 a[TM][CB], b[CB], d[MK == MK_NONE ? 1 : CB];
 #pragma unroll
     for (int u = 0; u < CB; ++u) {
       const int c = cb + u < c1 ? cb + u : c1 - 1;
-#ifdef GNF_LIN_EXP_NOX
-      a[u] = f32x4{1.f, 2.f, 3.f, (float)c};
-#else
-      a[u] = *reinterpret_cast<const f32x4u*>(xr + 16 * c);
-#endif
-#ifdef GNF_LIN_EXP_NOW
-      b[u] = f32x4{1.f, 2.f, 3.f, (float)c};
-#else
+#pragma unroll
+      for (int t = 0; t < TM; ++t) a[t][u] = *reinterpret_cast<const f32x4u*>(xr[t] + 16 * c);
       b[u] = *reinterpret_cast<const f32x4u*>(wr + 16 * c);
-#endif
-      if (MK != MK_NONE) d[u] = *reinterpret_cast<const f32x4u*>(fr + 16 * c);
+      if (MK == MK_FULL) d[u] = *reinterpret_cast<const f32x4u*>(fr + 16 * c);
+      if (MK == MK_DEG) {                              // c is wave-uniform: 16 scalar loads, then the lane's slot
+        const float* dc = dcol + 16 * c;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float s0 = dc[r], s1 = dc[4 + r], s2 = dc[8 + r], s3 = dc[12 + r];
+          d[u][r] = q == 0 ? s0 : (q == 1 ? s1 : (q == 2 ? s2 : s3));
+        }
+      }
     }
+    if (MK == MK_DEG && cb == c0) dr = mk.drow[nok ? n : 0];      // behind the fragment requests: not a round trip of its own
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int u = 0; u < CB; ++u) {
@@ -103,22 +117,25 @@ __global__ __launch_bounds__(64 * NW) void lin_fwd_skinny_k(const float* __restr
           float bv = b[u][r];
           if (MK == MK_DEG) bv *= deg_keep(d[u][r], dr, mk.strict);
           else if (MK == MK_FULL) bv *= d[u][r];
-          acc = mfma(mok ? a[u][r] : 0.f, nok ? bv : 0.f, acc);
+          bv = nok ? bv : 0.f;
+#pragma unroll
+          for (int t = 0; t < TM; ++t) acc[t] = mfma(mok[t] ? a[t][u][r] : 0.f, bv, acc[t]);
         }
       }
     }
   }
-  red[wave][lane] = acc;
-  __syncthreads();
-  if (wave == 0) {
-    f32x4 s = red[0][lane];
 #pragma unroll
-    for (int w = 1; w < NW; ++w) s += red[w][lane];
+  for (int t = 0; t < TM; ++t) red[wave][t][lane] = acc[t];
+  __syncthreads();
+  if (wave < TM) {                                     // wavefront t finishes batch tile t
+    f32x4 s = red[0][wave][lane];
+#pragma unroll
+    for (int w = 1; w < NW; ++w) s += red[w][wave][lane];
     if (nok) {
       const float bv = bias ? bias[n] : 0.f;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int mo = 16 * mt + 4 * q + r;
+        const int mo = 16 * (TM * mp + wave) + 4 * q + r;
         if (mo < M) {
           float v = s[r] + bv;
           if (relu) v = fmaxf(v, 0.f);
@@ -135,13 +152,11 @@ __global__ __launch_bounds__(64 * NW) void lin_fwd_skinny_k(const float* __restr
 // row serves both tiles and four rows of one request are four full 128-B lines; the contraction runs over the out units
 // (K is even: a column pair never straddles the edge).
 template <int NW, int MK, int CB>
-__global__ __launch_bounds__(64 * NW) void lin_bwdx_skinny_k(const float* __restrict__ g, const float* __restrict__ W, LinMask mk,
-                                                             const float* __restrict__ gate, float* __restrict__ gx, int M,
-                                                             int N, int K) {
-  __shared__ f32x4 red[NW][2][64];
+__device__ __forceinline__ void lin_bwdx_body(f32x4 (*red)[2][64], int kt, int mt, const float* __restrict__ g,
+                                              const float* __restrict__ W, LinMask mk, const float* __restrict__ gate,
+                                              float* __restrict__ gx, int M, int N, int K) {
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int q = lane >> 4, j = lane & 15;
-  const int kt = blockIdx.x, mt = blockIdx.y;
   const int nchunks = N / 16;                          // chunks of out units
   const int c0 = nchunks * wave / NW, c1 = nchunks * (wave + 1) / NW;
   const int m = 16 * mt + j;
@@ -205,6 +220,13 @@ __global__ __launch_bounds__(64 * NW) void lin_bwdx_skinny_k(const float* __rest
     }
   }
 }
+template <int NW, int MK, int CB>
+__global__ __launch_bounds__(64 * NW) void lin_bwdx_skinny_k(const float* __restrict__ g, const float* __restrict__ W, LinMask mk,
+                                                             const float* __restrict__ gate, float* __restrict__ gx, int M,
+                                                             int N, int K) {
+  __shared__ f32x4 red[NW][2][64];
+  lin_bwdx_body<NW, MK, CB>(red, blockIdx.x, blockIdx.y, g, W, mk, gate, gx, M, N, K);
+}
 
 // ----------------------------------------------------------------------------------------------------- weight gradient
 // gW[o][i] = mask(o, i) sum_m g[m][o] a[m][i]: the contraction is the (small) batch.  Workgroup (ob, ib): 64 x 64 outputs
@@ -214,14 +236,13 @@ __global__ __launch_bounds__(64 * NW) void lin_bwdx_skinny_k(const float* __rest
 // in LDS), so that every operand of a wavefront is requested in ONE round (<= SB K-steps of 4 rows).  Column block 0
 // also sums g over the batch (the bias gradient).
 template <int MK, int SB>
-__global__ __launch_bounds__(512) void lin_bwdw_skinny_k(const float* __restrict__ g, const float* __restrict__ a, LinMask mk,
-                                                         float* __restrict__ gW, float* __restrict__ gb, int M, int N, int K) {
-  __shared__ f32x4 red[4][4][64];
-  __shared__ float redb[4][64];
+__device__ __forceinline__ void lin_bwdw_body(f32x4 (*red)[4][64], float (*redb)[64], int bx, int by, const float* __restrict__ g,
+                                              const float* __restrict__ a, LinMask mk, float* __restrict__ gW,
+                                              float* __restrict__ gb, int M, int N, int K) {
   const int lane = threadIdx.x & 63, wave8 = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int wave = wave8 & 3, half = wave8 >> 2;
   const int q = lane >> 4, j = lane & 15;
-  const int o0 = 64 * blockIdx.x, i0 = 64 * blockIdx.y;
+  const int o0 = 64 * bx, i0 = 64 * by;
   const int oa = o0 + 4 * j + wave;                    // out unit this lane feeds as the A operand
   const int ib = i0 + 4 * j;                           // first of this lane's four input columns
   const bool oaok = oa < N, ibok = ib + 3 < K;
@@ -297,19 +318,45 @@ __global__ __launch_bounds__(512) void lin_bwdw_skinny_k(const float* __restrict
         if (ib + c < K) gW[off + c] = v[c];
     }
   }
-  if (gb && blockIdx.y == 0) {                          // bias gradient: sum over the batch slots q of this lane's out unit
+  if (gb && by == 0) {                          // bias gradient: sum over the batch slots q of this lane's out unit
     bsum += __shfl_xor(bsum, 16, 64);
     bsum += __shfl_xor(bsum, 32, 64);
     if (q == 0 && oaok) gb[oa] = bsum;
   }
 }
+template <int MK, int SB>
+__global__ __launch_bounds__(512) void lin_bwdw_skinny_k(const float* __restrict__ g, const float* __restrict__ a, LinMask mk,
+                                                         float* __restrict__ gW, float* __restrict__ gb, int M, int N, int K) {
+  __shared__ f32x4 red[4][4][64];
+  __shared__ float redb[4][64];
+  lin_bwdw_body<MK, SB>(red, redb, blockIdx.x, blockIdx.y, g, a, mk, gW, gb, M, N, K);
+}
 
-template <int NW, int CB>
-void launch_fwd(int kind, dim3 grid, hipStream_t s, const float* x, const float* W, LinMask mk, const float* b, int relu, float* y,
-                int M, int N, int K) {
-  if (kind == MK_DEG) hipLaunchKernelGGL((lin_fwd_skinny_k<NW, MK_DEG, CB>), grid, dim3(64 * NW), 0, s, x, W, mk, b, relu, y, M, N, K);
-  else if (kind == MK_FULL) hipLaunchKernelGGL((lin_fwd_skinny_k<NW, MK_FULL, CB>), grid, dim3(64 * NW), 0, s, x, W, mk, b, relu, y, M, N, K);
-  else hipLaunchKernelGGL((lin_fwd_skinny_k<NW, MK_NONE, CB>), grid, dim3(64 * NW), 0, s, x, W, mk, b, relu, y, M, N, K);
+// ------------------------------------------------------------------------------------------- both gradients, one launch
+// The two gradients of a layer read the same g and write disjoint outputs; at these sizes each is a few memory round
+// trips plus a launch, so they run side by side, two workgroups per CU (<= 128 registers: the data-gradient role asks
+// for 4 chunks per round instead of 8).  Workgroups [0, nbx) take the data-gradient role -- the longer one when the
+// contraction over the out units needs several rounds -- so that on a grid above the 512 resident workgroups (1568 out
+// units: 624) it is the short weight-gradient workgroups that start late.
+template <int MK>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) void lin_bwd_both_k(const float* __restrict__ g, const float* __restrict__ W,
+                                                      const float* __restrict__ a, LinMask mk, const float* __restrict__ gate,
+                                                      float* __restrict__ gx, float* __restrict__ gW, float* __restrict__ gb,
+                                                      int M, int N, int K, int nbx, int wgx, int xgx) {
+  __shared__ f32x4 red[8 * 2 * 64];
+  __shared__ float redb[4][64];
+  const int bid = blockIdx.x;
+  if (bid < nbx) lin_bwdx_body<8, MK, 4>(reinterpret_cast<f32x4 (*)[2][64]>(red), bid % xgx, bid / xgx, g, W, mk, gate, gx, M, N, K);
+  else lin_bwdw_body<MK, 16>(reinterpret_cast<f32x4 (*)[4][64]>(red), redb, (bid - nbx) % wgx, (bid - nbx) / wgx, g, a, mk, gW, gb, M, N, K);
+}
+
+template <int NW, int CB, int TM>
+void launch_fwd(int kind, hipStream_t s, const float* x, const float* W, LinMask mk, const float* b, int relu, float* y, int M,
+                int N, int K) {
+  const dim3 grid((unsigned)((N + 15) / 16), (unsigned)((M + 16 * TM - 1) / (16 * TM)));
+  if (kind == MK_DEG) hipLaunchKernelGGL((lin_fwd_skinny_k<NW, MK_DEG, CB, TM>), grid, dim3(64 * NW), 0, s, x, W, mk, b, relu, y, M, N, K);
+  else if (kind == MK_FULL) hipLaunchKernelGGL((lin_fwd_skinny_k<NW, MK_FULL, CB, TM>), grid, dim3(64 * NW), 0, s, x, W, mk, b, relu, y, M, N, K);
+  else hipLaunchKernelGGL((lin_fwd_skinny_k<NW, MK_NONE, CB, TM>), grid, dim3(64 * NW), 0, s, x, W, mk, b, relu, y, M, N, K);
 }
 template <int NW, int CB>
 void launch_bwdx(int kind, dim3 grid, hipStream_t s, const float* g, const float* W, LinMask mk, const float* gate, float* gx,
@@ -346,10 +393,11 @@ int gnf_linear_fwd(const float* x, const float* W, const float* b, const float* 
   if (!x || !W || !y || (!deg_out) != (!deg_in)) return GNF_EINVAL;
   if (skinny_ok(M) && K % 16 == 0) {
     const LinMask mk{mask, deg_out, deg_in, strict};
-    const dim3 grid((unsigned)((N + 15) / 16), (unsigned)((M + 15) / 16));
-    // enough wavefronts that each requests its whole share of the contraction in one round (<= 8 chunks of 16)
-    if (K <= 1024) launch_fwd<8, 8>(mask_kind(mask, deg_out), grid, (hipStream_t)stream, x, W, mk, b, relu, y, (int)M, (int)N, (int)K);
-    else launch_fwd<16, 8>(mask_kind(mask, deg_out), grid, (hipStream_t)stream, x, W, mk, b, relu, y, (int)M, (int)N, (int)K);
+    // 16 wavefronts: K = 1024 is 4 chunks of 16 per wavefront, requested in one round.  Two batch tiles per workgroup
+    // unless that grid is more than one round of the CUs (1568 out units at B = 100: 392 workgroups) -- then four.
+    const int64_t two = (N + 15) / 16 * ((M + 31) / 32);
+    if (two <= 256 || M <= 32) launch_fwd<16, 4, 2>(mask_kind(mask, deg_out), (hipStream_t)stream, x, W, mk, b, relu, y, (int)M, (int)N, (int)K);
+    else launch_fwd<16, 4, 4>(mask_kind(mask, deg_out), (hipStream_t)stream, x, W, mk, b, relu, y, (int)M, (int)N, (int)K);
     GNF_LAUNCH_CHECK();
     return 0;
   }
@@ -397,6 +445,30 @@ int gnf_linear_bwd_w(const float* g, const float* a, const float* mask, const fl
   if (M == 0) return (int)hipMemsetAsync(gb, 0, sizeof(float) * N, (hipStream_t)stream);
   if (ws_bytes < gnf_colsum_ws_bytes(M, N)) return GNF_EWS;
   return gnf_colsum(g, N, gb, M, N, ws, stream);
+}
+
+// both gradients of one layer (gnf_linear_bwd_w + gnf_linear_bwd_x, same arguments); small batches: ONE launch
+int gnf_linear_bwd(const float* g, const float* W, const float* a, const float* mask, const float* deg_out,
+                   const float* deg_in, int strict, const float* gate, float* gx, float* gW, float* gb, int64_t M,
+                   int64_t N, int64_t K, float* ws, int64_t ws_bytes, gnf_stream_t stream) {
+  if (M < 0 || N <= 0 || K <= 0) return GNF_EINVAL;
+  if (!gW || (M > 0 && (!g || !a || !W || !gx)) || (!deg_out) != (!deg_in)) return GNF_EINVAL;
+  static const bool split = getenv("GNF_LINEAR_BWD_SPLIT") && getenv("GNF_LINEAR_BWD_SPLIT")[0] == '1';   // A/B switch
+  if (M > 0 && !split && skinny_ok(M) && N % 16 == 0 && K % 2 == 0) {
+    const LinMask mk{mask, deg_out, deg_in, strict};
+    const int wgx = (int)((N + 63) / 64), wgy = (int)((K + 63) / 64), xgx = (int)((K + 31) / 32), xgy = (int)((M + 15) / 16);
+    const int nbx = xgx * xgy;
+    const dim3 grid((unsigned)(nbx + wgx * wgy));
+    const int kind = mask_kind(mask, deg_out);
+    if (kind == MK_DEG) hipLaunchKernelGGL((lin_bwd_both_k<MK_DEG>), grid, dim3(512), 0, (hipStream_t)stream, g, W, a, mk, gate, gx, gW, gb, (int)M, (int)N, (int)K, nbx, wgx, xgx);
+    else if (kind == MK_FULL) hipLaunchKernelGGL((lin_bwd_both_k<MK_FULL>), grid, dim3(512), 0, (hipStream_t)stream, g, W, a, mk, gate, gx, gW, gb, (int)M, (int)N, (int)K, nbx, wgx, xgx);
+    else hipLaunchKernelGGL((lin_bwd_both_k<MK_NONE>), grid, dim3(512), 0, (hipStream_t)stream, g, W, a, mk, gate, gx, gW, gb, (int)M, (int)N, (int)K, nbx, wgx, xgx);
+    GNF_LAUNCH_CHECK();
+    return 0;
+  }
+  const int rc = gnf_linear_bwd_w(g, a, mask, deg_out, deg_in, strict, gW, gb, M, N, K, ws, ws_bytes, stream);
+  if (rc || M == 0) return rc;                         // an empty batch: zero weight gradients, no rows of gx
+  return gnf_linear_bwd_x(g, W, mask, deg_out, deg_in, strict, gate, gx, M, N, K, ws, ws_bytes, stream);
 }
 
 }  // extern "C"

@@ -947,14 +947,33 @@ __device__ __forceinline__ void adam_body(float* __restrict__ p, const float* __
                                           float bc2_sqrt) {
   const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, nth = (int64_t)gridDim.x * blockDim.x;
   const int64_t n4 = vec ? n >> 2 : 0;
-  for (int64_t i = tid; i < n4; i += nth) {
-    float4 pp = reinterpret_cast<float4*>(p)[i], mm = reinterpret_cast<float4*>(m)[i], vv = reinterpret_cast<float4*>(v)[i];
-    const float4 gg = reinterpret_cast<const float4*>(g)[i];
+  float4* p4 = reinterpret_cast<float4*>(p);
+  float4* m4 = reinterpret_cast<float4*>(m);
+  float4* v4 = reinterpret_cast<float4*>(v);
+  const float4* g4 = reinterpret_cast<const float4*>(g);
+  int64_t i = tid;
+  for (; i + nth < n4; i += 2 * nth) {               // two independent groups per thread: eight 16-B requests in flight
+    const int64_t k = i + nth;
+    float4 pa = p4[i], ma = m4[i], va = v4[i], pb = p4[k], mb = m4[k], vb = v4[k];
+    const float4 ga = g4[i], gb = g4[k];
+    adam_elem(pa.x, ga.x, ma.x, va.x, c, step_size, bc2_sqrt);
+    adam_elem(pa.y, ga.y, ma.y, va.y, c, step_size, bc2_sqrt);
+    adam_elem(pa.z, ga.z, ma.z, va.z, c, step_size, bc2_sqrt);
+    adam_elem(pa.w, ga.w, ma.w, va.w, c, step_size, bc2_sqrt);
+    adam_elem(pb.x, gb.x, mb.x, vb.x, c, step_size, bc2_sqrt);
+    adam_elem(pb.y, gb.y, mb.y, vb.y, c, step_size, bc2_sqrt);
+    adam_elem(pb.z, gb.z, mb.z, vb.z, c, step_size, bc2_sqrt);
+    adam_elem(pb.w, gb.w, mb.w, vb.w, c, step_size, bc2_sqrt);
+    p4[i] = pa; m4[i] = ma; v4[i] = va; p4[k] = pb; m4[k] = mb; v4[k] = vb;
+  }
+  for (; i < n4; i += nth) {
+    float4 pp = p4[i], mm = m4[i], vv = v4[i];
+    const float4 gg = g4[i];
     adam_elem(pp.x, gg.x, mm.x, vv.x, c, step_size, bc2_sqrt);
     adam_elem(pp.y, gg.y, mm.y, vv.y, c, step_size, bc2_sqrt);
     adam_elem(pp.z, gg.z, mm.z, vv.z, c, step_size, bc2_sqrt);
     adam_elem(pp.w, gg.w, mm.w, vv.w, c, step_size, bc2_sqrt);
-    reinterpret_cast<float4*>(p)[i] = pp; reinterpret_cast<float4*>(m)[i] = mm; reinterpret_cast<float4*>(v)[i] = vv;
+    p4[i] = pp; m4[i] = mm; v4[i] = vv;
   }
   for (int64_t i = 4 * n4 + tid; i < n; i += nth) adam_elem(p[i], g[i], m[i], v[i], c, step_size, bc2_sqrt);
 }
@@ -965,15 +984,32 @@ __global__ void adam_k(float* __restrict__ p, const float* __restrict__ g, float
 }
 
 // Same update with the step count in device memory, so that a captured hipGraph of the whole training step can be
-// replayed: the bias corrections are recomputed on the device from *step_dev + 1; adam_bump_k then advances it.
-__global__ void adam_dev_k(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
-                           float* __restrict__ v, int64_t n, int vec, AdamC c, double lr, double b1, double b2,
-                           const int* __restrict__ step_dev) {
-  const double t = (double)(*step_dev + 1);
+// replayed: the bias corrections are recomputed on the device from step_dev[0] + 1.  advance: every workgroup takes a
+// ticket (step_dev[1]) once all its wavefronts have read the count, and whoever holds the LAST ticket stores the new
+// count at its end -- every other workgroup has read the old one by then -- and resets the tickets.  Same-address
+// device-scope atomics serialise at ~27 ns each: the grid is at most 256 workgroups of 1024 threads and the tickets are
+// drawn BEFORE the streaming loop, whose ~20 us hide them (drawn after it by 1568 workgroups they cost 43 us; a release
+// fence in front of them, one L2 write-back per workgroup: 100 us).  A separate one-thread launch for the increment cost
+// 4 us of a 170-us MADE step.
+constexpr int kAdamDevBlock = 1024;
+__global__ __launch_bounds__(kAdamDevBlock) void adam_dev_k(float* __restrict__ p, const float* __restrict__ g,
+                                                            float* __restrict__ m, float* __restrict__ v, int64_t n, int vec,
+                                                            AdamC c, double lr, double b1, double b2, int* step_dev, int advance) {
+  const int taken = *reinterpret_cast<volatile int*>(step_dev);
+  unsigned ticket = 0;
+  if (advance) {
+    __syncthreads();
+    if (threadIdx.x == 0)
+      ticket = __hip_atomic_fetch_add(reinterpret_cast<unsigned*>(step_dev + 1), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  const double t = (double)(taken + 1);
   const float step_size = (float)(lr / (1.0 - pow(b1, t))), bc2_sqrt = (float)sqrt(1.0 - pow(b2, t));
   adam_body(p, g, m, v, n, vec != 0, c, step_size, bc2_sqrt);
+  if (advance && threadIdx.x == 0 && ticket == gridDim.x - 1) {
+    step_dev[1] = 0;
+    step_dev[0] = taken + 1;
+  }
 }
-__global__ void adam_bump_k(int* step_dev) { *step_dev += 1; }
 
 // out[n] (+)= sum_p src[p*N + n]: 64 columns per block, 16 wavefronts stride over the rows
 // (coalesced 256-B row segments), fixed-order LDS tree across the wavefronts -> deterministic.
@@ -1240,7 +1276,7 @@ int gnf_adam_step(float* p, const float* g, float* m, float* v, int64_t n, doubl
   const float step_size = (float)(lr / (1.0 - pow(beta1, (double)step)));
   const float bc2s = (float)sqrt(1.0 - pow(beta2, (double)step));
   const int vec = adam_vec_ok(p, g, m, v);
-  hipLaunchKernelGGL(adam_k, dim3(grid_1d(vec ? (n + 3) / 4 : n)), dim3(kBlock), 0, (hipStream_t)stream, p, g, m, v, n,
+  hipLaunchKernelGGL(adam_k, dim3(grid_1d(vec ? (n + 7) / 8 : n)), dim3(kBlock), 0, (hipStream_t)stream, p, g, m, v, n,
                      vec, adam_consts(beta1, beta2, eps, weight_decay, grad_scale), step_size, bc2s);
   GNF_LAUNCH_CHECK();
   return 0;
@@ -1253,10 +1289,11 @@ int gnf_adam_step_dev(float* p, const float* g, float* m, float* v, int64_t n, d
   if (n == 0) return 0;
   if (!p || !g || !m || !v) return GNF_EINVAL;
   const int vec = adam_vec_ok(p, g, m, v);
-  hipLaunchKernelGGL(adam_dev_k, dim3(grid_1d(vec ? (n + 3) / 4 : n)), dim3(kBlock), 0, (hipStream_t)stream, p, g, m, v,
-                     n, vec, adam_consts(beta1, beta2, eps, weight_decay, grad_scale), lr, beta1, beta2,
-                     (const int*)step_dev);
-  if (advance) hipLaunchKernelGGL(adam_bump_k, dim3(1), dim3(1), 0, (hipStream_t)stream, step_dev);
+  int64_t grid = ((vec ? (n + 7) / 8 : n) + kAdamDevBlock - 1) / kAdamDevBlock;
+  if (grid > 256) grid = 256;
+  hipLaunchKernelGGL(adam_dev_k, dim3((unsigned)grid), dim3(kAdamDevBlock), 0, (hipStream_t)stream, p, g, m, v,
+                     n, vec, adam_consts(beta1, beta2, eps, weight_decay, grad_scale), lr, beta1, beta2, step_dev,
+                     advance);
   GNF_LAUNCH_CHECK();
   return 0;
 }

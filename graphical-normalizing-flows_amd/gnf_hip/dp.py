@@ -26,13 +26,11 @@ class FlatState:
         self.m = torch.zeros(n, device=dev)
         self.v = torch.zeros(n, device=dev)
         o = 0
-        self._pads = []                            # zero fillers between parameters, for the one-launch gradient pack
         for p in self.params:
             k = p.numel()
             self.flat[o:o + k].copy_(p.data.reshape(-1))
             p.data = self.flat[o:o + k].view_as(p)
             p.grad = None
-            self._pads.append(torch.zeros(pad4(k) - k, device=dev))
             o += pad4(k)
         self.t = 0
         self._offsets = []
@@ -41,27 +39,37 @@ class FlatState:
             self._offsets.append(o)
             o += pad4(q.numel())
         self.active_runs = [(0, n)]                # [(offset, length)] of the flat buffer Adam steps; see pack_grads
+        # the slot of every parameter's gradient in the flat buffer: backward kernels write there directly (ops.grad_out)
+        self.grad_views = [self.grad[o:o + p.numel()] for o, p in zip(self._offsets, self.params)]
+        self._taken = set()
+        from . import ops
+        ops.register_grad_slots(self, self.params)
 
     def pack_grads(self, grads=None):
-        """flat gradient buffer <- the .grad tensors autograd just produced (or the given list, in self.params order),
-        in ONE concatenation launch.  (.grad views into the flat buffer would cost a zero-fill plus one accumulate
-        kernel per parameter per step.)"""
-        parts, runs = [], []
-        for i, (p, pad) in enumerate(zip(self.params, self._pads)):
+        """flat gradient buffer <- the .grad tensors autograd just produced (or the given list, in self.params order).
+        Gradients the backward kernels already wrote into their slot (ops.grad_out) stay where they are; the others are
+        copied in one multi-tensor launch.  (.grad views into the flat buffer for everything would cost a zero-fill plus
+        one accumulate kernel per parameter per step.)"""
+        dst, src, runs = [], [], []
+        for i, (p, slot) in enumerate(zip(self.params, self.grad_views)):
             g = p.grad if grads is None else grads[i]
-            parts.append(g.reshape(-1) if g is not None else torch.zeros(p.numel(), device=pad.device))
-            if pad.numel():
-                parts.append(pad)
-            if g is not None:
-                # torch.optim.Adam skips parameters without a gradient (no weight decay, no moment update): a frozen A
-                # (post_process) must not decay.  Adam therefore steps the runs of consecutive parameters that have one.
-                o, k = self._offsets[i], (p.numel() + 3) // 4 * 4
-                if runs and runs[-1][0] + runs[-1][1] == o:
-                    runs[-1] = (runs[-1][0], runs[-1][1] + k)
-                else:
-                    runs.append((o, k))
+            if g is None:
+                slot.zero_()                       # e.g. a frozen A: the all-reduce must not sum stale values
+                continue
+            if not (g.data_ptr() == slot.data_ptr() and g.is_contiguous()):
+                dst.append(slot)
+                src.append(g.reshape(-1))
+            # torch.optim.Adam skips parameters without a gradient (no weight decay, no moment update): a frozen A
+            # (post_process) must not decay.  Adam therefore steps the runs of consecutive parameters that have one.
+            o, k = self._offsets[i], (p.numel() + 3) // 4 * 4
+            if runs and runs[-1][0] + runs[-1][1] == o:
+                runs[-1] = (runs[-1][0], runs[-1][1] + k)
+            else:
+                runs.append((o, k))
         self.active_runs = runs
-        torch.cat(parts, out=self.grad)
+        if dst:
+            torch._foreach_copy_(dst, src)
+        self._taken.clear()
         if grads is None:
             for p in self.params:
                 p.grad = None
@@ -214,6 +222,17 @@ def train_step(flow, state, x_shard, lr=1e-3, weight_decay=1e-5, optimizer=hip_a
     return loss
 
 
+_ONES = {}
+
+
+def _one(like):
+    """the cotangent of the scalar loss, kept per device: autograd would fill a fresh one per step (one launch)"""
+    key = (like.device, like.dtype)
+    if key not in _ONES:
+        _ONES[key] = torch.ones((), device=like.device, dtype=like.dtype)
+    return _ONES[key]
+
+
 def accumulate(flow, x_shard, scale=1.):
     """fwd + log|det J| + NLL (+ constraints) + bwd of ONE micro-batch; gradients add up in `.grad` until apply_step().
     The image driver's gradient accumulation (ImageExperiments.py:205-213: loss / batch_per_optim_step, backward on
@@ -222,7 +241,7 @@ def accumulate(flow, x_shard, scale=1.):
     loss = flow.loss(z, logdet)
     if scale != 1.:
         loss = loss * scale
-    loss.backward()
+    loss.backward(_one(loss) if loss.dim() == 0 else None)
     return loss
 
 
@@ -259,7 +278,8 @@ class GraphedStep:
             raise RuntimeError("GraphedStep is single-process; use train_step under torchrun")
         self.state, self.flow = state, flow
         self.lr, self.weight_decay = lr, weight_decay
-        self.step_dev = torch.full((1,), state.t, dtype=torch.int32, device=x_example.device)
+        self._step_buf = torch.zeros(2, dtype=torch.int32, device=x_example.device)    # {steps taken, ticket counter}
+        self.step_dev = self._step_buf[:1]
         self.captures = 0
         self._graphs = {}                    # fingerprint -> (graph, loss tensor, input buffer)
         self.loss = self._capture(x_example, max(warmup, 1))
@@ -314,7 +334,7 @@ class GraphedStep:
         def body():
             leaves = [p.detach().requires_grad_(i in live) for i, p in enumerate(state.params)]
             loss = torch.func.functional_call(wrapper, dict(zip(names, leaves)), (xbuf,))
-            got = torch.autograd.grad(loss, [leaves[i] for i in live], allow_unused=True)
+            got = torch.autograd.grad(loss, [leaves[i] for i in live], grad_outputs=one, allow_unused=True)
             grads = [None] * len(leaves)
             for i, g in zip(live, got):
                 grads[i] = g
@@ -322,9 +342,10 @@ class GraphedStep:
             runs = state.active_runs
             for k, (o, n) in enumerate(runs):       # the device-side counter is advanced by the last launch only
                 ops.adam_step_dev(state.flat[o:o + n], state.grad[o:o + n], state.m[o:o + n], state.v[o:o + n],
-                                  self.step_dev, lr=lr, weight_decay=weight_decay, advance=(k == len(runs) - 1))
+                                  self._step_buf, lr=lr, weight_decay=weight_decay, advance=(k == len(runs) - 1))
             return loss.detach()
 
+        one = _one(xbuf)
         self.step_dev.fill_(state.t)
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())

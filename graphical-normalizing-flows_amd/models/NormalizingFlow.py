@@ -129,11 +129,11 @@ class FCNormalizingFlow(NormalizingFlow):
         return [n for s in self.steps for n in s.getNormalizers()]
 
     def forward(self, x, context=None):
-        logdet = 0.
+        logdet = None
         last = len(self.steps) - 1
         for k, flow_step in enumerate(self.steps):
             z, ld = flow_step(x, context)
-            logdet = logdet + ld
+            logdet = ld if logdet is None else logdet + ld      # (the reference's 0. + ld is one more launch)
             if k < last:
                 x = torch.flip(z, dims=[1])      # the reference's z[:, inv_idx] (:120-123)
         return z, logdet                         # the last step's z is returned un-flipped (:126)
@@ -178,10 +178,10 @@ class CNNormalizingFlow(FCNormalizingFlow):
 
     def forward(self, x, context=None):
         batch = x.shape[0]
-        logdet, latents = 0., []
+        logdet, latents = None, []
         for flow, drop in zip(self.steps, self.dropping_factors):
             z, ld = flow(x, context)
-            logdet = logdet + ld
+            logdet = ld if logdet is None else logdet + ld
             blocks = self._blocks(z, flow.img_sizes, drop)
             latents.append(blocks[..., 1:].reshape(batch, -1))
             x = blocks[..., 0].reshape(batch, -1)

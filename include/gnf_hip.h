@@ -92,6 +92,8 @@ int gnf_colsum(const float* a, int64_t lda, float* out, int64_t M, int64_t N, fl
  *   fwd:    y  = act(x (W o mask)^T + b)                       relu != 0: act = ReLU
  *   bwd_x:  gx = (g (W o mask)) o [gate > 0]                   g: [M,N]; gate: [M,K] (the layer's input) or NULL
  *   bwd_w:  gW = (g^T a) o mask, gb = column sums of g         a: [M,K]; gb: [N] or NULL
+ *   bwd:    bwd_w and bwd_x of one layer (what autograd runs for F.linear when both the weight and the input need a
+ *           gradient); at M <= 128 the two run side by side in ONE launch
  * ws: >= gnf_linear_ws_bytes(M,N,K) bytes. */
 int64_t gnf_linear_ws_bytes(int64_t M, int64_t N, int64_t K);
 int gnf_linear_fwd(const float* x, const float* W, const float* b, const float* mask, const float* deg_out,
@@ -103,6 +105,9 @@ int gnf_linear_bwd_x(const float* g, const float* W, const float* mask, const fl
 int gnf_linear_bwd_w(const float* g, const float* a, const float* mask, const float* deg_out, const float* deg_in,
                      int strict, float* gW, float* gb, int64_t M, int64_t N, int64_t K,
                      float* ws, int64_t ws_bytes, gnf_stream_t stream);
+int gnf_linear_bwd(const float* g, const float* W, const float* a, const float* mask, const float* deg_out,
+                   const float* deg_in, int strict, const float* gate, float* gx, float* gW, float* gb, int64_t M,
+                   int64_t N, int64_t K, float* ws, int64_t ws_bytes, gnf_stream_t stream);
 
 /* ---- fp32 MFMA GEMM with fused masks / bias / ReLU ------------------------------------
  * Replaces F.linear(input, mask*weight, bias) (AutoregressiveConditioner.py:24-25), the
@@ -279,7 +284,8 @@ int gnf_adam_step(float* p, const float* g, float* m, float* v, int64_t n,
                   double grad_scale, int step, gnf_stream_t stream);
 
 /* Same update (torch.optim.Adam at ImageExperiments.py:173 / UCIExperiments.py:97), with the step count in device
- * memory (*step_dev = number of steps already taken; incremented by the call when advance != 0 -- a step over
+ * memory: step_dev points to TWO ints, {number of steps already taken, 0} -- the second is the ticket counter by which
+ * the last workgroup of the launch increments the first when advance != 0, and reads 0 again afterwards (a step over
  * several disjoint runs of the flat buffer, e.g. around a frozen parameter, advances on its last launch only):
  * nothing step-dependent is passed by value, so a captured hipGraph of a whole training step can be replayed
  * (gnf_hip.dp.GraphedStep -- the launch-bound configurations). */

@@ -557,6 +557,32 @@ def test_linear_layer_kernels_vs_torch(M, N, K, mask_kind):
             assert int(((a.grad.cpu() != 0) & (mk == 0)).sum()) == 0
 
 
+@pytest.mark.parametrize("M,N,K", [(100, 1024, 784), (9, 48, 32), (130, 64, 64)])
+@pytest.mark.parametrize("frozen", ["input", "weights"])
+def test_linear_layer_single_gradient_launches(M, N, K, frozen):
+    """gnf_linear_bwd runs both gradients of a layer in one launch; a layer whose input (the first MADE layer: x carries
+    no gradient) or whose weights (a frozen conditioner) need none goes through gnf_linear_bwd_w / _bwd_x alone."""
+    from gnf_hip import ops
+    g = torch.Generator().manual_seed(M + N + K)
+    x = torch.randn(M, K, generator=g)
+    W, b = torch.randn(N, K, generator=g) / K ** .5, torch.randn(N, generator=g) * .1
+    do, di = torch.randint(0, 5, (N,), generator=g).float(), torch.randint(0, 5, (K,), generator=g).float()
+    m = (di[None, :] <= do[:, None]).float()
+    gy = torch.randn(M, N, generator=g)
+    xr, Wr, br = (t.clone().requires_grad_(True) for t in (x, W, b))
+    (torch.nn.functional.linear(xr, Wr * m, br) * gy).sum().backward()
+    xg = cu(x).requires_grad_(frozen != "input")
+    Wg, bg = (cu(t).requires_grad_(frozen != "weights") for t in (W, b))
+    y = ops.mlp(xg, [(Wg, bg)], [cu(m)], degs=[(cu(do), cu(di), False)])
+    (y * cu(gy)).sum().backward()
+    if frozen == "input":
+        assert xg.grad is None
+        assert rel_err(Wg.grad.cpu(), Wr.grad) < GTOL and rel_err(bg.grad.cpu(), br.grad) < GTOL
+    else:
+        assert Wg.grad is None and bg.grad is None
+        assert rel_err(xg.grad.cpu(), xr.grad) < GTOL
+
+
 def test_made_degree_rule_is_verified_against_the_mask_buffer():
     """MaskedLinear hands the kernels its degree vectors only while the mask buffer equals the degree rule; a mask that
     was overwritten (a checkpoint, a user's own pattern) is read as a tensor again, and the result follows it."""
@@ -871,11 +897,20 @@ def test_abi_error_codes():
     p0, g0 = torch.randn(1000, device=DEV), torch.randn(1000, device=DEV)
     pa, ma, va = p0.clone(), torch.zeros_like(p0), torch.zeros_like(p0)
     pb, mb, vb = p0.clone(), torch.zeros_like(p0), torch.zeros_like(p0)
-    step = torch.zeros(1, dtype=torch.int32, device=DEV)
+    step = torch.zeros(2, dtype=torch.int32, device=DEV)             # {steps taken, ticket counter of the last launch}
     for t in (1, 2, 3):
         ops.adam_step(pa, g0, ma, va, t, lr=1e-2, weight_decay=1e-4)
         ops.adam_step_dev(pb, g0, mb, vb, step, lr=1e-2, weight_decay=1e-4)
-    assert int(step.item()) == 3 and rel_err(pb.cpu(), pa.cpu()) < 1e-6
+    assert step.tolist() == [3, 0] and rel_err(pb.cpu(), pa.cpu()) < 1e-6
+    ops.adam_step_dev(pb, g0, mb, vb, step, lr=1e-2, weight_decay=1e-4, advance=False)
+    assert step.tolist() == [3, 0]
+    big = torch.randn(3_000_001, device=DEV)                          # many workgroups, scalar tail
+    pc, mc, vc = big.clone(), torch.zeros_like(big), torch.zeros_like(big)
+    pd, md, vd = big.clone(), torch.zeros_like(big), torch.zeros_like(big)
+    for t in (4, 5):
+        ops.adam_step(pc, big, mc, vc, t, lr=1e-2)
+        ops.adam_step_dev(pd, big, md, vd, step, lr=1e-2)
+    assert step.tolist() == [5, 0] and torch.equal(pc, pd)
 
 
 @pytest.mark.parametrize("name,B", [("cfg1", 512), ("cfg2", 10000), ("cfg3", 100), ("cfg5", 2000)])
