@@ -50,11 +50,12 @@ class FlatState:
         Gradients the backward kernels already wrote into their slot (ops.grad_out) stay where they are; the others are
         copied in one multi-tensor launch.  (.grad views into the flat buffer for everything would cost a zero-fill plus
         one accumulate kernel per parameter per step.)"""
-        dst, src, runs = [], [], []
+        dst, src, runs, absent = [], [], [], 0
         for i, (p, slot) in enumerate(zip(self.params, self.grad_views)):
             g = p.grad if grads is None else grads[i]
             if g is None:
                 slot.zero_()                       # e.g. a frozen A: the all-reduce must not sum stale values
+                absent += 1
                 continue
             if not (g.data_ptr() == slot.data_ptr() and g.is_contiguous()):
                 dst.append(slot)
@@ -67,6 +68,7 @@ class FlatState:
             else:
                 runs.append((o, k))
         self.active_runs = runs
+        self.pack_stats = {"in_place": len(self.params) - len(dst) - absent, "copied": len(dst), "absent": absent}
         if dst:
             torch._foreach_copy_(dst, src)
         self._taken.clear()

@@ -465,3 +465,58 @@ def test_train_step_auto_graph_follows_epoch_level_changes():
                     c.post_process(.1)
     assert rel_err(tb.flat.cpu(), ta.flat.cpu()) < 1e-5
     assert tb._graphed.captures == 3
+
+
+def test_gradients_are_written_into_the_flat_buffer():
+    """ops.grad_out: the backward kernels of a MADE + Affine step write every parameter gradient into its slot of
+    FlatState.grad (no concatenation launch); the parameters after two steps are bit-identical to the run that packs fresh
+    gradient tensors.  A weight used twice in one graph, and a second micro-batch accumulating into .grad, get a fresh
+    tensor for the second contribution -- the sums are those of plain autograd."""
+    from gnf_hip import dp, ops
+    from models import buildFCNormalizingFlow, AutoregressiveConditioner, AffineNormalizer
+    def make():
+        torch.manual_seed(5)
+        return buildFCNormalizingFlow(1, AutoregressiveConditioner, {"in_size": 12, "hidden": [32, 32], "out_size": 2},
+                                      AffineNormalizer, {}).to(DEV)
+    x = torch.randn(10, 12, device=DEV)
+    fa, fb = make(), make()
+    sa, sb = dp.FlatState(fa), dp.FlatState(fb)
+    for graph in (False, "auto", "auto"):
+        dp.train_step(fa, sa, x, graph=graph)
+        if graph is False:
+            assert sa.pack_stats == {"in_place": len(sa.params), "copied": 0, "absent": 0}
+    old = ops._SINK
+    ops._SINK = False
+    try:
+        for graph in (False, "auto", "auto"):
+            dp.train_step(fb, sb, x, graph=graph)
+            if graph is False:
+                assert sb.pack_stats == {"in_place": 0, "copied": len(sb.params), "absent": 0}
+    finally:
+        ops._SINK = old
+    assert torch.equal(sa.flat, sb.flat) and torch.equal(sa.m, sb.m) and torch.equal(sa.v, sb.v)
+
+    # a shared weight: y = L(relu(L(x))) with the same (W, b) twice
+    torch.manual_seed(6)
+    lin = torch.nn.Linear(16, 16).to(DEV)
+    st = dp.FlatState(lin)
+    xs = torch.randn(7, 16, device=DEV)
+    h = ops.mlp(xs, [(lin.weight, lin.bias)])
+    y = ops.mlp(torch.relu(h), [(lin.weight, lin.bias)])
+    y.square().sum().backward()
+    Wr, br = lin.weight.detach().cpu().requires_grad_(True), lin.bias.detach().cpu().requires_grad_(True)
+    yr = torch.nn.functional.linear(torch.relu(torch.nn.functional.linear(xs.cpu(), Wr, br)), Wr, br)
+    yr.square().sum().backward()
+    st.pack_grads()
+    assert_close(st.grad_views[0].view(16, 16), Wr.grad, rtol=1e-5, atol=1e-5, what="shared weight gradient")
+    assert_close(st.grad_views[1], br.grad, rtol=1e-5, atol=1e-5, what="shared bias gradient")
+
+    # two micro-batches into .grad, then one pack
+    for k in range(2):
+        ops.mlp(xs[3 * k:3 * k + 3], [(lin.weight, lin.bias)]).square().sum().backward()
+    Wr.grad = br.grad = None
+    for k in range(2):
+        torch.nn.functional.linear(xs[3 * k:3 * k + 3].cpu(), Wr, br).square().sum().backward()
+    st.pack_grads()
+    assert_close(st.grad_views[0].view(16, 16), Wr.grad, rtol=1e-5, atol=1e-5, what="accumulated weight gradient")
+    assert_close(st.grad_views[1], br.grad, rtol=1e-5, atol=1e-5, what="accumulated bias gradient")
