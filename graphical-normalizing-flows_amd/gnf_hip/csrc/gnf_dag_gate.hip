@@ -218,12 +218,28 @@ __global__ void dag_gate_bwd_dp_k(GateArgs a) {
     if (h < nv) a.ws[(int64_t)blockIdx.y * dd + i * d + j0 + h] = acc[h];
 }
 
-// gA = (sum over the batch chunks, taken by the shared deterministic row-sum kernel) * dP/dA
-__global__ void dag_gate_bwd_dA_k(const float* __restrict__ tab, const float* __restrict__ sums, float* __restrict__ gA,
-                                  int64_t dd) {
-  const int64_t ij = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (ij >= dd) return;
-  gA[ij] = sums[ij] * tab[dd + ij];
+// gA = (sum over the nc batch chunks, in chunk order: deterministic) * dP/dA.  The chunks are few (<= 16) and long (d*d):
+// one pass with four elements per thread; as a launch of the shared row-sum kernel (16 wavefronts per 64 columns, made for
+// MANY short partial rows) plus this product the tail of the cfg4 gate backward was 18 + 5 us.
+__global__ void dag_gate_bwd_dA_k(const float* __restrict__ tab, const float* __restrict__ part, int nc,
+                                  float* __restrict__ gA, int64_t dd) {
+  const int64_t i4 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+  if (i4 >= dd) return;
+  if (i4 + 3 < dd && (dd & 3) == 0) {
+    float4 s = *reinterpret_cast<const float4*>(part + i4);
+    for (int c = 1; c < nc; ++c) {
+      const float4 v = *reinterpret_cast<const float4*>(part + (int64_t)c * dd + i4);
+      s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
+    const float4 t = *reinterpret_cast<const float4*>(tab + dd + i4);
+    *reinterpret_cast<float4*>(gA + i4) = make_float4(s.x * t.x, s.y * t.y, s.z * t.z, s.w * t.w);
+    return;
+  }
+  for (int64_t ij = i4; ij < dd && ij < i4 + 4; ++ij) {
+    float s = part[ij];
+    for (int c = 1; c < nc; ++c) s += part[(int64_t)c * dd + ij];
+    gA[ij] = s * tab[dd + ij];
+  }
 }
 
 // gx partial sums over a chunk of i (blockIdx.y):  out[chunk][b,j] = sum_{i in chunk} ge[b,i,j] * de/dx[b,i,j];  one thread
@@ -451,19 +467,23 @@ int gnf_dag_gate_bwd(const float* x, const float* A, const float* ge, int64_t ld
   if (gA) {
     const int64_t nc = bwd_chunks(B, d);
     a.chunk = B > 0 ? (B + nc - 1) / nc : 1;
-    const unsigned gxd = (unsigned)((d * d + kBlock - 1) / kBlock);
     const unsigned gxp = (unsigned)((d * ((d + 3) / 4) + kBlock - 1) / kBlock);
     hipLaunchKernelGGL(dag_gate_bwd_dp_k, dim3(gxp, (unsigned)nc), dim3(kBlock), 0, s, a);
     GNF_LAUNCH_CHECK();
-    // second stage: a small-d / large-B call (POWER: d = 6, B = 10000) has 2048 chunk rows of only 36 columns; one thread
-    // per column walking them serially took 0.45 ms, the row-sum kernel spreads the rows over 16 wavefronts
-    float* sums = a.ws;                                    // a single chunk (large d) is its own sum
-    if (nc > 1) {
-      sums = a.ws + nc * d * d;
-      rc = gnf_rowsum_launch(a.ws, sums, nc, d * d, 0, s);
+    // second stage.  A small-d / large-B call (POWER: d = 6, B = 10000) has 2048 chunk rows of only 36 columns: the
+    // row-sum kernel spreads the rows over 16 wavefronts (one thread per column walking them serially took 0.45 ms);
+    // a few long chunks (MNIST: d*d = 614 656 columns) are summed by the product kernel itself
+    const float* sums = a.ws;
+    int nsum = (int)nc;
+    if (nc > 16) {
+      float* tot = a.ws + nc * d * d;
+      rc = gnf_rowsum_launch(a.ws, tot, nc, d * d, 0, s);
       if (rc) return rc;
+      sums = tot;
+      nsum = 1;
     }
-    hipLaunchKernelGGL(dag_gate_bwd_dA_k, dim3(gxd), dim3(kBlock), 0, s, tab, sums, gA, d * d);
+    const unsigned gx4 = (unsigned)(((d * d + 3) / 4 + kBlock - 1) / kBlock);
+    hipLaunchKernelGGL(dag_gate_bwd_dA_k, dim3(gx4), dim3(kBlock), 0, s, tab, sums, nsum, gA, d * d);
     GNF_LAUNCH_CHECK();
   }
   if (gx && B > 0) {

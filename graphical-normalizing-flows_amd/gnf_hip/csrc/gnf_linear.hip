@@ -20,6 +20,7 @@
 // Everything else (M > 128, K not a multiple of 16) goes to the tiled GEMM unchanged.
 #include "gnf_common.h"
 #include "gnf_gemm.h"
+#include "gnf_linear_tall.h"
 #include <cstdlib>
 
 extern "C" int64_t gnf_gemm_ws_bytes(int64_t M, int64_t N, int64_t K);
@@ -382,6 +383,10 @@ int64_t gnf_linear_ws_bytes(int64_t M, int64_t N, int64_t K) {
   int64_t w = gnf_gemm_ws_bytes(M, N, K);
   const int64_t w2 = gnf_gemm_ws_bytes(M, K, N), w3 = gnf_gemm_ws_bytes(N, K, M), w4 = gnf_colsum_ws_bytes(M, N);
   w = w > w2 ? w : w2; w = w > w3 ? w : w3; w = w > w4 ? w : w4;
+  if (gnf_linear_tall_ok(M, N, K)) {
+    const int64_t w5 = gnf_linear_tall_ws_floats(M, N, K) * (int64_t)sizeof(float);
+    w = w > w5 ? w : w5;
+  }
   return w;
 }
 
@@ -401,6 +406,8 @@ int gnf_linear_fwd(const float* x, const float* W, const float* b, const float* 
     GNF_LAUNCH_CHECK();
     return 0;
   }
+  if (!mask && !deg_out && gnf_linear_tall_ok(M, N, K))
+    return gnf_linear_tall_fwd(x, W, b, relu, y, M, N, K, (hipStream_t)stream);
   if (deg_out && !mask) return GNF_EINVAL;             // the tiled GEMM multiplies a mask tensor in
   return gnf_gemm(x, K, 1, W, mask, 1, K, y, N, 1, b, nullptr, 0, 0, nullptr, 0, 0, relu ? GNF_GEMM_RELU : 0, M, N, K, ws,
                   ws_bytes, stream);
@@ -465,6 +472,10 @@ int gnf_linear_bwd(const float* g, const float* W, const float* a, const float* 
     else hipLaunchKernelGGL((lin_bwd_both_k<MK_NONE>), grid, dim3(512), 0, (hipStream_t)stream, g, W, a, mk, gate, gx, gW, gb, (int)M, (int)N, (int)K, nbx, wgx, xgx);
     GNF_LAUNCH_CHECK();
     return 0;
+  }
+  if (!mask && !deg_out && gnf_linear_tall_ok(M, N, K) && (!gate || gate == a)) {
+    if (!ws || ws_bytes < gnf_linear_tall_ws_floats(M, N, K) * (int64_t)sizeof(float)) return GNF_EWS;
+    return gnf_linear_tall_bwd(g, W, a, gate, gx, gW, gb, M, N, K, ws, (hipStream_t)stream);
   }
   const int rc = gnf_linear_bwd_w(g, a, mask, deg_out, deg_in, strict, gW, gb, M, N, K, ws, ws_bytes, stream);
   if (rc || M == 0) return rc;                         // an empty batch: zero weight gradients, no rows of gx

@@ -498,7 +498,7 @@ class DagGateFn(torch.autograd.Function):
         imp_mode, gate_mode, h_thresh, temperature, ld, seed, offset = ctx.cfg
         B, d = x.shape
         ge = ge.contiguous()
-        gA = _empty((d, d), x) if ctx.needs_input_grad[1] else None
+        gA = grad_out(A) if ctx.needs_input_grad[1] else None      # (the flat-buffer slot unless the loss term took it)
         gx = _empty((B, d), x) if ctx.needs_input_grad[0] else None
         ws = _ws(abi.load().gnf_dag_gate_bwd_ws_bytes(B, d), x)
         call("gnf_dag_gate_bwd", ptr(x), ptr(A), ptr(ge), ld, imp_mode, gate_mode, h_thresh, temperature, ptr(u1),
@@ -760,6 +760,6 @@ class DagLossFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         A, P, out4 = ctx.saved_tensors
-        gA = torch.empty_like(A)
+        gA = grad_out(A)
         call("gnf_dag_loss_bwd", ptr(A), ptr(P), ptr(out4), ptr(g.contiguous().reshape(1)), ptr(gA), A.shape[0], stream())
         return gA, None, None, None, None, None, None, None

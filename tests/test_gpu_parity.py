@@ -583,6 +583,42 @@ def test_linear_layer_single_gradient_launches(M, N, K, frozen):
         assert rel_err(xg.grad.cpu(), xr.grad) < GTOL
 
 
+@pytest.mark.parametrize("M,H,N", [(4099, 128, 30), (2048, 64, 32), (78400, 128, 30), (3000, 128, 1), (2500, 64, 17),
+                                   (60000, 60, 60), (5003, 60, 30), (2100, 12, 30), (2500, 64, 64), (3000, 128, 64),
+                                   (2049, 4, 33), (2600, 100, 50)])
+def test_linear_tall_narrow_layers(M, H, N):
+    """gnf_linear_tall.hip: the fc2 shape of the headline model (78 400 x 128 -> 30), the DAGMLP layers of cfg2
+    (60 000 x 12 -> 60 -> 60 -> 60 -> 30, DAGConditioner.py:7-20) and their relatives (N <= 64, K <= 128 a multiple of
+    4) -- forward with the weight resident in registers, both gradients + the ReLU gate of the layer's input in one
+    launch -- against F.linear and its autograd in fp64 on the CPU, as both layers of a chain (the second gated) and
+    alone."""
+    from gnf_hip import ops
+    g = torch.Generator().manual_seed(M + H + N)
+    x = torch.randn(M, 24, generator=g)
+    W1, b1 = torch.randn(H, 24, generator=g) / 24 ** .5, torch.randn(H, generator=g) * .1
+    W2, b2 = torch.randn(N, H, generator=g) / H ** .5, torch.randn(N, generator=g) * .1
+    gy = torch.randn(M, N, generator=g)
+    ref = [t.double().requires_grad_(True) for t in (x, W1, b1, W2, b2)]
+    h = torch.relu(torch.nn.functional.linear(ref[0], ref[1], ref[2]))
+    y0 = torch.nn.functional.linear(h, ref[3], ref[4])
+    (y0 * gy.double()).sum().backward()
+    dev = [req(t) for t in (x, W1, b1, W2, b2)]
+    y = ops.mlp(dev[0], [(dev[1], dev[2]), (dev[3], dev[4])])
+    assert_close(y, y0.float(), rtol=1e-5, atol=2e-5, what="y")
+    (y * cu(gy)).sum().backward()
+    for name, a, r in zip(("gx", "gW1", "gb1", "gW2", "gb2"), dev, ref):
+        assert rel_err(a.grad.cpu(), r.grad.float()) < GTOL, (name, rel_err(a.grad.cpu(), r.grad.float()))
+    # alone (no gate), input and weights needing gradients
+    hd = h.detach().float()
+    hr = hd.double().requires_grad_(True)
+    W2r, b2r = ref[3].detach().clone().requires_grad_(True), ref[4].detach().clone().requires_grad_(True)
+    (torch.nn.functional.linear(hr, W2r, b2r) * gy.double()).sum().backward()
+    hg, W2g, b2g = req(hd), req(W2), req(b2)
+    (ops.mlp(hg, [(W2g, b2g)]) * cu(gy)).sum().backward()
+    for name, a, r in (("gx", hg, hr), ("gW", W2g, W2r), ("gb", b2g, b2r)):
+        assert rel_err(a.grad.cpu(), r.grad.float()) < GTOL, (name, rel_err(a.grad.cpu(), r.grad.float()))
+
+
 def test_made_degree_rule_is_verified_against_the_mask_buffer():
     """MaskedLinear hands the kernels its degree vectors only while the mask buffer equals the degree rule; a mask that
     was overwritten (a checkpoint, a user's own pattern) is read as a tensor again, and the result follows it."""
