@@ -237,10 +237,32 @@ struct WideCtx {                    // what both roles need
   static constexpr int HP = PL::HP, P = PL::P;
 };
 
+// Work items of the persistent backward loop.  A group is 32 elements x 2 quadrature nodes per batch.  When the groups
+// do not fill the last round of the grid (POWER: 1875 groups on 256 CUs = 7.3 rounds, the last one 8 % of the kernel),
+// the elements of that round are dealt as HALF groups instead: 16 elements x 4 nodes per batch -- the element-half bit nh
+// of a pair becomes a node bit -- so a half group needs half the batches, and the partial first-layer sums of its two
+// node halves meet in the group epilogue.
+struct WideSched {
+  int64_t nfull;      // full groups (a multiple of the grid when there are half groups)
+  int64_t nhalf;      // half groups behind them (<= grid), element base 32 nfull + 16 h
+};
+__host__ __device__ inline WideSched wide_sched(int64_t ecount, int64_t grid) {
+  const int64_t g32 = (ecount + kGE - 1) / kGE;
+  const int64_t tail = g32 % grid;
+  WideSched w{g32, 0};
+  if (tail != 0 && g32 > grid) {
+    const int64_t nfull = g32 - tail;
+    const int64_t nhalf = (ecount - nfull * kGE + 15) / 16;
+    if (nhalf <= grid) { w.nfull = nfull; w.nhalf = nhalf; }
+  }
+  return w;
+}
+
 // Per-group epilogue, all 8 wavefronts, behind the [Ds written] barrier: rows 0..31 of the input-1 buffer hold Ds (the
 // first layer's dpre summed over the nodes) of the group's elements -> Dsum rows (for d W1h, d b1) and dh
 template <int HT, int NH>
-__device__ __forceinline__ void group_epilogue(const MonoArgs& a, float* smem, int64_t grp, int64_t erows, int wave, int q, int j) {
+__device__ __forceinline__ void group_epilogue(const MonoArgs& a, float* smem, int64_t ebase, bool half, int64_t erows, int wave,
+                                               int q, int j) {
   using PL = WidePlan<HT, NH>;
   constexpr int HP = PL::HP, P = PL::P, MF = HT / 2, XT = HT & 1;
   const MonoLayout& L = a.L;
@@ -254,14 +276,24 @@ __device__ __forceinline__ void group_epilogue(const MonoArgs& a, float* smem, i
     wg_barrier();
   }
   constexpr int C4 = HP / 4;
-  for (int idx = threadIdx.x; idx < kGE * C4; idx += blockDim.x) {
+  if (half) {                       // rows 16.. hold the second node half of elements 0..15
+    for (int idx = threadIdx.x; idx < 16 * C4; idx += blockDim.x) {
+      const int el = idx / C4, c4 = idx - el * C4;
+      float* p0 = d0 + el * P + 4 * c4;
+      *reinterpret_cast<f32x4*>(p0) = ld4(p0) + ld4(p0 + 16 * P);
+    }
+    wg_barrier();
+  }
+  const int nel = half ? 16 : kGE;
+  for (int idx = threadIdx.x; idx < nel * C4; idx += blockDim.x) {
     const int el = idx / C4, c4 = idx - el * C4;
-    const int64_t row = grp * kGE + el;
+    const int64_t row = ebase + el;
     if (row < erows) *reinterpret_cast<f32x4*>(a.Dsum + row * HP + 4 * c4) = ld4(d0 + el * P + 4 * c4);
   }
   // dh[el][cc] = sum_u W1h[u][cc] Ds[el][u]: (c tile, element half) pairs dealt over the wavefronts
   for (int idx = wave; idx < 2 * (L.CP / 16); idx += kWideWaves) {
     const int ct = idx >> 1, eh = idx & 1;
+    if (half && eh) continue;
     f32x4 o = f32x4{0.f, 0.f, 0.f, 0.f};
     const float* dr = d0 + (16 * eh + j) * P + 4 * q;
 #pragma unroll
@@ -271,7 +303,7 @@ __device__ __forceinline__ void group_epilogue(const MonoArgs& a, float* smem, i
 #pragma unroll
       for (int r = 0; r < 4; ++r) o = mfma(A[r], Bv[r], o);
     }
-    const int64_t el = grp * kGE + 16 * eh + j;
+    const int64_t el = ebase + 16 * eh + j;
     if (el < a.ecount) {
       const int64_t e = a.e0 + el;
       const int64_t b = e / a.d, i = e - b * a.d;
@@ -290,7 +322,7 @@ __device__ __forceinline__ void group_epilogue(const MonoArgs& a, float* smem, i
 // weight-gradient role (wavefronts 4..7): accumulator tiles per DwDeal, all layers, for the whole persistent loop
 // =========================================================================================================================
 template <int HT, int NH, int W>
-__device__ __forceinline__ void dw_role(const MonoArgs& a, float* smem, int w, int64_t ngroups, int64_t erows, int wave,
+__device__ __forceinline__ void dw_role(const MonoArgs& a, float* smem, int w, WideSched ws, int64_t erows, int wave,
                                         int q, int j, float* prow_g) {
   using PL = WidePlan<HT, NH>;
   using D = DwDeal<HT, W>;
@@ -307,10 +339,14 @@ __device__ __forceinline__ void dw_role(const MonoArgs& a, float* smem, int w, i
   }
   const float* dsrc = smem + PL::o_dp + q * P + 16 * ti0 + j;
   const int aroff = q * P + 16 * tn0 + j;
-  for (int64_t grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
+  for (int64_t grp = blockIdx.x; grp < ws.nfull + ws.nhalf; grp += gridDim.x) {
+    const bool half = grp >= ws.nfull;                // (one round of half groups: workgroup b takes half group b)
+    const int64_t ebase = half ? ws.nfull * kGE + 16 * (grp - ws.nfull) : grp * kGE;
+    const int nbat = half ? (a.NK + 3) / 4 : a.NK / 2;
     wg_barrier();                                     // c1 written
-    for (int k0 = 0; k0 < a.NK; k0 += 2) {
+    for (int bt = 0; bt < nbat; ++bt) {
       const int lane = threadIdx.x & 63;
+      const int k0 = 2 * bt;
       STAMP_SEL(grp, k0);
       STAMP(0);
 #pragma unroll
@@ -326,7 +362,7 @@ __device__ __forceinline__ void dw_role(const MonoArgs& a, float* smem, int w, i
       }
     }
     wg_barrier();                                     // Ds written
-    group_epilogue<HT, NH>(a, smem, grp, erows, wave, q, j);
+    group_epilogue<HT, NH>(a, smem, ebase, half, erows, wave, q, j);
   }
   if (D::bias_rt(w)) {
 #pragma unroll
@@ -374,7 +410,7 @@ __global__ __launch_bounds__(64 * kWideWaves, 1) void mono_bwd_wide_k(MonoArgs a
   if (threadIdx.x == 0) smem[PL::o_bL] = a.pack[L.o_bL];
   // (the first barrier of the group loop orders these stores before their readers)
 
-  const int64_t ngroups = (a.ecount + kGE - 1) / kGE;
+  const WideSched ws = wide_sched(a.ecount, gridDim.x);
   const int64_t erows = (a.ecount + 15) / 16 * 16;    // Dsum rows the caller's column sums read
   const int64_t vecw = (NH + 2) * HP + 4;
   float* const prow_g = a.part + ((int64_t)blockIdx.x * kWaves + (wave & 3)) * vecw;   // one row per pair of wavefronts
@@ -382,13 +418,13 @@ __global__ __launch_bounds__(64 * kWideWaves, 1) void mono_bwd_wide_k(MonoArgs a
   if (wave >= 4) {
     const int w = wave - 4;
     if constexpr (XT == 0) {
-      dw_role<HT, NH, -1>(a, smem, w, ngroups, erows, wave, q, j, prow_g);
+      dw_role<HT, NH, -1>(a, smem, w, ws, erows, wave, q, j, prow_g);
     } else {
       switch (w) {
-        case 0: dw_role<HT, NH, 0>(a, smem, w, ngroups, erows, wave, q, j, prow_g); break;
-        case 1: dw_role<HT, NH, 1>(a, smem, w, ngroups, erows, wave, q, j, prow_g); break;
-        case 2: dw_role<HT, NH, 2>(a, smem, w, ngroups, erows, wave, q, j, prow_g); break;
-        default: dw_role<HT, NH, 3>(a, smem, w, ngroups, erows, wave, q, j, prow_g); break;
+        case 0: dw_role<HT, NH, 0>(a, smem, w, ws, erows, wave, q, j, prow_g); break;
+        case 1: dw_role<HT, NH, 1>(a, smem, w, ws, erows, wave, q, j, prow_g); break;
+        case 2: dw_role<HT, NH, 2>(a, smem, w, ws, erows, wave, q, j, prow_g); break;
+        default: dw_role<HT, NH, 3>(a, smem, w, ws, erows, wave, q, j, prow_g); break;
       }
     }
     return;
@@ -418,9 +454,14 @@ __global__ __launch_bounds__(64 * kWideWaves, 1) void mono_bwd_wide_k(MonoArgs a
   }
   const float fS = (float)a.S;
 
-  for (int64_t grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
-    // ---- the lane's element
-    const int64_t el = grp * kGE + 16 * nh + j;
+  for (int64_t grp = blockIdx.x; grp < ws.nfull + ws.nhalf; grp += gridDim.x) {
+    // ---- the lane's element.  Half group: both element halves nh hold elements 0..15 and nh is a node bit instead
+    const bool half = grp >= ws.nfull;
+    const int64_t ebase = half ? ws.nfull * kGE + 16 * (grp - ws.nfull) : grp * kGE;
+    const int nbat = half ? (a.NK + 3) / 4 : a.NK / 2;
+    const int knh = half ? 2 * nh : 0;                // node offset of this element half inside a batch
+    const int kstep = half ? 4 : 2;
+    const int64_t el = ebase + (half ? j : 16 * nh + j);
     const bool valid = el < a.ecount;
     const int64_t e = a.e0 + (valid ? el : a.ecount - 1);
     const float xv = a.x[e];
@@ -459,6 +500,7 @@ __global__ __launch_bounds__(64 * kWideWaves, 1) void mono_bwd_wide_k(MonoArgs a
 #pragma unroll
     for (int mi = 0; mi < MT; ++mi) Ds[mi] = f32x4{0.f, 0.f, 0.f, 0.f};
     float fjac = 0.f;
+    bool sawj = false;                                // this wavefront's pairs include the Jacobian node of its element
 
     // The node loop is software-pipelined by one serial section: the input of hidden layer 1 (rank-1 in x_k) of batch
     // k0 + 2 is computed at the END of batch k0 -- in front of the barrier at which the chain wavefronts wait for the
@@ -470,7 +512,7 @@ __global__ __launch_bounds__(64 * kWideWaves, 1) void mono_bwd_wide_k(MonoArgs a
     auto node_params = [&](int k0) {
 #pragma unroll
       for (int sl = 0; sl < 2; ++sl) {
-        const int k = k0 + sl;
+        const int k = k0 + knh + sl;
         const bool isq = k <= a.S;
         isj[sl] = k == a.S + 1;
         const float wk = isq ? a.ccw[k] : 0.f, tk = isq ? a.cct[k] : 0.f;
@@ -497,7 +539,8 @@ __global__ __launch_bounds__(64 * kWideWaves, 1) void mono_bwd_wide_k(MonoArgs a
     layer0(opaque_v(ucol_c), opaque_v(xcol_c));
     frag_prefetch<HT, MF, XT>(rs, 16 * lane, opaque_s(4 * (L.o_Wf[1] + m0 * HT * 256)), opaque_s(4 * (L.o_Wf[1] + MF * HT * 256)), Apre);
 
-    for (int k0 = 0; k0 < a.NK; k0 += 2) {
+    for (int bt = 0; bt < nbat; ++bt) {
+      const int k0 = kstep * bt;
       const int ucol = opaque_v(ucol_c), xcol = opaque_v(xcol_c);   // (see opaque_v)
       STAMP_SEL(grp, k0);
       STAMP(0);
@@ -578,7 +621,7 @@ __global__ __launch_bounds__(64 * kWideWaves, 1) void mono_bwd_wide_k(MonoArgs a
 #pragma unroll
       for (int sl = 0; sl < 2; ++sl) {
         const float s = (sred[kGE * sl + 16 * nh + j] + sred[kNP + kGE * sl + 16 * nh + j]) + smem[PL::o_bL];
-        if (isj[sl]) fjac = elu_plus(s);
+        if (isj[sl]) { fjac = elu_plus(s); sawj = true; }
         dpl[sl] = cot[sl] * (s > 0.f ? 1.f : expf(s));
       }
       const float dplx = mh ? dpl[1] : dpl[0];
@@ -661,8 +704,8 @@ __global__ __launch_bounds__(64 * kWideWaves, 1) void mono_bwd_wide_k(MonoArgs a
         v = qsum(v);
         if (q == 0) sxbuf[mh * kGE + 16 * nh + j] = v;
       }
-      if (k0 + 2 < a.NK) {                            // layer-1 input of the next batch, stored at the top of the loop
-        node_params(k0 + 2);
+      if (bt + 1 < nbat) {                            // layer-1 input of the next batch, stored at the top of the loop
+        node_params(k0 + kstep);
         layer0(ucol, xcol);
       }
       STAMP(30);
@@ -678,8 +721,8 @@ __global__ __launch_bounds__(64 * kWideWaves, 1) void mono_bwd_wide_k(MonoArgs a
         *reinterpret_cast<f32x4*>(d1 + (mi < MF ? prow : xrow) + col(mi, ucol_c, xcol_c)) = Ds[mi];
     }
     wg_barrier();                                     // Ds written
-    group_epilogue<HT, NH>(a, smem, grp, erows, wave, q, j);
-    if (mh == 0 && q == 0 && valid && a.gx)           // Leibniz rule: dz/dx = f(x; h);  + gjac df/dx(x; h) (its cotangent was gjac)
+    group_epilogue<HT, NH>(a, smem, ebase, half, erows, wave, q, j);
+    if (mh == 0 && q == 0 && valid && sawj && a.gx)   // Leibniz rule: dz/dx = f(x; h);  + gjac df/dx(x; h) (its cotangent was gjac)
       a.gx[e] = gz * fjac + (sxbuf[16 * nh + j] + sxbuf[kGE + 16 * nh + j]);
     // (the [c1 written] barrier of the next group orders these reads before the next writes of the buffers)
   }

@@ -971,10 +971,15 @@ def test_baseline_configs_train_step(name, B):
 
 
 @pytest.mark.parametrize("B,d,hidden", [(1, 1, [50, 50, 50]), (3, 7, [50, 50, 50]), (5, 13, [100, 100, 100]),
-                                        (2, 9, [150, 150]), (70, 3, [100, 100, 100])])
+                                        (2, 9, [150, 150]), (70, 3, [100, 100, 100]),
+                                        # more than one round of the 256 persistent workgroups with a ragged last round:
+                                        # 8238 elements = 256 full groups of 32 + three HALF groups (16 elements x 4 nodes
+                                        # per batch, the last one with 14 elements); 8220 = 256 + two half groups
+                                        (1373, 6, [100, 100, 100]), (1370, 6, [150, 150])])
 def test_monotonic_ragged_sizes(B, d, hidden):
     """element counts that leave wavefronts of the last workgroup without a group of their own (and the wide-net
-    weight-swapping mode, whose workgroups iterate in lockstep) -- regression for a staging clobber by tail waves."""
+    weight-swapping mode, whose workgroups iterate in lockstep) -- regression for a staging clobber by tail waves; the
+    wide nets' backward deals the elements of an unfilled last round as half groups (gnf_monotonic_wide.hip, WideSched)."""
     from models import MonotonicNormalizer
     torch.manual_seed(B * 100 + d)
     c, S = 30, 20
