@@ -787,12 +787,16 @@ __global__ __launch_bounds__(64 * kWaves, 2) void mono_fwd_wide_k(MonoArgs a) {
   const int prow = (16 * nh + j) * P, xrow = prow + mh * kGE * P;
   const int ucol_c = 16 * m0 + 4 * q, xcol_c = 16 * MF + 4 * q;
   auto col = [&](int mi, int uc, int xc) { return mi < MF ? uc + 16 * mi : xc; };
-  const int64_t ngroups = (a.n + kGE - 1) / kGE;
+  const WideSched ws = wide_sched(a.n, gridDim.x);      // (an unfilled last round is dealt as half groups, see WideSched)
   const float fS = (float)a.S;
   const int NK = (a.S + 2 + 1) / 2 * 2;
 
-  for (int64_t grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
-    const int64_t el = grp * kGE + 16 * nh + j;
+  for (int64_t grp = blockIdx.x; grp < ws.nfull + ws.nhalf; grp += gridDim.x) {
+    const bool half = grp >= ws.nfull;
+    const int64_t ebase = half ? ws.nfull * kGE + 16 * (grp - ws.nfull) : grp * kGE;
+    const int nbat = half ? (NK + 3) / 4 : NK / 2;
+    const int knh = half ? 2 * nh : 0, kstep = half ? 4 : 2;
+    const int64_t el = ebase + (half ? j : 16 * nh + j);
     const bool valid = el < a.n;
     const int64_t e = valid ? el : a.n - 1;
     const int64_t b = e / a.d, i = e - b * a.d;
@@ -831,7 +835,7 @@ __global__ __launch_bounds__(64 * kWaves, 2) void mono_fwd_wide_k(MonoArgs a) {
     auto node_params = [&](int k0) {
 #pragma unroll
       for (int sl = 0; sl < 2; ++sl) {
-        const int k = k0 + sl;
+        const int k = k0 + knh + sl;
         const bool isq = k <= a.S;
         isj[sl] = k == a.S + 1;
         wq[sl] = isq ? a.ccw[k] : 0.f;
@@ -865,7 +869,8 @@ __global__ __launch_bounds__(64 * kWaves, 2) void mono_fwd_wide_k(MonoArgs a) {
     frag_prefetch<HT, MF, XT>(rs, 16 * lane, opaque_s(4 * (L.o_Wf[1] + m0 * HT * 256)), opaque_s(4 * (L.o_Wf[1] + MF * HT * 256)), Apre);
     float zacc = 0.f, fjac = 0.f;
 
-    for (int k0 = 0; k0 < NK; k0 += 2) {
+    for (int bt = 0; bt < nbat; ++bt) {
+      const int k0 = kstep * bt;
       const int ucol = opaque_v(ucol_c), xcol = opaque_v(xcol_c);
       store_act(ucol, xcol);                          // input of hidden layer 1 (computed ahead)
       __syncthreads();
@@ -924,12 +929,18 @@ __global__ __launch_bounds__(64 * kWaves, 2) void mono_fwd_wide_k(MonoArgs a) {
         zacc = fmaf(wq[sl], f, zacc);
         if (isj[sl]) fjac = f;
       }
-      if (k0 + 2 < NK) {
-        node_params(k0 + 2);
+      if (bt + 1 < nbat) {
+        node_params(k0 + kstep);
         layer0(ucol, xcol);
       }
     }
-    if (valid && mh == 0 && q == 0) {
+    if (half) {                                       // the two node halves of an element meet (nh = 1 -> nh = 0)
+      __syncthreads();                                // the last batch's partial dots are read
+      if (nh == 1 && mh == 0 && q == 0) { sred[j] = zacc; sred[16 + j] = fjac; }
+      __syncthreads();
+      if (nh == 0) { zacc += sred[j]; fjac += sred[16 + j]; }   // (the Jacobian node was in one half: the other holds 0)
+    }
+    if (valid && mh == 0 && q == 0 && (!half || nh == 0)) {
       a.z[el] = zacc * xT * .5f + h0;
       a.jac[el] = fjac;
     }

@@ -1001,6 +1001,24 @@ def test_monotonic_ragged_sizes(B, d, hidden):
         assert rel_err(pw.grad.cpu(), W.grad) < GTOL and rel_err(pb.grad.cpu(), b.grad) < GTOL
 
 
+@pytest.mark.parametrize("B,d,hidden", [(4100, 6, [100, 100, 100]), (4099, 4, [150, 150])])
+def test_monotonic_forward_half_groups(B, d, hidden):
+    """the wide nets' forward kernel runs up to three persistent workgroups per CU; element counts just above a whole
+    number of rounds (24 600 = 768 groups of 32 + two half groups; 16 396 = 512 + two, the second with 12 elements) take
+    the half-group path (16 elements x 4 nodes per batch, the two node halves of an element summed in LDS)."""
+    from models import MonotonicNormalizer
+    torch.manual_seed(B + d)
+    c, S = 30, 20
+    norm = MonotonicNormalizer(hidden, c, nb_steps=S)
+    x, h = torch.randn(B, d) * 1.5, torch.randn(B, d, c)
+    with torch.no_grad():
+        z0, j0 = O.monotonic_forward(x, h, _layers_cpu(norm), S)
+        z, jac = norm.to(DEV)(cu(x), cu(h))
+    assert rel_err(z.cpu(), z0) < TOL and rel_err(jac.cpu(), j0) < TOL
+    assert_close(z, z0, atol=3e-6, what="z")
+    assert_close(jac, j0, what="jac")
+
+
 def test_train_uci_driver_and_checkpoint_formats(tmp_path):
     """train_uci.py (UCIExperiments.py's role): two epochs on synthetic POWER-shaped data; model.pt carries the
     reference's state_dict keys and ADAM.pt loads into torch.optim.Adam(model.parameters())."""
