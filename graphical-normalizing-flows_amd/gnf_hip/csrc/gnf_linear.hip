@@ -382,7 +382,8 @@ extern "C" {
 int64_t gnf_linear_ws_bytes(int64_t M, int64_t N, int64_t K) {
   int64_t w = gnf_gemm_ws_bytes(M, N, K);
   const int64_t w2 = gnf_gemm_ws_bytes(M, K, N), w3 = gnf_gemm_ws_bytes(N, K, M), w4 = gnf_colsum_ws_bytes(M, N);
-  w = w > w2 ? w : w2; w = w > w3 ? w : w3; w = w > w4 ? w : w4;
+  const int64_t w6 = gnf_colsum_ws_bytes(M, K);
+  w = w > w2 ? w : w2; w = w > w3 ? w : w3; w = w > w4 ? w : w4; w = w > w6 ? w : w6;
   if (gnf_linear_tall_ok(M, N, K)) {
     const int64_t w5 = gnf_linear_tall_ws_floats(M, N, K) * (int64_t)sizeof(float);
     w = w > w5 ? w : w5;
@@ -454,10 +455,16 @@ int gnf_linear_bwd_w(const float* g, const float* a, const float* mask, const fl
   return gnf_colsum(g, N, gb, M, N, ws, stream);
 }
 
-// both gradients of one layer (gnf_linear_bwd_w + gnf_linear_bwd_x, same arguments); small batches: ONE launch
+// 1 when gnf_linear_bwd produces `gxsum` in the launch that produces gx (else it costs a column-sum pass over gx)
+int gnf_linear_gxsum_fused(int64_t M, int64_t N, int64_t K, int masked) {
+  return (!masked && gnf_linear_tall_ok(M, N, K)) ? 1 : 0;
+}
+
+// both gradients of one layer (gnf_linear_bwd_w + gnf_linear_bwd_x, same arguments); small and tall-narrow batches: ONE
+// launch.  gxsum (may be NULL): column sums of gx, i.e. the bias gradient of the layer that produced `a`.
 int gnf_linear_bwd(const float* g, const float* W, const float* a, const float* mask, const float* deg_out,
-                   const float* deg_in, int strict, const float* gate, float* gx, float* gW, float* gb, int64_t M,
-                   int64_t N, int64_t K, float* ws, int64_t ws_bytes, gnf_stream_t stream) {
+                   const float* deg_in, int strict, const float* gate, float* gx, float* gW, float* gb, float* gxsum,
+                   int64_t M, int64_t N, int64_t K, float* ws, int64_t ws_bytes, gnf_stream_t stream) {
   if (M < 0 || N <= 0 || K <= 0) return GNF_EINVAL;
   if (!gW || (M > 0 && (!g || !a || !W || !gx)) || (!deg_out) != (!deg_in)) return GNF_EINVAL;
   static const bool split = getenv("GNF_LINEAR_BWD_SPLIT") && getenv("GNF_LINEAR_BWD_SPLIT")[0] == '1';   // A/B switch
@@ -471,15 +478,24 @@ int gnf_linear_bwd(const float* g, const float* W, const float* a, const float* 
     else if (kind == MK_FULL) hipLaunchKernelGGL((lin_bwd_both_k<MK_FULL>), grid, dim3(512), 0, (hipStream_t)stream, g, W, a, mk, gate, gx, gW, gb, (int)M, (int)N, (int)K, nbx, wgx, xgx);
     else hipLaunchKernelGGL((lin_bwd_both_k<MK_NONE>), grid, dim3(512), 0, (hipStream_t)stream, g, W, a, mk, gate, gx, gW, gb, (int)M, (int)N, (int)K, nbx, wgx, xgx);
     GNF_LAUNCH_CHECK();
+    if (gxsum) {
+      if (ws_bytes < gnf_colsum_ws_bytes(M, K)) return GNF_EWS;
+      return gnf_colsum(gx, K, gxsum, M, K, ws, stream);
+    }
     return 0;
   }
   if (!mask && !deg_out && gnf_linear_tall_ok(M, N, K) && (!gate || gate == a)) {
     if (!ws || ws_bytes < gnf_linear_tall_ws_floats(M, N, K) * (int64_t)sizeof(float)) return GNF_EWS;
-    return gnf_linear_tall_bwd(g, W, a, gate, gx, gW, gb, M, N, K, ws, (hipStream_t)stream);
+    return gnf_linear_tall_bwd(g, W, a, gate, gx, gW, gb, gxsum, M, N, K, ws, (hipStream_t)stream);
   }
   const int rc = gnf_linear_bwd_w(g, a, mask, deg_out, deg_in, strict, gW, gb, M, N, K, ws, ws_bytes, stream);
-  if (rc || M == 0) return rc;                         // an empty batch: zero weight gradients, no rows of gx
-  return gnf_linear_bwd_x(g, W, mask, deg_out, deg_in, strict, gate, gx, M, N, K, ws, ws_bytes, stream);
+  if (rc) return rc;
+  if (M == 0)                                          // an empty batch: zero weight gradients, no rows of gx
+    return gxsum ? (int)hipMemsetAsync(gxsum, 0, sizeof(float) * K, (hipStream_t)stream) : 0;
+  const int rx = gnf_linear_bwd_x(g, W, mask, deg_out, deg_in, strict, gate, gx, M, N, K, ws, ws_bytes, stream);
+  if (rx || !gxsum) return rx;
+  if (ws_bytes < gnf_colsum_ws_bytes(M, K)) return GNF_EWS;
+  return gnf_colsum(gx, K, gxsum, M, K, ws, stream);
 }
 
 }  // extern "C"

@@ -10,6 +10,7 @@ bool gnf_linear_tall_ok(int64_t M, int64_t N, int64_t K);
 int64_t gnf_linear_tall_ws_floats(int64_t M, int64_t N, int64_t K);
 int gnf_linear_tall_fwd(const float* x, const float* W, const float* b, int relu, float* y, int64_t M, int64_t N, int64_t K,
                         hipStream_t s);
-// gx = (g W) o [gate > 0] (gate: the layer's input `a` or NULL), gW = g^T a, gb = colsum g (gb may be NULL)
+// gx = (g W) o [gate > 0] (gate: the layer's input `a` or NULL), gW = g^T a, gb = colsum g (gb may be NULL),
+// gxsum = colsum gx ([K], may be NULL)
 int gnf_linear_tall_bwd(const float* g, const float* W, const float* a, const float* gate, float* gx, float* gW, float* gb,
-                        int64_t M, int64_t N, int64_t K, float* ws, hipStream_t s);
+                        float* gxsum, int64_t M, int64_t N, int64_t K, float* ws, hipStream_t s);

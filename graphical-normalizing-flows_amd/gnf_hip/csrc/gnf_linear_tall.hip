@@ -13,7 +13,8 @@
 //             gb += colsum g over the same tiles in the same order (16 accumulator tiles at K = 128: interleaved
 //             columns, unit 64 blk + 4 j + c in lane j of tile c, so that a lane's dwordx4 of an `a` row serves four
 //             tiles) -- the second reader of a tile finds it in L2.  Partials per workgroup, summed in fixed order by
-//             lin_tall_reduce_k.  g rows are 120 B: dwordx4 at dword alignment, through a bounds-checked buffer
+//             lin_tall_reduce_k -- which also returns the column sums of gx when the caller asks (the bias gradient of the
+//             layer below: fc1's, a 40 MB column-sum pass otherwise).  g rows are 120 B: dwordx4 at dword alignment, through a bounds-checked buffer
 //             descriptor (the last row's overhang reads zeros).
 #include "gnf_common.h"
 #include "gnf_linear_tall.h"
@@ -35,25 +36,30 @@ __device__ __forceinline__ f32x4 mfma(float a, float b, f32x4 c) {
 // first floats when ncols is not a multiple of 4, or a whole chunk of padding) cleared
 typedef __amdgpu_buffer_rsrc_t rsrc_t;
 __device__ __forceinline__ f32x4 ldrow(rsrc_t rs, int r, int ncols, int c0) {
-  f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
-  if (c0 < ncols) {
-    const u32x4 u = __builtin_amdgcn_raw_buffer_load_b128(rs, (r * ncols + c0) * 4, 0, 0);
-    v = __builtin_bit_cast(f32x4, u);
+  // always issued (no branch around a load: the requests of a tile must go out back to back); what lies outside the
+  // row is cleared afterwards
+  const u32x4 u = __builtin_amdgcn_raw_buffer_load_b128(rs, (r * ncols + c0) * 4, 0, 0);
+  f32x4 v = __builtin_bit_cast(f32x4, u);
 #pragma unroll
-    for (int k = 1; k < 4; ++k)
-      if (c0 + k >= ncols) v[k] = 0.f;
-  }
+  for (int k = 0; k < 4; ++k) v[k] = c0 + k < ncols ? v[k] : 0.f;
   return v;
+}
+// a row whose length is a whole number of 16-wide chunks (KX instantiations): a plain 16-B aligned global load
+template <bool KX>
+__device__ __forceinline__ f32x4 ldrowx(const float* base, rsrc_t rs, int r, int ncols, int c0) {
+  if constexpr (KX) return *reinterpret_cast<const f32x4*>(base + (int64_t)r * ncols + c0);
+  else return ldrow(rs, r, ncols, c0);
 }
 __device__ __forceinline__ rsrc_t mkrsrc(const float* p, int64_t floats) {
   return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p), 0, (int)(floats * 4), 0x00020000);
 }
 
 // ------------------------------------------------------------------------------------------------------------- forward
-template <int NT, int KC>           // N <= 16 NT out units, K <= 16 KC inputs
+template <int NT, int KC, bool KX>  // N <= 16 NT out units, K <= 16 KC inputs (KX: K == 16 KC exactly)
 __global__ __launch_bounds__(256) void lin_fwd_tall_k(const float* __restrict__ x, const float* __restrict__ W,
                                                       const float* __restrict__ bias, int relu, float* __restrict__ y,
-                                                      int M, int N, int K) {
+                                                      int M, int N, int Krt) {
+  const int K = KX ? 16 * KC : Krt;                   // a compile-time row pitch in the exact instantiations
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int q = lane >> 4, j = lane & 15;
   const rsrc_t rx = mkrsrc(x, (int64_t)M * K), rw = mkrsrc(W, (int64_t)N * K);
@@ -74,7 +80,7 @@ __global__ __launch_bounds__(256) void lin_fwd_tall_k(const float* __restrict__ 
     const int row = 16 * tl + j;
     const int rc = row < M ? row : M - 1;
 #pragma unroll
-    for (int t = 0; t < KC; ++t) dst[t] = ldrow(rx, rc, K, 16 * t + 4 * q);
+    for (int t = 0; t < KC; ++t) dst[t] = ldrowx<KX>(x, rx, rc, K, 16 * t + 4 * q);
   };
   if (tile < ntiles) load(tile, xv);
   for (; tile < ntiles; tile += stride) {
@@ -117,13 +123,15 @@ __global__ __launch_bounds__(256) void lin_fwd_tall_k(const float* __restrict__ 
 }
 
 // ------------------------------------------------------------------------------------------------------------ backward
-template <int NT, int KC>
+template <int NT, int KC, bool KX>
 __global__ __launch_bounds__(512, 1) void lin_bwd_tall_k(const float* __restrict__ g, const float* __restrict__ W,
                                                          const float* __restrict__ a, int gated, float* __restrict__ gx,
-                                                         float* __restrict__ part, int M, int N, int K) {
+                                                         float* __restrict__ part, int M, int N, int Krt, int want_xsum) {
+  const int K = KX ? 16 * KC : Krt;                   // a compile-time row pitch in the exact instantiations
   constexpr int KB = (KC + 3) / 4;                    // 64-column blocks of the weight-gradient role
   __shared__ f32x4 red[4][NT * KB * 4][64];           // the four weight-gradient wavefronts' accumulators
   __shared__ float redb[4][NT][16];
+  __shared__ float redx[4][16 * KC];                  // column sums of gx (the bias gradient of the layer below)
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int q = lane >> 4, j = lane & 15;
   const int ntiles = (M + 15) / 16;
@@ -142,7 +150,9 @@ __global__ __launch_bounds__(512, 1) void lin_bwd_tall_k(const float* __restrict
           const int o = 16 * t + 4 * q + r, i = 16 * it + j;
           wa[it][t][r] = (o < N && i < K) ? W[(int64_t)o * K + i] : 0.f;
         }
-    f32x4 gv[NT], av[KC];
+    f32x4 gv[NT], av[KC], xs[KC];
+#pragma unroll
+    for (int it = 0; it < KC; ++it) xs[it] = f32x4{0.f, 0.f, 0.f, 0.f};
     auto load = [&](int tl, f32x4* gd, f32x4* ad) {
       const int row = 16 * tl + j;
       const int rc = row < M ? row : M - 1;
@@ -150,7 +160,7 @@ __global__ __launch_bounds__(512, 1) void lin_bwd_tall_k(const float* __restrict
       for (int t = 0; t < NT; ++t) gd[t] = ldrow(rg, rc, N, 16 * t + 4 * q);
       if (gated) {
 #pragma unroll
-        for (int it = 0; it < KC; ++it) ad[it] = ldrow(ra, rc, K, 16 * it + 4 * q);
+        for (int it = 0; it < KC; ++it) ad[it] = ldrowx<KX>(a, ra, rc, K, 16 * it + 4 * q);
       }
     };
     int tile = blockIdx.x * 4 + wave;
@@ -173,7 +183,10 @@ __global__ __launch_bounds__(512, 1) void lin_bwd_tall_k(const float* __restrict
           for (int r = 0; r < 4; ++r) acc[r] = av[it][r] > 0.f ? acc[r] : 0.f;
         }
         const int c0 = 16 * it + 4 * q;               // K is a multiple of 4: a quad is inside the row or outside
-        if (row < M && c0 < K) *reinterpret_cast<f32x4u*>(xr + c0) = acc;
+        if (row < M && c0 < K) {
+          *reinterpret_cast<f32x4u*>(xr + c0) = acc;
+          xs[it] += acc;
+        }
       }
       if (more) {
 #pragma unroll
@@ -181,6 +194,16 @@ __global__ __launch_bounds__(512, 1) void lin_bwd_tall_k(const float* __restrict
 #pragma unroll
         for (int it = 0; it < KC; ++it) av[it] = an[it];
       }
+    }
+    if (want_xsum) {                                  // rows live in the lanes j: sum over them, lane (q, 0) holds units 4 q + r
+#pragma unroll
+      for (int it = 0; it < KC; ++it)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float v = xs[it][r];
+          v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 8, 64);
+          if (j == 0) redx[wave][16 * it + 4 * q + r] = v;
+        }
     }
     __syncthreads();
   } else {
@@ -206,7 +229,7 @@ __global__ __launch_bounds__(512, 1) void lin_bwd_tall_k(const float* __restrict
 #pragma unroll
         for (int ot = 0; ot < NT; ++ot) gd[ot][r] = (16 * ot + j < N) ? g[(int64_t)rc * N + 16 * ot + j] : 0.f;
 #pragma unroll
-        for (int b = 0; b < KB; ++b) ad[b][r] = ldrow(ra, rc, K, 64 * b + 4 * j);
+        for (int b = 0; b < KB; ++b) ad[b][r] = ldrowx<(KX && KC % 4 == 0)>(a, ra, rc, K, 64 * b + 4 * j);
       }
     };
     int tile = blockIdx.x * 4 + w;
@@ -253,7 +276,10 @@ __global__ __launch_bounds__(512, 1) void lin_bwd_tall_k(const float* __restrict
     __syncthreads();
   }
   // ---- the workgroup's partial: [N][K] weights then [N] biases, the four wavefronts summed in fixed order
-  float* prow = part + (int64_t)blockIdx.x * ((int64_t)N * K + N);
+  float* prow = part + (int64_t)blockIdx.x * ((int64_t)N * K + N + K);
+  if (want_xsum)
+    for (int i = threadIdx.x; i < K; i += blockDim.x)
+      prow[(int64_t)N * K + N + i] = ((redx[0][i] + redx[1][i]) + redx[2][i]) + redx[3][i];
   for (int idx = threadIdx.x; idx < NT * KB * 4 * 64; idx += blockDim.x) {
     // item (ot, blk, r, lane): the lane's four interleaved tiles c hold four consecutive columns
     const int ln = idx & 63, r = (idx >> 6) & 3, b = (idx >> 8) % KB, ot = (idx >> 8) / KB;
@@ -277,13 +303,14 @@ __global__ __launch_bounds__(512, 1) void lin_bwd_tall_k(const float* __restrict
 // gW / gb <- the workgroups' partials, summed in a fixed order (deterministic): 64 columns per workgroup, wavefront w of 16
 // sums the partial rows w, w + 16, ... (four independent chains), the 16 sums meet in LDS
 __global__ __launch_bounds__(1024) void lin_tall_reduce_k(const float* __restrict__ part, int nparts, int64_t nw, int64_t nb,
-                                                          float* __restrict__ gW, float* __restrict__ gb) {
+                                                          int64_t nx, int64_t ncols, float* __restrict__ gW,
+                                                          float* __restrict__ gb, float* __restrict__ gxs) {
   __shared__ float red[16][64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int64_t i = (int64_t)blockIdx.x * 64 + lane;
-  const int64_t ld = nw + nb;
+  const int64_t ld = nw + nb + nx;                      // row pitch; the first ncols columns are summed
   float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-  if (i < ld) {
+  if (i < ncols) {
     const float* p = part + i;
     int b = wave;
     for (; b + 48 < nparts; b += 64) {
@@ -293,12 +320,13 @@ __global__ __launch_bounds__(1024) void lin_tall_reduce_k(const float* __restric
   }
   red[wave][lane] = (s0 + s1) + (s2 + s3);
   __syncthreads();
-  if (wave == 0 && i < ld) {
+  if (wave == 0 && i < ncols) {
     float s = red[0][lane];
 #pragma unroll
     for (int w = 1; w < 16; ++w) s += red[w][lane];
     if (i < nw) gW[i] = s;
-    else if (gb) gb[i - nw] = s;
+    else if (i < nw + nb) { if (gb) gb[i - nw] = s; }
+    else gxs[i - nw - nb] = s;
   }
 }
 
@@ -315,17 +343,19 @@ bool gnf_linear_tall_ok(int64_t M, int64_t N, int64_t K) {
   return !off && M >= 2048 && N >= 1 && N <= 64 && K >= 4 && K <= 128 && K % 4 == 0 && M * (K > N ? K : N) * 4 < (1ll << 31);
 }
 
-int64_t gnf_linear_tall_ws_floats(int64_t M, int64_t N, int64_t K) { return (int64_t)tall_grid(M) * (N * K + N); }
+int64_t gnf_linear_tall_ws_floats(int64_t M, int64_t N, int64_t K) { return (int64_t)tall_grid(M) * (N * K + N + K); }
 
 namespace {
 template <int NT, int KC>
 void launch_tall_fwd(dim3 g, hipStream_t s, const float* x, const float* W, const float* b, int relu, float* y, int M, int N, int K) {
-  hipLaunchKernelGGL((lin_fwd_tall_k<NT, KC>), g, dim3(256), 0, s, x, W, b, relu, y, M, N, K);
+  if (K == 16 * KC) hipLaunchKernelGGL((lin_fwd_tall_k<NT, KC, true>), g, dim3(256), 0, s, x, W, b, relu, y, M, N, K);
+  else hipLaunchKernelGGL((lin_fwd_tall_k<NT, KC, false>), g, dim3(256), 0, s, x, W, b, relu, y, M, N, K);
 }
 template <int NT, int KC>
 void launch_tall_bwd(dim3 g, hipStream_t s, const float* gr, const float* W, const float* a, int gated, float* gx, float* part,
-                     int M, int N, int K) {
-  hipLaunchKernelGGL((lin_bwd_tall_k<NT, KC>), g, dim3(512), 0, s, gr, W, a, gated, gx, part, M, N, K);
+                     int M, int N, int K, int want_xsum) {
+  if (K == 16 * KC) hipLaunchKernelGGL((lin_bwd_tall_k<NT, KC, true>), g, dim3(512), 0, s, gr, W, a, gated, gx, part, M, N, K, want_xsum);
+  else hipLaunchKernelGGL((lin_bwd_tall_k<NT, KC, false>), g, dim3(512), 0, s, gr, W, a, gated, gx, part, M, N, K, want_xsum);
 }
 // instantiation (out tiles NT in {2, 4}) x (k chunks KC in {1, 4, 8})
 #define GNF_TALL_DISPATCH(fn, N, K, ...)                                        \
@@ -354,14 +384,15 @@ int gnf_linear_tall_fwd(const float* x, const float* W, const float* b, int relu
 }
 
 int gnf_linear_tall_bwd(const float* g, const float* W, const float* a, const float* gate, float* gx, float* gW, float* gb,
-                        int64_t M, int64_t N, int64_t K, float* ws, hipStream_t s) {
+                        float* gxsum, int64_t M, int64_t N, int64_t K, float* ws, hipStream_t s) {
   if (gate && gate != a) return GNF_EINVAL;          // the ReLU gate of a layer IS its input
   const int grid = tall_grid(M);
   const dim3 gd((unsigned)grid);
-  GNF_TALL_DISPATCH(launch_tall_bwd, N, K, gd, s, g, W, a, gate ? 1 : 0, gx, ws, (int)M, (int)N, (int)K);
+  GNF_TALL_DISPATCH(launch_tall_bwd, N, K, gd, s, g, W, a, gate ? 1 : 0, gx, ws, (int)M, (int)N, (int)K, gxsum ? 1 : 0);
   GNF_LAUNCH_CHECK();
-  const int64_t nw = N * K;
-  hipLaunchKernelGGL(lin_tall_reduce_k, dim3((unsigned)((nw + N + 63) / 64)), dim3(1024), 0, s, ws, grid, nw, (int64_t)N, gW, gb);
+  const int64_t nw = N * K, ncols = nw + N + (gxsum ? K : 0);
+  hipLaunchKernelGGL(lin_tall_reduce_k, dim3((unsigned)((ncols + 63) / 64)), dim3(1024), 0, s, ws, grid, nw, (int64_t)N, K, ncols,
+                     gW, gb, gxsum);
   GNF_LAUNCH_CHECK();
   return 0;
 }

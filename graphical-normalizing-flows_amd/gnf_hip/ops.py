@@ -281,6 +281,7 @@ class MLPFn(torch.autograd.Function):
         g = gy.contiguous()
         grads = [None] * (2 * n)
         gx = None
+        gb_ready = None                     # bias gradient of layer li, already produced by layer li + 1's launch
         for li in range(n - 1, -1, -1):
             W = params[2 * li].contiguous()
             out_f, in_f = W.shape
@@ -292,21 +293,29 @@ class MLPFn(torch.autograd.Function):
             want_w, want_b = ctx.needs_input_grad[4 + 2 * li], ctx.needs_input_grad[5 + 2 * li]
             want_x = li > 0 or ctx.needs_input_grad[0]
             gW = grad_out(W) if want_w else None
-            gb = grad_out(params[2 * li + 1]) if (want_w and want_b) else None
+            gb = gb_ready
+            if gb is None and want_w and want_b:
+                gb = grad_out(params[2 * li + 1])
             ga = _empty((M, in_f), W) if want_x else None
             gate = a if (li > 0 or ctx.relu_in) else None
+            gb_next = None
             if want_w and want_x:
-                call("gnf_linear_bwd", ptr(g), ptr(W), ptr(a), mk, do, di, st, ptr(gate), ptr(ga), ptr(gW), ptr(gb), M, out_f,
-                     in_f, ptr(ws), nws, stream())
+                # the column sums of this layer's data gradient ARE the bias gradient of the layer below
+                if (li > 0 and ctx.needs_input_grad[5 + 2 * (li - 1)] and ctx.needs_input_grad[4 + 2 * (li - 1)]
+                        and abi.load().gnf_linear_gxsum_fused(M, out_f, in_f, int(mk is not None or do is not None))):
+                    gb_next = grad_out(params[2 * li - 1])
+                call("gnf_linear_bwd", ptr(g), ptr(W), ptr(a), mk, do, di, st, ptr(gate), ptr(ga), ptr(gW),
+                     None if gb_ready is not None else ptr(gb), ptr(gb_next), M, out_f, in_f, ptr(ws), nws, stream())
             elif want_w:
-                call("gnf_linear_bwd_w", ptr(g), ptr(a), mk, do, di, st, ptr(gW), ptr(gb), M, out_f, in_f, ptr(ws), nws,
-                     stream())
+                call("gnf_linear_bwd_w", ptr(g), ptr(a), mk, do, di, st, ptr(gW), None if gb_ready is not None else ptr(gb), M,
+                     out_f, in_f, ptr(ws), nws, stream())
             elif want_x:
                 call("gnf_linear_bwd_x", ptr(g), ptr(W), mk, do, di, st, ptr(gate), ptr(ga), M, out_f, in_f, ptr(ws), nws,
                      stream())
             grads[2 * li], grads[2 * li + 1] = gW, gb
             if want_b and not want_w:
                 grads[2 * li + 1] = colsum(g)
+            gb_ready = gb_next
             if want_x:
                 g = ga
                 if li == 0:

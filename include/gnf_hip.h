@@ -93,7 +93,10 @@ int gnf_colsum(const float* a, int64_t lda, float* out, int64_t M, int64_t N, fl
  *   bwd_x:  gx = (g (W o mask)) o [gate > 0]                   g: [M,N]; gate: [M,K] (the layer's input) or NULL
  *   bwd_w:  gW = (g^T a) o mask, gb = column sums of g         a: [M,K]; gb: [N] or NULL
  *   bwd:    bwd_w and bwd_x of one layer (what autograd runs for F.linear when both the weight and the input need a
- *           gradient); at M <= 128 the two run side by side in ONE launch
+ *           gradient); at M <= 128, and for tall batches with a narrow output (M >= 2048, N <= 64, K <= 128, no mask:
+ *           MNISTCNN.fc2, DAGMLP), the two run in ONE launch.  gxsum ([K] or NULL): the column sums of gx = the bias
+ *           gradient of the layer that produced `a`; gnf_linear_gxsum_fused() tells whether it comes out of the same
+ *           launch (else: one more pass over gx)
  * ws: >= gnf_linear_ws_bytes(M,N,K) bytes. */
 int64_t gnf_linear_ws_bytes(int64_t M, int64_t N, int64_t K);
 int gnf_linear_fwd(const float* x, const float* W, const float* b, const float* mask, const float* deg_out,
@@ -106,8 +109,9 @@ int gnf_linear_bwd_w(const float* g, const float* a, const float* mask, const fl
                      int strict, float* gW, float* gb, int64_t M, int64_t N, int64_t K,
                      float* ws, int64_t ws_bytes, gnf_stream_t stream);
 int gnf_linear_bwd(const float* g, const float* W, const float* a, const float* mask, const float* deg_out,
-                   const float* deg_in, int strict, const float* gate, float* gx, float* gW, float* gb, int64_t M,
-                   int64_t N, int64_t K, float* ws, int64_t ws_bytes, gnf_stream_t stream);
+                   const float* deg_in, int strict, const float* gate, float* gx, float* gW, float* gb, float* gxsum,
+                   int64_t M, int64_t N, int64_t K, float* ws, int64_t ws_bytes, gnf_stream_t stream);
+int gnf_linear_gxsum_fused(int64_t M, int64_t N, int64_t K, int masked);
 
 /* ---- fp32 MFMA GEMM with fused masks / bias / ReLU ------------------------------------
  * Replaces F.linear(input, mask*weight, bias) (AutoregressiveConditioner.py:24-25), the
