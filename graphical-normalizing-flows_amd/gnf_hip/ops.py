@@ -57,6 +57,30 @@ def grad_out(p):
     return torch.empty_like(p)
 
 
+def grad_out_shared(p):
+    """(tensor, finish) for a parameter that receives SEVERAL gradient contributions per backward (the DAG matrix A: gate
+    and acyclicity term).  The first contribution takes the flat-buffer slot as grad_out does; a later one is written to
+    a scratch tensor and finish() adds it INTO the slot and returns None, so autograd sees one contribution -- the slot --
+    instead of summing two tensors into a third that the gradient pack then copies (add + 2.4 MB copy per cfg4 step).
+    finish(t) returns what the backward hands to autograd."""
+    ent = _grad_slots.get(p.data_ptr()) if _SINK else None
+    owner = ent[0]() if ent is not None else None
+    if owner is not None:
+        i = ent[1]
+        v = owner.grad_views[i]
+        if v.numel() == p.numel() and p.is_contiguous() and v.device == p.device:
+            if i not in owner._taken:
+                owner._taken.add(i)
+                return v.view(p.shape), (lambda t: t)
+            held = owner.params[i].grad          # None inside a backward; a slot view while micro-batches accumulate
+            if held is None or held.data_ptr() == v.data_ptr():
+                def finish(t, v=v):
+                    v.add_(t.reshape(-1))
+                    return None
+                return torch.empty_like(p), finish
+    return torch.empty_like(p), (lambda t: t)
+
+
 # ----------------------------------------------------------------------------- Affine normalizer
 class AffineFn(torch.autograd.Function):
     """(z, jac, logdet, logn) of models/Normalizers/AffineNormalizer.py:9-12 fused with the log|det J| row reduction of
@@ -507,12 +531,12 @@ class DagGateFn(torch.autograd.Function):
         imp_mode, gate_mode, h_thresh, temperature, ld, seed, offset = ctx.cfg
         B, d = x.shape
         ge = ge.contiguous()
-        gA = grad_out(A) if ctx.needs_input_grad[1] else None      # (the flat-buffer slot unless the loss term took it)
+        gA, finish = grad_out_shared(A) if ctx.needs_input_grad[1] else (None, None)
         gx = _empty((B, d), x) if ctx.needs_input_grad[0] else None
         ws = _ws(abi.load().gnf_dag_gate_bwd_ws_bytes(B, d), x)
         call("gnf_dag_gate_bwd", ptr(x), ptr(A), ptr(ge), ld, imp_mode, gate_mode, h_thresh, temperature, ptr(u1),
              ptr(u2), seed, offset, ptr(gA), ptr(gx), ptr(ws), B, d, stream())
-        return gx, gA, None, None, None, None, None, None, None, None, None
+        return gx, (finish(gA) if gA is not None else None), None, None, None, None, None, None, None, None, None
 
 
 # ----------------------------------------------------------------------------- Monotonic (UMNN) normalizer
@@ -769,6 +793,6 @@ class DagLossFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         A, P, out4 = ctx.saved_tensors
-        gA = grad_out(A)
+        gA, finish = grad_out_shared(A)
         call("gnf_dag_loss_bwd", ptr(A), ptr(P), ptr(out4), ptr(g.contiguous().reshape(1)), ptr(gA), A.shape[0], stream())
-        return gA, None, None, None, None, None, None, None
+        return finish(gA), None, None, None, None, None, None, None

@@ -520,3 +520,38 @@ def test_gradients_are_written_into_the_flat_buffer():
     st.pack_grads()
     assert_close(st.grad_views[0].view(16, 16), Wr.grad, rtol=1e-5, atol=1e-5, what="accumulated weight gradient")
     assert_close(st.grad_views[1], br.grad, rtol=1e-5, atol=1e-5, what="accumulated bias gradient")
+
+
+def test_shared_gradient_slot_of_the_dag_matrix():
+    """A receives two gradient contributions per backward (gate and acyclicity term): the first is written into the
+    flat-buffer slot, the second added into it (ops.grad_out_shared) -- one step and two accumulated micro-batches give
+    the parameters of the run that packs fresh tensors (gradient slots off)."""
+    from gnf_hip import dp, ops
+    from models import buildFCNormalizingFlow, DAGConditioner, AffineNormalizer
+    def make():
+        torch.manual_seed(11)
+        f = buildFCNormalizingFlow(1, DAGConditioner, {"in_size": 6, "hidden": [16, 16], "out_size": 2, "l1": .1},
+                                   AffineNormalizer, {}).to(DEV)
+        for c in f.getConditioners():
+            c.stoch_gate = False
+        return f
+    x = torch.randn(12, 6, device=DEV)
+
+    def run(flow):
+        st = dp.FlatState(flow)
+        dp.train_step(flow, st, x, graph=False)
+        stats = dict(st.pack_stats)
+        for i in range(2):
+            dp.accumulate(flow, x[6 * i:6 * i + 6], .5)
+        dp.apply_step(st)
+        return st, stats
+    sa, stats = run(make())
+    assert stats == {"in_place": len(sa.params), "copied": 0, "absent": 0}
+    old = ops._SINK
+    ops._SINK = False
+    try:
+        sb, _ = run(make())
+    finally:
+        ops._SINK = old
+    assert_close(sa.flat, sb.flat, rtol=1e-6, atol=1e-7, what="parameters (slots on / off)")
+    assert_close(sa.m, sb.m, rtol=1e-5, atol=1e-8, what="first moments")
