@@ -57,23 +57,36 @@ def grad_out(p):
     return torch.empty_like(p)
 
 
+_open_slots = set()                    # (id(owner), index) of shared slots taken in the backward pass that is running NOW
+
+
+def _close_slots():
+    _open_slots.clear()
+
+
 def grad_out_shared(p):
     """(tensor, finish) for a parameter that receives SEVERAL gradient contributions per backward (the DAG matrix A: gate
-    and acyclicity term).  The first contribution takes the flat-buffer slot as grad_out does; a later one is written to
-    a scratch tensor and finish() adds it INTO the slot and returns None, so autograd sees one contribution -- the slot --
-    instead of summing two tensors into a third that the gradient pack then copies (add + 2.4 MB copy per cfg4 step).
-    finish(t) returns what the backward hands to autograd."""
+    and acyclicity term).  The first contribution takes the flat-buffer slot as grad_out does; a later one OF THE SAME
+    BACKWARD PASS is written to a scratch tensor and finish() adds it INTO the slot and returns None, so autograd sees one
+    contribution -- the slot -- instead of summing two tensors into a third that the gradient pack then copies (add +
+    2.4 MB copy per cfg4 step).  "Same pass" is tracked by a callback the autograd engine runs when the pass ends: a slot
+    left taken by an earlier pass (a backward without a gradient pack behind it, a previous micro-batch) is never added
+    into -- that contribution gets a fresh tensor and autograd sums as usual.  finish(t) returns what the backward hands
+    to autograd."""
     ent = _grad_slots.get(p.data_ptr()) if _SINK else None
     owner = ent[0]() if ent is not None else None
     if owner is not None:
         i = ent[1]
         v = owner.grad_views[i]
         if v.numel() == p.numel() and p.is_contiguous() and v.device == p.device:
+            key = (id(owner), i)
             if i not in owner._taken:
                 owner._taken.add(i)
+                if not _open_slots:
+                    torch.autograd.Variable._execution_engine.queue_callback(_close_slots)
+                _open_slots.add(key)
                 return v.view(p.shape), (lambda t: t)
-            held = owner.params[i].grad          # None inside a backward; a slot view while micro-batches accumulate
-            if held is None or held.data_ptr() == v.data_ptr():
+            if key in _open_slots:
                 def finish(t, v=v):
                     v.add_(t.reshape(-1))
                     return None

@@ -555,3 +555,20 @@ def test_shared_gradient_slot_of_the_dag_matrix():
         ops._SINK = old
     assert_close(sa.flat, sb.flat, rtol=1e-6, atol=1e-7, what="parameters (slots on / off)")
     assert_close(sa.m, sb.m, rtol=1e-5, atol=1e-8, what="first moments")
+
+    # a backward with NO gradient pack behind it (a user inspecting gradients, bench.py's fwd+bwd-only loop) leaves the
+    # slots marked taken: the next backward must still hand A the sum of both contributions
+    flow = make()
+    st = dp.FlatState(flow)
+    A = flow.getConditioners()[0].A
+    grads = []
+    for _ in range(3):
+        for p in flow.parameters():
+            p.grad = None
+        z, ld = flow(x)
+        flow.loss(z, ld).backward()
+        assert A.grad is not None
+        grads.append(A.grad.clone())
+    assert torch.equal(grads[0], grads[1]) and torch.equal(grads[1], grads[2])
+    dp.train_step(flow, st, x, graph=False)                    # ... and the step behind it sees every gradient
+    assert st.pack_stats["absent"] == 0

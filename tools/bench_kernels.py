@@ -104,12 +104,23 @@ def main():
         for t in (xl, Wl, bl, W2l, b2l):
             t.grad = None
         ops.mlp(xl, [(Wl, bl), (W2l, b2l)], [mk, mk], degs=[(dg, dg, False), (dg, dg, False)]).sum().backward()
-    for entry in ("gnf_linear_fwd", "gnf_linear_bwd_x", "gnf_linear_bwd_w"):
+    for entry, nw in (("gnf_linear_fwd", 1), ("gnf_linear_bwd", 2)):       # bwd: both gradients in one launch, weights read twice
         ms = time_entry(entry, lin_step)
-        rows.append({"kernel": entry + " (MADE mask as degrees)", "shape": [M, N, K], "ms": round(ms, 4), "bound": "hbm (weights once)",
-                     "achieved_GBps": round(4. * N * K / ms / 1e6, 1), "frac_of_8TBps": round(4. * N * K / ms / 1e6 / HBM_PEAK, 3),
-                     "achieved_TFLOPs": round(2. * M * N * K / ms / 1e9, 1),
+        rows.append({"kernel": entry + " (MADE mask as degrees)", "shape": [M, N, K], "ms": round(ms, 4), "bound": "hbm (weights once per product)",
+                     "achieved_GBps": round(4. * nw * N * K / ms / 1e6, 1), "frac_of_8TBps": round(4. * nw * N * K / ms / 1e6 / HBM_PEAK, 3),
+                     "achieved_TFLOPs": round(2. * nw * M * N * K / ms / 1e9, 1),
                      "note": "HIP events around ONE launch on an idle stream: includes ~3 us of dispatch; rocprofv3 kernel durations in profiles/r03_linear_kernels.txt"})
+    # ---- tall batch, narrow output (gnf_linear_tall.hip): fc2 of the cfg4 embedding net, a DAGMLP hidden layer of cfg2
+    for M, N, K, what in [(78400, 30, 128, "cfg4 MNISTCNN.fc2"), (60000, 60, 60, "cfg2 DAGMLP hidden")]:
+        xt = torch.relu(torch.randn(M, K, device=DEV)).requires_grad_(True)
+        Wt, bt = (torch.randn(N, K, device=DEV) / K ** .5).requires_grad_(True), torch.zeros(N, device=DEV, requires_grad=True)
+
+        def tall_step():
+            for t in (xt, Wt, bt):
+                t.grad = None
+            ops.mlp(xt, [(Wt, bt)], relu_in=True).sum().backward()
+        for entry, nbytes in (("gnf_linear_fwd", 4. * M * (K + N)), ("gnf_linear_bwd", 4. * M * (N + 2 * K))):
+            hbm(entry + " " + what, [M, N, K], time_entry(entry, tall_step), nbytes)
     # ---- Monotonic quadrature, forward: 2*M*(S+2) flop per element
     for (B, d, c, hid, tag) in [(100, 784, 30, [50, 50, 50], "cfg4"), (10000, 6, 30, [100, 100, 100], "cfg2"),
                                 (50000, 63, 30, [150, 150, 150], "cfg5")]:

@@ -1,6 +1,7 @@
 """Small-batch Linear kernels (gnf_linear.hip) at the MADE layer shape of BASELINE cfg3 (100 x 1024 x 1024, GNF_LIN_SHAPE=M,N,K
 for others): HIP-event time of each entry point with the mask as a degree rule / a tensor / absent, against the bytes a
-layer has to stream (weights once: 4 N K).    python tools/bench_linear.py"""
+layer has to stream (weights once per product: 4 N K).  GNF_LINEAR_BWD_SPLIT=1 runs the two gradients as two launches.
+python tools/bench_linear.py"""
 import os, sys, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, ROOT + '/graphical-normalizing-flows_amd']
@@ -19,7 +20,7 @@ b2 = torch.zeros(N, device=dev, requires_grad=True)
 do, di = (783 - torch.arange(N, device=dev) % 784).float(), (783 - torch.arange(K, device=dev) % 784).float()
 mask = (di[None, :] <= do[:, None]).float()
 mask2 = (do[None, :] <= do[:, None]).float()
-names = ("gnf_linear_fwd", "gnf_linear_bwd_x", "gnf_linear_bwd_w")
+names = ("gnf_linear_fwd", "gnf_linear_bwd")           # bwd: both gradients of a layer, one launch
 for kind in ("deg", "full", "none"):
     masks = None if kind == "none" else [mask, mask2]
     degs = [(do, di, False), (do, do, False)] if kind == "deg" else None
