@@ -990,7 +990,11 @@ __global__ void adam_k(float* __restrict__ p, const float* __restrict__ g, float
 // device-scope atomics serialise at ~27 ns each: the grid is at most 256 workgroups of 1024 threads and the tickets are
 // drawn BEFORE the streaming loop, whose ~20 us hide them (drawn after it by 1568 workgroups they cost 43 us; a release
 // fence in front of them, one L2 write-back per workgroup: 100 us).  A separate one-thread launch for the increment cost
-// 4 us of a 170-us MADE step.
+// 4 us of a 170-us MADE step.  tools/bench_adam.py at 3.2 M parameters (HIP events): adam_k 17.3 us, this kernel 19.3
+// without / 20.5 with the increment; the 2 us are occupancy (one 16-wavefront workgroup per CU against seven 4-wavefront
+// ones) -- more, smaller workgroups cost more in tickets than they win (512 x 1024: 27 us, 768 x 512: 25 us, also with
+// two-level tickets), and neither cached bias corrections instead of two double pow() per thread nor non-temporal
+// gradient loads moved it.
 constexpr int kAdamDevBlock = 1024;
 __global__ __launch_bounds__(kAdamDevBlock) void adam_dev_k(float* __restrict__ p, const float* __restrict__ g,
                                                             float* __restrict__ m, float* __restrict__ v, int64_t n, int vec,
