@@ -451,13 +451,19 @@ __global__ __launch_bounds__(64 * kWaves) void mono_fwd_k(MonoArgs a) {
 // 8) wavefronts of a workgroup share ONE group of 16 elements and split the quadrature nodes (pairs w, w+nw, ...); the
 // partial sums meet in LDS once per bisection step (double-buffered: one barrier per step) and are added in a fixed
 // order, so all wavefronts take identical decisions.  WM as in mono_fwd_k (0 or 1).
+// EPG (elements per group) = 4: the 16 columns of a tile are 4 elements x 4 node pairs instead of 16 elements x 1, i.e. a
+// group is a quarter of the elements and needs a quarter of the wavefronts -- four times as many workgroups for the same
+// MFMA work.  A DAG level of MNIST sampling is ~720 elements: 45 groups of 16 kept 45 of the 256 CUs busy, each with 12
+// wavefronts queueing on its 4 MFMA pipes (a bisection step = 3 pair evaluations deep); 180 groups of 4 x 3 wavefronts
+// put ONE pair evaluation per SIMD on 180 CUs.
 constexpr int kSplitWaves = 8;
-template <int HT, int WM>
+template <int HT, int WM, int EPG = 16>
 __global__ __launch_bounds__(64 * kSplitWaves) void mono_inv_split_k(MonoArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const MonoLayout& L = a.L;
   const float* wp = a.pack;
   float* psum = smem;                            // [2][nw][16]
+  constexpr int NS = 16 / EPG;                   // node sub-slots of a wavefront: lane j -> element j % EPG, sub-slot j / EPG
   const int nw = blockDim.x >> 6;                // wavefronts sharing the group (<= kSplitWaves)
   if (WM == 1) {
     for (int i = threadIdx.x * 4; i < L.fwd_floats; i += blockDim.x * 4)
@@ -469,11 +475,12 @@ __global__ __launch_bounds__(64 * kSplitWaves) void mono_inv_split_k(MonoArgs a)
   auto getW = [&](int l) -> const float* { return wp + L.o_W[l]; };
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int q = lane >> 4, j = lane & 15;
-  const int64_t ngroups = (a.n + 15) / 16;
+  const int64_t ngroups = (a.n + EPG - 1) / EPG;
   const float fS = (float)a.S;
   int buf = 0;
   for (int64_t grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
-    const int64_t e = grp * 16 + j;
+    const int64_t e = grp * EPG + (j % EPG);
+    const int slot = wave * NS + j / EPG, nslots = nw * NS;        // this lane's node-pair slot
     const bool valid = e < a.n;
     const int64_t ec = valid ? e : a.n - 1;
     const int64_t b = ec / a.d, i = ec - b * a.d;
@@ -487,26 +494,32 @@ __global__ __launch_bounds__(64 * kSplitWaves) void mono_inv_split_k(MonoArgs a)
       const float xm = (xmax + xmin) * .5f;
       const float xT = fS * (xm / fS);
       float acc = 0.f;
-      for (int k = 2 * wave; k <= a.S; k += 2 * nw) {
-        const int k1 = k + 1;
-        const float wb = k1 <= a.S ? a.ccw[k1] : 0.f;
+      for (int kb = 0; kb <= a.S; kb += 2 * nslots) {              // wave-uniform trip count; a lane past the rule idles at weight 0
+        const int kk = kb + 2 * slot;
+        const bool on = kk <= a.S;
+        const int k = on ? kk : 0, k1 = k + 1;
+        const float wa = on ? a.ccw[k] : 0.f;
+        const float wb = (on && k1 <= a.S) ? a.ccw[k1] : 0.f;
         const float xa = xT * (a.cct[k] + 1.f) * .5f;
         const float xb = k1 <= a.S ? xT * (a.cct[k1] + 1.f) * .5f : xa;
         float fa, fb;
         eval2<HT>(wp, L, c1, xa, xb, q, j, fa, fb, getW);
-        acc = fmaf(a.ccw[k], fa, acc);
+        acc = fmaf(wa, fa, acc);
         acc = fmaf(wb, fb, acc);
       }
       if (q == 0) psum[(buf * nw + wave) * 16 + j] = acc;
       __syncthreads();
-      const float* ps = psum + buf * nw * 16 + j;
-      float tot = ps[0];
-      for (int w = 1; w < nw; ++w) tot += ps[16 * w];
+      // the element's node slots: wavefront-major, sub-slot-minor, the same order in every lane of the element
+      const float* ps = psum + buf * nw * 16 + (j % EPG);
+      float tot = 0.f;
+      for (int w = 0; w < nw; ++w)
+#pragma unroll
+        for (int u = 0; u < NS; ++u) tot += ps[16 * w + EPG * u];
       const float zm = tot * xT * .5f + h0;
       buf ^= 1;
       if (zm > zt) xmax = xm; else xmin = xm;
     }
-    if (valid && q == 0 && wave == 0) a.xo[e] = (xmax + xmin) * .5f;
+    if (valid && q == 0 && wave == 0 && j < EPG) a.xo[e] = (xmax + xmin) * .5f;
   }
 }
 
@@ -515,12 +528,13 @@ __global__ __launch_bounds__(64 * kSplitWaves) void mono_inv_split_k(MonoArgs a)
 // evaluation (144 MFMAs) instead of two of the padded form (2 x 256) -- the level kernel of MNIST sampling 256 -> see
 // DESIGN.md section 6.  The partial sums are added in the fixed order of the wavefronts, as above.
 constexpr int kSplitWavesX = 12;     // 3 wavefronts per SIMD: 168 registers (at 16 / 128 registers eval2x spills)
-template <int HM, int EX, int WM>
+template <int HM, int EX, int WM, int EPG = 16>
 __global__ __launch_bounds__(64 * kSplitWavesX) void mono_inv_split_x_k(MonoArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const MonoLayout& L = a.L;
   const float* wp = a.pack;
   float* psum = smem;                            // [2][nw][16]
+  constexpr int NS = 16 / EPG;                   // node sub-slots of a wavefront: lane j -> element j % EPG, sub-slot j / EPG
   const int nw = blockDim.x >> 6;                // wavefronts sharing the group (<= kSplitWavesX)
   if (WM == 1) {
     for (int i = threadIdx.x * 4; i < L.fwd_floats; i += blockDim.x * 4)
@@ -532,11 +546,12 @@ __global__ __launch_bounds__(64 * kSplitWavesX) void mono_inv_split_x_k(MonoArgs
   auto getW = [&](int l) -> const float* { return wp + L.o_W[l]; };
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int q = lane >> 4, j = lane & 15;
-  const int64_t ngroups = (a.n + 15) / 16;
+  const int64_t ngroups = (a.n + EPG - 1) / EPG;
   const float fS = (float)a.S;
   int buf = 0;
   for (int64_t grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
-    const int64_t e = grp * 16 + j;
+    const int64_t e = grp * EPG + (j % EPG);
+    const int slot = wave * NS + j / EPG, nslots = nw * NS;        // this lane's node-pair slot
     const bool valid = e < a.n;
     const int64_t ec = valid ? e : a.n - 1;
     const int64_t b = ec / a.d, i = ec - b * a.d;
@@ -551,26 +566,32 @@ __global__ __launch_bounds__(64 * kSplitWavesX) void mono_inv_split_x_k(MonoArgs
       const float xm = (xmax + xmin) * .5f;
       const float xT = fS * (xm / fS);
       float acc = 0.f;
-      for (int k = 2 * wave; k <= a.S; k += 2 * nw) {
-        const int k1 = k + 1;
-        const float wb = k1 <= a.S ? a.ccw[k1] : 0.f;
+      for (int kb = 0; kb <= a.S; kb += 2 * nslots) {              // wave-uniform trip count; a lane past the rule idles at weight 0
+        const int kk = kb + 2 * slot;
+        const bool on = kk <= a.S;
+        const int k = on ? kk : 0, k1 = k + 1;
+        const float wa = on ? a.ccw[k] : 0.f;
+        const float wb = (on && k1 <= a.S) ? a.ccw[k1] : 0.f;
         const float xa = xT * (a.cct[k] + 1.f) * .5f;
         const float xb = k1 <= a.S ? xT * (a.cct[k1] + 1.f) * .5f : xa;
         float fa, fb;
         eval2x<HM, EX>(wp, L, c1, c1x, xa, xb, q, j, fa, fb, getW);
-        acc = fmaf(a.ccw[k], fa, acc);
+        acc = fmaf(wa, fa, acc);
         acc = fmaf(wb, fb, acc);
       }
       if (q == 0) psum[(buf * nw + wave) * 16 + j] = acc;
       __syncthreads();
-      const float* ps = psum + buf * nw * 16 + j;
-      float tot = ps[0];
-      for (int w = 1; w < nw; ++w) tot += ps[16 * w];
+      // the element's node slots: wavefront-major, sub-slot-minor, the same order in every lane of the element
+      const float* ps = psum + buf * nw * 16 + (j % EPG);
+      float tot = 0.f;
+      for (int w = 0; w < nw; ++w)
+#pragma unroll
+        for (int u = 0; u < NS; ++u) tot += ps[16 * w + EPG * u];
       const float zm = tot * xT * .5f + h0;
       buf ^= 1;
       if (zm > zt) xmax = xm; else xmin = xm;
     }
-    if (valid && q == 0 && wave == 0) a.xo[e] = (xmax + xmin) * .5f;
+    if (valid && q == 0 && wave == 0 && j < EPG) a.xo[e] = (xmax + xmin) * .5f;
   }
 }
 
@@ -1749,6 +1770,25 @@ int launch_fwd(const MonoArgs& a, hipStream_t s) {
   if (INV && !swap && ngroups <= 512 && a.S >= 7) {
     // fewer groups than a resident wave of workgroups: split the quadrature nodes over the workgroup's wavefronts
     const int pairs = (a.S + 2) / 2;
+    static const bool quarter_off = getenv("GNF_MONO_INV_EPG4") && getenv("GNF_MONO_INV_EPG4")[0] == '0';   // A/B switch
+    const bool quarter = !quarter_off && ngroups < 256;               // groups of 4 elements x 4 node pairs (see above)
+    if (a.L.EX > 0 && quarter) {
+      const int nwq = (pairs + 3) / 4 < kSplitWavesX ? (pairs + 3) / 4 : kSplitWavesX;
+      const size_t lds_q = (wlds ? lds : 0) + 2 * nwq * 16 * sizeof(float);
+      const unsigned gq = (unsigned)((a.n + 3) / 4);
+#define GNF_INVXQ(EX_)                                                                                         \
+      if (wlds) {                                                                                              \
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mono_inv_split_x_k<3, EX_, 1, 4>),            \
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_q);                     \
+        hipLaunchKernelGGL((mono_inv_split_x_k<3, EX_, 1, 4>), dim3(gq), dim3(64 * nwq), lds_q, s, a);         \
+      } else {                                                                                                 \
+        hipLaunchKernelGGL((mono_inv_split_x_k<3, EX_, 0, 4>), dim3(gq), dim3(64 * nwq), lds_q, s, a);         \
+      }
+      if (a.L.EX <= 2) { GNF_INVXQ(2) } else { GNF_INVXQ(3) }
+#undef GNF_INVXQ
+      GNF_LAUNCH_CHECK();
+      return 0;
+    }
     if (a.L.EX > 0) {                                                 // peeled narrow net: up to 16 wavefronts per group
       const int nwx = pairs < kSplitWavesX ? pairs : kSplitWavesX;
       const size_t lds_x = (wlds ? lds : 0) + 2 * nwx * 16 * sizeof(float);
@@ -1762,6 +1802,28 @@ int launch_fwd(const MonoArgs& a, hipStream_t s) {
       }
       if (a.L.EX <= 2) { GNF_INVX(2) } else { GNF_INVX(3) }
 #undef GNF_INVX
+      GNF_LAUNCH_CHECK();
+      return 0;
+    }
+    if (quarter) {
+      const int nwq = (pairs + 3) / 4 < kSplitWaves ? (pairs + 3) / 4 : kSplitWaves;
+      const size_t lds_q = (wlds ? lds : 0) + 2 * nwq * 16 * sizeof(float);
+      const unsigned gq = (unsigned)((a.n + 3) / 4);
+#define GNF_INVQ_CASE(HT_)                                                                                     \
+  case HT_:                                                                                                   \
+    if (wlds) {                                                                                               \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mono_inv_split_k<HT_, 1, 4>),                  \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_q);                      \
+      hipLaunchKernelGGL((mono_inv_split_k<HT_, 1, 4>), dim3(gq), dim3(64 * nwq), lds_q, s, a);               \
+    } else {                                                                                                  \
+      hipLaunchKernelGGL((mono_inv_split_k<HT_, 0, 4>), dim3(gq), dim3(64 * nwq), lds_q, s, a);               \
+    }                                                                                                         \
+    break;
+      switch (HT) {
+        GNF_INVQ_CASE(2) GNF_INVQ_CASE(4) GNF_INVQ_CASE(7) GNF_INVQ_CASE(10) GNF_INVQ_CASE(16)
+        default: return GNF_ESHAPE;
+      }
+#undef GNF_INVQ_CASE
       GNF_LAUNCH_CHECK();
       return 0;
     }

@@ -600,12 +600,21 @@ def _mono_net(params):
 
 
 def _mono_pack(net, like):
+    """the kernels' image of the integrand net's parameters (padded, transposed and fragment-major copies)"""
     nfl = abi.load().gnf_monotonic_pack_floats(ctypes.byref(net))
     if nfl < 0:
         abi.check(int(nfl), "gnf_monotonic_pack_floats")
     pack = _empty((int(nfl),), like)
     call("gnf_monotonic_pack", ctypes.byref(net), ptr(pack), stream())
     return pack
+
+
+def monotonic_pack(params, like):
+    """the weight image for `monotonic_inverse(..., pack=...)`: a caller that inverts many times with unchanged parameters
+    (the 109 DAG levels of one MNIST sampling pass) packs once.  (Not cached behind the caller's back: the fused Adam
+    launch and a replayed hipGraph rewrite the parameters without touching torch's version counters.)"""
+    params = [p.detach().contiguous() for p in params]
+    return _mono_pack(_mono_net(params), like)
 
 
 class MonotonicFn(torch.autograd.Function):
@@ -657,14 +666,15 @@ class MonotonicFn(torch.autograd.Function):
         return (gx, gh, None, *gparams)
 
 
-def monotonic_inverse(z, h, nb_steps, params):
+def monotonic_inverse(z, h, nb_steps, params, pack=None):
     """20-step bisection on [-20, 20], the quadrature fused in the kernel
     (MonotonicNormalizer.py:69-83)."""
     z = z.contiguous()
     params = [p.detach().contiguous() for p in params]
     B, d = z.shape
     net = _mono_net(params)
-    pack = _mono_pack(net, z)
+    if pack is None:
+        pack = _mono_pack(net, z)
     w, t = cc_rule(nb_steps, z.device)
     x = _empty((B, d), z)
     call("gnf_monotonic_inv", ptr(pack), ctypes.byref(net), ptr(z), ptr(h), h.stride(0), h.stride(1), h.stride(2),

@@ -95,4 +95,23 @@ class MonotonicNormalizer(Normalizer):
         with torch.no_grad():
             if not self._fused():
                 return ops.module_monotonic_inverse(z, h, self.integrand_net, int(self.nb_steps))
-            return ops.monotonic_inverse(z, h, int(self.nb_steps), self._params())
+            return ops.monotonic_inverse(z, h, int(self.nb_steps), self._params(), pack=self._held_pack)
+
+    _held_pack = None
+
+    def hold_pack(self):
+        """context manager for a caller that inverts many times with unchanged parameters (the levels / fixed-point
+        passes of one `invert`): the kernels' weight image is built once instead of once per call"""
+        import contextlib
+
+        @contextlib.contextmanager
+        def hold():
+            prev = self._held_pack
+            if self._fused() and prev is None:
+                ps = self._params()
+                self._held_pack = ops.monotonic_pack(ps, ps[0])
+            try:
+                yield
+            finally:
+                self._held_pack = prev
+        return hold()

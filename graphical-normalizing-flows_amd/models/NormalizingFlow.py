@@ -101,7 +101,9 @@ class NormalizingFlowStep(NormalizingFlow):
     def invert(self, z, context=None):
         """Reference :98-107: fixed point of x <- normalizer^-1(z, conditioner(x)) from x = 0, depth()+1 passes, early
         exit once a pass changes nothing (its progress print is dropped)."""
-        with torch.no_grad():
+        import contextlib
+        hold = getattr(self.normalizer, "hold_pack", None)       # parameters do not change inside: pack the weights once
+        with torch.no_grad(), (hold() if hold is not None else contextlib.nullcontext()):
             x = self._invert_by_levels(z, context)
             if x is not None:
                 return x
