@@ -206,6 +206,7 @@ def main():
     dp.seed_gates(flow, rank)                                # per-rank, per-conditioner Philox keys (like DP replicas)
     state = dp.FlatState(flow)
     state.broadcast(0)
+    _flush_c_stdio()                                         # RCCL has announced itself by now (first collective): every rank
     x = pseudo_mnist(torch.Generator().manual_seed(1234 + rank), B_PER_GPU, D).to(dev)
 
     def fence():
@@ -384,9 +385,21 @@ def main():
         out["roofline"]["frac_of_measured_peak"] = round(achieved / out["measured_peaks"]["mfma_f32_TFLOPs"], 4)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
-        print(json.dumps(out), flush=True)
     if collective:
         dist.destroy_process_group()
+    if rank == 0:
+        # the JSON line is the LAST line of stdout: RCCL announces itself through C stdio ("Librccl path : ..."), whose
+        # buffer would otherwise be flushed at process exit, behind Python's
+        _flush_c_stdio()
+        print(json.dumps(out), flush=True)
+
+
+def _flush_c_stdio():
+    import ctypes
+    try:
+        ctypes.CDLL(None).fflush(None)
+    except OSError:
+        pass
 
 
 if __name__ == "__main__":
