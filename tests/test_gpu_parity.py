@@ -619,6 +619,38 @@ def test_linear_tall_narrow_layers(M, H, N):
         assert rel_err(a.grad.cpu(), r.grad.float()) < GTOL, (name, rel_err(a.grad.cpu(), r.grad.float()))
 
 
+@pytest.mark.parametrize("M,N,K", [(100, 64, 48), (300, 40, 24), (4099, 30, 128)])
+def test_linear_bwd_entry_with_column_sums(M, N, K):
+    """gnf_linear_bwd through the C ABI with `gxsum` (the column sums of the data gradient = the bias gradient of the
+    layer below): produced by the same launch on the tall-batch path (gnf_linear_gxsum_fused == 1), by a column-sum pass
+    behind the small-batch / tiled paths -- against torch on the CPU; and the entry point's argument checks."""
+    import ctypes
+    from gnf_hip import abi
+    lib = abi.load()
+    g = torch.Generator().manual_seed(M + N + K)
+    a = torch.relu(torch.randn(M, K, generator=g))
+    W, gy = torch.randn(N, K, generator=g) / K ** .5, torch.randn(M, N, generator=g)
+    gx0 = (gy.double() @ W.double()) * (a > 0)
+    gW0, gb0 = gy.double().t() @ a.double(), gy.double().sum(0)
+    ad, Wd, gd = cu(a), cu(W), cu(gy)
+    gx, gW, gb, gxs = (torch.empty(s, device=DEV) for s in ((M, K), (N, K), (N,), (K,)))
+    nws = lib.gnf_linear_ws_bytes(M, N, K)
+    ws = torch.empty(max(nws // 4, 1), device=DEV)
+    P = lambda t: ctypes.c_void_p(t.data_ptr())
+    st = abi.stream()
+    args = lambda **o: [P(gd), P(Wd), P(ad), None, None, None, 0, P(ad), o.get("gx", P(gx)), o.get("gW", P(gW)), P(gb), P(gxs), M, N, K,
+                        P(ws), o.get("nws", nws), st]
+    assert lib.gnf_linear_bwd(*args()) == 0
+    fused = lib.gnf_linear_gxsum_fused(M, N, K, 0)
+    assert fused == (1 if (M >= 2048 and N <= 64 and K <= 128 and K % 4 == 0) else 0)
+    for name, t, r in (("gx", gx, gx0), ("gW", gW, gW0), ("gb", gb, gb0), ("gxsum", gxs, gx0.sum(0))):
+        assert rel_err(t.cpu(), r.float()) < GTOL, (name, rel_err(t.cpu(), r.float()))
+    assert lib.gnf_linear_bwd(*args(gW=None)) == -1                      # GNF_EINVAL
+    assert lib.gnf_linear_bwd(*args(gx=None)) == -1
+    if fused:
+        assert lib.gnf_linear_bwd(*args(nws=16)) == -3                   # GNF_EWS: the partials do not fit
+
+
 def test_made_degree_rule_is_verified_against_the_mask_buffer():
     """MaskedLinear hands the kernels its degree vectors only while the mask buffer equals the degree rule; a mask that
     was overwritten (a checkpoint, a user's own pattern) is read as a tensor again, and the result follows it."""
