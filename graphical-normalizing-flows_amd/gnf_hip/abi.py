@@ -42,7 +42,7 @@ SIGNATURES = {
     "gnf_normal_logdensity_bwd": (c_int, [c_f, c_f, c_f, c_i64, c_i64, c_stream]),
     "gnf_nll_reduce_fwd": (c_int, [c_f, c_f, c_f, c_f, c_i64, c_i64, c_stream]),
     "gnf_nll_reduce_bwd": (c_int, [c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_i64, c_i64, c_stream]),
-    "gnf_nll_mean_fwd": (c_int, [c_f, c_f, c_f, c_i64, c_stream]),
+    "gnf_nll_mean_fwd": (c_int, [c_f, c_f, c_f, c_f, c_i64, c_stream]),
     "gnf_nll_mean_bwd": (c_int, [c_f, c_f, c_f, c_i64, c_stream]),
     "gnf_colsum_ws_bytes": (c_i64, [c_i64, c_i64]),
     "gnf_colsum": (c_int, [c_f, c_i64, c_f, c_i64, c_i64, c_f, c_stream]),

@@ -880,7 +880,7 @@ int nll_rows_bwd_launch(const float* z, const float* jac, const float* glogdet, 
 // launch (torch: add, mean, neg + their backward = 8 launches of a step that has ~40).  One workgroup, fixed summation
 // order: per-thread strided partials, butterfly per wavefront, the 16 wavefront sums in order.
 __global__ __launch_bounds__(1024) void nll_mean_k(const float* __restrict__ logdet, const float* __restrict__ logn,
-                                                   float* __restrict__ out, int64_t B) {
+                                                   const float* __restrict__ addend, float* __restrict__ out, int64_t B) {
   __shared__ float red[16];
   float s = 0.f;
   for (int64_t b = threadIdx.x; b < B; b += 1024) s += logdet[b] + logn[b];
@@ -892,7 +892,8 @@ __global__ __launch_bounds__(1024) void nll_mean_k(const float* __restrict__ log
     float t = 0.f;
 #pragma unroll
     for (int w = 0; w < 16; ++w) t += red[w];
-    out[0] = -t / (float)B;
+    const float nll = -t / (float)B;
+    out[0] = addend ? addend[0] + nll : nll;          // c + (-mean) == c - mean: the reference's constraints - mean(...)
   }
 }
 // both cotangents of the above: glogdet[b] = glogn[b] = -g / B (g: device scalar)
@@ -1225,9 +1226,10 @@ int gnf_nll_reduce_bwd(const float* z, const float* jac, const float* glogdet, c
   return nll_rows_bwd_launch(z, jac, glogdet, glogn, gz_in, gz, gjac, B, d, (hipStream_t)stream);
 }
 
-int gnf_nll_mean_fwd(const float* logdet, const float* logn, float* out, int64_t B, gnf_stream_t stream) {
+int gnf_nll_mean_fwd(const float* logdet, const float* logn, const float* addend, float* out, int64_t B,
+                     gnf_stream_t stream) {
   if (B <= 0 || !logdet || !logn || !out) return GNF_EINVAL;
-  hipLaunchKernelGGL(nll_mean_k, dim3(1), dim3(1024), 0, (hipStream_t)stream, logdet, logn, out, B);
+  hipLaunchKernelGGL(nll_mean_k, dim3(1), dim3(1024), 0, (hipStream_t)stream, logdet, logn, addend, out, B);
   GNF_LAUNCH_CHECK();
   return 0;
 }

@@ -7,7 +7,9 @@ ONE collective -- an all-reduce(sum) of the flat gradient buffer over RCCL/xGMI 
 by one fused Adam launch.  The DAG acyclicity term depends on parameters only: every rank
 computes it redundantly, so after averaging it is counted once, like the reference where it is
 added once on GPU 0."""
+import gc
 import os
+import weakref
 
 import torch
 import torch.distributed as dist
@@ -216,7 +218,8 @@ def train_step(flow, state, x_shard, lr=1e-3, weight_decay=1e-5, optimizer=hip_a
             and x_shard.numel() <= GRAPH_MAX_ELEMS and torch.is_grad_enabled() and GraphedStep.graphable(flow)):
         gs = getattr(state, "_graphed", None)
         if gs is None or gs.flow is not flow or (gs.lr, gs.weight_decay) != (lr, weight_decay):
-            state._graphed = gs = GraphedStep(flow, state, x_shard, lr=lr, weight_decay=weight_decay, warmup=1)
+            state._graphed = gs = GraphedStep(flow, state, x_shard, lr=lr, weight_decay=weight_decay, warmup=1,
+                                              owned_by_state=True)
             return gs.loss
         return gs(x_shard)
     loss = accumulate(flow, x_shard)
@@ -275,16 +278,29 @@ class GraphedStep:
 
     MAX_GRAPHS = 16                      # captured variants kept (node-count jitter 20..29 of the drivers = 10)
 
-    def __init__(self, flow, state, x_example, lr=1e-3, weight_decay=1e-5, warmup=3):
+    def __init__(self, flow, state, x_example, lr=1e-3, weight_decay=1e-5, warmup=3, owned_by_state=False):
         if dist.is_initialized() and dist.get_world_size() > 1:
             raise RuntimeError("GraphedStep is single-process; use train_step under torchrun")
-        self.state, self.flow = state, flow
+        # owned_by_state (train_step keeps this object in `state._graphed`): only a weak reference back, so that the pair
+        # is NOT a reference cycle -- a cycle is freed by the garbage collector at an arbitrary later moment, and destroying
+        # captured graphs while ANOTHER capture is in progress aborts the process (hipGraphDestroy inside a capturing
+        # stream).  A GraphedStep the caller builds itself keeps its state alive.
+        self._state_ref = weakref.ref(state)
+        self._state_keep = None if owned_by_state else state
+        self.flow = flow
         self.lr, self.weight_decay = lr, weight_decay
         self._step_buf = torch.zeros(2, dtype=torch.int32, device=x_example.device)    # {steps taken, ticket counter}
         self.step_dev = self._step_buf[:1]
         self.captures = 0
         self._graphs = {}                    # fingerprint -> (graph, loss tensor, input buffer)
         self.loss = self._capture(x_example, max(warmup, 1))
+
+    @property
+    def state(self):
+        st = self._state_ref()
+        if st is None:
+            raise RuntimeError("the FlatState of this GraphedStep is gone")
+        return st
 
     @staticmethod
     def graphable(flow):
@@ -357,8 +373,15 @@ class GraphedStep:
                 state.t += 1
         torch.cuda.current_stream().wait_stream(side)
         graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph):
-            loss = body()
+        gc_was_on = gc.isenabled()
+        gc.collect()
+        gc.disable()                            # no finaliser (of some older graph, event, ...) may run inside the capture
+        try:
+            with torch.cuda.graph(graph):
+                loss = body()
+        finally:
+            if gc_was_on:
+                gc.enable()
         if len(self._graphs) >= self.MAX_GRAPHS:
             self._graphs.pop(next(iter(self._graphs)))
         self._graphs[self._fingerprint(x.shape)] = (graph, loss, xbuf)

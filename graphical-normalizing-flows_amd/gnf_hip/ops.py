@@ -216,14 +216,14 @@ class NllReduceFn(torch.autograd.Function):
 
 
 class NllMeanFn(torch.autograd.Function):
-    """-(logdet + logn).mean(): the data term of FCNormalizingFlow.loss (models/NormalizingFlow.py:144-146) and both of its
-    cotangents in one launch each."""
+    """addend - (logdet + logn).mean(): FCNormalizingFlow.loss (models/NormalizingFlow.py:144-146; addend = the constraints
+    term as a 0-dim tensor, or None) and its cotangents, one launch each way."""
 
     @staticmethod
-    def forward(ctx, logdet, logn):
+    def forward(ctx, logdet, logn, addend=None):
         logdet, logn = logdet.contiguous(), logn.contiguous()
         out = _empty((), logdet)
-        call("gnf_nll_mean_fwd", ptr(logdet), ptr(logn), ptr(out), logdet.shape[0], stream())
+        call("gnf_nll_mean_fwd", ptr(logdet), ptr(logn), ptr(addend), ptr(out), logdet.shape[0], stream())
         ctx.B = logdet.shape[0]
         ctx.like = logdet
         return out
@@ -232,7 +232,7 @@ class NllMeanFn(torch.autograd.Function):
     def backward(ctx, g):
         gl, gn = _empty((ctx.B,), ctx.like), _empty((ctx.B,), ctx.like)
         call("gnf_nll_mean_bwd", ptr(g.contiguous()), ptr(gl), ptr(gn), ctx.B, stream())
-        return gl, gn
+        return gl, gn, (g if len(ctx.needs_input_grad) > 2 and ctx.needs_input_grad[2] else None)
 
 
 def stash_logn(z, logn):

@@ -40,7 +40,11 @@ class NormalizingFlow(nn.Module):
         raise NotImplementedError
 
     def constraintsLoss(self):
-        return sum((c.loss() for c in self.getConditioners() if _is_dag(c)), 0.)
+        total = None                                    # (sum(..., 0.) of the reference: 0. + loss is one more launch)
+        for c in self.getConditioners():
+            if _is_dag(c):
+                total = c.loss() if total is None else total + c.loss()
+        return 0. if total is None else total
 
     def DAGness(self):
         return [c.get_power_trace() if _is_dag(c) else 0. for c in self.getConditioners()]
@@ -144,9 +148,12 @@ class FCNormalizingFlow(NormalizingFlow):
         logn = self.z_log_density(z)
         if (jac.is_cuda and jac.dim() == 1 and logn.shape == jac.shape and jac.shape[0] > 0
                 and jac.dtype == torch.float32 and logn.dtype == torch.float32):
-            nll = ops.NllMeanFn.apply(jac, logn)                                 # -(jac + logn).mean(), one launch
             c = self.constraintsLoss()
-            return nll if (isinstance(c, float) and c == 0.) else c + nll
+            if isinstance(c, float) and c == 0.:
+                return ops.NllMeanFn.apply(jac, logn)                            # -(jac + logn).mean(), one launch
+            if torch.is_tensor(c) and c.is_cuda and c.dim() == 0 and c.dtype == torch.float32:
+                return ops.NllMeanFn.apply(jac, logn, c)                         # constraints - mean(...), the same launch
+            return c + ops.NllMeanFn.apply(jac, logn)
         return self.constraintsLoss() - (jac + logn).mean()
 
     def invert(self, z, context=None):

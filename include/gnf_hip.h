@@ -73,9 +73,11 @@ int gnf_nll_reduce_fwd(const float* z, const float* jac, float* logdet, float* l
                        gnf_stream_t stream);
 int gnf_nll_reduce_bwd(const float* z, const float* jac, const float* glogdet, const float* glogn, const float* gz_in,
                        float* gz, float* gjac, int64_t B, int64_t d, gnf_stream_t stream);
-/* The data term of FCNormalizingFlow.loss (models/NormalizingFlow.py:144-146): out[0] = -mean_b(logdet[b] + logn[b]), one
- * workgroup, fixed summation order;  bwd: glogdet[b] = glogn[b] = -g[0]/B (g: device scalar). */
-int gnf_nll_mean_fwd(const float* logdet, const float* logn, float* out, int64_t B, gnf_stream_t stream);
+/* FCNormalizingFlow.loss (models/NormalizingFlow.py:144-146): out[0] = addend[0] - mean_b(logdet[b] + logn[b]) (addend: the
+ * constraints term as a device scalar, or NULL = 0), one workgroup, fixed summation order;
+ * bwd: glogdet[b] = glogn[b] = -g[0]/B (g: device scalar; the addend's cotangent is g itself). */
+int gnf_nll_mean_fwd(const float* logdet, const float* logn, const float* addend, float* out, int64_t B,
+                     gnf_stream_t stream);
 int gnf_nll_mean_bwd(const float* g, float* glogdet, float* glogn, int64_t B, gnf_stream_t stream);
 /* out[n] = sum_m a[m*lda + n]  (bias gradients; deterministic two-level reduction).
  * ws: >= gnf_colsum_ws_bytes(M,N) bytes. */
