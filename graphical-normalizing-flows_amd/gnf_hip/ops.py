@@ -51,7 +51,8 @@ def grad_out(p):
         else:
             i = ent[1]
             v = owner.grad_views[i]
-            if i not in owner._taken and v.numel() == p.numel() and p.is_contiguous() and v.device == p.device:
+            if (i not in owner._taken and v.numel() == p.numel() and p.is_contiguous() and v.device == p.device
+                    and v.dtype == p.dtype):
                 owner._taken.add(i)
                 return v.view(p.shape)
     return torch.empty_like(p)
@@ -78,7 +79,7 @@ def grad_out_shared(p):
     if owner is not None:
         i = ent[1]
         v = owner.grad_views[i]
-        if v.numel() == p.numel() and p.is_contiguous() and v.device == p.device:
+        if v.numel() == p.numel() and p.is_contiguous() and v.device == p.device and v.dtype == p.dtype:
             key = (id(owner), i)
             if i not in owner._taken:
                 owner._taken.add(i)
