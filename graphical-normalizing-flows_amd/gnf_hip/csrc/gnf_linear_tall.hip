@@ -330,6 +330,132 @@ __global__ __launch_bounds__(1024) void lin_tall_reduce_k(const float* __restric
   }
 }
 
+// ------------------------------------------------------------------------------------------ weight gradient alone
+// gW[o][i] = sum_rows g[row][o] a[row][i], gb[o] (+)= sum_rows g[row][o] for a tall g [M x N <= 64] (row pitch ldg) and a
+// tall a [M x K <= 64] (row pitch lda, any K): the first-layer products of the Monotonic backward -- d W1h = Dsum^T h and
+// d b1 = colsum Dsum (MonotonicNormalizer.py:21-38 autograd; 78 400 x 64 against 78 400 x 30 at cfg4), which ran as a
+// split-K tiled GEMM + its reduction + a two-stage column sum (17 + 5 + 13 us).  All eight wavefronts take the
+// weight-gradient role of lin_bwd_tall_k above; partials per workgroup, summed in fixed order.
+template <int NT>
+__global__ __launch_bounds__(512, 1) void lin_wgrad_tall_k(const float* __restrict__ g, int ldg, const float* __restrict__ a,
+                                                           int lda, float* __restrict__ partW, float* __restrict__ partB,
+                                                           int M, int N, int K) {
+  __shared__ f32x4 red[8][NT * 4][64];
+  __shared__ float redb[8][NT][16];
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int q = lane >> 4, j = lane & 15;
+  const int ntiles = (M + 15) / 16;
+  const int stride = gridDim.x * 8;
+  const rsrc_t ra = mkrsrc(a, (int64_t)(M - 1) * lda + K);
+  f32x4 acc[NT][4];
+  float bsum[NT];
+#pragma unroll
+  for (int ot = 0; ot < NT; ++ot) {
+    bsum[ot] = 0.f;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) acc[ot][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  float gv[NT][4];
+  f32x4 av[4];
+  auto load = [&](int tl, float (*gd)[4], f32x4* ad) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = 16 * tl + 4 * q + r;
+      const int rc = row < M ? row : M - 1;
+#pragma unroll
+      for (int ot = 0; ot < NT; ++ot) gd[ot][r] = (16 * ot + j < N) ? g[(int64_t)rc * ldg + 16 * ot + j] : 0.f;
+      const u32x4 u = __builtin_amdgcn_raw_buffer_load_b128(ra, (rc * lda + 4 * j) * 4, 0, 0);
+      f32x4 v = __builtin_bit_cast(f32x4, u);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) v[k] = 4 * j + k < K ? v[k] : 0.f;
+      ad[r] = v;
+    }
+  };
+  int tile = blockIdx.x * 8 + wave;
+  if (tile < ntiles) load(tile, gv, av);
+  for (; tile < ntiles; tile += stride) {
+    float gn[NT][4];
+    f32x4 an[4];
+    const bool more = tile + stride < ntiles;
+    if (more) load(tile + stride, gn, an);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const bool ok = 16 * tile + 4 * q + r < M;
+#pragma unroll
+      for (int ot = 0; ot < NT; ++ot) {
+        const float gg = ok ? gv[ot][r] : 0.f;
+        bsum[ot] += gg;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) acc[ot][c] = mfma(gg, av[r][c], acc[ot][c]);
+      }
+    }
+    if (more) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+#pragma unroll
+        for (int ot = 0; ot < NT; ++ot) gv[ot][r] = gn[ot][r];
+        av[r] = an[r];
+      }
+    }
+  }
+#pragma unroll
+  for (int ot = 0; ot < NT; ++ot) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c) red[wave][ot * 4 + c][lane] = acc[ot][c];
+    float s = bsum[ot];
+    s += __shfl_xor(s, 16, 64);
+    s += __shfl_xor(s, 32, 64);
+    if (q == 0) redb[wave][ot][j] = s;
+  }
+  __syncthreads();
+  float* pw = partW + (int64_t)blockIdx.x * ((int64_t)N * K);
+  for (int idx = threadIdx.x; idx < NT * 4 * 64 * 4; idx += blockDim.x) {
+    // item (ot, r, lane, c): out unit 16 ot + 4 (lane >> 4) + r, column 4 (lane & 15) + c
+    const int c = idx & 3, ln = (idx >> 2) & 63, r = (idx >> 8) & 3, ot = idx >> 10;
+    const int o = 16 * ot + 4 * (ln >> 4) + r, i = 4 * (ln & 15) + c;
+    if (o >= N || i >= K) continue;
+    float v = 0.f;
+#pragma unroll
+    for (int w = 0; w < 8; ++w) v += red[w][ot * 4 + c][ln][r];
+    pw[(int64_t)o * K + i] = v;
+  }
+  if (threadIdx.x < NT * 16) {
+    const int ot = threadIdx.x >> 4, jj = threadIdx.x & 15;
+    if (16 * ot + jj < N) {
+      float v = 0.f;
+#pragma unroll
+      for (int w = 0; w < 8; ++w) v += redb[w][ot][jj];
+      partB[(int64_t)blockIdx.x * N + 16 * ot + jj] = v;
+    }
+  }
+}
+
+// out[i] (+)= sum over the workgroups' partials, fixed order
+__global__ __launch_bounds__(1024) void lin_wgrad_reduce_k(const float* __restrict__ partW, const float* __restrict__ partB,
+                                                           int nparts, int64_t nw, int64_t nb, float* __restrict__ gW,
+                                                           float* __restrict__ gb, int acc_b) {
+  __shared__ float red[16][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t i = (int64_t)blockIdx.x * 64 + lane;
+  float s0 = 0.f, s1 = 0.f;
+  if (i < nw + nb) {
+    const float* p = i < nw ? partW + i : partB + (i - nw);
+    const int64_t ld = i < nw ? nw : nb;
+    int b = wave;
+    for (; b + 16 < nparts; b += 32) { s0 += p[(int64_t)b * ld]; s1 += p[(int64_t)(b + 16) * ld]; }
+    for (; b < nparts; b += 16) s0 += p[(int64_t)b * ld];
+  }
+  red[wave][lane] = s0 + s1;
+  __syncthreads();
+  if (wave == 0 && i < nw + nb) {
+    float s = red[0][lane];
+#pragma unroll
+    for (int w = 1; w < 16; ++w) s += red[w][lane];
+    if (i < nw) gW[i] = s;
+    else if (gb) gb[i - nw] = acc_b ? gb[i - nw] + s : s;
+  }
+}
+
 int tall_grid(int64_t M) {
   const int64_t ntiles = (M + 15) / 16;
   const int64_t g = (ntiles + 3) / 4;
@@ -393,6 +519,27 @@ int gnf_linear_tall_bwd(const float* g, const float* W, const float* a, const fl
   const int64_t nw = N * K, ncols = nw + N + (gxsum ? K : 0);
   hipLaunchKernelGGL(lin_tall_reduce_k, dim3((unsigned)((ncols + 63) / 64)), dim3(1024), 0, s, ws, grid, nw, (int64_t)N, K, ncols,
                      gW, gb, gxsum);
+  GNF_LAUNCH_CHECK();
+  return 0;
+}
+
+bool gnf_linear_tall_wgrad_ok(int64_t M, int64_t N, int64_t K, int64_t ldg, int64_t lda) {
+  static const bool off = getenv("GNF_LINEAR_TALL") && getenv("GNF_LINEAR_TALL")[0] == '0';
+  return !off && M >= 2048 && N >= 1 && N <= 64 && K >= 1 && K <= 64 && ldg >= N && lda >= K && M * (lda > ldg ? lda : ldg) * 4 < (1ll << 31);
+}
+
+int gnf_linear_tall_wgrad_parts(int64_t M) { return tall_grid(M); }
+
+int gnf_linear_tall_wgrad(const float* g, int64_t ldg, const float* a, int64_t lda, float* gW, float* gb, int accumulate_b,
+                          int64_t M, int64_t N, int64_t K, float* partW, float* partB, hipStream_t s) {
+  const int grid = tall_grid(M);
+  const dim3 gd((unsigned)grid), blk(512);
+  if (N <= 32) hipLaunchKernelGGL((lin_wgrad_tall_k<2>), gd, blk, 0, s, g, (int)ldg, a, (int)lda, partW, partB, (int)M, (int)N, (int)K);
+  else hipLaunchKernelGGL((lin_wgrad_tall_k<4>), gd, blk, 0, s, g, (int)ldg, a, (int)lda, partW, partB, (int)M, (int)N, (int)K);
+  GNF_LAUNCH_CHECK();
+  const int64_t nw = N * K;
+  hipLaunchKernelGGL(lin_wgrad_reduce_k, dim3((unsigned)((nw + N + 63) / 64)), dim3(1024), 0, s, partW, partB, grid, nw, N, gW,
+                     gb, accumulate_b);
   GNF_LAUNCH_CHECK();
   return 0;
 }

@@ -28,6 +28,7 @@
 // the split-K fp32 MFMA GEMM (gnf_gemm.hip) contracts them, chunk by chunk.
 #include "gnf_common.h"
 #include "gnf_gemm.h"
+#include "gnf_linear_tall.h"
 #include "gnf_monotonic.h"
 #include <cstdlib>
 
@@ -2296,7 +2297,11 @@ int gnf_monotonic_bwd(const float* pack, const gnf_mono_net* net, const float* x
       if (ck == 0) nsp_w = gnf_gemm_num_splits(rows, kSplits);
       if ((rc = gnf_gemm_launch(g, ck == 0 ? kSplits : (int)nsp_w, s))) return rc;
     }
-    {  // d W1[:,1:] (+)= Dsum^T * h
+    // d W1[:,1:] = Dsum^T h and d b1 = colsum Dsum: one tall weight-gradient launch + its reduction for narrow nets on
+    // contiguous conditioner outputs (cfg4: 17 + 5 + 13 us of GEMM, split-K reduction and two-stage column sum before)
+    const bool tall_w1 = nchunks == 1 && h_sc == 1 && HP <= 64 &&
+                         gnf_linear_tall_wgrad_ok(a.ecount, HP, L.c, HP, h_sd);
+    if (!tall_w1) {  // d W1[:,1:] (+)= Dsum^T * h
       GemmArgs g{};
       g.A = a.Dsum; g.sam = 1; g.sak = HP;
       g.B = h + a.e0 * h_sd; g.sbk = h_sd; g.sbn = h_sc;
@@ -2306,7 +2311,13 @@ int gnf_monotonic_bwd(const float* pack, const gnf_mono_net* net, const float* x
       if ((rc = gnf_gemm_launch(g, ck == 0 ? kSplits : (int)nsp_h, s))) return rc;
     }
     if ((rc = rowsum(a.part, w + P.o_vec, part_rows, vecw, ck > 0))) return rc;
-    if (HT > 4 || a.ones) {            // first-layer bias gradient (and wide nets' others): column sums of staged arrays
+    if (tall_w1) {
+      nsp_h = 0;                       // (no split-K partials to sum behind the loop)
+      if ((rc = gnf_linear_tall_wgrad(a.Dsum, HP, h + a.e0 * h_sd, h_sd, w + P.o_dW1h,
+                                      (HT > 4 || a.ones) ? w + P.o_vec + 2 * HP : nullptr, 1, a.ecount, HP, L.c,
+                                      w + P.o_hpart, w + P.o_rs, s)))
+        return rc;
+    } else if (HT > 4 || a.ones) {     // first-layer bias gradient (and wide nets' others): column sums of staged arrays
       if ((rc = gnf_rowsum_tall_launch(a.Dsum, w + P.o_vec + 2 * HP, groups * 16, HP, 1, w + P.o_rs, s))) return rc;
       if (HT > 10)
         for (int l = 1; l < NH; ++l)
@@ -2323,7 +2334,7 @@ int gnf_monotonic_bwd(const float* pack, const gnf_mono_net* net, const float* x
     if (!indw && (rc = rowsum(w + P.o_gpart[l], w + P.o_dW[l], nsp_w, HP * HP, 0))) return rc;
     u.dWpad[l] = w + P.o_dW[l];
   }
-  if ((rc = rowsum(w + P.o_hpart, w + P.o_dW1h, nsp_h, HP * L.c, 0))) return rc;
+  if (nsp_h > 0 && (rc = rowsum(w + P.o_hpart, w + P.o_dW1h, nsp_h, HP * L.c, 0))) return rc;
   u.dW1h = w + P.o_dW1h; u.vec = w + P.o_vec; u.ones = a.ones;
   hipLaunchKernelGGL(mono_unpack_k, dim3(64), dim3(256), 0, s, u);
   GNF_LAUNCH_CHECK();

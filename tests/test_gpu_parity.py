@@ -1007,7 +1007,10 @@ def test_baseline_configs_train_step(name, B):
                                         # more than one round of the 256 persistent workgroups with a ragged last round:
                                         # 8238 elements = 256 full groups of 32 + three HALF groups (16 elements x 4 nodes
                                         # per batch, the last one with 14 elements); 8220 = 256 + two half groups
-                                        (1373, 6, [100, 100, 100]), (1370, 6, [150, 150])])
+                                        (1373, 6, [100, 100, 100]), (1370, 6, [150, 150]),
+                                        # narrow nets above 2048 elements: d W1h = Dsum^T h and d b1 on the tall
+                                        # weight-gradient kernel (gnf_linear_tall_wgrad) instead of GEMM + reductions
+                                        (300, 7, [50, 50, 50]), (131, 17, [40, 64, 24]), (2049, 1, [16, 16])])
 def test_monotonic_ragged_sizes(B, d, hidden):
     """element counts that leave wavefronts of the last workgroup without a group of their own (and the wide-net
     weight-swapping mode, whose workgroups iterate in lockstep) -- regression for a staging clobber by tail waves; the
