@@ -152,10 +152,25 @@ __global__ __launch_bounds__(64 * FWD_WAVES) void cnn_fwd_k(CnnArgs a) {
 // ---------------------------------------------------------------------------------------------
 constexpr int A1SZ = NCH * CH;
 
+// 2x2 max pool of one (channel, tile): the four outputs of the tile
+__device__ __forceinline__ void pool_store4(const CnnArgs& a, int64_t o, float v00, float v01, float v10, float v11) {
+  float best = v00; int bi = 0;                        // first max wins ties (torch max_pool2d order)
+  if (v01 > best) { best = v01; bi = 1; }
+  if (v10 > best) { best = v10; bi = 2; }
+  if (v11 > best) { best = v11; bi = 3; }
+  a.pooled[o] = best;
+  a.arg[o] = (unsigned char)bi;
+}
+// column half of the output transform (s0 / s1 = the two rows of A^T M) + the pool
+__device__ __forceinline__ void pool_store(const CnnArgs& a, int64_t o, const float (&s0)[4], const float (&s1)[4]) {
+  pool_store4(a, o, s0[0] + s0[1] + s0[2], s0[1] - s0[2] - s0[3], s1[0] + s1[1] + s1[2], s1[1] - s1[2] - s1[3]);
+}
+
 __global__ __launch_bounds__(64 * FWD_WAVES) void cnn_fwd_wino_k(CnnArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* e_s = smem;                       // [2][ESZ]
   float* a1_s = smem + 2 * ESZ;            // [2][16][26][ROW]
+  float* xch = smem + 2 * ESZ + 2 * A1SZ;  // [2 items][2 halves][16][64]: partial output transforms of the split items
   const int tid = threadIdx.x, lane = tid & 63, q = lane >> 4, j = lane & 15;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   constexpr int NW = FWD_WAVES, NT = 64 * FWD_WAVES;
@@ -207,6 +222,17 @@ __global__ __launch_bounds__(64 * FWD_WAVES) void cnn_fwd_wino_k(CnnArgs a) {
     c1off[k] = (((tile < 86 ? sl : 0) * ESZ + y * ROWE + x) << 16) | (ok ? (sl << 15) | (y * ROW + x) : 0xFFFF);
   }
 
+  int64_t prev_ob = -1;                    // output offset of this wavefront's split item of the previous pair (or none)
+  auto finish_split = [&](const float* xb0, int64_t ob) {      // xb0: [2 halves][16][64] of the item
+    const float* xa = xb0 + lane;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      float v[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) v[k] = xa[(r * 4 + k) * 64] + xa[16 * 64 + (r * 4 + k) * 64];
+      pool_store4(a, ob + r * (PO * PO), v[0], v[1], v[2], v[3]);
+    }
+  };
   const int64_t npair = (a.n + 1) >> 1;
   constexpr int EPT = (2 * IMG * IMG + NT - 1) / NT;          // pixels of an image pair per thread
   float pre[EPT];
@@ -261,8 +287,17 @@ __global__ __launch_bounds__(64 * FWD_WAVES) void cnn_fwd_wino_k(CnnArgs a) {
     }
     __syncthreads();
 
+    // the split items of the PREVIOUS pair: the partner's half arrived before the barrier at the top of this iteration
+    if (wave < 4 && !(wave & 1) && prev_ob >= 0) finish_split(xch + (wave >> 1) * 2 * 16 * 64, prev_ob);
+    prev_ob = -1;
+
+    // 18 items (image, group of 16 Winograd tiles) over 4 SIMDs: 16 whole ones, two per wavefront, and the last two
+    // SPLIT by xi_y halves over the wavefronts 0..3 (one per SIMD), so that every SIMD carries 4.5 items instead of
+    // 5 / 5 / 4 / 4 (two SIMDs idle for one item in five).  A half item accumulates 8 of the 16 transform points, applies
+    // its rows of the output transform A^T M (row sums are additive in xi_y) and leaves 32 partial values per lane in
+    // LDS; the wavefront holding xi_y = 0, 1 adds its partner's at the top of the next iteration (above) and finishes.
 #pragma nounroll
-    for (int item = wave; item < 18; item += NW) {
+    for (int item = wave; item < 16; item += NW) {
       const int s = item >= 9, grp = item - 9 * s;     // wave-uniform
       const int64_t img = 2 * pair + s;
       if (img >= a.n) continue;
@@ -308,21 +343,74 @@ __global__ __launch_bounds__(64 * FWD_WAVES) void cnn_fwd_wino_k(CnnArgs a) {
           s0[c] = acc[c][r] + acc[4 + c][r] + acc[8 + c][r];
           s1[c] = acc[4 + c][r] - acc[8 + c][r] - acc[12 + c][r];
         }
-        const float v00 = s0[0] + s0[1] + s0[2], v01 = s0[1] - s0[2] - s0[3];
-        const float v10 = s1[0] + s1[1] + s1[2], v11 = s1[1] - s1[2] - s1[3];
-        float best = v00; int bi = 0;                  // first max wins ties (torch max_pool2d order)
-        if (v01 > best) { best = v01; bi = 1; }
-        if (v10 > best) { best = v10; bi = 2; }
-        if (v11 > best) { best = v11; bi = 3; }
-        a.pooled[ob + r * (PO * PO)] = best;
-        a.arg[ob + r * (PO * PO)] = (unsigned char)bi;
+        pool_store(a, ob + r * (PO * PO), s0, s1);
+      }
+    }
+    if (wave < 4) {
+      const int item = 16 + (wave >> 1), hf = wave & 1;          // item 16 / 17 = groups 7 / 8 of image 1; xi_y in {2 hf, 2 hf + 1}
+      const int grp = item - 9;
+      const int64_t img = 2 * pair + 1;
+      if (img < a.n) {
+        const int t = 16 * grp + j, ty = t / 12, tx = t - 12 * ty;
+        const float* base = a1_s + A1SZ + q * CH + 2 * ty * ROW + 2 * tx;
+        f32x4 acc[8];
+#pragma unroll
+        for (int xi = 0; xi < 8; ++xi) acc[xi] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (hf == 0) acc[5] = b2v;
+        f32x2 plo[4], phi[4];
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+          plo[rr] = *reinterpret_cast<const f32x2*>(base + rr * ROW);
+          phi[rr] = *reinterpret_cast<const f32x2*>(base + rr * ROW + 2);
+        }
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          float vv[16];
+          wino_in(plo, phi, vv);
+          if (g < 3) {
+            const float* p = base + 4 * (g + 1) * CH;
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) {
+              plo[rr] = *reinterpret_cast<const f32x2*>(p + rr * ROW);
+              phi[rr] = *reinterpret_cast<const f32x2*>(p + rr * ROW + 2);
+            }
+          }
+          __builtin_amdgcn_sched_barrier(0);
+          if (hf == 0) {
+#pragma unroll
+            for (int xi = 0; xi < 8; ++xi) acc[xi] = mfma(uw[xi * 4 + g], vv[xi], acc[xi]);
+          } else {
+#pragma unroll
+            for (int xi = 0; xi < 8; ++xi) acc[xi] = mfma(uw[(8 + xi) * 4 + g], vv[8 + xi], acc[xi]);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        // this half's share of A^T M A: rows s0 += xi_y 0, 1, 2;  s1 += xi_y 1, -2, -3, then the (linear) column half
+        float* xb = xch + ((wave >> 1) * 2 + hf) * 16 * 64 + lane;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float p0[4], p1[4];
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            p0[c] = hf == 0 ? acc[c][r] + acc[4 + c][r] : acc[c][r];
+            p1[c] = hf == 0 ? acc[4 + c][r] : -acc[c][r] - acc[4 + c][r];
+          }
+          xb[(r * 4 + 0) * 64] = p0[0] + p0[1] + p0[2];
+          xb[(r * 4 + 1) * 64] = p0[1] - p0[2] - p0[3];
+          xb[(r * 4 + 2) * 64] = p1[0] + p1[1] + p1[2];
+          xb[(r * 4 + 3) * 64] = p1[1] - p1[2] - p1[3];
+        }
+        if (hf == 0) prev_ob = img * NPOOL + 4 * q * (PO * PO) + t;
       }
     }
   }
+  __syncthreads();                                     // the last pair's halves
+  if (wave < 4 && !(wave & 1) && prev_ob >= 0) finish_split(xch + (wave >> 1) * 2 * 16 * 64, prev_ob);
 }
 
 constexpr size_t kFwdLds = (size_t)(ESZ + NCH * CH) * sizeof(float);
-constexpr size_t kWinoLds = (size_t)(2 * ESZ + 2 * A1SZ) * sizeof(float);
+constexpr size_t kWinoLds = (size_t)(2 * ESZ + 2 * A1SZ + 2 * 2 * 16 * 64) * sizeof(float);   // + the split items' exchange
+static_assert(kWinoLds <= 160 * 1024, "one workgroup per CU");
 constexpr unsigned kWinoGrid = 256;                  // one 8-wave workgroup per CU, two images per iteration
 constexpr unsigned kFwdGrid = 512;                   // direct kernel: 512 measured faster than 256
 
