@@ -401,8 +401,10 @@ __global__ __launch_bounds__(64 * BWD_WAVES) void cnn_bwd_wino_k(CnnArgs a) {
     for (int k = 0; k < 8; ++k) a.part[((int64_t)gridDim.x * NW + 1) * PROW + wave * 8 + k] = (float)tacc[k];
 #endif
 
-  // ---- per-wave partial row: dW2 [16][144] | dW1+db1 [16][16] | db2 [16]
-  float* prow = a.part + ((int64_t)blockIdx.x * NW + wave) * PROW;
+  // ---- per-wave partial row: dW2 [16][144] | dW1+db1 [16][16] | db2 [16] -- into LDS (the images are done), the eight
+  //      rows of the workgroup are then added in wavefront order: 256 partial rows for the row-sum launch, not 2048
+  __syncthreads();                                     // the last de gather has read its T planes
+  float* prow = smem + wave * PROW;
 #pragma unroll
   for (int r = 0; r < 4; ++r) {          // this half's share of dw = G^T dU G for (o = 4q+r, c = j); the halves add up
     float ar[3][4];                      // G^T = [[1,.5,.5,0],[0,.5,-.5,0],[0,.5,.5,1]]
@@ -438,6 +440,14 @@ __global__ __launch_bounds__(64 * BWD_WAVES) void cnn_bwd_wino_k(CnnArgs a) {
   for (int off = 16; off > 0; off >>= 1) gb2 += __shfl_xor(gb2, off, 64);    // over the 32 threads of a channel
   if ((lane & 31) == 0) prow[NCH * 144 + NCH * 16 + 2 * wave + (lane >> 5)] = gb2;
   if (lane < NCH && (lane >> 1) != wave) prow[NCH * 144 + NCH * 16 + lane] = 0.f;
+  __syncthreads();
+  float* grow = a.part + (int64_t)blockIdx.x * PROW;
+  for (int i = tid; i < PROW; i += 64 * NW) {
+    float v = smem[i];
+#pragma unroll
+    for (int w = 1; w < NW; ++w) v += smem[w * PROW + i];
+    grow[i] = v;
+  }
 }
 
 // unpack the summed partial row into the parameter-shaped gradients
@@ -455,6 +465,7 @@ __global__ void cnn_unpack_k(const float* __restrict__ vec, float* gW1, float* g
 
 constexpr size_t kBwdWinoLds = (size_t)(2 * ESZB + NCH * CHB + DSZW + 9 * CS + USZ) * sizeof(float);
 static_assert(kBwdWinoLds <= 160 * 1024, "conv backward LDS image");
+static_assert((size_t)BWD_WAVES * PROW * sizeof(float) <= kBwdWinoLds, "the partial rows of the epilogue reuse the image LDS");
 // one 8-wave workgroup per CU: at its 256 VGPRs a second one is not admitted
 constexpr unsigned kBwdGrid = 256;
 
@@ -482,7 +493,7 @@ int gnf_mnistcnn_conv_bwd(const float* e, const float* W1, const float* b1, cons
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)kBwdWinoLds);
   hipLaunchKernelGGL(cnn_bwd_wino_k, dim3(kBwdGrid), dim3(64 * BWD_WAVES), kBwdWinoLds, (hipStream_t)stream, a);
   GNF_LAUNCH_CHECK();
-  const int64_t rows = (int64_t)kBwdGrid * BWD_WAVES;
+  const int64_t rows = (int64_t)kBwdGrid;             // one partial row per workgroup
   float* vec = (float*)ws + rows * PROW;
   const int rc = gnf_rowsum_launch((const float*)ws, vec, rows, PROW, 0, (hipStream_t)stream);
   if (rc) return rc;
