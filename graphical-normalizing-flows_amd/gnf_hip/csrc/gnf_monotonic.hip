@@ -2297,10 +2297,10 @@ int gnf_monotonic_bwd(const float* pack, const gnf_mono_net* net, const float* x
       if (ck == 0) nsp_w = gnf_gemm_num_splits(rows, kSplits);
       if ((rc = gnf_gemm_launch(g, ck == 0 ? kSplits : (int)nsp_w, s))) return rc;
     }
-    // d W1[:,1:] = Dsum^T h and d b1 = colsum Dsum: one tall weight-gradient launch + its reduction for narrow nets on
-    // contiguous conditioner outputs (cfg4: 17 + 5 + 13 us of GEMM, split-K reduction and two-stage column sum before)
-    const bool tall_w1 = nchunks == 1 && h_sc == 1 && HP <= 64 &&
-                         gnf_linear_tall_wgrad_ok(a.ecount, HP, L.c, HP, h_sd);
+    // d W1[:,1:] = Dsum^T h and d b1 = colsum Dsum: tall weight-gradient launches (64 hidden units each) + their
+    // reductions on contiguous conditioner outputs instead of a split-K tiled GEMM, its reduction and a two-stage column
+    // sum (cfg4: 17 + 5 + 13 us; cfg5, where Dsum is 2 GB: 3.6 + 0.8 ms at 0.7 TB/s)
+    const bool tall_w1 = nchunks == 1 && h_sc == 1 && gnf_linear_tall_wgrad_ok(a.ecount, HP < 64 ? HP : 64, L.c, HP, h_sd);
     if (!tall_w1) {  // d W1[:,1:] (+)= Dsum^T * h
       GemmArgs g{};
       g.A = a.Dsum; g.sam = 1; g.sak = HP;
@@ -2313,10 +2313,13 @@ int gnf_monotonic_bwd(const float* pack, const gnf_mono_net* net, const float* x
     if ((rc = rowsum(a.part, w + P.o_vec, part_rows, vecw, ck > 0))) return rc;
     if (tall_w1) {
       nsp_h = 0;                       // (no split-K partials to sum behind the loop)
-      if ((rc = gnf_linear_tall_wgrad(a.Dsum, HP, h + a.e0 * h_sd, h_sd, w + P.o_dW1h,
-                                      (HT > 4 || a.ones) ? w + P.o_vec + 2 * HP : nullptr, 1, a.ecount, HP, L.c,
-                                      w + P.o_hpart, w + P.o_rs, s)))
-        return rc;
+      for (int64_t u0 = 0; u0 < HP; u0 += 64) {
+        const int64_t nu = HP - u0 < 64 ? HP - u0 : 64;
+        if ((rc = gnf_linear_tall_wgrad(a.Dsum + u0, HP, h + a.e0 * h_sd, h_sd, w + P.o_dW1h + u0 * L.c,
+                                        (HT > 4 || a.ones) ? w + P.o_vec + 2 * HP + u0 : nullptr, 1, a.ecount, nu, L.c,
+                                        w + P.o_hpart, w + P.o_rs, s)))
+          return rc;
+      }
     } else if (HT > 4 || a.ones) {     // first-layer bias gradient (and wide nets' others): column sums of staged arrays
       if ((rc = gnf_rowsum_tall_launch(a.Dsum, w + P.o_vec + 2 * HP, groups * 16, HP, 1, w + P.o_rs, s))) return rc;
       if (HT > 10)
