@@ -60,7 +60,7 @@ SIGNATURES = {
     "gnf_dag_gate_fwd": (c_int, [c_f, c_f, c_f, c_i64, c_int, c_int, c_float, c_float, c_f, c_f, c_u64, c_u64, c_int,
                                  c_f, c_i64, c_i64, c_stream]),
     "gnf_dag_gate_bwd_ws_bytes": (c_i64, [c_i64, c_i64]),
-    "gnf_dag_gate_bwd": (c_int, [c_f, c_f, c_f, c_i64, c_int, c_int, c_float, c_float, c_f, c_f, c_u64, c_u64, c_f,
+    "gnf_dag_gate_bwd": (c_int, [c_f, c_f, c_f, c_i64, c_int, c_int, c_float, c_float, c_f, c_f, c_u64, c_u64, c_f, c_f,
                                  c_f, c_f, c_i64, c_i64, c_stream]),
     "gnf_monotonic_pack_floats": (c_i64, [ctypes.POINTER(MonoNet)]),
     "gnf_monotonic_pack": (c_int, [ctypes.POINTER(MonoNet), c_f, c_stream]),

@@ -451,15 +451,18 @@ int64_t gnf_dag_gate_bwd_ws_bytes(int64_t B, int64_t d) {
 
 int gnf_dag_gate_bwd(const float* x, const float* A, const float* ge, int64_t ld_e, int imp_mode, int gate_mode,
                      float h_thresh, float temperature, const float* u1, const float* u2, uint64_t seed,
-                     uint64_t offset, float* gA, float* gx, float* ws, int64_t B, int64_t d, gnf_stream_t stream) {
+                     uint64_t offset, const float* tab_fwd, float* gA, float* gx, float* ws, int64_t B, int64_t d,
+                     gnf_stream_t stream) {
   if (((!x || !ge) && B > 0) || !A || !ws || B < 0 || d <= 0 || imp_mode < 0 || imp_mode > 3 || gate_mode < 0 ||
       gate_mode > 2)
     return GNF_EINVAL;                // empty batch: gA = 0 through the same kernels
   if (gate_mode == 1 && u1 && !u2) return GNF_EINVAL;
   if (imp_mode == 0) gate_mode = 0;
   hipStream_t s = (hipStream_t)stream;
-  float* tab = ws;                           // [4][d*d] table, then the chunk partials
-  int rc = launch_tab(A, tab, imp_mode, h_thresh, temperature, d, s);
+  // [4][d*d] table, then the chunk partials.  tab_fwd: the table the forward call left at the start of ITS workspace
+  // (same A / imp_mode / h_thresh / temperature), if the caller kept that buffer: one launch less
+  const float* tab = tab_fwd ? tab_fwd : ws;
+  int rc = tab_fwd ? 0 : launch_tab(A, ws, imp_mode, h_thresh, temperature, d, s);
   if (rc) return rc;
   GateArgs a{};
   a.x = x; a.tab = tab; a.ge = ge; a.ld_e = ld_e; a.gate_mode = gate_mode; a.T = temperature; a.u1 = u1; a.u2 = u2;

@@ -450,11 +450,26 @@ __global__ __launch_bounds__(64 * BWD_WAVES) void cnn_bwd_wino_k(CnnArgs a) {
   }
 }
 
-// unpack the summed partial row into the parameter-shaped gradients
-__global__ void cnn_unpack_k(const float* __restrict__ vec, float* gW1, float* gb1, float* gW2, float* gb2) {
-  const int n = blockIdx.x * blockDim.x + threadIdx.x;
-  if (n >= PROW) return;
-  const float s = vec[n];
+// the workgroups' partial rows summed in row order (64 columns per workgroup, wavefront w of 16 takes rows w, w + 16, ...,
+// the 16 sums meet in LDS: deterministic) and written straight into the parameter-shaped gradients
+__global__ __launch_bounds__(1024) void cnn_reduce_unpack_k(const float* __restrict__ part, int rows, float* gW1, float* gb1,
+                                                            float* gW2, float* gb2) {
+  __shared__ float red[16][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int n = blockIdx.x * 64 + lane;
+  float s0 = 0.f, s1 = 0.f;
+  if (n < PROW) {
+    const float* p = part + n;
+    int r = wave;
+    for (; r + 16 < rows; r += 32) { s0 += p[(int64_t)r * PROW]; s1 += p[(int64_t)(r + 16) * PROW]; }
+    for (; r < rows; r += 16) s0 += p[(int64_t)r * PROW];
+  }
+  red[wave][lane] = s0 + s1;
+  __syncthreads();
+  if (wave != 0 || n >= PROW) return;
+  float s = red[0][lane];
+#pragma unroll
+  for (int w = 1; w < 16; ++w) s += red[w][lane];
   if (n < NCH * 144) gW2[n] = s;
   else if (n < NCH * 144 + NCH * 16) {
     const int k = n - NCH * 144, oc = k >> 4, c = k & 15;
@@ -493,12 +508,9 @@ int gnf_mnistcnn_conv_bwd(const float* e, const float* W1, const float* b1, cons
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)kBwdWinoLds);
   hipLaunchKernelGGL(cnn_bwd_wino_k, dim3(kBwdGrid), dim3(64 * BWD_WAVES), kBwdWinoLds, (hipStream_t)stream, a);
   GNF_LAUNCH_CHECK();
-  const int64_t rows = (int64_t)kBwdGrid;             // one partial row per workgroup
-  float* vec = (float*)ws + rows * PROW;
-  const int rc = gnf_rowsum_launch((const float*)ws, vec, rows, PROW, 0, (hipStream_t)stream);
-  if (rc) return rc;
-  hipLaunchKernelGGL(cnn_unpack_k, dim3((PROW + 255) / 256), dim3(256), 0, (hipStream_t)stream, vec, gW1, gb1, gW2,
-                     gb2);
+  // one partial row per workgroup -> the four gradients, one launch
+  hipLaunchKernelGGL(cnn_reduce_unpack_k, dim3((PROW + 63) / 64), dim3(1024), 0, (hipStream_t)stream, (const float*)ws,
+                     (int)kBwdGrid, gW1, gb1, gW2, gb2);
   GNF_LAUNCH_CHECK();
   return 0;
 }

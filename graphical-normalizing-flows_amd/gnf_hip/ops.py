@@ -532,9 +532,12 @@ class DagGateFn(torch.autograd.Function):
         e = _empty((B * d, ld), x)
         u1 = u1.contiguous() if u1 is not None else None
         u2 = u2.contiguous() if u2 is not None else None
-        ws = _ws(abi.load().gnf_dag_gate_fwd_ws_bytes(d), x)
+        nws = abi.load().gnf_dag_gate_fwd_ws_bytes(d)
+        keep = A.requires_grad or x.requires_grad          # a backward will follow: its own buffer keeps the (i, j) table
+        ws = torch.empty(max(int(nws) // 4, 1), dtype=torch.float32, device=x.device) if keep else _ws(nws, x)
         call("gnf_dag_gate_fwd", ptr(x), ptr(A), ptr(e), ld, imp_mode, gate_mode, float(h_thresh), float(temperature),
              ptr(u1), ptr(u2), seed, offset, int(hot), ptr(ws), B, d, stream())
+        ctx.tab = ws if (keep and B > 0) else None
         ctx.save_for_backward(x, A, u1, u2)
         ctx.cfg = (imp_mode, gate_mode, float(h_thresh), float(temperature), ld, seed, offset)
         return e
@@ -549,7 +552,7 @@ class DagGateFn(torch.autograd.Function):
         gx = _empty((B, d), x) if ctx.needs_input_grad[0] else None
         ws = _ws(abi.load().gnf_dag_gate_bwd_ws_bytes(B, d), x)
         call("gnf_dag_gate_bwd", ptr(x), ptr(A), ptr(ge), ld, imp_mode, gate_mode, h_thresh, temperature, ptr(u1),
-             ptr(u2), seed, offset, ptr(gA), ptr(gx), ptr(ws), B, d, stream())
+             ptr(u2), seed, offset, ptr(ctx.tab), ptr(gA), ptr(gx), ptr(ws), B, d, stream())
         return gx, (finish(gA) if gA is not None else None), None, None, None, None, None, None, None, None, None
 
 

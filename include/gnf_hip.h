@@ -156,11 +156,13 @@ int gnf_dag_gate_fwd(const float* x, const float* A, float* e, int64_t ld_e,
                      const float* u1, const float* u2, uint64_t seed, uint64_t offset,
                      int hot, float* ws, int64_t B, int64_t d, gnf_stream_t stream);
 /* ge: [(B*d), ld_e].  gA: [d,d] (written, not accumulated) or NULL; gx: [B,d] or NULL.
+ * tab_fwd: the workspace the matching gnf_dag_gate_fwd call was given, if the caller kept it intact (its first
+ * gnf_dag_gate_fwd_ws_bytes(d) bytes hold the per-(i,j) table of the same A and gate settings), else NULL = recomputed.
  * ws: >= gnf_dag_gate_bwd_ws_bytes(B,d). */
 int64_t gnf_dag_gate_bwd_ws_bytes(int64_t B, int64_t d);
 int gnf_dag_gate_bwd(const float* x, const float* A, const float* ge, int64_t ld_e,
                      int imp_mode, int gate_mode, float h_thresh, float temperature,
-                     const float* u1, const float* u2, uint64_t seed, uint64_t offset,
+                     const float* u1, const float* u2, uint64_t seed, uint64_t offset, const float* tab_fwd,
                      float* gA, float* gx, float* ws, int64_t B, int64_t d, gnf_stream_t stream);
 
 /* ---- DAG acyclicity + l1 term: DAGConditioner.get_power_trace / loss (DAGConditioner.py:176-194, 268-271) --------
