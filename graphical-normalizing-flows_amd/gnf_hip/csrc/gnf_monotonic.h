@@ -71,7 +71,8 @@ struct MonoArgs {
   int indw;                             // backward: weight gradients accumulated in the chain kernel (1, 2: narrow nets;
                                         // 3: wide nets, gnf_monotonic_wide.hip)
   float* wpart;                         // [workgroups * kWaves][(NH-1) * HP * HP] accumulator rows of that variant
-                                        // (indw = 3: one row per workgroup)
+                                        // (indw = 3, or wcomb: one row per workgroup)
+  int wcomb;                            // mono_bwd_pair_x_k: the wavefronts' accumulator rows are added in LDS at the end
 };
 
 __device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }

@@ -1688,8 +1688,12 @@ __global__ __launch_bounds__(64 * kWaves, 1) void mono_bwd_pair_x_k(MonoArgs a) 
     }
   const float vbl = jsum(p_bL);
   if (lane == 0) { prow[(NH + 2) * HP] = vbl; prow[(NH + 2) * HP + 1] = 0.f; prow[(NH + 2) * HP + 2] = 0.f; prow[(NH + 2) * HP + 3] = 0.f; }
-  // ---- accumulator rows in the padded [HP][HP] form (row = out unit, column = in unit, column HP-1 = bias gradient)
-  float* wrow = a.wpart + ((int64_t)blockIdx.x * kWaves + wave) * ((NH - 1) * HP * HP);
+  // ---- accumulator rows in the padded [HP][HP] form (row = out unit, column = in unit, column HP-1 = bias gradient).
+  //      wcomb: through LDS (every wavefront is done with the image and its tiles), the workgroup's four rows added in
+  //      wavefront order -- 256 partial rows (8 MB at NH = 3) for the row-sum launch instead of 1024 (33 MB)
+  constexpr int WSZ = (NH - 1) * HP * HP;
+  if (a.wcomb) __syncthreads();
+  float* wrow = a.wcomb ? smem + wave * WSZ : a.wpart + ((int64_t)blockIdx.x * kWaves + wave) * WSZ;
 #pragma unroll
   for (int l = 0; l < NH - 1; ++l)
 #pragma unroll
@@ -1698,6 +1702,16 @@ __global__ __launch_bounds__(64 * kWaves, 1) void mono_bwd_pair_x_k(MonoArgs a) 
       for (int tn = 0; tn < HT; ++tn)
 #pragma unroll
         for (int r = 0; r < 4; ++r) wrow[l * HP * HP + (16 * ti + 4 * q + r) * HP + 16 * tn + j] = accW[l][ti][tn][r];
+  if (a.wcomb) {
+    __syncthreads();
+    float* grow = a.wpart + (int64_t)blockIdx.x * WSZ;
+    for (int i = 4 * threadIdx.x; i < WSZ; i += 4 * 64 * kWaves) {
+      f32x4 v = ld4(smem + i);
+#pragma unroll
+      for (int w = 1; w < kWaves; ++w) v += ld4(smem + w * WSZ + i);
+      *reinterpret_cast<f32x4*>(grow + i) = v;
+    }
+  }
 }
 
 struct UnpackArgs {
@@ -2250,6 +2264,8 @@ int gnf_monotonic_bwd(const float* pack, const gnf_mono_net* net, const float* x
                              (size_t)kWaves * (2 * (NH - 1) + 1) * 16 * kTS) * sizeof(float);
     static const bool one = getenv("GNF_MONO_INDW") && getenv("GNF_MONO_INDW")[0] == '1';
     if (lds_pair <= (size_t)160 * 1024 && !one) a.indw = 2;
+    // the peeled two-node kernel can add its wavefronts' weight-gradient rows in LDS when they fit its allocation
+    a.wcomb = a.indw == 2 && HT == 4 && L.EX > 0 && (size_t)kWaves * (NH - 1) * HP * HP * sizeof(float) <= lds_pair;
   }
   a.wpart = w + P.o_wpart;
   const unsigned bwd_grid = wide ? gnf_mono_bwd_wide_grid(L, n < P.chunk_elems ? n : P.chunk_elems)
@@ -2260,7 +2276,7 @@ int gnf_monotonic_bwd(const float* pack, const gnf_mono_net* net, const float* x
   };
   const int64_t nchunks = (n + P.chunk_elems - 1) / P.chunk_elems;
   const int64_t part_rows = (int64_t)bwd_grid * kWaves;
-  const int64_t wpart_rows = wide ? (int64_t)bwd_grid : part_rows;
+  const int64_t wpart_rows = (wide || a.wcomb) ? (int64_t)bwd_grid : part_rows;
   int64_t nsp_w = 1, nsp_h = 1;
   int rc = 0;
   for (int64_t ck = 0; ck < nchunks; ++ck) {
