@@ -502,7 +502,10 @@ int gnf_linear_tall_fwd(const float* x, const float* W, const float* b, int relu
                         hipStream_t s) {
   const int64_t ntiles = (M + 15) / 16;
   int64_t grid = (ntiles + 3) / 4;
-  if (grid > 256 * 3) grid = 256 * 3;
+  // one 4-wavefront workgroup per CU: every wavefront first pulls the whole weight into registers (15 KB at 30 x 128), so
+  // more, shorter-lived wavefronts re-read it more often than they add loads in flight (78 400 x 128 -> 30, HIP events
+  // around the entry point: 128 workgroups 23.8 us, 256: 16.6, 384: 22.3, 512: 19.5, 768: 20.7, 1225: 23.4)
+  if (grid > 256) grid = 256;
   const dim3 g((unsigned)grid);
   GNF_TALL_DISPATCH(launch_tall_fwd, N, K, g, s, x, W, b, relu, y, (int)M, (int)N, (int)K);
   GNF_LAUNCH_CHECK();
