@@ -310,7 +310,7 @@ __device__ __forceinline__ void lin_bwdw_body(f32x4 (*red)[4][64], float (*redb)
       for (int c = 0; c < 4; ++c) v[c] *= deg_keep(dcv[c], dr, mk.strict);
     } else if (MK == MK_FULL) {
 #pragma unroll
-      for (int c = 0; c < 4; ++c) v[c] *= mk.full[ib + c < K ? off + c : off];
+      for (int c = 0; c < 4; ++c) v[c] *= mk.full[ib + c < K ? off + c : (int64_t)o * K];   // never past row o (ib may be >= K)
     }
     if (ibok) *reinterpret_cast<f32x4u*>(gW + off) = v;
     else {

@@ -2338,10 +2338,12 @@ int gnf_monotonic_bwd(const float* pack, const gnf_mono_net* net, const float* x
       }
     } else if (HT > 4 || a.ones) {     // first-layer bias gradient (and wide nets' others): column sums of staged arrays
       if ((rc = gnf_rowsum_tall_launch(a.Dsum, w + P.o_vec + 2 * HP, groups * 16, HP, 1, w + P.o_rs, s))) return rc;
-      if (HT > 10)
-        for (int l = 1; l < NH; ++l)
-          if ((rc = gnf_rowsum_tall_launch(a.SD[l], w + P.o_vec + (2 + l) * HP, rows, HP, 1, w + P.o_rs, s))) return rc;
     }
+    // widest nets (H = 161..256): bias gradients of the hidden->hidden layers = column sums of the staged dpre rows --
+    // on BOTH first-layer paths (inside the else-branch above they were skipped whenever tall_w1 held: zero db_l)
+    if (HT > 10)
+      for (int l = 1; l < NH; ++l)
+        if ((rc = gnf_rowsum_tall_launch(a.SD[l], w + P.o_vec + (2 + l) * HP, rows, HP, 1, w + P.o_rs, s))) return rc;
   }
   if ((HT == 7 || HT == 10) && !wide)  // bias gradients of the hidden->hidden layers: partial column sums of mono_dw_k
     for (int l = 1; l < NH; ++l)

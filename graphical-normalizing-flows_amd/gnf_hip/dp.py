@@ -78,6 +78,13 @@ class FlatState:
             for p in self.params:
                 p.grad = None
 
+    def drop_grads(self):
+        """forget every pending gradient (the reference's zero_grad() between accumulation windows): clears .grad AND the
+        record of which flat-buffer slots the backward kernels handed out, so the next backward writes in place again"""
+        for p in self.params:
+            p.grad = None
+        self._taken.clear()
+
     def broadcast(self, src=0):
         if collective_on():
             if dist.get_backend() == "gloo" and self.flat.is_cuda:

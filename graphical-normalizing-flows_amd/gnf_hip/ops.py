@@ -239,12 +239,22 @@ class NllMeanFn(torch.autograd.Function):
 def stash_logn(z, logn):
     """remember the Normal log-density that was reduced in the pass producing z; NormalLogDensity picks it up when it is
     handed the very same tensor (flow.loss(z, logdet) right after flow(x)) instead of reading z again"""
-    z._gnf_logn = logn
+    z._gnf_logn = (logn, z._version, z.data_ptr())
     return z
 
 
 def cached_logn(z):
-    return getattr(z, "_gnf_logn", None)
+    """the stashed density, or None when z is not the untouched tensor it was reduced from: an in-place update
+    (z.add_(..), clamp_) bumps z._version and keeps the Python attribute, so the stash alone would be stale
+    (reference: NormalizingFlowFactories.py:15-16 always reads the z it is handed)"""
+    st = getattr(z, "_gnf_logn", None)
+    if st is None:
+        return None
+    logn, version, data_ptr = st
+    if z._version != version or z.data_ptr() != data_ptr:
+        z._gnf_logn = None
+        return None
+    return logn
 
 
 def colsum(a):

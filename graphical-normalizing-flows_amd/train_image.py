@@ -243,8 +243,8 @@ def train(args):
             if args.max_batches:
                 shards = shards[:args.max_batches]
             if k_acc > 1:                                    # micro-batch gradients left over from an epoch whose batch
-                for p in state.params:                       # count is no multiple of k are dropped, as the reference's
-                    p.grad = None                            # zero_grad() at batch_idx % k == 0 does (:210-211)
+                state.drop_grads()                           # count is no multiple of k are dropped, as the reference's
+                                                             # zero_grad() at batch_idx % k == 0 does (:210-211)
             for n, rows in enumerate(shards, 1):
                 if norm_t is MonotonicNormalizer:            # node-count jitter (:201-203)
                     k = args.nb_steps + int(torch.randint(0, 10, [1], generator=host_gen))

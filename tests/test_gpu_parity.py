@@ -755,6 +755,34 @@ def test_flow_loss_uses_the_density_reduced_with_z():
             assert rel_err(a.cpu(), b.cpu()) < 1e-5
 
 
+@pytest.mark.parametrize("norm_kind", ["affine", "monotonic"])
+def test_normal_log_density_ignores_a_stale_stash(norm_kind):
+    """the density stashed on z by the kernel that produced it must not survive an in-place update of z: the reference's
+    NormalLogDensity (NormalizingFlowFactories.py:15-16) always reads the z it is handed."""
+    from models import buildFCNormalizingFlow, AutoregressiveConditioner, AffineNormalizer, MonotonicNormalizer
+    from gnf_hip import ops
+    torch.manual_seed(5)
+    norm_t, args, hs = ((AffineNormalizer, {}, 2) if norm_kind == "affine" else
+                        (MonotonicNormalizer, {"integrand_net": [16, 16], "cond_size": 6, "nb_steps": 15, "solver": "CC"}, 6))
+    flow = buildFCNormalizingFlow(1, AutoregressiveConditioner, {"in_size": 9, "hidden": [32, 32], "out_size": hs},
+                                  norm_t, args).to(DEV)
+    x = torch.randn(33, 9, device=DEV)
+    with torch.no_grad():
+        z, ld = flow(x)
+        assert ops.cached_logn(z) is not None
+        fresh = O.normal_log_density(z.cpu())
+        assert_close(flow.z_log_density(z), fresh, what="stashed density")
+        z.add_(1.)                                            # any in-place change: version counter moves, attribute stays
+        assert ops.cached_logn(z) is None
+        moved = O.normal_log_density(z.cpu())
+        assert (moved - fresh).abs().max() > .1               # the test would be blind otherwise
+        assert_close(flow.z_log_density(z), moved, what="density after z.add_")
+        assert abs(flow.loss(z, ld).item() - (-(ld.cpu() + moved).mean()).item()) < 1e-5 * max(1., moved.abs().mean().item())
+        z2, _ = flow(x)                                       # a different tensor with the same storage is not the stashed one
+        v = z2.view(-1).view(33, 9)
+        assert ops.cached_logn(v) is None
+
+
 # --------------------------------------------------------------------------------- Monotonic vs oracle
 def _mono_case(B, d, c, hidden, S, seed, h_layout="contig"):
     from models import MonotonicNormalizer
@@ -1010,7 +1038,11 @@ def test_baseline_configs_train_step(name, B):
                                         (1373, 6, [100, 100, 100]), (1370, 6, [150, 150]),
                                         # narrow nets above 2048 elements: d W1h = Dsum^T h and d b1 on the tall
                                         # weight-gradient kernel (gnf_linear_tall_wgrad) instead of GEMM + reductions
-                                        (300, 7, [50, 50, 50]), (131, 17, [40, 64, 24]), (2049, 1, [16, 16])])
+                                        (300, 7, [50, 50, 50]), (131, 17, [40, 64, 24]), (2049, 1, [16, 16]),
+                                        # widest nets (H = 161..256, the UCI configs' [200,200,200]) on the same tall
+                                        # first-layer path: the hidden-layer BIAS gradients are column sums of the staged
+                                        # dpre rows and were skipped there (zero db_l) -- round-3 advisor finding
+                                        (300, 7, [200, 200]), (420, 5, [200, 200, 200])])
 def test_monotonic_ragged_sizes(B, d, hidden):
     """element counts that leave wavefronts of the last workgroup without a group of their own (and the wide-net
     weight-swapping mode, whose workgroups iterate in lockstep) -- regression for a staging clobber by tail waves; the

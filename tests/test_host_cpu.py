@@ -3,6 +3,7 @@ declares; host-side logic of the mirrored plug-in API (constructors, masks, prio
 state_dict keys, quadrature rule) against the reference-generated golden vectors; and the
 product path refuses to run without the GPU (no CPU fallback)."""
 import ctypes
+import math
 import os
 import re
 
@@ -204,3 +205,61 @@ def test_bench_launcher_spawns_ranks_without_touching_the_gpu(tmp_path, monkeypa
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4"], cwd=ROOT, env=env,
                        capture_output=True, text=True)
     assert r.returncode != 0 and "WORLD_SIZE=2" in r.stderr
+
+
+REF_FACTORIES = "/root/reference/models/NormalizingFlowFactories.py"
+
+
+@pytest.mark.skipif(not os.path.exists(REF_FACTORIES), reason="the reference tree exists in the build container only")
+def test_reference_factory_source_runs_unchanged_on_the_repo_classes():
+    """north_star: "drops into NormalizingFlowFactories unchanged".  The reference's OWN factory file is loaded (never
+    copied) as a module of the repo's `models` package, so its `from .Normalizers import *`, `.Conditionners`,
+    `.NormalizingFlow`, `.MLP` imports resolve to the MI355X-backed classes; the flows it builds must be the repo's
+    classes with the reference's state_dict keys (reference NormalizingFlowFactories.py:19-32, 49-97)."""
+    import importlib.util
+    import models
+    from models import (CouplingConditioner, AutoregressiveConditioner, DAGConditioner, AffineNormalizer,
+                        MonotonicNormalizer, MNISTCNN)
+    from models.NormalizingFlow import NormalizingFlowStep, FCNormalizingFlow, CNNormalizingFlow
+    spec = importlib.util.spec_from_file_location("models._reference_factories", REF_FACTORIES)
+    ref = importlib.util.module_from_spec(spec)
+    ref.__package__ = "models"
+    spec.loader.exec_module(ref)
+    assert ref.NormalizingFlowStep is NormalizingFlowStep and ref.DAGConditioner is DAGConditioner   # repo classes
+    assert os.path.samefile(ref.__file__, REF_FACTORIES) and ref is not models.NormalizingFlowFactories
+
+    fc_cases = {
+        "flow_affine_coupling_3": ref.buildFCNormalizingFlow(3, CouplingConditioner, {"in_size": 5, "hidden": [16, 16],
+                                                                                      "out_size": 2}, AffineNormalizer, {}),
+        "flow_affine_dag_2": ref.buildFCNormalizingFlow(2, DAGConditioner, {"in_size": 6, "hidden": [16, 16], "out_size": 2,
+                                                                            "l1": .05, "gumble_T": .5, "hot_encoding": True},
+                                                        AffineNormalizer, {}),
+        "flow_mono_made_1": ref.buildFCNormalizingFlow(1, AutoregressiveConditioner, {"in_size": 4, "hidden": [12, 12],
+                                                                                      "out_size": 6},
+                                                       MonotonicNormalizer, {"integrand_net": [10, 10], "cond_size": 6,
+                                                                             "nb_steps": 20, "solver": "CC"}),
+    }
+    for name, flow in fc_cases.items():
+        assert type(flow) is FCNormalizingFlow and all(type(s) is NormalizingFlowStep for s in flow.steps)
+        assert list(flow.state_dict().keys()) == list(load_golden(name)["state_keys"]), name
+
+    # one scale (the headline model, cfg4: Monotonic + DAG over MNISTCNN, prior_kernel = 2) and its Affine golden
+    one = ref.buildMNISTNormalizingFlow([1], AffineNormalizer, {}, prior_kernel=2)
+    assert type(one) is FCNormalizingFlow and type(one.steps[0].conditioner) is DAGConditioner
+    assert type(one.steps[0].conditioner.embedding_net) is MNISTCNN
+    assert list(one.state_dict().keys()) == list(load_golden("flow_mnist_affine_dag")["state_keys"])
+    mono = ref.buildMNISTNormalizingFlow([1], MonotonicNormalizer, {"integrand_net": [50, 50, 50], "nb_steps": 20,
+                                                                    "solver": "CC"}, prior_kernel=2)
+    assert type(mono.steps[0].normalizer) is MonotonicNormalizer
+    ours = models.NormalizingFlowFactories.buildMNISTNormalizingFlow(
+        [1], MonotonicNormalizer, {"integrand_net": [50, 50, 50], "nb_steps": 20, "solver": "CC"}, prior_kernel=2)
+    assert list(mono.state_dict().keys()) == list(ours.state_dict().keys())
+    assert torch.equal(mono.steps[0].conditioner.A.detach(), ours.steps[0].conditioner.A.detach())   # = MNIST_A_prior(28, 2)
+
+    # three scales
+    three = ref.buildMNISTNormalizingFlow([1, 1, 1], AffineNormalizer, {}, prior_kernel=2)
+    assert type(three) is CNNormalizingFlow and all(type(f) is FCNormalizingFlow for f in three.steps)
+    assert list(three.state_dict().keys()) == list(load_golden("flow_mnist3_affine")["state_keys"])
+    # the reference's density class on the reference's formula, beside the repo's (the one the restated factories build)
+    z = torch.randn(5, 7)
+    assert torch.allclose(ref.NormalLogDensity()(z), -.5 * (math.log(2 * math.pi) + z ** 2).sum(1), atol=1e-6)
