@@ -1062,10 +1062,17 @@ def test_monotonic_ragged_sizes(B, d, hidden):
     z, jac = norm(xg, hg)
     assert rel_err(z.cpu(), z0.detach()) < TOL and rel_err(jac.cpu(), j0.detach()) < TOL
     ((z * cu(gz)).sum() + (jac * cu(gj)).sum()).backward()
-    assert rel_err(xg.grad.cpu(), xr.grad) < GTOL and rel_err(hg.grad.cpu(), hr.grad) < GTOL
+    # ReLU gates on the knife edge: with 2 100 elements x 22 nodes x 200 units x 3 layers a handful of pre-activations lie
+    # within fp32 roundoff of zero and the gate differs between two correct fp32 evaluations; one flipped gate moves a row
+    # of dW by ~1e-4 of the tensor's max (tools/dbg_mono_wide_grads.py against an fp64 oracle: at [150]^3 it is the TORCH
+    # fp32 oracle that sits 1.2e-4 from fp64 and the kernel 4e-7, at [200]^3 the other way round).  The defect this case
+    # guards against (bias gradients skipped: rel_err = 1) is three orders of magnitude above the relaxed bound.
+    gtol = 2e-3 if (B * d >= 2048 and max(hidden) > 160) else GTOL
+    assert rel_err(xg.grad.cpu(), xr.grad) < gtol and rel_err(hg.grad.cpu(), hr.grad) < gtol
     ps = norm.integrand_net.flat_params()
     for (W, b), pw, pb in zip(layers, ps[0::2], ps[1::2]):
-        assert rel_err(pw.grad.cpu(), W.grad) < GTOL and rel_err(pb.grad.cpu(), b.grad) < GTOL
+        assert rel_err(pw.grad.cpu(), W.grad) < gtol, ("W", tuple(W.shape), rel_err(pw.grad.cpu(), W.grad))
+        assert rel_err(pb.grad.cpu(), b.grad) < gtol, ("b", tuple(b.shape), rel_err(pb.grad.cpu(), b.grad))
 
 
 @pytest.mark.parametrize("B,d,hidden", [(4100, 6, [100, 100, 100]), (4099, 4, [150, 150])])
