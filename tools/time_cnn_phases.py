@@ -29,7 +29,7 @@ for _ in range(2):
 torch.cuda.synchronize()
 PROW = 16 * 144 + 256 + 16
 t = ws[(256 * 8 + 1) * PROW:(256 * 8 + 1) * PROW + 64].view(8, 8).cpu()
-names = ["stage e(next) + barrier A + dY2 scatter", "P1 conv1 + barrier B", "P3 dW2", "P4a mfma", "de(prev)", "P4b outT+gate", "P4c dW1", "P4d T"]
+names = ["B3 wait", "stage + prefetch", "dW2", "de(prev) + B2 wait", "conv1 first", "da1 group 0", "da1 group 1", "conv1 last + scatter(next)"]
 imgs = (n - 7 + 255) // 256
 print("rc", rc, "images per WG", imgs)
 for w in range(8):
