@@ -64,58 +64,71 @@ static_assert(CHB >= 25 * ROWB + C1 && CHB % 4 == 2, "a1 channel stride");
 static_assert(DCS % 64 == 8 && DCS >= DPAD + 64, "dY2 channel slots");
 __device__ __forceinline__ int dslot(int o) { return (o & 3) + 4 * (o >> 3) + 8 * ((o >> 2) & 1); }
 
-// conv1 tiles (of 43) each wavefront recomputes for the NEXT image inside interval Xb, as one or two batches.  The da1
-// groups are 2/2/2/1/1/1/1/1 over the wavefronts (3/3/3/2 per SIMD), so SIMD 3 (wavefronts 3, 7) takes most of conv1.
-__device__ constexpr int C1B0[8] = {0, 0, 0, 7, 7, 6, 6, 7};
-__device__ constexpr int C1B1[8] = {0, 0, 0, 5, 0, 0, 0, 5};
-__device__ constexpr int C1PRO[8] = {6, 6, 6, 5, 5, 5, 5, 5};   // the first image: dealt evenly (nothing to overlap with)
-constexpr int c1sum(const int (&a)[8], const int (&b)[8]) { int s = 0; for (int i = 0; i < 8; ++i) s += a[i] + b[i]; return s; }
-constexpr int ZERO8[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-static_assert(c1sum(C1B0, C1B1) == 43 && c1sum(C1PRO, ZERO8) == 43, "conv1 tiles");
+// conv1 is recomputed in UNITS of 64 consecutive positions of the flat 26 x 26 grid (11 per image, see conv1_units).  Units
+// each wavefront takes for the NEXT image inside interval Xb: the da1 groups are 2/2/2/1/1/1/1/1 over the wavefronts
+// (3/3/3/2 per SIMD), so SIMD 3 (wavefronts 3, 7) takes most of conv1.  (4/1/1/1/4 measured: SIMD 3 becomes the last
+// one, 2.906 -> 2.919 ms; a unit is ~1 000 cycles, the balance cannot get finer than that.)
+__device__ constexpr int C1U[8] = {0, 0, 0, 3, 2, 2, 1, 3};
+__device__ constexpr int C1PRO[8] = {2, 2, 2, 1, 1, 1, 1, 1};   // the first image: dealt evenly (nothing to overlap with)
+constexpr int c1sum(const int (&a)[8]) { int s = 0; for (int i = 0; i < 8; ++i) s += a[i]; return s; }
+constexpr int NU1 = (C1 * C1 + 63) / 64;
+static_assert(c1sum(C1U) == NU1 && c1sum(C1PRO) == NU1, "conv1 units");
 
-// conv1 + ReLU of NB flat tiles (16 consecutive positions of the 26 x 26 grid) starting at tile t0: all operand reads, NB
-// independent 3-step MFMA chains, then the stores
 // max(x, 0) as ONE v_max_f32: fmaxf() compiles into a canonicalising v_max(x, x) plus the maximum
 __device__ __forceinline__ float relu1(float x) { float y; asm("v_max_f32 %0, 0, %1" : "=v"(y) : "v"(x)); return y; }
 
-template <int NB>
-__device__ __forceinline__ void conv1_batch(const float* e_rd, float* a1_wr, int t0, const float (&w1f)[3],
-                                            const int (&off1)[3], const f32x4& b1v, int q, int j) {
-  // the tile -> LDS offsets do not depend on the image: left alone, hipcc hoists them out of the image loop for every
-  // tile of every batch (~30 registers that spill) -- the opaque copy of t0 keeps the three VALU ops per tile in place.
-  // pos = 16 tile + j; y = pos / 26 = (pos * 2521) >> 16 for pos < 1024; y * IMG + x = pos + 2 y (same pitch for e and a1)
-  asm volatile("" : "+s"(t0));
-  int po[NB];
-  f32x4 acc[NB];
-  float ev[NB][3];
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+// conv1 + ReLU of NU units starting at unit u0, on v_mfma_f32_16x16x1_4b_f32 (four independent 16 x 16 x 1 products per
+// instruction): block b = the 16-position tile 4 u + b, ONE tap per instruction -- 9 instructions per 64 positions where
+// the 16x16x4 form takes 4 x 3 K-steps (a quarter of them multiplying the zero taps 9..11).  B operand = the lane's OWN
+// position 64 u + lane, so a tap is an immediate offset of its read (one address per unit instead of three per tile);
+// A operand = W1[channel j][tap] for every block; D: register 4 b + r = channel 4 q + r at position 64 u + 16 b + j.
+// All reads first, then NU independent chains of 9 MFMAs, then the stores.
+template <int NU>
+__device__ __forceinline__ void conv1_units(const float* e_rd, float* a1_wr, int u0, const float* w1p, const f32x4& b1v,
+                                            int q, int j, int lane) {
+  // the position -> LDS offsets do not depend on the image: left alone, hipcc hoists them out of the image loop for every
+  // unit (registers that spill) -- the opaque copy of u0 keeps the few VALU ops in place.
+  // y = pos / 26 = (pos * 2521) >> 16 for pos < 1024; y * IMG + x = pos + 2 y (same pitch for e and a1)
+  u0 = __builtin_amdgcn_readfirstlane(u0);
+  asm volatile("" : "+s"(u0));
+  f32x16 acc[NU];
+  float ev[NU][9], w1a[9];
 #pragma unroll
-  for (int k = 0; k < NB; ++k) {
-    const int pos = 16 * (t0 + k) + j;
+  for (int tap = 0; tap < 9; ++tap) w1a[tap] = w1p[16 * tap];
+#pragma unroll
+  for (int k = 0; k < NU; ++k) {
+    const int pos = 64 * (u0 + k) + lane;
     const int pc = pos < C1 * C1 ? pos : 0;
-    const int o = pc + 2 * (int)(__umul24((unsigned)pc, 2521u) >> 16);
-    po[k] = pos < C1 * C1 ? o : -1;
+    const float* pe = e_rd + pc + 2 * (int)(__umul24((unsigned)pc, 2521u) >> 16);
 #pragma unroll
-    for (int s = 0; s < 3; ++s) ev[k][s] = e_rd[o + off1[s]];
-    acc[k] = b1v;
+    for (int tap = 0; tap < 9; ++tap) ev[k][tap] = pe[(tap / 3) * IMG + tap % 3];
+#pragma unroll
+    for (int v = 0; v < 16; ++v) acc[k][v] = b1v[v & 3];
   }
-  __builtin_amdgcn_sched_barrier(0);                   // all 3 NB reads in flight before the first MFMA (the scheduler
-#pragma unroll                                          // otherwise sinks every read next to its MFMA: 3 NB LDS round trips)
-  for (int s = 0; s < 3; ++s)
+  __builtin_amdgcn_sched_barrier(0);                   // all reads in flight before the first MFMA (the scheduler otherwise
+#pragma unroll                                          // sinks every read next to its MFMA: one LDS round trip each)
+  for (int tap = 0; tap < 9; ++tap)
 #pragma unroll
-    for (int k = 0; k < NB; ++k) acc[k] = mfma(w1f[s], ev[k][s], acc[k]);
+    for (int k = 0; k < NU; ++k) acc[k] = __builtin_amdgcn_mfma_f32_16x16x1f32(w1a[tap], ev[k][tap], acc[k], 0, 0, 0);
   __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-  for (int k = 0; k < NB; ++k)
-    if (po[k] >= 0) {
+  for (int k = 0; k < NU; ++k)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) a1_wr[(4 * q + r) * CHB + po[k]] = relu1(acc[k][r]);
+    for (int b = 0; b < 4; ++b) {
+      const int pos = 64 * (u0 + k) + 16 * b + j;
+      if (pos < C1 * C1) {
+        float* pa = a1_wr + 4 * q * CHB + pos + 2 * (int)(__umul24((unsigned)pos, 2521u) >> 16);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) pa[r * CHB] = relu1(acc[k][4 * b + r]);
+      }
     }
 }
-__device__ __forceinline__ void conv1_run(const float* e_rd, float* a1_wr, int t0, int nb, const float (&w1f)[3],
-                                          const int (&off1)[3], const f32x4& b1v, int q, int j) {
-  if (nb == 7) conv1_batch<7>(e_rd, a1_wr, t0, w1f, off1, b1v, q, j);          // nb is wave-uniform
-  else if (nb == 6) conv1_batch<6>(e_rd, a1_wr, t0, w1f, off1, b1v, q, j);
-  else if (nb == 5) conv1_batch<5>(e_rd, a1_wr, t0, w1f, off1, b1v, q, j);
+__device__ __forceinline__ void conv1_run(const float* e_rd, float* a1_wr, int u0, int nu, const float* w1a,
+                                          const f32x4& b1v, int q, int j, int lane) {
+  if (nu == 3) conv1_units<3>(e_rd, a1_wr, u0, w1a, b1v, q, j, lane);          // nu is wave-uniform
+  else if (nu == 2) conv1_units<2>(e_rd, a1_wr, u0, w1a, b1v, q, j, lane);
+  else if (nu == 1) conv1_units<1>(e_rd, a1_wr, u0, w1a, b1v, q, j, lane);
 }
 
 // ---- dW2: dU_xi[o][c] += sum_tiles Z_xi[o][tile] V_xi[c][tile], this wavefront's xi_y half (HY) and its 3 tile rows:
@@ -179,20 +192,14 @@ __global__ __launch_bounds__(64 * BWD_WAVES) void cnn_bwd_wino_k(CnnArgs a) {
   float* d_s = a1_s + 2 * A1B;              // dY2, window-major
   float* u_s = d_s + DSZW;                  // U' as [g][xi_y][lane][xi_x]
   unsigned* cnt_s = reinterpret_cast<unsigned*>(u_s + USZ);      // "wavefronts done reading dY2", counts up over the images
+  float* w1_s = u_s + USZ + 4;                                   // W1 as [tap][channel]: conv1's A operands are re-read per call
   const int tid = threadIdx.x, lane = tid & 63, q = lane >> 4, j = lane & 15;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   constexpr int NW = BWD_WAVES, NT = 64 * BWD_WAVES;
   static_assert(((2 * ESZB) % 4 == 0) && ((2 * A1B) % 4 == 0) && (DSZW % 4 == 0), "d_s / u_s must be 16-B aligned");
 
-  float w1f[3];
-  int off1[3];
-#pragma unroll
-  for (int s = 0; s < 3; ++s) {
-    const int tap = 4 * s + q;
-    w1f[s] = tap < 9 ? a.W1[j * 9 + tap] : 0.f;
-    const int tt = tap < 9 ? tap : 0;
-    off1[s] = (tt / 3) * IMG + tt % 3;
-  }
+  if (tid < 9 * NCH) w1_s[tid] = a.W1[(tid & 15) * 9 + (tid >> 4)];   // (nine registers per lane otherwise: the kernel is at 256)
+  const float* w1a = w1_s + j;               // W1 as A operand of conv1: row = channel j (every block), tap t at w1a[16 t]
   f32x4 b1v;
 #pragma unroll
   for (int r = 0; r < 4; ++r) b1v[r] = a.b1[4 * q + r];
@@ -350,10 +357,10 @@ __global__ __launch_bounds__(64 * BWD_WAVES) void cnn_bwd_wino_k(CnnArgs a) {
   prefetch_e(img0 + gstride);
   __syncthreads();                                               // e(0) staged, U' and the dY2 zeros written
   if (img0 < a.n) {
-    int t0 = 0;
+    int u0 = 0;
 #pragma unroll
-    for (int w = 0; w < NW; ++w) t0 += w < wave ? C1PRO[w] : 0;
-    conv1_run(e_s, a1_s, t0, C1PRO[wave], w1f, off1, b1v, q, j);
+    for (int w = 0; w < NW; ++w) u0 += w < wave ? C1PRO[w] : 0;
+    conv1_run(e_s, a1_s, u0, C1PRO[wave], w1a, b1v, q, j, lane);
   }
 
   // ---- dY2 = pool-backward scatter of g_pooled: every window holds ONE non-zero, so the previous image's entry is
@@ -402,11 +409,15 @@ __global__ __launch_bounds__(64 * BWD_WAVES) void cnn_bwd_wino_k(CnnArgs a) {
     const bool has_next = img + gstride < a.n;
     int c1t0 = 0;
 #pragma unroll
-    for (int w = 0; w < NW; ++w) c1t0 += w < wave ? C1B0[w] + C1B1[w] : 0;
+    for (int w = 0; w < NW; ++w) c1t0 += w < wave ? C1U[w] : 0;
     const bool c1_first = wave != 7;                             // SIMD 3 holds two conv1-heavy wavefronts: one starts with conv1,
-    if (has_next && c1_first) {                                  // the other with its da1 group
-      conv1_run(e_nx, a1n, c1t0, C1B0[wave], w1f, off1, b1v, q, j);
-      conv1_run(e_nx, a1n, c1t0 + C1B0[wave], C1B1[wave], w1f, off1, b1v, q, j);
+#ifdef GNF_CNN_EXP_NOCONV1
+    const bool c1_on = false;
+#else
+    const bool c1_on = has_next;
+#endif
+    if (c1_on && c1_first) {                                     // the other with its da1 group
+      conv1_run(e_nx, a1n, c1t0, C1U[wave], w1a, b1v, q, j, lane);
     }
     TSTAMP(4);
     // ---- da1: dpre1 = conv2^T(dY2) * gate on 2x2 tiles: per 4 dY2 channels (step g: channels 4q+g) 16 operands, then 16 MFMAs
@@ -480,6 +491,7 @@ __global__ __launch_bounds__(64 * BWD_WAVES) void cnn_bwd_wino_k(CnnArgs a) {
             ep[rr][0] = lo.x; ep[rr][1] = lo.y; ep[rr][2] = hi.x; ep[rr][3] = hi.y;
           }
         }
+#ifndef GNF_CNN_EXP_NODW1
 #pragma unroll
         for (int h = 0; h < 2; ++h) {                           // packed over the channel pair (2 flops per lane per op)
           f32x2 d2[4];
@@ -498,6 +510,7 @@ __global__ __launch_bounds__(64 * BWD_WAVES) void cnn_bwd_wino_k(CnnArgs a) {
             __builtin_amdgcn_sched_barrier(0);
           }
         }
+#endif
         // T[tap][pos] = sum_oc W1[oc][tap] dpre1[oc][pos]: dpre1 in the C/D layout IS the B operand
         f32x4 tq[4];
 #pragma unroll
@@ -516,9 +529,8 @@ __global__ __launch_bounds__(64 * BWD_WAVES) void cnn_bwd_wino_k(CnnArgs a) {
       }
       TSTAMP(5 + k);
     }
-    if (has_next && !c1_first) {
-      conv1_run(e_nx, a1n, c1t0, C1B0[wave], w1f, off1, b1v, q, j);
-      conv1_run(e_nx, a1n, c1t0 + C1B0[wave], C1B1[wave], w1f, off1, b1v, q, j);
+    if (c1_on && !c1_first) {
+      conv1_run(e_nx, a1n, c1t0, C1U[wave], w1a, b1v, q, j, lane);
     }
     // the next image's dY2 as soon as EVERY wavefront is done reading this one's -- normally long before this point (the
     // last group's output transform, dW1 partials and T planes lie in between): no separate barrier interval for the scatter
@@ -622,7 +634,7 @@ __global__ __launch_bounds__(1024) void cnn_reduce_unpack_k(const float* __restr
   } else gb2[n - NCH * 144 - NCH * 16] = s;
 }
 
-constexpr size_t kBwdWinoLds = (size_t)(2 * ESZB + 2 * A1B + DSZW + USZ + 4) * sizeof(float);
+constexpr size_t kBwdWinoLds = (size_t)(2 * ESZB + 2 * A1B + DSZW + USZ + 4 + 9 * NCH) * sizeof(float);
 static_assert(kBwdWinoLds <= 160 * 1024, "conv backward LDS image");
 static_assert((size_t)BWD_WAVES * PROW * sizeof(float) <= kBwdWinoLds, "the partial rows of the epilogue reuse the image LDS");
 // one 8-wave workgroup per CU: at its 256 VGPRs a second one is not admitted
