@@ -61,6 +61,56 @@ struct CnnArgs {
   int64_t n;
 };
 
+// max(x, 0) as ONE v_max_f32: fmaxf() compiles into a canonicalising v_max(x, x) plus the maximum
+__device__ __forceinline__ float relu1(float x) { float y; asm("v_max_f32 %0, 0, %1" : "=v"(y) : "v"(x)); return y; }
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+// conv1 + ReLU of NU units starting at unit u0, on v_mfma_f32_16x16x1_4b_f32 (four independent 16 x 16 x 1 products per
+// instruction): block b = the 16-position tile 4 u + b, ONE tap per instruction -- 9 instructions per 64 positions where
+// the 16x16x4 form takes 4 x 3 K-steps (a quarter of them multiplying the zero taps 9..11).  B operand = the lane's OWN
+// position 64 u + lane, so a tap is an immediate offset of its read (one address per unit instead of three per tile);
+// A operand = W1[channel j][tap] for every block; D: register 4 b + r = channel 4 q + r at position 64 u + 16 b + j.
+// All reads first, then NU independent chains of 9 MFMAs, then the stores.
+template <int NU, int CHS>
+__device__ __forceinline__ void conv1_units(const float* e_rd, float* a1_wr, int u0, const float* w1p, const f32x4& b1v,
+                                            int q, int j, int lane) {
+  // the position -> LDS offsets do not depend on the image: left alone, hipcc hoists them out of the image loop for every
+  // unit (registers that spill) -- the opaque copy of u0 keeps the few VALU ops in place.
+  // y = pos / 26 = (pos * 2521) >> 16 for pos < 1024; y * IMG + x = pos + 2 y (e and a1 share the row pitch IMG = 28; CHS = channel stride of a1)
+  u0 = __builtin_amdgcn_readfirstlane(u0);
+  asm volatile("" : "+s"(u0));
+  f32x16 acc[NU];
+  float ev[NU][9], w1a[9];
+#pragma unroll
+  for (int tap = 0; tap < 9; ++tap) w1a[tap] = w1p[16 * tap];
+#pragma unroll
+  for (int k = 0; k < NU; ++k) {
+    const int pos = 64 * (u0 + k) + lane;
+    const int pc = pos < C1 * C1 ? pos : 0;
+    const float* pe = e_rd + pc + 2 * (int)(__umul24((unsigned)pc, 2521u) >> 16);
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) ev[k][tap] = pe[(tap / 3) * IMG + tap % 3];
+#pragma unroll
+    for (int v = 0; v < 16; ++v) acc[k][v] = b1v[v & 3];
+  }
+  __builtin_amdgcn_sched_barrier(0);                   // all reads in flight before the first MFMA (the scheduler otherwise
+#pragma unroll                                          // sinks every read next to its MFMA: one LDS round trip each)
+  for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+    for (int k = 0; k < NU; ++k) acc[k] = __builtin_amdgcn_mfma_f32_16x16x1f32(w1a[tap], ev[k][tap], acc[k], 0, 0, 0);
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int k = 0; k < NU; ++k)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      const int pos = 64 * (u0 + k) + 16 * b + j;
+      if (pos < C1 * C1) {
+        float* pa = a1_wr + 4 * q * CHS + pos + 2 * (int)(__umul24((unsigned)pos, 2521u) >> 16);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) pa[r * CHS] = relu1(acc[k][4 * b + r]);
+      }
+    }
+}
 // conv1 + ReLU of the image in e_s into a1_s; 43 tiles of 16 consecutive positions of the 26x26 grid.
 // All operand reads of a wave's (up to 6) tiles are issued first, then 6 independent 3-step MFMA chains,
 // then the stores: the phase is latency-bound, so nothing may serialise behind a single chain.

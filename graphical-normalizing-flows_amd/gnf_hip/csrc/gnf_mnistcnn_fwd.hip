@@ -150,7 +150,15 @@ __global__ __launch_bounds__(64 * FWD_WAVES) void cnn_fwd_k(CnnArgs a) {
 //   D: lane (q,j) holds out-channels 4q..4q+3 of tile j for all 16 xi -> the output transform is lane-local.
 // A workgroup handles two images per iteration (18 groups of 16 tiles over 8 wavefronts: 5/5/4/4 per SIMD).
 // ---------------------------------------------------------------------------------------------
-constexpr int A1SZ = NCH * CH;
+// LDS geometry of the Winograd forward (round 4): a1 as [image][16][26][WROW = 28] with channel stride WCH = 736.
+//  * the patch gather reads row pairs of 16 consecutive tiles of ONE channel per 16-lane group (hipcc fuses the two b64
+//    halves of a patch row into one ds_read2_b64: 2 x 4 groups of 16 contiguous lanes over 32 banks): tiles are 2 dwords
+//    apart, 12 per tile row, so the row wrap 2 WROW - 22 must be 2 (mod 32): WROW = 28 (the [26][40] image of rounds 1-3
+//    put the wrap at 26 mod 32: bank conflicts were 47 % of the LDS-active cycles, profiles/r03_cnn_pmc.json);
+//    WCH = 32 (mod 64) keeps the two channels of a 32-lane group apart where the halves stay plain ds_read_b64.
+//  * 47 KB per image instead of 66.5; the input images are unpadded (pitch 28 = WROW: one offset serves e and a1).
+constexpr int WROW = IMG, WCH = 736, A1SZ = NCH * WCH, WESZ = IMG * IMG;
+static_assert(WCH >= 25 * WROW + C1 && WCH % 64 == 32 && (2 * WROW - 22) % 32 == 2, "forward a1 layout");
 
 // 2x2 max pool of one (channel, tile): the four outputs of the tile
 __device__ __forceinline__ void pool_store4(const CnnArgs& a, int64_t o, float v00, float v01, float v10, float v11) {
@@ -166,24 +174,20 @@ __device__ __forceinline__ void pool_store(const CnnArgs& a, int64_t o, const fl
   pool_store4(a, o, s0[0] + s0[1] + s0[2], s0[1] - s0[2] - s0[3], s1[0] + s1[1] + s1[2], s1[1] - s1[2] - s1[3]);
 }
 
+// conv1 units (64 positions each, 11 per image) per wavefront: image 0 on wavefronts 0-3, image 1 on wavefronts 4-7
+__device__ constexpr int FC1U[4] = {3, 3, 3, 2};
+
 __global__ __launch_bounds__(64 * FWD_WAVES) void cnn_fwd_wino_k(CnnArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* e_s = smem;                       // [2][ESZ]
-  float* a1_s = smem + 2 * ESZ;            // [2][16][26][ROW]
-  float* xch = smem + 2 * ESZ + 2 * A1SZ;  // [2 items][2 halves][16][64]: partial output transforms of the split items
+  float* e_s = smem;                       // [2][28 x 28]
+  float* a1_s = smem + 2 * WESZ;           // [2][16][26][WROW]
+  float* xch = a1_s + 2 * A1SZ;            // [2 items][2 halves][16][64]: partial output transforms of the split items
+  float* w1_s = xch + 2 * 2 * 16 * 64;     // W1 as [tap][channel]: conv1's A operands, re-read per call
   const int tid = threadIdx.x, lane = tid & 63, q = lane >> 4, j = lane & 15;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   constexpr int NW = FWD_WAVES, NT = 64 * FWD_WAVES;
 
-  float w1f[3];
-  int off1[3];
-#pragma unroll
-  for (int s = 0; s < 3; ++s) {
-    const int tap = 4 * s + q;
-    w1f[s] = tap < 9 ? a.W1[j * 9 + tap] : 0.f;
-    const int tt = tap < 9 ? tap : 0;
-    off1[s] = (tt / 3) * ROWE + tt % 3;
-  }
+  if (tid < 9 * NCH) w1_s[tid] = a.W1[(tid & 15) * 9 + (tid >> 4)];
   f32x4 b1v, b2v;
 #pragma unroll
   for (int r = 0; r < 4; ++r) { b1v[r] = a.b1[4 * q + r]; b2v[r] = a.b2[4 * q + r]; }
@@ -208,19 +212,12 @@ __global__ __launch_bounds__(64 * FWD_WAVES) void cnn_fwd_wino_k(CnnArgs a) {
     }
   }
 
-  for (int i = tid; i < 2 * ESZ; i += NT) e_s[i] = 0.f;
-  // conv1 tile k of this wavefront: (image slot, 16 positions) -> e_s offset (high half) | a1_s offset (low half,
-  // 0xFFFF: nothing to store).  a1 offsets of slot 1 exceed 16 bits, so the slot is folded in as s * A1SZ at use.
-  int c1off[12];
+  // this wavefront's conv1 units: image slot wave / 4, units [c1u0, c1u0 + FC1U[wave & 3])
+  const int c1s = wave >> 2;
+  int c1u0 = 0;
 #pragma unroll
-  for (int k = 0; k < 12; ++k) {
-    const int tile = wave + NW * k;
-    const int sl = tile >= 43, pos = 16 * (tile - 43 * sl) + j;
-    const bool ok = tile < 86 && pos < C1 * C1;
-    const int pc = ok ? pos : 0;
-    const int y = pc / C1, x = pc - y * C1;
-    c1off[k] = (((tile < 86 ? sl : 0) * ESZ + y * ROWE + x) << 16) | (ok ? (sl << 15) | (y * ROW + x) : 0xFFFF);
-  }
+  for (int w = 0; w < 4; ++w) c1u0 += w < (wave & 3) ? FC1U[w] : 0;
+  const int c1n = FC1U[wave & 3];
 
   int64_t prev_ob = -1;                    // output offset of this wavefront's split item of the previous pair (or none)
   auto finish_split = [&](const float* xb0, int64_t ob) {      // xb0: [2 halves][16][64] of the item
@@ -250,41 +247,14 @@ __global__ __launch_bounds__(64 * FWD_WAVES) void cnn_fwd_wino_k(CnnArgs a) {
 #pragma unroll
     for (int k = 0; k < EPT; ++k) {
       const int i = tid + k * NT;
-      if (i < 2 * IMG * IMG) {
-        const int s = i >= IMG * IMG, p = i - s * (IMG * IMG);
-        e_s[s * ESZ + (p / IMG) * ROWE + p % IMG] = pre[k];
-      }
+      if (i < 2 * IMG * IMG) e_s[i] = pre[k];          // the two unpadded images are contiguous in LDS as in memory
     }
     __syncthreads();
     fetch(pair + gridDim.x);                           // next pair's pixels: in flight under the MFMAs
 
-    // conv1 + ReLU of both images: 86 tiles of 16 consecutive positions, up to 6 in flight per wavefront; the tile ->
-    // LDS offsets are the same for every image pair and come packed from c1off (computed once per kernel)
-#pragma unroll
-    for (int k0 = 0; k0 < 12; k0 += 6) {
-      f32x4 acc[6];
-      float ev[6][3];
-#pragma unroll
-      for (int k = 0; k < 6; ++k) {
-        const float* pe = e_s + (c1off[k0 + k] >> 16);
-#pragma unroll
-        for (int t = 0; t < 3; ++t) ev[k][t] = pe[off1[t]];
-        acc[k] = b1v;
-      }
-#pragma unroll
-      for (int t = 0; t < 3; ++t)
-#pragma unroll
-        for (int k = 0; k < 6; ++k) acc[k] = mfma(w1f[t], ev[k][t], acc[k]);
-#pragma unroll
-      for (int k = 0; k < 6; ++k) {
-        const int pk = c1off[k0 + k] & 0xFFFF;
-        if (pk != 0xFFFF) {
-          const int po = (pk >> 15) * A1SZ + (pk & 0x7FFF);
-#pragma unroll
-          for (int r = 0; r < 4; ++r) a1_s[(4 * q + r) * CH + po] = fmaxf(acc[k][r], 0.f);
-        }
-      }
-    }
+    // conv1 + ReLU of both images: 2 x 11 units of 64 positions on v_mfma_f32_16x16x1_4b_f32 (gnf_mnistcnn.h)
+    if (c1n == 3) conv1_units<3, WCH>(e_s + c1s * WESZ, a1_s + c1s * A1SZ, c1u0, w1_s + j, b1v, q, j, lane);
+    else conv1_units<2, WCH>(e_s + c1s * WESZ, a1_s + c1s * A1SZ, c1u0, w1_s + j, b1v, q, j, lane);
     __syncthreads();
 
     // the split items of the PREVIOUS pair: the partner's half arrived before the barrier at the top of this iteration
@@ -302,7 +272,7 @@ __global__ __launch_bounds__(64 * FWD_WAVES) void cnn_fwd_wino_k(CnnArgs a) {
       const int64_t img = 2 * pair + s;
       if (img >= a.n) continue;
       const int t = 16 * grp + j, ty = t / 12, tx = t - 12 * ty;
-      const float* base = a1_s + s * A1SZ + q * CH + 2 * ty * ROW + 2 * tx;
+      const float* base = a1_s + s * A1SZ + q * WCH + 2 * ty * WROW + 2 * tx;
       f32x4 acc[16];
 #pragma unroll
       for (int xi = 0; xi < 16; ++xi) acc[xi] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -313,19 +283,19 @@ __global__ __launch_bounds__(64 * FWD_WAVES) void cnn_fwd_wino_k(CnnArgs a) {
       f32x2 plo[4], phi[4];                            // patch rows as two column pairs
 #pragma unroll
       for (int rr = 0; rr < 4; ++rr) {
-        plo[rr] = *reinterpret_cast<const f32x2*>(base + rr * ROW);
-        phi[rr] = *reinterpret_cast<const f32x2*>(base + rr * ROW + 2);
+        plo[rr] = *reinterpret_cast<const f32x2*>(base + rr * WROW);
+        phi[rr] = *reinterpret_cast<const f32x2*>(base + rr * WROW + 2);
       }
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         float vv[16];
         wino_in(plo, phi, vv);
         if (g < 3) {
-          const float* p = base + 4 * (g + 1) * CH;
+          const float* p = base + 4 * (g + 1) * WCH;
 #pragma unroll
           for (int rr = 0; rr < 4; ++rr) {
-            plo[rr] = *reinterpret_cast<const f32x2*>(p + rr * ROW);
-            phi[rr] = *reinterpret_cast<const f32x2*>(p + rr * ROW + 2);
+            plo[rr] = *reinterpret_cast<const f32x2*>(p + rr * WROW);
+            phi[rr] = *reinterpret_cast<const f32x2*>(p + rr * WROW + 2);
           }
         }
         __builtin_amdgcn_sched_barrier(0);
@@ -352,7 +322,7 @@ __global__ __launch_bounds__(64 * FWD_WAVES) void cnn_fwd_wino_k(CnnArgs a) {
       const int64_t img = 2 * pair + 1;
       if (img < a.n) {
         const int t = 16 * grp + j, ty = t / 12, tx = t - 12 * ty;
-        const float* base = a1_s + A1SZ + q * CH + 2 * ty * ROW + 2 * tx;
+        const float* base = a1_s + A1SZ + q * WCH + 2 * ty * WROW + 2 * tx;
         f32x4 acc[8];
 #pragma unroll
         for (int xi = 0; xi < 8; ++xi) acc[xi] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -360,19 +330,19 @@ __global__ __launch_bounds__(64 * FWD_WAVES) void cnn_fwd_wino_k(CnnArgs a) {
         f32x2 plo[4], phi[4];
 #pragma unroll
         for (int rr = 0; rr < 4; ++rr) {
-          plo[rr] = *reinterpret_cast<const f32x2*>(base + rr * ROW);
-          phi[rr] = *reinterpret_cast<const f32x2*>(base + rr * ROW + 2);
+          plo[rr] = *reinterpret_cast<const f32x2*>(base + rr * WROW);
+          phi[rr] = *reinterpret_cast<const f32x2*>(base + rr * WROW + 2);
         }
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
           float vv[16];
           wino_in(plo, phi, vv);
           if (g < 3) {
-            const float* p = base + 4 * (g + 1) * CH;
+            const float* p = base + 4 * (g + 1) * WCH;
 #pragma unroll
             for (int rr = 0; rr < 4; ++rr) {
-              plo[rr] = *reinterpret_cast<const f32x2*>(p + rr * ROW);
-              phi[rr] = *reinterpret_cast<const f32x2*>(p + rr * ROW + 2);
+              plo[rr] = *reinterpret_cast<const f32x2*>(p + rr * WROW);
+              phi[rr] = *reinterpret_cast<const f32x2*>(p + rr * WROW + 2);
             }
           }
           __builtin_amdgcn_sched_barrier(0);
@@ -409,7 +379,7 @@ __global__ __launch_bounds__(64 * FWD_WAVES) void cnn_fwd_wino_k(CnnArgs a) {
 }
 
 constexpr size_t kFwdLds = (size_t)(ESZ + NCH * CH) * sizeof(float);
-constexpr size_t kWinoLds = (size_t)(2 * ESZ + 2 * A1SZ + 2 * 2 * 16 * 64) * sizeof(float);   // + the split items' exchange
+constexpr size_t kWinoLds = (size_t)(2 * WESZ + 2 * A1SZ + 2 * 2 * 16 * 64 + 9 * NCH) * sizeof(float);   // + the split items' exchange, the W1 table
 static_assert(kWinoLds <= 160 * 1024, "one workgroup per CU");
 constexpr unsigned kWinoGrid = 256;                  // one 8-wave workgroup per CU, two images per iteration
 constexpr unsigned kFwdGrid = 512;                   // direct kernel: 512 measured faster than 256
