@@ -148,7 +148,6 @@ __global__ __launch_bounds__(64 * FWD_WAVES) void cnn_fwd_k(CnnArgs a) {
 //   A operand = U_xi (transformed weights, 64 registers per lane, resident for the whole kernel),
 //   B operand = V_xi computed by the lane itself from its 4x4 patch (8 ds_read_b64 + 32 adds feed 16 MFMAs),
 //   D: lane (q,j) holds out-channels 4q..4q+3 of tile j for all 16 xi -> the output transform is lane-local.
-// A workgroup handles two images per iteration (18 groups of 16 tiles over 8 wavefronts: 5/5/4/4 per SIMD).
 // ---------------------------------------------------------------------------------------------
 // LDS geometry of the Winograd forward (round 4): a1 as [image][16][26][WROW = 28] with channel stride WCH = 736.
 //  * the patch gather reads row pairs of 16 consecutive tiles of ONE channel per 16-lane group (hipcc fuses the two b64
@@ -160,32 +159,35 @@ __global__ __launch_bounds__(64 * FWD_WAVES) void cnn_fwd_k(CnnArgs a) {
 constexpr int WROW = IMG, WCH = 736, A1SZ = NCH * WCH, WESZ = IMG * IMG;
 static_assert(WCH >= 25 * WROW + C1 && WCH % 64 == 32 && (2 * WROW - 22) % 32 == 2, "forward a1 layout");
 
-// 2x2 max pool of one (channel, tile): the four outputs of the tile
-__device__ __forceinline__ void pool_store4(const CnnArgs& a, int64_t o, float v00, float v01, float v10, float v11) {
-  float best = v00; int bi = 0;                        // first max wins ties (torch max_pool2d order)
-  if (v01 > best) { best = v01; bi = 1; }
-  if (v10 > best) { best = v10; bi = 2; }
-  if (v11 > best) { best = v11; bi = 3; }
-  a.pooled[o] = best;
-  a.arg[o] = (unsigned char)bi;
-}
-// column half of the output transform (s0 / s1 = the two rows of A^T M) + the pool
-__device__ __forceinline__ void pool_store(const CnnArgs& a, int64_t o, const float (&s0)[4], const float (&s1)[4]) {
-  pool_store4(a, o, s0[0] + s0[1] + s0[2], s0[1] - s0[2] - s0[3], s1[0] + s1[1] + s1[2], s1[1] - s1[2] - s1[3]);
-}
-
-// conv1 units (64 positions each, 11 per image) per wavefront: image 0 on wavefronts 0-3, image 1 on wavefronts 4-7
-__device__ constexpr int FC1U[4] = {3, 3, 3, 2};
+// ---------------------------------------------------------------------------------------------
+// Round 4: ONE image per barrier interval, two a1 buffers -- the next image's conv1 runs UNDER this image's Winograd items
+// (rounds 1-3: two images per iteration, conv1 in a barrier interval of its own).  Per interval i
+// (p = i & 1):   items of image i from a1[p]  |  conv1(i+1): e[1-p] -> a1[1-p]  |  stage e(i+2) -> e[p]  |  the
+// previous image's split item is finished.  9 items + 11 conv1 units (~0.3 item each) over 4 SIMDs: every wavefront one
+// whole item (group w), group 8 split by xi_y halves over wavefronts 0 and 1, the units dealt to the others:
+//   SIMD 0 (w0, w4): 1.5 + 1 items + 2 units     SIMD 2 (w2, w6): 2 items + 4 units
+//   SIMD 1 (w1, w5): 1.5 + 1 items + 2 units     SIMD 3 (w3, w7): 2 items + 3 units
+// (1/1/5/4 units measured: the same within the +-3 % run-to-run spread of this kernel, as is the round-3 structure with two
+// images per iteration and conv1 in a barrier interval of its own: 1.34-1.42 ms in every variant on one box -- the kernel
+// is bound by its ALU work, 64 MFMAs + ~260 other VALU instructions per item at two wavefronts per SIMD.)
+// and of the two wavefronts of a SIMD one starts with its units (latency-bound), the other with its item (MFMA-bound).
+// Outputs leave through per-image buffer descriptors (one 32-bit lane offset, no 64-bit address arithmetic).
+// ---------------------------------------------------------------------------------------------
+__device__ constexpr int F1U[8] = {0, 0, 2, 2, 2, 2, 2, 1};          // conv1 units of the next image per wavefront
+__device__ constexpr int F1PRO[8] = {2, 2, 2, 1, 1, 1, 1, 1};        // the first image: dealt evenly
+constexpr int fsum(const int (&v)[8]) { int t = 0; for (int i = 0; i < 8; ++i) t += v[i]; return t; }
+static_assert(fsum(F1U) == 11 && fsum(F1PRO) == 11, "conv1 units");
 
 __global__ __launch_bounds__(64 * FWD_WAVES) void cnn_fwd_wino_k(CnnArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* e_s = smem;                       // [2][28 x 28]
   float* a1_s = smem + 2 * WESZ;           // [2][16][26][WROW]
-  float* xch = a1_s + 2 * A1SZ;            // [2 items][2 halves][16][64]: partial output transforms of the split items
+  float* xch = a1_s + 2 * A1SZ;            // [2 images][2 halves][16][64]: partial output transforms of the split item
   float* w1_s = xch + 2 * 2 * 16 * 64;     // W1 as [tap][channel]: conv1's A operands, re-read per call
   const int tid = threadIdx.x, lane = tid & 63, q = lane >> 4, j = lane & 15;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   constexpr int NW = FWD_WAVES, NT = 64 * FWD_WAVES;
+  typedef __amdgpu_buffer_rsrc_t rsrc_t;
 
   if (tid < 9 * NCH) w1_s[tid] = a.W1[(tid & 15) * 9 + (tid >> 4)];
   f32x4 b1v, b2v;
@@ -212,176 +214,185 @@ __global__ __launch_bounds__(64 * FWD_WAVES) void cnn_fwd_wino_k(CnnArgs a) {
     }
   }
 
-  // this wavefront's conv1 units: image slot wave / 4, units [c1u0, c1u0 + FC1U[wave & 3])
-  const int c1s = wave >> 2;
-  int c1u0 = 0;
+  auto rsrc_of = [&](const void* base, int64_t im, int bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(static_cast<const char*>(base)) + im * bytes, 0,
+                                             im < a.n ? bytes : 0, 0x00020000);
+  };
+  constexpr int EPT = (IMG * IMG + NT - 1) / NT;
+  float pre[EPT];
+  auto fetch = [&](int64_t im) {           // raw loads only; out-of-range lanes / images read 0
+    const rsrc_t rs = rsrc_of(a.e, im, IMG * IMG * 4);
 #pragma unroll
-  for (int w = 0; w < 4; ++w) c1u0 += w < (wave & 3) ? FC1U[w] : 0;
-  const int c1n = FC1U[wave & 3];
-
-  int64_t prev_ob = -1;                    // output offset of this wavefront's split item of the previous pair (or none)
-  auto finish_split = [&](const float* xb0, int64_t ob) {      // xb0: [2 halves][16][64] of the item
+    for (int k = 0; k < EPT; ++k) pre[k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, (tid + k * NT) * 4, 0, 0));
+  };
+  auto stage = [&](float* dst) {
+#pragma unroll
+    for (int k = 0; k < EPT; ++k)
+      if (tid + k * NT < IMG * IMG) dst[tid + k * NT] = pre[k];
+  };
+  // 2x2 max pool of (channel 4q+r, tile t) into the image's outputs; first max wins ties (torch max_pool2d order)
+  auto pool_out = [&](rsrc_t rp, rsrc_t ra, int t, int r, float v00, float v01, float v10, float v11) {
+    float best = v00; int bi = 0;
+    if (v01 > best) { best = v01; bi = 1; }
+    if (v10 > best) { best = v10; bi = 2; }
+    if (v11 > best) { best = v11; bi = 3; }
+    const int o = (4 * q + r) * (PO * PO) + t;
+    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, best), rp, o * 4, 0, 0);
+    __builtin_amdgcn_raw_buffer_store_b8((unsigned char)bi, ra, o, 0, 0);
+  };
+  auto finish_split = [&](const float* xb0, int64_t im) {      // xb0: [2 halves][16][64] of the item (group 8)
+    const rsrc_t rp = rsrc_of(a.pooled, im, NPOOL * 4), ra = rsrc_of(a.arg, im, NPOOL);
     const float* xa = xb0 + lane;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       float v[4];
 #pragma unroll
       for (int k = 0; k < 4; ++k) v[k] = xa[(r * 4 + k) * 64] + xa[16 * 64 + (r * 4 + k) * 64];
-      pool_store4(a, ob + r * (PO * PO), v[0], v[1], v[2], v[3]);
+      pool_out(rp, ra, 16 * 8 + j, r, v[0], v[1], v[2], v[3]);
     }
   };
-  const int64_t npair = (a.n + 1) >> 1;
-  constexpr int EPT = (2 * IMG * IMG + NT - 1) / NT;          // pixels of an image pair per thread
-  float pre[EPT];
-  auto fetch = [&](int64_t pair) {
-#pragma unroll
-    for (int k = 0; k < EPT; ++k) {
-      const int i = tid + k * NT;
-      const int64_t o = pair * (2 * IMG * IMG) + i;
-      pre[k] = (pair < npair && i < 2 * IMG * IMG && o < a.n * (IMG * IMG)) ? a.e[o] : 0.f;
-    }
+  auto conv1_do = [&](const float* e_rd, float* a1_wr, int u0, int nu) {     // nu wave-uniform
+    if (nu == 3) conv1_units<3, WCH>(e_rd, a1_wr, u0, w1_s + j, b1v, q, j, lane);
+    else if (nu == 2) conv1_units<2, WCH>(e_rd, a1_wr, u0, w1_s + j, b1v, q, j, lane);
+    else if (nu == 1) conv1_units<1, WCH>(e_rd, a1_wr, u0, w1_s + j, b1v, q, j, lane);
   };
-  fetch(blockIdx.x);
-  for (int64_t pair = blockIdx.x; pair < npair; pair += gridDim.x) {
-    __syncthreads();                                   // previous pair fully consumed
+  // one whole item: group grp of 16 tiles of the image in a1
+  auto whole_item = [&](const float* a1, int grp, int64_t im) {
+    const int t = 16 * grp + j, ty = t / 12, tx = t - 12 * ty;
+    const float* base = a1 + q * WCH + 2 * ty * WROW + 2 * tx;
+    f32x4 acc[16];
 #pragma unroll
-    for (int k = 0; k < EPT; ++k) {
-      const int i = tid + k * NT;
-      if (i < 2 * IMG * IMG) e_s[i] = pre[k];          // the two unpadded images are contiguous in LDS as in memory
+    for (int xi = 0; xi < 16; ++xi) acc[xi] = f32x4{0.f, 0.f, 0.f, 0.f};
+    acc[5] = b2v;                                      // xi = (1,1) reaches all four outputs with weight +1: the bias
+    f32x2 plo[4], phi[4];                              // patch rows as two column pairs
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) {
+      plo[rr] = *reinterpret_cast<const f32x2*>(base + rr * WROW);
+      phi[rr] = *reinterpret_cast<const f32x2*>(base + rr * WROW + 2);
     }
-    __syncthreads();
-    fetch(pair + gridDim.x);                           // next pair's pixels: in flight under the MFMAs
-
-    // conv1 + ReLU of both images: 2 x 11 units of 64 positions on v_mfma_f32_16x16x1_4b_f32 (gnf_mnistcnn.h)
-    if (c1n == 3) conv1_units<3, WCH>(e_s + c1s * WESZ, a1_s + c1s * A1SZ, c1u0, w1_s + j, b1v, q, j, lane);
-    else conv1_units<2, WCH>(e_s + c1s * WESZ, a1_s + c1s * A1SZ, c1u0, w1_s + j, b1v, q, j, lane);
-    __syncthreads();
-
-    // the split items of the PREVIOUS pair: the partner's half arrived before the barrier at the top of this iteration
-    if (wave < 4 && !(wave & 1) && prev_ob >= 0) finish_split(xch + (wave >> 1) * 2 * 16 * 64, prev_ob);
-    prev_ob = -1;
-
-    // 18 items (image, group of 16 Winograd tiles) over 4 SIMDs: 16 whole ones, two per wavefront, and the last two
-    // SPLIT by xi_y halves over the wavefronts 0..3 (one per SIMD), so that every SIMD carries 4.5 items instead of
-    // 5 / 5 / 4 / 4 (two SIMDs idle for one item in five).  A half item accumulates 8 of the 16 transform points, applies
-    // its rows of the output transform A^T M (row sums are additive in xi_y) and leaves 32 partial values per lane in
-    // LDS; the wavefront holding xi_y = 0, 1 adds its partner's at the top of the next iteration (above) and finishes.
-#pragma nounroll
-    for (int item = wave; item < 16; item += NW) {
-      const int s = item >= 9, grp = item - 9 * s;     // wave-uniform
-      const int64_t img = 2 * pair + s;
-      if (img >= a.n) continue;
-      const int t = 16 * grp + j, ty = t / 12, tx = t - 12 * ty;
-      const float* base = a1_s + s * A1SZ + q * WCH + 2 * ty * WROW + 2 * tx;
-      f32x4 acc[16];
 #pragma unroll
-      for (int xi = 0; xi < 16; ++xi) acc[xi] = f32x4{0.f, 0.f, 0.f, 0.f};
-      acc[5] = b2v;                                    // xi = (1,1) reaches all four outputs with weight +1: the bias
-      // per 4 input channels: 16 operands first, then 16 back-to-back MFMAs (VALU and MFMA of one wavefront do not
-      // overlap, tools/mfma_feed.hip); the next channel group's patch is loaded before the MFMAs so that its LDS
-      // latency hides under them
-      f32x2 plo[4], phi[4];                            // patch rows as two column pairs
-#pragma unroll
-      for (int rr = 0; rr < 4; ++rr) {
-        plo[rr] = *reinterpret_cast<const f32x2*>(base + rr * WROW);
-        phi[rr] = *reinterpret_cast<const f32x2*>(base + rr * WROW + 2);
-      }
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        float vv[16];
-        wino_in(plo, phi, vv);
-        if (g < 3) {
-          const float* p = base + 4 * (g + 1) * WCH;
-#pragma unroll
-          for (int rr = 0; rr < 4; ++rr) {
-            plo[rr] = *reinterpret_cast<const f32x2*>(p + rr * WROW);
-            phi[rr] = *reinterpret_cast<const f32x2*>(p + rr * WROW + 2);
-          }
-        }
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int xi = 0; xi < 16; ++xi) acc[xi] = mfma(uw[xi * 4 + g], vv[xi], acc[xi]);
-        __builtin_amdgcn_sched_barrier(0);
-      }
-      // output transform A^T M A (A^T = [[1,1,1,0],[0,1,-1,-1]]) + 2x2 max pool, lane-local
-      const int64_t ob = img * NPOOL + 4 * q * (PO * PO) + t;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        float s0[4], s1[4];
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-          s0[c] = acc[c][r] + acc[4 + c][r] + acc[8 + c][r];
-          s1[c] = acc[4 + c][r] - acc[8 + c][r] - acc[12 + c][r];
-        }
-        pool_store(a, ob + r * (PO * PO), s0, s1);
-      }
-    }
-    if (wave < 4) {
-      const int item = 16 + (wave >> 1), hf = wave & 1;          // item 16 / 17 = groups 7 / 8 of image 1; xi_y in {2 hf, 2 hf + 1}
-      const int grp = item - 9;
-      const int64_t img = 2 * pair + 1;
-      if (img < a.n) {
-        const int t = 16 * grp + j, ty = t / 12, tx = t - 12 * ty;
-        const float* base = a1_s + A1SZ + q * WCH + 2 * ty * WROW + 2 * tx;
-        f32x4 acc[8];
-#pragma unroll
-        for (int xi = 0; xi < 8; ++xi) acc[xi] = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (hf == 0) acc[5] = b2v;
-        f32x2 plo[4], phi[4];
+    for (int g = 0; g < 4; ++g) {
+      float vv[16];
+      wino_in(plo, phi, vv);
+      if (g < 3) {
+        const float* p = base + 4 * (g + 1) * WCH;
 #pragma unroll
         for (int rr = 0; rr < 4; ++rr) {
-          plo[rr] = *reinterpret_cast<const f32x2*>(base + rr * WROW);
-          phi[rr] = *reinterpret_cast<const f32x2*>(base + rr * WROW + 2);
+          plo[rr] = *reinterpret_cast<const f32x2*>(p + rr * WROW);
+          phi[rr] = *reinterpret_cast<const f32x2*>(p + rr * WROW + 2);
         }
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          float vv[16];
-          wino_in(plo, phi, vv);
-          if (g < 3) {
-            const float* p = base + 4 * (g + 1) * WCH;
-#pragma unroll
-            for (int rr = 0; rr < 4; ++rr) {
-              plo[rr] = *reinterpret_cast<const f32x2*>(p + rr * WROW);
-              phi[rr] = *reinterpret_cast<const f32x2*>(p + rr * WROW + 2);
-            }
-          }
-          __builtin_amdgcn_sched_barrier(0);
-          if (hf == 0) {
-#pragma unroll
-            for (int xi = 0; xi < 8; ++xi) acc[xi] = mfma(uw[xi * 4 + g], vv[xi], acc[xi]);
-          } else {
-#pragma unroll
-            for (int xi = 0; xi < 8; ++xi) acc[xi] = mfma(uw[(8 + xi) * 4 + g], vv[8 + xi], acc[xi]);
-          }
-          __builtin_amdgcn_sched_barrier(0);
-        }
-        // this half's share of A^T M A: rows s0 += xi_y 0, 1, 2;  s1 += xi_y 1, -2, -3, then the (linear) column half
-        float* xb = xch + ((wave >> 1) * 2 + hf) * 16 * 64 + lane;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          float p0[4], p1[4];
-#pragma unroll
-          for (int c = 0; c < 4; ++c) {
-            p0[c] = hf == 0 ? acc[c][r] + acc[4 + c][r] : acc[c][r];
-            p1[c] = hf == 0 ? acc[4 + c][r] : -acc[c][r] - acc[4 + c][r];
-          }
-          xb[(r * 4 + 0) * 64] = p0[0] + p0[1] + p0[2];
-          xb[(r * 4 + 1) * 64] = p0[1] - p0[2] - p0[3];
-          xb[(r * 4 + 2) * 64] = p1[0] + p1[1] + p1[2];
-          xb[(r * 4 + 3) * 64] = p1[1] - p1[2] - p1[3];
-        }
-        if (hf == 0) prev_ob = img * NPOOL + 4 * q * (PO * PO) + t;
       }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int xi = 0; xi < 16; ++xi) acc[xi] = mfma(uw[xi * 4 + g], vv[xi], acc[xi]);
+      __builtin_amdgcn_sched_barrier(0);
     }
+    const rsrc_t rp = rsrc_of(a.pooled, im, NPOOL * 4), ra = rsrc_of(a.arg, im, NPOOL);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {                      // output transform A^T M A (A^T = [[1,1,1,0],[0,1,-1,-1]]) + pool
+      float s0[4], s1[4];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        s0[c] = acc[c][r] + acc[4 + c][r] + acc[8 + c][r];
+        s1[c] = acc[4 + c][r] - acc[8 + c][r] - acc[12 + c][r];
+      }
+      pool_out(rp, ra, t, r, s0[0] + s0[1] + s0[2], s0[1] - s0[2] - s0[3], s1[0] + s1[1] + s1[2], s1[1] - s1[2] - s1[3]);
+    }
+  };
+  // half of the split item (group 8): xi_y in {2 hf, 2 hf + 1}; partial output transform into xb
+  auto half_item = [&](const float* a1, int hf, float* xb0) {
+    const int t = 16 * 8 + j, ty = t / 12, tx = t - 12 * ty;
+    const float* base = a1 + q * WCH + 2 * ty * WROW + 2 * tx;
+    f32x4 acc[8];
+#pragma unroll
+    for (int xi = 0; xi < 8; ++xi) acc[xi] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (hf == 0) acc[5] = b2v;
+    f32x2 plo[4], phi[4];
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) {
+      plo[rr] = *reinterpret_cast<const f32x2*>(base + rr * WROW);
+      phi[rr] = *reinterpret_cast<const f32x2*>(base + rr * WROW + 2);
+    }
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      float vv[16];
+      wino_in(plo, phi, vv);
+      if (g < 3) {
+        const float* p = base + 4 * (g + 1) * WCH;
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+          plo[rr] = *reinterpret_cast<const f32x2*>(p + rr * WROW);
+          phi[rr] = *reinterpret_cast<const f32x2*>(p + rr * WROW + 2);
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      if (hf == 0) {
+#pragma unroll
+        for (int xi = 0; xi < 8; ++xi) acc[xi] = mfma(uw[xi * 4 + g], vv[xi], acc[xi]);
+      } else {
+#pragma unroll
+        for (int xi = 0; xi < 8; ++xi) acc[xi] = mfma(uw[(8 + xi) * 4 + g], vv[8 + xi], acc[xi]);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    // this half's share of A^T M A: rows s0 += xi_y 0, 1, 2;  s1 += xi_y 1, -2, -3, then the (linear) column half
+    float* xb = xb0 + hf * 16 * 64 + lane;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      float p0[4], p1[4];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        p0[c] = hf == 0 ? acc[c][r] + acc[4 + c][r] : acc[c][r];
+        p1[c] = hf == 0 ? acc[4 + c][r] : -acc[c][r] - acc[4 + c][r];
+      }
+      xb[(r * 4 + 0) * 64] = p0[0] + p0[1] + p0[2];
+      xb[(r * 4 + 1) * 64] = p0[1] - p0[2] - p0[3];
+      xb[(r * 4 + 2) * 64] = p1[0] + p1[1] + p1[2];
+      xb[(r * 4 + 3) * 64] = p1[1] - p1[2] - p1[3];
+    }
+  };
+
+  // ---- prologue: images 0 and 1 staged, conv1 of image 0 dealt evenly, image 2 requested
+  const int64_t img0 = blockIdx.x, gs = gridDim.x;
+  fetch(img0); stage(e_s);
+  fetch(img0 + gs); stage(e_s + WESZ);
+  fetch(img0 + 2 * gs);
+  __syncthreads();
+  {
+    int u0 = 0;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) u0 += w < wave ? F1PRO[w] : 0;
+    if (img0 < a.n) conv1_do(e_s, a1_s, u0, F1PRO[wave]);
   }
-  __syncthreads();                                     // the last pair's halves
-  if (wave < 4 && !(wave & 1) && prev_ob >= 0) finish_split(xch + (wave >> 1) * 2 * 16 * 64, prev_ob);
+  int c1u0 = 0;
+#pragma unroll
+  for (int w = 0; w < NW; ++w) c1u0 += w < wave ? F1U[w] : 0;
+  const bool units_first = wave >= 4;                  // one wavefront of every SIMD starts with conv1, the other with its item
+
+  int par = 0;
+  int64_t prev = -1;                                   // image whose split item waits in xch[par ^ 1]
+  for (int64_t img = img0; img < a.n; img += gs, par ^= 1) {
+    __syncthreads();                                   // a1[par] complete; a1[par^1], e[par] free; the previous halves in xch
+    const float* a1p = a1_s + par * A1SZ;
+    float* a1n = a1_s + (par ^ 1) * A1SZ;
+    const bool has_next = img + gs < a.n;
+    stage(e_s + par * WESZ);                           // image i+2 (requested one interval ago)
+    fetch(img + 3 * gs);
+    if (wave == 0 && prev >= 0) finish_split(xch + (par ^ 1) * 2 * 16 * 64, prev);
+    if (has_next && units_first) conv1_do(e_s + (par ^ 1) * WESZ, a1n, c1u0, F1U[wave]);
+    whole_item(a1p, wave, img);
+    if (wave < 2) half_item(a1p, wave, xch + par * 2 * 16 * 64);
+    if (has_next && !units_first) conv1_do(e_s + (par ^ 1) * WESZ, a1n, c1u0, F1U[wave]);
+    prev = img;
+  }
+  __syncthreads();                                     // the last image's halves
+  if (wave == 0 && prev >= 0) finish_split(xch + (par ^ 1) * 2 * 16 * 64, prev);
 }
 
 constexpr size_t kFwdLds = (size_t)(ESZ + NCH * CH) * sizeof(float);
 constexpr size_t kWinoLds = (size_t)(2 * WESZ + 2 * A1SZ + 2 * 2 * 16 * 64 + 9 * NCH) * sizeof(float);   // + the split items' exchange, the W1 table
 static_assert(kWinoLds <= 160 * 1024, "one workgroup per CU");
-constexpr unsigned kWinoGrid = 256;                  // one 8-wave workgroup per CU, two images per iteration
+constexpr unsigned kWinoGrid = 256;                  // one 8-wave workgroup per CU
 constexpr unsigned kFwdGrid = 512;                   // direct kernel: 512 measured faster than 256
 
 }  // namespace
@@ -403,8 +414,7 @@ int gnf_mnistcnn_conv_fwd(const float* e, const float* W1, const float* b1, cons
   } else {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&cnn_fwd_wino_k),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)kWinoLds);
-    const int64_t npair = (n_img + 1) / 2;
-    const unsigned grid = npair < kWinoGrid ? (unsigned)npair : kWinoGrid;
+    const unsigned grid = n_img < kWinoGrid ? (unsigned)n_img : kWinoGrid;
     hipLaunchKernelGGL(cnn_fwd_wino_k, dim3(grid), dim3(64 * FWD_WAVES), kWinoLds, (hipStream_t)stream, a);
   }
   GNF_LAUNCH_CHECK();
