@@ -34,6 +34,8 @@ INT_NET = [50, 50, 50]
 COND = 30
 S_NODES = 20
 PEAK_F32_TFLOPS = 157.3          # MI355X fp32 MFMA/vector peak (MI355X_MICROARCH.md)
+NOMINAL_GHZ = 2.4                # the clock behind that peak: 256 CUs x 4 SIMDs x 64 flop/clk x 2.4 GHz
+PMC_INPUTS = "r04_bench_inputs.json"
 
 
 def pseudo_mnist(gen, B, d):
@@ -157,6 +159,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--global-batch", type=int, default=0,
+                    help="strong scaling: the GLOBAL batch G is fixed and every rank takes G / N rows (default: weak "
+                         "scaling, BASELINE's 100 rows per GPU)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the secondary figures (tests of the N>1 path)")
     args = ap.parse_args()
@@ -177,6 +182,9 @@ def main():
                          " and let it spawn them)" % (args.gpus, world))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.global_batch and (args.global_batch <= 0 or args.global_batch % world):
+        raise SystemExit("bench.py: --global-batch %d is not a positive multiple of the %d ranks" % (args.global_batch, world))
+    b_rank = args.global_batch // world if args.global_batch else B_PER_GPU      # rows of this rank per step
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback of the product path)")
     ndev = torch.cuda.device_count()
@@ -207,7 +215,7 @@ def main():
     state = dp.FlatState(flow)
     state.broadcast(0)
     _flush_c_stdio()                                         # RCCL has announced itself by now (first collective): every rank
-    x = pseudo_mnist(torch.Generator().manual_seed(1234 + rank), B_PER_GPU, D).to(dev)
+    x = pseudo_mnist(torch.Generator().manual_seed(1234 + rank), b_rank, D).to(dev)
 
     def fence():
         if collective:
@@ -304,7 +312,7 @@ def main():
         raise SystemExit("data-parallel replicas diverged (parameter checksums differ across ranks)")
 
     if rank == 0:
-        n_elem = B_PER_GPU * D                                  # = masked images per step = Monotonic elements
+        n_elem = b_rank * D                                     # = masked images per step = Monotonic elements
         macs = (1 + COND) * INT_NET[0] + sum(a * b for a, b in zip(INT_NET[:-1], INT_NET[1:])) + INT_NET[-1]
         # algorithmic flop per launch (SURVEY.md 8d / DESIGN.md 4); padding and recompute are NOT counted as work
         CONV1, CONV2 = 97344, 1327104                           # MACs per 28x28 image (MLP.py:36-41)
@@ -327,9 +335,9 @@ def main():
         achieved = kern[dom]["achieved"]
         out = {
             "metric": "samples/sec (fwd+log|detJ|+bwd) MNIST d=784 Monotonic-DAG",
-            "value": B_PER_GPU * world * args.steps / dt, "unit": "samples/s", "n_gpus": world, "steps": args.steps,
+            "value": b_rank * world * args.steps / dt, "unit": "samples/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "scaling": "strong" if args.global_batch else "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "parity_note": "UMNN 1.0 parity unpinned: the Clenshaw-Curtis integral of the Monotonic normalizer is "
                            "checked against this repo's own restatement + mathematics, not against the absent package; "
                            "everything else on the path is pinned by reference-generated fixtures",
@@ -339,46 +347,64 @@ def main():
             "ms_per_step_per_rank": [round(v, 4) for v in per_rank_ms],
             "config": {"workload": "cfg4: MNIST d=784, MonotonicNormalizer[50,50,50] cond 30 S=20 + DAGConditioner("
                                    "MNISTCNN->30, prior_A_kernel=2, hot_encoding=False, Gumbel gate T=1), "
-                                   "b_size=100 per GPU; step = fwd+logdet+NLL+bwd+allreduce+Adam",
-                       "global_batch": B_PER_GPU * world, "parallelism": "dp%d" % world},
+                                   "b_size=%d per GPU%s; step = fwd+logdet+NLL+bwd+allreduce+Adam"
+                                   % (b_rank, " (global batch fixed at %d: strong scaling)" % args.global_batch if args.global_batch else ""),
+                       "global_batch": b_rank * world, "parallelism": "dp%d" % world},
             "roofline": {"bound": "mfma", "kernel": kern[dom]["kernel"], "ms_per_launch": kern[dom]["ms"],
                          "achieved": achieved, "peak": PEAK_F32_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_F32_TFLOPS, "traffic": None},
             "roofline_other": [v for k, v in kern.items() if k != dom],
             "ops_ms": {k: round(v, 4) for k, v in prof.items()},
         }
-        # PMC counters cannot be read from inside this process: HBM bytes per launch, MFMA instructions per image and other
-        # VALU instructions per MFMA of the conv pair are READ from profiles/r03_bench_inputs.json, which
-        # tools/make_bench_inputs.py writes from rocprofv3 --pmc passes over the same kernels at the same per-GPU size
-        # (null when the file is missing or the size differs)
+        # PMC counters cannot be read from inside this process: HBM bytes per launch, MFMA instructions per image, other VALU
+        # instructions per MFMA and the effective clock of the hand-written kernels are READ from
+        # profiles/r04_bench_inputs.json, which tools/make_bench_inputs.py writes from rocprofv3 --pmc passes over the same
+        # kernels at the same per-GPU size (null when the file is missing or the size differs)
         pmc = {}
         try:
-            with open(os.path.join(ROOT, "profiles", "r03_bench_inputs.json")) as f:
+            with open(os.path.join(ROOT, "profiles", PMC_INPUTS)) as f:
                 pmc_file = json.load(f)
             if pmc_file.get("n_images") == n_elem:
                 pmc = pmc_file["kernels"]
-                out["roofline"]["pmc_source"] = "profiles/r03_bench_inputs.json (" + pmc_file["how"][:60] + "...)"
+                out["roofline"]["pmc_source"] = "profiles/" + PMC_INPUTS + " (" + pmc_file["how"][:60] + "...)"
         except (OSError, ValueError, KeyError):
             pass
         alg_bytes = {"gnf_mnistcnn_conv_bwd": n_elem * (784 * 4 + 2304 * 5 + 784 * 4),
                      "gnf_mnistcnn_conv_fwd": n_elem * (784 * 4 + 2304 * 5)}
-        if dom in pmc:
-            out["roofline"]["traffic"] = pmc[dom]["hbm_bytes_per_launch"]
-            out["roofline"]["traffic_algorithmic"] = float(alg_bytes[dom])
-            # MFMA issue slots used by the dominant kernel: v_mfma_f32_16x16x4_f32 issued per image (Winograd form, incl.
-            # padding and the conv1 recompute) x 2048 flop / time / peak -- the head-room left, see DESIGN.md section 4
-            out["roofline"]["mfma_issue_frac"] = round(pmc[dom]["mfma_per_image"] * 2048. * n_elem / (prof[dom] * 1e-3) / 1e12
-                                                       / PEAK_F32_TFLOPS, 4)
+
+        def issued(k, entry):
+            """what the kernel ISSUES, next to `frac` (= ALGORITHMIC flop / time / peak: for the conv pair the direct-convolution
+            count of SURVEY.md 8(d), although the Winograd form issues 2.25x fewer multiplies -- hence values near or above 1).
+            mfma_issue_frac: MFMA instructions per image x 2048 flop / time / peak = the share of the f32-MFMA issue slots in
+            use at the nominal 2.4 GHz behind the 157.3 TFLOP/s; frac_of_peak_at_clock: the same against the peak at the clock
+            the kernel actually ran at (GRBM_GUI_ACTIVE / duration)."""
+            p = pmc.get(k)
+            if not p:
+                return
+            entry["frac_algorithmic"] = entry["frac"]
+            mi = p["mfma_per_image"] * 2048. * n_elem / (prof[k] * 1e-3) / 1e12 / PEAK_F32_TFLOPS
+            entry["mfma_issue_frac"] = round(mi, 4)
             # f32 MFMA and the other VALU instructions share one ALU per SIMD on gfx950 (tools/mfma_pipe.hip, valu_cost.hip:
             # 32.5 cycles per v_mfma_f32_16x16x4_f32 + ~3 per VALU instruction, additive at 2, 3 and 4 wavefronts per SIMD),
             # so with V other VALU instructions per MFMA the issue fraction cannot exceed 32.5 / (32.5 + 3 V)
-            v_per_mfma = pmc[dom]["valu_per_mfma"]
-            out["roofline"]["valu_per_mfma"] = round(v_per_mfma, 3)
-            out["roofline"]["issue_frac_ceiling_shared_alu"] = round(32.5 / (32.5 + 3. * v_per_mfma), 3)
-        out["secondary"] = {"fwd_bwd_only_samples_per_s": round(B_PER_GPU * world / t_fb, 1) if t_fb else None,
-                            "full_step_S_mix_20_29_samples_per_s": round(B_PER_GPU * world / t_mix, 1) if t_mix else None,
+            entry["valu_per_mfma"] = round(p["valu_per_mfma"], 3)
+            entry["issue_frac_ceiling_shared_alu"] = round(32.5 / (32.5 + 3. * p["valu_per_mfma"]), 3)
+            if p.get("effective_clock_GHz"):
+                entry["effective_clock_GHz"] = round(p["effective_clock_GHz"], 3)
+                entry["frac_of_peak_at_clock"] = round(mi * NOMINAL_GHZ / p["effective_clock_GHz"], 4)
+            if p.get("mfma_pipe_busy_frac_of_simd_cycles") is not None:
+                entry["mfma_pipe_busy_frac_of_simd_cycles"] = p["mfma_pipe_busy_frac_of_simd_cycles"]
+            if k in alg_bytes:
+                entry["traffic"] = p["hbm_bytes_per_launch"]
+                entry["traffic_algorithmic"] = float(alg_bytes[k])
+        issued(dom, out["roofline"])
+        for k, entry in kern.items():
+            if k != dom:
+                issued(k, entry)
+        out["secondary"] = {"fwd_bwd_only_samples_per_s": round(b_rank * world / t_fb, 1) if t_fb else None,
+                            "full_step_S_mix_20_29_samples_per_s": round(b_rank * world / t_mix, 1) if t_mix else None,
                             "full_step_frozen_deterministic_gate_samples_per_s":
-                                round(B_PER_GPU * world / t_det, 1) if t_det else None,
+                                round(b_rank * world / t_det, 1) if t_det else None,
                             "frozen_gate_error": det_error,
                             "note": "10 steps each, wall clock between barriers, max over ranks"}
         out["measured_peaks"] = measured_peaks(dev)

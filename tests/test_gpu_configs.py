@@ -291,6 +291,58 @@ def test_bench_two_ranks_product_flow():
     assert len(out["ms_per_step_per_rank"]) == 2 and max(out["ms_per_step_per_rank"]) <= out["ms_per_step"] * 1.0001
 
 
+@pytest.mark.parametrize("gpus", [1, 2])
+def test_bench_strong_scaling_holds_the_global_batch(gpus):
+    """`bench.py --global-batch G`: G is fixed and every rank takes G / N rows, "scaling": "strong" (north_star asks for
+    strong scaling; the default line stays BASELINE's weak point of 100 rows per GPU).  N = 1 runs all 200 rows in one
+    step, N = 2 (gloo transport on this one-GPU box) 100 per rank: same global batch, same accounting."""
+    import json
+    import subprocess
+    env = dict(os.environ, GNF_DIST_BACKEND="gloo")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(gpus), "--global-batch", "200",
+                        "--steps", "3", "--warmup", "1", "--no-secondary", "--no-cpu-baseline"], cwd=ROOT, env=env,
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == gpus and out["scaling"] == "strong" and out["config"]["global_batch"] == 200
+    assert "b_size=%d per GPU" % (200 // gpus) in out["config"]["workload"]
+    assert abs(out["value"] - 200 * 3 / (out["ms_per_step"] * 3e-3)) < 1e-6 * out["value"]
+    assert out["replicas_identical"] is True
+    # a global batch that does not divide over the ranks is refused before anything runs
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(gpus), "--global-batch", "201",
+                        "--steps", "1", "--warmup", "0"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=300)
+    assert (r.returncode != 0) == (gpus == 2)
+
+
+def test_bench_line_carries_issue_figures():
+    """the default N = 1 line: roofline.frac is the driver's contract (algorithmic flop / time / peak), and every
+    hand-written kernel of the step also says what it ISSUES -- frac_algorithmic, mfma_issue_frac, its ceiling, the
+    effective clock from profiles/r04_bench_inputs.json and the fraction of the peak at that clock."""
+    import json
+    import subprocess
+    env = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "GNF_DIST_BACKEND", "GNF_FORCE_DIST"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1", "--no-secondary",
+                        "--no-cpu-baseline"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert out["scaling"] == "weak" and out["config"]["global_batch"] == 100
+    entries = [out["roofline"]] + out["roofline_other"]
+    assert len(entries) == 4
+    for e in entries:
+        for f in ("frac", "frac_algorithmic", "mfma_issue_frac", "issue_frac_ceiling_shared_alu", "valu_per_mfma",
+                  "effective_clock_GHz", "frac_of_peak_at_clock"):
+            assert f in e, (e["kernel"], f)
+        assert e["frac"] == e["frac_algorithmic"] and 0 < e["mfma_issue_frac"] < e["issue_frac_ceiling_shared_alu"] + .05
+        assert e["mfma_issue_frac"] <= e["frac_of_peak_at_clock"] < 1.
+    assert out["roofline"]["traffic"] and out["roofline"]["traffic_algorithmic"]
+
+
 def test_bench_rccl_branch_at_world_size_one():
     """The RCCL code path itself on the ONE GPU of this box (GNF_FORCE_DIST=1): init_process_group("nccl", device_id=...)
     with world size 1, the in-place device all-reduce of the flat gradient buffer inside every step, the device

@@ -1,10 +1,15 @@
 #!/bin/bash
-# Round evidence in one GPU call: bash tools/collect_evidence.sh r03   (writes gpurun_out/<tag>_*; copy what is kept to profiles/)
-tag=${1:-r03}; out=gpurun_out; mkdir -p $out
+# Round evidence in one GPU call, AFTER the last kernel commit: bash tools/collect_evidence.sh r04   (writes gpurun_out/<tag>_*;
+# copy what is kept to profiles/)
+tag=${1:-r04}; out=gpurun_out; mkdir -p $out
 export TMPDIR=/tmp
 python bench.py --steps 20 --warmup 3 2> $out/${tag}_bench.err | tail -1 > $out/${tag}_bench.json
 ( cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/${tag}_kt -o p -- python3 $GRAFT_REPO_ROOT/bench.py --steps 20 --warmup 3 --no-cpu-baseline > /dev/null 2>&1 )
 cp $(find /tmp/${tag}_kt -name "*kernel_stats.csv" | head -1) $out/${tag}_bench_kernel_stats.csv
+# the conv pair: the PMC-derived inputs bench.py reads (incl. the Monotonic kernels), the full counter set, the per-phase cycle account
+python tools/make_bench_inputs.py $out/${tag}_bench_inputs.json > /dev/null 2>&1
+python tools/pmc_run.py "cnn_" $out/${tag}_cnn_pmc.json -- python3 tools/prof_cnn.py cnn 2 > /dev/null 2>&1
+python tools/time_cnn_phases.py > $out/${tag}_cnn_phases.txt 2>&1
 python tools/bench_configs.py --graph 2>/dev/null | grep '^{' > $out/${tag}_all_configs.jsonl
 python tools/bench_configs.py cfg4det cfg4dag --graph 2>/dev/null | grep '^{' >> $out/${tag}_all_configs.jsonl
 python tools/bench_kernels.py --json $out/${tag}_kernel_roofline_table.json > /dev/null 2>&1

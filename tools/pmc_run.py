@@ -38,7 +38,7 @@ for k, cs in acc.items():
     if "SQ_VALU_MFMA_BUSY_CYCLES" in c and "SQ_BUSY_CU_CYCLES" in c and c["SQ_BUSY_CU_CYCLES"]:
         d["mfma_pipe_busy_frac_of_simd_cycles"] = round(c["SQ_VALU_MFMA_BUSY_CYCLES"] / (4 * c["SQ_BUSY_CU_CYCLES"]), 4)
     if "SQ_INSTS_MFMA" in c and "SQ_INSTS_VALU" in c and c["SQ_INSTS_MFMA"]:
-        d["valu_non_mfma_per_mfma"] = round((c["SQ_INSTS_VALU"] - 0 * c["SQ_INSTS_MFMA"]) / c["SQ_INSTS_MFMA"], 3)
+        d["valu_non_mfma_per_mfma"] = round((c["SQ_INSTS_VALU"] - c["SQ_INSTS_MFMA"]) / c["SQ_INSTS_MFMA"], 3)   # SQ_INSTS_VALU counts the MFMAs too
     if "SQ_LDS_IDX_ACTIVE" in c and "SQ_BUSY_CU_CYCLES" in c and c["SQ_BUSY_CU_CYCLES"]:
         d["lds_active_frac_of_cu_cycles"] = round(c["SQ_LDS_IDX_ACTIVE"] / c["SQ_BUSY_CU_CYCLES"], 4)
         d["lds_bank_conflict_frac_of_cu_cycles"] = round(c.get("SQ_LDS_BANK_CONFLICT", 0) / c["SQ_BUSY_CU_CYCLES"], 4)
