@@ -7,12 +7,19 @@ by name); the bodies are written against gnf_hip.ops.
     stack:  steps in sequence, feature order reversed between steps, log-dets added             (reference :110-126)
     loss:   sum of conditioner constraint terms - mean(log|det J| + log N(z))                  (reference :128-146)
 """
+import weakref
+
 import torch
 import torch.nn as nn
 
 from gnf_hip import ops
 from .Conditionners import Conditioner, DAGConditioner
 from .Normalizers import Normalizer
+
+
+# captured inversion graphs per NormalizingFlowStep, kept OUTSIDE the modules: a hipGraph is neither copyable nor
+# picklable, and flows are deep-copied / saved by the drivers
+_INV_GRAPHS = weakref.WeakKeyDictionary()
 
 
 def _is_dag(conditioner):
@@ -69,6 +76,7 @@ class NormalizingFlowStep(NormalizingFlow):
         self.conditioner = conditioner
         self.normalizer = normalizer
         self.level_schedule = True       # invert(): topological level schedule for DAG conditioners
+        self.graph_invert = True         # ... replayed as a hipGraph from the second pass of a shape on (frozen A, GPU)
 
     def getConditioners(self):
         return [self.conditioner]
@@ -85,22 +93,89 @@ class NormalizingFlowStep(NormalizingFlow):
         return z, ops.LogSumRowsFn.apply(jac)
 
     # -- inversion ----------------------------------------------------------------------------------------------
-    def _invert_by_levels(self, z, context):
-        """DAG conditioner with a deterministic gate: every variable is inverted once, after its parents -- d
-        conditioner rows in total instead of (depth + 1) * d.  Same values as the fixed-point passes (non-parents are
-        masked by exact zeros either way).  Returns None when not applicable."""
+    def _levels(self, importance):
+        """the level schedule of the current gate, recomputed only when A (storage or version counter) or the gate's
+        thresholds changed: DAGConditioner.levels() copies the 784 x 784 adjacency to the host and walks it in Python
+        (a few ms per call, a host synchronisation in front of every sampling pass otherwise)"""
         cond = self.conditioner
-        if not (_is_dag(cond) and context is None and self.level_schedule):
-            return None
-        importance = cond.deterministic_importance()
-        levels = cond.levels(importance, with_host=True) if importance is not None else None
-        if levels is None:
-            return None
+        key = (cond.A.data_ptr(), cond.A._version, float(cond.h_thresh), bool(cond.s_thresh), cond.A.device)
+        if getattr(self, "_levels_key", None) != key:
+            self._levels_val = cond.levels(importance, with_host=True)
+            self._levels_key = key
+            _INV_GRAPHS.pop(self, None)                 # graphs captured for another gate replay another schedule
+        return self._levels_val, key
+
+    def _invert_levels_body(self, z, levels, importance, context):
+        cond = self.conditioner
         x = torch.zeros_like(z)
         for rows, host_rows in levels:
             h = cond.forward_rows(x, rows, importance, host_rows)
             x[:, rows] = self.normalizer.inverse_transform(z[:, rows].contiguous(), h, context)
         return x
+
+    GRAPH_INVERT_MAX = 8                 # captured (batch shape, node count) variants kept per step
+
+    def _invert_by_levels(self, z, context):
+        """DAG conditioner with a deterministic gate: every variable is inverted once, after its parents -- d
+        conditioner rows in total instead of (depth + 1) * d.  Same values as the fixed-point passes (non-parents are
+        masked by exact zeros either way).  Returns None when not applicable.
+
+        On the GPU the pass of a given (gate, batch shape, node count) is captured into a hipGraph the second time it is
+        asked for and replayed from then on (`graph_invert`): with a frozen A the schedule, the row tables and the sparse
+        plans are static, and a sampling pass over MNIST is ~650 launches of 5-100 us (reference ImageExperiments.py:341-350
+        samples after post_process()).  The weight image of the normalizer is packed INSIDE the graph, so a replay reads
+        the current parameters."""
+        cond = self.conditioner
+        if not (_is_dag(cond) and context is None and self.level_schedule):
+            return None
+        importance = cond.deterministic_importance()
+        if importance is None:
+            return None
+        levels, lkey = self._levels(importance)
+        if levels is None:
+            return None
+        graphable = (self.graph_invert and z.is_cuda and not cond.A.requires_grad and z.dtype == torch.float32
+                     and len(levels) > 4 and not torch.cuda.is_current_stream_capturing())
+        if not graphable:
+            return self._invert_levels_body(z, levels, importance, context)
+        key = (tuple(z.shape), int(getattr(self.normalizer, "nb_steps", 0)), bool(getattr(cond, "sparse_front", False)))
+        graphs = _INV_GRAPHS.setdefault(self, {})
+        entry = graphs.get(key)
+        if entry is None:                               # first request: eager (workspaces, plans and tables come to exist)
+            graphs[key] = "warm"
+            return self._invert_levels_body(z, levels, importance, context)
+        if entry == "warm":
+            import gc
+            zbuf = z.clone()
+            hold = getattr(self.normalizer, "hold_pack", None)
+            prev_pack = getattr(self.normalizer, "_held_pack", None)
+            if hold is not None:
+                self.normalizer._held_pack = None       # the pack launch belongs INTO the graph (current parameters on replay)
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):               # once on the capture stream's allocator pool
+                self._invert_levels_body(zbuf, levels, importance, context)
+            torch.cuda.current_stream().wait_stream(side)
+            graph = torch.cuda.CUDAGraph()
+            gc_was_on = gc.isenabled()
+            gc.collect()
+            gc.disable()                                # no finaliser may run inside the capture
+            try:
+                import contextlib
+                with torch.cuda.graph(graph), (hold() if hold is not None else contextlib.nullcontext()):
+                    xbuf = self._invert_levels_body(zbuf, levels, importance, context)
+            finally:
+                if gc_was_on:
+                    gc.enable()
+                if hold is not None:
+                    self.normalizer._held_pack = prev_pack
+            if len(graphs) > self.GRAPH_INVERT_MAX:
+                graphs.clear()
+            entry = graphs[key] = (graph, zbuf, xbuf)
+        graph, zbuf, xbuf = entry
+        zbuf.copy_(z, non_blocking=True)
+        graph.replay()
+        return xbuf.clone()
 
     def invert(self, z, context=None):
         """Reference :98-107: fixed point of x <- normalizer^-1(z, conditioner(x)) from x = 0, depth()+1 passes, early

@@ -1420,6 +1420,62 @@ def test_mnist_level_inversion_uses_sparse_front():
     assert rel_err(z_back.cpu(), z.cpu()) < 1e-4
 
 
+@pytest.mark.parametrize("normalizer", ["affine", "monotonic"])
+def test_level_inversion_replayed_as_a_graph(normalizer):
+    """sampling with a frozen gate (reference ImageExperiments.py:341-350 samples after post_process()): the first pass of a
+    shape runs eagerly, the second is captured into a hipGraph, later ones replay it.  All three give the SAME bits as the
+    eager pass; a replay reads the CURRENT parameters (the normalizer's weight image is packed inside the graph) and a
+    changed gate drops the graphs."""
+    from models import DAGConditioner, AffineNormalizer, MonotonicNormalizer
+    from models.NormalizingFlow import NormalizingFlowStep, _INV_GRAPHS
+    from models.MLP import MNISTCNN
+    torch.manual_seed(13)
+    A = torch.zeros(784, 784)
+    for i in range(28, 784):
+        A[i, i - 28] = 1.
+        if i % 28:
+            A[i, i - 29] = 1.
+    mono = normalizer == "monotonic"
+    cond = DAGConditioner(784, MNISTCNN(out_d=30 if mono else 2), 30 if mono else 2, A_prior=A).to(DEV)
+    cond.stoch_gate, cond.s_thresh, cond.h_thresh = False, False, 0.
+    cond.A.requires_grad = False
+    norm = MonotonicNormalizer([50, 50, 50], 30, nb_steps=20, solver="CC") if mono else AffineNormalizer()
+    step = NormalizingFlowStep(cond, norm).to(DEV)
+    z = cu(torch.randn(3, 784) * .5)
+    step.graph_invert = False
+    x_eager = step.invert(z)
+    step.graph_invert = True
+    x1 = step.invert(z)                       # eager, marks the shape
+    x2 = step.invert(z)                       # captured + replayed
+    x3 = step.invert(z)                       # replayed
+    graphs = _INV_GRAPHS[step]
+    assert len(graphs) == 1 and isinstance(next(iter(graphs.values())), tuple)
+    for x in (x1, x2, x3):
+        assert torch.equal(x, x_eager)
+    z2 = cu(torch.randn(3, 784) * .5)         # other inputs through the same graph
+    step.graph_invert = False
+    ref2 = step.invert(z2)
+    step.graph_invert = True
+    assert torch.equal(step.invert(z2), ref2)
+    with torch.no_grad():                     # parameters move (a training step between two sampling passes)
+        for p in step.parameters():
+            if p.requires_grad:
+                p.mul_(1.01)
+    step.graph_invert = False
+    ref3 = step.invert(z)
+    step.graph_invert = True
+    got3 = step.invert(z)
+    assert torch.equal(got3, ref3) and not torch.equal(ref3, x_eager)
+    with torch.no_grad():                     # another gate: new schedule, the graphs are dropped
+        cond.A[100, 72] = 0.
+    x4 = step.invert(z)
+    assert step not in _INV_GRAPHS or all(v == "warm" for v in _INV_GRAPHS[step].values())
+    with torch.no_grad():
+        zb, _ = step(x4)
+    assert rel_err(zb.cpu(), z.cpu()) < 1e-4
+    assert not any("graph" in k.lower() and k != "graph_invert" for k in step.__dict__)    # graphs live outside the module
+
+
 @pytest.mark.parametrize("d,l1", [(84, .3), (6, 0.), (50, .5), (784, .1)])
 def test_dag_loss_fused_vs_reference_expression(d, l1):
     """DAGConditioner.loss() through the fused kernels == the reference's expression (:176-194, :268-271) evaluated with
