@@ -138,7 +138,10 @@ class NormalizingFlowStep(NormalizingFlow):
                      and len(levels) > 4 and not torch.cuda.is_current_stream_capturing())
         if not graphable:
             return self._invert_levels_body(z, levels, importance, context)
-        key = (tuple(z.shape), int(getattr(self.normalizer, "nb_steps", 0)), bool(getattr(cond, "sparse_front", False)))
+        # what a captured pass bakes in: shapes, the node count, the front, and the ADDRESSES of every parameter and buffer
+        # (values may change freely; a re-bound or moved tensor must not be read through a stale pointer)
+        key = (tuple(z.shape), int(getattr(self.normalizer, "nb_steps", 0)), bool(getattr(cond, "sparse_front", False)),
+               tuple(t.data_ptr() for t in self.parameters()), tuple(t.data_ptr() for t in self.buffers()))
         graphs = _INV_GRAPHS.setdefault(self, {})
         entry = graphs.get(key)
         if entry is None:                               # first request: eager (workspaces, plans and tables come to exist)
