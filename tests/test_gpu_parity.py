@@ -298,7 +298,11 @@ def test_mnistcnn_golden():
     grads_match(net, g)
 
 
-@pytest.mark.parametrize("n,kind", [(1, "dense"), (3, "sparse"), (700, "dense"), (1300, "sparse")])
+@pytest.mark.parametrize("n,kind", [(1, "dense"), (3, "sparse"), (700, "dense"), (1300, "sparse"),
+                                    # the software-pipelined kernels of round 4 (next image's conv1 under this image's MFMA
+                                    # work, two input / a1 buffers): workgroups with exactly one image, one workgroup with
+                                    # two and the others with one, exactly two each, an odd tail
+                                    (2, "dense"), (257, "dense"), (512, "dense"), (515, "sparse")])
 def test_mnist_conv_front_vs_torch_cpu(n, kind):
     """fused conv1+ReLU+conv2+maxpool kernel (fwd, bwd) vs the same torch-CPU ops the oracle uses;
     'sparse' images have large exactly-constant regions -> exact pool ties (first max must win)."""
