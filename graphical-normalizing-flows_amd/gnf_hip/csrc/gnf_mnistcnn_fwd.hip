@@ -15,9 +15,10 @@
 // image, takes the pool argmax saved by the forward (1 byte per pooled value), and keeps the
 // weight-gradient accumulators in registers across all images of a workgroup.
 //
-// This file: the FORWARD kernels (Winograd, and the direct tie-exact one).  Built with -fno-slp-vectorize: the SLP
-// vectoriser packs the scalar adds of the output transform into v_pk_add_f32 and pays for it with 77 v_mov per 64 MFMAs
-// to form the register pairs (1.44 -> 1.40 ms at cfg4); the backward (gnf_mnistcnn.hip) is faster WITH it.
+// This file: the FORWARD kernels (Winograd, and the direct tie-exact one).  Both conv units are built with
+// -fno-slp-vectorize (gnf_hip/build.py): the SLP vectoriser packs the scalar adds of the output transform into v_pk_add_f32
+// and pays for it with 77 v_mov per 64 MFMAs to form the register pairs (forward 1.44 -> 1.40 ms at cfg4; the round-4
+// backward 2.89 -> 2.86 ms -- the round-3 backward was faster WITH it).
 #include "gnf_mnistcnn.h"
 
 namespace {

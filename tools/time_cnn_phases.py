@@ -5,7 +5,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, ROOT + '/graphical-normalizing-flows_amd']
 src = ROOT + '/graphical-normalizing-flows_amd/gnf_hip/csrc/'
 so = '/tmp/libgnf_timing.so'
-subprocess.run(['hipcc', '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-shared', '-DGNF_CNN_TIMING'] + sys.argv[1:] + ['-I' + ROOT + '/include', '-I' + src,
+subprocess.run(['hipcc', '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-shared', '-fno-slp-vectorize', '-DGNF_CNN_TIMING'] + sys.argv[1:] + ['-I' + ROOT + '/include', '-I' + src,
                 src + 'gnf_mnistcnn_fwd.hip', src + 'gnf_mnistcnn.hip', src + 'gnf_rowwise.hip', '-o', so], check=True)
 lib = ctypes.CDLL(so)
 n = 78400
