@@ -20,7 +20,10 @@ ARCH = "gfx950"
 SOURCES = ["gnf_rowwise.hip", "gnf_dag_gate.hip", "gnf_gemm.hip", "gnf_linear.hip", "gnf_linear_tall.hip", "gnf_monotonic.hip", "gnf_monotonic_wide.hip", "gnf_mnistcnn_fwd.hip",
            "gnf_mnistcnn.hip", "gnf_mnistcnn_sparse.hip", "gnf_probe.hip"]
 # per-file extra flags, each with the measurement that justifies it (tools/bench_cnn.py, cfg4 size)
-EXTRA_FLAGS = {"gnf_mnistcnn_fwd.hip": ["-fno-slp-vectorize"],   # conv forward 1.44 -> 1.40 ms (see the file header)
+EXTRA_FLAGS = {"gnf_mnistcnn_fwd.hip": ["-fno-slp-vectorize",     # conv forward 1.44 -> 1.40 ms (see the file header)
+                                        # round 4: without the post-RA machine scheduler 1.390 / 1.392 / 1.420 -> 1.372 / 1.382 /
+                                        # 1.388 ms (alternating on one box; the backward LOSES 2 % with it: 2.86 -> 2.92)
+                                        "-mllvm", "-enable-post-misched=0"],
                # round 4: the restructured backward is faster WITHOUT the SLP vectoriser too (2.886 / 2.888 / 2.891 ->
                # 2.858 / 2.859 / 2.859 ms, three alternating runs on one box; the round-3 kernel was faster with it)
                "gnf_mnistcnn.hip": ["-fno-slp-vectorize"]}
