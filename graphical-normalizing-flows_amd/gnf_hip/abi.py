@@ -20,7 +20,7 @@ c_u64 = ctypes.c_uint64
 c_stream = ctypes.c_void_p
 
 MONO_MAX_LAYERS = 8
-ABI_VERSION = 3           # GNF_ABI_VERSION of include/gnf_hip.h this binding was written against
+ABI_VERSION = 4           # GNF_ABI_VERSION of include/gnf_hip.h this binding was written against
 
 
 class MonoNet(ctypes.Structure):
@@ -83,6 +83,10 @@ SIGNATURES = {
     "gnf_mnistcnn_sparse_fwd": (c_int, [c_f, c_i64, c_f, ctypes.c_void_p, c_i64, ctypes.c_void_p, c_i64, c_f, c_f, c_f,
                                         c_f, c_f, c_f, c_i64, c_f, c_f, ctypes.c_void_p, ctypes.c_void_p, c_i64,
                                         c_stream]),
+    "gnf_mnistcnn_sparse_prep_bytes": (c_i64, [c_i64]),
+    "gnf_mnistcnn_sparse_prepare": (c_int, [c_f, c_f, c_f, c_f, c_f, c_i64, ctypes.c_void_p, c_i64, c_stream]),
+    "gnf_mnistcnn_sparse_fwd_prepared": (c_int, [c_f, c_i64, c_f, ctypes.c_void_p, c_i64, ctypes.c_void_p, c_i64, c_f, c_f,
+                                                 c_f, c_f, c_i64, ctypes.c_void_p, c_f, ctypes.c_void_p, c_i64, c_stream]),
     "gnf_mnistcnn_sparse_bwd_ws_bytes": (c_i64, [c_i64, c_i64, c_i64]),
     "gnf_mnistcnn_sparse_bwd": (c_int, [c_f, c_i64, c_f, ctypes.c_void_p, c_i64, ctypes.c_void_p, c_i64,
                                         ctypes.c_void_p, c_i64, ctypes.c_void_p, c_f, c_f, c_f,

@@ -498,6 +498,43 @@ int64_t gnf_mnistcnn_sparse_ws_bytes(int64_t n_rows, int64_t F) {
   return (n_rows * KD + (int64_t)NORIG * KD * F + NCH + F + 64) * (int64_t)sizeof(float);
 }
 
+// the parameter-only part of the front: Wg [64][400][F] (the fc1 weight columns of each crop origin), bg [16] (conv2's output
+// over the all-zero image), hbg [F] (fc1 of that background + bias) -- laid out as [Wg | bg | hbg]
+static int sparse_tables(const float* b1, const float* W2, const float* b2, const float* Wfc1, const float* bfc1, int64_t F,
+                         float* Wg, hipStream_t s) {
+  float* bg = Wg + (int64_t)NORIG * KD * F;
+  float* hbg = bg + NCH;
+  hipLaunchKernelGGL(sparse_bg_k, dim3((unsigned)((F + 3) / 4)), dim3(256), 0, s, b1, W2, b2, Wfc1, bfc1, (int)F, bg, hbg);
+  GNF_LAUNCH_CHECK();
+  hipLaunchKernelGGL(sparse_gather_fc1_k, dim3(2048), dim3(256), 0, s, Wfc1, (int)F, Wg);
+  GNF_LAUNCH_CHECK();
+  return 0;
+}
+
+// crop convolutions + grouped fc1 GEMM against tables that exist
+static int sparse_front(const float* x, int64_t B, const float* P, const int32_t* pix, const int32_t* groups,
+                        int64_t max_group_rows, const float* W1, const float* b1, const float* W2, const float* b2, int64_t F,
+                        const float* Wg, float* h1, float* pd, unsigned char* argmax_save, int64_t items, hipStream_t s) {
+  const float* bg = Wg + (int64_t)NORIG * KD * F;
+  const float* hbg = bg + NCH;
+  SparseArgs a{x, P, pix, W1, b1, W2, b2, bg, pd, argmax_save, B, items};
+  constexpr size_t lds = (size_t)WAVES * WLDS * sizeof(float);
+  int64_t grid = (items + WAVES - 1) / WAVES;
+  if (grid > 256 * 3) grid = 256 * 3;
+  if (argmax_save) hipLaunchKernelGGL(sparse_crop_k<true>, dim3((unsigned)grid), dim3(64 * WAVES), lds, s, a);
+  else hipLaunchKernelGGL(sparse_crop_k<false>, dim3((unsigned)grid), dim3(64 * WAVES), lds, s, a);
+  GNF_LAUNCH_CHECK();
+
+  GemmArgs g{};
+  g.A = pd; g.sam = KD; g.sak = 1;
+  g.B = Wg; g.sbk = F; g.sbn = 1; g.b_grp_stride = (int64_t)KD * F;
+  g.C = h1; g.scm = F; g.scn = 1;
+  g.bias = hbg; g.flags = GNF_GEMM_RELU;
+  g.M = max_group_rows; g.N = F; g.K = KD;
+  g.grp = groups;
+  return gnf_gemm_grouped_launch(g, NORIG, s);
+}
+
 int gnf_mnistcnn_sparse_fwd(const float* x, int64_t B, const float* P, const int32_t* pix, int64_t R,
                             const int32_t* groups, int64_t max_group_rows,
                             const float* W1, const float* b1, const float* W2, const float* b2,
@@ -515,31 +552,37 @@ int gnf_mnistcnn_sparse_fwd(const float* x, int64_t B, const float* P, const int
     return GNF_EINVAL;
   hipStream_t s = (hipStream_t)stream;
   float* pd = pd_save ? pd_save : (float*)ws;   // [items][400]
-  float* Wg = (float*)ws + items * KD;          // [64][400][F]
-  float* bg = Wg + (int64_t)NORIG * KD * F;     // [16]
-  float* hbg = bg + NCH;                        // [F]
+  float* Wg = (float*)ws + items * KD;          // [64][400][F] | bg [16] | hbg [F]
+  if (int rc = sparse_tables(b1, W2, b2, Wfc1, bfc1, F, Wg, s)) return rc;
+  return sparse_front(x, B, P, pix, groups, max_group_rows, W1, b1, W2, b2, F, Wg, h1, pd, argmax_save, items, s);
+}
 
-  hipLaunchKernelGGL(sparse_bg_k, dim3((unsigned)((F + 3) / 4)), dim3(256), 0, s, b1, W2, b2, Wfc1, bfc1, (int)F, bg, hbg);
-  GNF_LAUNCH_CHECK();
-  hipLaunchKernelGGL(sparse_gather_fc1_k, dim3(2048), dim3(256), 0, s, Wfc1, (int)F, Wg);
-  GNF_LAUNCH_CHECK();
+int64_t gnf_mnistcnn_sparse_prep_bytes(int64_t F) {
+  if (F < 0) return 0;
+  return ((int64_t)NORIG * KD * F + NCH + F + 64) * (int64_t)sizeof(float);
+}
 
-  SparseArgs a{x, P, pix, W1, b1, W2, b2, bg, pd, argmax_save, B, items};
-  constexpr size_t lds = (size_t)WAVES * WLDS * sizeof(float);
-  int64_t grid = (items + WAVES - 1) / WAVES;
-  if (grid > 256 * 3) grid = 256 * 3;
-  if (argmax_save) hipLaunchKernelGGL(sparse_crop_k<true>, dim3((unsigned)grid), dim3(64 * WAVES), lds, s, a);
-  else hipLaunchKernelGGL(sparse_crop_k<false>, dim3((unsigned)grid), dim3(64 * WAVES), lds, s, a);
-  GNF_LAUNCH_CHECK();
+int gnf_mnistcnn_sparse_prepare(const float* b1, const float* W2, const float* b2, const float* Wfc1, const float* bfc1,
+                                int64_t F, void* prep, int64_t prep_bytes, gnf_stream_t stream) {
+  if (!b1 || !W2 || !b2 || !Wfc1 || !bfc1 || !prep || F <= 0) return GNF_EINVAL;
+  if (F % 4 || F > 65535 * 64) return GNF_ESHAPE;
+  if (prep_bytes < gnf_mnistcnn_sparse_prep_bytes(F)) return GNF_EWS;
+  return sparse_tables(b1, W2, b2, Wfc1, bfc1, F, (float*)prep, (hipStream_t)stream);
+}
 
-  GemmArgs g{};
-  g.A = pd; g.sam = KD; g.sak = 1;
-  g.B = Wg; g.sbk = F; g.sbn = 1; g.b_grp_stride = (int64_t)KD * F;
-  g.C = h1; g.scm = F; g.scn = 1;
-  g.bias = hbg; g.flags = GNF_GEMM_RELU;
-  g.M = max_group_rows; g.N = F; g.K = KD;
-  g.grp = groups;
-  return gnf_gemm_grouped_launch(g, NORIG, s);
+int gnf_mnistcnn_sparse_fwd_prepared(const float* x, int64_t B, const float* P, const int32_t* pix, int64_t R,
+                                     const int32_t* groups, int64_t max_group_rows,
+                                     const float* W1, const float* b1, const float* W2, const float* b2, int64_t F,
+                                     const void* prep, float* h1, void* ws, int64_t ws_bytes, gnf_stream_t stream) {
+  if (!W1 || !b1 || !W2 || !b2 || !prep || B < 0 || R < 0 || F <= 0) return GNF_EINVAL;
+  if (F % 4 || F > 65535 * 64) return GNF_ESHAPE;
+  const int64_t items = R * B;
+  if (items == 0) return 0;
+  if (!x || !P || !pix || !groups || !h1) return GNF_EINVAL;
+  if (!ws || ws_bytes < items * KD * (int64_t)sizeof(float) || max_group_rows <= 0 || max_group_rows > items)
+    return GNF_EINVAL;
+  return sparse_front(x, B, P, pix, groups, max_group_rows, W1, b1, W2, b2, F, (const float*)prep, h1, (float*)ws, nullptr,
+                      items, (hipStream_t)stream);
 }
 
 static int64_t bwd_rows_n(int64_t F) {                 // widest row the two-level column sums see

@@ -467,14 +467,24 @@ class MnistSparseFn(torch.autograd.Function):
     the six network parameters only (x and P are treated as constants: frozen deterministic gate)."""
 
     @staticmethod
-    def forward(ctx, x, P, sr, pre_gated, W1, b1, W2, b2, Wfc1, bfc1):
-        """pre_gated: the consumer returns the cotangent of h1 already multiplied by [h1 > 0] (MLPFn's relu_in)"""
+    def forward(ctx, x, P, sr, pre_gated, W1, b1, W2, b2, Wfc1, bfc1, prep=None, grad_mode=True):
+        """pre_gated: the consumer returns the cotangent of h1 already multiplied by [h1 > 0] (MLPFn's relu_in);
+        prep: the parameter-only tables of mnistcnn_sparse_prepare (inference: they are not rebuilt per call)"""
         x, P = x.contiguous(), P.contiguous()
         ws_ = [t.contiguous() for t in (W1, b1, W2, b2, Wfc1, bfc1)]
         F = Wfc1.shape[0]
         n = sr.R * sr.B
         h1 = _empty((n, F), x)
-        train = any(ctx.needs_input_grad[4:])
+        # (needs_input_grad reports the parameters' requires_grad even under torch.no_grad(), and inside forward() the
+        # grad mode is always off: the caller's mode comes in as an argument -- without it every sampling / evaluation pass
+        # saved the pooled blocks and the argmax bytes of a backward that never comes)
+        train = bool(grad_mode) and any(ctx.needs_input_grad[4:10])
+        if prep is not None and not train:
+            nws = n * 400 * 4
+            ws = _ws(nws, x)
+            call("gnf_mnistcnn_sparse_fwd_prepared", ptr(x), sr.B, ptr(P), abi.rawptr(sr.pix), sr.R, abi.rawptr(sr.groups),
+                 sr.max_group_rows, *[ptr(t) for t in ws_[:4]], F, abi.rawptr(prep), ptr(h1), abi.rawptr(ws), nws, stream())
+            return h1
         ctx.pre_gated = bool(pre_gated)
         pd = _empty((n, 400), x) if train else None
         arg = torch.empty((n, 400), dtype=torch.uint8, device=x.device) if train else None
@@ -502,11 +512,22 @@ class MnistSparseFn(torch.autograd.Function):
         call("gnf_mnistcnn_sparse_bwd", ptr(x), sr.B, ptr(P), abi.rawptr(sr.pix), sr.R, abi.rawptr(sr.groups),
              sr.max_group_rows, abi.rawptr(sr.kgroups), sr.n_kgroups, abi.rawptr(sr.origin_chunks), ptr(W1), ptr(b1), ptr(W2), ptr(b2), ptr(Wfc1), F, ptr(pd), abi.rawptr(arg), ptr(g),
              ptr(gW1), ptr(gb1), ptr(gW2), ptr(gb2), ptr(gWf), ptr(gbf), abi.rawptr(ws), nws, stream())
-        return None, None, None, None, gW1, gb1, gW2, gb2, gWf, gbf
+        return None, None, None, None, gW1, gb1, gW2, gb2, gWf, gbf, None, None
 
 
-def mnistcnn_sparse_fwd(x, P, sr, W1, b1, W2, b2, Wfc1, bfc1, pre_gated=False):
-    return MnistSparseFn.apply(x, P, sr, pre_gated, W1, b1, W2, b2, Wfc1, bfc1)
+def mnistcnn_sparse_fwd(x, P, sr, W1, b1, W2, b2, Wfc1, bfc1, pre_gated=False, prep=None):
+    return MnistSparseFn.apply(x, P, sr, pre_gated, W1, b1, W2, b2, Wfc1, bfc1, prep, torch.is_grad_enabled())
+
+
+def mnistcnn_sparse_prepare(b1, W2, b2, Wfc1, bfc1):
+    """the parameter-only tables of the sparse front (fc1 weight columns per crop origin, background responses), built
+    once for a caller that evaluates the front many times with unchanged parameters (the levels of a sampling pass)"""
+    ts = [t.detach().contiguous() for t in (b1, W2, b2, Wfc1, bfc1)]
+    F = Wfc1.shape[0]
+    nb = abi.load().gnf_mnistcnn_sparse_prep_bytes(F)
+    prep = _ws(nb, Wfc1)
+    call("gnf_mnistcnn_sparse_prepare", *[ptr(t) for t in ts], F, abi.rawptr(prep), nb, stream())
+    return prep
 
 
 class PermuteRowsFn(torch.autograd.Function):

@@ -115,6 +115,17 @@ class NormalizingFlowStep(NormalizingFlow):
 
     GRAPH_INVERT_MAX = 8                 # captured (batch shape, node count) variants kept per step
 
+    def _holders(self):
+        """objects that can build parameter-only images ONCE for a whole inversion (attribute name, context factory):
+        the normalizer's packed integrand weights, the embedding net's sparse-front tables"""
+        out = []
+        if getattr(self.normalizer, "hold_pack", None) is not None:
+            out.append((self.normalizer, "_held_pack", self.normalizer.hold_pack))
+        net = getattr(self.conditioner, "embedding_net", None)
+        if getattr(net, "hold_prepared", None) is not None:
+            out.append((net, "_held_prep", net.hold_prepared))
+        return out
+
     def _invert_by_levels(self, z, context):
         """DAG conditioner with a deterministic gate: every variable is inverted once, after its parents -- d
         conditioner rows in total instead of (depth + 1) * d.  Same values as the fixed-point passes (non-parents are
@@ -150,28 +161,33 @@ class NormalizingFlowStep(NormalizingFlow):
         if entry == "warm":
             import gc
             zbuf = z.clone()
-            hold = getattr(self.normalizer, "hold_pack", None)
-            prev_pack = getattr(self.normalizer, "_held_pack", None)
-            if hold is not None:
-                self.normalizer._held_pack = None       # the pack launch belongs INTO the graph (current parameters on replay)
+            import contextlib
+            holders = self._holders()
+            saved = [(obj, attr, getattr(obj, attr)) for obj, attr, _ in holders]
+            for obj, attr, _ in holders:                # the build launches belong INTO the graph (current parameters on replay)
+                setattr(obj, attr, None)
             side = torch.cuda.Stream()
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):               # once on the capture stream's allocator pool
-                self._invert_levels_body(zbuf, levels, importance, context)
+                with contextlib.ExitStack() as stack:
+                    for _, _, make in holders:
+                        stack.enter_context(make())
+                    self._invert_levels_body(zbuf, levels, importance, context)
             torch.cuda.current_stream().wait_stream(side)
             graph = torch.cuda.CUDAGraph()
             gc_was_on = gc.isenabled()
             gc.collect()
             gc.disable()                                # no finaliser may run inside the capture
             try:
-                import contextlib
-                with torch.cuda.graph(graph), (hold() if hold is not None else contextlib.nullcontext()):
+                with torch.cuda.graph(graph), contextlib.ExitStack() as stack:
+                    for _, _, make in holders:
+                        stack.enter_context(make())
                     xbuf = self._invert_levels_body(zbuf, levels, importance, context)
             finally:
                 if gc_was_on:
                     gc.enable()
-                if hold is not None:
-                    self.normalizer._held_pack = prev_pack
+                for obj, attr, val in saved:
+                    setattr(obj, attr, val)
             if len(graphs) > self.GRAPH_INVERT_MAX:
                 graphs.clear()
             entry = graphs[key] = (graph, zbuf, xbuf)
@@ -184,8 +200,9 @@ class NormalizingFlowStep(NormalizingFlow):
         """Reference :98-107: fixed point of x <- normalizer^-1(z, conditioner(x)) from x = 0, depth()+1 passes, early
         exit once a pass changes nothing (its progress print is dropped)."""
         import contextlib
-        hold = getattr(self.normalizer, "hold_pack", None)       # parameters do not change inside: pack the weights once
-        with torch.no_grad(), (hold() if hold is not None else contextlib.nullcontext()):
+        with torch.no_grad(), contextlib.ExitStack() as stack:   # parameters do not change inside: build their images once
+            for _, _, make in self._holders():
+                stack.enter_context(make())
             x = self._invert_by_levels(z, context)
             if x is not None:
                 return x

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define GNF_ABI_VERSION 3
+#define GNF_ABI_VERSION 4
 #define GNF_EINVAL (-1)   /* bad argument (null pointer, negative size, ...)          */
 #define GNF_ESHAPE (-2)   /* shape not supported by any compiled kernel instantiation */
 #define GNF_EWS    (-3)   /* workspace too small                                      */
@@ -266,6 +266,19 @@ int gnf_mnistcnn_sparse_fwd(const float* x, int64_t B, const float* P, const int
                             const float* Wfc1, const float* bfc1, int64_t F,
                             float* h1, float* pd_save, unsigned char* argmax_save,
                             void* ws, int64_t ws_bytes, gnf_stream_t stream);
+/* The same front for a caller that evaluates it MANY times with unchanged parameters (the 109 levels of one sampling
+ * pass, NormalizingFlow.py:98-107 under ImageExperiments.py:341-350): the parameter-only tables -- the fc1 weight columns
+ * of each crop origin, conv2's response to the all-zero image and fc1 of that background -- are built once by
+ * gnf_mnistcnn_sparse_prepare into `prep` (>= gnf_mnistcnn_sparse_prep_bytes(F) bytes) and read by every
+ * gnf_mnistcnn_sparse_fwd_prepared call (inference only: nothing is saved for a backward; ws >= R*B*400*4 bytes).
+ * Same h1 as gnf_mnistcnn_sparse_fwd, bit for bit. */
+int64_t gnf_mnistcnn_sparse_prep_bytes(int64_t F);
+int gnf_mnistcnn_sparse_prepare(const float* b1, const float* W2, const float* b2, const float* Wfc1, const float* bfc1,
+                                int64_t F, void* prep, int64_t prep_bytes, gnf_stream_t stream);
+int gnf_mnistcnn_sparse_fwd_prepared(const float* x, int64_t B, const float* P, const int32_t* pix, int64_t R,
+                                     const int32_t* groups, int64_t max_group_rows,
+                                     const float* W1, const float* b1, const float* W2, const float* b2, int64_t F,
+                                     const void* prep, float* h1, void* ws, int64_t ws_bytes, gnf_stream_t stream);
 /* Backward w.r.t. the network parameters (training with a frozen deterministic gate: P and x get no gradient).
  * g_h1 [R*B, F]: cotangent of h1 with the ReLU already applied (zero where h1 == 0).  Gradients are written, not
  * accumulated: gW1 [16,1,3,3], gb1 [16], gW2 [16,16,3,3], gb2 [16], gWfc1 [F,2304], gbfc1 [F].

@@ -1370,6 +1370,53 @@ def test_sparse_front_reference_golden():
     assert rel_err(z2.cpu(), g["z"]) < TOL and rel_err(ld2.cpu(), g["logdet"]) < TOL
 
 
+def test_sparse_front_prepared_tables_give_the_same_bits():
+    """gnf_mnistcnn_sparse_prepare + _fwd_prepared (the parameter-only tables built once for the 109 levels of a sampling
+    pass) == gnf_mnistcnn_sparse_fwd, bit for bit; the holder is only consulted without autograd."""
+    from models import DAGConditioner
+    from models.MLP import MNISTCNN
+    from gnf_hip import ops
+    torch.manual_seed(21)
+    net = MNISTCNN(out_d=30).to(DEV)
+    A = torch.zeros(784, 784)
+    for i in range(784):
+        for dr in (-2, -1, 0, 1, 2):
+            for dc in (-2, -1, 0, 1, 2):
+                r, c = i // 28 + dr, i % 28 + dc
+                if (dr or dc) and 0 <= r < 28 and 0 <= c < 28:
+                    A[i, r * 28 + c] = float(torch.rand(()) < .5)
+    P = cu(A)
+    x = cu(torch.randn(5, 784))
+    rows = [0, 27, 300, 391, 392, 783, 29]
+    sr = ops.SparseRows(rows, 5, torch.device(DEV))
+    with torch.no_grad():
+        ref = net.sparse_rows(x, P, sr)
+        assert net._held_prep is None
+        with net.hold_prepared():
+            assert net._held_prep is not None
+            got = net.sparse_rows(x, P, sr)
+            got2 = net.sparse_rows(x * 2., P, sr)           # the tables do not depend on the inputs
+        assert net._held_prep is None
+        ref2 = net.sparse_rows(x * 2., P, sr)
+    assert torch.equal(got, ref) and torch.equal(got2, ref2)
+    with net.hold_prepared():                               # with autograd on, the holder is ignored (the backward needs pd / argmax)
+        out = net.sparse_rows(x, P, sr)
+        out.sum().backward()
+    assert net.fc1.weight.grad is not None and torch.equal(out.detach(), ref)
+    # ABI validation of the new entry points
+    from gnf_hip import abi
+    lib = abi.load()
+    F = 128
+    nb = lib.gnf_mnistcnn_sparse_prep_bytes(F)
+    assert nb == (64 * 400 * F + 16 + F + 64) * 4
+    prep = torch.empty(nb // 4, device=DEV)
+    ps = [net.conv1.bias, net.conv2.weight, net.conv2.bias, net.fc1.weight, net.fc1.bias]
+    st = abi.stream()
+    assert lib.gnf_mnistcnn_sparse_prepare(*[abi.ptr(t) for t in ps], F, abi.rawptr(prep), nb - 4, st) == -3
+    assert lib.gnf_mnistcnn_sparse_prepare(*[abi.ptr(t) for t in ps], 130, abi.rawptr(prep), nb, st) == -2
+    assert lib.gnf_mnistcnn_sparse_prepare(*[abi.ptr(t) for t in ps], F, None, nb, st) == -1
+
+
 def test_sparse_front_abi_validation():
     import ctypes
     from gnf_hip import abi
