@@ -407,7 +407,7 @@ int gnf_linear_fwd(const float* x, const float* W, const float* b, const float* 
     GNF_LAUNCH_CHECK();
     return 0;
   }
-  if (!mask && !deg_out && gnf_linear_tall_ok(M, N, K))
+  if (!mask && !deg_out && gnf_linear_tall_fwd_ok(M, N, K))
     return gnf_linear_tall_fwd(x, W, b, relu, y, M, N, K, (hipStream_t)stream);
   if (deg_out && !mask) return GNF_EINVAL;             // the tiled GEMM multiplies a mask tensor in
   return gnf_gemm(x, K, 1, W, mask, 1, K, y, N, 1, b, nullptr, 0, 0, nullptr, 0, 0, relu ? GNF_GEMM_RELU : 0, M, N, K, ws,

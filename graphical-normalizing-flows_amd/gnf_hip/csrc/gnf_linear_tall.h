@@ -6,6 +6,7 @@
 
 // M >= 2048 rows, N <= 64 out units, K <= 128 a multiple of 4, no mask
 bool gnf_linear_tall_ok(int64_t M, int64_t N, int64_t K);
+bool gnf_linear_tall_fwd_ok(int64_t M, int64_t N, int64_t K);      // forward only: any M > 128
 // floats of workspace gnf_linear_tall_bwd needs (per-workgroup partial weight / bias gradients)
 int64_t gnf_linear_tall_ws_floats(int64_t M, int64_t N, int64_t K);
 int gnf_linear_tall_fwd(const float* x, const float* W, const float* b, int relu, float* y, int64_t M, int64_t N, int64_t K,

@@ -434,6 +434,7 @@ class SparseRows:
         origin = [8 * crop_origin(r // 28) + crop_origin(r % 28) for r in rows]
         order = sorted(range(len(rows)), key=lambda k: (origin[k], rows[k]))
         self.R, self.B = len(rows), B
+        self.identity = order == list(range(len(rows)))         # the caller's rows already are in the kernels' order
         self.pix = torch.tensor([rows[k] for k in order], dtype=torch.int32, device=device)
         inv = [0] * len(rows)
         for pos, k in enumerate(order):

@@ -344,13 +344,17 @@ class DAGConditioner(Conditioner):
             return self.soft_thresholded_A()
         return self.A
 
-    def forward_rows(self, x, rows, P, host_rows=None):
+    def forward_rows(self, x, rows, P, host_rows=None, variable_major=False):
         """h[:, rows, :] only: the conditioner output of row i depends on x through x * P[i] alone, so a
-        level-scheduled inversion evaluates each row exactly once."""
+        level-scheduled inversion evaluates each row exactly once.  variable_major: the result as
+        [R, B, out] (any strides) instead of [B, R, out] -- the sparse kernels produce that layout, and the level loop
+        of the inversion consumes it without a permuting copy."""
         B, R = x.shape[0], rows.numel()
         plan = self._sparse_plan(x, rows.tolist() if host_rows is None else host_rows, P)
         if plan is not None:
-            return self.embedding_net.sparse_rows(x, P, plan)
+            return self.embedding_net.sparse_rows(x, P, plan, variable_major=variable_major)
+        if variable_major:
+            return self.forward_rows(x, rows, P, host_rows).permute(1, 0, 2)
         if hasattr(self.embedding_net, "exact_pool_ties"):
             self.embedding_net.exact_pool_ties = True                    # deterministic gate by construction
         e = x.unsqueeze(1) * P[rows].unsqueeze(0)                        # [B, R, d]

@@ -79,7 +79,7 @@ class MNISTCNN(nn.Module):
         """the sparse masked-copy front (gnf_hip.ops.mnistcnn_sparse_fwd) covers the 28x28 net with fc1 on 2304 inputs"""
         return (self._fused_front(x) and self.fc1.in_features == 2304 and self.fc1.out_features % 4 == 0)
 
-    def sparse_rows(self, x, P, sr):
+    def sparse_rows(self, x, P, sr, variable_major=False):
         """Embeddings [B, R, out_d] of the masked copies x * P[i], i in the gnf_hip.ops.SparseRows `sr` (returned in the
         caller's order), for an importance matrix P that is zero outside the 5x5 pixel windows: only the 14x14 crop
         that can differ from the all-zero image is convolved.  Differentiable w.r.t. the network's
@@ -88,6 +88,9 @@ class MNISTCNN(nn.Module):
                                      self.conv2.bias, self.fc1.weight, self.fc1.bias, pre_gated=True,
                                      prep=None if torch.is_grad_enabled() else self._held_prep)
         out = ops.mlp(h1, [(self.fc2.weight, self.fc2.bias)], relu_in=True)       # gates h1's cotangent in its epilogue
+        if variable_major:                       # [R, B, out_d]; a caller whose rows are already in the kernels' order
+            out = out.view(sr.R, sr.B, -1)       # (sorted by crop origin) gets the output without a gather
+            return out if sr.identity else ops.PermuteRowsFn.apply(out, sr.unsort, sr.order)
         return ops.PermuteRowsFn.apply(out.view(sr.R, sr.B, -1), sr.unsort, sr.order).permute(1, 0, 2)
 
     _held_prep = None

@@ -100,17 +100,34 @@ class NormalizingFlowStep(NormalizingFlow):
         cond = self.conditioner
         key = (cond.A.data_ptr(), cond.A._version, float(cond.h_thresh), bool(cond.s_thresh), cond.A.device)
         if getattr(self, "_levels_key", None) != key:
-            self._levels_val = cond.levels(importance, with_host=True)
+            lv = cond.levels(importance, with_host=True)
+            if lv is not None and cond.A.shape[0] == 784:
+                # the order of the variables INSIDE a level is free: take the one the sparse embedding kernels work in (crop
+                # origin, then pixel), so that their output needs no un-sorting gather
+                lv = [(torch.as_tensor(sorted(hr, key=lambda r: (8 * ops.crop_origin(r // 28) + ops.crop_origin(r % 28), r)),
+                                       dtype=torch.long, device=rows.device),
+                       tuple(sorted(hr, key=lambda r: (8 * ops.crop_origin(r // 28) + ops.crop_origin(r % 28), r))))
+                      for rows, hr in lv]
+            self._levels_val = lv
+            self._levels_all = torch.cat([rows for rows, _ in lv]) if lv else None   # one gather of z per pass
             self._levels_key = key
             _INV_GRAPHS.pop(self, None)                 # graphs captured for another gate replay another schedule
         return self._levels_val, key
 
     def _invert_levels_body(self, z, levels, importance, context):
+        """variable-major inside: z is gathered ONCE into [sum of level sizes, B] (a level is a contiguous slice), the
+        conditioner rows come as [R, B, out] -- the layout the sparse kernels write -- and the normalizer's inverse is
+        element-wise in whatever two leading dimensions z and h share.  Per level that leaves the embedding front, the
+        inverse and one scatter into x (no gather of z, no un-sorting or permuting copy of h)."""
         cond = self.conditioner
         x = torch.zeros_like(z)
+        zt = z.t()[self._levels_all]                    # [sum R, B], contiguous
+        off = 0
         for rows, host_rows in levels:
-            h = cond.forward_rows(x, rows, importance, host_rows)
-            x[:, rows] = self.normalizer.inverse_transform(z[:, rows].contiguous(), h, context)
+            R = rows.numel()
+            h = cond.forward_rows(x, rows, importance, host_rows, variable_major=True)
+            x[:, rows] = self.normalizer.inverse_transform(zt[off:off + R], h, context).t()
+            off += R
         return x
 
     GRAPH_INVERT_MAX = 8                 # captured (batch shape, node count) variants kept per step

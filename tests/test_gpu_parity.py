@@ -589,7 +589,10 @@ def test_linear_layer_single_gradient_launches(M, N, K, frozen):
 
 @pytest.mark.parametrize("M,H,N", [(4099, 128, 30), (2048, 64, 32), (78400, 128, 30), (3000, 128, 1), (2500, 64, 17),
                                    (60000, 60, 60), (5003, 60, 30), (2100, 12, 30), (2500, 64, 64), (3000, 128, 64),
-                                   (2049, 4, 33), (2600, 100, 50)])
+                                   (2049, 4, 33), (2600, 100, 50),
+                                   # below 2048 rows only the FORWARD takes the tall kernel (a level of a sampling pass: a
+                                   # few hundred rows through fc2), the gradients stay on the tiled GEMM
+                                   (129, 128, 30), (700, 128, 30), (1999, 64, 17), (333, 12, 60)])
 def test_linear_tall_narrow_layers(M, H, N):
     """gnf_linear_tall.hip: the fc2 shape of the headline model (78 400 x 128 -> 30), the DAGMLP layers of cfg2
     (60 000 x 12 -> 60 -> 60 -> 60 -> 30, DAGConditioner.py:7-20) and their relatives (N <= 64, K <= 128 a multiple of
