@@ -35,8 +35,7 @@ for which, regex, entries in (("cnn", "cnn_", (("gnf_mnistcnn_conv_bwd", "cnn_bw
             "hbm_fetch_KB_raw": c["FETCH_SIZE"], "hbm_write_KB_raw": c["WRITE_SIZE"],
             "mfma_pipe_busy_frac_of_simd_cycles": k["derived"].get("mfma_pipe_busy_frac_of_simd_cycles"),
             "lds_bank_conflict_frac_of_lds_cycles": (c["SQ_LDS_BANK_CONFLICT"] / c["SQ_LDS_IDX_ACTIVE"]) if c.get("SQ_LDS_IDX_ACTIVE") else None,
-            # GRBM_GUI_ACTIVE is summed over the 8 XCDs
-            "effective_clock_GHz": (k["derived"]["effective_clock_GHz"] / 8.) if k["derived"].get("effective_clock_GHz") else None,
+            "effective_clock_GHz": k["derived"].get("effective_clock_GHz"),     # pmc_run.py: GRBM_GUI_ACTIVE / 8 XCDs / duration
         }
 res["how"] = "python tools/make_bench_inputs.py  (" + " | ".join(hows) + ")"
 os.makedirs(os.path.dirname(out), exist_ok=True)

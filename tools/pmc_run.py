@@ -42,8 +42,8 @@ for k, cs in acc.items():
     if "SQ_LDS_IDX_ACTIVE" in c and "SQ_BUSY_CU_CYCLES" in c and c["SQ_BUSY_CU_CYCLES"]:
         d["lds_active_frac_of_cu_cycles"] = round(c["SQ_LDS_IDX_ACTIVE"] / c["SQ_BUSY_CU_CYCLES"], 4)
         d["lds_bank_conflict_frac_of_cu_cycles"] = round(c.get("SQ_LDS_BANK_CONFLICT", 0) / c["SQ_BUSY_CU_CYCLES"], 4)
-    if "GRBM_GUI_ACTIVE" in c and c.get("_duration_ns_grbm_pass"):
-        d["effective_clock_GHz"] = round(c["GRBM_GUI_ACTIVE"] / c["_duration_ns_grbm_pass"], 3)
+    if "GRBM_GUI_ACTIVE" in c and c.get("_duration_ns_grbm_pass", 0) > 5e4:      # not for launches of a few us: the counter window is wider than the kernel
+        d["effective_clock_GHz"] = round(c["GRBM_GUI_ACTIVE"] / 8. / c["_duration_ns_grbm_pass"], 3)   # summed over the 8 XCDs
     if "FETCH_SIZE" in c:                             # KB units
         d["hbm_fetch_GB_doubled"] = round(2 * c["FETCH_SIZE"] * 1024 / 1e9, 3)
     if "WRITE_SIZE" in c:
