@@ -1303,18 +1303,24 @@ __global__ __launch_bounds__(64 * kWaves, 1) void mono_bwd_pair_k(MonoArgs a) {
 //                rank-EX update W[:, U] x[U]
 //   dW, db       stay on the MFMA in the padded 4-tile form (K = the 16 elements: nothing to skip there, and per-lane
 //                partial accumulators for the peeled rows / columns / biases would cost 132 registers: measured, they
-//                spill); the peeled units and the constant 1 of the bias column are written into the fourth tile
+//                spill); the peeled units and the constant 1 of the bias column are written into the fourth tile.
+//                RP (row peel): the fourth OUT tile alone -- the rows dW[U][:], db[U] -- leaves the MFMA: 12 instead of
+//                16 tile products per layer and node, 15 per-lane partials per peeled row (dpre[U] x the lane's own
+//                inputs, which the data-gradient section reads back for its gates anyway) instead of 16 accumulator
+//                registers per dropped tile: +28 registers at NH = 3, which fit
 //   da           main inputs: W^T on the MFMA + rank-EX update W[U][:] dpre[U];  inputs U: q-sum of the lane's partial dot
 //                of W[:, U] with the main dpre + the corner
 // The pack, the LDS image, the per-wavefront element-major tiles and every output (accumulator rows in the padded
 // [HP][HP] form with the bias gradient in column HP-1, Dsum, the partial vector row) are those of mono_bwd_pair_k.
 // ---------------------------------------------------------------------------------------
-template <int HM, int NH, int EX>
+template <int HM, int NH, int EX, bool RP = false>
 __global__ __launch_bounds__(64 * kWaves, 1) void mono_bwd_pair_x_k(MonoArgs a) {
   static_assert(HM >= 1 && HM <= 3 && NH >= 2 && EX >= 1 && EX <= 3, "peeled narrow nets");
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const MonoLayout& L = a.L;
   constexpr int HT = HM + 1, HP = 16 * HT, LDW = HP + 4, U0 = 16 * HM;
+  constexpr int HTO = RP ? HM : HT;              // out tiles of the weight gradient on the MFMA
+  constexpr int NPR = RP ? NH - 1 : 1;
   constexpr int matf = HP * LDW;
   const int small = L.o_W1h;
   float* sW = smem + small;                      // W_l at sW + (l-1) * (matf + HP), b_l right behind it
@@ -1337,10 +1343,24 @@ __global__ __launch_bounds__(64 * kWaves, 1) void mono_bwd_pair_x_k(MonoArgs a) 
   const int64_t ngroups = (a.ecount + 15) / 16;
   const float fS = (float)a.S;
 
-  f32x4 p_wL[HM], p_w1x[HM], accW[NH - 1][HT][HT];      // dW_l in the padded form (the weight gradient keeps all 4 tiles)
+  f32x4 p_wL[HM], p_w1x[HM], accW[NH - 1][HTO][HT];     // dW_l in the padded form (all 4 in tiles; 4 or, RP, 3 out tiles)
   float p_wLx[EX], p_w1xx[EX];                            // d wL[U], d w1x[U] (same value in all q lanes)
   float p_bL = 0.f;
   const f32x4 z4 = f32x4{0.f, 0.f, 0.f, 0.f};
+  // RP: per-lane partials of the peeled rows: dW[U][the lane's main inputs], dW[U][U'], db[U] (the last two: the same
+  // value in all q lanes)
+  f32x4 prw[NPR][EX][HM];
+  float prx[NPR][EX][EX], prb[NPR][EX];
+#pragma unroll
+  for (int l = 0; l < NPR; ++l)
+#pragma unroll
+    for (int ee = 0; ee < EX; ++ee) {
+#pragma unroll
+      for (int t = 0; t < HM; ++t) prw[l][ee][t] = z4;
+#pragma unroll
+      for (int e2 = 0; e2 < EX; ++e2) prx[l][ee][e2] = 0.f;
+      prb[l][ee] = 0.f;
+    }
 #pragma unroll
   for (int t = 0; t < HM; ++t) { p_wL[t] = z4; p_w1x[t] = z4; }
 #pragma unroll
@@ -1348,7 +1368,7 @@ __global__ __launch_bounds__(64 * kWaves, 1) void mono_bwd_pair_x_k(MonoArgs a) 
 #pragma unroll
   for (int l = 0; l < NH - 1; ++l)
 #pragma unroll
-    for (int ti = 0; ti < HT; ++ti)
+    for (int ti = 0; ti < HTO; ++ti)
 #pragma unroll
       for (int tn = 0; tn < HT; ++tn) accW[l][ti][tn] = z4;
 
@@ -1533,18 +1553,23 @@ __global__ __launch_bounds__(64 * kWaves, 1) void mono_bwd_pair_x_k(MonoArgs a) 
         for (int u = 0; u < 2; ++u) {
 #pragma unroll
           for (int t = 0; t < HM; ++t) *reinterpret_cast<f32x4*>(td + tile_w(j, t, q)) = dp[u][t];
-          f32x4 vx = z4;
+          if constexpr (!RP) {
+            f32x4 vx = z4;
 #pragma unroll
-          for (int ee = 0; ee < EX; ++ee) vx[ee] = q == 0 ? dpx[u][ee] : 0.f;
-          *reinterpret_cast<f32x4*>(td + tile_w(j, HM, q)) = vx;
+            for (int ee = 0; ee < EX; ++ee) vx[ee] = q == 0 ? dpx[u][ee] : 0.f;
+            *reinterpret_cast<f32x4*>(td + tile_w(j, HM, q)) = vx;
+          }
           const float* ta = tiles + (2 * (l - 1) + u) * 16 * kTS;
+#ifdef GNF_MONO_EXP_NODW           // measurement only (wrong weight gradients): what the dW contraction costs
+          if (a.NK > 1000)
+#endif
 #pragma unroll
           for (int sK = 0; sK < 4; ++sK) {
-            float fa[HT], fb[HT];
+            float fa[HTO], fb[HT];
 #pragma unroll
-            for (int t = 0; t < HT; ++t) { fa[t] = td[tile_r(sK, q, t, j)]; fb[t] = ta[tile_r(sK, q, t, j)]; }
+            for (int t = 0; t < HT; ++t) { if (t < HTO) fa[t < HTO ? t : 0] = td[tile_r(sK, q, t, j)]; fb[t] = ta[tile_r(sK, q, t, j)]; }
 #pragma unroll
-            for (int ti = 0; ti < HT; ++ti)
+            for (int ti = 0; ti < HTO; ++ti)
 #pragma unroll
               for (int tn = 0; tn < HT; ++tn) accW[l - 1][ti][tn] = mfma(fa[ti], fb[tn], accW[l - 1][ti][tn]);
           }
@@ -1581,6 +1606,18 @@ __global__ __launch_bounds__(64 * kWaves, 1) void mono_bwd_pair_x_k(MonoArgs a) 
           const float* tg = tiles + (2 * (l - 1) + u) * 16 * kTS;
 #pragma unroll
           for (int t = 0; t < HM; ++t) ain[t] = *reinterpret_cast<const f32x4*>(tg + tile_w(j, t, q));
+          if constexpr (RP) {                          // the peeled rows of dW_l, db_l: dpre_l[U] x (inputs, 1)
+#pragma unroll
+            for (int ee = 0; ee < EX; ++ee) {
+#pragma unroll
+              for (int t = 0; t < HM; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) prw[l - 1][ee][t][r] = fmaf(dpx[u][ee], ain[t][r], prw[l - 1][ee][t][r]);
+#pragma unroll
+              for (int e2 = 0; e2 < EX; ++e2) prx[l - 1][ee][e2] = fmaf(dpx[u][ee], axin[l - 1][u][e2], prx[l - 1][ee][e2]);
+              prb[l - 1][ee] += dpx[u][ee];
+            }
+          }
           // da of the peeled inputs U' = sum_o W[o][U'] dp[o] + sum_U W[U][U'] dpx[U]
 #pragma unroll
           for (int e2 = 0; e2 < EX; ++e2) {
@@ -1697,11 +1734,40 @@ __global__ __launch_bounds__(64 * kWaves, 1) void mono_bwd_pair_x_k(MonoArgs a) 
 #pragma unroll
   for (int l = 0; l < NH - 1; ++l)
 #pragma unroll
-    for (int ti = 0; ti < HT; ++ti)
+    for (int ti = 0; ti < HTO; ++ti)
 #pragma unroll
       for (int tn = 0; tn < HT; ++tn)
 #pragma unroll
         for (int r = 0; r < 4; ++r) wrow[l * HP * HP + (16 * ti + 4 * q + r) * HP + 16 * tn + j] = accW[l][ti][tn][r];
+  if constexpr (RP) {
+    // the fourth row tile: rows U0 + ee from the per-lane partials (summed over the 16 elements of a lane slot), the
+    // padding rows zero; every location is written by exactly one lane
+#pragma unroll
+    for (int l = 0; l < NH - 1; ++l) {
+      float* wl = wrow + l * HP * HP;
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int tn = 0; tn < HT; ++tn)
+          if (!(q == 0 && r < EX)) wl[(U0 + 4 * q + r) * HP + 16 * tn + j] = 0.f;
+#pragma unroll
+      for (int ee = 0; ee < EX; ++ee) {
+#pragma unroll
+        for (int t = 0; t < HM; ++t)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float v = jsum(prw[l][ee][t][r]);
+            if (j == 0) wl[(U0 + ee) * HP + 16 * t + 4 * q + r] = v;
+          }
+        float vt = 0.f;                                  // columns U0 .. HP-1: peeled inputs, padding, bias gradient
+#pragma unroll
+        for (int e2 = 0; e2 < EX; ++e2) { const float v = jsum(prx[l][ee][e2]); if (j == e2) vt = v; }
+        const float vb = jsum(prb[l][ee]);
+        if (j == 15) vt = vb;
+        if (q == 0) wl[(U0 + ee) * HP + U0 + j] = vt;
+      }
+    }
+  }
   if (a.wcomb) {
     __syncthreads();
     float* grow = a.wpart + (int64_t)blockIdx.x * WSZ;
@@ -1911,7 +1977,14 @@ int launch_bwd_one(const MonoArgs& a, unsigned grid, hipStream_t s) {
                                (size_t)kWaves * (2 * (NH - 1) + 1) * 16 * kTS) * sizeof(float);
       if constexpr (HT == 4) {
         if (a.L.EX > 0) {                       // peeled: 3 tiles on the MFMA, the H mod 16 leftover units on the VALU
-          if (a.L.EX <= 2) {
+          // row peel (the weight gradient's fourth out tile on the VALU) where its partials fit the register file
+          static const bool no_rp = getenv("GNF_MONO_ROWPEEL") && getenv("GNF_MONO_ROWPEEL")[0] == '0';
+          constexpr bool kRP = NH <= 3;          // NH = 4: 122 registers spilled
+          if (kRP && a.L.EX <= 2 && !no_rp) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mono_bwd_pair_x_k<3, NH, 2, kRP>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_pair);
+            hipLaunchKernelGGL((mono_bwd_pair_x_k<3, NH, 2, kRP>), dim3(grid), dim3(64 * kWaves), lds_pair, s, a);
+          } else if (a.L.EX <= 2) {
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mono_bwd_pair_x_k<3, NH, 2>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_pair);
             hipLaunchKernelGGL((mono_bwd_pair_x_k<3, NH, 2>), dim3(grid), dim3(64 * kWaves), lds_pair, s, a);
