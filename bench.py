@@ -36,6 +36,8 @@ S_NODES = 20
 PEAK_F32_TFLOPS = 157.3          # MI355X fp32 MFMA/vector peak (MI355X_MICROARCH.md)
 NOMINAL_GHZ = 2.4                # the clock behind that peak: 256 CUs x 4 SIMDs x 64 flop/clk x 2.4 GHz
 PMC_INPUTS = "r04_bench_inputs.json"
+DOMINANT_OP = "gnf_mnistcnn_conv_bwd"       # the entry point of the dominant kernel (cnn_bwd_wino_k): timed live in the region
+OPS_STEPS = 5                               # untimed steps behind the region in which every entry point is timed (at least; = --steps)
 
 
 def pseudo_mnist(gen, B, d):
@@ -225,18 +227,32 @@ def main():
     for _ in range(args.warmup):
         train_step(flow, state, x)
     fence()
-    abi.profile_enable(("gnf_mnistcnn_conv_fwd", "gnf_mnistcnn_conv_bwd", "gnf_monotonic_fwd", "gnf_monotonic_bwd",
-                        "gnf_dag_gate_fwd", "gnf_dag_gate_bwd", "gnf_gemm"))
+    # HIP events INSIDE the timed region around the dominant kernel's entry point only: an event record between two
+    # dependent launches leaves the GPU idle for ~5.5 us (kernel trace, tools/trace_gaps.py: with all seven entry points
+    # instrumented a step carried 12 such gaps = 65 us = 1 % of it).  The other entry points are timed the same way in
+    # OPS_STEPS untimed steps right behind the region.
+    abi.profile_enable((DOMINANT_OP,))
     dp.comm_profile(True)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = train_step(flow, state, x)
     fence()
     dt = time.perf_counter() - t0
-    prof = abi.profile_collect()
+    prof_live = abi.profile_collect()
     allreduce_ms = dp.comm_profile(False)                    # HIP events around the step's one collective
     if not torch.isfinite(loss).item():
         raise SystemExit("non-finite loss")
+    ops_steps = max(OPS_STEPS, args.steps)
+    for _ in range(2):                                       # lead-in: the fence above left the GPU idle
+        train_step(flow, state, x)
+    abi.profile_enable(("gnf_mnistcnn_conv_fwd", "gnf_mnistcnn_conv_bwd", "gnf_monotonic_fwd", "gnf_monotonic_bwd",
+                        "gnf_dag_gate_fwd", "gnf_dag_gate_bwd", "gnf_gemm"))
+    for _ in range(ops_steps):
+        train_step(flow, state, x)
+    fence()
+    prof = abi.profile_collect()
+    dom_ms_untimed_pass = prof.get(DOMINANT_OP)
+    prof.update(prof_live)                                   # the dominant kernel: the live figure of the timed region
 
     # secondary figures of SURVEY.md 8(d), outside the timed region of the headline: (i) fwd + log-det + NLL + bwd
     # without all-reduce / Adam, (ii) the full step with the training-realistic node count S ~ U{20..29}
@@ -332,6 +348,8 @@ def main():
                 kern[k] = {"kernel": label, "ms": round(prof[k], 4), "achieved": round(tf, 2), "unit": "TFLOP/s",
                            "frac": round(tf / PEAK_F32_TFLOPS, 4)}
         dom = max((k for k in kern), key=lambda k: prof[k])     # dominant hand-written kernel by time
+        if dom != DOMINANT_OP:
+            raise SystemExit("the kernel timed inside the region (%s) is not the dominant one (%s)" % (DOMINANT_OP, dom))
         achieved = kern[dom]["achieved"]
         out = {
             "metric": "samples/sec (fwd+log|detJ|+bwd) MNIST d=784 Monotonic-DAG",
@@ -355,7 +373,13 @@ def main():
                          "frac": achieved / PEAK_F32_TFLOPS, "traffic": None},
             "roofline_other": [v for k, v in kern.items() if k != dom],
             "ops_ms": {k: round(v, 4) for k, v in prof.items()},
+            "ops_ms_source": {DOMINANT_OP: "HIP events on the launch stream in every one of the %d timed steps" % args.steps,
+                              "others": "HIP events on the launch stream in %d untimed steps right behind the timed region "
+                                        "(an event pair idles the GPU for ~11 us per entry point and step)" % ops_steps,
+                              DOMINANT_OP + "_in_the_untimed_pass": round(dom_ms_untimed_pass, 4) if dom_ms_untimed_pass else None},
         }
+        for v in out["roofline_other"]:
+            v["measured"] = "%d untimed steps behind the timed region" % ops_steps
         # PMC counters cannot be read from inside this process: HBM bytes per launch, MFMA instructions per image, other VALU
         # instructions per MFMA and the effective clock of the hand-written kernels are READ from
         # profiles/r04_bench_inputs.json, which tools/make_bench_inputs.py writes from rocprofv3 --pmc passes over the same

@@ -341,6 +341,11 @@ def test_bench_line_carries_issue_figures():
         assert e["frac"] == e["frac_algorithmic"] and 0 < e["mfma_issue_frac"] < e["issue_frac_ceiling_shared_alu"] + .05
         assert e["mfma_issue_frac"] <= e["frac_of_peak_at_clock"] < 1.
     assert out["roofline"]["traffic"] and out["roofline"]["traffic_algorithmic"]
+    # only the dominant kernel's entry point is timed (HIP events) inside the region, the others behind it
+    src = out["ops_ms_source"]
+    assert "timed steps" in src["gnf_mnistcnn_conv_bwd"] and "untimed" in src["others"]
+    assert abs(src["gnf_mnistcnn_conv_bwd_in_the_untimed_pass"] / out["ops_ms"]["gnf_mnistcnn_conv_bwd"] - 1.) < .1
+    assert all("untimed" in e["measured"] for e in out["roofline_other"])
 
 
 def test_bench_rccl_branch_at_world_size_one():
