@@ -401,7 +401,7 @@ def main():
             count of SURVEY.md 8(d), although the Winograd form issues 2.25x fewer multiplies -- hence values near or above 1).
             mfma_issue_frac: MFMA instructions per image x 2048 flop / time / peak = the share of the f32-MFMA issue slots in
             use at the nominal 2.4 GHz behind the 157.3 TFLOP/s; frac_of_peak_at_clock: the same against the peak at the clock
-            the kernel actually ran at (GRBM_GUI_ACTIVE / duration)."""
+            the kernel ran at in this run (cycles per launch from the counter pass / live launch time)."""
             p = pmc.get(k)
             if not p:
                 return
@@ -413,9 +413,14 @@ def main():
             # so with V other VALU instructions per MFMA the issue fraction cannot exceed 32.5 / (32.5 + 3 V)
             entry["valu_per_mfma"] = round(p["valu_per_mfma"], 3)
             entry["issue_frac_ceiling_shared_alu"] = round(32.5 / (32.5 + 3. * p["valu_per_mfma"]), 3)
-            if p.get("effective_clock_GHz"):
-                entry["effective_clock_GHz"] = round(p["effective_clock_GHz"], 3)
-                entry["frac_of_peak_at_clock"] = round(mi * NOMINAL_GHZ / p["effective_clock_GHz"], 4)
+            # The clock of THIS run = cycles of a launch (GRBM_GUI_ACTIVE / 8 XCDs, counter pass) / the live launch time.  The
+            # clock of the counter pass itself is not the clock of this run: under rocprofv3 --pmc the HBM-streaming kernels
+            # take ~10 % longer at a ~10 % lower clock (same cycle count); rocm-smi reads 2.39 GHz during this benchmark.
+            if p.get("cycles_per_launch"):
+                ghz = p["cycles_per_launch"] / (prof[k] * 1e6)
+                entry["effective_clock_GHz"] = round(ghz, 3)
+                entry["effective_clock_GHz_in_pmc_pass"] = round(p["effective_clock_GHz_in_pmc_pass"], 3)
+                entry["frac_of_peak_at_clock"] = round(mi * NOMINAL_GHZ / ghz, 4)
             if p.get("mfma_pipe_busy_frac_of_simd_cycles") is not None:
                 entry["mfma_pipe_busy_frac_of_simd_cycles"] = p["mfma_pipe_busy_frac_of_simd_cycles"]
             if k in alg_bytes:

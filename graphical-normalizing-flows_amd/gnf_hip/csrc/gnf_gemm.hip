@@ -441,6 +441,130 @@ __global__ __launch_bounds__(64 * WWAVES, 1) void gemm_wide_k(GemmArgs g) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Tall-skinny product with both operands k-contiguous, N <= 128, K % 32 == 0, bias / ReLU epilogue only: the fc1 forward
+// of the MNISTCNN embedding (78 400 x 128 x 2304, models/MLP.py:44).  One 8-wavefront workgroup per CU owns a
+// (64 TMW) x 128 row block (TMW = 5: 245 blocks for 78 400 rows); K-slabs of 32 go global -> registers under the MFMAs of the
+// current slab, registers -> LDS (one ds_write_b128 per 16-B piece) behind them, two LDS stages, ONE workgroup barrier per
+// slab; fragments are ds_read_b128 (4 k per lane, chunk position XOR-swizzled by the row: conflict-free).  Wavefront
+// (wm, wn) of the 4 x 2 grid holds TMW x 4 accumulator tiles: every A fragment feeds 4 MFMAs, every B fragment TMW.
+// Main loop 87 % of the MFMA-bound cycle count; 0.382 ms = 121 TFLOP/s against 0.427 ms of gemm_vec_k<160,128> on a warm
+// GPU (tools/tall_gemm.hip is the stand-alone form; the round-3 "no gain" was measured on a GPU that had not ramped its
+// clocks up: 10 launches right behind a 700 MB host copy).
+// ---------------------------------------------------------------------------------------------
+constexpr int TBK = 32, TBN = 128, TWAVES = 8;
+template <int TMW>
+constexpr size_t tall_lds() { return 2 * (size_t)(64 * TMW + TBN) * TBK * sizeof(float); }
+
+template <int TMW>
+__global__ __launch_bounds__(64 * TWAVES, 1) void gemm_tall_k(GemmArgs g) {
+  constexpr int BM = 64 * TMW;                  // 4 wavefront rows x TMW tiles x 16
+  constexpr int SLAB = (BM + TBN) * TBK;        // floats per stage
+  extern __shared__ __attribute__((aligned(16))) float tsm[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int q = lane >> 4, j = lane & 15;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int64_t M = g.M, K = g.K;
+  const int N = (int)g.N;
+  const int64_t ntiles = (M + BM - 1) / BM;
+  for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const int64_t m0 = tile * BM;
+    f32x4w acc[TMW][4];
+#pragma unroll
+    for (int a = 0; a < TMW; ++a)
+#pragma unroll
+      for (int b = 0; b < 4; ++b) acc[a][b] = f32x4w{0.f, 0.f, 0.f, 0.f};
+    // this thread's 16-B pieces of a slab: piece p covers position P = p * 512 + tid -> row P / 8, chunk position P % 8,
+    // holding the row's logical chunk (P % 8) ^ ((row >> 1) & 7); rows past M / N repeat the last one (never stored)
+    constexpr int PIECES = (BM + TBN) * 8 / 512;
+    const float* src[PIECES];
+#pragma unroll
+    for (int p = 0; p < PIECES; ++p) {
+      const int P = p * 512 + tid;
+      const int row = P >> 3, c = (P & 7) ^ ((row >> 1) & 7);
+      if (row < BM) {
+        int64_t gm = m0 + row;
+        if (gm >= M) gm = M - 1;
+        src[p] = g.A + gm * g.sam + 4 * c;
+      } else {
+        int gn = row - BM;
+        if (gn >= N) gn = N - 1;
+        src[p] = g.B + (int64_t)gn * g.sbn + 4 * c;
+      }
+    }
+    f32x4w pre[PIECES];
+    auto fetch = [&](int64_t k0) {
+#pragma unroll
+      for (int p = 0; p < PIECES; ++p) pre[p] = *reinterpret_cast<const f32x4w*>(src[p] + k0);
+    };
+    auto stash = [&](int stage) {
+      float* base = tsm + stage * SLAB + tid * 4;
+#pragma unroll
+      for (int p = 0; p < PIECES; ++p) *reinterpret_cast<f32x4w*>(base + p * 2048) = pre[p];
+    };
+    fetch(0);
+    stash(0);
+    const int nslab = (int)(K / TBK);
+    for (int s = 0; s < nslab; ++s) {
+      __syncthreads();                             // slab s visible; everybody done reading the other stage
+      if (s + 1 < nslab) fetch((int64_t)(s + 1) * TBK);
+      const float* As = tsm + (s & 1) * SLAB;
+      const float* Bs = As + BM * TBK;
+#pragma unroll
+      for (int kg = 0; kg < 2; ++kg) {
+        f32x4w af[TMW], bf[4];
+#pragma unroll
+        for (int a = 0; a < TMW; ++a) {
+          const int row = (wm * TMW + a) * 16 + j;
+          af[a] = *reinterpret_cast<const f32x4w*>(As + row * TBK + 4 * ((4 * kg + q) ^ ((row >> 1) & 7)));
+        }
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+          const int row = (wn * 4 + b) * 16 + j;
+          bf[b] = *reinterpret_cast<const f32x4w*>(Bs + row * TBK + 4 * ((4 * kg + q) ^ ((row >> 1) & 7)));
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+          for (int a = 0; a < TMW; ++a)
+#pragma unroll
+            for (int b = 0; b < 4; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[a][r], bf[b][r], acc[a][b], 0, 0, 0);
+      }
+      if (s + 1 < nslab) stash((s + 1) & 1);
+    }
+    __syncthreads();                               // all reads of the last slab done before the next block's first stash
+    // D layout of a 16x16 tile: lane (q, j) holds rows 4q..4q+3 of the A tile, column j of the B tile
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      const int n = (wn * 4 + b) * 16 + j;
+      const float bv = (g.bias && n < N) ? g.bias[n] : 0.f;
+#pragma unroll
+      for (int a = 0; a < TMW; ++a)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int64_t m = m0 + (wm * TMW + a) * 16 + 4 * q + r;
+          if (m < M && n < N) {
+            float v = acc[a][b][r] + bv;
+            if (g.flags & GNF_GEMM_RELU) v = fmaxf(v, 0.f);
+            g.C[m * g.scm + n * g.scn] = v;
+          }
+        }
+    }
+  }
+}
+
+// the tile height (TMW) that wastes the least of the chip on a tall M, 0 when every choice idles > 10 % of it
+static int tall_tmw(int64_t M) {
+  int best = 0;
+  double best_waste = .10;
+  for (int tmw = 5; tmw >= 3; --tmw) {
+    const int64_t bm = 64 * tmw, tiles = (M + bm - 1) / bm, rounds = (tiles + 255) / 256;
+    const double waste = 1. - (double)M / (double)(rounds * 256 * bm);
+    if (waste < best_waste) { best_waste = waste; best = tmw; }
+  }
+  return best;
+}
+
 // split-K epilogue: C = epi(sum_z partial[z]) with the same options as the fused epilogue
 __global__ void gemm_reduce_k(const float* __restrict__ part, int64_t nsp, GemmArgs g) {
   const int64_t total = g.M * g.N;
@@ -503,8 +627,29 @@ int gnf_gemm_launch(GemmArgs g, int splits, hipStream_t s) {
     else if (bkf) hipLaunchKernelGGL((gemm_vec_k<BT, BT, false, true>), grid, dim3(256), 0, s, g);       \
     else hipLaunchKernelGGL((gemm_vec_k<BT, BT, false, false>), grid, dim3(256), 0, s, g);               \
   } while (0)
-  // one column of 128-wide tiles over a tall M (fc1 forward: 78 400 x 128 x 2304): pick the tile height that leaves the
-  // fewest tile-rows on the busiest CU
+  // one column of <= 128-wide tiles over a tall M, long K (fc1 forward: 78 400 x 128 x 2304): the persistent tall kernel when
+  // one of its block heights fills the chip
+  if (vec && akf && bkf && bt == 128 && gy == 1 && nsp == 1 && !g.grp && !g.Bmask && !g.Cmask && !g.gate &&
+      !(g.flags & ~GNF_GEMM_RELU) && g.N > 96 && g.K % TBK == 0 && g.K >= 8 * TBK && g.sam % 4 == 0 && g.sbn % 4 == 0 &&
+      (((uintptr_t)g.A | (uintptr_t)g.B) & 15) == 0) {
+    static const bool no_tall = getenv("GNF_GEMM_TALL") && getenv("GNF_GEMM_TALL")[0] == '0';      // A/B switch
+    const int tmw = no_tall ? 0 : tall_tmw(g.M);
+    if (tmw) {
+      const int64_t tiles = (g.M + 64 * tmw - 1) / (64 * tmw);
+      const unsigned tgrid = (unsigned)(tiles < 256 ? tiles : 256);
+#define GNF_TALL_LAUNCH(T)                                                                                        \
+  do {                                                                                                            \
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tall_k<T>),                                      \
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)tall_lds<T>());                     \
+    hipLaunchKernelGGL(gemm_tall_k<T>, dim3(tgrid), dim3(64 * TWAVES), tall_lds<T>(), s, g);                       \
+  } while (0)
+      if (tmw == 5) GNF_TALL_LAUNCH(5); else if (tmw == 4) GNF_TALL_LAUNCH(4); else GNF_TALL_LAUNCH(3);
+#undef GNF_TALL_LAUNCH
+      GNF_LAUNCH_CHECK();
+      return 0;
+    }
+  }
+  // otherwise pick the tile height that leaves the fewest tile-rows on the busiest CU
   if (vec && akf && bkf && bt == 128 && gy == 1 && nsp == 1 && !g.grp) {
     const int64_t t160 = (g.M + 159) / 160;
     if (((t160 + 255) / 256) * 160 < ((gx + 255) / 256) * 128) {

@@ -23,7 +23,10 @@ def test_bench_reads_pmc_figures_from_profiles():
     for k in ("gnf_mnistcnn_conv_bwd", "gnf_mnistcnn_conv_fwd", "gnf_monotonic_bwd", "gnf_monotonic_fwd"):
         e = d["kernels"][k]
         assert e["mfma_per_image"] > 10 and e["valu_per_mfma"] > 0 and e["hbm_bytes_per_launch"] > 1e6, k
-        assert 1.5 < e["effective_clock_GHz"] < 2.6, (k, e["effective_clock_GHz"])
+        # the clock of the COUNTER pass and the cycles of a launch: bench.py derives the clock of its own run from the latter
+        # (HBM-streaming kernels run ~10 % slower, at a ~10 % lower clock, under rocprofv3 --pmc)
+        assert 1.5 < e["effective_clock_GHz_in_pmc_pass"] < 2.6, (k, e["effective_clock_GHz_in_pmc_pass"])
+        assert abs(e["cycles_per_launch"] / e["duration_ns_in_pmc_pass"] - e["effective_clock_GHz_in_pmc_pass"]) < 2e-3
         assert 0 <= e["lds_bank_conflict_frac_of_lds_cycles"] < 1
     # the conv backward of round 4 issues fewer MFMAs per image than rounds 1-3 (conv1 on 16x16x1_4b: 99 instead of 129)
     assert d["kernels"]["gnf_mnistcnn_conv_bwd"]["mfma_per_image"] < 1590
@@ -35,7 +38,7 @@ def test_bench_prints_issue_figures_for_every_kernel():
     AT that clock (verdict r03 item 8).  Checked on the source (the GPU run is test_bench_line_carries_issue_figures)."""
     src = open(os.path.join(ROOT, "bench.py")).read()
     for field in ("frac_algorithmic", "mfma_issue_frac", "issue_frac_ceiling_shared_alu", "effective_clock_GHz",
-                  "frac_of_peak_at_clock", "valu_per_mfma", "--global-batch", '"strong" if args.global_batch else "weak"'):
+                  "effective_clock_GHz_in_pmc_pass", "cycles_per_launch", "frac_of_peak_at_clock", "valu_per_mfma", "--global-batch", '"strong" if args.global_batch else "weak"'):
         assert field in src, field
     assert "issued(dom, out[\"roofline\"])" in src and "for k, entry in kern.items()" in src
 

@@ -159,6 +159,29 @@ def test_gemm_shapes(M, N, K):
     assert rel_err(C3.cpu(), ref3) < 2e-6
 
 
+@pytest.mark.parametrize("M,N,K", [(78400, 128, 2304), (65536, 128, 256), (65000, 100, 288), (49152, 128, 256),
+                                   (48500, 127, 320), (40000, 128, 256)])
+def test_gemm_tall_long_k_path(M, N, K):
+    """C = relu(A[M x K] W[N x K]^T + b), both k-contiguous, 96 < N <= 128, K % 32 == 0, tall M (the fc1 forward of the
+    MNISTCNN): the persistent gemm_tall_k with 320- / 256- / 192-row blocks (78 400 -> 5, 65 536 -> 4, 49 152 -> 3 tiles per
+    wavefront row), ragged last blocks and N < 128 included; 40 000 rows fill no block height and stay on gemm_vec_k.
+    Strided rows of A / C and a plain (no bias, no ReLU) call too; every entry of C is written exactly where it belongs."""
+    from gnf_hip import ops
+    torch.manual_seed(M + N + K)
+    A, W, bias = torch.randn(M, K, device=DEV), torch.randn(N, K, device=DEV), torch.randn(N, device=DEV)
+    C = torch.full((M, N), float("nan"), device=DEV)
+    ops.gemm(A, (K, 1), W, (1, K), C, (N, 1), M, N, K, bias=bias, relu=True)
+    rows = torch.cat([torch.arange(0, 700), torch.randint(0, M, (3000,)), torch.arange(M - 700, M)]).to(DEV)
+    ref = torch.relu(A[rows].double() @ W.double().t() + bias.double())
+    assert not torch.isnan(C).any()
+    assert rel_err(C[rows].cpu(), ref.cpu()) < 2e-6
+    if M <= 50000:
+        Aw, Cw = torch.randn(M, K + 8, device=DEV), torch.zeros(M, N + 4, device=DEV)
+        ops.gemm(Aw, (K + 8, 1), W, (1, K), Cw, (N + 4, 1), M, N, K)
+        assert rel_err(Cw[rows, :N].cpu(), (Aw[rows, :K].double() @ W.double().t()).cpu()) < 2e-6
+        assert float(Cw[:, N:].abs().max()) == 0.
+
+
 @pytest.mark.parametrize("M,N", [(4096, 512), (5003, 644), (78400, 2304)])
 def test_gemm_wide_short_k_path(M, N):
     """C = A[M x 128] * B[128 x N], A k-contiguous, B n-contiguous, no epilogue options (the fc1 data gradient of the

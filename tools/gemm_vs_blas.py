@@ -16,7 +16,7 @@ def g(A, B):
 
 
 def timeit(f, n=20):
-    for _ in range(3): f()
+    for _ in range(150): f()      # warm: the first ~50 ms of kernels of a process run at ~2.15 GHz
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()

@@ -136,13 +136,13 @@ int main(int argc, char** argv) {
   const long long ntiles = (M + 64 * TMW - 1) / (64 * TMW);
   const unsigned grid = ntiles < 256 ? (unsigned)ntiles : 256;
   hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
-  for (int r = 0; r < 3; ++r) hipLaunchKernelGGL(tall_gemm_k<TMW>, dim3(grid), dim3(64 * WAVES), lds, 0, A, B, b, C, M, N, K, 1, cyc);
+  for (int r = 0; r < 300; ++r) hipLaunchKernelGGL(tall_gemm_k<TMW>, dim3(grid), dim3(64 * WAVES), lds, 0, A, B, b, C, M, N, K, 1, cyc);
   (void)hipEventRecord(e0, 0);
-  for (int r = 0; r < 10; ++r) hipLaunchKernelGGL(tall_gemm_k<TMW>, dim3(grid), dim3(64 * WAVES), lds, 0, A, B, b, C, M, N, K, 1, cyc);
+  for (int r = 0; r < 50; ++r) hipLaunchKernelGGL(tall_gemm_k<TMW>, dim3(grid), dim3(64 * WAVES), lds, 0, A, B, b, C, M, N, K, 1, cyc);
   (void)hipEventRecord(e1, 0);
   (void)hipDeviceSynchronize();
   printf("launch status: %s\n", hipGetErrorString(hipGetLastError()));
-  float ms; (void)hipEventElapsedTime(&ms, e0, e1); ms /= 10;
+  float ms; (void)hipEventElapsedTime(&ms, e0, e1); ms /= 50;   // 300 launches first: a GPU that has just been handed 700 MB of operands runs its first ~50 ms of kernels at ~2.15 GHz
   printf("M=%lld N=%d K=%d tiles=%lld: %.4f ms = %.1f TFLOP/s\n", M, N, K, ntiles, ms, 2.0 * M * N * K / (ms * 1e-3) / 1e12);
   long long hc[8]; (void)hipMemcpy(hc, cyc, 64, hipMemcpyDeviceToHost);
   printf("main loop cycles per slab (wave 0..7):"); for (int w = 0; w < 8; ++w) printf(" %lld", hc[w] / (K / BK)); printf("  (MFMA-bound: %d)\n", 2 * 160 * 32);
