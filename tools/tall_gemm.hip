@@ -72,6 +72,7 @@ __global__ __launch_bounds__(64 * WAVES, 1) void tall_gemm_k(const float* __rest
       if (s + 1 < nslab) fetch((s + 1) * BK);
       const float* As = smem + (s & 1) * SLAB;
       const float* Bs = As + BM * BK;
+#ifndef VARIANT
 #pragma unroll
       for (int kg = 0; kg < 2; ++kg) {
         f32x4 af[TMW], bf[4];
@@ -93,6 +94,40 @@ __global__ __launch_bounds__(64 * WAVES, 1) void tall_gemm_k(const float* __rest
             for (int b = 0; b < 4; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[a][r], bf[b][r], acc[a][b], 0, 0, 0);
       }
       if (s + 1 < nslab) stash((s + 1) & 1);
+#else
+      // both k-groups' fragments requested up front; the next slab goes to LDS between the two MFMA blocks
+      f32x4 af[2][TMW], bf[2][4];
+#pragma unroll
+      for (int kg = 0; kg < 2; ++kg) {
+#pragma unroll
+        for (int a = 0; a < TMW; ++a) {
+          const int row = (wm * TMW + a) * 16 + j;
+          af[kg][a] = *reinterpret_cast<const f32x4*>(As + row * BK + 4 * ((4 * kg + q) ^ ((row >> 1) & 7)));
+        }
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+          const int row = (wn * 4 + b) * 16 + j;
+          bf[kg][b] = *reinterpret_cast<const f32x4*>(Bs + row * BK + 4 * ((4 * kg + q) ^ ((row >> 1) & 7)));
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int a = 0; a < TMW; ++a)
+#pragma unroll
+          for (int b = 0; b < 4; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[0][a][r], bf[0][b][r], acc[a][b], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      if (s + 1 < nslab) stash((s + 1) & 1);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int a = 0; a < TMW; ++a)
+#pragma unroll
+          for (int b = 0; b < 4; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[1][a][r], bf[1][b][r], acc[a][b], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+#endif
     }
     if (cyc && blockIdx.x == 0 && lane == 0) cyc[wave] = __builtin_readcyclecounter() - tc0;
     __syncthreads();                               // all reads of the last slab done before the next tile's first issue
