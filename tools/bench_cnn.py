@@ -10,6 +10,7 @@ label = sys.argv[sys.argv.index('--label') + 1] if '--label' in sys.argv else ' 
 so = '/tmp/libgnf_cnn_ab_%d.so' % os.getpid()
 sys.path.insert(0, ROOT + '/graphical-normalizing-flows_amd')
 from gnf_hip.build import EXTRA_FLAGS   # the product's per-file flags apply here too
+from _warm import warm_gpu  # noqa: E402
 objs = []
 for f in (os.environ.get('GNF_CNN_FWD_SRC', 'gnf_mnistcnn_fwd.hip'), os.environ.get('GNF_CNN_BWD_SRC', 'gnf_mnistcnn.hip'),
           'gnf_rowwise.hip'):                                       # A/B against other sources in csrc/
@@ -50,6 +51,7 @@ def bwd():
 
 
 def timeit(fn, reps=15):
+    warm_gpu()
     for _ in range(3):
         assert fn() == 0
     ts = []

@@ -11,6 +11,7 @@ import os
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, ROOT + '/graphical-normalizing-flows_amd']
 from gnf_hip import abi  # noqa: E402
+from _warm import warm_gpu  # noqa: E402
 from models import MonotonicNormalizer  # noqa: E402
 
 DEV = "cuda:0"
@@ -35,6 +36,7 @@ def main():
             loss = flow.loss(z, ld)
             loss.backward()
             return loss
+        warm_gpu()
         for _ in range(3):
             loss = step()
         torch.cuda.synchronize()
@@ -76,6 +78,7 @@ def main():
             torch.cuda.synchronize()
             t_eager = (time.perf_counter() - t0) / 50
             gs = dp.GraphedStep(flow, state, x)
+            warm_gpu()                                 # the capture idled the GPU
             for _ in range(3):
                 gs(x)
             torch.cuda.synchronize()

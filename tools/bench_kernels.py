@@ -10,6 +10,7 @@ import os
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, ROOT + '/graphical-normalizing-flows_amd']
 from gnf_hip import abi, ops  # noqa: E402
+from _warm import warm_gpu  # noqa: E402
 from models import MonotonicNormalizer  # noqa: E402
 
 DEV = "cuda:0"
@@ -17,6 +18,7 @@ HBM_PEAK, F32_PEAK = 8000., 157.3       # GB/s (spec), TFLOP/s (fp32 MFMA)
 
 
 def timeit(fn, n=20, warm=3):
+    warm_gpu(.15)
     for _ in range(warm):
         fn()
     torch.cuda.synchronize()
@@ -35,6 +37,7 @@ def timeit(fn, n=20, warm=3):
 def time_entry(name, fn, n=20, warm=3):
     """median-free mean of the HIP events gnf_hip.abi records around the NAMED C-ABI entry point (on its launch stream):
     the kernel(s) of that entry point alone, without autograd bookkeeping, output allocation or other launches"""
+    warm_gpu(.15)
     for _ in range(warm):
         fn()
     abi.profile_enable((name,))

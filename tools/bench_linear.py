@@ -6,6 +6,7 @@ import os, sys, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, ROOT + '/graphical-normalizing-flows_amd']
 from gnf_hip import abi, ops
+from _warm import warm_gpu  # noqa: E402
 if os.environ.get('GNF_AB_LIB'):
     abi.LIB_PATH = os.path.join(ROOT, os.environ['GNF_AB_LIB'])
 dev = 'cuda:0'
@@ -28,6 +29,7 @@ for kind in ("deg", "full", "none"):
         for t in (x, W, b, W2, b2): t.grad = None
         y = ops.mlp(x, [(W, b), (W2, b2)], masks, degs=degs)
         y.sum().backward()
+    warm_gpu()
     for _ in range(5): step()
     abi.profile_enable(names)
     for _ in range(20): step()

@@ -7,6 +7,7 @@ from gnf_hip import abi
 if os.environ.get('GNF_AB_LIB'):                      # A/B against another build of the library (tools/*.bin)
     abi.LIB_PATH = os.path.join(ROOT, os.environ['GNF_AB_LIB'])
 from models import MonotonicNormalizer
+from _warm import warm_gpu  # noqa: E402
 dev = 'cuda:0'
 for H in [int(a) for a in sys.argv[1:]] or [50]:
     torch.manual_seed(0)
@@ -19,6 +20,7 @@ for H in [int(a) for a in sys.argv[1:]] or [50]:
         z, jac = norm(x, h)
         (z.sum() + torch.log(jac).sum()).backward()
         return z
+    warm_gpu()
     for _ in range(3): step()
     abi.profile_enable(("gnf_monotonic_fwd", "gnf_monotonic_bwd"))
     for _ in range(10): z = step()
