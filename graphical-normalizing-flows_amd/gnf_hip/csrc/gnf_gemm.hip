@@ -335,51 +335,67 @@ typedef float f32x4wu __attribute__((ext_vector_type(4), aligned(4)));
 constexpr int WK = 128, WBM = 128, WBN = 128, WWAVES = 8, WLDB = WBN + 4;
 constexpr size_t kWideLds = (size_t)(WBM * WK + 2 * 64 * WLDB) * sizeof(float);
 
+// Addressing: one buffer descriptor per operand / row block, 32-bit lane offsets (the 64-bit `m * scm + n` of the first
+// version cost 100 VALU and 110 SALU instructions per unit and wavefront: 0.459 ms against the 0.419 of the stand-alone form
+// with compile-time strides); rows past M and columns past N are dropped (stores) or read as 0 (loads) by the range check, so
+// no memory instruction sits under a branch.  Request order: half (u+1, 1) at the top of (u, 1), half (u+2, 0) inside (u, 1),
+// BOTH complete before the stores of unit u are issued (a use of their registers: hipcc waits there, where the loads are
+// old, and not in front of the next unit's LDS writes, behind 32 stores in the in-order vmcnt queue).
 __global__ __launch_bounds__(64 * WWAVES, 1) void gemm_wide_k(GemmArgs g) {
   extern __shared__ __attribute__((aligned(16))) float wsm[];
   float* As = wsm;                        // [WBM][WK], chunk-swizzled
   float* Bs = wsm + WBM * WK;             // 2 x [64][WLDB]
-  const float* __restrict__ A = g.A;
-  const float* __restrict__ B = g.B;
-  float* __restrict__ C = g.C;
-  const int64_t M = g.M, N = g.N;
+  typedef unsigned int u32x4w __attribute__((ext_vector_type(4)));
+  const int64_t M = g.M;
+  const int N = (int)g.N, sam = (int)g.sam, sbk = (int)g.sbk, scm = (int)g.scm;
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int q = lane >> 4, j = lane & 15;
   const int wm = wave >> 1, wn = wave & 1;            // 4 x 2 wavefronts: 32 rows x 64 cols each = 2 x 4 tiles of 16x16
-  const int64_t nblk = (M + WBM - 1) / WBM, ntile = (N + WBN - 1) / WBN;
+  const int64_t nblk = (M + WBM - 1) / WBM;
+  const int ntile = (N + WBN - 1) / WBN;
   const int64_t units = nblk * ntile;
   const int64_t u0 = units * blockIdx.x / gridDim.x, u1 = units * (blockIdx.x + 1) / gridDim.x;
-  f32x4w pre[4];
-  auto fetch = [&](int64_t u, int h) {
-    const int64_t t = u % ntile;
+  const __amdgpu_buffer_rsrc_t rsB =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.B), 0, (int)(((int64_t)(WK - 1) * sbk + N) * 4), 0x00020000);
+  f32x4w pre[2][4];
+  auto fetch = [&](f32x4w (&dst)[4], int64_t u, int h) {
+    const int t = (int)(u % ntile);
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
       const int P = p * 512 + tid, k = P >> 5, n4 = P & 31;          // k 0..63, 4 consecutive n
-      int64_t gn = WBN * t + 4 * n4;
-      if (gn + 3 >= N) gn = N - 4;                                   // N % 4 == 0, N >= 4: stays in range, never stored
-      pre[p] = *reinterpret_cast<const f32x4wu*>(B + (int64_t)(64 * h + k) * g.sbk + gn);
+      const int gn = WBN * t + 4 * n4;                               // N % 4 == 0: a quad is inside the row or past it
+      const unsigned off = gn < N ? (unsigned)((64 * h + k) * sbk + gn) * 4u : 0xfffffff0u;
+      dst[p] = __builtin_bit_cast(f32x4w, __builtin_amdgcn_raw_buffer_load_b128(rsB, off, 0, 0));
     }
   };
-  auto stash = [&](int buf) {
+  auto stash = [&](const f32x4w (&src)[4], int buf) {
     float* base = Bs + buf * (64 * WLDB);
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
       const int P = p * 512 + tid, k = P >> 5, n4 = P & 31;
-      *reinterpret_cast<f32x4w*>(base + k * WLDB + 4 * n4) = pre[p];
+      *reinterpret_cast<f32x4w*>(base + k * WLDB + 4 * n4) = src[p];
     }
   };
   int64_t cur_blk = -1;
-  if (u0 < u1) { fetch(u0, 0); stash(0); }
+  if (u0 < u1) {
+    fetch(pre[0], u0, 0);
+    stash(pre[0], 0);
+    fetch(pre[1], u0, 1);
+    fetch(pre[0], u0 + 1 < u1 ? u0 + 1 : u0, 0);
+  }
   for (int64_t u = u0; u < u1; ++u) {
-    const int64_t blk = u / ntile, t = u - blk * ntile, m0 = blk * WBM;
+    const int64_t blk = u / ntile, m0 = blk * WBM;
+    const int t = (int)(u - blk * ntile);
+    const int rows = (int)(M - m0 < WBM ? M - m0 : WBM);
     if (blk != cur_blk) {                   // (re)load the A block: 4096 16-B chunks, 8 per thread
       __syncthreads();
+      const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.A) + m0 * sam, 0,
+                                                                           ((rows - 1) * sam + WK) * 4, 0x00020000);
 #pragma unroll
       for (int p = 0; p < 8; ++p) {
         const int P = p * 512 + tid, row = P >> 5, c = P & 31;
-        int64_t gm = m0 + row;
-        if (gm >= M) gm = M - 1;
-        const f32x4w v = *reinterpret_cast<const f32x4wu*>(A + gm * g.sam + 4 * c);
+        const unsigned off = row < rows ? (unsigned)(row * sam + 4 * c) * 4u : 0xfffffff0u;      // rows past M: zeros
+        const f32x4w v = __builtin_bit_cast(f32x4w, __builtin_amdgcn_raw_buffer_load_b128(rsA, off, 0, 0));
         *reinterpret_cast<f32x4w*>(As + row * WK + 4 * ((c & ~7) | ((c & 7) ^ ((row >> 1) & 7)))) = v;
       }
       cur_blk = blk;
@@ -392,10 +408,12 @@ __global__ __launch_bounds__(64 * WWAVES, 1) void gemm_wide_k(GemmArgs g) {
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
       __syncthreads();
-      const int64_t nu = h == 1 ? u + 1 : u;
-      const int nh = h ^ 1;
-      const bool more = nu < u1;
-      if (more) fetch(nu, nh);
+      if (h == 0) {
+        stash(pre[1], 1);                                   // (u, 1): requested at the top of (u-1, 1)
+      } else {
+        stash(pre[0], 0);                                   // (u+1, 0): requested inside (u-1, 1)
+        fetch(pre[1], u + 1 < u1 ? u + 1 : u, 1);           // (a clamped unit past the end is never used)
+      }
       const float* Bh = Bs + h * (64 * WLDB);
       f32x4w af[2][2], bf[2][4];
       auto frags = [&](int kg, int slot) {
@@ -424,18 +442,28 @@ __global__ __launch_bounds__(64 * WWAVES, 1) void gemm_wide_k(GemmArgs g) {
             for (int b = 0; b < 4; ++b)
               acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[kg & 1][a][r], bf[kg & 1][b][r], acc[a][b], 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
+        if (h == 1 && kg == 0) {
+          fetch(pre[0], u + 2 < u1 ? u + 2 : u, 0);
+          __builtin_amdgcn_sched_barrier(0);
+        }
       }
-      if (more) stash(nh);
     }
 #pragma unroll
+    for (int p = 0; p < 4; ++p) asm volatile("" : "+v"(pre[0][p]), "+v"(pre[1][p]));     // both requests complete HERE
+    __builtin_amdgcn_sched_barrier(0);
+    const __amdgpu_buffer_rsrc_t rsC =
+        __builtin_amdgcn_make_buffer_rsrc(g.C + m0 * scm, 0, ((rows - 1) * scm + N) * 4, 0x00020000);
+#pragma unroll
     for (int b = 0; b < 4; ++b) {
-      const int64_t n = WBN * t + (wn * 4 + b) * 16 + j;
+      const int n = WBN * t + (wn * 4 + b) * 16 + j;
 #pragma unroll
       for (int a = 0; a < 2; ++a)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const int64_t m = m0 + (wm * 2 + a) * 16 + 4 * q + r;
-          if (m < M && n < N) C[m * g.scm + n] = acc[a][b][r];
+          const int row = (wm * 2 + a) * 16 + 4 * q + r;
+          const unsigned off = (n < N && row < rows) ? (unsigned)(row * scm + n) * 4u : 0xfffffff0u;
+          const float val = acc[a][b][r];      // (a scalar first: bit-casting the vector element stored element 0 four times)
+          __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(val), rsC, off, 0, 0);
         }
     }
   }
@@ -609,7 +637,10 @@ int gnf_gemm_launch(GemmArgs g, int splits, hipStream_t s) {
   const dim3 grid((unsigned)gx, (unsigned)gy, (unsigned)nsp);
   // short K, wide N, tall M, no epilogue options (fc1 data gradient): the persistent unit-range kernel
   if (g.K == WK && nsp == 1 && !g.grp && g.sak == 1 && g.sbn == 1 && g.scn == 1 && !g.bias && !g.Bmask && !g.Cmask &&
-      !g.gate && g.flags == 0 && g.N % 4 == 0 && g.N >= 4 * WBN && g.M >= 32 * WBM) {
+      !g.gate && g.flags == 0 && g.N % 4 == 0 && g.N >= 4 * WBN && g.M >= 32 * WBM &&
+      // 32-bit lane offsets inside a row block / inside B, 16-B aligned quads
+      g.sam % 4 == 0 && g.sbk % 4 == 0 && (((uintptr_t)g.A | (uintptr_t)g.B) & 15) == 0 && g.N < (1 << 24) &&
+      (int64_t)WBM * g.sam < (1 << 28) && (int64_t)WBM * g.scm < (1 << 28) && (int64_t)WK * g.sbk < (1 << 28)) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_wide_k), hipFuncAttributeMaxDynamicSharedMemorySize,
                               (int)kWideLds);
     hipLaunchKernelGGL(gemm_wide_k, dim3(256), dim3(64 * WWAVES), kWideLds, s, g);
