@@ -593,6 +593,97 @@ static int tall_tmw(int64_t M) {
   return best;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Split-K product with BOTH operands k-major, M <= 128:  C[M x N] = A[K x M]^T B[K x N]  -- the weight gradient of a
+// <= 128-wide layer over a tall batch (MNISTCNN fc1: dW = dY^T X, 128 x 2304 x 78 400, models/MLP.py:44 backward).  One
+// 8-wavefront workgroup owns a 128 x 128 output tile over one K range (blockIdx = tile + ntile * split: 18 x 14 = 252
+// workgroups for fc1); K-slabs of 64 rows go through two LDS stages IN THEIR GLOBAL LAYOUT ([k][128], 512-B rows: nothing is
+// transposed on the way in).  Fragments: ONE ds_read_b128 at [k = 4 kk + q][m = 4 j .. 4 j + 3] is the A operand of FOUR MFMAs
+// -- row i of tile t is m = 4 i + t (any row permutation is as good as another as long as the epilogue knows it), the B
+// side likewise with two tiles per ds_read_b64; wavefront (wm, wn) of a 2 x 4 grid holds 64 m x 32 n.  Buffer descriptors
+// per K range: rows past the range read as zeros, columns past N are neither read nor stored.  Partials go to
+// C + split * c_split_stride as float2 (the caller reduces them).  0.372 + 0.006 ms against 0.417 + 0.013 of
+// gemm_vec_k<128,128> with 36 splits (tools/kmajor_gemm.hip is the stand-alone form).
+// ---------------------------------------------------------------------------------------------
+constexpr int KMK = 64, KMN = 128, KMLDS = 2 * KMK * (128 + KMN) * (int)sizeof(float);
+
+__global__ __launch_bounds__(512, 1) void gemm_kmajor_k(GemmArgs g) {
+  extern __shared__ __attribute__((aligned(16))) float ksm[];
+  typedef float f32x2w __attribute__((ext_vector_type(2)));
+  constexpr int SLAB = KMK * (128 + KMN);
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int q = lane >> 4, j = lane & 15;
+  const int wm = wave >> 2, wn = wave & 3;
+  const int M = (int)g.M, N = (int)g.N, sak = (int)g.sak, sbk = (int)g.sbk;
+  const int ntile = (N + KMN - 1) / KMN;
+  const int tile = blockIdx.x % ntile, split = blockIdx.x / ntile;
+  const int64_t k0 = (int64_t)split * g.k_per_split;
+  if (k0 >= g.K) return;
+  const int kn = (int)(g.K - k0 < g.k_per_split ? g.K - k0 : g.k_per_split);
+  const int n0 = tile * KMN;
+  const __amdgpu_buffer_rsrc_t rsA =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.A) + k0 * sak, 0, ((kn - 1) * sak + M) * 4, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsB =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.B) + k0 * sbk, 0, ((kn - 1) * sbk + N) * 4, 0x00020000);
+  // 16-B pieces of a slab: 64 rows x 32 quads per operand, 4 + 4 per thread
+  f32x4w pa[4], pb[4];
+  auto fetch = [&](int s) {
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      const int P = p * 512 + tid, row = s * KMK + (P >> 5), c = P & 31;
+      pa[p] = __builtin_bit_cast(f32x4w, __builtin_amdgcn_raw_buffer_load_b128(
+                                             rsA, 4 * c < M ? (unsigned)(row * sak + 4 * c) * 4u : 0xfffffff0u, 0, 0));
+      const int gn = n0 + 4 * c;
+      pb[p] = __builtin_bit_cast(f32x4w, __builtin_amdgcn_raw_buffer_load_b128(
+                                             rsB, gn < N ? (unsigned)(row * sbk + gn) * 4u : 0xfffffff0u, 0, 0));
+    }
+  };
+  auto stash = [&](int stage) {
+    float* a = ksm + stage * SLAB;
+    float* b = a + KMK * 128;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      const int P = p * 512 + tid, row = P >> 5, c = P & 31;
+      *reinterpret_cast<f32x4w*>(a + row * 128 + 4 * c) = pa[p];
+      *reinterpret_cast<f32x4w*>(b + row * KMN + 4 * c) = pb[p];
+    }
+  };
+  f32x4w acc[4][2];
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b) acc[a][b] = f32x4w{0.f, 0.f, 0.f, 0.f};
+  const int nslab = (kn + KMK - 1) / KMK;
+  fetch(0);
+  stash(0);
+  for (int s = 0; s < nslab; ++s) {
+    __syncthreads();                               // slab s visible; everybody done reading the other stage
+    if (s + 1 < nslab) fetch(s + 1);
+    const float* As = ksm + (s & 1) * SLAB;
+    const float* Bs = As + KMK * 128;
+#pragma unroll
+    for (int kk = 0; kk < KMK / 4; ++kk) {
+      const f32x4w af = *reinterpret_cast<const f32x4w*>(As + (4 * kk + q) * 128 + 64 * wm + 4 * j);
+      const f32x2w bf = *reinterpret_cast<const f32x2w*>(Bs + (4 * kk + q) * KMN + 32 * wn + 2 * j);
+#pragma unroll
+      for (int a = 0; a < 4; ++a) {
+        acc[a][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[a], bf[0], acc[a][0], 0, 0, 0);
+        acc[a][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[a], bf[1], acc[a][1], 0, 0, 0);
+      }
+    }
+    if (s + 1 < nslab) stash((s + 1) & 1);
+  }
+  // D tile (a, b): lane (q, j) holds rows i = 4 q + r -> m = 64 wm + 4 i + a, column j -> n = 32 wn + 2 j + b
+  float* out = g.C + (int64_t)split * g.c_split_stride;
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int m = 64 * wm + 4 * (4 * q + r) + a, n = n0 + 32 * wn + 2 * j;
+      if (m < M && n < N) *reinterpret_cast<f32x2w*>(out + (int64_t)m * g.scm + n) = f32x2w{acc[a][0][r], acc[a][1][r]};
+    }
+}
+
 // split-K epilogue: C = epi(sum_z partial[z]) with the same options as the fused epilogue
 __global__ void gemm_reduce_k(const float* __restrict__ part, int64_t nsp, GemmArgs g) {
   const int64_t total = g.M * g.N;
@@ -635,6 +726,20 @@ int gnf_gemm_launch(GemmArgs g, int splits, hipStream_t s) {
   const int64_t gx = (g.M + bt - 1) / bt, gy = (g.N + bt - 1) / bt;
   if (gy > 65535 || nsp > 65535) return GNF_ESHAPE;
   const dim3 grid((unsigned)gx, (unsigned)gy, (unsigned)nsp);
+  // both operands k-major, M <= 128, a long K per split, plain partial / plain output (fc1 weight gradient)
+  if (g.sam == 1 && g.sbn == 1 && g.scn == 1 && g.M <= 128 && g.M % 4 == 0 && !g.grp && !g.bias && !g.Bmask && !g.Cmask && !g.gate &&
+      g.flags == 0 && g.N % 4 == 0 && g.sak % 4 == 0 && g.sbk % 4 == 0 && g.scm % 2 == 0 && g.k_per_split >= 512 &&
+      (((uintptr_t)g.A | (uintptr_t)g.B) & 15) == 0 && (((uintptr_t)g.C | (uintptr_t)(g.c_split_stride * 4)) & 7) == 0 &&
+      g.k_per_split * (g.sak > g.sbk ? g.sak : g.sbk) < (1 << 28) && ((g.N + KMN - 1) / KMN) * nsp >= 64 && nsp <= 4096) {
+    static const bool no_km = getenv("GNF_GEMM_KMAJOR") && getenv("GNF_GEMM_KMAJOR")[0] == '0';      // A/B switch
+    if (!no_km) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kmajor_k), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                KMLDS);
+      hipLaunchKernelGGL(gemm_kmajor_k, dim3((unsigned)(((g.N + KMN - 1) / KMN) * nsp)), dim3(512), KMLDS, s, g);
+      GNF_LAUNCH_CHECK();
+      return 0;
+    }
+  }
   // short K, wide N, tall M, no epilogue options (fc1 data gradient): the persistent unit-range kernel
   if (g.K == WK && nsp == 1 && !g.grp && g.sak == 1 && g.sbn == 1 && g.scn == 1 && !g.bias && !g.Bmask && !g.Cmask &&
       !g.gate && g.flags == 0 && g.N % 4 == 0 && g.N >= 4 * WBN && g.M >= 32 * WBM &&
@@ -741,6 +846,14 @@ static int plan_splits(int64_t M, int64_t N, int64_t K) {
   const int64_t t128 = ((M + 127) / 128) * ((N + 127) / 128);
   // (t128 up to 128: the 1890 x 630 x 50 000 weight gradient of cfg5's last MADE layer is 75 such tiles -- as 300 unsplit
   // 64 x 64 tiles it streamed 7.7 GB of operands in 2.63 ms, 45 TFLOP/s.)
+  // M <= 128 over a very long K (fc1 weight gradient 128 x 2304 x 78 400): gemm_kmajor_k runs ONE 128-KB-LDS workgroup per
+  // CU, so as many (tile, split) pairs as CUs: 18 tiles x 14 splits (the generic kernels took 36 splits: 3 x the partials)
+  static const bool no_km_plan = getenv("GNF_GEMM_KMAJOR") && getenv("GNF_GEMM_KMAJOR")[0] == '0';
+  if (M <= 128 && N % 4 == 0 && N >= 512 && K >= 16384 && !no_km_plan) {
+    int64_t s = 256 / ((N + 127) / 128);
+    if (s > K / 512) s = K / 512;
+    if (s >= 2) return (int)s;
+  }
   if (K >= 8192 && t128 <= 128 && t128 * 16 <= tiles * 5) {
     int64_t s128 = (640 + t128 - 1) / t128;
     if (s128 > K / 512) s128 = K / 512;

@@ -182,6 +182,24 @@ def test_gemm_tall_long_k_path(M, N, K):
         assert float(Cw[:, N:].abs().max()) == 0.
 
 
+@pytest.mark.parametrize("M,N,K", [(128, 2304, 78400), (64, 516, 40001), (128, 640, 20000), (100, 1024, 33000)])
+def test_gemm_kmajor_split_k_path(M, N, K):
+    """C[M x N] = dY[K x M]^T X[K x N], both operands k-major, M <= 128, K >= 16 384 (the fc1 weight gradient of the
+    MNISTCNN): gemm_kmajor_k over 256 / ntile K ranges + the split-K reduction; ragged K ranges (K not a multiple of 64 or
+    of the split count), ragged N tiles, M < 128, and strided rows of both operands (views into wider buffers)"""
+    from gnf_hip import ops
+    torch.manual_seed(M + N + K)
+    dY, X = torch.randn(K, M, device=DEV), torch.randn(K, N, device=DEV)
+    C = torch.full((M, N), float("nan"), device=DEV)
+    ops.gemm(dY, (1, M), X, (N, 1), C, (N, 1), M, N, K)
+    ref = dY.double().t() @ X.double()
+    assert rel_err(C.cpu(), ref.cpu()) < 2e-6
+    dYw, Xw = torch.randn(K, M + 4, device=DEV), torch.randn(K, N + 8, device=DEV)
+    C2 = torch.full((M, N), float("nan"), device=DEV)
+    ops.gemm(dYw, (1, M + 4), Xw, (N + 8, 1), C2, (N, 1), M, N, K)
+    assert rel_err(C2.cpu(), (dYw[:, :M].double().t() @ Xw[:, :N].double()).cpu()) < 2e-6
+
+
 @pytest.mark.parametrize("M,N", [(4096, 512), (5003, 644), (78400, 2304)])
 def test_gemm_wide_short_k_path(M, N):
     """C = A[M x 128] * B[128 x N], A k-contiguous, B n-contiguous, no epilogue options (the fc1 data gradient of the
