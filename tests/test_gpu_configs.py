@@ -339,7 +339,11 @@ def test_bench_line_carries_issue_figures():
                   "effective_clock_GHz", "frac_of_peak_at_clock"):
             assert f in e, (e["kernel"], f)
         assert e["frac"] == e["frac_algorithmic"] and 0 < e["mfma_issue_frac"] < e["issue_frac_ceiling_shared_alu"] + .05
-        assert e["mfma_issue_frac"] <= e["frac_of_peak_at_clock"] < 1.
+        # the clock of the run (cycles of a launch from the counter pass / live launch time) sits within a few per cent of the
+        # nominal 2.4 GHz on a warm GPU -- on either side of it (boost) -- and the two fractions differ by exactly that ratio
+        assert 2.0 < e["effective_clock_GHz"] < 2.6 and 1.9 < e["effective_clock_GHz_in_pmc_pass"] < 2.6
+        assert abs(e["frac_of_peak_at_clock"] * e["effective_clock_GHz"] / 2.4 / e["mfma_issue_frac"] - 1.) < 2e-3
+        assert 0 < e["frac_of_peak_at_clock"] < 1.
     assert out["roofline"]["traffic"] and out["roofline"]["traffic_algorithmic"]
     # only the dominant kernel's entry point is timed (HIP events) inside the region, the others behind it
     src = out["ops_ms_source"]
