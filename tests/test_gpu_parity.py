@@ -1594,6 +1594,43 @@ def test_dag_loss_fused_vs_reference_expression(d, l1):
     assert rel_err(got_g.cpu(), cond.A.grad.cpu()) < GTOL
 
 
+def test_dag_loss_of_a_frozen_gate_is_evaluated_once_per_state():
+    """post_process() froze A but the constraint is still on: the term has no gradient left, so loss() evaluates its matrix
+    power once per state of (A, dual buffers, exponent) and returns the same value until one of them changes"""
+    from gnf_hip import ops
+    from models import DAGConditioner
+    torch.manual_seed(2)
+    cond = DAGConditioner(56, [8], 2, l1=.2).to(DEV)
+    with torch.no_grad():
+        cond.A.mul_(.4)
+        cond.post_process(zero_threshold=.1)
+        cond.lambd.fill_(.3)
+    calls = []
+    real = ops.DagLossFn.apply
+    try:
+        ops.DagLossFn.apply = lambda *a: (calls.append(1), real(*a))[1]
+        v1 = cond.loss()
+        v2 = cond.loss()
+        assert len(calls) == 1 and v1 is v2 and not v1.requires_grad
+        lag = cond.get_power_trace()
+        ref = cond.dag_const * (cond.lambd * lag + cond.c / 2 * lag ** 2) + cond.l1_weight * cond.A.abs().mean()
+        assert rel_err(v1.cpu(), ref.cpu()) < TOL
+        with torch.no_grad():
+            cond.lambd.add_(1.)                    # in-place change of a dual buffer: new state
+        v3 = cond.loss()
+        assert len(calls) == 2
+        ref3 = cond.dag_const * (cond.lambd * lag + cond.c / 2 * lag ** 2) + cond.l1_weight * cond.A.abs().mean()
+        assert rel_err(v3.cpu(), ref3.cpu()) < TOL
+        cond.exponent += 50                        # what update_dual_param() does when the trace vanishes
+        cond.loss()
+        assert len(calls) == 3
+        cond.A.requires_grad = True                # re-opened: the term has a gradient again, nothing is cached
+        cond.loss(); cond.loss()
+        assert len(calls) == 5
+    finally:
+        ops.DagLossFn.apply = real
+
+
 def test_dag_loss_switched_off_after_dag_phase():
     """dag_const = l1_weight = 0 with a frozen A (what update_dual_param() leaves): loss() is exactly 0 without touching
     the matrix power, and comes back when the buffers change"""
