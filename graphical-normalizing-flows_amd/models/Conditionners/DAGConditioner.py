@@ -219,8 +219,9 @@ class DAGConditioner(Conditioner):
         if not self.A.requires_grad and self._constraints_off():
             return torch.zeros((), device=self.A.device)
         if self.A.is_cuda and self.hutchinson == 0:
-            if not self.A.requires_grad and not torch.cuda.is_current_stream_capturing():
-                # (a captured step keeps evaluating the term: a replay must see dual buffers rewritten after the capture)
+            if not self.A.requires_grad:
+                # (a captured step bakes the value in: GraphedStep's fingerprint carries the buffers' version counters, so a
+                # rewritten dual buffer means a new capture)
                 # A frozen gate (post_process()) with the constraint still switched on: the term is a CONSTANT of the step --
                 # no parameter receives a gradient from it -- so its d x d matrix power (6 library GEMMs + 3 launches, 0.11 ms
                 # of a 2.96 ms cfg4 step after the DAG phase) is evaluated once per state of (A, the dual buffers, exponent)

@@ -227,6 +227,46 @@ def test_graphed_step_vs_torch_adam_reference():
         assert rel_err(pb.detach().cpu(), pa.detach().cpu()) < 1e-5, k
 
 
+def test_graphed_frozen_gate_step_sees_a_rewritten_dual_buffer():
+    """a captured step of a flow whose DAG gate is frozen bakes the constraint term in as a constant (DAGConditioner.loss
+    evaluates it once per state); an in-place change of a dual buffer (what update_dual_param() does between epochs) must
+    lead to a new capture, not to a replay with the stale constant.  Reference: the same trajectory stepped eagerly."""
+    from gnf_hip import dp
+    from models import buildFCNormalizingFlow, DAGConditioner, AffineNormalizer
+
+    def make():
+        torch.manual_seed(17)
+        f = buildFCNormalizingFlow(1, DAGConditioner, {"in_size": 10, "hidden": [32, 32], "out_size": 2, "l1": .3},
+                                   AffineNormalizer, {}).to(DEV)
+        with torch.no_grad():
+            for c in f.getConditioners():
+                c.A.mul_(.5)
+                c.post_process(zero_threshold=.1)
+                c.lambd.fill_(.25)
+        return f
+    xs = [torch.randn(40, 10, generator=torch.Generator().manual_seed(300 + i)).to(DEV) for i in range(6)]
+
+    def run(graph):
+        f = make()
+        st = dp.FlatState(f)
+        out = []
+        for i, x in enumerate(xs):
+            if i == 3:
+                with torch.no_grad():
+                    for c in f.getConditioners():
+                        c.lambd.add_(2.)                 # in place: same buffer object, new version
+            out.append(dp.train_step(f, st, x, lr=1e-2, graph="auto" if graph else False).detach().clone())
+        torch.cuda.synchronize()
+        return out, [p.detach().clone() for p in f.parameters()]
+    lg, pg = run(True)
+    le, pe = run(False)
+    for a, b in zip(lg, le):
+        assert rel_err(a.cpu(), b.cpu()) < 1e-5, (lg, le)
+    assert abs(float(le[3] - le[2])) > 1e-3              # the change of lambd is visible in the loss at all
+    for a, b in zip(pg, pe):
+        assert rel_err(a.cpu(), b.cpu()) < 1e-5
+
+
 def test_graph_replay_after_eager_steps_keeps_the_adam_step_count():
     """train_step(graph='auto') interleaved with eager steps (graph=False): the eager ones advance state.t but not the
     device-side counter of the captured Adam launches; a later replay must see the right count (bias corrections).
