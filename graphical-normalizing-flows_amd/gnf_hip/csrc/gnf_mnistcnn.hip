@@ -68,7 +68,10 @@ __device__ __forceinline__ int dslot(int o) { return (o & 3) + 4 * (o >> 3) + 8 
 // each wavefront takes for the NEXT image inside interval Xb: the da1 groups are 2/2/2/1/1/1/1/1 over the wavefronts
 // (3/3/3/2 per SIMD), so SIMD 3 (wavefronts 3, 7) takes most of conv1.  (4/1/1/1/4 measured: SIMD 3 becomes the last
 // one, 2.906 -> 2.919 ms; a unit is ~1 000 cycles, the balance cannot get finer than that.)
-__device__ constexpr int C1U[8] = {0, 0, 0, 3, 2, 2, 1, 3};
+#ifndef GNF_BWD_C1U
+#define GNF_BWD_C1U {0, 0, 0, 3, 2, 2, 1, 3}
+#endif
+__device__ constexpr int C1U[8] = GNF_BWD_C1U;
 __device__ constexpr int C1PRO[8] = {2, 2, 2, 1, 1, 1, 1, 1};   // the first image: dealt evenly (nothing to overlap with)
 constexpr int c1sum(const int (&a)[8]) { int s = 0; for (int i = 0; i < 8; ++i) s += a[i]; return s; }
 constexpr int NU1 = (C1 * C1 + 63) / 64;

@@ -174,7 +174,13 @@ static_assert(WCH >= 25 * WROW + C1 && WCH % 64 == 32 && (2 * WROW - 22) % 32 ==
 // and of the two wavefronts of a SIMD one starts with its units (latency-bound), the other with its item (MFMA-bound).
 // Outputs leave through per-image buffer descriptors (one 32-bit lane offset, no 64-bit address arithmetic).
 // ---------------------------------------------------------------------------------------------
-__device__ constexpr int F1U[8] = {0, 0, 2, 2, 2, 2, 2, 1};          // conv1 units of the next image per wavefront
+#ifndef GNF_FWD_F1U
+#define GNF_FWD_F1U {0, 0, 3, 2, 1, 1, 2, 2}     // by barrier-wait timing (tools/time_cnn_phases.py): {0,0,2,2,2,2,2,1} left SIMD 0 (wavefronts 0 + 4: the split item, its finish and two units) 10 % behind the others: 1.331 -> 1.272 ms
+#endif
+#ifndef GNF_FWD_SPLIT_WAVE
+#define GNF_FWD_SPLIT_WAVE 0
+#endif
+__device__ constexpr int F1U[8] = GNF_FWD_F1U;                       // conv1 units of the next image per wavefront
 __device__ constexpr int F1PRO[8] = {2, 2, 2, 1, 1, 1, 1, 1};        // the first image: dealt evenly
 constexpr int fsum(const int (&v)[8]) { int t = 0; for (int i = 0; i < 8; ++i) t += v[i]; return t; }
 static_assert(fsum(F1U) == 11 && fsum(F1PRO) == 11, "conv1 units");
@@ -372,22 +378,41 @@ __global__ __launch_bounds__(64 * FWD_WAVES) void cnn_fwd_wino_k(CnnArgs a) {
 
   int par = 0;
   int64_t prev = -1;                                   // image whose split item waits in xch[par ^ 1]
+#ifdef GNF_CNN_TIMING      // measurement build (tools/time_cnn_phases.py): cycle counts per phase and wavefront
+  long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  long long tlast = __builtin_readcyclecounter();
+#define FSTAMP(k) do { const long long t__ = __builtin_readcyclecounter(); tacc[k] += t__ - tlast; tlast = t__; } while (0)
+#else
+#define FSTAMP(k)
+#endif
   for (int64_t img = img0; img < a.n; img += gs, par ^= 1) {
+    FSTAMP(5);
     __syncthreads();                                   // a1[par] complete; a1[par^1], e[par] free; the previous halves in xch
+    FSTAMP(0);
     const float* a1p = a1_s + par * A1SZ;
     float* a1n = a1_s + (par ^ 1) * A1SZ;
     const bool has_next = img + gs < a.n;
     stage(e_s + par * WESZ);                           // image i+2 (requested one interval ago)
     fetch(img + 3 * gs);
-    if (wave == 0 && prev >= 0) finish_split(xch + (par ^ 1) * 2 * 16 * 64, prev);
+    if (wave == GNF_FWD_SPLIT_WAVE && prev >= 0) finish_split(xch + (par ^ 1) * 2 * 16 * 64, prev);
+    FSTAMP(1);
     if (has_next && units_first) conv1_do(e_s + (par ^ 1) * WESZ, a1n, c1u0, F1U[wave]);
+    FSTAMP(2);
     whole_item(a1p, wave, img);
+    FSTAMP(3);
     if (wave < 2) half_item(a1p, wave, xch + par * 2 * 16 * 64);
+    FSTAMP(4);
     if (has_next && !units_first) conv1_do(e_s + (par ^ 1) * WESZ, a1n, c1u0, F1U[wave]);
+    FSTAMP(2);
     prev = img;
   }
   __syncthreads();                                     // the last image's halves
-  if (wave == 0 && prev >= 0) finish_split(xch + (par ^ 1) * 2 * 16 * 64, prev);
+  if (wave == GNF_FWD_SPLIT_WAVE && prev >= 0) finish_split(xch + (par ^ 1) * 2 * 16 * 64, prev);
+#ifdef GNF_CNN_TIMING
+  if (blockIdx.x == 7 && lane == 0)                    // (overwrites the head of image 0's output: measurement build only)
+    for (int k = 0; k < 8; ++k) a.pooled[wave * 8 + k] = (float)tacc[k];
+#endif
+#undef FSTAMP
 }
 
 constexpr size_t kFwdLds = (size_t)(ESZ + NCH * CH) * sizeof(float);

@@ -19,6 +19,14 @@ P = ctypes.c_void_p
 st = P(torch.cuda.current_stream().cuda_stream)
 lib.gnf_mnistcnn_conv_bwd_ws_bytes.restype = ctypes.c_int64
 rc = lib.gnf_mnistcnn_conv_fwd(P(e.data_ptr()), P(W1.data_ptr()), P(b1.data_ptr()), P(W2.data_ptr()), P(b2.data_ptr()), P(pooled.data_ptr()), P(arg.data_ptr()), ctypes.c_int64(n), ctypes.c_int(0), st)
+torch.cuda.synchronize()
+tf = pooled[0, :64].view(8, 8).cpu()
+fimgs = (n - 7 + 255) // 256
+fnames = ["barrier wait", "stage + fetch (+ split finish)", "conv1 units (next image)", "whole item", "half item", "loop"]
+print("forward (cnn_fwd_wino_k), images per WG", fimgs)
+for w in range(8):
+    print("wave", w, {fnames[k]: int(tf[w, k].item() / fimgs) for k in range(6)}, "total/img", int(tf[w, :6].sum().item() / fimgs))
+rc = lib.gnf_mnistcnn_conv_fwd(P(e.data_ptr()), P(W1.data_ptr()), P(b1.data_ptr()), P(W2.data_ptr()), P(b2.data_ptr()), P(pooled.data_ptr()), P(arg.data_ptr()), ctypes.c_int64(n), ctypes.c_int(0), st)
 nws = lib.gnf_mnistcnn_conv_bwd_ws_bytes(ctypes.c_int64(n))
 ws = torch.zeros(nws // 4, device=dev)
 gp = torch.randn(n, 2304, device=dev); ge = torch.empty(n, 784, device=dev)
