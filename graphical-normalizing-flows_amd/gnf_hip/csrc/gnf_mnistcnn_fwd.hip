@@ -374,7 +374,10 @@ __global__ __launch_bounds__(64 * FWD_WAVES) void cnn_fwd_wino_k(CnnArgs a) {
   int c1u0 = 0;
 #pragma unroll
   for (int w = 0; w < NW; ++w) c1u0 += w < wave ? F1U[w] : 0;
-  const bool units_first = wave >= 4;                  // one wavefront of every SIMD starts with conv1, the other with its item
+#ifndef GNF_FWD_UNITS_FIRST
+#define GNF_FWD_UNITS_FIRST (wave >= 4)
+#endif
+  const bool units_first = GNF_FWD_UNITS_FIRST;        // one wavefront of every SIMD starts with conv1, the other with its item
 
   int par = 0;
   int64_t prev = -1;                                   // image whose split item waits in xch[par ^ 1]
