@@ -476,17 +476,22 @@ __global__ __launch_bounds__(64 * WWAVES, 1) void gemm_wide_k(GemmArgs g) {
 // current slab, registers -> LDS (one ds_write_b128 per 16-B piece) behind them, two LDS stages, ONE workgroup barrier per
 // slab; fragments are ds_read_b128 (4 k per lane, chunk position XOR-swizzled by the row: conflict-free).  Wavefront
 // (wm, wn) of the 4 x 2 grid holds TMW x 4 accumulator tiles: every A fragment feeds 4 MFMAs, every B fragment TMW.
-// Main loop 87 % of the MFMA-bound cycle count; 0.382 ms = 121 TFLOP/s against 0.427 ms of gemm_vec_k<160,128> on a warm
+// Main loop 87 % of the MFMA-bound cycle count; 0.368 ms = 126 TFLOP/s against 0.427 ms of gemm_vec_k<160,128> on a warm
 // GPU (tools/tall_gemm.hip is the stand-alone form; the round-3 "no gain" was measured on a GPU that had not ramped its
 // clocks up: 10 launches right behind a 700 MB host copy).
 // ---------------------------------------------------------------------------------------------
-constexpr int TBK = 32, TBN = 128, TWAVES = 8;
-template <int TMW>
-constexpr size_t tall_lds() { return 2 * (size_t)(64 * TMW + TBN) * TBK * sizeof(float); }
+// WR = 4 (shipped): one 8-wavefront workgroup per CU with (64 TMW)-row blocks.  WR = 2 (GNF_GEMM_TALL=2): TWO 4-wavefront
+// workgroups per CU with (32 TMW)-row blocks -- their barriers are independent, so while one waits at its slab boundary the
+// other feeds the MFMA pipe: 0.381 -> 0.364 ms in the stand-alone form (tools/tall_gemm.hip -DWROWS=2), but once the loads
+// of this kernel were lean (below) the two forms measure the same here: 0.368 / 0.373 ms, 6.55-6.57 ms per step either way.
+constexpr int TBK = 32, TBN = 128;
+template <int TMW, int WR>
+constexpr size_t tall_lds() { return 2 * (size_t)(16 * WR * TMW + TBN) * TBK * sizeof(float); }
 
-template <int TMW>
-__global__ __launch_bounds__(64 * TWAVES, 1) void gemm_tall_k(GemmArgs g) {
-  constexpr int BM = 64 * TMW;                  // 4 wavefront rows x TMW tiles x 16
+template <int TMW, int WR>
+__global__ __launch_bounds__(128 * WR, 4 / WR) void gemm_tall_k(GemmArgs g) {
+  constexpr int BM = 16 * WR * TMW;             // WR wavefront rows x TMW tiles x 16
+  constexpr int NT = 128 * WR;                  // threads
   constexpr int SLAB = (BM + TBN) * TBK;        // floats per stage
   extern __shared__ __attribute__((aligned(16))) float tsm[];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -502,40 +507,44 @@ __global__ __launch_bounds__(64 * TWAVES, 1) void gemm_tall_k(GemmArgs g) {
     for (int a = 0; a < TMW; ++a)
 #pragma unroll
       for (int b = 0; b < 4; ++b) acc[a][b] = f32x4w{0.f, 0.f, 0.f, 0.f};
-    // this thread's 16-B pieces of a slab: piece p covers position P = p * 512 + tid -> row P / 8, chunk position P % 8,
-    // holding the row's logical chunk (P % 8) ^ ((row >> 1) & 7); rows past M / N repeat the last one (never stored)
-    constexpr int PIECES = (BM + TBN) * 8 / 512;
-    const float* src[PIECES];
+    // this thread's 16-B pieces of a slab: piece p covers position P = p * NT + tid -> row P / 8, chunk position P % 8,
+    // holding the row's logical chunk (P % 8) ^ ((row >> 1) & 7).  The first PA pieces are rows of A, the rest rows of B
+    // (BM * 8 is a multiple of NT).  One buffer descriptor per operand (A: per row block), a 32-bit lane offset that does
+    // not depend on the slab (its k offset rides in the scalar offset of the load): nothing is computed per slab, rows past
+    // M / N read as zeros.  (With 64-bit pointers per piece the two-workgroup form carried 22 v_lshl_add_u64 and 85 v_mov
+    // per slab and wavefront: 0.404 ms against 0.363 of the stand-alone form.)
+    constexpr int PIECES = (BM + TBN) * 8 / NT, PA = BM * 8 / NT;
+    static_assert((BM + TBN) * 8 % NT == 0 && BM * 8 % NT == 0, "whole pieces per thread, A and B pieces apart");
+    const int rows = (int)(M - m0 < BM ? M - m0 : BM);
+    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.A) + m0 * g.sam, 0,
+                                                                         (int)(((int64_t)(rows - 1) * g.sam + K) * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.B), 0,
+                                                                         (int)(((int64_t)(N - 1) * g.sbn + K) * 4), 0x00020000);
+    unsigned voff[PIECES];
 #pragma unroll
     for (int p = 0; p < PIECES; ++p) {
-      const int P = p * 512 + tid;
+      const int P = p * NT + tid;
       const int row = P >> 3, c = (P & 7) ^ ((row >> 1) & 7);
-      if (row < BM) {
-        int64_t gm = m0 + row;
-        if (gm >= M) gm = M - 1;
-        src[p] = g.A + gm * g.sam + 4 * c;
-      } else {
-        int gn = row - BM;
-        if (gn >= N) gn = N - 1;
-        src[p] = g.B + (int64_t)gn * g.sbn + 4 * c;
-      }
+      if (p < PA) voff[p] = row < rows ? (unsigned)(row * (int)g.sam + 4 * c) * 4u : 0xfffffff0u;
+      else voff[p] = row - BM < N ? (unsigned)((row - BM) * (int)g.sbn + 4 * c) * 4u : 0xfffffff0u;
     }
     f32x4w pre[PIECES];
-    auto fetch = [&](int64_t k0) {
+    auto fetch = [&](int k0) {
 #pragma unroll
-      for (int p = 0; p < PIECES; ++p) pre[p] = *reinterpret_cast<const f32x4w*>(src[p] + k0);
+      for (int p = 0; p < PIECES; ++p)
+        pre[p] = __builtin_bit_cast(f32x4w, __builtin_amdgcn_raw_buffer_load_b128(p < PA ? rsA : rsB, voff[p], k0 * 4, 0));
     };
     auto stash = [&](int stage) {
       float* base = tsm + stage * SLAB + tid * 4;
 #pragma unroll
-      for (int p = 0; p < PIECES; ++p) *reinterpret_cast<f32x4w*>(base + p * 2048) = pre[p];
+      for (int p = 0; p < PIECES; ++p) *reinterpret_cast<f32x4w*>(base + p * NT * 4) = pre[p];
     };
     fetch(0);
     stash(0);
     const int nslab = (int)(K / TBK);
     for (int s = 0; s < nslab; ++s) {
       __syncthreads();                             // slab s visible; everybody done reading the other stage
-      if (s + 1 < nslab) fetch((int64_t)(s + 1) * TBK);
+      if (s + 1 < nslab) fetch((s + 1) * TBK);
       const float* As = tsm + (s & 1) * SLAB;
       const float* Bs = As + BM * TBK;
 #pragma unroll
@@ -582,12 +591,13 @@ __global__ __launch_bounds__(64 * TWAVES, 1) void gemm_tall_k(GemmArgs g) {
 }
 
 // the tile height (TMW) that wastes the least of the chip on a tall M, 0 when every choice idles > 10 % of it
-static int tall_tmw(int64_t M) {
+static int tall_tmw(int64_t M, int wr) {
   int best = 0;
   double best_waste = .10;
+  const int64_t slots = 256 * (4 / wr);
   for (int tmw = 5; tmw >= 3; --tmw) {
-    const int64_t bm = 64 * tmw, tiles = (M + bm - 1) / bm, rounds = (tiles + 255) / 256;
-    const double waste = 1. - (double)M / (double)(rounds * 256 * bm);
+    const int64_t bm = 16 * wr * tmw, tiles = (M + bm - 1) / bm, rounds = (tiles + slots - 1) / slots;
+    const double waste = 1. - (double)M / (double)(rounds * slots * bm);
     if (waste < best_waste) { best_waste = waste; best = tmw; }
   }
   return best;
@@ -767,19 +777,24 @@ int gnf_gemm_launch(GemmArgs g, int splits, hipStream_t s) {
   // one of its block heights fills the chip
   if (vec && akf && bkf && bt == 128 && gy == 1 && nsp == 1 && !g.grp && !g.Bmask && !g.Cmask && !g.gate &&
       !(g.flags & ~GNF_GEMM_RELU) && g.N > 96 && g.K % TBK == 0 && g.K >= 8 * TBK && g.sam % 4 == 0 && g.sbn % 4 == 0 &&
-      (((uintptr_t)g.A | (uintptr_t)g.B) & 15) == 0) {
-    static const bool no_tall = getenv("GNF_GEMM_TALL") && getenv("GNF_GEMM_TALL")[0] == '0';      // A/B switch
-    const int tmw = no_tall ? 0 : tall_tmw(g.M);
+      (((uintptr_t)g.A | (uintptr_t)g.B) & 15) == 0 && 320 * g.sam + g.K < (1 << 28) && 128 * g.sbn + g.K < (1 << 28)) {
+    static const char tall_mode = getenv("GNF_GEMM_TALL") ? getenv("GNF_GEMM_TALL")[0] : '4';      // A/B: 0 off, 2 two 4-wave groups
+    const int wr = tall_mode == '2' ? 2 : 4;
+    const int tmw = tall_mode == '0' ? 0 : tall_tmw(g.M, wr);
     if (tmw) {
-      const int64_t tiles = (g.M + 64 * tmw - 1) / (64 * tmw);
-      const unsigned tgrid = (unsigned)(tiles < 256 ? tiles : 256);
-#define GNF_TALL_LAUNCH(T)                                                                                        \
+      const int64_t bm = 16 * wr * tmw, tiles = (g.M + bm - 1) / bm, slots = 256 * (4 / wr);
+      const unsigned tgrid = (unsigned)(tiles < slots ? tiles : slots);
+#define GNF_TALL_LAUNCH(T, W)                                                                                     \
   do {                                                                                                            \
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tall_k<T>),                                      \
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)tall_lds<T>());                     \
-    hipLaunchKernelGGL(gemm_tall_k<T>, dim3(tgrid), dim3(64 * TWAVES), tall_lds<T>(), s, g);                       \
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tall_k<T, W>),                                   \
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)tall_lds<T, W>());                  \
+    hipLaunchKernelGGL((gemm_tall_k<T, W>), dim3(tgrid), dim3(128 * W), (tall_lds<T, W>()), s, g);                 \
   } while (0)
-      if (tmw == 5) GNF_TALL_LAUNCH(5); else if (tmw == 4) GNF_TALL_LAUNCH(4); else GNF_TALL_LAUNCH(3);
+      if (wr == 2) {
+        if (tmw == 5) GNF_TALL_LAUNCH(5, 2); else if (tmw == 4) GNF_TALL_LAUNCH(4, 2); else GNF_TALL_LAUNCH(3, 2);
+      } else {
+        if (tmw == 5) GNF_TALL_LAUNCH(5, 4); else if (tmw == 4) GNF_TALL_LAUNCH(4, 4); else GNF_TALL_LAUNCH(3, 4);
+      }
 #undef GNF_TALL_LAUNCH
       GNF_LAUNCH_CHECK();
       return 0;

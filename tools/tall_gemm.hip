@@ -9,7 +9,10 @@
 #include <cmath>
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int BK = 32, BN = 128, WAVES = 8;
+#ifndef WROWS
+#define WROWS 4
+#endif
+constexpr int BK = 32, BN = 128, WAVES = 2 * WROWS;     // WROWS = 2: 160-row blocks, 4 wavefronts, TWO workgroups per CU
 
 __device__ __forceinline__ void glds16(const float* g, float* l) {
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
@@ -18,10 +21,10 @@ __device__ __forceinline__ void glds16(const float* g, float* l) {
 
 // LDS slab: rows of 32 floats = 8 chunks of 16 B; chunk c of row r sits at chunk position c ^ ((r >> 1) & 7)
 template <int TMW>
-__global__ __launch_bounds__(64 * WAVES, 1) void tall_gemm_k(const float* __restrict__ A, const float* __restrict__ B,
+__global__ __launch_bounds__(64 * WAVES, 8 / WAVES) void tall_gemm_k(const float* __restrict__ A, const float* __restrict__ B,
                                                             const float* __restrict__ bias, float* __restrict__ C,
                                                             long long M, int N, int K, int relu, long long* cyc) {
-  constexpr int BM = 64 * TMW;                  // 4 wave-rows x TMW tiles x 16
+  constexpr int BM = 16 * WROWS * TMW;          // WROWS wave-rows x TMW tiles x 16
   constexpr int SLAB = (BM + BN) * BK;          // floats per stage
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -39,11 +42,12 @@ __global__ __launch_bounds__(64 * WAVES, 1) void tall_gemm_k(const float* __rest
     // position P % 8, holding logical chunk (P % 8) ^ ((row >> 1) & 7).  Global -> registers while the MFMAs of the
     // current slab run, registers -> LDS (one ds_write_b128 per piece) behind them.  (global_load_lds costs 60-185 issue
     // cycles per 1 KB piece next to MFMAs -- 7 per wavefront and slab were 17 % of the loop.)
-    constexpr int PIECES = (BM + BN) * 8 / 512;
+    constexpr int NT_ = 64 * WAVES;
+    constexpr int PIECES = (BM + BN) * 8 / NT_;
     const float* src[PIECES];
 #pragma unroll
     for (int p = 0; p < PIECES; ++p) {
-      const int P = p * 512 + tid;
+      const int P = p * NT_ + tid;
       const int row = P >> 3, c = (P & 7) ^ ((row >> 1) & 7);
       if (row < BM) {
         long long gm = m0 + row; if (gm >= M) gm = M - 1;
@@ -61,7 +65,7 @@ __global__ __launch_bounds__(64 * WAVES, 1) void tall_gemm_k(const float* __rest
     auto stash = [&](int stage) {
       float* base = smem + stage * SLAB + tid * 4;
 #pragma unroll
-      for (int p = 0; p < PIECES; ++p) *reinterpret_cast<f32x4*>(base + p * 2048) = pre[p];
+      for (int p = 0; p < PIECES; ++p) *reinterpret_cast<f32x4*>(base + p * NT_ * 4) = pre[p];
     };
     fetch(0);
     stash(0);
@@ -166,10 +170,10 @@ int main(int argc, char** argv) {
   (void)hipMemcpy(b, hb.data(), N * 4, hipMemcpyHostToDevice);
   long long* cyc; (void)hipMalloc(&cyc, 64);
   constexpr int TMW = 5;
-  const size_t lds = 2 * (size_t)(64 * TMW + BN) * BK * 4;
+  const size_t lds = 2 * (size_t)(16 * WROWS * TMW + BN) * BK * 4;
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&tall_gemm_k<TMW>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  const long long ntiles = (M + 64 * TMW - 1) / (64 * TMW);
-  const unsigned grid = ntiles < 256 ? (unsigned)ntiles : 256;
+  const long long ntiles = (M + 16 * WROWS * TMW - 1) / (16 * WROWS * TMW);
+  const unsigned grid = ntiles < 256 * (8 / WAVES) ? (unsigned)ntiles : 256 * (8 / WAVES);
   hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
   for (int r = 0; r < 300; ++r) hipLaunchKernelGGL(tall_gemm_k<TMW>, dim3(grid), dim3(64 * WAVES), lds, 0, A, B, b, C, M, N, K, 1, cyc);
   (void)hipEventRecord(e0, 0);
