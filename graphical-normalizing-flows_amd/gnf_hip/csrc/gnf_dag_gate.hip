@@ -61,7 +61,8 @@ __global__ void dag_gate_tab_k(const float* __restrict__ A, float* __restrict__ 
 //       four columns: the counter is the column QUAD (row * ceil(d/4) + jq).
 //   gate_mode 2 (noise gate): one standard normal per column; Philox: both Box-Muller outputs of each uniform pair.
 // Forward and backward use the same mapping, so the backward regenerates the forward's noise.
-struct Draw4 { float v[4]; };
+// gate_mode 1: the ratio is handed on as numerator v / denominator w (the gate then needs ONE division, see gumbel_gate)
+struct Draw4 { float v[4]; float w[4]; };
 
 // 23-bit uniform centred in its cell: never exactly 0 or 1.  (With 24 bits the + .5f is a rounding tie for words >= 2^23 and
 // rounds to even: 16777215.5 -> 16777216, i.e. V = 1.0f about four times per cfg4 step and V / (1 - V) = inf in the
@@ -74,7 +75,7 @@ __device__ __forceinline__ Draw4 draw4(int gate_mode, const float* u1, const flo
                                        int64_t row, int64_t jq, int64_t d) {
   Draw4 n;
 #pragma unroll
-  for (int h = 0; h < 4; ++h) n.v[h] = 0.f;
+  for (int h = 0; h < 4; ++h) { n.v[h] = 0.f; n.w[h] = 1.f; }
   if (gate_mode == 0) return n;
   const int64_t j0 = 4 * jq;
   if (u1) {
@@ -82,7 +83,8 @@ __device__ __forceinline__ Draw4 draw4(int gate_mode, const float* u1, const flo
     for (int h = 0; h < 4; ++h)
       if (j0 + h < d) {
         const float a = u1[row * d + j0 + h];
-        n.v[h] = gate_mode == 1 ? log2f(a) / log2f(u2[row * d + j0 + h]) : a;      // ln u1 / ln u2 = exp(g2 - g1)
+        if (gate_mode == 1) { n.v[h] = log2f(a); n.w[h] = log2f(u2[row * d + j0 + h]); }      // ln u1 / ln u2 = exp(g2 - g1)
+        else n.v[h] = a;
       }
     return n;
   }
@@ -94,7 +96,8 @@ __device__ __forceinline__ Draw4 draw4(int gate_mode, const float* u1, const flo
 #pragma unroll
     for (int h = 0; h < 4; ++h) {
       const float V = u01_open(r[h]);
-      n.v[h] = V / (1.f - V);
+      n.v[h] = V;
+      n.w[h] = 1.f - V;
     }
   } else {
 #pragma unroll
@@ -121,9 +124,15 @@ __device__ __forceinline__ bool quad_aligned(const float* base, int64_t ld) {
   return ((ld | (int64_t)(reinterpret_cast<uintptr_t>(base) >> 2)) & 3) == 0;
 }
 
-// Gumbel-softmax gate z1/(z1+z2) = 1/(1 + ET * v^(1/T)) from the table entry ET and the ratio v
-__device__ __forceinline__ float gumbel_gate(float ET, float v, float T) {
-  const float vT = T == 1.f ? v : (T == .5f ? v * v : exp2f(log2f(v) / T));
+// Gumbel-softmax gate z1/(z1+z2) = 1/(1 + ET * v^(1/T)) from the table entry ET and the ratio v = num / den.  For the two
+// temperatures the drivers use the ratio is never formed: 1/(1 + ET num/den) = den / (den + ET num) -- ONE IEEE division per
+// gate instead of two (a division is ~10 VALU instructions, the two of them cost as much as the gate's share of the Philox
+// call: 0.094 -> 0.08 ms forward, 0.111 -> 0.09 ms backward at cfg4).  num, den have the same sign (both logs <= 0, or V and
+// 1 - V in (0, 1)); num = 0 -> 1, den = 0 -> 0, as the two-division form.
+__device__ __forceinline__ float gumbel_gate(float ET, float num, float den, float T) {
+  if (T == 1.f) return den / fmaf(ET, num, den);
+  if (T == .5f) { const float n2 = num * num, d2 = den * den; return d2 / fmaf(ET, n2, d2); }
+  const float vT = exp2f(log2f(num / den) / T);
   return 1.f / (1.f + ET * vT);                       // u1 -> 0: gate 0;  u2 -> 0: gate 1 (as the reference)
 }
 
@@ -157,7 +166,7 @@ __global__ void dag_gate_fwd_k(GateArgs a) {
     for (int h = 0; h < 4; ++h) {
       const float p = p4[h], xv = x4[h];
       if (a.gate_mode == 0) out[h] = xv * p;
-      else out[h] = a.gate_mode == 1 ? xv * gumbel_gate(et4[h], n.v[h], a.T) : p * (xv + n.v[h] * fabsf(1.f - p));
+      else out[h] = a.gate_mode == 1 ? xv * gumbel_gate(et4[h], n.v[h], n.w[h], a.T) : p * (xv + n.v[h] * fabsf(1.f - p));
     }
     float* erow = a.e + bi * a.ld_e + j0;
     if (nv == 4 && ve) {
@@ -204,7 +213,7 @@ __global__ void dag_gate_bwd_dp_k(GateArgs a) {
       if (a.gate_mode == 0) {
         acc[h] = fmaf(g, xv, acc[h]);
       } else if (a.gate_mode == 1) {
-        const float s = gumbel_gate(ET[h], n.v[h], a.T);
+        const float s = gumbel_gate(ET[h], n.v[h], n.w[h], a.T);
         acc[h] = fmaf(g * xv, s * (1.f - s) * Q[h], acc[h]);
       } else {
         const float om = 1.f - p[h];
@@ -263,7 +272,7 @@ __global__ void dag_gate_bwd_dx_k(GateArgs a) {
 #pragma unroll
       for (int h = 0; h < 4; ++h) {
         if (h >= nv) break;
-        const float gate = a.gate_mode == 1 ? gumbel_gate(t4[h], nz.v[h], a.T) : t4[h];
+        const float gate = a.gate_mode == 1 ? gumbel_gate(t4[h], nz.v[h], nz.w[h], a.T) : t4[h];
         acc[h] = fmaf(g4[h], gate, acc[h]);
       }
     }
