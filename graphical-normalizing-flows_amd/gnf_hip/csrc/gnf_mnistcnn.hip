@@ -67,7 +67,8 @@ __device__ __forceinline__ int dslot(int o) { return (o & 3) + 4 * (o >> 3) + 8 
 // conv1 is recomputed in UNITS of 64 consecutive positions of the flat 26 x 26 grid (11 per image, see conv1_units).  Units
 // each wavefront takes for the NEXT image inside interval Xb: the da1 groups are 2/2/2/1/1/1/1/1 over the wavefronts
 // (3/3/3/2 per SIMD), so SIMD 3 (wavefronts 3, 7) takes most of conv1.  (4/1/1/1/4 measured: SIMD 3 becomes the last
-// one, 2.906 -> 2.919 ms; a unit is ~1 000 cycles, the balance cannot get finer than that.)
+// one, 2.906 -> 2.919 ms; a unit is ~1 000 cycles, the balance cannot get finer than that.  Round 4, with the barrier
+// waits per wavefront in hand: eleven other deals incl. 4-unit wavefronts, -DGNF_BWD_C1U=..., all within +-0.3 % of this one.)
 #ifndef GNF_BWD_C1U
 #define GNF_BWD_C1U {0, 0, 0, 3, 2, 2, 1, 3}
 #endif
@@ -79,7 +80,10 @@ static_assert(c1sum(C1U) == NU1 && c1sum(C1PRO) == NU1, "conv1 units");
 
 __device__ __forceinline__ void conv1_run(const float* e_rd, float* a1_wr, int u0, int nu, const float* w1a,
                                           const f32x4& b1v, int q, int j, int lane) {
-  if (nu == 3) conv1_units<3, CHB>(e_rd, a1_wr, u0, w1a, b1v, q, j, lane);          // nu is wave-uniform
+  if (nu == 4) {                                                                     // (two calls: 4 units at once spill)
+    conv1_units<2, CHB>(e_rd, a1_wr, u0, w1a, b1v, q, j, lane);
+    conv1_units<2, CHB>(e_rd, a1_wr, u0 + 2, w1a, b1v, q, j, lane);
+  } else if (nu == 3) conv1_units<3, CHB>(e_rd, a1_wr, u0, w1a, b1v, q, j, lane);   // nu is wave-uniform
   else if (nu == 2) conv1_units<2, CHB>(e_rd, a1_wr, u0, w1a, b1v, q, j, lane);
   else if (nu == 1) conv1_units<1, CHB>(e_rd, a1_wr, u0, w1a, b1v, q, j, lane);
 }
