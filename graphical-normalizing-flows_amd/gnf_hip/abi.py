@@ -20,7 +20,8 @@ c_u64 = ctypes.c_uint64
 c_stream = ctypes.c_void_p
 
 MONO_MAX_LAYERS = 8
-ABI_VERSION = 4           # GNF_ABI_VERSION of include/gnf_hip.h this binding was written against
+DAG_PLAN_KC = 32          # GNF_DAG_PLAN_KC
+ABI_VERSION = 5           # GNF_ABI_VERSION of include/gnf_hip.h this binding was written against
 
 
 class MonoNet(ctypes.Structure):
@@ -62,6 +63,12 @@ SIGNATURES = {
     "gnf_dag_gate_bwd_ws_bytes": (c_i64, [c_i64, c_i64]),
     "gnf_dag_gate_bwd": (c_int, [c_f, c_f, c_f, c_i64, c_int, c_int, c_float, c_float, c_f, c_f, c_u64, c_u64, c_f, c_f,
                                  c_f, c_f, c_i64, c_i64, c_stream]),
+    "gnf_dag_gate_plan_bytes": (c_i64, [c_i64]),
+    "gnf_dag_gate_fwd_plan": (c_int, [c_f, c_f, c_f, c_i64, c_int, c_int, c_float, c_float, c_f, c_f, c_u64, c_u64, c_int,
+                                      c_f, ctypes.c_void_p, c_i64, c_i64, c_i64, c_stream]),
+    "gnf_dag_gate_bwd_cols_ws_bytes": (c_i64, [c_i64, c_i64]),
+    "gnf_dag_gate_bwd_cols": (c_int, [c_f, c_f, c_f, ctypes.c_void_p, c_int, c_int, c_float, c_f, c_f, c_u64, c_u64, c_f,
+                                      c_f, c_f, c_i64, c_i64, c_stream]),
     "gnf_monotonic_pack_floats": (c_i64, [ctypes.POINTER(MonoNet)]),
     "gnf_monotonic_pack": (c_int, [ctypes.POINTER(MonoNet), c_f, c_stream]),
     "gnf_monotonic_fwd": (c_int, [c_f, ctypes.POINTER(MonoNet), c_f, c_f, c_i64, c_i64, c_i64, c_f, c_f, c_int, c_f,
@@ -79,6 +86,8 @@ SIGNATURES = {
     "gnf_mnistcnn_conv_bwd_ws_bytes": (c_i64, [c_i64]),
     "gnf_mnistcnn_conv_bwd": (c_int, [c_f, c_f, c_f, c_f, c_f, ctypes.c_void_p, c_f, c_f, c_f, c_f, c_f,
                                       ctypes.c_void_p, c_i64, c_i64, c_stream]),
+    "gnf_mnistcnn_conv_bwd_cols": (c_int, [c_f, c_f, c_f, c_f, c_f, ctypes.c_void_p, c_f, ctypes.c_void_p, c_i64, c_f,
+                                           c_f, c_f, c_f, c_f, ctypes.c_void_p, c_i64, c_i64, c_stream]),
     "gnf_mnistcnn_sparse_ws_bytes": (c_i64, [c_i64, c_i64]),
     "gnf_mnistcnn_sparse_fwd": (c_int, [c_f, c_i64, c_f, ctypes.c_void_p, c_i64, ctypes.c_void_p, c_i64, c_f, c_f, c_f,
                                         c_f, c_f, c_f, c_i64, c_f, c_f, ctypes.c_void_p, ctypes.c_void_p, c_i64,

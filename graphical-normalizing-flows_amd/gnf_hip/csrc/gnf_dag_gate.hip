@@ -52,6 +52,59 @@ __global__ void dag_gate_tab_k(const float* __restrict__ A, float* __restrict__ 
   tab[3 * dd + ij] = (1.f / pa + 1.f / pb) / T;
 }
 
+// Column plan of the backward (round 5): dL/dA[i,j] = dP/dA[i,j] * sum_b ..., so wherever dP/dA is exactly zero -- every entry
+// of A that is zero under the soft / hard thresholds: 97.2 % of the MNIST prior (NormalizingFlowFactories.py:35-46) -- the
+// cotangent of e[b,i,j] is multiplied by an exact 0 and never needed (as long as x wants no gradient).  One wavefront per
+// row i compacts the columns with dP/dA != 0 in ascending order:
+//   plan[i] = their number (also when it exceeds KC),   cols[i][k] (int16, behind the d counts) = the k-th such column.
+// A consumer uses the lists only if NO row holds more than KC columns (plan_overflows) and runs its dense path otherwise:
+// the decision is taken on the device from the same table the forward used -- nothing is cached on the host.
+constexpr int KC = GNF_DAG_PLAN_KC;
+// the table of dag_gate_tab_k AND the plan in one launch: one workgroup per row i
+__global__ __launch_bounds__(kBlock) void dag_gate_tab_plan_k(const float* __restrict__ A, float* __restrict__ tab,
+                                                              int imp_mode, float h_thresh, float T, int64_t d,
+                                                              int32_t* __restrict__ plan) {
+  __shared__ int wcnt[kBlock / 64];
+  const int64_t i = blockIdx.x, dd = d * d;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  int16_t* cols = reinterpret_cast<int16_t*>(plan + d) + i * KC;
+  int n = 0;                                               // columns found so far (the same in every thread)
+  for (int64_t j0 = 0; j0 < d; j0 += kBlock) {
+    const int64_t j = j0 + tid, ij = i * d + j;
+    bool on = false;
+    if (j < d) {
+      float dpda;
+      const float p = importance(A[ij], imp_mode, h_thresh, &dpda);
+      const float eps = 1e-6f;
+      const float pa = p + eps, pb = 1.f - p + eps;
+      tab[ij] = p;
+      tab[dd + ij] = dpda;
+      tab[2 * dd + ij] = expf((logf(pb) - logf(pa)) / T);
+      tab[3 * dd + ij] = (1.f / pa + 1.f / pb) / T;
+      on = dpda != 0.f;
+    }
+    const uint64_t m = __ballot(on);
+    if (lane == 0) wcnt[w] = __popcll(m);
+    __syncthreads();
+    int base = n, tot = n;
+#pragma unroll
+    for (int ww = 0; ww < kBlock / 64; ++ww) { base += ww < w ? wcnt[ww] : 0; tot += wcnt[ww]; }
+    const int k = base + __popcll(m & ((1ull << lane) - 1ull));
+    if (on && k < KC) cols[k] = (int16_t)j;
+    n = tot;
+    __syncthreads();
+  }
+  if (tid >= n && tid < KC) cols[tid] = (int16_t)-1;
+  if (tid == 0) plan[i] = n;
+}
+
+// true when a row of the plan holds more than KC columns: every thread of the workgroup gets the same answer
+__device__ __forceinline__ bool plan_overflows(const int32_t* __restrict__ plan, int64_t d) {
+  int over = 0;
+  for (int64_t t = threadIdx.x; t < d; t += blockDim.x) over |= plan[t] > KC;
+  return __syncthreads_or(over) != 0;
+}
+
 // Noise of the FOUR adjacent columns 4 jq .. 4 jq + 3 of row (b*d + i), one value per column:
 //   gate_mode 1 (Gumbel-softmax): v = exp(g2 - g1) = E1 / E2, the ratio of two independent Exp(1) variates.
 //     * injected uniforms (parity tests, the reference's draw order u1 then u2):  v = ln u1 / ln u2;
@@ -140,6 +193,7 @@ struct GateArgs {
   const float* x; const float* tab; float* e; const float* ge; int64_t ld_e;
   int gate_mode; float T; const float* u1; const float* u2; uint64_t seed, offset; int hot;
   float* ws; float* gA; float* gx; int64_t B, d, chunk;
+  const int32_t* plan; const float* gec; float* part_sp; int64_t chunk_sp; int* flag;
 };
 
 // One thread per (i, column quad), looping over the samples of its chunk (blockIdx.y): the table entries of the quad are
@@ -184,10 +238,11 @@ __global__ void dag_gate_fwd_k(GateArgs a) {
   }
 }
 
-// dL/dp partial sums over a chunk of b:  ws[chunk][i*d+j] = sum_b ge[b,i,j] * de/dp[b,i,j];  one thread per (i, column quad)
-__global__ void dag_gate_bwd_dp_k(GateArgs a) {
+// dL/dp partial sums over a chunk of b:  ws[chunk][i*d+j] = sum_b ge[b,i,j] * de/dp[b,i,j];  one thread per (i, column quad);
+// (bx, by) = the workgroup's position in the (column-quad blocks, sample chunks) grid
+__device__ __forceinline__ void dp_dense_unit(const GateArgs& a, int64_t bx, int64_t by) {
   const int64_t d = a.d, dd = d * d, dq = (d + 3) / 4;
-  const int64_t ip = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t ip = bx * blockDim.x + threadIdx.x;
   if (ip >= d * dq) return;
   const int64_t i = ip / dq, jq = ip - i * dq, j0 = 4 * jq;
   const int nv = d - j0 < 4 ? (int)(d - j0) : 4;
@@ -197,7 +252,7 @@ __global__ void dag_gate_bwd_dp_k(GateArgs a) {
     const int64_t ij = i * d + j0 + (h < nv ? h : 0);
     p[h] = a.tab[ij]; ET[h] = a.tab[2 * dd + ij]; Q[h] = a.tab[3 * dd + ij];
   }
-  const int64_t b0 = (int64_t)blockIdx.y * a.chunk;
+  const int64_t b0 = by * a.chunk;
   const int64_t b1 = b0 + a.chunk < a.B ? b0 + a.chunk : a.B;
   const bool vg = quad_aligned(a.ge, a.ld_e), vx = quad_aligned(a.x, d);
   for (int64_t b = b0; b < b1; ++b) {
@@ -224,7 +279,59 @@ __global__ void dag_gate_bwd_dp_k(GateArgs a) {
   }
 #pragma unroll
   for (int h = 0; h < 4; ++h)
-    if (h < nv) a.ws[(int64_t)blockIdx.y * dd + i * d + j0 + h] = acc[h];
+    if (h < nv) a.ws[by * dd + i * d + j0 + h] = acc[h];
+}
+
+__global__ void dag_gate_bwd_dp_k(GateArgs a) { dp_dense_unit(a, blockIdx.x, blockIdx.y); }
+
+// The same sums from the COMPACT cotangent gec[(b*d+i)][k] = dL/de[b,i,cols[i][k]] that the conv backward of the fused
+// masked-image front leaves (gnf_mnistcnn_conv_bwd_cols): one thread per (i, slot k < plan[i]) and chunk of samples,
+//   part_sp[chunk][i*KC + k] = sum_b gec[b,i,k] * de/dp[b,i,j],  j = cols[i][k]
+// -- 17 172 (i,j) pairs instead of 614 656 at the MNIST prior.  The noise of (b,i,j) is element j & 3 of the Philox call
+// of its column quad, exactly as the forward drew it.  1-D grid of gx_sp * nc_sp workgroups; if a row of the plan
+// overflows, the same workgroups walk the units of the dense kernel over ge instead (the conv backward took the same
+// decision and wrote the dense ge).  flag <- which of the two happened, for dag_gate_bwd_dA_plan_k.
+__global__ void dag_gate_bwd_dp_plan_k(GateArgs a, unsigned gx_dense, unsigned ny_dense, unsigned gx_sp) {
+  const bool over = plan_overflows(a.plan, a.d);
+  if (blockIdx.x == 0 && threadIdx.x == 0) *a.flag = over ? 1 : 0;
+  if (over) {
+    for (unsigned u = blockIdx.x; u < gx_dense * ny_dense; u += gridDim.x) dp_dense_unit(a, u % gx_dense, u / gx_dense);
+    return;
+  }
+  const int64_t d = a.d, dd = d * d;
+  const int64_t bx = blockIdx.x % gx_sp, by = blockIdx.x / gx_sp;
+  const int64_t it = bx * blockDim.x + threadIdx.x;
+  if (it >= d * KC) return;
+  const int64_t i = it / KC;
+  const int k = (int)(it - i * KC);
+  if (k >= a.plan[i]) return;
+  const int64_t j = reinterpret_cast<const int16_t*>(a.plan + d)[it];
+  const int64_t ij = i * d + j, jq = j >> 2;
+  const int h = (int)(j & 3);
+  const float p = a.tab[ij], ET = a.tab[2 * dd + ij], Q = a.tab[3 * dd + ij];
+  const int64_t b0 = by * a.chunk_sp;
+  const int64_t b1 = b0 + a.chunk_sp < a.B ? b0 + a.chunk_sp : a.B;
+  float acc = 0.f;
+  for (int64_t b = b0; b < b1; ++b) {
+    const Draw4 n = draw4(a.gate_mode, a.u1, a.u2, a.seed, a.offset, b * d + i, jq, d);
+    const float g = a.gec[(b * d + i) * KC + k];
+    const float xv = a.x[b * d + j];
+    float nv = n.v[0], nw = n.w[0];                            // element h of the quad (h is not a compile-time index)
+    nv = h == 1 ? n.v[1] : nv; nw = h == 1 ? n.w[1] : nw;
+    nv = h == 2 ? n.v[2] : nv; nw = h == 2 ? n.w[2] : nw;
+    nv = h == 3 ? n.v[3] : nv; nw = h == 3 ? n.w[3] : nw;
+    if (a.gate_mode == 0) {
+      acc = fmaf(g, xv, acc);
+    } else if (a.gate_mode == 1) {
+      const float s = gumbel_gate(ET, nv, nw, a.T);
+      acc = fmaf(g * xv, s * (1.f - s) * Q, acc);
+    } else {
+      const float om = 1.f - p;
+      const float sgn = om > 0.f ? 1.f : (om < 0.f ? -1.f : 0.f);
+      acc = fmaf(g, xv + nv * fabsf(om) - p * nv * sgn, acc);
+    }
+  }
+  a.part_sp[by * d * KC + it] = acc;
 }
 
 // gA = (sum over the nc batch chunks, in chunk order: deterministic) * dP/dA.  The chunks are few (<= 16) and long (d*d):
@@ -248,6 +355,36 @@ __global__ void dag_gate_bwd_dA_k(const float* __restrict__ tab, const float* __
     float s = part[ij];
     for (int c = 1; c < nc; ++c) s += part[(int64_t)c * dd + ij];
     gA[ij] = s * tab[dd + ij];
+  }
+}
+
+// gA for the plan variant: the dense sums (flag set: a row of the plan overflowed) or, per entry with dP/dA != 0, the sums of
+// its slot in the compact partials; entries with dP/dA == 0 get the exact 0 the dense product would give them
+__global__ void dag_gate_bwd_dA_plan_k(const float* __restrict__ tab, const float* __restrict__ part, int nc,
+                                       const float* __restrict__ part_sp, int nc_sp, const int32_t* __restrict__ plan,
+                                       const int* __restrict__ flag, float* __restrict__ gA, int64_t d) {
+  const int64_t dd = d * d;
+  const int64_t i4 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+  if (i4 >= dd) return;
+  const bool dense = *flag != 0;
+  const int16_t* cols = reinterpret_cast<const int16_t*>(plan + d);
+  for (int64_t ij = i4; ij < dd && ij < i4 + 4; ++ij) {
+    const float dp = tab[dd + ij];
+    float s = 0.f;
+    if (dense) {
+      s = part[ij];
+      for (int c = 1; c < nc; ++c) s += part[(int64_t)c * dd + ij];
+    } else if (dp != 0.f) {
+      const int64_t i = ij / d, j = ij - i * d;
+      const int n = plan[i] < KC ? plan[i] : KC;
+      int k = -1;
+      for (int t = 0; t < n; ++t) k = cols[i * KC + t] == (int16_t)j ? t : k;
+      if (k >= 0) {
+        s = part_sp[i * KC + k];
+        for (int c = 1; c < nc_sp; ++c) s += part_sp[(int64_t)c * d * KC + i * KC + k];
+      }
+    }
+    gA[ij] = s * dp;
   }
 }
 
@@ -432,15 +569,32 @@ int64_t gnf_dag_gate_fwd_ws_bytes(int64_t d) { return 4 * d * d * (int64_t)sizeo
 int gnf_dag_gate_fwd(const float* x, const float* A, float* e, int64_t ld_e, int imp_mode, int gate_mode,
                      float h_thresh, float temperature, const float* u1, const float* u2, uint64_t seed,
                      uint64_t offset, int hot, float* ws, int64_t B, int64_t d, gnf_stream_t stream) {
+  return gnf_dag_gate_fwd_plan(x, A, e, ld_e, imp_mode, gate_mode, h_thresh, temperature, u1, u2, seed, offset, hot, ws,
+                               nullptr, 0, B, d, stream);
+}
+
+int gnf_dag_gate_fwd_plan(const float* x, const float* A, float* e, int64_t ld_e, int imp_mode, int gate_mode,
+                          float h_thresh, float temperature, const float* u1, const float* u2, uint64_t seed,
+                          uint64_t offset, int hot, float* ws, int32_t* plan, int64_t plan_bytes, int64_t B, int64_t d,
+                          gnf_stream_t stream) {
   if (((!x || !e) && B > 0) || !A || !ws || B < 0 || d <= 0 || imp_mode < 0 || imp_mode > 3 || gate_mode < 0 ||
       gate_mode > 2)
     return GNF_EINVAL;                // batch-sized arrays may be NULL for an empty batch
   if (ld_e < (hot ? 2 * d : d)) return GNF_EINVAL;
   if (gate_mode == 1 && u1 && !u2) return GNF_EINVAL;
   if (imp_mode == 0) gate_mode = 0;   // DAG:151-153: raw A, no gate
+  if (plan && d > 32767) return GNF_ESHAPE;               // 16-bit column indices
+  if (plan && plan_bytes < gnf_dag_gate_plan_bytes(d)) return GNF_EWS;
   if (B == 0) return 0;
   hipStream_t s = (hipStream_t)stream;
-  int rc = launch_tab(A, ws, imp_mode, h_thresh, temperature, d, s);
+  int rc = 0;
+  if (plan) {
+    hipLaunchKernelGGL(dag_gate_tab_plan_k, dim3((unsigned)d), dim3(kBlock), 0, s, A, ws, imp_mode, h_thresh, temperature,
+                       d, plan);
+    GNF_LAUNCH_CHECK();
+  } else {
+    rc = launch_tab(A, ws, imp_mode, h_thresh, temperature, d, s);
+  }
   if (rc) return rc;
   GateArgs a{};
   a.x = x; a.tab = ws; a.e = e; a.ld_e = ld_e; a.gate_mode = gate_mode; a.T = temperature; a.u1 = u1; a.u2 = u2;
@@ -449,6 +603,61 @@ int gnf_dag_gate_fwd(const float* x, const float* A, float* e, int64_t ld_e, int
   a.chunk = (B + nc - 1) / nc;
   const unsigned gxp = (unsigned)((d * ((d + 3) / 4) + kBlock - 1) / kBlock);
   hipLaunchKernelGGL(dag_gate_fwd_k, dim3(gxp, (unsigned)nc), dim3(kBlock), 0, s, a);
+  GNF_LAUNCH_CHECK();
+  return 0;
+}
+
+int64_t gnf_dag_gate_plan_bytes(int64_t d) { return (d + (d * KC + 1) / 2) * (int64_t)sizeof(int32_t); }
+
+// chunks of the sample loop of the compact (i, slot)-threaded kernel: ~2048 workgroups
+inline int64_t sp_chunk(int64_t B, int64_t d) {
+  const int64_t gxs = (d * KC + kBlock - 1) / kBlock;
+  int64_t nc = (2048 + gxs - 1) / gxs;
+  if (nc > 64) nc = 64;
+  if (nc > B) nc = B;
+  if (nc < 1) nc = 1;
+  return B > 0 ? (B + nc - 1) / nc : 1;                   // samples per chunk
+}
+inline int64_t sp_chunks(int64_t B, int64_t d) {
+  const int64_t ch = sp_chunk(B, d);
+  const int64_t nc = (B + ch - 1) / ch;
+  return nc < 1 ? 1 : nc;
+}
+
+int64_t gnf_dag_gate_bwd_cols_ws_bytes(int64_t B, int64_t d) {
+  // the dense layout (the fallback runs in it) | compact chunk partials [nc_sp d KC] | flag
+  return gnf_dag_gate_bwd_ws_bytes(B, d) + (sp_chunks(B, d) * d * KC + 4) * (int64_t)sizeof(float);
+}
+
+int gnf_dag_gate_bwd_cols(const float* x, const float* ge, const float* ge_cols, const int32_t* plan, int imp_mode,
+                          int gate_mode, float temperature, const float* u1, const float* u2, uint64_t seed,
+                          uint64_t offset, const float* tab_fwd, float* gA, float* ws, int64_t B, int64_t d,
+                          gnf_stream_t stream) {
+  if (((!x || !ge || !ge_cols) && B > 0) || !plan || !tab_fwd || !gA || !ws || B < 0 || d <= 0 || imp_mode < 0 ||
+      imp_mode > 3 || gate_mode < 0 || gate_mode > 2)
+    return GNF_EINVAL;
+  if (gate_mode == 1 && u1 && !u2) return GNF_EINVAL;
+  if (d > 32767) return GNF_ESHAPE;
+  if (imp_mode == 0) gate_mode = 0;
+  hipStream_t s = (hipStream_t)stream;
+  GateArgs a{};
+  a.x = x; a.tab = tab_fwd; a.ge = ge; a.ld_e = d; a.gate_mode = gate_mode; a.T = temperature; a.u1 = u1; a.u2 = u2;
+  a.seed = seed; a.offset = offset; a.B = B; a.d = d; a.gA = gA; a.ws = ws + 4 * d * d;
+  a.plan = plan; a.gec = ge_cols;
+  const int64_t nc = bwd_chunks(B, d);
+  a.chunk = B > 0 ? (B + nc - 1) / nc : 1;
+  a.chunk_sp = sp_chunk(B, d);
+  const int64_t ncs = sp_chunks(B, d);
+  float* tail = ws + gnf_dag_gate_bwd_ws_bytes(B, d) / (int64_t)sizeof(float);
+  a.part_sp = tail;
+  a.flag = reinterpret_cast<int*>(tail + ncs * d * KC);
+  const unsigned gxp = (unsigned)((d * ((d + 3) / 4) + kBlock - 1) / kBlock);
+  const unsigned gxs = (unsigned)((d * KC + kBlock - 1) / kBlock);
+  hipLaunchKernelGGL(dag_gate_bwd_dp_plan_k, dim3(gxs * (unsigned)ncs), dim3(kBlock), 0, s, a, gxp, (unsigned)nc, gxs);
+  GNF_LAUNCH_CHECK();
+  const unsigned gx4 = (unsigned)(((d * d + 3) / 4 + kBlock - 1) / kBlock);
+  hipLaunchKernelGGL(dag_gate_bwd_dA_plan_k, dim3(gx4), dim3(kBlock), 0, s, tab_fwd, (const float*)a.ws, (int)nc,
+                     (const float*)a.part_sp, (int)ncs, plan, (const int*)a.flag, gA, d);
   GNF_LAUNCH_CHECK();
   return 0;
 }

@@ -59,6 +59,7 @@ struct CnnArgs {
   float* pooled; unsigned char* arg;                                // forward outputs
   const float* gp; const unsigned char* argin; float* ge; float* part;   // backward
   int64_t n;
+  const int32_t* plan; float* gec; int dplan;                             // backward, column plan (gnf_hip.h) or NULL
 };
 
 // max(x, 0) as ONE v_max_f32: fmaxf() compiles into a canonicalising v_max(x, x) plus the maximum

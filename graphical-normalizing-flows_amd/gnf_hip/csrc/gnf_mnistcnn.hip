@@ -138,18 +138,24 @@ __device__ __forceinline__ void dw2_phase(const float* av, const float* dz, f32x
   }
 }
 
-__global__ __launch_bounds__(64 * BWD_WAVES) void cnn_bwd_wino_k(CnnArgs a) {
+// SP: the cotangent of the input image is wanted at the <= KC columns of the plan's row i = image % dplan only (gnf_hip.h,
+// "structural zeros of the gate backward"): the de gather shrinks to one half wavefront and a dword store per column, and
+// a da1 group whose 16 tiles no such column reaches (bit of the per-row group mask gmt[i], built once per kernel in LDS)
+// skips its T planes -- 16 of its 80 MFMAs and the stores.
+constexpr int KC = GNF_DAG_PLAN_KC;
+template <bool SP>
+__device__ __forceinline__ void cnn_bwd_body(const CnnArgs& a, float* smem) {
 #ifdef GNF_CNN_TIMING
   long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   long long tlast = __builtin_readcyclecounter();
 #endif
-  extern __shared__ __attribute__((aligned(16))) float smem[];
   float* e_s = smem;                        // [2][28 x 28] input images
   float* a1_s = smem + 2 * ESZB;            // [2][16][CHB] conv1 activations; channels 0..8 become the T planes of the image
   float* d_s = a1_s + 2 * A1B;              // dY2, window-major
   float* u_s = d_s + DSZW;                  // U' as [g][xi_y][lane][xi_x]
   unsigned* cnt_s = reinterpret_cast<unsigned*>(u_s + USZ);      // "wavefronts done reading dY2", counts up over the images
   float* w1_s = u_s + USZ + 4;                                   // W1 as [tap][channel]: conv1's A operands are re-read per call
+  unsigned* gmt_s = reinterpret_cast<unsigned*>(w1_s + 9 * NCH); // SP: per plan row, the da1 groups whose T planes a column reads
   const int tid = threadIdx.x, lane = tid & 63, q = lane >> 4, j = lane & 15;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   constexpr int NW = BWD_WAVES, NT = 64 * BWD_WAVES;
@@ -203,6 +209,28 @@ __global__ __launch_bounds__(64 * BWD_WAVES) void cnn_bwd_wino_k(CnnArgs a) {
   for (int i = tid; i < DSZW; i += NT) d_s[i] = 0.f;              // the zero pads stay zero, the windows are rewritten
   for (int i = tid; i < 2 * A1B; i += NT) a1_s[i] = 0.f;          // the pad columns of the a1 / T planes (see de_gather)
   if (tid == 0) *cnt_s = 0u;
+  // SP: gmt[i] = the da1 groups (16 consecutive tiles of the 13 x 13 grid) holding a conv1 position (y - ky, x - kx) that the
+  // de of one of row i's columns (y, x) sums over -- exactly the T entries de_cols reads.  Built once per workgroup.
+  const int16_t* const pcols = SP ? reinterpret_cast<const int16_t*>(a.plan + a.dplan) : nullptr;
+  if (SP) {
+    for (int i = tid; i < a.dplan; i += NT) gmt_s[i] = 0u;
+    __syncthreads();
+    for (int t = tid; t < a.dplan * KC; t += NT) {
+      const int jj = pcols[t];
+      if (jj >= 0) {
+        const int y = jj / IMG, x = jj - y * IMG;
+        unsigned m = 0u;
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+          for (int kx = 0; kx < 3; ++kx) {
+            const int py = y - ky, px = x - kx;
+            if ((unsigned)py < (unsigned)C1 && (unsigned)px < (unsigned)C1) m |= 1u << ((13 * (py >> 1) + (px >> 1)) >> 4);
+          }
+        atomicOr(&gmt_s[t / KC], m);
+      }
+    }
+  }
 
   constexpr int EPT = (IMG * IMG + NT - 1) / NT, WPT = (PO * PO + 31) / 32;
   float epre[EPT], gpre[WPT];
@@ -306,8 +334,30 @@ __global__ __launch_bounds__(64 * BWD_WAVES) void cnn_bwd_wino_k(CnnArgs a) {
     }
   };
 
+  // SP: de at the plan's columns only -- lane k < KC of ONE wavefront takes column cj = cols[row][k] (-1: none), same nine
+  // reads and row selects as above, one dword into the compact slab ge_cols[image][k]
+  auto de_cols = [&](int64_t im, int cj, const float* Tp) {
+    const rsrc_t rs = rsrc_of(a.gec, im, KC * 4);
+    const int ic = cj >= 0 ? cj : 0;
+    const int y = (int)(__umul24((unsigned)ic, 2341u) >> 16);
+    const float* tp = Tp + ic;
+    float t[9];
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) t[tap] = tp[tap * CHB - (tap / 3) * IMG - tap % 3];
+    float sum = 0.f;
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky) {
+      const float r3 = (t[3 * ky] + t[3 * ky + 1]) + t[3 * ky + 2];
+      sum += (unsigned)(y - ky) < (unsigned)C1 ? r3 : 0.f;
+    }
+    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, sum), rs, cj >= 0 && lane < KC ? lane * 4 : KC * 4, 0, 0);
+  };
+
   // ---- prologue: the first image's input, its conv1 (dealt evenly), the prefetches of what the first Xa consumes
   const int64_t img0 = blockIdx.x, gstride = gridDim.x;
+  // SP: plan row (= image % dplan) of the previous / this image, advanced without a 64-bit division per image
+  const int rstep = SP ? (int)(gstride % a.dplan) : 0;
+  int rowc = SP ? (int)(img0 % a.dplan) : 0, rowp = 0;
   prefetch_e(img0);
   prefetch_g(img0);
   stage_e(e_s);
@@ -354,11 +404,17 @@ __global__ __launch_bounds__(64 * BWD_WAVES) void cnn_bwd_wino_k(CnnArgs a) {
     stage_e(e_nx);
     prefetch_e(img + 2 * gstride);
     prefetch_g(img + gstride);
+    int cjp = -1;                                                // SP: the previous image's column of this lane (wavefront 0),
+    if (SP && wave == 0 && img != img0 && lane < KC) cjp = pcols[rowp * KC + lane];   // requested ahead of dW2
+    unsigned gm = 0x7FFu;                                        // da1 groups whose T planes are wanted
+    if (SP) gm = __builtin_amdgcn_readfirstlane(gmt_s[rowc]);
     TSTAMP(1);
     if (hy == 0) dw2_phase<0>(a1p + vb, d_s + zb, dU);
     else dw2_phase<1>(a1p + vb, d_s + zb, dU);
     TSTAMP(2);
-    if (img != img0) de_gather(img - gstride, a1n);
+    if (SP) {
+      if (wave == 0 && img != img0) de_cols(img - gstride, cjp, a1n);
+    } else if (img != img0) de_gather(img - gstride, a1n);
     __syncthreads();
     TSTAMP(3);
     // ---- Xb: da1 of this image and conv1 of the next one.  Of the two wavefronts of a SIMD one starts with its conv1
@@ -469,20 +525,22 @@ __global__ __launch_bounds__(64 * BWD_WAVES) void cnn_bwd_wino_k(CnnArgs a) {
         }
 #endif
         // T[tap][pos] = sum_oc W1[oc][tap] dpre1[oc][pos]: dpre1 in the C/D layout IS the B operand
-        f32x4 tq[4];
+        if (!SP || ((gm >> grp) & 1u)) {                        // (wave-uniform) SP: only where a plan column reads it
+          f32x4 tq[4];
 #pragma unroll
-        for (int p = 0; p < 4; ++p) tq[p] = f32x4{0.f, 0.f, 0.f, 0.f};
+          for (int p = 0; p < 4; ++p) tq[p] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int r = 0; r < 4; ++r)
+          for (int r = 0; r < 4; ++r)
 #pragma unroll
-          for (int p = 0; p < 4; ++p) tq[p] = mfma(w1t[r], dp[p][r], tq[p]);
-        // plane of tap 4q+r = channel plane 4q+r of this a1 buffer, at the addresses the gates came from
+            for (int p = 0; p < 4; ++p) tq[p] = mfma(w1t[r], dp[p][r], tq[p]);
+          // plane of tap 4q+r = channel plane 4q+r of this a1 buffer, at the addresses the gates came from
 #pragma unroll
-        for (int r = 0; r < 4; ++r)
-          if (ok && 4 * q + r < 9) {                             // taps 9..15 of the MFMA tile and idle lanes: nothing to store
-            *reinterpret_cast<float2*>(pa + r * CHB) = make_float2(tq[0][r], tq[1][r]);
-            *reinterpret_cast<float2*>(pa + r * CHB + ROWB) = make_float2(tq[2][r], tq[3][r]);
-          }
+          for (int r = 0; r < 4; ++r)
+            if (ok && 4 * q + r < 9) {                           // taps 9..15 of the MFMA tile and idle lanes: nothing to store
+              *reinterpret_cast<float2*>(pa + r * CHB) = make_float2(tq[0][r], tq[1][r]);
+              *reinterpret_cast<float2*>(pa + r * CHB + ROWB) = make_float2(tq[2][r], tq[3][r]);
+            }
+        }
       }
       TSTAMP(5 + k);
     }
@@ -495,12 +553,15 @@ __global__ __launch_bounds__(64 * BWD_WAVES) void cnn_bwd_wino_k(CnnArgs a) {
       while (__hip_atomic_load(cnt_s, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < rd_target) __builtin_amdgcn_s_sleep(1);
       scatter();
     }
+    if (SP) { rowp = rowc; rowc += rstep; rowc -= rowc >= a.dplan ? a.dplan : 0; }
     TSTAMP(7);
   }
   __syncthreads();
   if (img0 < a.n) {                                              // the last image's de (par was flipped once more)
     const int64_t last = img0 + (a.n - 1 - img0) / gstride * gstride;
-    de_gather(last, a1_s + (par ^ 1) * A1B);
+    if (SP) {
+      if (wave == 0) de_cols(last, lane < KC ? (int)pcols[rowp * KC + lane] : -1, a1_s + (par ^ 1) * A1B);
+    } else de_gather(last, a1_s + (par ^ 1) * A1B);
   }
 #ifdef GNF_CNN_TIMING
   if (blockIdx.x == 7 && (tid & 63) == 0)
@@ -563,6 +624,21 @@ __global__ __launch_bounds__(64 * BWD_WAVES) void cnn_bwd_wino_k(CnnArgs a) {
   }
 }
 
+// With a plan: compact de unless one of its rows holds more than KC columns -- decided here, on the device, by every
+// workgroup from the plan's counts (the gate backward takes the same decision from the same counts).
+__global__ __launch_bounds__(64 * BWD_WAVES) void cnn_bwd_wino_k(CnnArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  if (a.plan) {
+    int over = 0;
+    for (int t = threadIdx.x; t < a.dplan; t += 64 * BWD_WAVES) over |= a.plan[t] > KC;
+    if (!__syncthreads_or(over)) {
+      cnn_bwd_body<true>(a, smem);
+      return;
+    }
+  }
+  cnn_bwd_body<false>(a, smem);
+}
+
 // the workgroups' partial rows summed in row order (64 columns per workgroup, wavefront w of 16 takes rows w, w + 16, ...,
 // the 16 sums meet in LDS: deterministic) and written straight into the parameter-shaped gradients
 __global__ __launch_bounds__(1024) void cnn_reduce_unpack_k(const float* __restrict__ part, int rows, float* gW1, float* gb1,
@@ -591,7 +667,8 @@ __global__ __launch_bounds__(1024) void cnn_reduce_unpack_k(const float* __restr
   } else gb2[n - NCH * 144 - NCH * 16] = s;
 }
 
-constexpr size_t kBwdWinoLds = (size_t)(2 * ESZB + 2 * A1B + DSZW + USZ + 4 + 9 * NCH) * sizeof(float);
+constexpr int kPlanRows = IMG * IMG;                // the plan's rows are the masked copies of ONE sample: d = 784
+constexpr size_t kBwdWinoLds = (size_t)(2 * ESZB + 2 * A1B + DSZW + USZ + 4 + 9 * NCH + kPlanRows) * sizeof(float);
 static_assert(kBwdWinoLds <= 160 * 1024, "conv backward LDS image");
 static_assert((size_t)BWD_WAVES * PROW * sizeof(float) <= kBwdWinoLds, "the partial rows of the epilogue reuse the image LDS");
 // one 8-wave workgroup per CU: at its 256 VGPRs a second one is not admitted
@@ -609,13 +686,24 @@ int64_t gnf_mnistcnn_conv_bwd_ws_bytes(int64_t n_img) {
 int gnf_mnistcnn_conv_bwd(const float* e, const float* W1, const float* b1, const float* W2, const float* g_pooled,
                           const unsigned char* argmax, float* ge, float* gW1, float* gb1, float* gW2, float* gb2,
                           void* ws, int64_t ws_bytes, int64_t n_img, gnf_stream_t stream) {
+  return gnf_mnistcnn_conv_bwd_cols(e, W1, b1, W2, g_pooled, argmax, ge, nullptr, 0, nullptr, gW1, gb1, gW2, gb2, ws,
+                                    ws_bytes, n_img, stream);
+}
+
+int gnf_mnistcnn_conv_bwd_cols(const float* e, const float* W1, const float* b1, const float* W2, const float* g_pooled,
+                               const unsigned char* argmax, float* ge, const int32_t* plan, int64_t d_plan,
+                               float* ge_cols, float* gW1, float* gb1, float* gW2, float* gb2, void* ws,
+                               int64_t ws_bytes, int64_t n_img, gnf_stream_t stream) {
   if (((!e || !g_pooled || !argmax || !ge) && n_img > 0) || !W1 || !b1 || !W2 || !gW1 || !gb1 || !gW2 || !gb2 || !ws ||
       n_img < 0)
     return GNF_EINVAL;                       // empty batch: zero weight gradients through the same kernels
+  if (plan && (!ge_cols && n_img > 0)) return GNF_EINVAL;
+  if (plan && d_plan != kPlanRows) return GNF_ESHAPE;              // a masked copy per pixel of the 28 x 28 image
   if (ws_bytes < gnf_mnistcnn_conv_bwd_ws_bytes(n_img)) return GNF_EWS;
   CnnArgs a{};
   a.e = e; a.W1 = W1; a.b1 = b1; a.W2 = W2; a.gp = g_pooled; a.argin = argmax; a.ge = ge; a.part = (float*)ws;
   a.n = n_img;
+  a.plan = plan; a.gec = ge_cols; a.dplan = (int)d_plan;
   // fixed grid: every workgroup (also one without images) writes its partial rows
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&cnn_bwd_wino_k),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)kBwdWinoLds);

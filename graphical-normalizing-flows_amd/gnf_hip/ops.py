@@ -588,6 +588,84 @@ class DagGateFn(torch.autograd.Function):
         return gx, (finish(gA) if gA is not None else None), None, None, None, None, None, None, None, None, None
 
 
+class DagConvFrontFn(torch.autograd.Function):
+    """flatten(max_pool2d(conv2(relu(conv1(e))), 2)) of the masked copies e[b*d+i, :] = x[b, :] * gate(importance(A[i, :]))
+    -- DagGateFn and MnistConvFn as ONE autograd node (DAGConditioner.py:94-166,169 -> MLP.py:36-43), which is what lets the
+    backward drop the structural zeros: dL/dA[i,j] = dP/dA[i,j] * (...) and dP/dA is exactly 0 wherever A is (97.2 % of
+    MNIST_A_prior, DAGConditioner.py:118-119), so when x wants no gradient the conv backward writes the cotangent of e at
+    the <= 32 columns per row the forward's plan lists (10 MB instead of 243 MB at B = 100, and it skips the W1^T dpre1
+    products nobody reads) and the gate backward visits those (i, j) pairs only.  The plan is rebuilt from A on the device
+    in every forward; a row with more columns than the plan holds sends both kernels down their dense code (decided on the
+    device); x.requires_grad takes the dense entry points."""
+
+    @staticmethod
+    def forward(ctx, x, A, imp_mode, gate_mode, h_thresh, temperature, u1, u2, seed, offset, W1, b1, W2, b2, exact_ties,
+                grad_mode):
+        x, A = x.contiguous(), A.contiguous()
+        B, d = x.shape
+        if d != 784:
+            raise abi.GnfError("the fused masked-image front is the 28 x 28 MNISTCNN one: d = %d" % d)
+        n = B * d
+        e = _empty((n, d), x)
+        u1 = u1.contiguous() if u1 is not None else None
+        u2 = u2.contiguous() if u2 is not None else None
+        lib = abi.load()
+        tab = torch.empty(max(int(lib.gnf_dag_gate_fwd_ws_bytes(d)) // 4, 1), dtype=torch.float32, device=x.device)
+        want_plan = bool(grad_mode) and ctx.needs_input_grad[1] and not ctx.needs_input_grad[0] and B > 0
+        plan, nplan = None, 0
+        if want_plan:
+            nplan = int(lib.gnf_dag_gate_plan_bytes(d))
+            plan = torch.empty(nplan // 4, dtype=torch.int32, device=x.device)
+        call("gnf_dag_gate_fwd_plan", ptr(x), ptr(A), ptr(e), d, imp_mode, gate_mode, float(h_thresh), float(temperature),
+             ptr(u1), ptr(u2), seed, offset, 0, ptr(tab), abi.rawptr(plan) if plan is not None else None, nplan, B, d,
+             stream())
+        W1c, b1c, W2c, b2c = W1.contiguous(), b1.contiguous(), W2.contiguous(), b2.contiguous()
+        pooled = _empty((n, 2304), x)
+        arg = torch.empty((n, 2304), dtype=torch.uint8, device=x.device)
+        call("gnf_mnistcnn_conv_fwd", ptr(e), ptr(W1c), ptr(b1c), ptr(W2c), ptr(b2c), ptr(pooled), abi.rawptr(arg), n,
+             int(bool(exact_ties)), stream())
+        ctx.save_for_backward(x, A, u1, u2, e, W1c, b1c, W2c, b2c, arg)
+        ctx.tab, ctx.plan = (tab if B > 0 else None), plan
+        ctx.cfg = (imp_mode, gate_mode, float(h_thresh), float(temperature), seed, offset)
+        return pooled
+
+    @staticmethod
+    def backward(ctx, gp):
+        x, A, u1, u2, e, W1, b1, W2, b2, arg = ctx.saved_tensors
+        imp_mode, gate_mode, h_thresh, temperature, seed, offset = ctx.cfg
+        B, d = x.shape
+        n = B * d
+        lib = abi.load()
+        gp = gp.contiguous()
+        ge = _empty((n, d), x)                 # (with a plan: touched only if one of its rows overflows)
+        gW1, gb1, gW2, gb2 = grad_out(W1), grad_out(b1), grad_out(W2), grad_out(b2)
+        nws = lib.gnf_mnistcnn_conv_bwd_ws_bytes(n)
+        ws = _ws(nws, x)
+        plan = ctx.plan
+        gec = _empty((n, abi.DAG_PLAN_KC), x) if plan is not None else None
+        call("gnf_mnistcnn_conv_bwd_cols", ptr(e), ptr(W1), ptr(b1), ptr(W2), ptr(gp), abi.rawptr(arg), ptr(ge),
+             abi.rawptr(plan) if plan is not None else None, d, ptr(gec), ptr(gW1), ptr(gb1), ptr(gW2), ptr(gb2),
+             abi.rawptr(ws), nws, n, stream())
+        gA, finish = grad_out_shared(A) if ctx.needs_input_grad[1] else (None, None)
+        gx = _empty((B, d), x) if ctx.needs_input_grad[0] else None
+        if plan is not None:
+            ws2 = _ws(lib.gnf_dag_gate_bwd_cols_ws_bytes(B, d), x)
+            call("gnf_dag_gate_bwd_cols", ptr(x), ptr(ge), ptr(gec), abi.rawptr(plan), imp_mode, gate_mode, temperature,
+                 ptr(u1), ptr(u2), seed, offset, ptr(ctx.tab), ptr(gA), ptr(ws2), B, d, stream())
+        elif gA is not None or gx is not None:
+            ws2 = _ws(lib.gnf_dag_gate_bwd_ws_bytes(B, d), x)
+            call("gnf_dag_gate_bwd", ptr(x), ptr(A), ptr(ge), d, imp_mode, gate_mode, h_thresh, temperature, ptr(u1),
+                 ptr(u2), seed, offset, ptr(ctx.tab), ptr(gA), ptr(gx), ptr(ws2), B, d, stream())
+        return (gx, (finish(gA) if gA is not None else None), None, None, None, None, None, None, None, None,
+                gW1, gb1, gW2, gb2, None, None)
+
+
+def dag_conv_front(x, A, imp_mode, gate_mode, h_thresh, temperature, u1, u2, seed, offset, W1, b1, W2, b2,
+                   exact_ties=False):
+    return DagConvFrontFn.apply(x, A, imp_mode, gate_mode, h_thresh, temperature, u1, u2, seed, offset, W1, b1, W2, b2,
+                                exact_ties, torch.is_grad_enabled())
+
+
 # ----------------------------------------------------------------------------- Monotonic (UMNN) normalizer
 _CC = {}
 

@@ -80,6 +80,7 @@ class DAGConditioner(Conditioner):
         self.no_update = 0
         self.is_invertible = False
         self.sparse_front = True        # deterministic gate + windowed, frozen A: sparse embedding front
+        self.fused_front = True         # gate + MNISTCNN conv front as one autograd node (False: DagGateFn + MnistConvFn)
         self._sparse_outside = None     # 1 outside the 5x5 pixel windows (device mask, built on first use)
         self._sparse_checked = (None, False)
         self._off_key, self._off = None, False
@@ -186,6 +187,20 @@ class DAGConditioner(Conditioner):
             # deterministic gate on the dense kernels (trainable A, or a gradient wanted for x): the masked copies
             # have exactly-constant regions, so the embedding net must break pool ties the way torch does
             self.embedding_net.exact_pool_ties = P is not None
+        net = self.embedding_net
+        if (self.fused_front and not self.hot_encoding and not self.cond_in and hasattr(net, "forward_gated")
+                and x.shape[1] == self.in_size and net.supports_gated(x)):
+            imp, gate = self._modes()
+            if gate != ops.GATE_GUMBEL or self.gumble:
+                # gate + conv front as ONE autograd node: with x frozen its backward skips the entries of dL/de that
+                # dP/dA = 0 multiplies (every zero of the prior, reference :118-119)
+                u1 = u2 = None
+                if self.gate_noise is not None and gate != ops.GATE_DET:
+                    u1, u2 = self.gate_noise
+                self._gate_calls += 1
+                h = net.forward_gated(x, self.A, imp, gate, float(self.h_thresh), float(self.gumble_T), u1, u2,
+                                      self.gate_seed, self._gate_calls)
+                return h.view(x.shape[0], self.in_size, -1)
         e = self.masked_inputs(x)
         return self.embedding_net(e).view(x.shape[0], self.in_size, -1)
 

@@ -93,6 +93,19 @@ class MNISTCNN(nn.Module):
             return out if sr.identity else ops.PermuteRowsFn.apply(out, sr.unsort, sr.order)
         return ops.PermuteRowsFn.apply(out.view(sr.R, sr.B, -1), sr.unsort, sr.order).permute(1, 0, 2)
 
+    def supports_gated(self, x):
+        """the gate of a DAG conditioner + this net's conv front as one autograd node (gnf_hip.ops.DagConvFrontFn): the
+        28 x 28 net on a [B, 784] batch, one masked copy per pixel"""
+        return x.dim() == 2 and self._fused_front(x)
+
+    def forward_gated(self, x, A, imp_mode, gate_mode, h_thresh, temperature, u1, u2, seed, offset):
+        """embedding_net(e) for e[b*d+i] = x[b] * gate(importance(A[i])) (DAGConditioner.py:94-166,169), e built inside the
+        fused front: [B*784, out_d]"""
+        pooled = ops.dag_conv_front(x, A, imp_mode, gate_mode, h_thresh, temperature, u1, u2, seed, offset,
+                                    self.conv1.weight, self.conv1.bias, self.conv2.weight, self.conv2.bias,
+                                    self.exact_pool_ties)
+        return ops.mlp(pooled, _linears([self.fc1, self.fc2]))
+
     _held_prep = None
 
     def hold_prepared(self):

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define GNF_ABI_VERSION 4
+#define GNF_ABI_VERSION 5
 #define GNF_EINVAL (-1)   /* bad argument (null pointer, negative size, ...)          */
 #define GNF_ESHAPE (-2)   /* shape not supported by any compiled kernel instantiation */
 #define GNF_EWS    (-3)   /* workspace too small                                      */
@@ -146,8 +146,8 @@ int gnf_gemm(const float* A, int64_t sam, int64_t sak,
  *             2: noise gate imp*(x + n*|1-imp|) (:114-116)
  * Randomness: if u1 != NULL the uniforms (gate 1: u1,u2; gate 2: u1 holds N(0,1)
  * samples) are read from [B,d,d] arrays (parity tests); otherwise a Philox4x32-10
- * stream keyed by (seed, offset) is used -- counter = (b*d+i)*ceil(d/2) + j/2, one call
- * serving the two adjacent columns 2(j/2), 2(j/2)+1 -- and the backward regenerates the
+ * stream keyed by (seed, offset) is used -- counter = (b*d+i)*ceil(d/4) + j/4, one call
+ * serving the four adjacent columns 4(j/4) .. 4(j/4)+3 -- and the backward regenerates the
  * same numbers from the same (seed, offset). */
 /* ws: >= gnf_dag_gate_fwd_ws_bytes(d) bytes (per-(i,j) table of importance / gate constants). */
 int64_t gnf_dag_gate_fwd_ws_bytes(int64_t d);
@@ -164,6 +164,32 @@ int gnf_dag_gate_bwd(const float* x, const float* A, const float* ge, int64_t ld
                      int imp_mode, int gate_mode, float h_thresh, float temperature,
                      const float* u1, const float* u2, uint64_t seed, uint64_t offset, const float* tab_fwd,
                      float* gA, float* gx, float* ws, int64_t B, int64_t d, gnf_stream_t stream);
+
+/* ---- structural zeros of the gate backward (round 5) --------------------------------------------------------------
+ * dL/dA[i,j] = dP/dA[i,j] * sum_b dL/de[b,i,j] x[b,j] dgate/dP (DAGConditioner.py:118-119: dP/dA = 8 A s(1-s) is
+ * EXACTLY zero wherever A is zero -- 97.2 % of MNIST_A_prior(28, 2), NormalizingFlowFactories.py:35-46), so with no
+ * gradient wanted for x the cotangent of e is only needed at the columns j of row i with dP/dA[i,j] != 0.
+ *   plan (gnf_dag_gate_plan_bytes(d) bytes, written by gnf_dag_gate_fwd_plan from the very table its gate uses):
+ *     int32 count[d] (columns with dP/dA != 0 in row i, also when more than GNF_DAG_PLAN_KC),
+ *     int16 cols[d][GNF_DAG_PLAN_KC] (those columns in ascending order, -1 padded).
+ *   Consumers (gnf_mnistcnn_conv_bwd_cols, gnf_dag_gate_bwd_cols) use the lists only if NO row overflows KC and run
+ *   their dense code otherwise; the decision is taken on the device, nothing is cached on the host.
+ *   ge_cols [(B*d), GNF_DAG_PLAN_KC]: ge_cols[(b*d+i)*KC + k] = dL/de[b,i,cols[i][k]] for k < count[i].
+ * gnf_dag_gate_fwd_plan = gnf_dag_gate_fwd that also writes the plan (plan == NULL: exactly gnf_dag_gate_fwd).
+ * gnf_dag_gate_bwd_cols: gA only (x frozen), no one-hot columns (ld_e = d); tab_fwd (required) = the forward's ws;
+ *   ge [(B*d), d] is read when the plan overflows, ge_cols otherwise. */
+#define GNF_DAG_PLAN_KC 32
+int64_t gnf_dag_gate_plan_bytes(int64_t d);
+int gnf_dag_gate_fwd_plan(const float* x, const float* A, float* e, int64_t ld_e,
+                          int imp_mode, int gate_mode, float h_thresh, float temperature,
+                          const float* u1, const float* u2, uint64_t seed, uint64_t offset,
+                          int hot, float* ws, int32_t* plan, int64_t plan_bytes, int64_t B, int64_t d,
+                          gnf_stream_t stream);
+int64_t gnf_dag_gate_bwd_cols_ws_bytes(int64_t B, int64_t d);
+int gnf_dag_gate_bwd_cols(const float* x, const float* ge, const float* ge_cols, const int32_t* plan,
+                          int imp_mode, int gate_mode, float temperature,
+                          const float* u1, const float* u2, uint64_t seed, uint64_t offset, const float* tab_fwd,
+                          float* gA, float* ws, int64_t B, int64_t d, gnf_stream_t stream);
 
 /* ---- DAG acyclicity + l1 term: DAGConditioner.get_power_trace / loss (DAGConditioner.py:176-194, 268-271) --------
  * The d x d matrix power stays on the GEMM library; these entries fuse the ~40 elementwise / reduction
@@ -243,6 +269,16 @@ int gnf_mnistcnn_conv_bwd(const float* e, const float* W1, const float* b1, cons
                           const float* g_pooled, const unsigned char* argmax,
                           float* ge, float* gW1, float* gb1, float* gW2, float* gb2,
                           void* ws, int64_t ws_bytes, int64_t n_img, gnf_stream_t stream);
+/* The same backward for the masked copies of a DAG conditioner whose gate backward needs the cotangent of e at the plan's
+ * columns only (above): image n is the masked copy (b, i) = (n / d_plan, n % d_plan), d_plan = 784.  Unless a row of the
+ * plan overflows, ge is NOT written: ge_cols [n_img, GNF_DAG_PLAN_KC] receives dL/de at the row's columns, and the
+ * kernel skips the W1^T dpre1 products of the conv1 positions no such column reaches (7 of 11 position groups at the
+ * MNIST prior).  The parameter gradients are those of gnf_mnistcnn_conv_bwd, bit for bit.  plan == NULL: that call. */
+int gnf_mnistcnn_conv_bwd_cols(const float* e, const float* W1, const float* b1, const float* W2,
+                               const float* g_pooled, const unsigned char* argmax,
+                               float* ge, const int32_t* plan, int64_t d_plan, float* ge_cols,
+                               float* gW1, float* gb1, float* gW2, float* gb2,
+                               void* ws, int64_t ws_bytes, int64_t n_img, gnf_stream_t stream);
 
 /* ---- sparse masked-image front for a DETERMINISTIC DAG gate ---------------
  * Replaces, for evaluation / sampling, the chain  e = x * P[i]  (DAGConditioner.py:142-153, deterministic branches)

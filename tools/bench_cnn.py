@@ -50,6 +50,29 @@ def bwd():
                                      ctypes.c_int64(n), st)
 
 
+# round 5: the compact-de variant (gnf_mnistcnn_conv_bwd_cols) with the plan of MNIST_A_prior(28, 2), built on the host here
+# (the product builds it on the device in gnf_dag_gate_fwd_plan)
+KC = 32
+r_, c_ = torch.arange(28).repeat_interleave(28), torch.arange(28).repeat(28)
+win = ((r_[:, None] - r_[None, :]).abs() <= 2) & ((c_[:, None] - c_[None, :]).abs() <= 2)
+win.fill_diagonal_(False)
+cols = torch.full((784, KC), -1, dtype=torch.int16)
+for i in range(784):
+    jj = win[i].nonzero().flatten()
+    cols[i, :len(jj)] = jj.to(torch.int16)
+plan = torch.cat([win.sum(1).to(torch.int32), cols.view(-1).view(torch.int32)]).to(dev)
+gec = torch.empty(n, KC, device=dev)
+HAS_COLS = hasattr(lib, 'gnf_mnistcnn_conv_bwd_cols')
+
+
+def bwd_cols():
+    return lib.gnf_mnistcnn_conv_bwd_cols(P(e.data_ptr()), P(W1.data_ptr()), P(b1.data_ptr()), P(W2.data_ptr()), P(gp.data_ptr()),
+                                          P(arg.data_ptr()), P(ge.data_ptr()), P(plan.data_ptr()), ctypes.c_int64(784),
+                                          P(gec.data_ptr()), P(g[0].data_ptr()), P(g[1].data_ptr()),
+                                          P(g[2].data_ptr()), P(g[3].data_ptr()), P(ws.data_ptr()), ctypes.c_int64(nws),
+                                          ctypes.c_int64(n), st)
+
+
 def timeit(fn, reps=15):
     warm_gpu()
     for _ in range(3):
@@ -66,4 +89,15 @@ def timeit(fn, reps=15):
 tf, tb = timeit(fwd), timeit(bwd)
 chk = (pooled.double().sum().item(), ge.double().sum().item(), g[2].double().sum().item(), g[0].double().sum().item())
 print("[%s] conv fwd %.4f ms   conv bwd %.4f ms   checksums pooled %.6e ge %.6e gW2 %.6e gW1 %.6e" % ((label, tf, tb) + chk))
+if HAS_COLS:
+    g2d, g0d = g[2].clone(), g[0].clone()
+    tc = timeit(bwd_cols)
+    rows = torch.arange(n, device=dev) % 784
+    cd = cols.to(dev).long()
+    bad = 0
+    for k in range(KC):
+        on = cd[rows, k] >= 0
+        bad += int((gec[on, k] != ge[on.nonzero().flatten(), cd[rows, k][on]]).sum())
+    print("[%s] conv bwd, compact de (MNIST window plan) %.4f ms   mismatching ge_cols entries %d   gW2 equal %s gW1 equal %s"
+          % (label, tc, bad, bool(torch.equal(g2d, g[2])), bool(torch.equal(g0d, g[0]))))
 os.remove(so)
