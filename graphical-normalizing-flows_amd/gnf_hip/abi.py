@@ -45,6 +45,9 @@ SIGNATURES = {
     "gnf_nll_reduce_bwd": (c_int, [c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_i64, c_i64, c_stream]),
     "gnf_nll_mean_fwd": (c_int, [c_f, c_f, c_f, c_f, c_i64, c_stream]),
     "gnf_nll_mean_bwd": (c_int, [c_f, c_f, c_f, c_i64, c_stream]),
+    "gnf_nll_loss_max_elems": (c_i64, []),
+    "gnf_nll_loss_fwd": (c_int, [c_f, c_f, c_f, c_f, c_i64, c_i64, c_stream]),
+    "gnf_nll_loss_bwd": (c_int, [c_f, c_f, c_f, c_f, c_i64, c_i64, c_stream]),
     "gnf_colsum_ws_bytes": (c_i64, [c_i64, c_i64]),
     "gnf_colsum": (c_int, [c_f, c_i64, c_f, c_i64, c_i64, c_f, c_stream]),
     "gnf_linear_ws_bytes": (c_i64, [c_i64, c_i64, c_i64]),
@@ -68,7 +71,7 @@ SIGNATURES = {
                                       c_f, ctypes.c_void_p, c_i64, c_i64, c_i64, c_stream]),
     "gnf_dag_gate_bwd_cols_ws_bytes": (c_i64, [c_i64, c_i64]),
     "gnf_dag_gate_bwd_cols": (c_int, [c_f, c_f, c_f, ctypes.c_void_p, c_int, c_int, c_float, c_f, c_f, c_u64, c_u64, c_f,
-                                      c_f, c_f, c_i64, c_i64, c_stream]),
+                                      c_f, c_int, c_f, c_i64, c_i64, c_stream]),
     "gnf_monotonic_pack_floats": (c_i64, [ctypes.POINTER(MonoNet)]),
     "gnf_monotonic_pack": (c_int, [ctypes.POINTER(MonoNet), c_f, c_stream]),
     "gnf_monotonic_fwd": (c_int, [c_f, ctypes.POINTER(MonoNet), c_f, c_f, c_i64, c_i64, c_i64, c_f, c_f, c_int, c_f,

@@ -60,15 +60,23 @@ def build_library(force=False, verbose=True):
         stamp = o + ".cmd"                      # an object built with other flags is stale too
         same_cmd = os.path.exists(stamp) and open(stamp).read() == " ".join(cmd)
         if force or not same_cmd or not _newer(o, [s] + headers):
-            with open(stamp, "w") as f:
-                f.write(" ".join(cmd))
+            for stale in (stamp, o):                # a failed compile must not leave an object that looks up to date
+                if os.path.exists(stale):
+                    os.remove(stale)
             if verbose:
                 print("[gnf_hip.build]", " ".join(cmd), flush=True)
-            jobs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
-    for src, p in jobs:
+            jobs.append((src, stamp, " ".join(cmd),
+                         subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
+    failed = []
+    for src, stamp, line, p in jobs:
         out, _ = p.communicate()
         if p.returncode != 0:
-            raise RuntimeError("hipcc failed on %s:\n%s" % (src, out))
+            failed.append("hipcc failed on %s:\n%s" % (src, out))
+        else:
+            with open(stamp, "w") as f:             # the flags an object was built with, written once it exists
+                f.write(line)
+    if failed:
+        raise RuntimeError("\n".join(failed))
     if force or jobs or not _newer(LIB, objs):
         cmd = [hipcc, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", LIB] + objs
         if verbose:

@@ -57,7 +57,7 @@ __global__ void dag_gate_tab_k(const float* __restrict__ A, float* __restrict__ 
 // cotangent of e[b,i,j] is multiplied by an exact 0 and never needed (as long as x wants no gradient).  One wavefront per
 // row i compacts the columns with dP/dA != 0 in ascending order:
 //   plan[i] = their number (also when it exceeds KC),   cols[i][k] (int16, behind the d counts) = the k-th such column.
-// A consumer uses the lists only if NO row holds more than KC columns (plan_overflows) and runs its dense path otherwise:
+// A consumer uses the lists only if NO row holds more than KC columns (the flag word behind them) and runs its dense path otherwise:
 // the decision is taken on the device from the same table the forward used -- nothing is cached on the host.
 constexpr int KC = GNF_DAG_PLAN_KC;
 // the table of dag_gate_tab_k AND the plan in one launch: one workgroup per row i
@@ -98,11 +98,14 @@ __global__ __launch_bounds__(kBlock) void dag_gate_tab_plan_k(const float* __res
   if (tid == 0) plan[i] = n;
 }
 
-// true when a row of the plan holds more than KC columns: every thread of the workgroup gets the same answer
-__device__ __forceinline__ bool plan_overflows(const int32_t* __restrict__ plan, int64_t d) {
+// plan[d + d*KC/2] = 1 when a row of the plan holds more than KC columns (consumers then run their dense code), else 0:
+// written by workgroup (0, 0) of the gate forward that follows the table launch in the same stream
+__device__ __forceinline__ int64_t plan_flag_index(int64_t d) { return d + (d * KC + 1) / 2; }
+__device__ __forceinline__ void plan_write_flag(int32_t* __restrict__ plan, int64_t d) {
   int over = 0;
   for (int64_t t = threadIdx.x; t < d; t += blockDim.x) over |= plan[t] > KC;
-  return __syncthreads_or(over) != 0;
+  over = __syncthreads_or(over);
+  if (threadIdx.x == 0) plan[plan_flag_index(d)] = over ? 1 : 0;
 }
 
 // Noise of the FOUR adjacent columns 4 jq .. 4 jq + 3 of row (b*d + i), one value per column:
@@ -193,13 +196,14 @@ struct GateArgs {
   const float* x; const float* tab; float* e; const float* ge; int64_t ld_e;
   int gate_mode; float T; const float* u1; const float* u2; uint64_t seed, offset; int hot;
   float* ws; float* gA; float* gx; int64_t B, d, chunk;
-  const int32_t* plan; const float* gec; float* part_sp; int64_t chunk_sp; int* flag;
+  int32_t* plan; const float* gec; float* part_sp; int64_t chunk_sp;
 };
 
 // One thread per (i, column quad), looping over the samples of its chunk (blockIdx.y): the table entries of the quad are
 // read once, every iteration is one Philox call + four gates + one 16-B store.  (One tiny thread per (b, i, quad)
 // -- 78 400 workgroups at cfg4 -- spent its time on the dependent table loads: 0.17 ms; this form 0.06.)
 __global__ void dag_gate_fwd_k(GateArgs a) {
+  if (a.plan && blockIdx.x == 0 && blockIdx.y == 0) plan_write_flag(a.plan, a.d);    // (uniform per workgroup)
   const int64_t d = a.d, dd = d * d, dq = (d + 3) / 4;
   const int64_t ip = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (ip >= d * dq) return;
@@ -290,45 +294,54 @@ __global__ void dag_gate_bwd_dp_k(GateArgs a) { dp_dense_unit(a, blockIdx.x, blo
 // -- 17 172 (i,j) pairs instead of 614 656 at the MNIST prior.  The noise of (b,i,j) is element j & 3 of the Philox call
 // of its column quad, exactly as the forward drew it.  1-D grid of gx_sp * nc_sp workgroups; if a row of the plan
 // overflows, the same workgroups walk the units of the dense kernel over ge instead (the conv backward took the same
-// decision and wrote the dense ge).  flag <- which of the two happened, for dag_gate_bwd_dA_plan_k.
+// decision from the same word and wrote the dense ge).
 __global__ void dag_gate_bwd_dp_plan_k(GateArgs a, unsigned gx_dense, unsigned ny_dense, unsigned gx_sp) {
-  const bool over = plan_overflows(a.plan, a.d);
-  if (blockIdx.x == 0 && threadIdx.x == 0) *a.flag = over ? 1 : 0;
-  if (over) {
+  const int64_t d = a.d, dd = d * d;
+  if (a.plan[plan_flag_index(d)] != 0) {                       // (the same word for every thread)
     for (unsigned u = blockIdx.x; u < gx_dense * ny_dense; u += gridDim.x) dp_dense_unit(a, u % gx_dense, u / gx_dense);
     return;
   }
-  const int64_t d = a.d, dd = d * d;
   const int64_t bx = blockIdx.x % gx_sp, by = blockIdx.x / gx_sp;
   const int64_t it = bx * blockDim.x + threadIdx.x;
   if (it >= d * KC) return;
   const int64_t i = it / KC;
   const int k = (int)(it - i * KC);
-  if (k >= a.plan[i]) return;
+  const int cnt = a.plan[i];
   const int64_t j = reinterpret_cast<const int16_t*>(a.plan + d)[it];
+  if (k >= cnt) return;
   const int64_t ij = i * d + j, jq = j >> 2;
   const int h = (int)(j & 3);
   const float p = a.tab[ij], ET = a.tab[2 * dd + ij], Q = a.tab[3 * dd + ij];
   const int64_t b0 = by * a.chunk_sp;
   const int64_t b1 = b0 + a.chunk_sp < a.B ? b0 + a.chunk_sp : a.B;
   float acc = 0.f;
-  for (int64_t b = b0; b < b1; ++b) {
-    const Draw4 n = draw4(a.gate_mode, a.u1, a.u2, a.seed, a.offset, b * d + i, jq, d);
-    const float g = a.gec[(b * d + i) * KC + k];
-    const float xv = a.x[b * d + j];
-    float nv = n.v[0], nw = n.w[0];                            // element h of the quad (h is not a compile-time index)
-    nv = h == 1 ? n.v[1] : nv; nw = h == 1 ? n.w[1] : nw;
-    nv = h == 2 ? n.v[2] : nv; nw = h == 2 ? n.w[2] : nw;
-    nv = h == 3 ? n.v[3] : nv; nw = h == 3 ? n.w[3] : nw;
-    if (a.gate_mode == 0) {
-      acc = fmaf(g, xv, acc);
-    } else if (a.gate_mode == 1) {
-      const float s = gumbel_gate(ET, nv, nw, a.T);
-      acc = fmaf(g * xv, s * (1.f - s) * Q, acc);
-    } else {
-      const float om = 1.f - p;
-      const float sgn = om > 0.f ? 1.f : (om < 0.f ? -1.f : 0.f);
-      acc = fmaf(g, xv + nv * fabsf(om) - p * nv * sgn, acc);
+  constexpr int UB = 4;                                        // samples per round: their loads are requested together
+  for (int64_t bb = b0; bb < b1; bb += UB) {
+    float g[UB], xv[UB];
+#pragma unroll
+    for (int u = 0; u < UB; ++u) {
+      const int64_t b = bb + u < b1 ? bb + u : b1 - 1;         // (clamped: a repeated sample is weighted 0 below)
+      g[u] = a.gec[(b * d + i) * KC + k];
+      xv[u] = a.x[b * d + j];
+    }
+#pragma unroll
+    for (int u = 0; u < UB; ++u) {
+      if (bb + u >= b1) break;
+      const Draw4 n = draw4(a.gate_mode, a.u1, a.u2, a.seed, a.offset, (bb + u) * d + i, jq, d);
+      float nv = n.v[0], nw = n.w[0];                          // element h of the quad (h is not a compile-time index)
+      nv = h == 1 ? n.v[1] : nv; nw = h == 1 ? n.w[1] : nw;
+      nv = h == 2 ? n.v[2] : nv; nw = h == 2 ? n.w[2] : nw;
+      nv = h == 3 ? n.v[3] : nv; nw = h == 3 ? n.w[3] : nw;
+      if (a.gate_mode == 0) {
+        acc = fmaf(g[u], xv[u], acc);
+      } else if (a.gate_mode == 1) {
+        const float s = gumbel_gate(ET, nv, nw, a.T);
+        acc = fmaf(g[u] * xv[u], s * (1.f - s) * Q, acc);
+      } else {
+        const float om = 1.f - p;
+        const float sgn = om > 0.f ? 1.f : (om < 0.f ? -1.f : 0.f);
+        acc = fmaf(g[u], xv[u] + nv * fabsf(om) - p * nv * sgn, acc);
+      }
     }
   }
   a.part_sp[by * d * KC + it] = acc;
@@ -358,34 +371,38 @@ __global__ void dag_gate_bwd_dA_k(const float* __restrict__ tab, const float* __
   }
 }
 
-// gA for the plan variant: the dense sums (flag set: a row of the plan overflowed) or, per entry with dP/dA != 0, the sums of
-// its slot in the compact partials; entries with dP/dA == 0 get the exact 0 the dense product would give them
-__global__ void dag_gate_bwd_dA_plan_k(const float* __restrict__ tab, const float* __restrict__ part, int nc,
-                                       const float* __restrict__ part_sp, int nc_sp, const int32_t* __restrict__ plan,
-                                       const int* __restrict__ flag, float* __restrict__ gA, int64_t d) {
-  const int64_t dd = d * d;
-  const int64_t i4 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
-  if (i4 >= dd) return;
-  const bool dense = *flag != 0;
-  const int16_t* cols = reinterpret_cast<const int16_t*>(plan + d);
-  for (int64_t ij = i4; ij < dd && ij < i4 + 4; ++ij) {
-    const float dp = tab[dd + ij];
-    float s = 0.f;
-    if (dense) {
-      s = part[ij];
+// gA for the plan variant, one workgroup per row i: the dense chunk sums (a row of the plan overflowed) or zeros + the chunk
+// sums of the row's <= KC slots scattered to their columns; entries with dP/dA == 0 get the exact 0 the dense product gives
+__global__ __launch_bounds__(kBlock) void dag_gate_bwd_dA_plan_k(const float* __restrict__ tab, const float* __restrict__ part,
+                                                                 int nc, const float* __restrict__ part_sp, int nc_sp,
+                                                                 const int32_t* __restrict__ plan, float* __restrict__ gA,
+                                                                 int accumulate, int64_t d) {
+  const int64_t dd = d * d, i = blockIdx.x;
+  const int tid = threadIdx.x;
+  if (plan[plan_flag_index(d)] != 0) {
+    for (int64_t j = tid; j < d; j += kBlock) {
+      const int64_t ij = i * d + j;
+      float s = part[ij];
       for (int c = 1; c < nc; ++c) s += part[(int64_t)c * dd + ij];
-    } else if (dp != 0.f) {
-      const int64_t i = ij / d, j = ij - i * d;
-      const int n = plan[i] < KC ? plan[i] : KC;
-      int k = -1;
-      for (int t = 0; t < n; ++t) k = cols[i * KC + t] == (int16_t)j ? t : k;
-      if (k >= 0) {
-        s = part_sp[i * KC + k];
-        for (int c = 1; c < nc_sp; ++c) s += part_sp[(int64_t)c * d * KC + i * KC + k];
-      }
+      gA[ij] = accumulate ? fmaf(s, tab[dd + ij], gA[ij]) : s * tab[dd + ij];
     }
-    gA[ij] = s * dp;
+    return;
   }
+  const int cnt = plan[i];
+  const int64_t jk = tid < KC ? reinterpret_cast<const int16_t*>(plan + d)[i * KC + tid] : -1;
+  float s = 0.f, dp = 0.f;
+  if (tid < cnt) {
+    dp = tab[dd + i * d + jk];
+    s = part_sp[i * KC + tid];
+    for (int c = 1; c < nc_sp; ++c) s += part_sp[(int64_t)c * d * KC + i * KC + tid];
+  }
+  if (accumulate) {                                            // gA already holds another contribution (the acyclicity term's):
+    if (tid < cnt) gA[i * d + jk] = fmaf(s, dp, gA[i * d + jk]);   // only the row's listed columns change
+    return;
+  }
+  for (int64_t j = tid; j < d; j += kBlock) gA[i * d + j] = 0.f;
+  __syncthreads();
+  if (tid < cnt) gA[i * d + jk] = s * dp;
 }
 
 // gx partial sums over a chunk of i (blockIdx.y):  out[chunk][b,j] = sum_{i in chunk} ge[b,i,j] * de/dx[b,i,j];  one thread
@@ -585,7 +602,7 @@ int gnf_dag_gate_fwd_plan(const float* x, const float* A, float* e, int64_t ld_e
   if (imp_mode == 0) gate_mode = 0;   // DAG:151-153: raw A, no gate
   if (plan && d > 32767) return GNF_ESHAPE;               // 16-bit column indices
   if (plan && plan_bytes < gnf_dag_gate_plan_bytes(d)) return GNF_EWS;
-  if (B == 0) return 0;
+  if (B == 0 && !plan) return 0;                          // (with a plan: table, plan and its flag are still written)
   hipStream_t s = (hipStream_t)stream;
   int rc = 0;
   if (plan) {
@@ -598,16 +615,16 @@ int gnf_dag_gate_fwd_plan(const float* x, const float* A, float* e, int64_t ld_e
   if (rc) return rc;
   GateArgs a{};
   a.x = x; a.tab = ws; a.e = e; a.ld_e = ld_e; a.gate_mode = gate_mode; a.T = temperature; a.u1 = u1; a.u2 = u2;
-  a.seed = seed; a.offset = offset; a.hot = hot; a.B = B; a.d = d;
+  a.seed = seed; a.offset = offset; a.hot = hot; a.B = B; a.d = d; a.plan = plan;
   const int64_t nc = bwd_chunks(B, d);
-  a.chunk = (B + nc - 1) / nc;
+  a.chunk = B > 0 ? (B + nc - 1) / nc : 1;
   const unsigned gxp = (unsigned)((d * ((d + 3) / 4) + kBlock - 1) / kBlock);
   hipLaunchKernelGGL(dag_gate_fwd_k, dim3(gxp, (unsigned)nc), dim3(kBlock), 0, s, a);
   GNF_LAUNCH_CHECK();
   return 0;
 }
 
-int64_t gnf_dag_gate_plan_bytes(int64_t d) { return (d + (d * KC + 1) / 2) * (int64_t)sizeof(int32_t); }
+int64_t gnf_dag_gate_plan_bytes(int64_t d) { return (d + (d * KC + 1) / 2 + 1) * (int64_t)sizeof(int32_t); }
 
 // chunks of the sample loop of the compact (i, slot)-threaded kernel: ~2048 workgroups
 inline int64_t sp_chunk(int64_t B, int64_t d) {
@@ -625,14 +642,14 @@ inline int64_t sp_chunks(int64_t B, int64_t d) {
 }
 
 int64_t gnf_dag_gate_bwd_cols_ws_bytes(int64_t B, int64_t d) {
-  // the dense layout (the fallback runs in it) | compact chunk partials [nc_sp d KC] | flag
+  // the dense layout (the fallback runs in it) | compact chunk partials [nc_sp d KC]
   return gnf_dag_gate_bwd_ws_bytes(B, d) + (sp_chunks(B, d) * d * KC + 4) * (int64_t)sizeof(float);
 }
 
 int gnf_dag_gate_bwd_cols(const float* x, const float* ge, const float* ge_cols, const int32_t* plan, int imp_mode,
                           int gate_mode, float temperature, const float* u1, const float* u2, uint64_t seed,
-                          uint64_t offset, const float* tab_fwd, float* gA, float* ws, int64_t B, int64_t d,
-                          gnf_stream_t stream) {
+                          uint64_t offset, const float* tab_fwd, float* gA, int accumulate, float* ws, int64_t B,
+                          int64_t d, gnf_stream_t stream) {
   if (((!x || !ge || !ge_cols) && B > 0) || !plan || !tab_fwd || !gA || !ws || B < 0 || d <= 0 || imp_mode < 0 ||
       imp_mode > 3 || gate_mode < 0 || gate_mode > 2)
     return GNF_EINVAL;
@@ -643,21 +660,19 @@ int gnf_dag_gate_bwd_cols(const float* x, const float* ge, const float* ge_cols,
   GateArgs a{};
   a.x = x; a.tab = tab_fwd; a.ge = ge; a.ld_e = d; a.gate_mode = gate_mode; a.T = temperature; a.u1 = u1; a.u2 = u2;
   a.seed = seed; a.offset = offset; a.B = B; a.d = d; a.gA = gA; a.ws = ws + 4 * d * d;
-  a.plan = plan; a.gec = ge_cols;
+  a.plan = const_cast<int32_t*>(plan); a.gec = ge_cols;
   const int64_t nc = bwd_chunks(B, d);
   a.chunk = B > 0 ? (B + nc - 1) / nc : 1;
   a.chunk_sp = sp_chunk(B, d);
   const int64_t ncs = sp_chunks(B, d);
   float* tail = ws + gnf_dag_gate_bwd_ws_bytes(B, d) / (int64_t)sizeof(float);
   a.part_sp = tail;
-  a.flag = reinterpret_cast<int*>(tail + ncs * d * KC);
   const unsigned gxp = (unsigned)((d * ((d + 3) / 4) + kBlock - 1) / kBlock);
   const unsigned gxs = (unsigned)((d * KC + kBlock - 1) / kBlock);
   hipLaunchKernelGGL(dag_gate_bwd_dp_plan_k, dim3(gxs * (unsigned)ncs), dim3(kBlock), 0, s, a, gxp, (unsigned)nc, gxs);
   GNF_LAUNCH_CHECK();
-  const unsigned gx4 = (unsigned)(((d * d + 3) / 4 + kBlock - 1) / kBlock);
-  hipLaunchKernelGGL(dag_gate_bwd_dA_plan_k, dim3(gx4), dim3(kBlock), 0, s, tab_fwd, (const float*)a.ws, (int)nc,
-                     (const float*)a.part_sp, (int)ncs, plan, (const int*)a.flag, gA, d);
+  hipLaunchKernelGGL(dag_gate_bwd_dA_plan_k, dim3((unsigned)d), dim3(kBlock), 0, s, tab_fwd, (const float*)a.ws, (int)nc,
+                     (const float*)a.part_sp, (int)ncs, plan, gA, accumulate, d);
   GNF_LAUNCH_CHECK();
   return 0;
 }

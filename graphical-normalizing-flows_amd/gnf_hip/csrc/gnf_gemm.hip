@@ -739,6 +739,7 @@ int gnf_gemm_launch(GemmArgs g, int splits, hipStream_t s) {
   // both operands k-major, M <= 128, a long K per split, plain partial / plain output (fc1 weight gradient)
   if (g.sam == 1 && g.sbn == 1 && g.scn == 1 && g.M <= 128 && g.M % 4 == 0 && !g.grp && !g.bias && !g.Bmask && !g.Cmask && !g.gate &&
       g.flags == 0 && g.N % 4 == 0 && g.sak % 4 == 0 && g.sbk % 4 == 0 && g.scm % 2 == 0 && g.k_per_split >= 512 &&
+      g.sak >= g.M && g.sbk >= g.N &&       // rows past a K range must lie past the descriptor's extent (they read as zeros)
       (((uintptr_t)g.A | (uintptr_t)g.B) & 15) == 0 && (((uintptr_t)g.C | (uintptr_t)(g.c_split_stride * 4)) & 7) == 0 &&
       g.k_per_split * (g.sak > g.sbk ? g.sak : g.sbk) < (1 << 28) && ((g.N + KMN - 1) / KMN) * nsp >= 64 && nsp <= 4096) {
     static const bool no_km = getenv("GNF_GEMM_KMAJOR") && getenv("GNF_GEMM_KMAJOR")[0] == '0';      // A/B switch
@@ -851,7 +852,7 @@ int gnf_gemm_grouped_launch(GemmArgs g, int ngroups, hipStream_t s) {
 }
 
 // split-K plan of the public entry: few output tiles and a long K -> spread K over the chip
-static int plan_splits(int64_t M, int64_t N, int64_t K) {
+static int plan_splits(int64_t M, int64_t N, int64_t K, bool kmajor_ok = true) {
   if (M <= 0 || N <= 0 || K <= 0) return 1;  // empty operands (a zero-row batch): nothing to split
   // Fewer 64x64 output tiles than ~3/4 of the CUs: split K until the chip is covered, at least 128 of K per split.
   // (The MADE layers at B = 100 are 2 x 16 tiles with K = 1024: unsplit they ran on 32 of the 256 CUs.)
@@ -864,7 +865,7 @@ static int plan_splits(int64_t M, int64_t N, int64_t K) {
   // M <= 128 over a very long K (fc1 weight gradient 128 x 2304 x 78 400): gemm_kmajor_k runs ONE 128-KB-LDS workgroup per
   // CU, so as many (tile, split) pairs as CUs: 18 tiles x 14 splits (the generic kernels took 36 splits: 3 x the partials)
   static const bool no_km_plan = getenv("GNF_GEMM_KMAJOR") && getenv("GNF_GEMM_KMAJOR")[0] == '0';
-  if (M <= 128 && N % 4 == 0 && N >= 512 && K >= 16384 && !no_km_plan) {
+  if (M <= 128 && N % 4 == 0 && N >= 512 && K >= 16384 && !no_km_plan && kmajor_ok) {
     int64_t s = 256 / ((N + 127) / 128);
     if (s > K / 512) s = K / 512;
     if (s >= 2) return (int)s;
@@ -882,8 +883,10 @@ static int plan_splits(int64_t M, int64_t N, int64_t K) {
   return s < 2 ? 1 : (int)s;
 }
 
+// (sized without knowing the strides: the larger of the k-major plan and the generic one)
 extern "C" int64_t gnf_gemm_ws_bytes(int64_t M, int64_t N, int64_t K) {
-  const int s = plan_splits(M, N, K);
+  const int a = plan_splits(M, N, K, true), b = plan_splits(M, N, K, false);
+  const int s = a > b ? a : b;
   return s > 1 ? (int64_t)(s + 1) * M * N * (int64_t)sizeof(float) : 0;     // partials + one row for their sum
 }
 
@@ -896,7 +899,12 @@ extern "C" int gnf_gemm(const float* A, int64_t sam, int64_t sak, const float* B
   if (!C || ((!A || !B) && K > 0)) return GNF_EINVAL;   // K == 0 (an empty batch as the contraction): C = epilogue(0)
   GemmArgs g{A, sam, sak, B, Bmask, sbk, sbn, C, scm, scn, bias, Cmask, scmm, scmn, gate, sgm, sgn,
              flags & GNF_GEMM_RELU, M, N, K, 0, 0};
-  const int splits = plan_splits(M, N, K);
+  // the few long splits of the k-major plan only for operands gemm_kmajor_k takes (the launcher's predicate on strides and
+  // alignment); anything else gets the generic kernels' tuned count
+  const bool km_ok = sam == 1 && sbn == 1 && scn == 1 && M % 4 == 0 && sak % 4 == 0 && sbk % 4 == 0 && sak >= M && sbk >= N &&
+                     !bias && !Bmask && !Cmask && !gate && !(flags & GNF_GEMM_RELU) &&
+                     (((uintptr_t)A | (uintptr_t)B) & 15) == 0;
+  const int splits = plan_splits(M, N, K, km_ok);
   if (splits > 1 && ws && ws_bytes >= gnf_gemm_ws_bytes(M, N, K)) {
     GemmArgs p = g;                       // partial products only: epilogue runs in the reduction
     p.C = ws; p.scm = N; p.scn = 1; p.c_split_stride = M * N;

@@ -624,17 +624,13 @@ __device__ __forceinline__ void cnn_bwd_body(const CnnArgs& a, float* smem) {
   }
 }
 
-// With a plan: compact de unless one of its rows holds more than KC columns -- decided here, on the device, by every
-// workgroup from the plan's counts (the gate backward takes the same decision from the same counts).
+// With a plan: compact de unless one of its rows holds more than KC columns -- decided on the device from the plan's
+// overflow word (the gate backward takes the same decision from the same word).
 __global__ __launch_bounds__(64 * BWD_WAVES) void cnn_bwd_wino_k(CnnArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  if (a.plan) {
-    int over = 0;
-    for (int t = threadIdx.x; t < a.dplan; t += 64 * BWD_WAVES) over |= a.plan[t] > KC;
-    if (!__syncthreads_or(over)) {
-      cnn_bwd_body<true>(a, smem);
-      return;
-    }
+  if (a.plan && a.plan[a.dplan + (a.dplan * KC + 1) / 2] == 0) {   // the plan's overflow word (gnf_hip.h)
+    cnn_bwd_body<true>(a, smem);
+    return;
   }
   cnn_bwd_body<false>(a, smem);
 }

@@ -905,6 +905,56 @@ __global__ void nll_mean_bwd_k(const float* __restrict__ g, float* __restrict__ 
   }
 }
 
+// The same term computed from z ITSELF: out = addend - mean_b(logdet[b] + logN(z[b,:])), logN(z) = -1/2 sum_i (log 2 pi + z_i^2)
+// (NormalizingFlowFactories.py:15-16).  The loss reads the z it is handed -- not a density some earlier kernel reduced from
+// what z held at that time -- so a z rewritten in any way between forward and loss (in place, through .data, by a raw
+// pointer) is simply the z that is scored, as in the reference.  One workgroup: sum_b logdet and the FLAT sum of z^2 over
+// all B*d elements (no row structure is needed for the mean), fixed summation order.  For B*d <= kLossFlatMax; larger
+// batches take the row kernel + nll_mean_k.
+constexpr int64_t kLossFlatMax = (int64_t)1 << 20;
+__global__ __launch_bounds__(1024) void nll_loss_k(const float* __restrict__ z, const float* __restrict__ logdet,
+                                                   const float* __restrict__ addend, float* __restrict__ out, int64_t B,
+                                                   int64_t d) {
+  __shared__ float red[2][16];
+  const int64_t n = B * d;
+  float s = 0.f, q0 = 0.f, q1 = 0.f, q2 = 0.f, q3 = 0.f;
+  for (int64_t b = threadIdx.x; b < B; b += 1024) s += logdet[b];
+  const bool vec = (reinterpret_cast<uintptr_t>(z) & 15) == 0;
+  const int64_t n4 = vec ? n / 4 : 0;
+  for (int64_t i = threadIdx.x; i < n4; i += 1024) {
+    const float4 v = reinterpret_cast<const float4*>(z)[i];
+    q0 = fmaf(v.x, v.x, q0); q1 = fmaf(v.y, v.y, q1); q2 = fmaf(v.z, v.z, q2); q3 = fmaf(v.w, v.w, q3);
+  }
+  for (int64_t i = 4 * n4 + threadIdx.x; i < n; i += 1024) q0 = fmaf(z[i], z[i], q0);
+  float q = (q0 + q1) + (q2 + q3);
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) { s += __shfl_xor(s, off, GNF_WAVE); q += __shfl_xor(q, off, GNF_WAVE); }
+  if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = s; red[1][threadIdx.x >> 6] = q; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float ts = 0.f, tq = 0.f;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) { ts += red[0][w]; tq += red[1][w]; }
+    const float logn = -.5f * ((float)d * (float)B * 1.8378770664093453f + tq);      // log(2 pi)
+    const float nll = -(ts + logn) / (float)B;
+    out[0] = addend ? addend[0] + nll : nll;
+  }
+}
+// its cotangents: gz[b,i] = g z[b,i] / B, glogdet[b] = -g / B (g: device scalar)
+__global__ void nll_loss_bwd_k(const float* __restrict__ g, const float* __restrict__ z, float* __restrict__ gz,
+                               float* __restrict__ glogdet, int64_t B, int64_t d) {
+  const float v = g[0] / (float)B;
+  const int64_t n = B * d, stride = (int64_t)gridDim.x * blockDim.x, t0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  for (int64_t b = t0; b < B; b += stride) glogdet[b] = -v;
+  const bool vec = ((reinterpret_cast<uintptr_t>(z) | reinterpret_cast<uintptr_t>(gz)) & 15) == 0;
+  const int64_t n4 = vec ? n / 4 : 0;
+  for (int64_t i = t0; i < n4; i += stride) {
+    const float4 a = reinterpret_cast<const float4*>(z)[i];
+    reinterpret_cast<float4*>(gz)[i] = make_float4(v * a.x, v * a.y, v * a.z, v * a.w);
+  }
+  for (int64_t i = 4 * n4 + t0; i < n; i += stride) gz[i] = v * z[i];
+}
+
 // ------------------------------------------------------------------ column sums
 // stage 1: block (bx, by) sums rows [by*R, by*R+R) of column tile bx into ws[by][n];
 // stage 2: sums the gridDim.y partials.  Fixed order -> bit-reproducible.
@@ -1239,6 +1289,27 @@ int gnf_nll_mean_bwd(const float* g, float* glogdet, float* glogn, int64_t B, gn
   int64_t grid = (B + kBlock - 1) / kBlock;
   if (grid > 1024) grid = 1024;
   hipLaunchKernelGGL(nll_mean_bwd_k, dim3((unsigned)grid), dim3(kBlock), 0, (hipStream_t)stream, g, glogdet, glogn, B);
+  GNF_LAUNCH_CHECK();
+  return 0;
+}
+
+int64_t gnf_nll_loss_max_elems(void) { return kLossFlatMax; }
+
+int gnf_nll_loss_fwd(const float* z, const float* logdet, const float* addend, float* out, int64_t B, int64_t d,
+                     gnf_stream_t stream) {
+  if (B <= 0 || d <= 0 || !z || !logdet || !out) return GNF_EINVAL;
+  if (B * d > kLossFlatMax) return GNF_ESHAPE;
+  hipLaunchKernelGGL(nll_loss_k, dim3(1), dim3(1024), 0, (hipStream_t)stream, z, logdet, addend, out, B, d);
+  GNF_LAUNCH_CHECK();
+  return 0;
+}
+
+int gnf_nll_loss_bwd(const float* g, const float* z, float* gz, float* glogdet, int64_t B, int64_t d, gnf_stream_t stream) {
+  if (B <= 0 || d <= 0 || !g || !z || !gz || !glogdet) return GNF_EINVAL;
+  int64_t grid = (B * d / 4 + kBlock - 1) / kBlock;
+  if (grid > 2048) grid = 2048;
+  if (grid < 1) grid = 1;
+  hipLaunchKernelGGL(nll_loss_bwd_k, dim3((unsigned)grid), dim3(kBlock), 0, (hipStream_t)stream, g, z, gz, glogdet, B, d);
   GNF_LAUNCH_CHECK();
   return 0;
 }

@@ -322,7 +322,8 @@ class GraphedStep:
         for c in self.flow.getConditioners():
             fp.append((getattr(c, "exponent", None), getattr(c, "stoch_gate", None), getattr(c, "noise_gate", None),
                        getattr(c, "s_thresh", None), float(getattr(c, "h_thresh", 0.)), getattr(c, "alpha_factor", None),
-                       tuple((id(b), b._version) for b in c.buffers(recurse=False))))   # (version: the constraint term of a
+                       tuple((id(b), b._version) for b in c.buffers(recurse=False)),    # (version: the constraint term of a
+                       getattr(c, "_cache_epoch", 0)))
             # frozen gate is a constant baked into the capture, DAGConditioner.loss)
         for nrm in self.flow.getNormalizers():
             fp.append(getattr(nrm, "nb_steps", None))

@@ -65,15 +65,16 @@ def _close_slots():
     _open_slots.clear()
 
 
-def grad_out_shared(p):
-    """(tensor, finish) for a parameter that receives SEVERAL gradient contributions per backward (the DAG matrix A: gate
+def grad_out_shared(p, accumulate_ok=False):
+    """(tensor, finish, accumulate) for a parameter that receives SEVERAL gradient contributions per backward (the DAG matrix A: gate
     and acyclicity term).  The first contribution takes the flat-buffer slot as grad_out does; a later one OF THE SAME
     BACKWARD PASS is written to a scratch tensor and finish() adds it INTO the slot and returns None, so autograd sees one
     contribution -- the slot -- instead of summing two tensors into a third that the gradient pack then copies (add +
     2.4 MB copy per cfg4 step).  "Same pass" is tracked by a callback the autograd engine runs when the pass ends: a slot
     left taken by an earlier pass (a backward without a gradient pack behind it, a previous micro-batch) is never added
     into -- that contribution gets a fresh tensor and autograd sums as usual.  finish(t) returns what the backward hands
-    to autograd."""
+    to autograd.  accumulate_ok: the caller's kernel can add into its output; a later contribution then gets the slot
+    itself with accumulate = True (no scratch tensor, no add launch)."""
     ent = _grad_slots.get(p.data_ptr()) if _SINK else None
     owner = ent[0]() if ent is not None else None
     if owner is not None:
@@ -86,13 +87,16 @@ def grad_out_shared(p):
                 if not _open_slots:
                     torch.autograd.Variable._execution_engine.queue_callback(_close_slots)
                 _open_slots.add(key)
-                return v.view(p.shape), (lambda t: t)
+                return v.view(p.shape), (lambda t: t), False
             if key in _open_slots:
+                if accumulate_ok:                                   # the caller's kernel adds INTO the slot itself
+                    return v.view(p.shape), (lambda t: None), True
+
                 def finish(t, v=v):
                     v.add_(t.reshape(-1))
                     return None
-                return torch.empty_like(p), finish
-    return torch.empty_like(p), (lambda t: t)
+                return torch.empty_like(p), finish, False
+    return torch.empty_like(p), (lambda t: t), False
 
 
 # ----------------------------------------------------------------------------- Affine normalizer
@@ -236,25 +240,39 @@ class NllMeanFn(torch.autograd.Function):
         return gl, gn, (g if len(ctx.needs_input_grad) > 2 and ctx.needs_input_grad[2] else None)
 
 
-def stash_logn(z, logn):
-    """remember the Normal log-density that was reduced in the pass producing z; NormalLogDensity picks it up when it is
-    handed the very same tensor (flow.loss(z, logdet) right after flow(x)) instead of reading z again"""
-    z._gnf_logn = (logn, z._version, z.data_ptr())
-    return z
+class NllLossFn(torch.autograd.Function):
+    """addend - (logdet + logN(z)).mean() with the Normal log-density computed from z ITSELF inside the loss launch
+    (FCNormalizingFlow.loss, models/NormalizingFlow.py:144-146 with NormalizingFlowFactories.py:15-16): one launch each
+    way.  Until round 4 the density was reduced by the kernel that produced z and remembered on the tensor; a z rewritten
+    through `.data` (no version bump) was then scored with the old density.  Now the loss reads the z it is handed."""
+
+    @staticmethod
+    def forward(ctx, z, logdet, addend=None):
+        z, logdet = z.contiguous(), logdet.contiguous()
+        B, d = z.shape
+        out = _empty((), z)
+        call("gnf_nll_loss_fwd", ptr(z), ptr(logdet), ptr(addend), ptr(out), B, d, stream())
+        ctx.save_for_backward(z)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        z, = ctx.saved_tensors
+        B, d = z.shape
+        gz, gl = _empty((B, d), z), _empty((B,), z)
+        call("gnf_nll_loss_bwd", ptr(g.contiguous()), ptr(z), ptr(gz), ptr(gl), B, d, stream())
+        return gz, gl, (g if len(ctx.needs_input_grad) > 2 and ctx.needs_input_grad[2] else None)
 
 
-def cached_logn(z):
-    """the stashed density, or None when z is not the untouched tensor it was reduced from: an in-place update
-    (z.add_(..), clamp_) bumps z._version and keeps the Python attribute, so the stash alone would be stale
-    (reference: NormalizingFlowFactories.py:15-16 always reads the z it is handed)"""
-    st = getattr(z, "_gnf_logn", None)
-    if st is None:
-        return None
-    logn, version, data_ptr = st
-    if z._version != version or z.data_ptr() != data_ptr:
-        z._gnf_logn = None
-        return None
-    return logn
+_LOSS_MAX = None
+
+
+def nll_loss_fits(z):
+    """True when NllLossFn takes this z (one workgroup reads all of it: up to 2^20 elements)"""
+    global _LOSS_MAX
+    if _LOSS_MAX is None:
+        _LOSS_MAX = int(abi.load().gnf_nll_loss_max_elems())
+    return z.dim() == 2 and 0 < z.numel() <= _LOSS_MAX
 
 
 def colsum(a):
@@ -580,7 +598,7 @@ class DagGateFn(torch.autograd.Function):
         imp_mode, gate_mode, h_thresh, temperature, ld, seed, offset = ctx.cfg
         B, d = x.shape
         ge = ge.contiguous()
-        gA, finish = grad_out_shared(A) if ctx.needs_input_grad[1] else (None, None)
+        gA, finish, _ = grad_out_shared(A) if ctx.needs_input_grad[1] else (None, None, False)
         gx = _empty((B, d), x) if ctx.needs_input_grad[0] else None
         ws = _ws(abi.load().gnf_dag_gate_bwd_ws_bytes(B, d), x)
         call("gnf_dag_gate_bwd", ptr(x), ptr(A), ptr(ge), ld, imp_mode, gate_mode, h_thresh, temperature, ptr(u1),
@@ -646,12 +664,13 @@ class DagConvFrontFn(torch.autograd.Function):
         call("gnf_mnistcnn_conv_bwd_cols", ptr(e), ptr(W1), ptr(b1), ptr(W2), ptr(gp), abi.rawptr(arg), ptr(ge),
              abi.rawptr(plan) if plan is not None else None, d, ptr(gec), ptr(gW1), ptr(gb1), ptr(gW2), ptr(gb2),
              abi.rawptr(ws), nws, n, stream())
-        gA, finish = grad_out_shared(A) if ctx.needs_input_grad[1] else (None, None)
+        gA, finish, acc = (grad_out_shared(A, accumulate_ok=plan is not None) if ctx.needs_input_grad[1]
+                           else (None, None, False))
         gx = _empty((B, d), x) if ctx.needs_input_grad[0] else None
         if plan is not None:
             ws2 = _ws(lib.gnf_dag_gate_bwd_cols_ws_bytes(B, d), x)
             call("gnf_dag_gate_bwd_cols", ptr(x), ptr(ge), ptr(gec), abi.rawptr(plan), imp_mode, gate_mode, temperature,
-                 ptr(u1), ptr(u2), seed, offset, ptr(ctx.tab), ptr(gA), ptr(ws2), B, d, stream())
+                 ptr(u1), ptr(u2), seed, offset, ptr(ctx.tab), ptr(gA), int(acc), ptr(ws2), B, d, stream())
         elif gA is not None or gx is not None:
             ws2 = _ws(lib.gnf_dag_gate_bwd_ws_bytes(B, d), x)
             call("gnf_dag_gate_bwd", ptr(x), ptr(A), ptr(ge), d, imp_mode, gate_mode, h_thresh, temperature, ptr(u1),
@@ -930,6 +949,6 @@ class DagLossFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         A, P, out4 = ctx.saved_tensors
-        gA, finish = grad_out_shared(A)
+        gA, finish, _ = grad_out_shared(A)
         call("gnf_dag_loss_bwd", ptr(A), ptr(P), ptr(out4), ptr(g.contiguous().reshape(1)), ptr(gA), A.shape[0], stream())
         return finish(gA), None, None, None, None, None, None, None

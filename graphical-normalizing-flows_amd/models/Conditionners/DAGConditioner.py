@@ -85,10 +85,32 @@ class DAGConditioner(Conditioner):
         self._sparse_checked = (None, False)
         self._off_key, self._off = None, False
         self._frozen_loss = (None, None)   # (state key, value) of the constraint term while A is frozen
+        self._cache_epoch = 0              # bumped by invalidate_caches(): part of every value-dependent cache key
         self._sparse_plans = {}
         self.gate_noise = None          # (u1, u2) [B,d,d] uniforms (test hook); None -> Philox
         self._gate_calls = 0
         self.gate_seed = int(torch.randint(0, 2 ** 31 - 1, (1,)).item())
+
+    def invalidate_caches(self):
+        """Forget everything this conditioner remembers ABOUT THE VALUES of A and of its dual buffers: the "A is windowed"
+        verdict of the sparse front, the "constraints are switched off" verdict, the constraint term of a frozen gate,
+        and (through `_cache_epoch`, part of their keys) the level schedule of NormalizingFlowStep.invert, its captured
+        sampling graphs and the captured steps of gnf_hip.dp.GraphedStep.
+
+        These caches are keyed on autograd's version counters and on storage addresses, which every in-place torch op
+        moves -- but a write through `.data` (`cond.A.data.mul_(.5)`, the idiom of the reference's own
+        DAGConditioner.py:89 and of torch-1.5-era callers) or through a raw pointer moves neither.  Every writer inside
+        this package calls this method (post_process, constrainA, the dual update, load_state_dict, the epoch-level
+        step()); a caller that edits a FROZEN A or a dual buffer behind autograd's back must call it too.  A trainable A
+        is never cached (the optimiser rewrites it every step)."""
+        self._cache_epoch = getattr(self, "_cache_epoch", 0) + 1
+        self._sparse_checked = (None, False)
+        self._off_key, self._off = None, False
+        self._frozen_loss = (None, None)
+
+    def _load_from_state_dict(self, *args, **kwargs):
+        super()._load_from_state_dict(*args, **kwargs)       # copies into A and the buffers through .data-like paths
+        self.invalidate_caches()
 
     def getAlpha(self):
         # the reference computes an SVD here and discards it (:66-71); alpha = 1/d
@@ -161,7 +183,7 @@ class DAGConditioner(Conditioner):
         # frozen one (post_process) only when its storage or version counter changed, so that a training step with
         # the frozen gate has no host synchronisation in it.
         key = None if self.A.requires_grad else (self.A.data_ptr(), self.A._version, float(self.h_thresh),
-                                                 bool(self.s_thresh))
+                                                 bool(self.s_thresh), self._cache_epoch)
         if key is None or key != self._sparse_checked[0]:
             if self._sparse_outside is None or self._sparse_outside.device != P.device:
                 self._sparse_outside = (~ops.mnist_window_mask(P.device)).float()
@@ -207,6 +229,7 @@ class DAGConditioner(Conditioner):
     def constrainA(self, zero_threshold=.0001):
         self.A *= (self.A.clone().abs() > zero_threshold).float()
         self.A *= 1. - torch.eye(self.in_size, device=self.A.device)
+        self.invalidate_caches()
         return
 
     def get_power_trace(self):
@@ -223,7 +246,7 @@ class DAGConditioner(Conditioner):
         """True once update_dual_param() has switched both terms off (dag_const = 0 and l1_weight = 0, reference
         :249-251): loss() is then identically 0 and its matrix power is skipped.  One host read per CHANGE of the two
         buffers (they are replaced / rewritten at epoch level only), none per step."""
-        key = (id(self.dag_const), self.dag_const._version, id(self.l1_weight), self.l1_weight._version)
+        key = (id(self.dag_const), self.dag_const._version, id(self.l1_weight), self.l1_weight._version, self._cache_epoch)
         if self._off_key != key:
             self._off_key = key
             self._off = bool(((self.dag_const == 0) & (self.l1_weight == 0)).item())
@@ -242,7 +265,8 @@ class DAGConditioner(Conditioner):
                 # of a 2.96 ms cfg4 step after the DAG phase) is evaluated once per state of (A, the dual buffers, exponent)
                 # and the same value is returned until one of them changes (version counters, as in _constraints_off)
                 bufs = (self.A, self.alpha, self.lambd, self.c, self.dag_const, self.l1_weight)
-                key = tuple((id(t), t.data_ptr(), t._version) for t in bufs) + (int(self.exponent), float(self.alpha_factor))
+                key = tuple((id(t), t.data_ptr(), t._version) for t in bufs) + (int(self.exponent), float(self.alpha_factor),
+                                                                                  self._cache_epoch)
                 if self._frozen_loss[0] != key:
                     with torch.no_grad():
                         val = ops.DagLossFn.apply(self.A, self.alpha, self.alpha_factor, self.lambd, self.c, self.dag_const,
@@ -274,6 +298,7 @@ class DAGConditioner(Conditioner):
                          * (1. - torch.eye(self.in_size, device=self.A.device)))
         self.A.requires_grad = False
         self.A.grad = None
+        self.invalidate_caches()
 
     def _reopen(self, A=None):
         self.stoch_gate = True
@@ -288,6 +313,7 @@ class DAGConditioner(Conditioner):
                 self.A.copy_(A)
         self.A.requires_grad = True
         self.A.grad = None               # the reference parks A.clone() here until its next zero_grad() (:226,244)
+        self.invalidate_caches()
         self._set("alpha", self.getAlpha())
         self._set("prev_trace", self.get_power_trace().detach())
 
@@ -298,9 +324,11 @@ class DAGConditioner(Conditioner):
         buf = getattr(self, name)
         with torch.no_grad():
             buf.copy_(torch.as_tensor(value, dtype=buf.dtype, device=buf.device))
+        self.invalidate_caches()
 
     def update_dual_param(self):
         """Augmented-Lagrangian update of (lambd, c) / post-processing (:196-260)."""
+        self.invalidate_caches()             # epoch-level decisions are taken on freshly evaluated values
         with torch.no_grad():
             lag_const = self.get_power_trace()
             while self.dag_const > 0. and lag_const < self.tol and self.exponent < self.in_size:
@@ -397,6 +425,7 @@ class DAGConditioner(Conditioner):
 
     def step(self, epoch_number, loss_avg=0.):
         """Once per epoch (:273-293): exponent back-off and dual update schedule."""
+        self.invalidate_caches()             # whatever was written since the last epoch, however: decide on fresh values
         with torch.no_grad():
             lag_const = self.get_power_trace()
             if lag_const > 50:

@@ -19,10 +19,9 @@ class AffineNormalizer(Normalizer):
         return z, jac
 
     def forward_logdet(self, x, h, context=None):
-        """(z, log|det J|) with the row reduction fused (used by NormalizingFlowStep); the same pass also reduces the Normal
-        log-density of z, which NormalLogDensity picks up when flow.loss() hands it this z (ops.stash_logn)."""
-        z, _, logdet, logn = ops.AffineFn.apply(x, h, self.inplace_clamp, False, True)
-        return ops.stash_logn(z, logn), logdet
+        """(z, log|det J|) with the row reduction fused into the kernel that computes z (used by NormalizingFlowStep)"""
+        z, _, logdet, _ = ops.AffineFn.apply(x, h, self.inplace_clamp, False, False)
+        return z, logdet
 
     def inverse_transform(self, z, h, context=None):
         return ops.affine_inverse(z, h)

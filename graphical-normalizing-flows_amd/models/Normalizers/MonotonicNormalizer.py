@@ -81,15 +81,12 @@ class MonotonicNormalizer(Normalizer):
 
     def forward_logdet(self, x, h, context=None):
         """(z, log|det J|) for NormalizingFlowStep: the integrand kernels emit z and jac per element (a row's elements are
-        spread over wavefronts and workgroups), so the step's tail -- log(jac).sum(1) and the Normal log-density of z --
-        is ONE reduction pass over both (gnf_nll_reduce) instead of two kernels re-reading jac and z; the density is
-        handed to NormalLogDensity through ops.stash_logn."""
+        spread over wavefronts and workgroups), log(jac).sum(1) is one reduction pass behind them"""
         out = self.forward(x, h, context)
         if out is None:
             return None
         z, jac = out
-        logdet, logn = ops.NllReduceFn.apply(z, jac)
-        return ops.stash_logn(z, logn), logdet
+        return z, ops.LogSumRowsFn.apply(jac)
 
     def inverse_transform(self, z, h, context=None):
         with torch.no_grad():

@@ -98,8 +98,13 @@ class NormalizingFlowStep(NormalizingFlow):
         thresholds changed: DAGConditioner.levels() copies the 784 x 784 adjacency to the host and walks it in Python
         (a few ms per call, a host synchronisation in front of every sampling pass otherwise)"""
         cond = self.conditioner
-        key = (cond.A.data_ptr(), cond.A._version, float(cond.h_thresh), bool(cond.s_thresh), cond.A.device)
-        if getattr(self, "_levels_key", None) != key:
+        # A trainable A is rewritten by the optimiser through a raw pointer (gnf_hip.dp: fused Adam on the flat buffer, a
+        # replayed hipGraph), which moves neither its version counter nor its address: nothing is cached for it.  A frozen
+        # one is keyed on (storage, version, thresholds, the conditioner's cache epoch -- see invalidate_caches()).
+        key = (None if cond.A.requires_grad else
+               (cond.A.data_ptr(), cond.A._version, float(cond.h_thresh), bool(cond.s_thresh), cond.A.device,
+                getattr(cond, "_cache_epoch", 0)))
+        if key is None or getattr(self, "_levels_key", None) != key:
             lv = cond.levels(importance, with_host=True)
             if lv is not None and cond.A.shape[0] == 784:
                 # the order of the variables INSIDE a level is free: take the one the sparse embedding kernels work in (crop
@@ -162,7 +167,10 @@ class NormalizingFlowStep(NormalizingFlow):
         levels, lkey = self._levels(importance)
         if levels is None:
             return None
+        # a captured pass bakes the ADDRESS of the importance matrix in: only A itself qualifies -- the thresholded forms
+        # (s_thresh / h_thresh > 0, the state the reference's threshold sweep sets) are temporaries freed after this call
         graphable = (self.graph_invert and z.is_cuda and not cond.A.requires_grad and z.dtype == torch.float32
+                     and importance.data_ptr() == cond.A.data_ptr()
                      and len(levels) > 4 and not torch.cuda.is_current_stream_capturing())
         if not graphable:
             return self._invert_levels_body(z, levels, importance, context)
@@ -174,6 +182,8 @@ class NormalizingFlowStep(NormalizingFlow):
         entry = graphs.get(key)
         if entry is None:                               # first request: eager (workspaces, plans and tables come to exist)
             graphs[key] = "warm"
+            return self._invert_levels_body(z, levels, importance, context)
+        if entry == "eager":                            # a capture of this variant failed once: launch by launch from then on
             return self._invert_levels_body(z, levels, importance, context)
         if entry == "warm":
             import gc
@@ -195,16 +205,23 @@ class NormalizingFlowStep(NormalizingFlow):
             gc_was_on = gc.isenabled()
             gc.collect()
             gc.disable()                                # no finaliser may run inside the capture
+            failed = None
             try:
                 with torch.cuda.graph(graph), contextlib.ExitStack() as stack:
                     for _, _, make in holders:
                         stack.enter_context(make())
                     xbuf = self._invert_levels_body(zbuf, levels, importance, context)
+            except Exception as exc:                    # noqa: BLE001  (e.g. a host synchronisation inside a user-supplied
+                failed = exc                            # integrand / embedding module): this variant stays eager
             finally:
                 if gc_was_on:
                     gc.enable()
                 for obj, attr, val in saved:
                     setattr(obj, attr, val)
+            if failed is not None:
+                graphs[key] = "eager"
+                torch.cuda.synchronize()
+                return self._invert_levels_body(z, levels, importance, context)
             if len(graphs) > self.GRAPH_INVERT_MAX:
                 graphs.clear()
             entry = graphs[key] = (graph, zbuf, xbuf)
@@ -257,16 +274,24 @@ class FCNormalizingFlow(NormalizingFlow):
         return z, logdet                         # the last step's z is returned un-flipped (:126)
 
     def loss(self, z, jac):
-        logn = self.z_log_density(z)
-        if (jac.is_cuda and jac.dim() == 1 and logn.shape == jac.shape and jac.shape[0] > 0
-                and jac.dtype == torch.float32 and logn.dtype == torch.float32):
-            c = self.constraintsLoss()
-            if isinstance(c, float) and c == 0.:
+        dens = self.z_log_density
+        fused = (z.is_cuda and jac.is_cuda and jac.dim() == 1 and z.dim() == 2 and jac.shape[0] == z.shape[0]
+                 and z.dtype == torch.float32 and jac.dtype == torch.float32)
+        c = self.constraintsLoss()
+        plain_c = isinstance(c, float) and c == 0.
+        dev_c = torch.is_tensor(c) and c.is_cuda and c.dim() == 0 and c.dtype == torch.float32
+        if fused and getattr(dens, "standard_normal", False) and ops.nll_loss_fits(z) and (plain_c or dev_c):
+            # constraints - mean(log|det J| + log N(z)) in ONE launch that reads z itself (the standard-normal base density of
+            # the factories; any other z_log_density module is called as the reference calls it)
+            return ops.NllLossFn.apply(z, jac, None if plain_c else c)
+        logn = dens(z)
+        if fused and logn.shape == jac.shape and jac.shape[0] > 0 and logn.dtype == torch.float32:
+            if plain_c:
                 return ops.NllMeanFn.apply(jac, logn)                            # -(jac + logn).mean(), one launch
-            if torch.is_tensor(c) and c.is_cuda and c.dim() == 0 and c.dtype == torch.float32:
+            if dev_c:
                 return ops.NllMeanFn.apply(jac, logn, c)                         # constraints - mean(...), the same launch
             return c + ops.NllMeanFn.apply(jac, logn)
-        return self.constraintsLoss() - (jac + logn).mean()
+        return c - (jac + logn).mean()
 
     def invert(self, z, context=None):
         """Exact inverse of forward for any number of steps.  The reference (:166-169) visits steps[-0] == steps[0]

@@ -16,15 +16,18 @@ from .MLP import MNISTCNN, CIFAR10CNN  # noqa: F401
 
 class NormalLogDensity(nn.Module):
     """Row-wise log N(z; 0, I) = -1/2 sum_d (log 2 pi + z_d^2)  (reference :10-16), one fused reduction kernel.  The
-    `pi` buffer exists only because reference checkpoints carry `z_log_density.pi`."""
+    `pi` buffer exists only because reference checkpoints carry `z_log_density.pi`.  Always computed from the z it is
+    handed; FCNormalizingFlow.loss folds this density into its own launch (gnf_hip.ops.NllLossFn) when this exact class
+    is the flow's base density."""
+
+    standard_normal = True               # FCNormalizingFlow.loss may fold this density into its own launch
 
     def __init__(self):
         super().__init__()
         self.register_buffer("pi", torch.tensor(math.pi))
 
     def forward(self, z):
-        logn = ops.cached_logn(z)                # reduced by the kernel that produced this very z (forward_logdet)
-        return logn if logn is not None else ops.NormalLogDensityFn.apply(z)
+        return ops.NormalLogDensityFn.apply(z)
 
 
 def buildFCNormalizingFlow(nb_steps, conditioner_type, conditioner_args, normalizer_type, normalizer_args):

@@ -79,6 +79,14 @@ int gnf_nll_reduce_bwd(const float* z, const float* jac, const float* glogdet, c
 int gnf_nll_mean_fwd(const float* logdet, const float* logn, const float* addend, float* out, int64_t B,
                      gnf_stream_t stream);
 int gnf_nll_mean_bwd(const float* g, float* glogdet, float* glogn, int64_t B, gnf_stream_t stream);
+/* The same loss from z itself (round 5): out[0] = addend[0] - mean_b(logdet[b] + logN(z[b,:])), logN as in
+ * NormalizingFlowFactories.py:15-16 -- the loss scores the z it is handed, whatever wrote it (no density remembered from
+ * the forward pass).  One workgroup, B*d <= gnf_nll_loss_max_elems() (GNF_ESHAPE above: use gnf_normal_logdensity_fwd +
+ * gnf_nll_mean_fwd).  bwd: gz[b,i] = g[0] z[b,i] / B, glogdet[b] = -g[0] / B. */
+int64_t gnf_nll_loss_max_elems(void);
+int gnf_nll_loss_fwd(const float* z, const float* logdet, const float* addend, float* out, int64_t B, int64_t d,
+                     gnf_stream_t stream);
+int gnf_nll_loss_bwd(const float* g, const float* z, float* gz, float* glogdet, int64_t B, int64_t d, gnf_stream_t stream);
 /* out[n] = sum_m a[m*lda + n]  (bias gradients; deterministic two-level reduction).
  * ws: >= gnf_colsum_ws_bytes(M,N) bytes. */
 int64_t gnf_colsum_ws_bytes(int64_t M, int64_t N);
@@ -171,13 +179,15 @@ int gnf_dag_gate_bwd(const float* x, const float* A, const float* ge, int64_t ld
  * gradient wanted for x the cotangent of e is only needed at the columns j of row i with dP/dA[i,j] != 0.
  *   plan (gnf_dag_gate_plan_bytes(d) bytes, written by gnf_dag_gate_fwd_plan from the very table its gate uses):
  *     int32 count[d] (columns with dP/dA != 0 in row i, also when more than GNF_DAG_PLAN_KC),
- *     int16 cols[d][GNF_DAG_PLAN_KC] (those columns in ascending order, -1 padded).
- *   Consumers (gnf_mnistcnn_conv_bwd_cols, gnf_dag_gate_bwd_cols) use the lists only if NO row overflows KC and run
+ *     int16 cols[d][GNF_DAG_PLAN_KC] (those columns in ascending order, -1 padded),
+ *     int32 overflow (1 when some count exceeds GNF_DAG_PLAN_KC).
+ *   Consumers (gnf_mnistcnn_conv_bwd_cols, gnf_dag_gate_bwd_cols) use the lists only if overflow == 0 and run
  *   their dense code otherwise; the decision is taken on the device, nothing is cached on the host.
  *   ge_cols [(B*d), GNF_DAG_PLAN_KC]: ge_cols[(b*d+i)*KC + k] = dL/de[b,i,cols[i][k]] for k < count[i].
  * gnf_dag_gate_fwd_plan = gnf_dag_gate_fwd that also writes the plan (plan == NULL: exactly gnf_dag_gate_fwd).
  * gnf_dag_gate_bwd_cols: gA only (x frozen), no one-hot columns (ld_e = d); tab_fwd (required) = the forward's ws;
- *   ge [(B*d), d] is read when the plan overflows, ge_cols otherwise. */
+ *   ge [(B*d), d] is read when the plan overflows, ge_cols otherwise; accumulate != 0: gA += (A's other contribution, the
+ *   acyclicity term's, is already there: no separate add launch). */
 #define GNF_DAG_PLAN_KC 32
 int64_t gnf_dag_gate_plan_bytes(int64_t d);
 int gnf_dag_gate_fwd_plan(const float* x, const float* A, float* e, int64_t ld_e,
@@ -189,7 +199,7 @@ int64_t gnf_dag_gate_bwd_cols_ws_bytes(int64_t B, int64_t d);
 int gnf_dag_gate_bwd_cols(const float* x, const float* ge, const float* ge_cols, const int32_t* plan,
                           int imp_mode, int gate_mode, float temperature,
                           const float* u1, const float* u2, uint64_t seed, uint64_t offset, const float* tab_fwd,
-                          float* gA, float* ws, int64_t B, int64_t d, gnf_stream_t stream);
+                          float* gA, int accumulate, float* ws, int64_t B, int64_t d, gnf_stream_t stream);
 
 /* ---- DAG acyclicity + l1 term: DAGConditioner.get_power_trace / loss (DAGConditioner.py:176-194, 268-271) --------
  * The d x d matrix power stays on the GEMM library; these entries fuse the ~40 elementwise / reduction

@@ -121,6 +121,55 @@ def test_cfg4_full_size_step_properties():
         o += (p.numel() + 3) // 4 * 4
 
 
+def test_cfg4_strong_scaling_n1_point_B800():
+    """The N = 1 point of north_star's strong-scaling curve: the global batch of 8 x 100 on ONE GPU (627 200 masked images;
+    pooled features 5.8 GB, so every kernel on the path addresses past 2^32 bytes).  Rows 0..99 of z and log|det J| equal a
+    B = 100 run with the same Philox key bit for bit (the noise counter is the row index), every gradient is finite and
+    non-zero, dA keeps its exact zeros, and a full dp.train_step moves every parameter tensor.
+    Reference: ImageExperiments.py:168,199-216 (the DataParallel batch of n_gpu x b_size rows)."""
+    from gnf_hip import dp
+    bench = _bench()
+    torch.manual_seed(0)
+    flow = bench.build_flow().to(DEV)
+    for nrm in flow.getNormalizers():
+        nrm.nb_steps = 20
+    cond = flow.steps[0].conditioner
+    x = bench.pseudo_mnist(torch.Generator().manual_seed(4321), 800, 784).to(DEV)
+    with torch.no_grad():
+        cond._gate_calls = 0
+        z1, ld1 = flow(x[:100])
+    cond._gate_calls = 0
+    z, ld = flow(x)
+    assert z.shape == (800, 784) and torch.equal(z[:100], z1) and torch.equal(ld[:100], ld1)
+    assert torch.isfinite(z).all() and torch.isfinite(ld).all()
+    loss = flow.loss(z, ld)
+    loss.backward()
+    assert torch.isfinite(loss).item()
+    for k, p in flow.named_parameters():
+        assert p.grad is not None and torch.isfinite(p.grad).all() and p.grad.abs().max() > 0, k
+    assert int(((cond.A.grad != 0) & (cond.A.detach() == 0)).sum()) == 0
+    # the last rows are computed as the first ones are: the same samples placed at the end of another batch give the same bits
+    # up to the gate noise (other row indices), so compare a deterministic-gate pass instead
+    cond.stoch_gate = False
+    with torch.no_grad():
+        za, _ = flow(x)
+        zb, _ = flow(torch.cat((x[700:], x[:100])))
+    cond.stoch_gate = True
+    assert torch.equal(za[700:], zb[:100])
+    for p in flow.parameters():
+        p.grad = None
+    del z, ld, loss, za, zb
+    state = dp.FlatState(flow)
+    before = state.flat.clone()
+    l2 = dp.train_step(flow, state, x)
+    assert torch.isfinite(l2).item() and state.t == 1
+    moved = (state.flat != before)
+    o = 0
+    for p in state.params:
+        assert moved[o:o + p.numel()].any(), "a parameter tensor did not move"
+        o += (p.numel() + 3) // 4 * 4
+
+
 def test_cfg5_full_size_monotonic_step():
     """cfg5 as BASELINE.json states it: d=63, B=50 000 on one GPU, MADE [630]*3 -> 30, Monotonic [150,150,150],
     S=20.  Properties: finite loss and gradients, loss decomposition, jac > 0.05, z(0) = h0-free check by shifting x
@@ -265,6 +314,121 @@ def test_graphed_frozen_gate_step_sees_a_rewritten_dual_buffer():
     assert abs(float(le[3] - le[2])) > 1e-3              # the change of lambd is visible in the loss at all
     for a, b in zip(pg, pe):
         assert rel_err(a.cpu(), b.cpu()) < 1e-5
+
+
+def test_data_writes_to_a_frozen_gate_need_invalidate_caches():
+    """A frozen A / a dual buffer rewritten through `.data` (reference DAGConditioner.py:89 writes A that way itself) moves
+    neither a version counter nor an address -- the keys of the conditioner's value caches.  The contract:
+    such a writer calls cond.invalidate_caches().  After it loss() is the oracle's dag_loss of the NEW values, eagerly and
+    through a replayed GraphedStep (new capture, not the stale constant); every writer inside the package (post_process,
+    constrainA, the dual update, load_state_dict, step()) invalidates by itself."""
+    from gnf_hip import dp
+    from models import buildFCNormalizingFlow, DAGConditioner, AffineNormalizer
+
+    def oracle_loss(c):
+        return O.dag_loss(c.A.detach().cpu(), c.alpha.cpu(), c.exponent, c.lambd.cpu(), c.c.cpu(), c.dag_const.cpu(),
+                          c.l1_weight.cpu())
+
+    torch.manual_seed(17)
+    f = buildFCNormalizingFlow(1, DAGConditioner, {"in_size": 10, "hidden": [32, 32], "out_size": 2, "l1": .3},
+                               AffineNormalizer, {}).to(DEV)
+    c = f.getConditioners()[0]
+    with torch.no_grad():
+        c.A.mul_(.5)
+        c.post_process(zero_threshold=.1)
+        c.lambd.fill_(.25)
+    v0 = c.loss()
+    assert rel_err(v0.cpu(), oracle_loss(c)) < TOL
+    version, address = c.A._version, c.A.data_ptr()
+    c.A.data.mul_(.5)
+    assert (c.A._version, c.A.data_ptr()) == (version, address)      # invisible to the cache keys ...
+    assert c.loss() is v0                                            # ... hence the documented stale value
+    c.invalidate_caches()
+    v1 = c.loss()
+    assert rel_err(v1.cpu(), oracle_loss(c)) < TOL and abs(float(v1 - v0)) > 1e-4
+    c.lambd.data.add_(1.)
+    c.invalidate_caches()
+    v2 = c.loss()
+    assert rel_err(v2.cpu(), oracle_loss(c)) < TOL and abs(float(v2 - v1)) > 1e-4
+    # the package's own writers invalidate by themselves
+    sd = {k: v.clone() for k, v in f.state_dict().items()}
+    sd["steps.0.conditioner.lambd"] = sd["steps.0.conditioner.lambd"] + 2.
+    f.load_state_dict(sd)
+    v3 = c.loss()
+    assert rel_err(v3.cpu(), oracle_loss(c)) < TOL and abs(float(v3 - v2)) > 1e-4
+
+    # through the captured step: the constant is baked into the graph; invalidate_caches() must force a new capture
+    xs = [torch.randn(40, 10, generator=torch.Generator().manual_seed(300 + i)).to(DEV) for i in range(6)]
+
+    def run(graph):
+        torch.manual_seed(17)
+        g = buildFCNormalizingFlow(1, DAGConditioner, {"in_size": 10, "hidden": [32, 32], "out_size": 2, "l1": .3},
+                                   AffineNormalizer, {}).to(DEV)
+        with torch.no_grad():
+            for cc in g.getConditioners():
+                cc.A.mul_(.5)
+                cc.post_process(zero_threshold=.1)
+                cc.lambd.fill_(.25)
+        st = dp.FlatState(g)
+        out = []
+        for i, x in enumerate(xs):
+            if i == 3:
+                for cc in g.getConditioners():
+                    cc.A.data.mul_(.5)
+                    cc.lambd.data.add_(2.)
+                    cc.invalidate_caches()
+            out.append(dp.train_step(g, st, x, lr=1e-2, graph="auto" if graph else False).detach().clone())
+        torch.cuda.synchronize()
+        return out
+    lg, le = run(True), run(False)
+    for a, b in zip(lg, le):
+        assert rel_err(a.cpu(), b.cpu()) < 1e-5, (lg, le)
+    assert abs(float(le[3] - le[2])) > 1e-3
+
+
+def test_level_schedule_is_not_cached_for_a_trainable_gate():
+    """with a trainable A under dp.FlatState the optimiser writes A through a raw pointer (no version bump, same
+    address): invert() must recompute the level schedule every time.  Here A changes from one DAG to another between two
+    inversions without any torch-visible write."""
+    from models import buildFCNormalizingFlow, DAGConditioner, AffineNormalizer
+    torch.manual_seed(3)
+    d = 8
+    f = buildFCNormalizingFlow(1, DAGConditioner, {"in_size": d, "hidden": [16], "out_size": 2}, AffineNormalizer, {}).to(DEV)
+    c = f.getConditioners()[0]
+    c.stoch_gate = False
+    lower = torch.tril(torch.ones(d, d), -1).to(DEV)
+    with torch.no_grad():
+        c.A.copy_(lower)
+    assert c.A.requires_grad
+    x = torch.randn(5, d, device=DEV)
+    z, _ = f(x)
+    assert rel_err(f.invert(z.detach()).cpu(), x.cpu()) < 1e-4
+    c.A.data.copy_(lower.t())                        # the reverse ordering, written behind autograd's back
+    z2, _ = f(x)
+    assert rel_err(f.invert(z2.detach()).cpu(), x.cpu()) < 1e-4
+
+
+def test_thresholded_importance_is_not_baked_into_a_sampling_graph():
+    """a frozen A with s_thresh on hands the level pass a TEMPORARY importance matrix; a captured pass would
+    replay reads of its freed address.  Such a gate must stay on the eager level pass (and still invert exactly)."""
+    from models import buildFCNormalizingFlow, DAGConditioner, AffineNormalizer
+    from models.NormalizingFlow import _INV_GRAPHS
+    torch.manual_seed(4)
+    d = 12
+    f = buildFCNormalizingFlow(1, DAGConditioner, {"in_size": d, "hidden": [16], "out_size": 2}, AffineNormalizer, {}).to(DEV)
+    c, step = f.getConditioners()[0], f.steps[0]
+    with torch.no_grad():
+        c.A.copy_(torch.tril(torch.ones(d, d), -1).to(DEV) * 1.2)
+    c.stoch_gate = False
+    c.A.requires_grad = False
+    assert c.s_thresh and c.deterministic_importance().data_ptr() != c.A.data_ptr()
+    x = torch.randn(6, d, device=DEV)
+    with torch.no_grad():
+        z, _ = f(x)
+        for _ in range(3):
+            torch.empty(1 << 20, device=DEV).normal_()         # churn the allocator between the passes
+            assert rel_err(f.invert(z).cpu(), x.cpu()) < 1e-4
+    assert not any(isinstance(v, tuple) for v in _INV_GRAPHS.get(step, {}).values())
 
 
 def test_graph_replay_after_eager_steps_keeps_the_adam_step_count():

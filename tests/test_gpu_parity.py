@@ -777,9 +777,10 @@ def test_affine_fused_normal_log_density(B, d, layout):
     assert rel_err(xg.grad.cpu(), xr.grad) < GTOL and rel_err(hg.grad.cpu(), hr.grad) < GTOL
 
 
-def test_flow_loss_uses_the_density_reduced_with_z():
-    """flow(x) stashes the Normal log-density on the z it returns; flow.loss(z, logdet) picks it up (no second pass
-    over z) and gives the value and gradients of the separate evaluation."""
+def test_flow_loss_in_one_launch_equals_the_separate_evaluation():
+    """flow.loss(z, logdet) -- the Normal log-density of z, the batch mean and the constraints term in ONE launch that reads
+    z itself (gnf_hip.ops.NllLossFn) -- gives the value and the gradients of the separate evaluation
+    constraints - (logdet + z_log_density(z)).mean() (reference NormalizingFlow.py:144-146)."""
     from models import buildFCNormalizingFlow, AutoregressiveConditioner, AffineNormalizer, MonotonicNormalizer
     from gnf_hip import ops
     for norm_t, args in ((AffineNormalizer, {}), (MonotonicNormalizer, {"integrand_net": [16, 16], "cond_size": 6})):
@@ -789,10 +790,12 @@ def test_flow_loss_uses_the_density_reduced_with_z():
                                       norm_t, args).to(DEV)
         x = torch.randn(21, 9, device=DEV)
         z, ld = flow(x)
-        assert ops.cached_logn(z) is not None
         loss = flow.loss(z, ld)
+        assert type(loss.grad_fn).__name__ == "NllLossFnBackward"
         fresh = flow.constraintsLoss() - (ld + ops.NormalLogDensityFn.apply(z.detach())).mean()
         assert abs(loss.item() - fresh.item()) <= 1e-6 * max(1., abs(fresh.item()))
+        ref = -(ld.detach().cpu().double() + O.normal_log_density(z.detach().cpu().double())).mean()
+        assert abs(loss.item() - ref.item()) <= 1e-6 * max(1., abs(ref.item()))
         loss.backward()
         g1 = [p.grad.clone() for p in flow.parameters()]
         for p in flow.parameters():
@@ -803,12 +806,36 @@ def test_flow_loss_uses_the_density_reduced_with_z():
             assert rel_err(a.cpu(), b.cpu()) < 1e-5
 
 
+@pytest.mark.parametrize("B,d", [(1, 1), (5, 3), (100, 784), (2, 784), (1000, 63), (16644, 63)])
+def test_nll_loss_entry_points_vs_torch(B, d):
+    """gnf_nll_loss_fwd / _bwd (the flat one-workgroup form) against torch on the CPU in fp64, with and without the
+    addend; above gnf_nll_loss_max_elems() the entry point refuses and the flow takes the row kernels"""
+    from gnf_hip import ops, abi
+    g = torch.Generator().manual_seed(B + d)
+    z, ld, c = torch.randn(B, d, generator=g) * 1.3, torch.randn(B, generator=g) * 5, torch.randn((), generator=g)
+    for addend in (None, c):
+        zr, lr = z.double().requires_grad_(True), ld.double().requires_grad_(True)
+        ref = (0. if addend is None else addend.double()) - (lr + O.normal_log_density(zr)).mean()
+        ref.backward()
+        zg, lg = req(z), req(ld)
+        out = ops.NllLossFn.apply(zg, lg, None if addend is None else cu(addend))
+        assert abs(out.item() - ref.item()) <= 2e-6 * max(1., abs(ref.item())), (out.item(), ref.item())
+        out.backward()
+        assert_close(zg.grad, zr.grad, rtol=1e-6, atol=1e-9, what="gz")
+        assert_close(lg.grad, lr.grad, rtol=1e-6, atol=1e-12, what="glogdet")
+    assert ops.nll_loss_fits(cu(z))
+    big = torch.empty(1 << 11, (1 << 9) + 1, device=DEV)
+    assert not ops.nll_loss_fits(big)
+    assert abi.load().gnf_nll_loss_fwd(big.data_ptr(), big.data_ptr(), None, big.data_ptr(), big.shape[0], big.shape[1], None) == -2
+
+
 @pytest.mark.parametrize("norm_kind", ["affine", "monotonic"])
-def test_normal_log_density_ignores_a_stale_stash(norm_kind):
-    """the density stashed on z by the kernel that produced it must not survive an in-place update of z: the reference's
-    NormalLogDensity (NormalizingFlowFactories.py:15-16) always reads the z it is handed."""
+def test_loss_and_density_read_the_z_they_are_handed(norm_kind):
+    """No density is remembered from the forward pass: after ANY rewrite of z -- an in-place op, or a write through `.data`
+    that moves neither the version counter nor the address (the idiom of the reference's own DAGConditioner.py:89 and of
+    torch-1.5-era callers; until round 4 such a z was scored with the density of its old contents) -- z_log_density(z) and
+    flow.loss(z, logdet) are those of the new contents, as in the reference (NormalizingFlowFactories.py:15-16)."""
     from models import buildFCNormalizingFlow, AutoregressiveConditioner, AffineNormalizer, MonotonicNormalizer
-    from gnf_hip import ops
     torch.manual_seed(5)
     norm_t, args, hs = ((AffineNormalizer, {}, 2) if norm_kind == "affine" else
                         (MonotonicNormalizer, {"integrand_net": [16, 16], "cond_size": 6, "nb_steps": 15, "solver": "CC"}, 6))
@@ -817,18 +844,18 @@ def test_normal_log_density_ignores_a_stale_stash(norm_kind):
     x = torch.randn(33, 9, device=DEV)
     with torch.no_grad():
         z, ld = flow(x)
-        assert ops.cached_logn(z) is not None
         fresh = O.normal_log_density(z.cpu())
-        assert_close(flow.z_log_density(z), fresh, what="stashed density")
-        z.add_(1.)                                            # any in-place change: version counter moves, attribute stays
-        assert ops.cached_logn(z) is None
-        moved = O.normal_log_density(z.cpu())
-        assert (moved - fresh).abs().max() > .1               # the test would be blind otherwise
-        assert_close(flow.z_log_density(z), moved, what="density after z.add_")
-        assert abs(flow.loss(z, ld).item() - (-(ld.cpu() + moved).mean()).item()) < 1e-5 * max(1., moved.abs().mean().item())
-        z2, _ = flow(x)                                       # a different tensor with the same storage is not the stashed one
-        v = z2.view(-1).view(33, 9)
-        assert ops.cached_logn(v) is None
+        assert_close(flow.z_log_density(z), fresh, what="density")
+        for k, write in enumerate((lambda t: t.add_(1.), lambda t: t.data.add_(1.), lambda t: t.data.mul_(.5))):
+            version = z._version
+            write(z)
+            assert (z._version == version) == (k > 0)         # the .data writes are invisible to autograd's counter
+            moved = O.normal_log_density(z.cpu())
+            assert (moved - fresh).abs().max() > .1            # the test would be blind otherwise
+            assert_close(flow.z_log_density(z), moved, what="density after write %d" % k)
+            want = (-(ld.cpu() + moved).mean()).item()
+            assert abs(flow.loss(z, ld).item() - want) < 1e-5 * max(1., abs(want)), k
+            fresh = moved
 
 
 # --------------------------------------------------------------------------------- Monotonic vs oracle

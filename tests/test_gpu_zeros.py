@@ -143,7 +143,8 @@ def test_x_gradient_on_the_prior_sparse_flow_vs_oracle():
 
 def _plan_arrays(plan, d):
     cnt = plan[:d].cpu()
-    cols = plan[d:].cpu().view(torch.int16).view(d, KC)
+    cols = plan[d:d + d * KC // 2].cpu().view(torch.int16).view(d, KC)
+    assert int(plan[d + d * KC // 2]) == int(bool((cnt > KC).any()))          # the overflow word
     return cnt, cols
 
 
@@ -212,9 +213,16 @@ def test_cols_entry_points_on_arbitrary_plans(B, per_row):
          ptr(ws0), B, d, stream())
     ws1 = torch.empty(lib.gnf_dag_gate_bwd_cols_ws_bytes(B, d) // 4, device=DEV)
     call("gnf_dag_gate_bwd_cols", ptr(x), ptr(ge1), ptr(gec), rawptr(plan), 1, 1, 1., None, None, 1234, 7, ptr(tab),
-         ptr(gA1), ptr(ws1), B, d, stream())
+         ptr(gA1), 0, ptr(ws1), B, d, stream())
     assert_close(gA1, gA0, rtol=1e-5, atol=1e-6 * max(gA0.abs().max().item(), 1e-30), what="gA")
     assert int(((gA1 != 0) & (A == 0)).sum()) == 0
+    # accumulate: gA += into whatever the buffer holds (the acyclicity term's contribution in a training step)
+    base = torch.randn(d, d, generator=g).to(DEV)
+    gA2 = base.clone()
+    call("gnf_dag_gate_bwd_cols", ptr(x), ptr(ge1), ptr(gec), rawptr(plan), 1, 1, 1., None, None, 1234, 7, ptr(tab),
+         ptr(gA2), 1, ptr(ws1), B, d, stream())
+    assert_close(gA2, base + gA1, rtol=1e-6, atol=1e-6 * max(gA0.abs().max().item(), 1.), what="gA accumulated")
+    assert torch.equal(gA2[A == 0], base[A == 0])
 
 
 def test_cols_entry_points_validate_their_arguments():
@@ -229,6 +237,6 @@ def test_cols_entry_points_validate_their_arguments():
     # a plan without the compact slab
     rc = lib.gnf_mnistcnn_conv_bwd_cols(p, p, p, p, p, p, p, p, 784, None, p, p, p, p, p, 1 << 30, 1, None)
     assert rc == -1
-    assert lib.gnf_dag_gate_bwd_cols(p, p, p, None, 1, 1, 1., None, None, 0, 0, p, p, p, 1, 784, None) == -1
+    assert lib.gnf_dag_gate_bwd_cols(p, p, p, None, 1, 1, 1., None, None, 0, 0, p, p, 0, p, 1, 784, None) == -1
     assert lib.gnf_dag_gate_fwd_plan(p, p, p, 784, 1, 1, 0., 1., None, None, 0, 0, 0, p, p, 16, 1, 784, None) == -3
     assert lib.gnf_dag_gate_fwd_plan(p, p, p, 40000, 1, 1, 0., 1., None, None, 0, 0, 0, p, p, 1 << 40, 1, 40000, None) == -2

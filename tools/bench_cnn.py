@@ -60,7 +60,7 @@ cols = torch.full((784, KC), -1, dtype=torch.int16)
 for i in range(784):
     jj = win[i].nonzero().flatten()
     cols[i, :len(jj)] = jj.to(torch.int16)
-plan = torch.cat([win.sum(1).to(torch.int32), cols.view(-1).view(torch.int32)]).to(dev)
+plan = torch.cat([win.sum(1).to(torch.int32), cols.view(-1).view(torch.int32), torch.zeros(1, dtype=torch.int32)]).to(dev)  # counts | cols | overflow word
 gec = torch.empty(n, KC, device=dev)
 HAS_COLS = hasattr(lib, 'gnf_mnistcnn_conv_bwd_cols')
 

@@ -15,6 +15,7 @@ if not steps:
     sys.exit("no steps found")
 tot = busy = 0
 per = {}
+cnt = {}
 for st in steps:
     t0, t1 = int(st[0]["Start_Timestamp"]), int(st[-1]["End_Timestamp"])
     end = t0
@@ -25,10 +26,16 @@ for st in steps:
             b += e - max(s, end)
             end = e
         per[r["Kernel_Name"][:80]] = per.get(r["Kernel_Name"][:80], 0) + e - s
+        cnt[r["Kernel_Name"][:80]] = cnt.get(r["Kernel_Name"][:80], 0) + 1
     tot += t1 - t0
     busy += b
 n = len(steps)
 print("%d steps: %.1f us from first launch to last end, GPU busy %.1f us (%.1f %% idle); %d launches per step" %
       (n, tot / n / 1e3, busy / n / 1e3, 100 * (1 - busy / tot), sum(len(s) for s in steps) / n))
-for k, v in sorted(per.items(), key=lambda kv: -kv[1])[:25]:
-    print("  %-80s %9.1f us/step" % (k, v / n / 1e3))
+small = 0.
+for k, v in sorted(per.items(), key=lambda kv: -kv[1]):
+    each = v / cnt[k] / 1e3
+    if each < 10.:
+        small += cnt[k] / n
+    print("  %-80s %9.1f us/step  %5.2f launches/step  %8.1f us each" % (k, v / n / 1e3, cnt[k] / n, each))
+print("launches under 10 us: %.1f per step" % small)
