@@ -388,21 +388,25 @@ __global__ __launch_bounds__(kBlock) void dag_gate_bwd_dA_plan_k(const float* __
     }
     return;
   }
+  // eight threads per slot split the chunk partials (a serial walk over ~20 chunks was 20 dependent round trips: 9.7 us for
+  // this launch), their sums meet in a fixed butterfly order
   const int cnt = plan[i];
-  const int64_t jk = tid < KC ? reinterpret_cast<const int16_t*>(plan + d)[i * KC + tid] : -1;
-  float s = 0.f, dp = 0.f;
-  if (tid < cnt) {
-    dp = tab[dd + i * d + jk];
-    s = part_sp[i * KC + tid];
-    for (int c = 1; c < nc_sp; ++c) s += part_sp[(int64_t)c * d * KC + i * KC + tid];
-  }
+  const int k = tid >> 3, cl = tid & 7;
+  static_assert(kBlock == 8 * KC, "one 8-thread group per slot");
+  const int64_t jk = reinterpret_cast<const int16_t*>(plan + d)[i * KC + k];
+  float s = 0.f;
+  if (k < cnt)
+    for (int c = cl; c < nc_sp; c += 8) s += part_sp[(int64_t)c * d * KC + i * KC + k];
+  s += __shfl_xor(s, 1, GNF_WAVE); s += __shfl_xor(s, 2, GNF_WAVE); s += __shfl_xor(s, 4, GNF_WAVE);
+  const bool writer = cl == 0 && k < cnt;
+  const float dp = writer ? tab[dd + i * d + jk] : 0.f;
   if (accumulate) {                                            // gA already holds another contribution (the acyclicity term's):
-    if (tid < cnt) gA[i * d + jk] = fmaf(s, dp, gA[i * d + jk]);   // only the row's listed columns change
+    if (writer) gA[i * d + jk] = fmaf(s, dp, gA[i * d + jk]);  // only the row's listed columns change
     return;
   }
   for (int64_t j = tid; j < d; j += kBlock) gA[i * d + j] = 0.f;
   __syncthreads();
-  if (tid < cnt) gA[i * d + jk] = s * dp;
+  if (writer) gA[i * d + jk] = s * dp;
 }
 
 // gx partial sums over a chunk of i (blockIdx.y):  out[chunk][b,j] = sum_{i in chunk} ge[b,i,j] * de/dx[b,i,j];  one thread

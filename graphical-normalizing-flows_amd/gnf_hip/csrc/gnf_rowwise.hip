@@ -921,11 +921,21 @@ __global__ __launch_bounds__(1024) void nll_loss_k(const float* __restrict__ z, 
   for (int64_t b = threadIdx.x; b < B; b += 1024) s += logdet[b];
   const bool vec = (reinterpret_cast<uintptr_t>(z) & 15) == 0;
   const int64_t n4 = vec ? n / 4 : 0;
-  for (int64_t i = threadIdx.x; i < n4; i += 1024) {
+  int64_t i = threadIdx.x;
+  for (; i + 7 * 1024 < n4; i += 8 * 1024) {                   // eight 16-B loads in flight per thread (one workgroup reads it all)
+    float4 v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = reinterpret_cast<const float4*>(z)[i + u * 1024];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      q0 = fmaf(v[u].x, v[u].x, q0); q1 = fmaf(v[u].y, v[u].y, q1); q2 = fmaf(v[u].z, v[u].z, q2); q3 = fmaf(v[u].w, v[u].w, q3);
+    }
+  }
+  for (; i < n4; i += 1024) {
     const float4 v = reinterpret_cast<const float4*>(z)[i];
     q0 = fmaf(v.x, v.x, q0); q1 = fmaf(v.y, v.y, q1); q2 = fmaf(v.z, v.z, q2); q3 = fmaf(v.w, v.w, q3);
   }
-  for (int64_t i = 4 * n4 + threadIdx.x; i < n; i += 1024) q0 = fmaf(z[i], z[i], q0);
+  for (int64_t t = 4 * n4 + threadIdx.x; t < n; t += 1024) q0 = fmaf(z[t], z[t], q0);
   float q = (q0 + q1) + (q2 + q3);
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) { s += __shfl_xor(s, off, GNF_WAVE); q += __shfl_xor(q, off, GNF_WAVE); }
