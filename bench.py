@@ -74,9 +74,13 @@ def train_step(flow, state, x):
     return dp.train_step(flow, state, x, lr=1e-3, weight_decay=1e-5)
 
 
+CPU_B = 8                                   # rows of the CPU sample ("B = 8-16 ... acceptable if stated")
+
+
 def cpu_baseline():
-    """CPU oracle, same model/inputs, B=2 sample (B=100 needs >10 GB of conv activations
-    and minutes per step on the host): fwd + log|det J| + NLL + bwd, all host threads."""
+    """CPU oracle, same model/inputs, a B = 8 sample (B=100 needs >10 GB of conv activations and minutes per step on the
+    host; round 4 took B = 2, where 6 272 single-channel images give torch's conv too little work per thread): fwd +
+    log|det J| + NLL + bwd, thread counts swept up to the physical cores."""
     from oracle import gnf_oracle as O
     torch.manual_seed(0)
     flow = build_flow()
@@ -89,7 +93,7 @@ def cpu_baseline():
     while ipre + "%d.weight" % k in sd:
         layers.append((sd[ipre + "%d.weight" % k].requires_grad_(True), sd[ipre + "%d.bias" % k].requires_grad_(True)))
         k += 2
-    Bc = 2
+    Bc = CPU_B
     x = pseudo_mnist(torch.Generator().manual_seed(1234), Bc, D)
     ncpu = os.cpu_count() or 1
     model = "unknown"
@@ -114,7 +118,7 @@ def cpu_baseline():
     # physical core count (os.cpu_count() counts SMT siblings) picks the fastest setting, the sweep is reported
     phys = max(1, ncpu // 2) if ncpu >= 16 else ncpu
     sweep = {}
-    for th in sorted({min(32, phys), min(64, phys), phys}):
+    for th in sorted({min(16, phys), min(32, phys), min(64, phys), phys}):
         torch.set_num_threads(th)
         step()                               # warm-up at this setting
         t0 = time.perf_counter()
@@ -298,6 +302,20 @@ def main():
             mixed(i)
     t_mix = timed(mixed, 10) if secondary else None
 
+    # (ii') the evaluation path of the reference: likelihoods under no_grad at nb_steps = 150 (ImageExperiments.py:232-243:
+    # z, jac = model(x); ll = z_log_density(z) + jac) -- parity-tested in tests/test_gpu_eval_path.py, timed here
+    def eval_fwd(_):
+        for nrm in flow.getNormalizers():
+            nrm.nb_steps = 150
+        with torch.no_grad():
+            z, ld = flow(x)
+            return flow.z_log_density(z) + ld
+    if secondary:
+        eval_fwd(0)
+    t_eval = timed(eval_fwd, 10) if secondary else None
+    for nrm in flow.getNormalizers():
+        nrm.nb_steps = S_NODES
+
     # (iii) the same full step after the DAG phase: post_process() froze a binary A and the gate is deterministic, so
     # the embedding net runs on the sparse crop kernels.  Fresh flow: A leaves the optimiser state.
     from gnf_hip import dp as _dp
@@ -324,7 +342,7 @@ def main():
         t_det, det_error = None, repr(exc)
     # max over ranks of every timing (a missing secondary figure travels as -1); replicas must have stayed identical:
     # compare an order-independent bit checksum of the flat parameter buffer across ranks
-    tmax = torch.tensor([dt, t_fb or -1., t_mix or -1., t_det or -1., allreduce_ms or -1.], dtype=torch.float64)
+    tmax = torch.tensor([dt, t_fb or -1., t_mix or -1., t_det or -1., allreduce_ms or -1., t_eval or -1.], dtype=torch.float64)
     replicas_identical = dp.replicas_identical(state, flow)
     per_rank_ms = [dt / args.steps * 1e3]
     if collective:
@@ -336,7 +354,7 @@ def main():
         tmax = tmax.to(cdev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         tmax = tmax.cpu()
-    dt, t_fb, t_mix, t_det, allreduce_ms = [v if v > 0 else None for v in tmax.tolist()]
+    dt, t_fb, t_mix, t_det, allreduce_ms, t_eval = [v if v > 0 else None for v in tmax.tolist()]
     if not replicas_identical:
         raise SystemExit("data-parallel replicas diverged (parameter checksums differ across ranks)")
 
@@ -451,6 +469,7 @@ def main():
                             "full_step_S_mix_20_29_samples_per_s": round(b_rank * world / t_mix, 1) if t_mix else None,
                             "full_step_frozen_deterministic_gate_samples_per_s":
                                 round(b_rank * world / t_det, 1) if t_det else None,
+                            "eval_forward_S150_samples_per_s": round(b_rank * world / t_eval, 1) if t_eval else None,
                             "frozen_gate_error": det_error,
                             "note": "10 steps each, wall clock between barriers, max over ranks"}
         out["measured_peaks"] = measured_peaks(dev)

@@ -723,6 +723,11 @@ int64_t gnf_gemm_num_splits(int64_t K, int splits) {
   return K > 0 ? (K + kps - 1) / kps : 1;
 }
 
+// which kernel the most recent gnf_gemm_launch of THIS thread dispatched to (measurement / tests: tools/bench_kernels.py names
+// the kernel behind each row, the dedicated-kernel tests check that their shapes reach it); no effect on any result
+static thread_local const char* g_last_kernel = "";
+extern "C" const char* gnf_gemm_last_kernel(void) { return g_last_kernel; }
+
 // Internal launcher shared with gnf_monotonic.hip (split-K weight-gradient GEMMs).
 int gnf_gemm_launch(GemmArgs g, int splits, hipStream_t s) {
   g.k_per_split = k_per_split(g.K, splits);
@@ -747,6 +752,7 @@ int gnf_gemm_launch(GemmArgs g, int splits, hipStream_t s) {
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kmajor_k), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 KMLDS);
       hipLaunchKernelGGL(gemm_kmajor_k, dim3((unsigned)(((g.N + KMN - 1) / KMN) * nsp)), dim3(512), KMLDS, s, g);
+      g_last_kernel = "gemm_kmajor_k";
       GNF_LAUNCH_CHECK();
       return 0;
     }
@@ -760,6 +766,7 @@ int gnf_gemm_launch(GemmArgs g, int splits, hipStream_t s) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_wide_k), hipFuncAttributeMaxDynamicSharedMemorySize,
                               (int)kWideLds);
     hipLaunchKernelGGL(gemm_wide_k, dim3(256), dim3(64 * WWAVES), kWideLds, s, g);
+    g_last_kernel = "gemm_wide_k";
     GNF_LAUNCH_CHECK();
     return 0;
   }
@@ -797,6 +804,7 @@ int gnf_gemm_launch(GemmArgs g, int splits, hipStream_t s) {
         if (tmw == 5) GNF_TALL_LAUNCH(5, 4); else if (tmw == 4) GNF_TALL_LAUNCH(4, 4); else GNF_TALL_LAUNCH(3, 4);
       }
 #undef GNF_TALL_LAUNCH
+      g_last_kernel = "gemm_tall_k";
       GNF_LAUNCH_CHECK();
       return 0;
     }
@@ -806,15 +814,18 @@ int gnf_gemm_launch(GemmArgs g, int splits, hipStream_t s) {
     const int64_t t160 = (g.M + 159) / 160;
     if (((t160 + 255) / 256) * 160 < ((gx + 255) / 256) * 128) {
       hipLaunchKernelGGL((gemm_vec_k<160, 128, true, true, 1>), dim3((unsigned)t160, 1, 1), dim3(256), 0, s, g);
+      g_last_kernel = "gemm_vec_k<160,128>";
       GNF_LAUNCH_CHECK();
       return 0;
     }
   }
   if (vec) {
     if (bt == 128) GNF_VEC_LAUNCH(128); else GNF_VEC_LAUNCH(64);
+    g_last_kernel = bt == 128 ? "gemm_vec_k<128,128>" : "gemm_vec_k<64,64>";
   } else {
     if (bt == 128) hipLaunchKernelGGL((gemm_k<128, 128>), grid, dim3(256), 0, s, g);
     else hipLaunchKernelGGL((gemm_k<64, 64>), grid, dim3(256), 0, s, g);
+    g_last_kernel = bt == 128 ? "gemm_k<128,128>" : "gemm_k<64,64>";
   }
 #undef GNF_VEC_LAUNCH
   GNF_LAUNCH_CHECK();

@@ -136,6 +136,9 @@ int gnf_linear_gxsum_fused(int64_t M, int64_t N, int64_t K, int masked);
  * that many bytes, K is spread over several workgroups (few output tiles, long K: the
  * weight-gradient shapes) and a second kernel reduces the partials and applies the
  * epilogue.  ws == NULL always selects the single-pass kernel. */
+/* name of the kernel family the most recent gnf_gemm (or Linear entry point routed through it) of the calling thread
+ * dispatched to -- "gemm_tall_k", "gemm_wide_k", "gemm_kmajor_k", "gemm_vec_k<128,128>", ...: measurement and tests only. */
+const char* gnf_gemm_last_kernel(void);
 int64_t gnf_gemm_ws_bytes(int64_t M, int64_t N, int64_t K);
 int gnf_gemm(const float* A, int64_t sam, int64_t sak,
              const float* B, const float* Bmask, int64_t sbk, int64_t sbn,

@@ -65,3 +65,21 @@ def test_baseline_config_builders_live_in_the_package():
     from gnf_hip import configs
     flow, x = configs.baseline_config("cfg1", device="cpu")
     assert tuple(x.shape) == (512, 2) and len(flow.steps) == 1
+
+
+def test_round5_evidence_hygiene_items():
+    """verdict r04 item 7, one assertion per item: the kernel table times the fc1 gradients through the product's operand
+    layouts and names the kernel that ran; one flop convention for the conv rows (the recompute is not algorithmic); the
+    CPU sample is B = 8 with the thread sweep kept; the evaluation path (no_grad, nb_steps = 150) is a secondary figure;
+    the stale GEMM-clock sentence of profiles/README.md is gone."""
+    bk = open(os.path.join(ROOT, "tools", "bench_kernels.py")).read()
+    assert "gnf_gemm_last_kernel" in bk and '"kernel_ran"' in bk
+    assert "sa, sb = (1, M), (N, 1)" in bk and "sa, sb = (K, 1), (N, 1)" in bk          # dW: both k-major; dX: B n-contiguous
+    assert "2 * 1327104 + 3 * 97344" not in bk and "2 * 1327104 + 2 * 97344" in bk
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    assert "CPU_B = 8" in src and "threads_sweep_samples_per_s" in src
+    assert "eval_forward_S150_samples_per_s" in src and "nrm.nb_steps = 150" in src and "torch.no_grad()" in src
+    readme = open(os.path.join(ROOT, "profiles", "README.md")).read()
+    assert "re-measured in the same call (fc1 GEMMs: 2.07-2.12 GHz" not in readme
+    # round 5: the plan-variant entry points are reported under the names of the calls they replace
+    assert '"gnf_mnistcnn_conv_bwd_cols": "gnf_mnistcnn_conv_bwd"' in src

@@ -159,6 +159,11 @@ def test_gemm_shapes(M, N, K):
     assert rel_err(C3.cpu(), ref3) < 2e-6
 
 
+def _last_gemm_kernel():
+    from gnf_hip import abi
+    return abi.load().gnf_gemm_last_kernel().decode()
+
+
 @pytest.mark.parametrize("M,N,K", [(78400, 128, 2304), (65536, 128, 256), (65000, 100, 288), (49152, 128, 256),
                                    (48500, 127, 320), (40000, 128, 256)])
 def test_gemm_tall_long_k_path(M, N, K):
@@ -171,6 +176,8 @@ def test_gemm_tall_long_k_path(M, N, K):
     A, W, bias = torch.randn(M, K, device=DEV), torch.randn(N, K, device=DEV), torch.randn(N, device=DEV)
     C = torch.full((M, N), float("nan"), device=DEV)
     ops.gemm(A, (K, 1), W, (1, K), C, (N, 1), M, N, K, bias=bias, relu=True)
+    ran = _last_gemm_kernel()
+    assert ran == ("gemm_tall_k" if M != 40000 else "gemm_vec_k<160,128>"), ran     # the shape reaches the kernel it is written for
     rows = torch.cat([torch.arange(0, 700), torch.randint(0, M, (3000,)), torch.arange(M - 700, M)]).to(DEV)
     ref = torch.relu(A[rows].double() @ W.double().t() + bias.double())
     assert not torch.isnan(C).any()
@@ -192,6 +199,7 @@ def test_gemm_kmajor_split_k_path(M, N, K):
     dY, X = torch.randn(K, M, device=DEV), torch.randn(K, N, device=DEV)
     C = torch.full((M, N), float("nan"), device=DEV)
     ops.gemm(dY, (1, M), X, (N, 1), C, (N, 1), M, N, K)
+    assert _last_gemm_kernel() == "gemm_kmajor_k", _last_gemm_kernel()
     ref = dY.double().t() @ X.double()
     assert rel_err(C.cpu(), ref.cpu()) < 2e-6
     dYw, Xw = torch.randn(K, M + 4, device=DEV), torch.randn(K, N + 8, device=DEV)
@@ -210,6 +218,7 @@ def test_gemm_wide_short_k_path(M, N):
     A, B = torch.randn(M, K, device=DEV), torch.randn(K, N, device=DEV)
     C = torch.full((M, N), float("nan"), device=DEV)
     ops.gemm(A, (K, 1), B, (N, 1), C, (N, 1), M, N, K)
+    assert _last_gemm_kernel() == "gemm_wide_k", _last_gemm_kernel()
     ref = (A.double() @ B.double())
     assert rel_err(C.cpu(), ref.cpu()) < 2e-6
     assert not torch.isnan(C).any()

@@ -87,14 +87,29 @@ def main():
         with torch.no_grad():
             f = lambda: ops.DagGateFn.apply(x, A, ops.IMP_SOFT, ops.GATE_GUMBEL, 0., 1., False, None, None, 1, 1)
             hbm("dag_gate_fwd(gumbel)", [B, d, d], timeit(f), 4. * B * d * d)
-    # ---- GEMM shapes on the measured configurations
-    for M, N, K, what in [(78400, 128, 2304, "cfg4 fc1 fwd"), (78400, 2304, 128, "cfg4 fc1 dX"),
-                          (128, 2304, 78400, "cfg4 fc1 dW (split-K)"), (100, 1024, 1024, "cfg3 MADE hidden"),
-                          (50000, 630, 630, "cfg5 MADE hidden"), (4096, 4096, 4096, "square")]:
-        Am, Bm = torch.randn(M, K, device=DEV), torch.randn(N, K, device=DEV)
+    # ---- GEMM shapes on the measured configurations, THROUGH THE STRIDES THE PRODUCT USES (ops.MLPFn -> gnf_linear_* -> gnf_gemm):
+    #      forward  y = a W^T        A = a [M,K] row-major, B[k][n] = W[n][k] (k-contiguous: strides (1, K))
+    #      dX       ga = g W         A = g [M,K] row-major, B = W [K,N] row-major (n-contiguous: strides (N, 1))
+    #      dW       gW = g^T a       A[m][k] = g[k][m] (k-major: strides (1, M)), B = a [K,N] row-major (strides (N, 1))
+    #      every row names the kernel family that ran (gnf_gemm_last_kernel)
+    lib = abi.load()
+    for M, N, K, what, layout in [(78400, 128, 2304, "cfg4 fc1 fwd", "fwd"), (78400, 2304, 128, "cfg4 fc1 dX", "dx"),
+                                  (128, 2304, 78400, "cfg4 fc1 dW (split-K)", "dw"), (100, 1024, 1024, "cfg3 MADE hidden", "fwd"),
+                                  (50000, 630, 630, "cfg5 MADE hidden", "fwd"), (4096, 4096, 4096, "square", "fwd")]:
         C = torch.empty(M, N, device=DEV)
-        mfma("gemm " + what, [M, N, K], timeit(lambda: ops.gemm(Am, (K, 1), Bm, (1, K), C, (N, 1), M, N, K)),
-             2. * M * N * K)
+        if layout == "fwd":
+            Am, Bm = torch.randn(M, K, device=DEV), torch.randn(N, K, device=DEV)
+            sa, sb = (K, 1), (1, K)
+        elif layout == "dx":
+            Am, Bm = torch.randn(M, K, device=DEV), torch.randn(K, N, device=DEV)
+            sa, sb = (K, 1), (N, 1)
+        else:
+            Am, Bm = torch.randn(K, M, device=DEV), torch.randn(K, N, device=DEV)
+            sa, sb = (1, M), (N, 1)
+        ms = timeit(lambda: ops.gemm(Am, sa, Bm, sb, C, (N, 1), M, N, K))
+        mfma("gemm " + what, [M, N, K], ms, 2. * M * N * K)
+        rows[-1]["kernel_ran"] = lib.gnf_gemm_last_kernel().decode()
+        rows[-1]["operand_strides"] = {"A": list(sa), "B": list(sb)}
     # ---- small-batch masked Linear (cfg3's MADE hidden layer, mask as degree vectors): weights streamed once (4 N K bytes)
     M, N, K = 100, 1024, 1024
     xl = torch.randn(M, K, device=DEV, requires_grad=True)
@@ -151,10 +166,11 @@ def main():
              2. * (97344 + 1327104) * n)
     out = ops.MnistConvFn.apply(e, W1, b1, W2, b2)
     gp = torch.randn_like(out)
-    # dW2 + da1 (2 x conv2 MACs) + conv1 recompute + dW1 + de (3 x conv1 MACs)
-    mfma("mnistcnn_conv_bwd", [n, 784],
+    # dW2 + da1 (2 x conv2 MACs) + dW1 + de (2 x conv1 MACs): the same convention as bench.py -- the conv1 RECOMPUTE of the
+    # kernel is not algorithmic work (until round 4 this row counted it: 1.025 here against 0.979 in the bench line)
+    mfma("mnistcnn_conv_bwd (dense de: x wants a gradient)", [n, 784],
          time_entry("gnf_mnistcnn_conv_bwd", lambda: torch.autograd.grad(out, (e, W1, b1, W2, b2), gp, retain_graph=True), n=10),
-         2. * (2 * 1327104 + 3 * 97344) * n)
+         2. * (2 * 1327104 + 2 * 97344) * n)
     for r in rows:
         print(json.dumps(r))
     if "--json" in sys.argv:
