@@ -70,3 +70,56 @@ def assert_close(a, b, rtol=1e-5, atol=1e-6, what=""):
                              % (what, k, a.reshape(-1)[k].item(), b.reshape(-1)[k].item(),
                                 (a - b).abs().reshape(-1)[k].item(), (atol + rtol * b.abs()).reshape(-1)[k].item(),
                                 int((excess > 0).sum()), excess.numel()))
+
+
+# ------------------------------------------------------------------------------- fp64 arbitration of knife-edge decisions
+# A ReLU gate / max-pool argmax decided on a quantity that lies within fp32 roundoff of the tie may legitimately differ
+# between two correct fp32 evaluations (different summation orders).  Instead of a loose blanket tolerance on the gradients,
+# the parity tests find those units with an fp64 evaluation, give them a ZERO cotangent (so they contribute to no gradient on
+# either side), bound their number, and compare everything else at the normal tolerance.
+EPS32 = float(torch.finfo(torch.float32).eps)
+
+
+def conv_front_knife_images(e, W1, b1, W2, b2, ulps=16.):
+    """[n] bool: images of the MNISTCNN conv front (MLP.py:36-41) holding a decision within `ulps` fp32 ulps OF ITS TERMS'
+    MAGNITUDE of a tie in an fp64 evaluation: a conv1 pre-activation near 0, or a pool window whose two largest conv2
+    outputs are closer than that without being exactly equal (exact ties -- constant image regions -- are decided by the
+    first-maximum rule on both sides).  Also returns the per-image counts (relu, pool)."""
+    import torch.nn.functional as F
+    e, W1, b1, W2, b2 = [t.detach().cpu().double() for t in (e, W1, b1, W2, b2)]
+    img = e.view(-1, 1, 28, 28)
+    pre1 = F.conv2d(img, W1.view(16, 1, 3, 3), b1)
+    mag1 = F.conv2d(img.abs(), W1.view(16, 1, 3, 3).abs(), b1.abs())
+    relu_k = (pre1.abs() < ulps * EPS32 * mag1) & (pre1 != 0)
+    a1 = torch.relu(pre1)
+    c2 = F.conv2d(a1, W2.view(16, 16, 3, 3), b2)
+    mag2 = F.conv2d(a1, W2.view(16, 16, 3, 3).abs(), b2.abs())
+    n = e.shape[0]
+    win = c2.view(n, 16, 12, 2, 12, 2).permute(0, 1, 2, 4, 3, 5).reshape(n, 2304, 4)
+    wmag = mag2.view(n, 16, 12, 2, 12, 2).permute(0, 1, 2, 4, 3, 5).reshape(n, 2304, 4).amax(2)
+    top = win.sort(dim=2, descending=True).values
+    gap = top[:, :, 0] - top[:, :, 1]
+    pool_k = (gap < ulps * EPS32 * wmag) & (gap != 0)
+    nr, npool = relu_k.flatten(1).sum(1), pool_k.sum(1)
+    return (nr + npool) > 0, nr, npool
+
+
+def integrand_knife_elements(x, h, layers, nb_steps, ulps=16.):
+    """[B, d] bool: elements of a Monotonic normalizer (MonotonicNormalizer.py:12-38, 51-66) with a hidden ReLU
+    pre-activation within `ulps` fp32 ulps of its terms' magnitude of zero at any quadrature node or at x itself, in an
+    fp64 evaluation of the integrand net"""
+    from oracle import gnf_oracle as O
+    _, t = O.cc_rule(nb_steps)
+    x, h = x.detach().cpu().double(), h.detach().cpu().double()
+    layers = [(W.detach().cpu().double(), b.detach().cpu().double()) for W, b in layers]
+    B, d = x.shape
+    knife = torch.zeros(B, d, dtype=torch.bool)
+    nodes = [x * (float(tk) + 1.) / 2. for tk in t] + [x]
+    for xk in nodes:
+        a = torch.cat((xk.reshape(B, d, 1), h), 2).reshape(B * d, -1)
+        for W, b in layers[:-1]:
+            pre = a @ W.t() + b
+            mag = a.abs() @ W.abs().t() + b.abs()
+            knife |= ((pre.abs() < ulps * EPS32 * mag) & (pre != 0)).any(1).view(B, d)
+            a = torch.relu(pre)
+    return knife

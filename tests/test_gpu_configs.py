@@ -85,6 +85,8 @@ def test_cfg4_composite_vs_oracle():
     for k, g0 in grads0.items():
         assert named[k].grad is not None, k
         assert rel_err(named[k].grad.cpu(), g0) < GTOL, (k, rel_err(named[k].grad.cpu(), g0))
+        # element-wise (verdict r04 item 5): every entry of every parameter gradient of the headline model
+        assert_close(named[k].grad, g0, rtol=1e-4, atol=1e-6 * g0.abs().max().item(), what="d " + k)
     # zero entries of the prior keep an exactly-zero gradient (grad ∝ A, DAG:118-119)
     assert int(((cond.A.grad != 0) & (cond.A.detach() == 0)).sum()) == 0
 
