@@ -783,7 +783,9 @@ int gnf_gemm_launch(GemmArgs g, int splits, hipStream_t s) {
   } while (0)
   // one column of <= 128-wide tiles over a tall M, long K (fc1 forward: 78 400 x 128 x 2304): the persistent tall kernel when
   // one of its block heights fills the chip
-  if (vec && akf && bkf && bt == 128 && gy == 1 && nsp == 1 && !g.grp && !g.Bmask && !g.Cmask && !g.gate &&
+  // (decided on N itself, not on the generic kernels' tile choice: that takes 64 x 64 tiles below 512 tiles of 128 x 128, and
+  // with it this branch was skipped for every M < 65 536 -- found in round 5 by asserting gnf_gemm_last_kernel in the tests)
+  if (vec && akf && bkf && g.N <= 128 && nsp == 1 && !g.grp && !g.Bmask && !g.Cmask && !g.gate &&
       !(g.flags & ~GNF_GEMM_RELU) && g.N > 96 && g.K % TBK == 0 && g.K >= 8 * TBK && g.sam % 4 == 0 && g.sbn % 4 == 0 &&
       (((uintptr_t)g.A | (uintptr_t)g.B) & 15) == 0 && 320 * g.sam + g.K < (1 << 28) && 128 * g.sbn + g.K < (1 << 28)) {
     static const char tall_mode = getenv("GNF_GEMM_TALL") ? getenv("GNF_GEMM_TALL")[0] : '4';      // A/B: 0 off, 2 two 4-wave groups
