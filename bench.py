@@ -273,7 +273,9 @@ def main():
 
     # secondary figures of SURVEY.md 8(d), outside the timed region of the headline: (i) fwd + log-det + NLL + bwd
     # without all-reduce / Adam, (ii) the full step with the training-realistic node count S ~ U{20..29}
-    def timed(fn, n):
+    def timed(fn, n, warm=2):
+        for i in range(warm):                # untimed: the first pass of a new loop shape grows the allocator pools (a 4 ms
+            fn(i)                            # one-off that read as "fwd+bwd alone is slower than the full step" in round 5)
         fence()
         t = time.perf_counter()
         for i in range(n):

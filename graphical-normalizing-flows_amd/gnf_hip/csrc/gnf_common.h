@@ -48,6 +48,9 @@ __device__ __forceinline__ float u01_24(uint32_t r) { return (float)(r >> 8) * (
 
 // out[n] (+)= sum_{p<P} src[p*N + n]   (gnf_rowwise.hip; deterministic order)
 int gnf_rowsum_launch(const float* src, float* out, int64_t P, int64_t N, int accumulate, hipStream_t s);
+// two independent row sums in one launch
+int gnf_rowsum2_launch(const float* src_a, float* out_a, int64_t Pa, int64_t Na, int acc_a, const float* src_b, float* out_b,
+                       int64_t Pb, int64_t Nb, int acc_b, hipStream_t s);
 // same for tall inputs: two-level, ws >= kRowsumChunks*N floats
 constexpr int kRowsumChunks = 1024;
 int gnf_rowsum_tall_launch(const float* src, float* out, int64_t P, int64_t N, int accumulate, float* ws,

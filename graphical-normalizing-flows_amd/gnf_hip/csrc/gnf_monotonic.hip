@@ -2363,9 +2363,8 @@ int gnf_monotonic_bwd(const float* pack, const gnf_mono_net* net, const float* x
     const int64_t rows = groups * NK * 16;
     const int accum = ck > 0 ? GNF_GEMM_ACCUM : 0;     // chunk 0 is the largest: it defines the split count
     // d W_l (+)= dpre_l^T * act_{l-1}   (split-K partials, accumulated across chunks)
-    if (indw) {                        // the chain kernel's accumulator rows -> dW (accumulated across chunks)
-      if ((rc = rowsum(a.wpart, w + P.o_dW[1], wpart_rows, (int64_t)(NH - 1) * HP * HP, ck > 0))) return rc;
-    }
+    // (indw: the chain kernel's accumulator rows -> dW, accumulated across chunks, ride in the launch that sums the partial
+    // vector rows below)
     for (int l = 1; l < NH && !indw; ++l) {
       if (HT == 7 || HT == 10) {       // wide nets: one pass over the staged rows, bias gradient fused
         const int64_t rpw = ((rows + kDwGrid - 1) / kDwGrid + kDwRows - 1) / kDwRows * kDwRows;
@@ -2399,7 +2398,11 @@ int gnf_monotonic_bwd(const float* pack, const gnf_mono_net* net, const float* x
       if (ck == 0) nsp_h = gnf_gemm_num_splits(a.ecount, kSplits);
       if ((rc = gnf_gemm_launch(g, ck == 0 ? kSplits : (int)nsp_h, s))) return rc;
     }
-    if ((rc = rowsum(a.part, w + P.o_vec, part_rows, vecw, ck > 0))) return rc;
+    if (indw) {
+      if ((rc = gnf_rowsum2_launch(a.wpart, w + P.o_dW[1], wpart_rows, (int64_t)(NH - 1) * HP * HP, ck > 0, a.part,
+                                   w + P.o_vec, part_rows, vecw, ck > 0, s)))
+        return rc;
+    } else if ((rc = rowsum(a.part, w + P.o_vec, part_rows, vecw, ck > 0))) return rc;
     if (tall_w1) {
       nsp_h = 0;                       // (no split-K partials to sum behind the loop)
       for (int64_t u0 = 0; u0 < HP; u0 += 64) {

@@ -1118,6 +1118,47 @@ inline unsigned grid_1d(int64_t n) {
 
 }  // namespace
 
+// Two independent row sums in ONE launch (the Monotonic backward's accumulator rows and its partial vector rows: two 6-us
+// launches behind the chain kernel before): workgroups [0, ga) take segment a, the rest segment b; same summation order
+// per segment as rowsum_k.
+struct RowsumSeg { const float* src; float* out; int64_t P, N; int accumulate; };
+__global__ __launch_bounds__(1024) void rowsum2_k(RowsumSeg a, RowsumSeg b, unsigned ga) {
+  __shared__ float red[16][64];
+  const bool first = blockIdx.x < ga;
+  const RowsumSeg& g = first ? a : b;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t n = (int64_t)(first ? blockIdx.x : blockIdx.x - ga) * 64 + lane;
+  const float* src = g.src;
+  const int64_t P = g.P, N = g.N;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  if (n < N) {
+    int64_t p = wave;
+    for (; p + 48 < P; p += 64) {
+      s0 += src[p * N + n]; s1 += src[(p + 16) * N + n]; s2 += src[(p + 32) * N + n]; s3 += src[(p + 48) * N + n];
+    }
+    for (; p < P; p += 16) s0 += src[p * N + n];
+  }
+  red[wave][lane] = (s0 + s1) + (s2 + s3);
+  __syncthreads();
+  if (wave == 0 && n < N) {
+    float s = g.accumulate ? g.out[n] : 0.f;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) s += red[w][lane];
+    g.out[n] = s;
+  }
+}
+
+int gnf_rowsum2_launch(const float* src_a, float* out_a, int64_t Pa, int64_t Na, int acc_a, const float* src_b, float* out_b,
+                       int64_t Pb, int64_t Nb, int acc_b, hipStream_t s) {
+  if (Na <= 0) return gnf_rowsum_launch(src_b, out_b, Pb, Nb, acc_b, s);
+  if (Nb <= 0) return gnf_rowsum_launch(src_a, out_a, Pa, Na, acc_a, s);
+  const unsigned ga = (unsigned)((Na + 63) / 64), gb = (unsigned)((Nb + 63) / 64);
+  hipLaunchKernelGGL(rowsum2_k, dim3(ga + gb), dim3(1024), 0, s, RowsumSeg{src_a, out_a, Pa, Na, acc_a},
+                     RowsumSeg{src_b, out_b, Pb, Nb, acc_b}, ga);
+  GNF_LAUNCH_CHECK();
+  return 0;
+}
+
 int gnf_rowsum_launch(const float* src, float* out, int64_t P, int64_t N, int accumulate, hipStream_t s) {
   if (N <= 0) return 0;
   hipLaunchKernelGGL(rowsum_k, dim3((unsigned)((N + 63) / 64), 1), dim3(1024), 0, s, src, out, P, N, accumulate,
