@@ -34,6 +34,14 @@ def timeit(fn, reps=41):
 
 
 fl = 2. * 78400 * 2304 * 128
-for name, fn in (("fwd  X W^T + b, relu", lambda: g(X, W.t(), b, True)), ("dX   dY W", lambda: g(dY, W)), ("dW   dY^T X", lambda: g(dY.t(), X))):
+def err(C, ref):
+    return ((C.double() - ref.double()).abs().max() / ref.double().abs().max()).item()
+
+
+rows = torch.cat([torch.arange(0, 300), torch.randint(0, 78400, (1500,)), torch.arange(78400 - 300, 78400)]).to(dev)
+for name, fn, ref in (("fwd  X W^T + b, relu", lambda: g(X, W.t(), b, True), lambda C: err(C[rows], torch.relu(X[rows].double() @ W.double().t() + b.double()))),
+                      ("dX   dY W", lambda: g(dY, W), lambda C: err(C[rows], dY[rows].double() @ W.double())),
+                      ("dW   dY^T X", lambda: g(dY.t(), X), lambda C: err(C, dY.double().t() @ X.double()))):
     t = timeit(fn)
-    print("%-22s %.4f ms  %.1f TFLOP/s" % (name, t, fl / t / 1e9))
+    print("%-22s %.4f ms  %.1f TFLOP/s   kernel %s   max rel err vs fp64 %.1e"
+          % (name, t, fl / t / 1e9, abi.load().gnf_gemm_last_kernel().decode(), ref(fn())))
