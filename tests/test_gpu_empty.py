@@ -115,6 +115,54 @@ def test_empty_batch_through_every_autograd_function():
         assert img.grad.shape == (0, 784)
 
 
+def test_empty_batch_through_the_fused_gate_conv_front_and_the_loss():
+    """round 5's autograd nodes and entry points on zero rows: gate + conv front as one node (dA and the conv gradients come
+    back as zeros), the *_cols entry points WITH a plan (table, plan and its overflow word are written for an empty batch too:
+    the backward kernels read them), and the one-launch loss (no rows: the flow falls back to the reference's expression)"""
+    import ctypes
+    from gnf_hip import ops, abi
+    from gnf_hip.abi import ptr, rawptr, call, stream
+    g = torch.Generator(device=DEV).manual_seed(1)
+    rnd = lambda *s: torch.randn(*s, device=DEV, generator=g).requires_grad_(True)
+    d = 784
+    A = rnd(d, d)
+    cw = [rnd(16, 1, 3, 3), rnd(16), rnd(16, 16, 3, 3), rnd(16)]
+    for xg in (False, True):
+        for p in [A] + cw:
+            p.grad = None
+        x = torch.zeros(0, d, device=DEV, requires_grad=xg)
+        pooled = ops.dag_conv_front(x, A, ops.IMP_SOFT, ops.GATE_GUMBEL, 0., 1., None, None, 7, 1, *cw)
+        assert pooled.shape == (0, 2304)
+        pooled.sum().backward()
+        _zero(A.grad, *[p.grad for p in cw])
+    # C ABI with a plan on an empty batch
+    lib = abi.load()
+    tab = torch.empty(lib.gnf_dag_gate_fwd_ws_bytes(d) // 4, device=DEV)
+    nplan = lib.gnf_dag_gate_plan_bytes(d)
+    plan = torch.full((nplan // 4,), -7, dtype=torch.int32, device=DEV)
+    Ad = A.detach()
+    call("gnf_dag_gate_fwd_plan", None, ptr(Ad), None, d, 1, 1, 0., 1., None, None, 7, 1, 0, ptr(tab), rawptr(plan), nplan, 0, d,
+         stream())
+    assert int(plan[d + d * 16]) == 1 and int(plan[:d].min()) >= 0              # dense random A: every row overflows the plan
+    gs = [torch.full_like(t.detach(), 5.) for t in cw]
+    ws = torch.empty(lib.gnf_mnistcnn_conv_bwd_ws_bytes(0) // 4, device=DEV)
+    call("gnf_mnistcnn_conv_bwd_cols", None, *[ptr(t.detach().contiguous()) for t in cw[:3]], None, None, None, rawptr(plan), d,
+         None, *[ptr(t) for t in gs], rawptr(ws), ws.numel() * 4, 0, stream())
+    _zero(*gs)
+    gA = torch.full((d, d), 5., device=DEV)
+    ws2 = torch.empty(lib.gnf_dag_gate_bwd_cols_ws_bytes(0, d) // 4, device=DEV)
+    call("gnf_dag_gate_bwd_cols", None, None, None, rawptr(plan), 1, 1, 1., None, None, 7, 1, ptr(tab), ptr(gA), 0, ptr(ws2),
+         0, d, stream())
+    _zero(gA)
+    # the loss launch refuses zero rows (the mean of nothing); FCNormalizingFlow.loss then evaluates the reference's expression
+    z0, l0 = torch.zeros(0, 5, device=DEV), torch.zeros(0, device=DEV)
+    assert not ops.nll_loss_fits(z0)
+    assert lib.gnf_nll_loss_fwd(None, None, None, ctypes.c_void_p(gA.data_ptr()), 0, 5, None) == -1
+    flow = _flow("CouplingConditioner", "Affine", 6)
+    z, ld = flow(torch.zeros(0, 6, device=DEV))
+    assert torch.isnan(flow.loss(z, ld)).item()                  # torch: mean of an empty tensor
+
+
 def test_empty_contraction_and_empty_column_sum():
     """a zero-row batch as the CONTRACTION of a weight-gradient GEMM (K = 0: C = 0, operands NULL) and as the rows of a
     bias-gradient column sum (M = 0: out = 0) -- what torch returns for x.t() @ g and g.sum(0) on [0, n] tensors"""
