@@ -35,7 +35,7 @@ COND = 30
 S_NODES = 20
 PEAK_F32_TFLOPS = 157.3          # MI355X fp32 MFMA/vector peak (MI355X_MICROARCH.md)
 NOMINAL_GHZ = 2.4                # the clock behind that peak: 256 CUs x 4 SIMDs x 64 flop/clk x 2.4 GHz
-PMC_INPUTS = "r04_bench_inputs.json"
+PMC_INPUTS = "r05_bench_inputs.json"
 DOMINANT_OP = "gnf_mnistcnn_conv_bwd"       # the entry point of the dominant kernel (cnn_bwd_wino_k): timed live in the region
 # round 5: with x frozen the step goes through the plan variants of three entry points (include/gnf_hip.h, "structural zeros of
 # the gate backward"); their times are reported under the names of the calls they replace
@@ -419,7 +419,7 @@ def main():
             v["measured"] = "%d untimed steps behind the timed region" % ops_steps
         # PMC counters cannot be read from inside this process: HBM bytes per launch, MFMA instructions per image, other VALU
         # instructions per MFMA and the effective clock of the hand-written kernels are READ from
-        # profiles/r04_bench_inputs.json, which tools/make_bench_inputs.py writes from rocprofv3 --pmc passes over the same
+        # profiles/r05_bench_inputs.json, which tools/make_bench_inputs.py writes from rocprofv3 --pmc passes over the same
         # kernels at the same per-GPU size (null when the file is missing or the size differs)
         pmc = {}
         try:

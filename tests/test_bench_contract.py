@@ -7,7 +7,7 @@ import re
 from conftest import ROOT
 
 
-PMC_FILE = "r04_bench_inputs.json"
+PMC_FILE = "r05_bench_inputs.json"
 
 
 def test_bench_reads_pmc_figures_from_profiles():
@@ -28,8 +28,11 @@ def test_bench_reads_pmc_figures_from_profiles():
         assert 1.5 < e["effective_clock_GHz_in_pmc_pass"] < 2.6, (k, e["effective_clock_GHz_in_pmc_pass"])
         assert abs(e["cycles_per_launch"] / e["duration_ns_in_pmc_pass"] - e["effective_clock_GHz_in_pmc_pass"]) < 2e-3
         assert 0 <= e["lds_bank_conflict_frac_of_lds_cycles"] < 1
-    # the conv backward of round 4 issues fewer MFMAs per image than rounds 1-3 (conv1 on 16x16x1_4b: 99 instead of 129)
-    assert d["kernels"]["gnf_mnistcnn_conv_bwd"]["mfma_per_image"] < 1590
+    # the conv backward of round 4 issues fewer MFMAs per image than rounds 1-3 (conv1 on 16x16x1_4b: 99 instead of 129), that of
+    # round 5 fewer again (the T planes of the da1 groups no plan column reads are skipped: 1 555 -> ~1 431 at the MNIST prior),
+    # and it no longer writes the dense 243 MB cotangent of e
+    assert d["kernels"]["gnf_mnistcnn_conv_bwd"]["mfma_per_image"] < 1460
+    assert d["kernels"]["gnf_mnistcnn_conv_bwd"]["hbm_bytes_per_launch"] < 1.25e9
 
 
 def test_bench_prints_issue_figures_for_every_kernel():
