@@ -284,10 +284,9 @@ def main():
         return (time.perf_counter() - t) / n
 
     def fwd_bwd(_):
-        for p in flow.parameters():
-            p.grad = None
-        z, ld = flow(x)
-        flow.loss(z, ld).backward()
+        state.drop_grads()                   # .grad = None AND the flat-buffer slots handed back: the backward kernels write the
+        z, ld = flow(x)                      # gradients in place as in a training step (with p.grad = None alone every step
+        flow.loss(z, ld).backward()          # allocated fresh gradient tensors and autograd added A's two contributions)
 
     def mixed(i):
         for nrm in flow.getNormalizers():
