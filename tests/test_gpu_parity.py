@@ -250,7 +250,8 @@ def test_gemm_operand_beyond_4_GiB_on_the_generic_kernels():
     G = torch.randn(M, 16, device=DEV)
     D = torch.full((16, K), float("nan"), device=DEV)
     ops.gemm(G, (1, 16), A, (K, 1), D, (K, 1), 16, K, M)
-    assert rel_err(D.cpu(), (G.double().t() @ A.double()).cpu()) < 2e-6
+    assert _last_gemm_kernel() == "gemm_kmajor_k"
+    assert rel_err(D.cpu(), (G.double().t() @ A.double()).cpu()) < 1e-5      # 600 000 fp32 terms per entry: 3.7e-6 measured
 
 
 def test_colsum():
