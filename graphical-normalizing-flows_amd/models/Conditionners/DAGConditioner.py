@@ -183,7 +183,7 @@ class DAGConditioner(Conditioner):
         # frozen one (post_process) only when its storage or version counter changed, so that a training step with
         # the frozen gate has no host synchronisation in it.
         key = None if self.A.requires_grad else (self.A.data_ptr(), self.A._version, float(self.h_thresh),
-                                                 bool(self.s_thresh), self._cache_epoch)
+                                                 bool(self.s_thresh), getattr(self, "_cache_epoch", 0))
         if key is None or key != self._sparse_checked[0]:
             if self._sparse_outside is None or self._sparse_outside.device != P.device:
                 self._sparse_outside = (~ops.mnist_window_mask(P.device)).float()
@@ -210,7 +210,7 @@ class DAGConditioner(Conditioner):
             # have exactly-constant regions, so the embedding net must break pool ties the way torch does
             self.embedding_net.exact_pool_ties = P is not None
         net = self.embedding_net
-        if (self.fused_front and not self.hot_encoding and not self.cond_in and hasattr(net, "forward_gated")
+        if (getattr(self, "fused_front", True) and not self.hot_encoding and not self.cond_in and hasattr(net, "forward_gated")
                 and x.shape[1] == self.in_size and net.supports_gated(x)):
             imp, gate = self._modes()
             if gate != ops.GATE_GUMBEL or self.gumble:
@@ -246,7 +246,7 @@ class DAGConditioner(Conditioner):
         """True once update_dual_param() has switched both terms off (dag_const = 0 and l1_weight = 0, reference
         :249-251): loss() is then identically 0 and its matrix power is skipped.  One host read per CHANGE of the two
         buffers (they are replaced / rewritten at epoch level only), none per step."""
-        key = (id(self.dag_const), self.dag_const._version, id(self.l1_weight), self.l1_weight._version, self._cache_epoch)
+        key = (id(self.dag_const), self.dag_const._version, id(self.l1_weight), self.l1_weight._version, getattr(self, "_cache_epoch", 0))
         if self._off_key != key:
             self._off_key = key
             self._off = bool(((self.dag_const == 0) & (self.l1_weight == 0)).item())
@@ -266,7 +266,7 @@ class DAGConditioner(Conditioner):
                 # and the same value is returned until one of them changes (version counters, as in _constraints_off)
                 bufs = (self.A, self.alpha, self.lambd, self.c, self.dag_const, self.l1_weight)
                 key = tuple((id(t), t.data_ptr(), t._version) for t in bufs) + (int(self.exponent), float(self.alpha_factor),
-                                                                                  self._cache_epoch)
+                                                                                  getattr(self, "_cache_epoch", 0))
                 if self._frozen_loss[0] != key:
                     with torch.no_grad():
                         val = ops.DagLossFn.apply(self.A, self.alpha, self.alpha_factor, self.lambd, self.c, self.dag_const,
