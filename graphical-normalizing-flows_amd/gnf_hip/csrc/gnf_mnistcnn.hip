@@ -69,8 +69,12 @@ __device__ __forceinline__ int dslot(int o) { return (o & 3) + 4 * (o >> 3) + 8 
 // (3/3/3/2 per SIMD), so SIMD 3 (wavefronts 3, 7) takes most of conv1.  (4/1/1/1/4 measured: SIMD 3 becomes the last
 // one, 2.906 -> 2.919 ms; a unit is ~1 000 cycles, the balance cannot get finer than that.  Round 4, with the barrier
 // waits per wavefront in hand: eleven other deals incl. 4-unit wavefronts, -DGNF_BWD_C1U=..., all within +-0.3 % of this one.)
+// Round 5 (compact de, lighter da1 groups): {0,0,0,4,1,1,2,3} -- one unit each off the second wavefronts of SIMD 0 / 1, which
+// reached the end-of-image barrier last (tools/time_cnn_phases.py) -- 2.723 / 2.719 / 2.729 -> 2.714 / 2.711 / 2.708 ms, alternating on
+// one box (dense de: 2.890 / 2.886 / 2.882 -> 2.886 / 2.863 / 2.874); fourteen other deals within +-0.5 % or worse
+// (profiles/r05_c1u_sweep.txt).
 #ifndef GNF_BWD_C1U
-#define GNF_BWD_C1U {0, 0, 0, 3, 2, 2, 1, 3}
+#define GNF_BWD_C1U {0, 0, 0, 4, 1, 1, 2, 3}
 #endif
 __device__ constexpr int C1U[8] = GNF_BWD_C1U;
 __device__ constexpr int C1PRO[8] = {2, 2, 2, 1, 1, 1, 1, 1};   // the first image: dealt evenly (nothing to overlap with)
