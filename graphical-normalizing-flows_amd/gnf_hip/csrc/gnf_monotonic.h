@@ -32,7 +32,7 @@ struct MonoLayout {
   int pack_floats;                    // size of the whole pack
 };
 
-__host__ __device__ inline MonoLayout make_layout(int HT, int NH, int c) {
+__host__ __device__ inline MonoLayout make_layout(int HT, int NH, int c, bool frag_copies = false) {
   MonoLayout L;
   L.HT = HT; L.HP = 16 * HT; L.NH = NH; L.c = c; L.HM = 0; L.EX = 0;
   L.CP = (c + 15) / 16 * 16; L.LDH = L.CP + 4; L.LDW = L.HP + 4;
@@ -48,7 +48,7 @@ __host__ __device__ inline MonoLayout make_layout(int HT, int NH, int c) {
   L.o_W1hT = o; o += L.CP * L.LDW;
   L.total_floats = o;
   for (int l = 1; l < NH; ++l) { L.o_Wf[l] = 0; L.o_WTf[l] = 0; }
-  if (HT >= 7) {
+  if (HT >= 7 || frag_copies) {       // (frag_copies: the GNF_MONO_WIDE_EXP=1 A/B of the two-role kernels on a narrow net)
     for (int l = 1; l < NH; ++l) { L.o_Wf[l] = o; o += L.HP * L.HP; L.o_WTf[l] = o; o += L.HP * L.HP; }
   }
   L.pack_floats = o;

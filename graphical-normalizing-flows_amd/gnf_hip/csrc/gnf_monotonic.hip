@@ -1827,10 +1827,18 @@ constexpr int kLdsBudget = 160 * 1024;
 
 // layout of a net's pack + whether its kernels peel the leftover units of the last tile (all hidden widths H with
 // H / 16 == 3 and H mod 16 in {1, 2, 3}: the reference's default [50, 50, 50]); GNF_MONO_PEEL=0 keeps the padded form
+// GNF_MONO_WIDE_EXP=1 (measurement, round 5): a 4-tile net (H = 49..64, no peel) on the TWO-ROLE pair-major kernels of
+// gnf_monotonic_wide.hip instead of the one-wavefront-per-SIMD kernels of this file -- the same-box A/B behind
+// profiles/r05_mono_two_role_ab.txt
+bool mono_wide_exp() {
+  static const bool on = [] { const char* e = std::getenv("GNF_MONO_WIDE_EXP"); return e && e[0] == '1'; }();
+  return on;
+}
+
 MonoLayout net_layout(const gnf_mono_net* net, int HT) {
-  MonoLayout L = make_layout(HT, net->nl - 1, net->dims[0] - 1);
+  MonoLayout L = make_layout(HT, net->nl - 1, net->dims[0] - 1, HT == 4 && mono_wide_exp());
   static const bool enabled = [] { const char* e = std::getenv("GNF_MONO_PEEL"); return !(e && e[0] == '0'); }();
-  if (enabled && HT == 4) {
+  if (enabled && HT == 4 && !mono_wide_exp()) {
     const int H = net->dims[1];
     bool same = true;
     for (int l = 1; l < net->nl; ++l) same = same && net->dims[l] == H;
@@ -2179,6 +2187,7 @@ struct BwdPlan {
 // accumulates the hidden-layer weight gradients itself, nothing but Dsum is staged
 bool use_indw(const gnf_mono_net* net, const MonoLayout& L) {
   if (L.HT > 4 || L.NH < 2) return false;
+  if (L.HT == 4 && mono_wide_exp() && gnf_mono_bwd_wide_ok(L)) return false;      // (the two-role kernel takes it)
   for (int l = 1; l < L.NH; ++l)
     if (net->dims[l] >= L.HP) return false;
   const size_t lds = ((size_t)(L.total_floats + 3) / 4 * 4 + (size_t)kWaves * L.NH * 16 * kTS) * sizeof(float);
@@ -2329,7 +2338,7 @@ int gnf_monotonic_bwd(const float* pack, const gnf_mono_net* net, const float* x
   a.gz = gz; a.gjac = gjac; a.gx = gx; a.gh = gh; a.g_sb = g_sb; a.g_sd = g_sd; a.g_sc = g_sc;
   for (int l = 1; l < NH; ++l) { a.SA[l] = w + P.o_SA[l]; a.SD[l] = w + P.o_SD[l]; }
   a.Dsum = w + P.o_Dsum; a.part = w + P.o_part; a.NK = (int)NK;
-  a.ones = HT <= 4 && NH > 1;
+  a.ones = HT <= 4 && NH > 1 && !wide;       // (the two-role kernels carry the bias gradients in their partial vector rows)
   for (int l = 1; l < NH; ++l) a.ones = a.ones && net->dims[l] < HP;
   a.indw = wide ? 3 : (int)indw;
   if (indw && !wide) {                            // the two-node kernel when its LDS plan fits (A/B: GNF_MONO_INDW=1 keeps one node)
@@ -2408,11 +2417,11 @@ int gnf_monotonic_bwd(const float* pack, const gnf_mono_net* net, const float* x
       for (int64_t u0 = 0; u0 < HP; u0 += 64) {
         const int64_t nu = HP - u0 < 64 ? HP - u0 : 64;
         if ((rc = gnf_linear_tall_wgrad(a.Dsum + u0, HP, h + a.e0 * h_sd, h_sd, w + P.o_dW1h + u0 * L.c,
-                                        (HT > 4 || a.ones) ? w + P.o_vec + 2 * HP + u0 : nullptr, 1, a.ecount, nu, L.c,
+                                        (HT > 4 || a.ones || wide) ? w + P.o_vec + 2 * HP + u0 : nullptr, 1, a.ecount, nu, L.c,
                                         w + P.o_hpart, w + P.o_rs, s)))
           return rc;
       }
-    } else if (HT > 4 || a.ones) {     // first-layer bias gradient (and wide nets' others): column sums of staged arrays
+    } else if (HT > 4 || a.ones || wide) {     // first-layer bias gradient (and wide nets' others): column sums of staged arrays
       if ((rc = gnf_rowsum_tall_launch(a.Dsum, w + P.o_vec + 2 * HP, groups * 16, HP, 1, w + P.o_rs, s))) return rc;
     }
     // widest nets (H = 161..256): bias gradients of the hidden->hidden layers = column sums of the staged dpre rows --
