@@ -419,6 +419,9 @@ __device__ __forceinline__ void cnn_bwd_body(const CnnArgs& a, float* smem) {
     if (SP) {
       if (wave == 0 && img != img0) de_cols(img - gstride, cjp, a1n);
     } else if (img != img0) de_gather(img - gstride, a1n);
+#ifdef GNF_CNN_EXP_NOBMID          // measurement only (wrong results): what the barrier between the two intervals costs
+    if (!SP)
+#endif
     __syncthreads();
     TSTAMP(3);
     // ---- Xb: da1 of this image and conv1 of the next one.  Of the two wavefronts of a SIMD one starts with its conv1
