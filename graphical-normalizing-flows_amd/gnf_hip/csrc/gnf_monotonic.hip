@@ -529,14 +529,20 @@ __global__ __launch_bounds__(64 * kSplitWaves) void mono_inv_split_k(MonoArgs a)
 // evaluation (144 MFMAs) instead of two of the padded form (2 x 256) -- the level kernel of MNIST sampling 256 -> see
 // DESIGN.md section 6.  The partial sums are added in the fixed order of the wavefronts, as above.
 constexpr int kSplitWavesX = 12;     // 3 wavefronts per SIMD: 168 registers (at 16 / 128 registers eval2x spills)
-template <int HM, int EX, int WM, int EPG = 16>
+// PTS = 3 (round 5): TWO bisection steps per round.  Step 2 evaluates the midpoint of whichever half step 1 keeps, i.e. one of
+// the two quarter points -- so a round evaluates the quadrature at the midpoint AND both quarter points at once, three
+// times the wavefronts (point p on wavefronts [p nwp, (p+1) nwp)), ONE barrier, and takes both decisions from the three
+// sums.  Same midpoints, same node order, same partial-sum order per point: the result is that of the 20 sequential steps bit
+// for bit, in 10 dependent quadratures instead of 20 (the level kernels of a sampling pass are latency-bound: 180 workgroups
+// of 3 wavefronts left every fourth SIMD idle and the other three waiting on one pair evaluation per step).
+template <int HM, int EX, int WM, int EPG = 16, int PTS = 1>
 __global__ __launch_bounds__(64 * kSplitWavesX) void mono_inv_split_x_k(MonoArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const MonoLayout& L = a.L;
   const float* wp = a.pack;
   float* psum = smem;                            // [2][nw][16]
   constexpr int NS = 16 / EPG;                   // node sub-slots of a wavefront: lane j -> element j % EPG, sub-slot j / EPG
-  const int nw = blockDim.x >> 6;                // wavefronts sharing the group (<= kSplitWavesX)
+  const int nw = blockDim.x >> 6;                // wavefronts of the workgroup (<= kSplitWavesX): PTS points x nwp node-slot waves
   if (WM == 1) {
     for (int i = threadIdx.x * 4; i < L.fwd_floats; i += blockDim.x * 4)
       *reinterpret_cast<f32x4*>(smem + i) = ld4(a.pack + i);
@@ -547,12 +553,14 @@ __global__ __launch_bounds__(64 * kSplitWavesX) void mono_inv_split_x_k(MonoArgs
   auto getW = [&](int l) -> const float* { return wp + L.o_W[l]; };
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int q = lane >> 4, j = lane & 15;
+  const int nwp = nw / PTS;                      // wavefronts per evaluation point
+  const int pt = PTS == 1 ? 0 : wave / nwp, wv = PTS == 1 ? wave : wave - pt * nwp;     // wave-uniform
   const int64_t ngroups = (a.n + EPG - 1) / EPG;
   const float fS = (float)a.S;
   int buf = 0;
   for (int64_t grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
     const int64_t e = grp * EPG + (j % EPG);
-    const int slot = wave * NS + j / EPG, nslots = nw * NS;        // this lane's node-pair slot
+    const int slot = wv * NS + j / EPG, nslots = nwp * NS;         // this lane's node-pair slot
     const bool valid = e < a.n;
     const int64_t ec = valid ? e : a.n - 1;
     const int64_t b = ec / a.d, i = ec - b * a.d;
@@ -563,9 +571,15 @@ __global__ __launch_bounds__(64 * kSplitWavesX) void mono_inv_split_x_k(MonoArgs
     const float h0 = a.h[hbase];
     const float zt = a.zt[ec];
     float xmax = 20.f, xmin = -20.f;
-    for (int it = 0; it < 20; ++it) {
+    for (int it = 0; it < 20; it += (PTS == 3 ? 2 : 1)) {
       const float xm = (xmax + xmin) * .5f;
-      const float xT = fS * (xm / fS);
+      // the points of this round: the midpoint; (PTS = 3) the midpoints of the left and of the right half
+      float xp[PTS];
+      xp[0] = xm;
+      if (PTS == 3) { xp[1] = (xm + xmin) * .5f; xp[2] = (xmax + xm) * .5f; }
+      float xe = xp[0];
+      if (PTS == 3) xe = pt == 1 ? xp[1] : (pt == 2 ? xp[2] : xe);
+      const float xT = fS * (xe / fS);
       float acc = 0.f;
       for (int kb = 0; kb <= a.S; kb += 2 * nslots) {              // wave-uniform trip count; a lane past the rule idles at weight 0
         const int kk = kb + 2 * slot;
@@ -582,15 +596,26 @@ __global__ __launch_bounds__(64 * kSplitWavesX) void mono_inv_split_x_k(MonoArgs
       }
       if (q == 0) psum[(buf * nw + wave) * 16 + j] = acc;
       __syncthreads();
-      // the element's node slots: wavefront-major, sub-slot-minor, the same order in every lane of the element
-      const float* ps = psum + buf * nw * 16 + (j % EPG);
-      float tot = 0.f;
-      for (int w = 0; w < nw; ++w)
+      // the element's node slots of each point: wavefront-major, sub-slot-minor, the same order in every lane of the element
+      float zp[PTS];
 #pragma unroll
-        for (int u = 0; u < NS; ++u) tot += ps[16 * w + EPG * u];
-      const float zm = tot * xT * .5f + h0;
+      for (int p = 0; p < PTS; ++p) {
+        const float* ps = psum + (buf * nw + p * nwp) * 16 + (j % EPG);
+        float tot = 0.f;
+        for (int w = 0; w < nwp; ++w)
+#pragma unroll
+          for (int u = 0; u < NS; ++u) tot += ps[16 * w + EPG * u];
+        const float xTp = fS * (xp[p] / fS);
+        zp[p] = tot * xTp * .5f + h0;
+      }
       buf ^= 1;
-      if (zm > zt) xmax = xm; else xmin = xm;
+      if (zp[0] > zt) {
+        xmax = xm;
+        if (PTS == 3) { if (zp[1] > zt) xmax = xp[1]; else xmin = xp[1]; }
+      } else {
+        xmin = xm;
+        if (PTS == 3) { if (zp[PTS - 1] > zt) xmax = xp[PTS - 1]; else xmin = xp[PTS - 1]; }
+      }
     }
     if (valid && q == 0 && wave == 0 && j < EPG) a.xo[e] = (xmax + xmin) * .5f;
   }
@@ -1863,10 +1888,19 @@ int launch_fwd(const MonoArgs& a, hipStream_t s) {
     const bool quarter = !quarter_off && ngroups < 256;               // groups of 4 elements x 4 node pairs (see above)
     if (a.L.EX > 0 && quarter) {
       const int nwq = (pairs + 3) / 4 < kSplitWavesX ? (pairs + 3) / 4 : kSplitWavesX;
-      const size_t lds_q = (wlds ? lds : 0) + 2 * nwq * 16 * sizeof(float);
+      // two bisection steps per round (three evaluation points, three times the wavefronts) when they fit the workgroup:
+      // S <= 30.  GNF_MONO_INV_PTS=1 keeps one step per round (A/B and the bit-equality test)
+      static const bool one_pt = getenv("GNF_MONO_INV_PTS") && getenv("GNF_MONO_INV_PTS")[0] == '1';
+      const bool three = !one_pt && wlds && 3 * nwq <= kSplitWavesX;
+      const int nwl = three ? 3 * nwq : nwq;
+      const size_t lds_q = (wlds ? lds : 0) + 2 * nwl * 16 * sizeof(float);
       const unsigned gq = (unsigned)((a.n + 3) / 4);
 #define GNF_INVXQ(EX_)                                                                                         \
-      if (wlds) {                                                                                              \
+      if (three) {                                                                                             \
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mono_inv_split_x_k<3, EX_, 1, 4, 3>),         \
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_q);                     \
+        hipLaunchKernelGGL((mono_inv_split_x_k<3, EX_, 1, 4, 3>), dim3(gq), dim3(64 * nwl), lds_q, s, a);      \
+      } else if (wlds) {                                                                                       \
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mono_inv_split_x_k<3, EX_, 1, 4>),            \
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_q);                     \
         hipLaunchKernelGGL((mono_inv_split_x_k<3, EX_, 1, 4>), dim3(gq), dim3(64 * nwq), lds_q, s, a);         \

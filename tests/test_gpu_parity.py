@@ -566,6 +566,41 @@ def test_mnist_three_scale_invert_round_trip():
     assert rel_err(xr.cpu(), x.cpu()) < 1e-4
 
 
+_INV_SNIPPET = """
+import sys, torch
+sys.path[:0] = %r
+from gnf_hip import ops
+from models import MonotonicNormalizer
+torch.manual_seed(3)
+n, d, c, S = %d, 1, 30, %d
+norm = MonotonicNormalizer([50, 50, 50], c, nb_steps=S).to("cuda:0")
+g = torch.Generator().manual_seed(4)
+z = (torch.randn(n, d, generator=g) * 3).to("cuda:0")
+h = torch.randn(n, d, c, generator=g).to("cuda:0")
+x = ops.monotonic_inverse(z, h, S, [p.detach() for p in norm.integrand_net.flat_params()])
+torch.save(x.cpu(), %r)
+"""
+
+
+@pytest.mark.parametrize("n,S", [(700, 20), (37, 20), (3, 27), (1000, 30), (700, 7)])
+def test_split_inverse_two_steps_per_round_is_bit_identical(n, S, tmp_path):
+    """the level kernels of a sampling pass take TWO bisection steps per round (midpoint + both quarter points evaluated at
+    once by three times the wavefronts, mono_inv_split_x_k<..., PTS = 3>): same midpoints, same sums, so the same bits as the
+    20 sequential steps (GNF_MONO_INV_PTS=1, run in a second process: the switch is read once) -- reference
+    MonotonicNormalizer.py:69-83"""
+    import os, subprocess, sys
+    from conftest import ROOT, PKG
+    outs = []
+    for tag, env in (("pts3", {}), ("pts1", {"GNF_MONO_INV_PTS": "1"})):
+        f = str(tmp_path / (tag + ".pt"))
+        code = _INV_SNIPPET % ([ROOT, PKG], n, S, f)
+        r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **env), capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs.append(torch.load(f))
+    assert torch.equal(outs[0], outs[1])
+    assert torch.isfinite(outs[0]).all() and float(outs[0].abs().max()) <= 20.
+
+
 @pytest.mark.parametrize("normalizer", ["affine", "monotonic"])
 def test_dag_level_schedule_inversion_equals_fixed_point(normalizer):
     """inverting each variable once, in topological order, gives the values of the reference's
