@@ -529,20 +529,14 @@ __global__ __launch_bounds__(64 * kSplitWaves) void mono_inv_split_k(MonoArgs a)
 // evaluation (144 MFMAs) instead of two of the padded form (2 x 256) -- the level kernel of MNIST sampling 256 -> see
 // DESIGN.md section 6.  The partial sums are added in the fixed order of the wavefronts, as above.
 constexpr int kSplitWavesX = 12;     // 3 wavefronts per SIMD: 168 registers (at 16 / 128 registers eval2x spills)
-// PTS = 3 (round 5): TWO bisection steps per round.  Step 2 evaluates the midpoint of whichever half step 1 keeps, i.e. one of
-// the two quarter points -- so a round evaluates the quadrature at the midpoint AND both quarter points at once, three
-// times the wavefronts (point p on wavefronts [p nwp, (p+1) nwp)), ONE barrier, and takes both decisions from the three
-// sums.  Same midpoints, same node order, same partial-sum order per point: the result is that of the 20 sequential steps bit
-// for bit, in 10 dependent quadratures instead of 20 (the level kernels of a sampling pass are latency-bound: 180 workgroups
-// of 3 wavefronts left every fourth SIMD idle and the other three waiting on one pair evaluation per step).
-template <int HM, int EX, int WM, int EPG = 16, int PTS = 1>
+template <int HM, int EX, int WM, int EPG = 16>
 __global__ __launch_bounds__(64 * kSplitWavesX) void mono_inv_split_x_k(MonoArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const MonoLayout& L = a.L;
   const float* wp = a.pack;
   float* psum = smem;                            // [2][nw][16]
   constexpr int NS = 16 / EPG;                   // node sub-slots of a wavefront: lane j -> element j % EPG, sub-slot j / EPG
-  const int nw = blockDim.x >> 6;                // wavefronts of the workgroup (<= kSplitWavesX): PTS points x nwp node-slot waves
+  const int nw = blockDim.x >> 6;                // wavefronts sharing the group (<= kSplitWavesX)
   if (WM == 1) {
     for (int i = threadIdx.x * 4; i < L.fwd_floats; i += blockDim.x * 4)
       *reinterpret_cast<f32x4*>(smem + i) = ld4(a.pack + i);
@@ -553,14 +547,12 @@ __global__ __launch_bounds__(64 * kSplitWavesX) void mono_inv_split_x_k(MonoArgs
   auto getW = [&](int l) -> const float* { return wp + L.o_W[l]; };
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int q = lane >> 4, j = lane & 15;
-  const int nwp = nw / PTS;                      // wavefronts per evaluation point
-  const int pt = PTS == 1 ? 0 : wave / nwp, wv = PTS == 1 ? wave : wave - pt * nwp;     // wave-uniform
   const int64_t ngroups = (a.n + EPG - 1) / EPG;
   const float fS = (float)a.S;
   int buf = 0;
   for (int64_t grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
     const int64_t e = grp * EPG + (j % EPG);
-    const int slot = wv * NS + j / EPG, nslots = nwp * NS;         // this lane's node-pair slot
+    const int slot = wave * NS + j / EPG, nslots = nw * NS;        // this lane's node-pair slot
     const bool valid = e < a.n;
     const int64_t ec = valid ? e : a.n - 1;
     const int64_t b = ec / a.d, i = ec - b * a.d;
@@ -571,15 +563,9 @@ __global__ __launch_bounds__(64 * kSplitWavesX) void mono_inv_split_x_k(MonoArgs
     const float h0 = a.h[hbase];
     const float zt = a.zt[ec];
     float xmax = 20.f, xmin = -20.f;
-    for (int it = 0; it < 20; it += (PTS == 3 ? 2 : 1)) {
+    for (int it = 0; it < 20; ++it) {
       const float xm = (xmax + xmin) * .5f;
-      // the points of this round: the midpoint; (PTS = 3) the midpoints of the left and of the right half
-      float xp[PTS];
-      xp[0] = xm;
-      if (PTS == 3) { xp[1] = (xm + xmin) * .5f; xp[2] = (xmax + xm) * .5f; }
-      float xe = xp[0];
-      if (PTS == 3) xe = pt == 1 ? xp[1] : (pt == 2 ? xp[2] : xe);
-      const float xT = fS * (xe / fS);
+      const float xT = fS * (xm / fS);
       float acc = 0.f;
       for (int kb = 0; kb <= a.S; kb += 2 * nslots) {              // wave-uniform trip count; a lane past the rule idles at weight 0
         const int kk = kb + 2 * slot;
@@ -596,25 +582,110 @@ __global__ __launch_bounds__(64 * kSplitWavesX) void mono_inv_split_x_k(MonoArgs
       }
       if (q == 0) psum[(buf * nw + wave) * 16 + j] = acc;
       __syncthreads();
-      // the element's node slots of each point: wavefront-major, sub-slot-minor, the same order in every lane of the element
-      float zp[PTS];
+      // the element's node slots: wavefront-major, sub-slot-minor, the same order in every lane of the element
+      const float* ps = psum + buf * nw * 16 + (j % EPG);
+      float tot = 0.f;
+      for (int w = 0; w < nw; ++w)
 #pragma unroll
-      for (int p = 0; p < PTS; ++p) {
-        const float* ps = psum + (buf * nw + p * nwp) * 16 + (j % EPG);
-        float tot = 0.f;
-        for (int w = 0; w < nwp; ++w)
+        for (int u = 0; u < NS; ++u) tot += ps[16 * w + EPG * u];
+      const float zm = tot * xT * .5f + h0;
+      buf ^= 1;
+      if (zm > zt) xmax = xm; else xmin = xm;
+    }
+    if (valid && q == 0 && wave == 0 && j < EPG) a.xo[e] = (xmax + xmin) * .5f;
+  }
+}
+
+// Round 5, the level kernel of a sampling pass: TWO bisection steps per round.  Step 2 evaluates the midpoint of whichever
+// half step 1 keeps, i.e. one of the two quarter points -- so a round evaluates the integrand at the nodes of THREE points
+// (midpoint, both quarter points) at once and takes both decisions from the three quadrature sums: 10 dependent quadratures
+// instead of 20, and the kernel is pure latency (180 workgroups of 3 wavefronts at S = 20, one pair evaluation deep).  The
+// 3 (S + 1) evaluations of an element are laid out FLAT over the node-pair slots (eval2x takes any two abscissae of an
+// element): 63 evaluations = 32 pairs = 8 wavefronts of 4 elements x 4 slots at S = 20 -- two pair evaluations per SIMD and
+// round, where a first version with one point per wavefront triple (3 x 3 wavefronts, 36 slots for 33 pairs) had three and
+// LOST to the sequential kernel (113 vs 103 us per level).  The raw integrand values meet in LDS; every lane of an element
+// then forms the three sums in exactly the order of mono_inv_split_x_k (pairs (0,1), (2,3), ... as fma chains, added
+// ascending), with the same midpoints: the result is that of the 20 sequential steps BIT FOR BIT (tested).  S <= 31.
+template <int HM, int EX>
+__global__ __launch_bounds__(64 * kSplitWavesX) void mono_inv_ks_x_k(MonoArgs a) {
+  constexpr int EPG = 4, NS = 16 / EPG;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const MonoLayout& L = a.L;
+  for (int i = threadIdx.x * 4; i < L.fwd_floats; i += blockDim.x * 4)
+    *reinterpret_cast<f32x4*>(smem + i) = ld4(a.pack + i);
+  const int S1 = a.S + 1, S1P = (S1 + 3) & ~3, NV = 3 * S1;
+  float* wq = smem + L.fwd_floats;               // [S + 1] weights of the rule
+  float* tq = wq + S1P;                          // [S + 1] its nodes
+  float* fbuf = tq + S1P;                        // [2][NV][EPG] integrand values of the round
+  float* zs = fbuf + 2 * NV * EPG;               // [2][3][EPG] the quadrature sums of the round
+  for (int i = threadIdx.x; i < S1; i += blockDim.x) { wq[i] = a.ccw[i]; tq[i] = a.cct[i]; }
+  __syncthreads();
+  const float* wp = smem;
+  auto getW = [&](int l) -> const float* { return wp + L.o_W[l]; };
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int q = lane >> 4, j = lane & 15, el = j % EPG;
+  // this lane's two evaluations: flat index v = point * (S + 1) + node
+  const int v0 = 2 * (wave * NS + j / EPG), v1 = v0 + 1;
+  const bool on0 = v0 < NV, on1 = v1 < NV;
+  const int p0 = on0 ? v0 / S1 : 0, k0 = on0 ? v0 - p0 * S1 : 0;
+  const int p1 = on1 ? v1 / S1 : p0, k1 = on1 ? v1 - p1 * S1 : k0;
+  const float ta = (tq[k0] + 1.f), tb = (tq[k1] + 1.f);
+  const int64_t ngroups = (a.n + EPG - 1) / EPG;
+  const float fS = (float)a.S;
+  int buf = 0;
+  for (int64_t grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
+    const int64_t e = grp * EPG + el;
+    const bool valid = e < a.n;
+    const int64_t ec = valid ? e : a.n - 1;
+    const int64_t b = ec / a.d, i = ec - b * a.d;
+    const int64_t hbase = b * a.h_sb + i * a.h_sd;
+    f32x4 c1[HM];
+    float c1x[EX];
+    cond_bias_x<HM, EX>(wp, L, a.h, hbase, a.h_sc, q, j, c1, c1x);
+    const float h0 = a.h[hbase];
+    const float zt = a.zt[ec];
+    float xmax = 20.f, xmin = -20.f;
+    for (int it = 0; it < 20; it += 2) {
+      const float xm = (xmax + xmin) * .5f;
+      float xp[3], xT[3];
+      xp[0] = xm; xp[1] = (xm + xmin) * .5f; xp[2] = (xmax + xm) * .5f;      // step 2's midpoint for either outcome of step 1
 #pragma unroll
-          for (int u = 0; u < NS; ++u) tot += ps[16 * w + EPG * u];
-        const float xTp = fS * (xp[p] / fS);
-        zp[p] = tot * xTp * .5f + h0;
+      for (int p = 0; p < 3; ++p) xT[p] = fS * (xp[p] / fS);
+      const float xTa = p0 == 0 ? xT[0] : (p0 == 1 ? xT[1] : xT[2]);
+      const float xTb = p1 == 0 ? xT[0] : (p1 == 1 ? xT[1] : xT[2]);
+      const float xa = xTa * ta * .5f, xb = xTb * tb * .5f;
+      float fa, fb;
+      eval2x<HM, EX>(wp, L, c1, c1x, xa, xb, q, j, fa, fb, getW);
+      float* fw = fbuf + buf * NV * EPG + el;
+      if (q == 0) {
+        if (on0) fw[v0 * EPG] = fa;
+        if (on1) fw[v1 * EPG] = fb;
       }
+      __syncthreads();
+      // the three sums of each element: ONE lane per (point, element) -- lane (q = point, j = element) of wavefront 0 -- walks
+      // the 21 values in the sequential kernel's order and leaves z in LDS (every lane of the workgroup forming all three
+      // sums itself was 126 LDS reads per lane and round: slower than the 20 sequential steps)
+      if (wave == 0 && q < 3 && j < EPG) {
+        const float* f = fbuf + buf * NV * EPG + j + q * S1 * EPG;
+        float tot = 0.f;
+        for (int kk = 0; kk < S1; kk += 2) {                // pair (kk, kk + 1) as the sequential kernel forms it
+          float acc = fmaf(wq[kk], f[kk * EPG], 0.f);
+          if (kk + 1 < S1) acc = fmaf(wq[kk + 1], f[(kk + 1) * EPG], acc);
+          tot += acc;
+        }
+        zs[(buf * 3 + q) * EPG + j] = tot;
+      }
+      __syncthreads();
+      float zp[3];
+#pragma unroll
+      for (int p = 0; p < 3; ++p) zp[p] = zs[(buf * 3 + p) * EPG + el] * xT[p] * .5f + h0;
       buf ^= 1;
       if (zp[0] > zt) {
         xmax = xm;
-        if (PTS == 3) { if (zp[1] > zt) xmax = xp[1]; else xmin = xp[1]; }
+        if (zp[1] > zt) xmax = xp[1]; else xmin = xp[1];
       } else {
         xmin = xm;
-        if (PTS == 3) { if (zp[PTS - 1] > zt) xmax = xp[PTS - 1]; else xmin = xp[PTS - 1]; }
+        if (zp[2] > zt) xmax = xp[2]; else xmin = xp[2];
       }
     }
     if (valid && q == 0 && wave == 0 && j < EPG) a.xo[e] = (xmax + xmin) * .5f;
@@ -1886,21 +1957,33 @@ int launch_fwd(const MonoArgs& a, hipStream_t s) {
     const int pairs = (a.S + 2) / 2;
     static const bool quarter_off = getenv("GNF_MONO_INV_EPG4") && getenv("GNF_MONO_INV_EPG4")[0] == '0';   // A/B switch
     const bool quarter = !quarter_off && ngroups < 256;               // groups of 4 elements x 4 node pairs (see above)
+    // level-sized problems on a peeled net: two bisection steps per round (mono_inv_ks_x_k) when the 3 (S + 1) evaluations of
+    // an element fit the workgroup's pair slots (S <= 31) and the weight image is LDS-resident; GNF_MONO_INV_PTS=1 keeps the
+    // one-step kernel (A/B and the bit-equality test)
+    static const bool one_pt = getenv("GNF_MONO_INV_PTS") && getenv("GNF_MONO_INV_PTS")[0] == '1';
+    const int ks_waves = (3 * (a.S + 1) + 7) / 8;                     // pairs / 4 slots per wavefront
+    if (a.L.EX > 0 && quarter && wlds && !one_pt && ks_waves <= kSplitWavesX) {
+      const int S1P = (a.S + 4) & ~3;
+      const size_t lds_k = lds + (size_t)(2 * S1P + 2 * 3 * (a.S + 1) * 4 + 2 * 3 * 4) * sizeof(float);
+      const unsigned gq = (unsigned)((a.n + 3) / 4);
+      if (a.L.EX <= 2) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mono_inv_ks_x_k<3, 2>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_k);
+        hipLaunchKernelGGL((mono_inv_ks_x_k<3, 2>), dim3(gq), dim3(64 * ks_waves), lds_k, s, a);
+      } else {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mono_inv_ks_x_k<3, 3>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_k);
+        hipLaunchKernelGGL((mono_inv_ks_x_k<3, 3>), dim3(gq), dim3(64 * ks_waves), lds_k, s, a);
+      }
+      GNF_LAUNCH_CHECK();
+      return 0;
+    }
     if (a.L.EX > 0 && quarter) {
       const int nwq = (pairs + 3) / 4 < kSplitWavesX ? (pairs + 3) / 4 : kSplitWavesX;
-      // two bisection steps per round (three evaluation points, three times the wavefronts) when they fit the workgroup:
-      // S <= 30.  GNF_MONO_INV_PTS=1 keeps one step per round (A/B and the bit-equality test)
-      static const bool one_pt = getenv("GNF_MONO_INV_PTS") && getenv("GNF_MONO_INV_PTS")[0] == '1';
-      const bool three = !one_pt && wlds && 3 * nwq <= kSplitWavesX;
-      const int nwl = three ? 3 * nwq : nwq;
-      const size_t lds_q = (wlds ? lds : 0) + 2 * nwl * 16 * sizeof(float);
+      const size_t lds_q = (wlds ? lds : 0) + 2 * nwq * 16 * sizeof(float);
       const unsigned gq = (unsigned)((a.n + 3) / 4);
 #define GNF_INVXQ(EX_)                                                                                         \
-      if (three) {                                                                                             \
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mono_inv_split_x_k<3, EX_, 1, 4, 3>),         \
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_q);                     \
-        hipLaunchKernelGGL((mono_inv_split_x_k<3, EX_, 1, 4, 3>), dim3(gq), dim3(64 * nwl), lds_q, s, a);      \
-      } else if (wlds) {                                                                                       \
+      if (wlds) {                                                                                              \
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mono_inv_split_x_k<3, EX_, 1, 4>),            \
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_q);                     \
         hipLaunchKernelGGL((mono_inv_split_x_k<3, EX_, 1, 4>), dim3(gq), dim3(64 * nwq), lds_q, s, a);         \
