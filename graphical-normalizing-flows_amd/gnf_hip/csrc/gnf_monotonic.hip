@@ -667,11 +667,23 @@ __global__ __launch_bounds__(64 * kSplitWavesX) void mono_inv_ks_x_k(MonoArgs a)
       // sums itself was 126 LDS reads per lane and round: slower than the 20 sequential steps)
       if (wave == 0 && q < 3 && j < EPG) {
         const float* f = fbuf + buf * NV * EPG + j + q * S1 * EPG;
+        // all reads first (S + 1 <= 32: the launch condition), then the chain: as a loop over a run-time node count every
+        // pair waited for its own LDS round trip (11 x ~150 cycles per round at S = 20)
+        float fv[32], wv[32];
+#pragma unroll
+        for (int kk = 0; kk < 32; ++kk) {
+          const int kc = kk < S1 ? kk : S1 - 1;
+          fv[kk] = f[kc * EPG];
+          wv[kk] = wq[kc];
+        }
         float tot = 0.f;
-        for (int kk = 0; kk < S1; kk += 2) {                // pair (kk, kk + 1) as the sequential kernel forms it
-          float acc = fmaf(wq[kk], f[kk * EPG], 0.f);
-          if (kk + 1 < S1) acc = fmaf(wq[kk + 1], f[(kk + 1) * EPG], acc);
-          tot += acc;
+#pragma unroll
+        for (int kk = 0; kk < 32; kk += 2) {                // pair (kk, kk + 1) as the sequential kernel forms it
+          if (kk < S1) {
+            float acc = fmaf(wv[kk], fv[kk], 0.f);
+            if (kk + 1 < S1) acc = fmaf(wv[kk + 1], fv[kk + 1], acc);
+            tot += acc;
+          }
         }
         zs[(buf * 3 + q) * EPG + j] = tot;
       }
