@@ -21,7 +21,7 @@ c_stream = ctypes.c_void_p
 
 MONO_MAX_LAYERS = 8
 DAG_PLAN_KC = 32          # GNF_DAG_PLAN_KC
-ABI_VERSION = 5           # GNF_ABI_VERSION of include/gnf_hip.h this binding was written against
+ABI_VERSION = 6           # GNF_ABI_VERSION of include/gnf_hip.h this binding was written against
 
 
 class MonoNet(ctypes.Structure):
@@ -79,6 +79,8 @@ SIGNATURES = {
                                   c_f, c_i64, c_i64, c_stream]),
     "gnf_monotonic_inv": (c_int, [c_f, ctypes.POINTER(MonoNet), c_f, c_f, c_i64, c_i64, c_i64, c_f, c_f, c_int, c_f,
                                   c_i64, c_i64, c_stream]),
+    "gnf_monotonic_inv_scatter": (c_int, [c_f, ctypes.POINTER(MonoNet), c_f, c_f, c_i64, c_i64, c_i64, c_f, c_f, c_int, c_f,
+                                          ctypes.c_void_p, c_i64, c_i64, c_i64, c_stream]),
     "gnf_monotonic_bwd_ws_bytes": (c_i64, [ctypes.POINTER(MonoNet), c_int, c_i64, c_i64]),
     "gnf_monotonic_bwd": (c_int, [c_f, ctypes.POINTER(MonoNet), c_f, c_f, c_i64, c_i64, c_i64, c_f, c_f, c_int, c_f,
                                   c_f, c_f, c_f, c_i64, c_i64, c_i64, ctypes.POINTER(ctypes.c_void_p),
@@ -100,6 +102,9 @@ SIGNATURES = {
     "gnf_mnistcnn_sparse_prepare": (c_int, [c_f, c_f, c_f, c_f, c_f, c_i64, ctypes.c_void_p, c_i64, c_stream]),
     "gnf_mnistcnn_sparse_fwd_prepared": (c_int, [c_f, c_i64, c_f, ctypes.c_void_p, c_i64, ctypes.c_void_p, c_i64, c_f, c_f,
                                                  c_f, c_f, c_i64, ctypes.c_void_p, c_f, ctypes.c_void_p, c_i64, c_stream]),
+    "gnf_mnistcnn_sparse_fwd_prepared_fc2": (c_int, [c_f, c_i64, c_f, ctypes.c_void_p, c_i64, ctypes.c_void_p, c_i64, c_f, c_f,
+                                                     c_f, c_f, c_i64, ctypes.c_void_p, c_f, c_f, c_i64, c_f, ctypes.c_void_p,
+                                                     c_i64, c_stream]),
     "gnf_mnistcnn_sparse_bwd_ws_bytes": (c_i64, [c_i64, c_i64, c_i64]),
     "gnf_mnistcnn_sparse_bwd": (c_int, [c_f, c_i64, c_f, ctypes.c_void_p, c_i64, ctypes.c_void_p, c_i64,
                                         ctypes.c_void_p, c_i64, ctypes.c_void_p, c_f, c_f, c_f,

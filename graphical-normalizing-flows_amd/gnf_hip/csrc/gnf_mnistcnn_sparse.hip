@@ -111,13 +111,20 @@ __device__ __forceinline__ int quad_min(int v) {
 
 // SAVE: also record, per (cell, channel), which of the 4 positions won the max-pool (first maximum in scan order, what
 // torch's max_pool2d backward uses) -- one byte each, same [cell][channel] layout as pd
-template <bool SAVE>
+//
+// SPLIT (inference on few copies -- a level of a sampling pass is ~700 of them, less than three per CU): the FOUR wavefronts
+// of a workgroup share one masked copy -- conv1's nine position tiles dealt 3/2/2/2, conv2's seven 2/2/2/1, two barriers --
+// so a copy's ~280 dependent MFMAs are a quarter as deep (the one-wavefront form is the throughput form: no barrier at all).
+template <bool SAVE, bool SPLIT>
 __global__ __launch_bounds__(64 * WAVES, 3) void sparse_crop_k(SparseArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int q = lane >> 4, j = lane & 15;
-  float* e_s = smem + wave * WLDS;
+  float* e_s = smem + (SPLIT ? 0 : wave * WLDS);
   float* a1_s = e_s + ESZ;
+  constexpr int N1 = SPLIT ? 3 : 9, N2 = SPLIT ? 2 : 7, NT = SPLIT ? 1 : 4;
+  const int nb1 = SPLIT ? (wave ? 2 * wave + 1 : 0) : 0, n1 = SPLIT ? (wave ? 2 : 3) : 9;   // conv1 tiles [nb1, nb1 + n1)
+  const int nb2 = SPLIT ? 2 * wave : 0, n2 = SPLIT ? (wave == 3 ? 1 : 2) : 7;              // conv2 tiles [nb2, nb2 + n2)
 
   // ---- weights as MFMA A operands: lane (j = output channel, q = K slot)
   float wa1[3], wa2[36];
@@ -133,91 +140,101 @@ __global__ __launch_bounds__(64 * WAVES, 3) void sparse_crop_k(SparseArgs a) {
   for (int r = 0; r < 4; ++r) { bias1[r] = a.b1[4 * q + r]; bias2[r] = a.b2[4 * q + r]; bgv[r] = a.bg[4 * q + r]; }
 
   // ---- per-lane LDS offsets, independent of the masked copy
-  int eo[9][3];                   // conv1 B operand: e_s offset of (position 16 nb + j, tap 4 s + q)
+  int eo[N1][3];                  // conv1 B operand: e_s offset of (position 16 nb + j, tap 4 s + q)
 #pragma unroll
-  for (int nb = 0; nb < 9; ++nb) {
+  for (int k = 0; k < N1; ++k) {
+    const int nb = nb1 + (k < n1 ? k : 0);
     const int p = 16 * nb + j, y = p / A1, x = p - A1 * y;
 #pragma unroll
     for (int s = 0; s < 3; ++s) {
       const int tap = 4 * s + q, ty = tap < 9 ? tap / 3 : 0, tx = tap < 9 ? tap - 3 * ty : 0;
-      eo[nb][s] = (y + ty) * ES + x + tx;
+      eo[k][s] = (y + ty) * ES + x + tx;
     }
   }
-  int po[7];                      // conv2 B operand: a1_s offset of (cell 4 nb + j/4, sub-position j%4, channel slot q)
+  int po[N2];                     // conv2 B operand: a1_s offset of (cell 4 nb + j/4, sub-position j%4, channel slot q)
 #pragma unroll
-  for (int nb = 0; nb < 7; ++nb) {
+  for (int k = 0; k < N2; ++k) {
+    const int nb = nb2 + (k < n2 ? k : 0);
     int cell = 4 * nb + (j >> 2);
     cell = cell < NCELL ? cell : NCELL - 1;
     const int cy = cell / 5, cx = cell - 5 * cy;
-    po[nb] = q * PL + (2 * cy + ((j >> 1) & 1)) * A1 + 2 * cx + (j & 1);
+    po[k] = q * PL + (2 * cy + ((j >> 1) & 1)) * A1 + 2 * cx + (j & 1);
   }
   const int a1w = 4 * q * PL + j;                              // conv1 D store: channel 4q + r, position 16 nb + j
 
-  // ---- the crop of e = x * P[pixel] of one masked copy: 196 values, 4 per lane (the last lane group idles on the 4th)
-  int ce[4], cl[4];
+  // ---- the crop of e = x * P[pixel] of one masked copy: 196 values, 4 per lane (the last lane group idles on the 4th;
+  //      SPLIT: one per thread of the workgroup)
+  int ce[NT], cl[NT];
 #pragma unroll
-  for (int t = 0; t < 4; ++t) {
-    const int idx = lane + 64 * t, ey = idx / CROP, ex = idx - CROP * ey;
+  for (int t = 0; t < NT; ++t) {
+    const int idx = lane + 64 * (SPLIT ? wave : t), ey = idx / CROP, ex = idx - CROP * ey;
     ce[t] = ey * IMG + ex;                                     // offset inside the image, relative to the crop corner
     cl[t] = idx < CROP * CROP ? ey * ES + ex : -1;
   }
-  float xv[4], pv[4];
+  float xv[NT], pv[NT];
   auto fetch = [&](int64_t item) {
     const int64_t r = item / a.B, b = item - r * a.B;
     const int pix = a.pix[r];
     const int corner = 2 * crop_origin(pix / IMG) * IMG + 2 * crop_origin(pix % IMG);
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
+    for (int t = 0; t < NT; ++t) {
       const bool ok = cl[t] >= 0;
       xv[t] = ok ? a.x[b * NPIX + corner + ce[t]] : 0.f;
       pv[t] = ok ? a.P[(int64_t)pix * NPIX + corner + ce[t]] : 0.f;
     }
   };
 
-  const int64_t stride = (int64_t)gridDim.x * WAVES;
-  int64_t item = (int64_t)blockIdx.x * WAVES + wave;
+  const int64_t stride = SPLIT ? (int64_t)gridDim.x : (int64_t)gridDim.x * WAVES;
+  int64_t item = SPLIT ? (int64_t)blockIdx.x : (int64_t)blockIdx.x * WAVES + wave;
   if (item < a.items) fetch(item);
   for (; item < a.items; item += stride) {
 #pragma unroll
-    for (int t = 0; t < 4; ++t)
+    for (int t = 0; t < NT; ++t)
       if (cl[t] >= 0) e_s[cl[t]] = xv[t] * pv[t];
     if (item + stride < a.items) fetch(item + stride);         // next copy's loads fly during this one's MFMAs
+    if (SPLIT) __syncthreads();
 
     // ---- conv1 + ReLU -> a1_s
 #pragma unroll
-    for (int nb = 0; nb < 9; ++nb) {
-      f32x4 d = bias1;
+    for (int k = 0; k < N1; ++k) {
+      if (!SPLIT || k < n1) {
+        f32x4 d = bias1;
 #pragma unroll
-      for (int s = 0; s < 3; ++s) d = mfma(wa1[s], e_s[eo[nb][s]], d);
+        for (int s = 0; s < 3; ++s) d = mfma(wa1[s], e_s[eo[k][s]], d);
 #pragma unroll
-      for (int r = 0; r < 4; ++r) a1_s[a1w + r * PL + 16 * nb] = fmaxf(d[r], 0.f);
+        for (int r = 0; r < 4; ++r) a1_s[a1w + r * PL + 16 * (nb1 + k)] = fmaxf(d[r], 0.f);
+      }
     }
+    if (SPLIT) __syncthreads();
     // ---- conv2 + 2x2 max-pool + bias - background -> pd[item][cell][channel]
     float* prow = a.pd + item * KD + 4 * q;
 #pragma unroll
-    for (int nb = 0; nb < 7; ++nb) {
-      f32x4 d0 = {0.f, 0.f, 0.f, 0.f}, d1 = d0;                // two chains: consecutive MFMAs are independent
-      const float* bp = a1_s + po[nb];
+    for (int k = 0; k < N2; ++k) {
+      if (!SPLIT || k < n2) {
+        f32x4 d0 = {0.f, 0.f, 0.f, 0.f}, d1 = d0;              // two chains: consecutive MFMAs are independent
+        const float* bp = a1_s + po[k];
 #pragma unroll
-      for (int s = 0; s < 36; s += 2) {
-        const int t0 = s >> 2, t1 = (s + 1) >> 2;
-        d0 = mfma(wa2[s], bp[4 * (s & 3) * PL + (t0 / 3) * A1 + t0 % 3], d0);
-        d1 = mfma(wa2[s + 1], bp[4 * ((s + 1) & 3) * PL + (t1 / 3) * A1 + t1 % 3], d1);
-      }
-      f32x4 v;
-      unsigned am = 0;
+        for (int s = 0; s < 36; s += 2) {
+          const int t0 = s >> 2, t1 = (s + 1) >> 2;
+          d0 = mfma(wa2[s], bp[4 * (s & 3) * PL + (t0 / 3) * A1 + t0 % 3], d0);
+          d1 = mfma(wa2[s + 1], bp[4 * ((s + 1) & 3) * PL + (t1 / 3) * A1 + t1 % 3], d1);
+        }
+        f32x4 v;
+        unsigned am = 0;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const float pre = d0[r] + d1[r], mx = quad_max(pre);
-        v[r] = mx + bias2[r] - bgv[r];
-        if (SAVE) am |= (unsigned)quad_min(pre == mx ? (j & 3) : 4) << (8 * r);
-      }
-      const int cell = 4 * nb + (j >> 2);
-      if ((j & 3) == 0 && cell < NCELL) {
-        *reinterpret_cast<f32x4*>(prow + cell * NCH) = v;
-        if (SAVE) *reinterpret_cast<unsigned*>(a.arg + item * KD + cell * NCH + 4 * q) = am;
+        for (int r = 0; r < 4; ++r) {
+          const float pre = d0[r] + d1[r], mx = quad_max(pre);
+          v[r] = mx + bias2[r] - bgv[r];
+          if (SAVE) am |= (unsigned)quad_min(pre == mx ? (j & 3) : 4) << (8 * r);
+        }
+        const int cell = 4 * (nb2 + k) + (j >> 2);
+        if ((j & 3) == 0 && cell < NCELL) {
+          *reinterpret_cast<f32x4*>(prow + cell * NCH) = v;
+          if (SAVE) *reinterpret_cast<unsigned*>(a.arg + item * KD + cell * NCH + 4 * q) = am;
+        }
       }
     }
+    if (SPLIT) __syncthreads();                                // (a persistent workgroup: the images are rewritten next)
   }
 }
 
@@ -489,6 +506,116 @@ __global__ __launch_bounds__(1024) void sparse_finish_k(const float* __restrict_
   }
 }
 
+// ---- fc1 + ReLU + fc2 of the masked copies in ONE launch (MLP.py:43-47; inference: the levels of a sampling pass) ----------
+// A level of the MNIST schedule holds ~700 masked copies in ~8 crop origins: the grouped 64 x 64-tile GEMM + the tall-layer
+// launch for fc2 cost 17 + 6 us of pure latency per level (100 dependent LDS-staged k-steps per tile).  Here a workgroup owns
+// 16 rows of one origin: 8 wavefronts = 2 halves of the 128 fc1 columns x 4 quarters of K = 400, every operand of a wavefront
+// requested up front (A: the 16 x 400 tile of pd through LDS, one conflict-free ds_read_b32 per k-step; B: one dwordx4 of the
+// k-major weight image straight into registers = the same k for four column sets, so a k-step is 4 MFMAs on one A register),
+// the quarters summed in fixed order through LDS
+// with bias + ReLU, and fc2 (<= 32 outputs) contracted from that LDS tile by wavefronts 0 and 1 against weights they asked for
+// at the top of the kernel.
+constexpr int kCropSplitMax = 256 * 8;                         // masked copies up to which a copy gets a whole workgroup
+constexpr int FC_F = 128, FC_ROWS = 16, FC_WAVES = 8, FC_KQ = 4;
+constexpr int FC_KSTEPS = KD / 4 / FC_KQ;                       // 25 MFMA k-steps per wavefront
+constexpr int FC_HP = FC_F + 4;                                 // LDS pitch of a 128-wide row (bank shift 4 per row)
+static_assert(FC_KSTEPS * 4 * FC_KQ == KD, "K = 400 splits into 4 quarters of 25 k-steps");
+
+struct FcArgs {
+  const float* pd; const float* Wg; const float* hbg; const int32_t* groups;
+  const float* W2; const float* b2; float* out; int out_d;
+};
+
+__global__ __launch_bounds__(64 * FC_WAVES) void sparse_fc12_k(FcArgs a) {
+  const int g = blockIdx.y;
+  const int first = a.groups[2 * g], rows = a.groups[2 * g + 1];
+  const int r0 = blockIdx.x * FC_ROWS;
+  if (r0 >= rows) return;                                       // (uniform per workgroup: in front of every barrier)
+  // the 16 x 400 tile of pd (pitch 404 = 20 mod 64 banks: the 64 (row, k) words of an A fragment lie in 64 banks), later
+  // the four K-quarter partial tiles in the same bytes
+  __shared__ __attribute__((aligned(16))) float buf[FC_KQ * FC_ROWS * FC_HP];
+  __shared__ __attribute__((aligned(16))) float h1s[FC_ROWS][FC_HP];
+  constexpr int AP = KD + 4;
+  static_assert(FC_ROWS * AP <= FC_KQ * FC_ROWS * FC_HP, "the pd tile fits the partial-sum buffer");
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, j = lane & 15, q = lane >> 4;
+  const int ch = wave & 1, kq = wave >> 1;
+  const int nvalid = rows - r0 < FC_ROWS ? rows - r0 : FC_ROWS;
+
+  // fc2's weights of wavefronts 0 / 1: lane (n = j, q) holds W2[n][16 T + 4 q .. + 3]
+  const int n2 = 16 * (wave & 1) + j;
+  f32x4 wv[FC_F / 16];
+  if (wave < 2) {
+    const float* w2p = a.W2 + (int64_t)(n2 < a.out_d ? n2 : a.out_d - 1) * FC_F + 4 * q;
+#pragma unroll
+    for (int T = 0; T < FC_F / 16; ++T) wv[T] = *reinterpret_cast<const f32x4*>(w2p + 16 * T);
+  }
+  const float* bp = a.Wg + ((int64_t)g * KD + kq * (FC_KSTEPS * 4) + q) * FC_F + 64 * ch + 4 * j;
+  f32x4 bv[FC_KSTEPS];
+#pragma unroll
+  for (int t = 0; t < FC_KSTEPS; ++t) bv[t] = *reinterpret_cast<const f32x4*>(bp + (int64_t)4 * t * FC_F);
+  // pd rows of the tile: 100 dwordx4 per row, coalesced (as A fragments straight from memory every wave-load touched 16 rows)
+  {
+    const float* src = a.pd + ((int64_t)first + r0) * KD;
+#pragma unroll
+    for (int it = 0; it < (FC_ROWS * KD / 4 + 64 * FC_WAVES - 1) / (64 * FC_WAVES); ++it) {
+      const int v = it * 64 * FC_WAVES + threadIdx.x, rr = v / (KD / 4), c4 = (v - rr * (KD / 4)) * 4;
+      if (rr < FC_ROWS) {
+        const int rs = rr < nvalid ? rr : nvalid - 1;            // rows past the end repeat the last one (not stored)
+        *reinterpret_cast<f32x4*>(&buf[rr * AP + c4]) = *reinterpret_cast<const f32x4*>(src + (int64_t)rs * KD + c4);
+      }
+    }
+  }
+  __syncthreads();
+  float av[FC_KSTEPS];
+  {
+    const float* ap = &buf[j * AP + kq * (FC_KSTEPS * 4) + q];
+#pragma unroll
+    for (int t = 0; t < FC_KSTEPS; ++t) av[t] = ap[4 * t];
+  }
+  f32x4 acc[4] = {};
+#pragma unroll
+  for (int t = 0; t < FC_KSTEPS; ++t) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc[i] = mfma(av[t], bv[t][i], acc[i]);
+  }
+  __syncthreads();                                               // every A fragment has been read: the bytes become `part`
+  // D of product i: row 4 q + r, column 64 ch + 4 j + i  ->  a lane owns 4 consecutive columns of 4 rows
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    f32x4 v = {acc[0][r], acc[1][r], acc[2][r], acc[3][r]};
+    *reinterpret_cast<f32x4*>(&buf[(kq * FC_ROWS + 4 * q + r) * FC_HP + 64 * ch + 4 * j]) = v;
+  }
+  __syncthreads();
+  {
+    const int rr = threadIdx.x >> 5, c4 = (threadIdx.x & 31) * 4;
+    f32x4 sum = *reinterpret_cast<const f32x4*>(&buf[rr * FC_HP + c4]);
+#pragma unroll
+    for (int k = 1; k < FC_KQ; ++k) sum += *reinterpret_cast<const f32x4*>(&buf[(k * FC_ROWS + rr) * FC_HP + c4]);
+    const f32x4 bias = *reinterpret_cast<const f32x4*>(a.hbg + c4);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) sum[i] = fmaxf(sum[i] + bias[i], 0.f);
+    *reinterpret_cast<f32x4*>(&h1s[rr][c4]) = sum;
+  }
+  __syncthreads();
+  if (wave < 2) {
+    f32x4 o0 = {}, o1 = {};
+#pragma unroll
+    for (int T = 0; T < FC_F / 16; ++T) {                        // product (T, i): k = 16 T + 4 q + i in both operands
+      const f32x4 hv = *reinterpret_cast<const f32x4*>(&h1s[j][16 * T + 4 * q]);
+      o0 = mfma(hv[0], wv[T][0], o0);
+      o1 = mfma(hv[1], wv[T][1], o1);
+      o0 = mfma(hv[2], wv[T][2], o0);
+      o1 = mfma(hv[3], wv[T][3], o1);
+    }
+    if (n2 < a.out_d) {
+      const float b = a.b2[n2];
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        if (4 * q + r < nvalid) a.out[((int64_t)first + r0 + 4 * q + r) * a.out_d + n2] = o0[r] + o1[r] + b;
+    }
+  }
+}
+
 }  // namespace
 
 extern "C" {
@@ -511,6 +638,18 @@ static int sparse_tables(const float* b1, const float* W2, const float* b2, cons
   return 0;
 }
 
+static void sparse_crop_launch(const SparseArgs& a, hipStream_t s) {
+  constexpr size_t lds = (size_t)WAVES * WLDS * sizeof(float);
+  if (!a.arg && a.items <= kCropSplitMax) {                     // few copies: four wavefronts per copy (latency form)
+    hipLaunchKernelGGL((sparse_crop_k<false, true>), dim3((unsigned)a.items), dim3(64 * WAVES), WLDS * sizeof(float), s, a);
+    return;
+  }
+  int64_t grid = (a.items + WAVES - 1) / WAVES;
+  if (grid > 256 * 3) grid = 256 * 3;
+  if (a.arg) hipLaunchKernelGGL((sparse_crop_k<true, false>), dim3((unsigned)grid), dim3(64 * WAVES), lds, s, a);
+  else hipLaunchKernelGGL((sparse_crop_k<false, false>), dim3((unsigned)grid), dim3(64 * WAVES), lds, s, a);
+}
+
 // crop convolutions + grouped fc1 GEMM against tables that exist
 static int sparse_front(const float* x, int64_t B, const float* P, const int32_t* pix, const int32_t* groups,
                         int64_t max_group_rows, const float* W1, const float* b1, const float* W2, const float* b2, int64_t F,
@@ -518,11 +657,7 @@ static int sparse_front(const float* x, int64_t B, const float* P, const int32_t
   const float* bg = Wg + (int64_t)NORIG * KD * F;
   const float* hbg = bg + NCH;
   SparseArgs a{x, P, pix, W1, b1, W2, b2, bg, pd, argmax_save, B, items};
-  constexpr size_t lds = (size_t)WAVES * WLDS * sizeof(float);
-  int64_t grid = (items + WAVES - 1) / WAVES;
-  if (grid > 256 * 3) grid = 256 * 3;
-  if (argmax_save) hipLaunchKernelGGL(sparse_crop_k<true>, dim3((unsigned)grid), dim3(64 * WAVES), lds, s, a);
-  else hipLaunchKernelGGL(sparse_crop_k<false>, dim3((unsigned)grid), dim3(64 * WAVES), lds, s, a);
+  sparse_crop_launch(a, s);
   GNF_LAUNCH_CHECK();
 
   GemmArgs g{};
@@ -583,6 +718,30 @@ int gnf_mnistcnn_sparse_fwd_prepared(const float* x, int64_t B, const float* P, 
     return GNF_EINVAL;
   return sparse_front(x, B, P, pix, groups, max_group_rows, W1, b1, W2, b2, F, (const float*)prep, h1, (float*)ws, nullptr,
                       items, (hipStream_t)stream);
+}
+
+int gnf_mnistcnn_sparse_fwd_prepared_fc2(const float* x, int64_t B, const float* P, const int32_t* pix, int64_t R,
+                                         const int32_t* groups, int64_t max_group_rows,
+                                         const float* W1, const float* b1, const float* W2, const float* b2, int64_t F,
+                                         const void* prep, const float* Wfc2, const float* bfc2, int64_t out_d,
+                                         float* h2, void* ws, int64_t ws_bytes, gnf_stream_t stream) {
+  if (!W1 || !b1 || !W2 || !b2 || !prep || !Wfc2 || !bfc2 || B < 0 || R < 0 || F <= 0 || out_d <= 0) return GNF_EINVAL;
+  if (F != FC_F || out_d > 32) return GNF_ESHAPE;          // (other widths: gnf_mnistcnn_sparse_fwd_prepared + gnf_linear_fwd)
+  const int64_t items = R * B;
+  if (items == 0) return 0;
+  if (!x || !P || !pix || !groups || !h2) return GNF_EINVAL;
+  if (!ws || ws_bytes < items * KD * (int64_t)sizeof(float) || max_group_rows <= 0 || max_group_rows > items)
+    return GNF_EINVAL;
+  hipStream_t s = (hipStream_t)stream;
+  const float* Wg = (const float*)prep;
+  const float* bg = Wg + (int64_t)NORIG * KD * F;
+  SparseArgs a{x, P, pix, W1, b1, W2, b2, bg, (float*)ws, nullptr, B, items};
+  sparse_crop_launch(a, s);
+  GNF_LAUNCH_CHECK();
+  FcArgs f{(const float*)ws, Wg, bg + NCH, groups, Wfc2, bfc2, h2, (int)out_d};
+  hipLaunchKernelGGL(sparse_fc12_k, dim3((unsigned)((max_group_rows + FC_ROWS - 1) / FC_ROWS), NORIG), dim3(64 * FC_WAVES), 0, s, f);
+  GNF_LAUNCH_CHECK();
+  return 0;
 }
 
 static int64_t bwd_rows_n(int64_t F) {                 // widest row the two-level column sums see

@@ -61,6 +61,7 @@ struct MonoArgs {
   const float* ccw; const float* cct; int S;
   float* z; float* jac;                 // forward outputs
   const float* zt; float* xo;           // inverse: target z, output x
+  const int32_t* xo_row; int64_t xo_sd; // inverse, scattered result (gnf_monotonic_inv_scatter): x[xo_row[e / d] + (e % d) * xo_sd]
   int64_t n, d;                         // n = B*d elements
   // backward
   const float* gz; const float* gjac; float* gx; float* gh; int64_t g_sb, g_sd, g_sc;
@@ -75,6 +76,14 @@ struct MonoArgs {
   int wcomb;                            // mono_bwd_pair_x_k: the wavefronts' accumulator rows are added in LDS at the end
 };
 
+__device__ __forceinline__ void store_inverse(const MonoArgs& a, int64_t e, float v) {
+  if (a.xo_row) {
+    const int64_t b = e / a.d;
+    a.xo[a.xo_row[b] + (e - b * a.d) * a.xo_sd] = v;
+  } else {
+    a.xo[e] = v;
+  }
+}
 __device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
 // 16 B per lane global -> LDS without passing through registers (global_load_lds_dwordx4): the LDS destination of a
 // wave-instruction is lane-linear, which a contiguous copy is.  Completion: s_waitcnt vmcnt(0) before the barrier.

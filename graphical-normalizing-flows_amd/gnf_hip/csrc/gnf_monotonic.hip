@@ -374,7 +374,7 @@ __global__ __launch_bounds__(64 * kWaves) void mono_fwd_x_k(MonoArgs a) {
         const float zm = quad(xT, 0.f, false, fj) * xT * .5f + h0;
         if (zm > zt) xmax = xm; else xmin = xm;
       }
-      if (valid && q == 0) a.xo[e] = (xmax + xmin) * .5f;
+      if (valid && q == 0) store_inverse(a, e, (xmax + xmin) * .5f);
     }
   }
 }
@@ -442,7 +442,7 @@ __global__ __launch_bounds__(64 * kWaves) void mono_fwd_k(MonoArgs a) {
         const float zm = quadrature<HT, false>(wp, L, c1, a.ccw, a.cct, a.S, xT, 0.f, q, j, dummy, getW) * xT * .5f + h0;
         if (zm > zt) xmax = xm; else xmin = xm;
       }
-      if (valid && q == 0) a.xo[e] = (xmax + xmin) * .5f;
+      if (valid && q == 0) store_inverse(a, e, (xmax + xmin) * .5f);
     }
   }
 }
@@ -520,7 +520,7 @@ __global__ __launch_bounds__(64 * kSplitWaves) void mono_inv_split_k(MonoArgs a)
       buf ^= 1;
       if (zm > zt) xmax = xm; else xmin = xm;
     }
-    if (valid && q == 0 && wave == 0 && j < EPG) a.xo[e] = (xmax + xmin) * .5f;
+    if (valid && q == 0 && wave == 0 && j < EPG) store_inverse(a, e, (xmax + xmin) * .5f);
   }
 }
 
@@ -592,7 +592,7 @@ __global__ __launch_bounds__(64 * kSplitWavesX) void mono_inv_split_x_k(MonoArgs
       buf ^= 1;
       if (zm > zt) xmax = xm; else xmin = xm;
     }
-    if (valid && q == 0 && wave == 0 && j < EPG) a.xo[e] = (xmax + xmin) * .5f;
+    if (valid && q == 0 && wave == 0 && j < EPG) store_inverse(a, e, (xmax + xmin) * .5f);
   }
 }
 
@@ -700,7 +700,7 @@ __global__ __launch_bounds__(64 * kSplitWavesX) void mono_inv_ks_x_k(MonoArgs a)
         if (zp[2] > zt) xmax = xp[2]; else xmin = xp[2];
       }
     }
-    if (valid && q == 0 && wave == 0 && j < EPG) a.xo[e] = (xmax + xmin) * .5f;
+    if (valid && q == 0 && wave == 0 && j < EPG) store_inverse(a, e, (xmax + xmin) * .5f);
   }
 }
 
@@ -2399,9 +2399,9 @@ int gnf_monotonic_fwd(const float* pack, const gnf_mono_net* net, const float* x
   return launch_fwd<false>(a, (hipStream_t)stream);
 }
 
-int gnf_monotonic_inv(const float* pack, const gnf_mono_net* net, const float* z, const float* h, int64_t h_sb,
-                      int64_t h_sd, int64_t h_sc, const float* cc_w, const float* cc_t, int S, float* x, int64_t B,
-                      int64_t d, gnf_stream_t stream) {
+int gnf_monotonic_inv_scatter(const float* pack, const gnf_mono_net* net, const float* z, const float* h, int64_t h_sb,
+                              int64_t h_sd, int64_t h_sc, const float* cc_w, const float* cc_t, int S, float* x,
+                              const int32_t* x_row_off, int64_t x_sd, int64_t B, int64_t d, gnf_stream_t stream) {
   const int HT = pick_ht(net);
   if (HT < 0) return GNF_ESHAPE;
   if (!pack || !cc_w || !cc_t || S < 1 || B < 0 || d <= 0) return GNF_EINVAL;
@@ -2411,7 +2411,14 @@ int gnf_monotonic_inv(const float* pack, const gnf_mono_net* net, const float* z
   a.pack = pack; a.L = net_layout(net, HT);
   a.h = h; a.h_sb = h_sb; a.h_sd = h_sd; a.h_sc = h_sc;
   a.ccw = cc_w; a.cct = cc_t; a.S = S; a.zt = z; a.xo = x; a.n = B * d; a.d = d;
+  a.xo_row = x_row_off; a.xo_sd = x_sd;
   return launch_fwd<true>(a, (hipStream_t)stream);
+}
+
+int gnf_monotonic_inv(const float* pack, const gnf_mono_net* net, const float* z, const float* h, int64_t h_sb,
+                      int64_t h_sd, int64_t h_sc, const float* cc_w, const float* cc_t, int S, float* x, int64_t B,
+                      int64_t d, gnf_stream_t stream) {
+  return gnf_monotonic_inv_scatter(pack, net, z, h, h_sb, h_sd, h_sc, cc_w, cc_t, S, x, nullptr, 0, B, d, stream);
 }
 
 int64_t gnf_monotonic_bwd_ws_bytes(const gnf_mono_net* net, int S, int64_t B, int64_t d) {

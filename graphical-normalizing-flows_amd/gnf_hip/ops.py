@@ -538,6 +538,29 @@ def mnistcnn_sparse_fwd(x, P, sr, W1, b1, W2, b2, Wfc1, bfc1, pre_gated=False, p
     return MnistSparseFn.apply(x, P, sr, pre_gated, W1, b1, W2, b2, Wfc1, bfc1, prep, torch.is_grad_enabled())
 
 
+def sparse_fc12_fits(Wfc1, Wfc2):
+    """the widths the one-launch fc1 + ReLU + fc2 kernel is built for (the reference's MNISTCNN: 2304 -> 128 -> <= 32);
+    GNF_SPARSE_FC12=0 keeps the grouped GEMM + tall-layer pair (A/B runs)"""
+    import os
+    return (Wfc1.shape[0] == 128 and Wfc2.shape[1] == 128 and 1 <= Wfc2.shape[0] <= 32
+            and os.environ.get("GNF_SPARSE_FC12", "1") != "0")
+
+
+def mnistcnn_sparse_fwd_fc2(x, P, sr, W1, b1, W2, b2, prep, Wfc2, bfc2):
+    """fc2(relu(fc1(conv front))) of the masked copies of `sr` against prepared tables: [R*B, out_d], inference only
+    (MLP.py:36-47 on the deterministic-gate copies, crop kernel + ONE launch for both linear layers)"""
+    x, P = x.detach().contiguous(), P.detach().contiguous()
+    ts = [t.detach().contiguous() for t in (W1, b1, W2, b2, Wfc2, bfc2)]
+    n, out_d = sr.R * sr.B, Wfc2.shape[0]
+    h2 = _empty((n, out_d), x)
+    nws = max(n, 1) * 400 * 4
+    ws = _ws(nws, x)
+    call("gnf_mnistcnn_sparse_fwd_prepared_fc2", ptr(x), sr.B, ptr(P), abi.rawptr(sr.pix), sr.R, abi.rawptr(sr.groups),
+         sr.max_group_rows, *[ptr(t) for t in ts[:4]], 128, abi.rawptr(prep), ptr(ts[4]), ptr(ts[5]), out_d, ptr(h2),
+         abi.rawptr(ws), nws, stream())
+    return h2
+
+
 def mnistcnn_sparse_prepare(b1, W2, b2, Wfc1, bfc1):
     """the parameter-only tables of the sparse front (fc1 weight columns per crop origin, background responses), built
     once for a caller that evaluates the front many times with unchanged parameters (the levels of a sampling pass)"""
@@ -799,9 +822,10 @@ class MonotonicFn(torch.autograd.Function):
         return (gx, gh, None, *gparams)
 
 
-def monotonic_inverse(z, h, nb_steps, params, pack=None):
+def monotonic_inverse(z, h, nb_steps, params, pack=None, out=None, out_cols=None):
     """20-step bisection on [-20, 20], the quadrature fused in the kernel
-    (MonotonicNormalizer.py:69-83)."""
+    (MonotonicNormalizer.py:69-83).  out / out_cols: write the TRANSPOSED result into columns out_cols of `out` (the
+    level loop of NormalizingFlowStep.invert: z is [level rows, batch], the sample is [batch, d])."""
     z = z.contiguous()
     params = [p.detach().contiguous() for p in params]
     B, d = z.shape
@@ -809,6 +833,13 @@ def monotonic_inverse(z, h, nb_steps, params, pack=None):
     if pack is None:
         pack = _mono_pack(net, z)
     w, t = cc_rule(nb_steps, z.device)
+    if out is not None:
+        # element (b, j) of this [B, d] problem -> out[j, out_cols[b]]  (out [d, width] contiguous, out_cols int32 [B])
+        assert out.is_contiguous() and out.dtype == torch.float32 and out.shape[0] == d and out_cols.dtype == torch.int32
+        assert out_cols.numel() == B and out_cols.device == z.device
+        call("gnf_monotonic_inv_scatter", ptr(pack), ctypes.byref(net), ptr(z), ptr(h), h.stride(0), h.stride(1),
+             h.stride(2), ptr(w), ptr(t), int(nb_steps), ptr(out), abi.rawptr(out_cols), out.shape[1], B, d, stream())
+        return out
     x = _empty((B, d), z)
     call("gnf_monotonic_inv", ptr(pack), ctypes.byref(net), ptr(z), ptr(h), h.stride(0), h.stride(1), h.stride(2),
          ptr(w), ptr(t), int(nb_steps), ptr(x), B, d, stream())

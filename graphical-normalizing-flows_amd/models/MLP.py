@@ -84,6 +84,15 @@ class MNISTCNN(nn.Module):
         caller's order), for an importance matrix P that is zero outside the 5x5 pixel windows: only the 14x14 crop
         that can differ from the all-zero image is convolved.  Differentiable w.r.t. the network's
         parameters (not x, not P)."""
+        if (not torch.is_grad_enabled() and self._held_prep is not None
+                and ops.sparse_fc12_fits(self.fc1.weight, self.fc2.weight)):
+            # inference against held tables: crop kernel + one launch for fc1 + ReLU + fc2
+            out = ops.mnistcnn_sparse_fwd_fc2(x.view(-1, 784), P, sr, self.conv1.weight, self.conv1.bias, self.conv2.weight,
+                                              self.conv2.bias, self._held_prep, self.fc2.weight, self.fc2.bias)
+            out = out.view(sr.R, sr.B, -1)
+            if not sr.identity:
+                out = out.index_select(0, sr.unsort)
+            return out if variable_major else out.permute(1, 0, 2)
         h1 = ops.mnistcnn_sparse_fwd(x.view(-1, 784), P, sr, self.conv1.weight, self.conv1.bias, self.conv2.weight,
                                      self.conv2.bias, self.fc1.weight, self.fc1.bias, pre_gated=True,
                                      prep=None if torch.is_grad_enabled() else self._held_prep)

@@ -94,6 +94,16 @@ class MonotonicNormalizer(Normalizer):
                 return ops.module_monotonic_inverse(z, h, self.integrand_net, int(self.nb_steps))
             return ops.monotonic_inverse(z, h, int(self.nb_steps), self._params(), pack=self._held_pack)
 
+    def inverse_transform_into(self, z, h, out, cols, context=None):
+        """out[:, cols] = inverse_transform(z, h).t() for a variable-major problem (z [R, B], h [R, B, c], out [B, d], cols
+        int32 [R]) without the transposing copy and the index_put: the kernel writes where the values belong.  Returns
+        False when the fused kernel does not apply (the caller then scatters the result of inverse_transform itself)."""
+        if not (self._fused() and out.is_cuda and out.is_contiguous() and out.dtype == torch.float32):
+            return False
+        with torch.no_grad():
+            ops.monotonic_inverse(z, h, int(self.nb_steps), self._params(), pack=self._held_pack, out=out, out_cols=cols)
+        return True
+
     _held_pack = None
 
     def hold_pack(self):

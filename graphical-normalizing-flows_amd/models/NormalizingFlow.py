@@ -115,6 +115,7 @@ class NormalizingFlowStep(NormalizingFlow):
                       for rows, hr in lv]
             self._levels_val = lv
             self._levels_all = torch.cat([rows for rows, _ in lv]) if lv else None   # one gather of z per pass
+            self._levels_rows32 = [rows.to(torch.int32) for rows, _ in lv] if lv else None   # scatter tables of the inverse
             self._levels_key = key
             _INV_GRAPHS.pop(self, None)                 # graphs captured for another gate replay another schedule
         return self._levels_val, key
@@ -128,10 +129,16 @@ class NormalizingFlowStep(NormalizingFlow):
         x = torch.zeros_like(z)
         zt = z.t()[self._levels_all]                    # [sum R, B], contiguous
         off = 0
-        for rows, host_rows in levels:
+        into = getattr(self.normalizer, "inverse_transform_into", None) if context is None else None
+        rows32 = getattr(self, "_levels_rows32", None)
+        if into is not None and (rows32 is None or len(rows32) != len(levels)):
+            into = None
+        for k, (rows, host_rows) in enumerate(levels):
             R = rows.numel()
             h = cond.forward_rows(x, rows, importance, host_rows, variable_major=True)
-            x[:, rows] = self.normalizer.inverse_transform(zt[off:off + R], h, context).t()
+            # the normalizer writes its [R, B] result into columns `rows` of x itself where it can
+            if into is None or not into(zt[off:off + R], h, x, rows32[k]):
+                x[:, rows] = self.normalizer.inverse_transform(zt[off:off + R], h, context).t()
             off += R
         return x
 

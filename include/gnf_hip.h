@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define GNF_ABI_VERSION 5
+#define GNF_ABI_VERSION 6
 #define GNF_EINVAL (-1)   /* bad argument (null pointer, negative size, ...)          */
 #define GNF_ESHAPE (-2)   /* shape not supported by any compiled kernel instantiation */
 #define GNF_EWS    (-3)   /* workspace too small                                      */
@@ -249,6 +249,14 @@ int gnf_monotonic_inv(const float* pack, const gnf_mono_net* net,
                       const float* z, const float* h, int64_t h_sb, int64_t h_sd, int64_t h_sc,
                       const float* cc_w, const float* cc_t, int S,
                       float* x, int64_t B, int64_t d, gnf_stream_t stream);
+/* The same inverse with a strided / scattered result: element (b, j) of the [B, d] problem is written to
+ * x[x_row_off[b] + j * x_sd] (x_row_off [B] int32 on the device, element offsets).  The level-scheduled inversion of a DAG flow
+ * (NormalizingFlow.py:98-107 restated per topological level) solves a [level rows, batch] problem whose result belongs in
+ * columns rows[.] of the [batch, d] sample: x_row_off = rows, x_sd = d -- no transposing copy, no index_put launch. */
+int gnf_monotonic_inv_scatter(const float* pack, const gnf_mono_net* net,
+                              const float* z, const float* h, int64_t h_sb, int64_t h_sd, int64_t h_sc,
+                              const float* cc_w, const float* cc_t, int S,
+                              float* x, const int32_t* x_row_off, int64_t x_sd, int64_t B, int64_t d, gnf_stream_t stream);
 /* Backward with UMNN's conventions: gx = gz*f(x;h) + gjac*df/dx(x;h) (Leibniz rule);
  * gh, gW, gb = quadrature of df/dh, df/dtheta weighted by gz*xT/2, plus the gjac path,
  * plus gz on h[..,0].  gW[l]/gb[l] are WRITTEN (same shapes as W[l]/b[l]).
@@ -328,6 +336,18 @@ int gnf_mnistcnn_sparse_fwd_prepared(const float* x, int64_t B, const float* P, 
                                      const int32_t* groups, int64_t max_group_rows,
                                      const float* W1, const float* b1, const float* W2, const float* b2, int64_t F,
                                      const void* prep, float* h1, void* ws, int64_t ws_bytes, gnf_stream_t stream);
+/* The prepared front followed by fc2 (MLP.py:47: out = fc2(relu(fc1(.)))) in the same call: the fc1 + ReLU + fc2 chain of
+ * the masked copies is ONE launch (a workgroup per 16 rows of a crop origin, relu(fc1) never leaves LDS) -- two launches per
+ * level of a sampling pass instead of three, ~7 us instead of ~23 after the crop kernel.
+ *   Wfc2 [out_d, F], bfc2 [out_d];  h2 [R*B, out_d] (out), row r*B + b as h1 above.
+ * GNF_ESHAPE unless F == 128 and out_d <= 32 (the reference's MNISTCNN: fc1 2304 -> 128, fc2 128 -> out_d = 30 for the
+ * Monotonic normalizer's conditioner, ImageExperiments.py:60-66); other widths take gnf_mnistcnn_sparse_fwd_prepared and
+ * gnf_linear_fwd.  Equal to that pair up to fp32 summation order.  ws >= R*B*400*4 bytes. */
+int gnf_mnistcnn_sparse_fwd_prepared_fc2(const float* x, int64_t B, const float* P, const int32_t* pix, int64_t R,
+                                         const int32_t* groups, int64_t max_group_rows,
+                                         const float* W1, const float* b1, const float* W2, const float* b2, int64_t F,
+                                         const void* prep, const float* Wfc2, const float* bfc2, int64_t out_d,
+                                         float* h2, void* ws, int64_t ws_bytes, gnf_stream_t stream);
 /* Backward w.r.t. the network parameters (training with a frozen deterministic gate: P and x get no gradient).
  * g_h1 [R*B, F]: cotangent of h1 with the ReLU already applied (zero where h1 == 0).  Gradients are written, not
  * accumulated: gW1 [16,1,3,3], gb1 [16], gW2 [16,16,3,3], gb2 [16], gWfc1 [F,2304], gbfc1 [F].

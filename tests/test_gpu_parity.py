@@ -1544,9 +1544,11 @@ def test_sparse_front_reference_golden():
     assert rel_err(z2.cpu(), g["z"]) < TOL and rel_err(ld2.cpu(), g["logdet"]) < TOL
 
 
-def test_sparse_front_prepared_tables_give_the_same_bits():
+def test_sparse_front_prepared_tables_give_the_same_bits(monkeypatch):
     """gnf_mnistcnn_sparse_prepare + _fwd_prepared (the parameter-only tables built once for the 109 levels of a sampling
-    pass) == gnf_mnistcnn_sparse_fwd, bit for bit; the holder is only consulted without autograd."""
+    pass) == gnf_mnistcnn_sparse_fwd, bit for bit; the holder is only consulted without autograd.  (GNF_SPARSE_FC12=0: the
+    one-launch fc1 + fc2 kernel of the held-table path sums in another order, test_sparse_front_fc12_* compares that one.)"""
+    monkeypatch.setenv("GNF_SPARSE_FC12", "0")
     from models import DAGConditioner
     from models.MLP import MNISTCNN
     from gnf_hip import ops
@@ -1589,6 +1591,87 @@ def test_sparse_front_prepared_tables_give_the_same_bits():
     assert lib.gnf_mnistcnn_sparse_prepare(*[abi.ptr(t) for t in ps], F, abi.rawptr(prep), nb - 4, st) == -3
     assert lib.gnf_mnistcnn_sparse_prepare(*[abi.ptr(t) for t in ps], 130, abi.rawptr(prep), nb, st) == -2
     assert lib.gnf_mnistcnn_sparse_prepare(*[abi.ptr(t) for t in ps], F, None, nb, st) == -1
+
+
+def _random_window_gate(seed):
+    g = torch.Generator().manual_seed(seed)
+    A = torch.zeros(784, 784)
+    for i in range(784):
+        for dr in (-2, -1, 0, 1, 2):
+            for dc in (-2, -1, 0, 1, 2):
+                r, c = i // 28 + dr, i % 28 + dc
+                if (dr or dc) and 0 <= r < 28 and 0 <= c < 28:
+                    A[i, r * 28 + c] = float(torch.rand((), generator=g) < .5) * float(torch.rand((), generator=g) + .2)
+    return A
+
+
+@pytest.mark.parametrize("B,rows,out_d", [(5, [0, 27, 300, 391, 392, 783, 29], 30), (1, [391], 30), (100, [3, 59, 115, 171], 30),
+                                          (37, list(range(0, 784, 5)), 30), (16, [400, 401], 1), (17, [10, 700], 32)])
+def test_sparse_front_fc12_one_launch_vs_oracle(B, rows, out_d, monkeypatch):
+    """gnf_mnistcnn_sparse_fwd_prepared_fc2 (crop kernel + ONE launch for fc1 + ReLU + fc2, MLP.py:43-47): element-wise
+    against the oracle's dense MNISTCNN on the masked copies, and against the grouped-GEMM + tall-layer pair it replaces.
+    Row counts per crop origin that are no multiple of the kernel's 16-row tiles, one masked copy, 157 of them, out_d = 1
+    and the widest fc2 the kernel takes."""
+    from models.MLP import MNISTCNN
+    from gnf_hip import ops
+    from conftest import assert_close
+    torch.manual_seed(5)
+    net = MNISTCNN(out_d=out_d).to(DEV)
+    P = cu(_random_window_gate(3))
+    x = cu(torch.randn(B, 784))
+    sr = ops.SparseRows(rows, B, torch.device(DEV))
+    with torch.no_grad(), net.hold_prepared():
+        got = net.sparse_rows(x, P, sr)                      # [B, R, out_d] through the one-launch kernel
+        monkeypatch.setenv("GNF_SPARSE_FC12", "0")
+        pair = net.sparse_rows(x, P, sr)
+        monkeypatch.delenv("GNF_SPARSE_FC12")
+        got_vm = net.sparse_rows(x, P, sr, variable_major=True)
+    assert got.shape == pair.shape == (B, len(rows), out_d) and torch.equal(got_vm.permute(1, 0, 2), got)
+    assert_close(got, pair, what="one launch vs GEMM pair")
+    ps = {k: v.detach().cpu() for k, v in net.state_dict().items()}
+    e = (x.cpu().unsqueeze(1) * P.cpu()[rows].unsqueeze(0)).reshape(B * len(rows), 784)
+    want = O.mnistcnn_forward(e, ps).view(B, len(rows), out_d)
+    assert_close(got, want, what="one launch vs oracle")
+
+
+def test_sparse_front_fc12_abi_validation():
+    import ctypes
+    from gnf_hip import abi
+    lib = abi.load()
+    N = None
+    t = torch.zeros(64 * 400 * 128 + 4096, device=DEV)
+    i32 = torch.zeros(128, dtype=torch.int32, device=DEV)
+    p, ip = ctypes.c_void_p(t.data_ptr()), ctypes.c_void_p(i32.data_ptr())
+    nb = 400 * 4
+    f = lib.gnf_mnistcnn_sparse_fwd_prepared_fc2
+    assert f(p, 1, p, ip, 1, ip, 1, p, p, p, p, 128, p, p, p, 30, p, p, nb, N) == 0          # (one masked copy, zero tables)
+    assert f(p, 1, p, ip, 1, ip, 1, p, p, p, p, 64, p, p, p, 30, p, p, nb, N) == -2           # fc1 width it is not built for
+    assert f(p, 1, p, ip, 1, ip, 1, p, p, p, p, 128, p, p, p, 33, p, p, nb, N) == -2          # fc2 wider than two MFMA tiles
+    assert f(p, 1, p, ip, 1, ip, 1, p, p, p, p, 128, p, p, p, 0, p, p, nb, N) == -1
+    assert f(p, 1, p, ip, 1, ip, 1, p, p, p, p, 128, p, N, p, 30, p, p, nb, N) == -1          # no fc2 weight
+    assert f(p, 1, p, ip, 1, ip, 1, p, p, p, p, 128, p, p, p, 30, p, p, nb - 4, N) == -1      # workspace short
+    assert f(p, 1, p, ip, 1, ip, 2, p, p, p, p, 128, p, p, p, 30, p, p, nb, N) == -1          # group larger than the call
+    assert f(p, 0, p, ip, 1, ip, 1, p, p, p, p, 128, p, p, p, 30, N, N, 0, N) == 0            # empty batch: nothing to do
+    torch.cuda.synchronize()
+
+
+@pytest.mark.parametrize("hidden,R,B", [([50, 50, 50], 7, 100), ([50, 50, 50], 1, 3), ([20, 20], 5, 33), ([100, 100, 100], 4, 40),
+                                        ([150, 150, 150], 3, 20)])
+def test_monotonic_inverse_scattered_result(hidden, R, B):
+    """gnf_monotonic_inv_scatter == gnf_monotonic_inv followed by x[:, rows] = result.t(), bit for bit, for the level kernels
+    (two steps per round and one), the register-chained and the wide nets; columns outside `rows` are not touched."""
+    from models import MonotonicNormalizer
+    torch.manual_seed(4)
+    nrm = MonotonicNormalizer(hidden, 30, nb_steps=20).to(DEV)
+    z = cu(torch.randn(R, B))
+    h = cu(torch.randn(R, B, 30))
+    rows = torch.randperm(784)[:R].to(torch.int32).to(DEV)
+    with torch.no_grad():
+        want = torch.full((B, 784), 7.5, device=DEV)
+        want[:, rows.long()] = nrm.inverse_transform(z, h).t()
+        got = torch.full((B, 784), 7.5, device=DEV)
+        assert nrm.inverse_transform_into(z, h, got, rows)
+    assert torch.equal(got, want)
 
 
 def test_sparse_front_abi_validation():

@@ -24,7 +24,8 @@ for n in flow.getNormalizers(): n.nb_steps = 20
 z = torch.randn(100, 784, device=DEV) * .3
 lv = cond.levels(cond.deterministic_importance())
 print("levels", len(lv))
-for sparse in (True, False):
+only = os.environ.get("BENCH_SAMPLING_ONLY")           # "sparse" / "dense": one front only (clean kernel traces)
+for sparse in ((True, False) if only is None else (only == "sparse",)):
     cond.sparse_front = sparse
     for _ in range(2): x = flow.invert(z)
     torch.cuda.synchronize(); t = time.perf_counter()
