@@ -606,9 +606,11 @@ __global__ __launch_bounds__(64 * kSplitWavesX) void mono_inv_split_x_k(MonoArgs
 // LOST to the sequential kernel (113 vs 103 us per level).  The raw integrand values meet in LDS; every lane of an element
 // then forms the three sums in exactly the order of mono_inv_split_x_k (pairs (0,1), (2,3), ... as fma chains, added
 // ascending), with the same midpoints: the result is that of the 20 sequential steps BIT FOR BIT (tested).  S <= 31.
-template <int HM, int EX>
+// EPG = elements per workgroup: 4 (8 wavefronts at S = 20), or 2 (4 wavefronts: ONE per SIMD) when the call holds so few
+// elements that every workgroup of two still finds a CU of its own -- a round is then one pair evaluation deep instead of two.
+template <int HM, int EX, int EPG>
 __global__ __launch_bounds__(64 * kSplitWavesX) void mono_inv_ks_x_k(MonoArgs a) {
-  constexpr int EPG = 4, NS = 16 / EPG;
+  constexpr int NS = 16 / EPG;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const MonoLayout& L = a.L;
   for (int i = threadIdx.x * 4; i < L.fwd_floats; i += blockDim.x * 4)
@@ -1973,20 +1975,21 @@ int launch_fwd(const MonoArgs& a, hipStream_t s) {
     // an element fit the workgroup's pair slots (S <= 31) and the weight image is LDS-resident; GNF_MONO_INV_PTS=1 keeps the
     // one-step kernel (A/B and the bit-equality test)
     static const bool one_pt = getenv("GNF_MONO_INV_PTS") && getenv("GNF_MONO_INV_PTS")[0] == '1';
-    const int ks_waves = (3 * (a.S + 1) + 7) / 8;                     // pairs / 4 slots per wavefront
+    const int epg = a.n <= 2 * 256 ? 2 : 4;                           // elements per workgroup (see mono_inv_ks_x_k)
+    const int ks_waves = ((3 * (a.S + 1) + 1) / 2 * epg + 15) / 16;   // node-pair columns / 16 per wavefront
     if (a.L.EX > 0 && quarter && wlds && !one_pt && ks_waves <= kSplitWavesX) {
       const int S1P = (a.S + 4) & ~3;
-      const size_t lds_k = lds + (size_t)(2 * S1P + 2 * 3 * (a.S + 1) * 4 + 2 * 3 * 4) * sizeof(float);
-      const unsigned gq = (unsigned)((a.n + 3) / 4);
-      if (a.L.EX <= 2) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mono_inv_ks_x_k<3, 2>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_k);
-        hipLaunchKernelGGL((mono_inv_ks_x_k<3, 2>), dim3(gq), dim3(64 * ks_waves), lds_k, s, a);
-      } else {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mono_inv_ks_x_k<3, 3>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_k);
-        hipLaunchKernelGGL((mono_inv_ks_x_k<3, 3>), dim3(gq), dim3(64 * ks_waves), lds_k, s, a);
+      const size_t lds_k = lds + (size_t)(2 * S1P + 2 * 3 * (a.S + 1) * epg + 2 * 3 * epg) * sizeof(float);
+      const unsigned gq = (unsigned)((a.n + epg - 1) / epg);
+#define GNF_INVKS(EX_, EPG_)                                                                                   \
+      {                                                                                                        \
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mono_inv_ks_x_k<3, EX_, EPG_>),               \
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_k);                     \
+        hipLaunchKernelGGL((mono_inv_ks_x_k<3, EX_, EPG_>), dim3(gq), dim3(64 * ks_waves), lds_k, s, a);       \
       }
+      if (a.L.EX <= 2) { if (epg == 2) GNF_INVKS(2, 2) else GNF_INVKS(2, 4) }
+      else { if (epg == 2) GNF_INVKS(3, 2) else GNF_INVKS(3, 4) }
+#undef GNF_INVKS
       GNF_LAUNCH_CHECK();
       return 0;
     }

@@ -582,12 +582,12 @@ torch.save(x.cpu(), %r)
 """
 
 
-@pytest.mark.parametrize("n,S", [(700, 20), (37, 20), (3, 27), (1000, 30), (700, 7)])
+@pytest.mark.parametrize("n,S", [(700, 20), (37, 20), (3, 27), (1000, 30), (700, 7), (512, 20), (513, 20), (301, 31)])
 def test_split_inverse_two_steps_per_round_is_bit_identical(n, S, tmp_path):
     """the level kernels of a sampling pass take TWO bisection steps per round (midpoint + both quarter points evaluated at
-    once by three times the wavefronts, mono_inv_split_x_k<..., PTS = 3>): same midpoints, same sums, so the same bits as the
-    20 sequential steps (GNF_MONO_INV_PTS=1, run in a second process: the switch is read once) -- reference
-    MonotonicNormalizer.py:69-83"""
+    once, mono_inv_ks_x_k; workgroups of two elements up to 512 elements per call, of four above): same midpoints, same sums,
+    so the same bits as the 20 sequential steps (GNF_MONO_INV_PTS=1, run in a second process: the switch is read once) --
+    reference MonotonicNormalizer.py:69-83"""
     import os, subprocess, sys
     from conftest import ROOT, PKG
     outs = []
