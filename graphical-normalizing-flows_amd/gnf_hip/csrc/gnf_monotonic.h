@@ -30,11 +30,37 @@ struct MonoLayout {
   // so that one global_load_dwordx4 per lane fetches a whole fragment as 1 KB of consecutive bytes.
   int o_Wf[kMaxNH], o_WTf[kMaxNH];
   int pack_floats;                    // size of the whole pack
+  // K order of the last unit tile (HT >= 7 only, round 5).  An MFMA k-step r of k-tile t contracts the padded positions
+  // 16 t + 4 q + r, q = 0..3: with the units of a width-H layer at positions 0 .. H-1 the H mod 16 units of the last tile are
+  // spread over all four of its k-steps (H = 100: one real unit and three zeros in each).  With perm = 1 the pack puts
+  // unit 16 T + i of the LAST tile T = (H-1)/16 at position 16 T + 4 (i mod 4) + i / 4, so that they fill k-step 0 first,
+  // then k-step 1, ...: the passes whose K runs over that layer stop after ksv[l] = 4 T + ceil((H - 16 T) / 4) k-steps
+  // (25 instead of 28 at H = 100, 38 instead of 40 at 150).  Everything else addresses padded positions and is unaffected;
+  // mono_pack_k / mono_unpack_k are the only places that translate (mono_pos_of / mono_unit_at).
+  int perm;
+  int ksv[kMaxNH + 1];                // k-steps of a contraction over the units of hidden layer l = 1..NH
 };
+
+// padded position of unit u of a width-H layer, and the unit at padded position p (-1: padding)
+__host__ __device__ inline int mono_pos_of(int u, int H, int perm) {
+  const int T = (H - 1) / 16;
+  if (!perm || u < 16 * T) return u;
+  const int i = u - 16 * T;
+  return 16 * T + 4 * (i & 3) + (i >> 2);
+}
+__host__ __device__ inline int mono_unit_at(int p, int H, int perm) {
+  const int T = (H - 1) / 16;
+  if (!perm || p < 16 * T) return p < H ? p : -1;
+  if (p >= 16 * (T + 1)) return -1;
+  const int i = p - 16 * T, u = 16 * T + (i >> 2) + 4 * (i & 3);
+  return u < H ? u : -1;
+}
 
 __host__ __device__ inline MonoLayout make_layout(int HT, int NH, int c, bool frag_copies = false) {
   MonoLayout L;
   L.HT = HT; L.HP = 16 * HT; L.NH = NH; L.c = c; L.HM = 0; L.EX = 0;
+  L.perm = 0;
+  for (int l = 0; l <= kMaxNH; ++l) L.ksv[l] = 4 * HT;
   L.CP = (c + 15) / 16 * 16; L.LDH = L.CP + 4; L.LDW = L.HP + 4;
   int o = 0;
   L.o_w1x = o; o += L.HP;

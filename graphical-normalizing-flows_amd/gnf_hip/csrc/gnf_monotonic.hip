@@ -45,6 +45,7 @@ __global__ void mono_pack_k(PackArgs a, float* __restrict__ pack) {
   const MonoLayout& L = a.L;
   const gnf_mono_net& N = a.net;
   const int H0 = N.dims[1];
+  auto unit = [&](int p, int l) { return mono_unit_at(p, N.dims[l], L.perm); };   // unit of hidden layer l at padded position p
   for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < L.pack_floats; idx += gridDim.x * blockDim.x) {
     float v = 0.f;
     if (idx >= L.total_floats) {                  // fragment-major copies of the hidden->hidden matrices (see MonoLayout)
@@ -54,40 +55,40 @@ __global__ void mono_pack_k(PackArgs a, float* __restrict__ pack) {
         if (k < 0 || k >= L.HP * L.HP) continue;
         const int frag = k >> 8, lane = (k >> 2) & 63, r = k & 3, mt = frag / L.HT, t = frag - mt * L.HT;
         const int q = lane >> 4, j = lane & 15;
-        const int row = tr ? 16 * t + 4 * q + r : 16 * mt + j;     // out unit
-        const int col = tr ? 16 * mt + j : 16 * t + 4 * q + r;     // in unit
-        if (row < N.dims[l + 1] && col < N.dims[l]) v = N.W[l][(int64_t)row * N.dims[l] + col];
+        const int row = unit(tr ? 16 * t + 4 * q + r : 16 * mt + j, l + 1);     // out unit
+        const int col = unit(tr ? 16 * mt + j : 16 * t + 4 * q + r, l);         // in unit
+        if (row >= 0 && col >= 0) v = N.W[l][(int64_t)row * N.dims[l] + col];
         break;
       }
       pack[idx] = v;
       continue;
     }
-    if (idx < L.o_b1) { const int k = idx - L.o_w1x; if (k < H0) v = N.W[0][(int64_t)k * N.dims[0]]; }
-    else if (idx < L.o_wL) { const int k = idx - L.o_b1; if (k < H0) v = N.b[0][k]; }
-    else if (idx < L.o_bL) { const int k = idx - L.o_wL; if (k < N.dims[L.NH]) v = N.W[L.NH][k]; }
+    if (idx < L.o_b1) { const int k = unit(idx - L.o_w1x, 1); if (k >= 0) v = N.W[0][(int64_t)k * N.dims[0]]; }
+    else if (idx < L.o_wL) { const int k = unit(idx - L.o_b1, 1); if (k >= 0) v = N.b[0][k]; }
+    else if (idx < L.o_bL) { const int k = unit(idx - L.o_wL, L.NH); if (k >= 0) v = N.W[L.NH][k]; }
     else if (idx < L.o_W1h) { if (idx == L.o_bL) v = N.b[L.NH][0]; }
     else if (idx < (L.NH > 1 ? L.o_W[1] : L.fwd_floats)) {
-      const int k = idx - L.o_W1h; const int r = k / L.LDH, cc = k % L.LDH;
-      if (r < H0 && cc < L.c) v = N.W[0][(int64_t)r * N.dims[0] + 1 + cc];
+      const int k = idx - L.o_W1h; const int r = unit(k / L.LDH, 1), cc = k % L.LDH;
+      if (r >= 0 && cc < L.c) v = N.W[0][(int64_t)r * N.dims[0] + 1 + cc];
     } else if (idx < L.fwd_floats) {
       for (int l = 1; l < L.NH; ++l) {
         if (idx >= L.o_W[l] && idx < L.o_b[l]) {
-          const int k = idx - L.o_W[l]; const int r = k / L.LDW, cc = k % L.LDW;
-          if (r < N.dims[l + 1] && cc < N.dims[l]) v = N.W[l][(int64_t)r * N.dims[l] + cc];
+          const int k = idx - L.o_W[l]; const int r = unit(k / L.LDW, l + 1), cc = unit(k % L.LDW, l);
+          if (r >= 0 && cc >= 0) v = N.W[l][(int64_t)r * N.dims[l] + cc];
         } else if (idx >= L.o_b[l] && idx < L.o_b[l] + L.HP) {
-          const int k = idx - L.o_b[l]; if (k < N.dims[l + 1]) v = N.b[l][k];
+          const int k = unit(idx - L.o_b[l], l + 1); if (k >= 0) v = N.b[l][k];
         }
       }
     } else if (idx < L.o_W1hT) {
       for (int l = 1; l < L.NH; ++l) {
         if (idx >= L.o_WT[l] && idx < L.o_WT[l] + L.HP * L.LDW) {
-          const int k = idx - L.o_WT[l]; const int r = k / L.LDW, cc = k % L.LDW;   // r = in, cc = out
-          if (r < N.dims[l] && cc < N.dims[l + 1]) v = N.W[l][(int64_t)cc * N.dims[l] + r];
+          const int k = idx - L.o_WT[l]; const int r = unit(k / L.LDW, l), cc = unit(k % L.LDW, l + 1);   // r = in, cc = out
+          if (r >= 0 && cc >= 0) v = N.W[l][(int64_t)cc * N.dims[l] + r];
         }
       }
     } else {
-      const int k = idx - L.o_W1hT; const int r = k / L.LDW, cc = k % L.LDW;       // r = cond idx, cc = hidden
-      if (r < L.c && cc < H0) v = N.W[0][(int64_t)cc * N.dims[0] + 1 + r];
+      const int k = idx - L.o_W1hT; const int r = k / L.LDW, cc = unit(k % L.LDW, 1);       // r = cond idx, cc = hidden
+      if (r < L.c && cc >= 0) v = N.W[0][(int64_t)cc * N.dims[0] + 1 + r];
     }
     pack[idx] = v;
   }
@@ -1905,17 +1906,19 @@ __global__ void mono_unpack_k(UnpackArgs u) {
   const int HP = L.HP, NH = L.NH;
   const int tid = blockIdx.x * blockDim.x + threadIdx.x, nth = gridDim.x * blockDim.x;
   const int H0 = N.dims[1], in0 = N.dims[0];
+  auto pos = [&](int unit, int l) { return mono_pos_of(unit, N.dims[l], L.perm); };     // padded position of a unit of layer l
   for (int k = tid; k < H0 * in0; k += nth) {
     const int r = k / in0, cc = k % in0;
-    u.gW[0][k] = cc == 0 ? u.vec[HP + r] : u.dW1h[r * L.c + (cc - 1)];
+    u.gW[0][k] = cc == 0 ? u.vec[HP + pos(r, 1)] : u.dW1h[pos(r, 1) * L.c + (cc - 1)];
   }
-  for (int k = tid; k < H0; k += nth) u.gb[0][k] = u.vec[2 * HP + k];
+  for (int k = tid; k < H0; k += nth) u.gb[0][k] = u.vec[2 * HP + pos(k, 1)];
   for (int l = 1; l < NH; ++l) {
     const int out = N.dims[l + 1], in = N.dims[l];
-    for (int k = tid; k < out * in; k += nth) u.gW[l][k] = u.dWpad[l][(k / in) * HP + (k % in)];
-    for (int k = tid; k < out; k += nth) u.gb[l][k] = u.ones ? u.dWpad[l][k * HP + HP - 1] : u.vec[(2 + l) * HP + k];
+    for (int k = tid; k < out * in; k += nth) u.gW[l][k] = u.dWpad[l][pos(k / in, l + 1) * HP + pos(k % in, l)];
+    for (int k = tid; k < out; k += nth)
+      u.gb[l][k] = u.ones ? u.dWpad[l][pos(k, l + 1) * HP + HP - 1] : u.vec[(2 + l) * HP + pos(k, l + 1)];
   }
-  for (int k = tid; k < N.dims[NH]; k += nth) u.gW[NH][k] = u.vec[k];
+  for (int k = tid; k < N.dims[NH]; k += nth) u.gW[NH][k] = u.vec[pos(k, NH)];
   if (tid == 0) u.gb[NH][0] = u.vec[(NH + 2) * HP];
 }
 
@@ -1953,6 +1956,14 @@ MonoLayout net_layout(const gnf_mono_net* net, int HT) {
     bool same = true;
     for (int l = 1; l < net->nl; ++l) same = same && net->dims[l] == H;
     if (same && H / 16 == 3 && H % 16 >= 1 && H % 16 <= 3) { L.HM = 3; L.EX = H % 16; }
+  }
+  static const bool perm_on = [] { const char* e = std::getenv("GNF_MONO_KPERM"); return !(e && e[0] == '0'); }();
+  if (HT >= 7 && perm_on) {                  // wide nets: K order of the last unit tile (see MonoLayout::perm)
+    L.perm = 1;
+    for (int l = 1; l < net->nl; ++l) {
+      const int H = net->dims[l], T = (H - 1) / 16;
+      L.ksv[l] = 4 * T + (H - 16 * T + 3) / 4;
+    }
   }
   return L;
 }

@@ -87,7 +87,7 @@ __device__ __forceinline__ void frag_prefetch(rsrc_t rs, int voff, int soff, int
 }
 template <int HT, int MF, int XT, int P>
 __device__ __forceinline__ void layer_pass(rsrc_t rs, int voff, int soff, int soffx, const float* bsrc, const float* bsrcx,
-                                           const f32x4 (&A0)[MF + XT], f32x4 (&acc)[MF + XT][2]) {
+                                           const f32x4 (&A0)[MF + XT], f32x4 (&acc)[MF + XT][2], int ksv) {
   f32x4 A[2][MF + XT], B[2][2 + XT];
   constexpr int MT = MF + XT, AH = (MT + 1) / 2;
   // the requests for k-tile t+1 ride in the shadow of the MFMAs of k-tile t, a few at a time: issued as one block between
@@ -120,11 +120,13 @@ __device__ __forceinline__ void layer_pass(rsrc_t rs, int voff, int soff, int so
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       __builtin_amdgcn_sched_barrier(0);
+      if (4 * t + r < ksv) {                 // (the k-steps past the layer's last unit multiply zeros: MonoLayout::perm)
 #pragma unroll
-      for (int mi = 0; mi < MF; ++mi)
+        for (int mi = 0; mi < MF; ++mi)
 #pragma unroll
-        for (int sl = 0; sl < 2; ++sl) acc[mi][sl] = mfma(A[t & 1][mi][r], B[t & 1][sl][r], acc[mi][sl]);
-      if constexpr (XT) acc[MF][0] = mfma(A[t & 1][MF][r], B[t & 1][2][r], acc[MF][0]);
+          for (int sl = 0; sl < 2; ++sl) acc[mi][sl] = mfma(A[t & 1][mi][r], B[t & 1][sl][r], acc[mi][sl]);
+        if constexpr (XT) acc[MF][0] = mfma(A[t & 1][MF][r], B[t & 1][2][r], acc[MF][0]);
+      }
       __builtin_amdgcn_sched_barrier(0);
       if (t + 1 < HT) fetch_part(r, t + 1, A[(t + 1) & 1], B[(t + 1) & 1]);
     }
@@ -567,7 +569,7 @@ __global__ __launch_bounds__(64 * kWideWaves, 1) void mono_bwd_wide_k(MonoArgs a
         }
         layer_pass<HT, MF, XT, P>(rs, 16 * lane, opaque_s(4 * (L.o_Wf[l] + m0 * HT * 256)),
                                   opaque_s(4 * (L.o_Wf[l] + MF * HT * 256)), actbuf(l) + prow + 4 * q,
-                                  actbuf(l) + xrow + 4 * q, Apre, acc);
+                                  actbuf(l) + xrow + 4 * q, Apre, acc, L.ksv[l]);
         {                                             // next pass: the next layer, or the top layer's transpose
           const int on = l < NH - 1 ? L.o_Wf[l < NH - 1 ? l + 1 : l] : L.o_WTf[NH - 1];
           frag_prefetch<HT, MF, XT>(rs, 16 * lane, opaque_s(4 * (on + m0 * HT * 256)), opaque_s(4 * (on + MF * HT * 256)), Apre);
@@ -658,7 +660,8 @@ __global__ __launch_bounds__(64 * kWideWaves, 1) void mono_bwd_wide_k(MonoArgs a
 #pragma unroll
         for (int mi = 0; mi < MT; ++mi) { acc[mi][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[mi][1] = acc[mi][0]; }
         layer_pass<HT, MF, XT, P>(rs, 16 * lane, opaque_s(4 * (L.o_WTf[l] + m0 * HT * 256)),
-                                  opaque_s(4 * (L.o_WTf[l] + MF * HT * 256)), dpbuf + prow + 4 * q, dpbuf + xrow + 4 * q, Apre, acc);
+                                  opaque_s(4 * (L.o_WTf[l] + MF * HT * 256)), dpbuf + prow + 4 * q, dpbuf + xrow + 4 * q, Apre, acc,
+                                  L.ksv[l + 1]);
         {                                             // next pass: the layer below, or layer 1 of the next batch
           const int on = l > 1 ? L.o_WTf[l > 1 ? l - 1 : l] : L.o_Wf[1];
           frag_prefetch<HT, MF, XT>(rs, 16 * lane, opaque_s(4 * (on + m0 * HT * 256)), opaque_s(4 * (on + MF * HT * 256)), Apre);
@@ -882,7 +885,7 @@ __global__ __launch_bounds__(64 * kWaves, 2) void mono_fwd_wide_k(MonoArgs a) {
           acc[mi][1] = acc[mi][0];
         }
         layer_pass<HT, MF, XT, P>(rs, 16 * lane, opaque_s(4 * (L.o_Wf[l] + m0 * HT * 256)),
-                                  opaque_s(4 * (L.o_Wf[l] + MF * HT * 256)), act + prow + 4 * q, act + xrow + 4 * q, Apre, acc);
+                                  opaque_s(4 * (L.o_Wf[l] + MF * HT * 256)), act + prow + 4 * q, act + xrow + 4 * q, Apre, acc, L.ksv[l]);
         {
           const int on = L.o_Wf[l < NH - 1 ? l + 1 : 1];
           frag_prefetch<HT, MF, XT>(rs, 16 * lane, opaque_s(4 * (on + m0 * HT * 256)), opaque_s(4 * (on + MF * HT * 256)), Apre);

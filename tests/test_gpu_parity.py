@@ -959,6 +959,10 @@ def _layers_cpu(norm):
                                               ([50, 50, 50], 29, "made"), ([100, 100, 100], 20, "contig"),
                                               ([150, 150, 150], 20, "made"), ([40, 64, 24], 15, "contig"),
                                               ([200, 200], 22, "contig"),
+                                              # wide nets whose layers end in DIFFERENT k-steps of their last unit tile (the
+                                              # pack's K order and the truncated contractions, MonoLayout::perm): 97 -> 1 of
+                                              # 4 k-steps of tile 6, 110 -> all 4 minus 2 units, 101 -> 2;  145 / 158 / 147
+                                              ([97, 110, 101], 20, "contig"), ([145, 158, 147], 20, "made"),
                                               # four hidden layers: narrow -> bias gradients through the ones column of the
                                               # staged activations (image + tiles exceed the LDS); wide (the reference's
                                               # default integrand) -> one hidden matrix swapped through LDS at a time
