@@ -609,19 +609,23 @@ __global__ __launch_bounds__(64 * kSplitWavesX) void mono_inv_split_x_k(MonoArgs
 // ascending), with the same midpoints: the result is that of the 20 sequential steps BIT FOR BIT (tested).  S <= 31.
 // EPG = elements per workgroup: 4 (8 wavefronts at S = 20), or 2 (4 wavefronts: ONE per SIMD) when the call holds so few
 // elements that every workgroup of two still finds a CU of its own -- a round is then one pair evaluation deep instead of two.
-template <int HM, int EX, int EPG>
-__global__ __launch_bounds__(64 * kSplitWavesX) void mono_inv_ks_x_k(MonoArgs a) {
+// MAXW = wavefronts the launch may use: 8 (S <= 20 with four elements: 256 registers, nothing spills) or kSplitWavesX (168
+// registers: the round's uniform values then live in spilled SGPRs, ~230 v_readlane / s_nop slots per round).
+template <int HM, int EX, int EPG, int MAXW>
+__global__ __launch_bounds__(64 * MAXW) void mono_inv_ks_x_k(MonoArgs a) {
   constexpr int NS = 16 / EPG;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const MonoLayout& L = a.L;
   for (int i = threadIdx.x * 4; i < L.fwd_floats; i += blockDim.x * 4)
     *reinterpret_cast<f32x4*>(smem + i) = ld4(a.pack + i);
-  const int S1 = a.S + 1, S1P = (S1 + 3) & ~3, NV = 3 * S1;
-  float* wq = smem + L.fwd_floats;               // [S + 1] weights of the rule
-  float* tq = wq + S1P;                          // [S + 1] its nodes
-  float* fbuf = tq + S1P;                        // [2][NV][EPG] integrand values of the round
-  float* zs = fbuf + 2 * NV * EPG;               // [2][3][EPG] the quadrature sums of the round
-  for (int i = threadIdx.x; i < S1; i += blockDim.x) { wq[i] = a.ccw[i]; tq[i] = a.cct[i]; }
+  const int S1 = a.S + 1, NV = 3 * S1;
+  constexpr int SP = 32;                         // node slots per point: S + 1 <= 32 (the launch condition), the rest stay 0
+  float* wq = smem + L.fwd_floats;               // [32] weights of the rule, zero past S
+  float* tq = wq + SP;                           // [32] its nodes
+  float* fbuf = tq + SP;                         // [2][3][32][EPG] integrand values of the round (slots past S: 0, never written)
+  float* zs = fbuf + 2 * 3 * SP * EPG;           // [2][3][EPG] the quadrature sums of the round
+  for (int i = threadIdx.x; i < SP; i += blockDim.x) { wq[i] = i < S1 ? a.ccw[i] : 0.f; tq[i] = i < S1 ? a.cct[i] : 0.f; }
+  for (int i = threadIdx.x; i < 2 * 3 * SP * EPG; i += blockDim.x) fbuf[i] = 0.f;
   __syncthreads();
   const float* wp = smem;
   auto getW = [&](int l) -> const float* { return wp + L.o_W[l]; };
@@ -658,36 +662,32 @@ __global__ __launch_bounds__(64 * kSplitWavesX) void mono_inv_ks_x_k(MonoArgs a)
       const float xTb = p1 == 0 ? xT[0] : (p1 == 1 ? xT[1] : xT[2]);
       const float xa = xTa * ta * .5f, xb = xTb * tb * .5f;
       float fa, fb;
+#ifdef GNF_INV_EXP_NOEVAL      // timing build: the round without its integrand evaluations (wrong results)
+      fa = xa * c1[0][0]; fb = xb * c1x[0];
+#else
       eval2x<HM, EX>(wp, L, c1, c1x, xa, xb, q, j, fa, fb, getW);
-      float* fw = fbuf + buf * NV * EPG + el;
+#endif
+      float* fw = fbuf + buf * 3 * SP * EPG + el;
       if (q == 0) {
-        if (on0) fw[v0 * EPG] = fa;
-        if (on1) fw[v1 * EPG] = fb;
+        if (on0) fw[(p0 * SP + k0) * EPG] = fa;
+        if (on1) fw[(p1 * SP + k1) * EPG] = fb;
       }
       __syncthreads();
       // the three sums of each element: ONE lane per (point, element) -- lane (q = point, j = element) of wavefront 0 -- walks
       // the 21 values in the sequential kernel's order and leaves z in LDS (every lane of the workgroup forming all three
       // sums itself was 126 LDS reads per lane and round: slower than the 20 sequential steps)
       if (wave == 0 && q < 3 && j < EPG) {
-        const float* f = fbuf + buf * NV * EPG + j + q * S1 * EPG;
-        // all reads first (S + 1 <= 32: the launch condition), then the chain: as a loop over a run-time node count every
-        // pair waited for its own LDS round trip (11 x ~150 cycles per round at S = 20)
-        float fv[32], wv[32];
+        const float* f = fbuf + (buf * 3 + q) * SP * EPG + j;
+        // 16 pairs at FIXED offsets: the slots past S hold w = 0 and f = 0, so their pairs add +0 (as a loop over a run-time
+        // node count every pair waited for its own LDS round trip, and with clamped run-time indices the 64 uniform addresses
+        // sat in SGPRs that spilled)
+        float fv[SP], wv[SP];
 #pragma unroll
-        for (int kk = 0; kk < 32; ++kk) {
-          const int kc = kk < S1 ? kk : S1 - 1;
-          fv[kk] = f[kc * EPG];
-          wv[kk] = wq[kc];
-        }
+        for (int kk = 0; kk < SP; ++kk) { fv[kk] = f[kk * EPG]; wv[kk] = wq[kk]; }
         float tot = 0.f;
 #pragma unroll
-        for (int kk = 0; kk < 32; kk += 2) {                // pair (kk, kk + 1) as the sequential kernel forms it
-          if (kk < S1) {
-            float acc = fmaf(wv[kk], fv[kk], 0.f);
-            if (kk + 1 < S1) acc = fmaf(wv[kk + 1], fv[kk + 1], acc);
-            tot += acc;
-          }
-        }
+        for (int kk = 0; kk < SP; kk += 2)                  // pair (kk, kk + 1) as the sequential kernel forms it
+          tot += fmaf(wv[kk + 1], fv[kk + 1], fmaf(wv[kk], fv[kk], 0.f));
         zs[(buf * 3 + q) * EPG + j] = tot;
       }
       __syncthreads();
@@ -1988,19 +1988,20 @@ int launch_fwd(const MonoArgs& a, hipStream_t s) {
     static const bool one_pt = getenv("GNF_MONO_INV_PTS") && getenv("GNF_MONO_INV_PTS")[0] == '1';
     const int epg = a.n <= 2 * 256 ? 2 : 4;                           // elements per workgroup (see mono_inv_ks_x_k)
     const int ks_waves = ((3 * (a.S + 1) + 1) / 2 * epg + 15) / 16;   // node-pair columns / 16 per wavefront
-    if (a.L.EX > 0 && quarter && wlds && !one_pt && ks_waves <= kSplitWavesX) {
-      const int S1P = (a.S + 4) & ~3;
-      const size_t lds_k = lds + (size_t)(2 * S1P + 2 * 3 * (a.S + 1) * epg + 2 * 3 * epg) * sizeof(float);
+    if (a.L.EX > 0 && quarter && wlds && !one_pt && ks_waves <= kSplitWavesX && a.S <= 31) {   // (32 node slots per point)
+      const size_t lds_k = lds + (size_t)(2 * 32 + 2 * 3 * 32 * epg + 2 * 3 * epg) * sizeof(float);
       const unsigned gq = (unsigned)((a.n + epg - 1) / epg);
-#define GNF_INVKS(EX_, EPG_)                                                                                   \
+#define GNF_INVKS_W(EX_, EPG_, MW_)                                                                            \
       {                                                                                                        \
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mono_inv_ks_x_k<3, EX_, EPG_>),               \
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mono_inv_ks_x_k<3, EX_, EPG_, MW_>),          \
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_k);                     \
-        hipLaunchKernelGGL((mono_inv_ks_x_k<3, EX_, EPG_>), dim3(gq), dim3(64 * ks_waves), lds_k, s, a);       \
+        hipLaunchKernelGGL((mono_inv_ks_x_k<3, EX_, EPG_, MW_>), dim3(gq), dim3(64 * ks_waves), lds_k, s, a);  \
       }
+#define GNF_INVKS(EX_, EPG_) { if (ks_waves <= 8) GNF_INVKS_W(EX_, EPG_, 8) else GNF_INVKS_W(EX_, EPG_, kSplitWavesX) }
       if (a.L.EX <= 2) { if (epg == 2) GNF_INVKS(2, 2) else GNF_INVKS(2, 4) }
       else { if (epg == 2) GNF_INVKS(3, 2) else GNF_INVKS(3, 4) }
 #undef GNF_INVKS
+#undef GNF_INVKS_W
       GNF_LAUNCH_CHECK();
       return 0;
     }

@@ -582,7 +582,10 @@ torch.save(x.cpu(), %r)
 """
 
 
-@pytest.mark.parametrize("n,S", [(700, 20), (37, 20), (3, 27), (1000, 30), (700, 7), (512, 20), (513, 20), (301, 31)])
+@pytest.mark.parametrize("n,S", [(700, 20), (37, 20), (3, 27), (1000, 30), (700, 7), (512, 20), (513, 20), (301, 31),
+                                 # more nodes than the two-steps-per-round kernel has slots for (32 per point): both runs take
+                                 # the one-step kernel -- a two-element workgroup would otherwise still fit its wavefront budget
+                                 (100, 40), (300, 32)])
 def test_split_inverse_two_steps_per_round_is_bit_identical(n, S, tmp_path):
     """the level kernels of a sampling pass take TWO bisection steps per round (midpoint + both quarter points evaluated at
     once, mono_inv_ks_x_k; workgroups of two elements up to 512 elements per call, of four above): same midpoints, same sums,
