@@ -572,8 +572,8 @@ sys.path[:0] = %r
 from gnf_hip import ops
 from models import MonotonicNormalizer
 torch.manual_seed(3)
-n, d, c, S = %d, 1, 30, %d
-norm = MonotonicNormalizer([50, 50, 50], c, nb_steps=S).to("cuda:0")
+n, d, c, S, H = %d, 1, 30, %d, %d
+norm = MonotonicNormalizer([H, H, H], c, nb_steps=S).to("cuda:0")
 g = torch.Generator().manual_seed(4)
 z = (torch.randn(n, d, generator=g) * 3).to("cuda:0")
 h = torch.randn(n, d, c, generator=g).to("cuda:0")
@@ -582,11 +582,14 @@ torch.save(x.cpu(), %r)
 """
 
 
-@pytest.mark.parametrize("n,S", [(700, 20), (37, 20), (3, 27), (1000, 30), (700, 7), (512, 20), (513, 20), (301, 31),
-                                 # more nodes than the two-steps-per-round kernel has slots for (32 per point): both runs take
-                                 # the one-step kernel -- a two-element workgroup would otherwise still fit its wavefront budget
-                                 (100, 40), (300, 32)])
-def test_split_inverse_two_steps_per_round_is_bit_identical(n, S, tmp_path):
+@pytest.mark.parametrize("n,S,H", [(700, 20, 50), (37, 20, 50), (3, 27, 50), (1000, 30, 50), (700, 7, 50), (512, 20, 50),
+                                   (513, 20, 50), (301, 31, 50),
+                                   # more nodes than the two-steps-per-round kernel has slots for (32 per point): both runs take
+                                   # the one-step kernel -- a two-element workgroup would otherwise still fit its wavefront budget
+                                   (100, 40, 50), (300, 32, 50),
+                                   # the other peeled widths: 51 = three tiles + THREE units on the VALU, 49 = + one
+                                   (700, 20, 51), (200, 20, 51), (700, 20, 49), (64, 9, 49)])
+def test_split_inverse_two_steps_per_round_is_bit_identical(n, S, H, tmp_path):
     """the level kernels of a sampling pass take TWO bisection steps per round (midpoint + both quarter points evaluated at
     once, mono_inv_ks_x_k; workgroups of two elements up to 512 elements per call, of four above): same midpoints, same sums,
     so the same bits as the 20 sequential steps (GNF_MONO_INV_PTS=1, run in a second process: the switch is read once) --
@@ -596,7 +599,7 @@ def test_split_inverse_two_steps_per_round_is_bit_identical(n, S, tmp_path):
     outs = []
     for tag, env in (("pts3", {}), ("pts1", {"GNF_MONO_INV_PTS": "1"})):
         f = str(tmp_path / (tag + ".pt"))
-        code = _INV_SNIPPET % ([ROOT, PKG], n, S, f)
+        code = _INV_SNIPPET % ([ROOT, PKG], n, S, H, f)
         r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **env), capture_output=True, text=True)
         assert r.returncode == 0, r.stderr[-2000:]
         outs.append(torch.load(f))
