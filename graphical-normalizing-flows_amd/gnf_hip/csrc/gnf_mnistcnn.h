@@ -112,6 +112,57 @@ __device__ __forceinline__ void conv1_units(const float* e_rd, float* a1_wr, int
       }
     }
 }
+// The same with the position -> LDS offsets of the units handed in (a wavefront runs the SAME units for every image of its
+// persistent loop): po[k] = {read offset | write offset of block 0 << 16, blocks 1 | 2 << 16, block 3}, 16 bits each, built
+// once by conv1_offsets.  Positions past the 26 x 26 grid (the tail of unit 10) read offset 0 and write into the 8 floats of
+// slack behind row 25 of their channel (CHS >= 25 IMG + 26 + 8), so there is no predicate either: ~8 VALU instructions per
+// unit instead of ~45 of address arithmetic.  Costs 3 registers per unit: for kernels that have them (the forward: 230).
+template <int CHS>
+__device__ __forceinline__ void conv1_offsets(int u, int q, int j, int lane, unsigned (&po)[3]) {
+  static_assert(CHS >= 25 * IMG + C1 + 8, "slack behind the last row of a channel");
+  const int pos = 64 * u + lane, pc = pos < C1 * C1 ? pos : 0;
+  unsigned w[4];
+#pragma unroll
+  for (int b = 0; b < 4; ++b) {
+    const int p = 64 * u + 16 * b + j;
+    w[b] = (unsigned)(4 * q * CHS + (p < C1 * C1 ? p + 2 * (p / C1) : 26 * IMG + (j & 7)));
+  }
+  po[0] = (unsigned)(pc + 2 * (pc / C1)) | (w[0] << 16);
+  po[1] = w[1] | (w[2] << 16);
+  po[2] = w[3];
+}
+template <int NU, int CHS>
+__device__ __forceinline__ void conv1_units_pre(const float* e_rd, float* a1_wr, const unsigned (&po)[3][3], const float* w1p,
+                                                const f32x4& b1v) {
+  f32x16 acc[NU];
+  float ev[NU][9], w1a[9];
+#pragma unroll
+  for (int tap = 0; tap < 9; ++tap) w1a[tap] = w1p[16 * tap];
+#pragma unroll
+  for (int k = 0; k < NU; ++k) {
+    const float* pe = e_rd + (po[k][0] & 0xffffu);
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) ev[k][tap] = pe[(tap / 3) * IMG + tap % 3];
+#pragma unroll
+    for (int v = 0; v < 16; ++v) acc[k][v] = b1v[v & 3];
+  }
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+    for (int k = 0; k < NU; ++k) acc[k] = __builtin_amdgcn_mfma_f32_16x16x1f32(w1a[tap], ev[k][tap], acc[k], 0, 0, 0);
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int k = 0; k < NU; ++k) {
+    const unsigned off[4] = {po[k][0] >> 16, po[k][1] & 0xffffu, po[k][1] >> 16, po[k][2]};
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      float* pa = a1_wr + off[b];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) pa[r * CHS] = relu1(acc[k][4 * b + r]);
+    }
+  }
+}
 // conv1 + ReLU of the image in e_s into a1_s; 43 tiles of 16 consecutive positions of the 26x26 grid.
 // All operand reads of a wave's (up to 6) tiles are issued first, then 6 independent 3-step MFMA chains,
 // then the stores: the phase is latency-bound, so nothing may serialise behind a single chain.

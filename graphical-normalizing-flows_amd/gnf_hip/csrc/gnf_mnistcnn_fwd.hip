@@ -184,6 +184,8 @@ __device__ constexpr int F1U[8] = GNF_FWD_F1U;                       // conv1 un
 __device__ constexpr int F1PRO[8] = {2, 2, 2, 1, 1, 1, 1, 1};        // the first image: dealt evenly
 constexpr int fsum(const int (&v)[8]) { int t = 0; for (int i = 0; i < 8; ++i) t += v[i]; return t; }
 static_assert(fsum(F1U) == 11 && fsum(F1PRO) == 11, "conv1 units");
+constexpr int fmax8(const int (&v)[8]) { int t = 0; for (int i = 0; i < 8; ++i) t = v[i] > t ? v[i] : t; return t; }
+static_assert(fmax8(F1U) <= 3 && fmax8(F1PRO) <= 3, "at most three units per wavefront (conv1_do, the packed offsets)");
 
 __global__ __launch_bounds__(64 * FWD_WAVES) void cnn_fwd_wino_k(CnnArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -374,6 +376,17 @@ __global__ __launch_bounds__(64 * FWD_WAVES) void cnn_fwd_wino_k(CnnArgs a) {
   int c1u0 = 0;
 #pragma unroll
   for (int w = 0; w < NW; ++w) c1u0 += w < wave ? F1U[w] : 0;
+  // the steady-state units of this wavefront are the same for every image: their LDS offsets once, packed (conv1_units_pre;
+  // 1.272 -> 1.244 ms: ~40 instructions of address arithmetic per unit and image were 17 % of the kernel's VALU work)
+  unsigned upo[3][3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) conv1_offsets<WCH>(c1u0 + (k < F1U[wave] ? k : 0), q, j, lane, upo[k]);
+  auto conv1_steady = [&](const float* e_rd, float* a1_wr) {
+    const int nu = F1U[wave];
+    if (nu == 3) conv1_units_pre<3, WCH>(e_rd, a1_wr, upo, w1_s + j, b1v);
+    else if (nu == 2) conv1_units_pre<2, WCH>(e_rd, a1_wr, upo, w1_s + j, b1v);
+    else if (nu == 1) conv1_units_pre<1, WCH>(e_rd, a1_wr, upo, w1_s + j, b1v);
+  };
 #ifndef GNF_FWD_UNITS_FIRST
 #define GNF_FWD_UNITS_FIRST (wave >= 4)
 #endif
@@ -399,13 +412,13 @@ __global__ __launch_bounds__(64 * FWD_WAVES) void cnn_fwd_wino_k(CnnArgs a) {
     fetch(img + 3 * gs);
     if (wave == GNF_FWD_SPLIT_WAVE && prev >= 0) finish_split(xch + (par ^ 1) * 2 * 16 * 64, prev);
     FSTAMP(1);
-    if (has_next && units_first) conv1_do(e_s + (par ^ 1) * WESZ, a1n, c1u0, F1U[wave]);
+    if (has_next && units_first) conv1_steady(e_s + (par ^ 1) * WESZ, a1n);
     FSTAMP(2);
     whole_item(a1p, wave, img);
     FSTAMP(3);
     if (wave < 2) half_item(a1p, wave, xch + par * 2 * 16 * 64);
     FSTAMP(4);
-    if (has_next && !units_first) conv1_do(e_s + (par ^ 1) * WESZ, a1n, c1u0, F1U[wave]);
+    if (has_next && !units_first) conv1_steady(e_s + (par ^ 1) * WESZ, a1n);
     FSTAMP(2);
     prev = img;
   }
