@@ -239,6 +239,7 @@ __global__ __launch_bounds__(64 * FWD_WAVES) void cnn_fwd_wino_k(CnnArgs a) {
     for (int k = 0; k < EPT; ++k)
       if (tid + k * NT < IMG * IMG) dst[tid + k * NT] = pre[k];
   };
+  auto half2 = [](const f32x4& v, int pr) { return pr ? f32x2{v[2], v[3]} : f32x2{v[0], v[1]}; };
   // 2x2 max pool of (channel 4q+r, tile t) into the image's outputs; first max wins ties (torch max_pool2d order)
   auto pool_out = [&](rsrc_t rp, rsrc_t ra, int t, int r, float v00, float v01, float v10, float v11) {
     float best = v00; int bi = 0;
@@ -297,15 +298,22 @@ __global__ __launch_bounds__(64 * FWD_WAVES) void cnn_fwd_wino_k(CnnArgs a) {
       __builtin_amdgcn_sched_barrier(0);
     }
     const rsrc_t rp = rsrc_of(a.pooled, im, NPOOL * 4), ra = rsrc_of(a.arg, im, NPOOL);
+    // output transform A^T M A (A^T = [[1,1,1,0],[0,1,-1,-1]]) + pool, two channels per instruction: the halves of an
+    // accumulator are an aligned register pair, so the 24 additions per channel are 12 v_pk_add_f32 per channel PAIR (this
+    // unit is built without the SLP vectoriser; same operation order per component, so the same bits)
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {                      // output transform A^T M A (A^T = [[1,1,1,0],[0,1,-1,-1]]) + pool
-      float s0[4], s1[4];
+    for (int pr = 0; pr < 2; ++pr) {
+      f32x2 s0[4], s1[4];
 #pragma unroll
       for (int c = 0; c < 4; ++c) {
-        s0[c] = acc[c][r] + acc[4 + c][r] + acc[8 + c][r];
-        s1[c] = acc[4 + c][r] - acc[8 + c][r] - acc[12 + c][r];
+        const f32x2 m0 = half2(acc[c], pr), m1 = half2(acc[4 + c], pr), m2 = half2(acc[8 + c], pr), m3 = half2(acc[12 + c], pr);
+        s0[c] = m0 + m1 + m2;
+        s1[c] = m1 - m2 - m3;
       }
-      pool_out(rp, ra, t, r, s0[0] + s0[1] + s0[2], s0[1] - s0[2] - s0[3], s1[0] + s1[1] + s1[2], s1[1] - s1[2] - s1[3]);
+      const f32x2 y00 = s0[0] + s0[1] + s0[2], y01 = s0[1] - s0[2] - s0[3];
+      const f32x2 y10 = s1[0] + s1[1] + s1[2], y11 = s1[1] - s1[2] - s1[3];
+      pool_out(rp, ra, t, 2 * pr, y00.x, y01.x, y10.x, y11.x);
+      pool_out(rp, ra, t, 2 * pr + 1, y00.y, y01.y, y10.y, y11.y);
     }
   };
   // half of the split item (group 8): xi_y in {2 hf, 2 hf + 1}; partial output transform into xb
@@ -347,17 +355,18 @@ __global__ __launch_bounds__(64 * FWD_WAVES) void cnn_fwd_wino_k(CnnArgs a) {
     // this half's share of A^T M A: rows s0 += xi_y 0, 1, 2;  s1 += xi_y 1, -2, -3, then the (linear) column half
     float* xb = xb0 + hf * 16 * 64 + lane;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      float p0[4], p1[4];
+    for (int pr = 0; pr < 2; ++pr) {
+      f32x2 p0[4], p1[4];
 #pragma unroll
       for (int c = 0; c < 4; ++c) {
-        p0[c] = hf == 0 ? acc[c][r] + acc[4 + c][r] : acc[c][r];
-        p1[c] = hf == 0 ? acc[4 + c][r] : -acc[c][r] - acc[4 + c][r];
+        const f32x2 m0 = half2(acc[c], pr), m1 = half2(acc[4 + c], pr);
+        p0[c] = hf == 0 ? m0 + m1 : m0;
+        p1[c] = hf == 0 ? m1 : -m0 - m1;
       }
-      xb[(r * 4 + 0) * 64] = p0[0] + p0[1] + p0[2];
-      xb[(r * 4 + 1) * 64] = p0[1] - p0[2] - p0[3];
-      xb[(r * 4 + 2) * 64] = p1[0] + p1[1] + p1[2];
-      xb[(r * 4 + 3) * 64] = p1[1] - p1[2] - p1[3];
+      const f32x2 y0 = p0[0] + p0[1] + p0[2], y1 = p0[1] - p0[2] - p0[3], y2 = p1[0] + p1[1] + p1[2], y3 = p1[1] - p1[2] - p1[3];
+      xb[(2 * pr * 4 + 0) * 64] = y0.x; xb[(2 * pr * 4 + 1) * 64] = y1.x; xb[(2 * pr * 4 + 2) * 64] = y2.x; xb[(2 * pr * 4 + 3) * 64] = y3.x;
+      xb[((2 * pr + 1) * 4 + 0) * 64] = y0.y; xb[((2 * pr + 1) * 4 + 1) * 64] = y1.y;
+      xb[((2 * pr + 1) * 4 + 2) * 64] = y2.y; xb[((2 * pr + 1) * 4 + 3) * 64] = y3.y;
     }
   };
 
