@@ -15,7 +15,7 @@ objs = []
 for f in (os.environ.get('GNF_CNN_FWD_SRC', 'gnf_mnistcnn_fwd.hip'), os.environ.get('GNF_CNN_BWD_SRC', 'gnf_mnistcnn.hip'),
           'gnf_rowwise.hip'):                                       # A/B against other sources in csrc/
     o = '/tmp/cnn_ab_%d_%s.o' % (os.getpid(), f)
-    subprocess.run(['hipcc', '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-Wno-unused-value'] + EXTRA_FLAGS.get(f, EXTRA_FLAGS.get('gnf_mnistcnn_fwd.hip', []) if 'fwd' in f else []) + flags +
+    subprocess.run(['hipcc', '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-Wno-unused-value'] + EXTRA_FLAGS.get(f, EXTRA_FLAGS.get('gnf_mnistcnn_fwd.hip' if 'fwd' in f else 'gnf_mnistcnn.hip', []) if 'mnistcnn' in f else []) + flags +
                    ['-I' + ROOT + '/include', '-I' + src, '-c', src + f, '-o', o], check=True)
     objs.append(o)
 subprocess.run(['hipcc', '--offload-arch=gfx950', '-shared', '-fPIC', '-o', so] + objs, check=True)
