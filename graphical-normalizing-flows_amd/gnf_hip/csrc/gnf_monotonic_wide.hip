@@ -90,6 +90,7 @@ __device__ __forceinline__ void layer_pass(rsrc_t rs, int voff, int soff, int so
                                            const f32x4 (&A0)[MF + XT], f32x4 (&acc)[MF + XT][2], int ksv) {
   f32x4 A[2][MF + XT], B[2][2 + XT];
   constexpr int MT = MF + XT, AH = (MT + 1) / 2;
+  const int rlast = __builtin_amdgcn_readfirstlane(ksv - 4 * (HT - 1));   // valid k-steps of the last tile (1..4)
   // the requests for k-tile t+1 ride in the shadow of the MFMAs of k-tile t, a few at a time: issued as one block between
   // two k-tiles they take ~100 issue cycles during which the matrix pipe runs dry (one wavefront per SIMD feeds it in the
   // forward passes): weight fragments behind the MFMAs of r = 0 and r = 1 (longest latency first), LDS reads behind r = 2
@@ -120,7 +121,10 @@ __device__ __forceinline__ void layer_pass(rsrc_t rs, int voff, int soff, int so
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       __builtin_amdgcn_sched_barrier(0);
-      if (4 * t + r < ksv) {                 // (the k-steps past the layer's last unit multiply zeros: MonoLayout::perm)
+      // (the k-steps past the layer's last unit multiply zeros, MonoLayout::perm; only the last tile can hold such steps, and
+      // rlast is wave-uniform BY CONSTRUCTION: left as a plain comparison against a kernel argument, hipcc precomputed all 4 HT
+      // conditions as 64-bit lane masks outside the batch loop and reloaded them from spilled SGPRs, two v_readlane each)
+      if (t < HT - 1 || r < rlast) {
 #pragma unroll
         for (int mi = 0; mi < MF; ++mi)
 #pragma unroll
