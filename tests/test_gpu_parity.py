@@ -969,6 +969,8 @@ def _layers_cpu(norm):
                                               # pack's K order and the truncated contractions, MonoLayout::perm): 97 -> 1 of
                                               # 4 k-steps of tile 6, 110 -> all 4 minus 2 units, 101 -> 2;  145 / 158 / 147
                                               ([97, 110, 101], 20, "contig"), ([145, 158, 147], 20, "made"),
+                                              # layers whose last real tile is not the padded image's last tile (HP = 160)
+                                              ([100, 150, 100], 20, "contig"),
                                               # four hidden layers: narrow -> bias gradients through the ones column of the
                                               # staged activations (image + tiles exceed the LDS); wide (the reference's
                                               # default integrand) -> one hidden matrix swapped through LDS at a time
