@@ -1,5 +1,5 @@
 """per-parameter gradient errors of the Monotonic backward against the fp32 AND an fp64 CPU oracle (is a 1e-4 miss roundoff
-of the fp32 oracle's own summation order, or a kernel defect?)   python tools/dbg_mono_wide_grads.py B d H,H,H"""
+of the fp32 oracle's own summation order, or a kernel defect?)   python tests/dbg_mono_wide_grads.py B d H,H,H"""
 import os, sys
 import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

@@ -1226,7 +1226,7 @@ def test_monotonic_ragged_sizes(B, d, hidden):
     z0, j0 = O.monotonic_forward(xr, hr, layers, S)
     # ReLU gates on the knife edge: with 2 100 elements x 22 nodes x 200 units x 3 layers a handful of pre-activations lie
     # within fp32 roundoff of zero and the gate differs between two correct fp32 evaluations; one flipped gate moves a row of
-    # dW by ~1e-4 of the tensor's max (tools/dbg_mono_wide_grads.py: sometimes the torch fp32 oracle is the side that is
+    # dW by ~1e-4 of the tensor's max (tests/dbg_mono_wide_grads.py: sometimes the torch fp32 oracle is the side that is
     # off).  An fp64 evaluation of the integrand net finds the elements that hold such a gate; they get a ZERO cotangent,
     # their share is bounded, and every gradient is compared at GTOL -- element-wise too.  (Until round 4: 2e-3 for the
     # widest nets.)
