@@ -12,3 +12,14 @@ def test_monotonic_random_shapes():
     res = fuzz_mono.walk(30, 7)
     bad = [(case, what, why) for case, what, why in res if why]
     assert not bad, bad
+
+
+def test_gemm_random_shapes():
+    """gnf_gemm against an fp64 product over random M, N, K, operand orders, paddings and epilogues (tests/fuzz_gemm.py): the
+    dispatcher chooses among six kernel families from exactly these numbers; the error bound is 2e-6 of the summed term
+    magnitudes per entry"""
+    import fuzz_gemm
+    res = fuzz_gemm.walk(80, 2)
+    bad = [(case, desc, worst) for case, desc, worst, b in res if b]
+    assert not bad, bad
+    assert len({desc.split()[-1] for _, desc, _, _ in res}) >= 3          # (more than one kernel family was exercised)
