@@ -23,3 +23,12 @@ def test_gemm_random_shapes():
     bad = [(case, desc, worst) for case, desc, worst, b in res if b]
     assert not bad, bad
     assert len({desc.split()[-1] for _, desc, _, _ in res}) >= 3          # (more than one kernel family was exercised)
+
+
+def test_linear_random_chains():
+    """Linear + ReLU chains of random depth / widths / batch sizes / mask kinds through the gnf_linear_* entry points against
+    an fp64 autograd (tests/fuzz_linear.py); rows on a ReLU knife edge get a zero cotangent"""
+    import fuzz_linear
+    res = fuzz_linear.walk(60, 3)
+    bad = [(case, desc, why) for case, desc, errs, why in res if why]
+    assert not bad, bad
