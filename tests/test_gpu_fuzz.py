@@ -32,3 +32,13 @@ def test_linear_random_chains():
     res = fuzz_linear.walk(60, 3)
     bad = [(case, desc, why) for case, desc, errs, why in res if why]
     assert not bad, bad
+
+
+def test_sparse_front_random_rows():
+    """random row subsets (one crop origin, a level diagonal, anything), batch sizes and window gates through the sparse
+    front -- both crop-kernel forms, the grouped GEMM pair and the one-launch fc kernel -- against the oracle's dense
+    MNISTCNN on the masked copies, element-wise at atol 1e-6 + rtol 1e-5 (tests/fuzz_sparse.py)"""
+    import fuzz_sparse
+    res = fuzz_sparse.walk(40, 5)
+    bad = [(case, desc, w) for case, desc, w, b in res if b]
+    assert not bad, bad
