@@ -1,0 +1,88 @@
+"""Random flows through the reference's factory (NormalizingFlowFactories.py:19-32): every conditioner x normalizer pair at random
+sizes, checked through properties that need no second implementation --
+  * log|det J| returned by the flow == log|det| of the Jacobian assembled from d backward passes of the SAME flow (the forward's
+    log-det reduction and the backward's data gradient have to agree with each other through every kernel on the way),
+  * invert(forward(x)) == x  (NormalizingFlow.py:98-107, 166-169; exact inverse for any number of steps here),
+  * loss finite, every parameter receives a finite gradient.
+python tests/fuzz_flow.py [n] [seed]"""
+import os, sys, random
+import torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "graphical-normalizing-flows_amd")]
+from models import (buildFCNormalizingFlow, CouplingConditioner, AutoregressiveConditioner, DAGConditioner,   # noqa: E402
+                    AffineNormalizer, MonotonicNormalizer)
+DEV = "cuda:0"
+
+
+def one(case, rng):
+    torch.manual_seed(case)
+    d = rng.choice([2, 3, 4, 5, 6, 7, 8, 12, 16, 17, 33])
+    B = rng.choice([1, 2, 3, 5, 8])
+    nb = rng.choice([1, 1, 2, 3])
+    hid = [rng.choice([4, 8, 15, 16, 24, 33, 64]) for _ in range(rng.choice([1, 2, 3]))]
+    ckind = rng.choice(["coupling", "made", "dag"])
+    nkind = rng.choice(["affine", "mono"])
+    out = 2 if nkind == "affine" else rng.choice([3, 6, 30])
+    if ckind == "coupling":
+        ctype, cargs = CouplingConditioner, {"in_size": d, "hidden": hid, "out_size": out}
+    elif ckind == "made":
+        ctype, cargs = AutoregressiveConditioner, {"in_size": d, "hidden": [max(h, d) for h in hid], "out_size": out}
+    else:
+        A = (torch.rand(d, d) < .5).float().tril(-1)                       # an acyclic gate: lower-triangular in the natural order
+        ctype, cargs = DAGConditioner, {"in_size": d, "hidden": hid, "out_size": out, "soft_thresholding": False,
+                                        "h_thresh": 0., "A_prior": A}
+    if nkind == "affine":
+        ntype, nargs = AffineNormalizer, {}
+    else:
+        ntype, nargs = MonotonicNormalizer, {"integrand_net": [rng.choice([8, 16, 50, 64])] * rng.choice([1, 2, 3]), "cond_size": out,
+                                             "nb_steps": rng.choice([10, 20, 31]), "solver": "CC"}
+    flow = buildFCNormalizingFlow(nb, ctype, cargs, ntype, nargs).to(DEV)
+    for c in flow.getConditioners():
+        if ckind == "dag":
+            c.stoch_gate, c.noise_gate = False, False                       # deterministic gate: J is a function of x alone
+    x = (torch.randn(B, d) * .7).to(DEV).requires_grad_(True)
+    z, logdet = flow(x)
+    J = torch.zeros(B, d, d, dtype=torch.float64)
+    for i in range(d):
+        cot = torch.zeros(B, d, device=DEV)
+        cot[:, i] = 1.
+        (gi,) = torch.autograd.grad(z, x, cot, retain_graph=True)
+        J[:, i, :] = gi.double().cpu()
+    sign, lad = torch.linalg.slogdet(J)
+    bad = []
+    e_ld = float((logdet.detach().double().cpu() - lad).abs().max())
+    if not e_ld < 2e-4 * max(1., float(lad.abs().max())):
+        bad.append("logdet %.2e" % e_ld)
+    loss = flow.loss(z, logdet)
+    loss.backward()
+    if not bool(torch.isfinite(loss)):
+        bad.append("loss")
+    for k, p in flow.named_parameters():
+        if p.requires_grad and (p.grad is None or not bool(torch.isfinite(p.grad).all())):
+            if not (ckind == "dag" and k.endswith(".A")):
+                bad.append("grad " + k)
+    e_inv = -1.
+    if ckind != "coupling" or True:
+        with torch.no_grad():
+            xr = flow.invert(z.detach())
+        e_inv = float((xr - x.detach()).abs().max())
+        if not e_inv < (5e-3 if nkind == "mono" else 1e-3):
+            bad.append("invert %.2e" % e_inv)
+    desc = "%-8s %-6s nb %d d %2d B %d hid %-14s out %2d" % (ckind, nkind, nb, d, B, hid, out)
+    return desc, e_ld, e_inv, bad
+
+
+def walk(n, seed):
+    rng = random.Random(seed)
+    return [(case,) + one(case, rng) for case in range(n)]
+
+
+if __name__ == "__main__":
+    n = int(sys.argv[1]) if len(sys.argv) > 1 else 60
+    fails = 0
+    for case, desc, e_ld, e_inv, bad in walk(n, int(sys.argv[2]) if len(sys.argv) > 2 else 0):
+        print("case %3d %s  |logdet - log|det J|| %.1e  |invert - x| %.1e %s" % (case, desc, e_ld, e_inv, ("FAIL " + ",".join(bad)) if bad else "ok"),
+              flush=True)
+        fails += bool(bad)
+    print("%d cases, %d failures" % (n, fails))
+    sys.exit(1 if fails else 0)

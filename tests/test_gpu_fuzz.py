@@ -42,3 +42,13 @@ def test_sparse_front_random_rows():
     res = fuzz_sparse.walk(40, 5)
     bad = [(case, desc, w) for case, desc, w, b in res if b]
     assert not bad, bad
+
+
+def test_random_flows_logdet_equals_jacobian_and_invert_round_trips():
+    """flows of the reference's factory at random sizes (Coupling / MADE / DAG x Affine / Monotonic, 1-3 steps): the log-det the
+    flow returns equals log|det| of the Jacobian assembled from d backward passes of the same flow, invert(forward(x)) == x, the
+    loss is finite and every parameter receives a finite gradient (tests/fuzz_flow.py)"""
+    import fuzz_flow
+    res = fuzz_flow.walk(40, 1)
+    bad = [(case, desc, why) for case, desc, e1, e2, why in res if why]
+    assert not bad, bad
