@@ -50,6 +50,25 @@ constexpr int WLDS = ESZ + NCH * PL;                   // floats of LDS per wave
 __device__ __forceinline__ f32x4 mfma(float a, float b, f32x4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }
+// Winograd F(2x2,3x3) input transform B^T d B of a 4x4 patch given as 4 rows x 2 column pairs; out[xi = 4 xi_y + xi_x] (the dense
+// kernels' routine, gnf_mnistcnn.h: two v_pk_add_f32 per row of B^T d)
+__device__ __forceinline__ f32x2 pk_v12(f32x2 a, f32x2 b) {
+  f32x2 r;
+  asm("v_pk_add_f32 %0, %1, %2 op_sel:[1,0] op_sel_hi:[1,0] neg_hi:[1,0]" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+__device__ __forceinline__ void wino_in(const f32x2 (&lo)[4], const f32x2 (&hi)[4], float (&v)[16]) {
+  f32x2 tl[4], th[4];
+  tl[0] = lo[0] - lo[2]; th[0] = hi[0] - hi[2];
+  tl[1] = lo[1] + lo[2]; th[1] = hi[1] + hi[2];
+  tl[2] = lo[2] - lo[1]; th[2] = hi[2] - hi[1];
+  tl[3] = lo[1] - lo[3]; th[3] = hi[1] - hi[3];
+#pragma unroll
+  for (int rr = 0; rr < 4; ++rr) {
+    const f32x2 v03 = tl[rr] - th[rr], v12 = pk_v12(tl[rr], th[rr]);
+    v[4 * rr + 0] = v03.x; v[4 * rr + 1] = v12.x; v[4 * rr + 2] = v12.y; v[4 * rr + 3] = v03.y;
+  }
+}
 __device__ __forceinline__ float quad_max(float v) {   // max over the 4 lanes of a quad
   v = fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, false)));   // [1,0,3,2]
   return fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xF, 0xF, false))); // [2,3,0,1]
@@ -115,8 +134,20 @@ __device__ __forceinline__ int quad_min(int v) {
 // SPLIT (inference on few copies -- a level of a sampling pass is ~700 of them, less than three per CU): the FOUR wavefronts
 // of a workgroup share one masked copy -- conv1's nine position tiles dealt 3/2/2/2, conv2's seven 2/2/2/1, two barriers --
 // so a copy's ~280 dependent MFMAs are a quarter as deep (the one-wavefront form is the throughput form: no barrier at all).
+// One wavefront per copy WITHOUT the argmax record (!SPLIT && !SAVE: evaluation of many copies under no_grad): conv2 in the
+// WINOGRAD F(2x2,3x3) domain, as in the dense kernels.  NOT for the training form: a deterministic gate leaves exactly constant
+// regions in a crop, whose pool windows are EXACT ties; the direct form gives bit-equal outputs for equal patches, so its first
+// maximum is torch's (max_pool2d's backward routes the cotangent there) -- the four outputs of a Winograd tile round differently
+// and the tie breaks elsewhere (conv1.weight gradient 1.3e-3 off in test_sparse_front_parameter_gradients).  Values agree to
+// rounding either way, which is all the inference form returns (the dense path has the same split: exact_ties).  The
+// 10 x 10 conv2 output of the crop is 5 x 5 tiles of 2 x 2 = the 25 pool cells: per transform point xi a 16 x 16 x 16 product
+// M_xi[o][tile] = sum_c U_xi[o][c] V_xi[c][tile] over two N tiles (cells 0..15, 16..24) -- 128 MFMAs per copy instead of 7 x 36, 64
+// ds_read_b64 of a1 instead of 252 ds_read_b32, and the D layout leaves all 16 xi of one (4 channels, cell) in ONE lane, so the
+// output transform, the bias (added at xi = (1,1)), the max-pool and its first-max argmax are lane-local (no DPP).  The filter
+// transforms U = G w G^T are computed in fp64 once per wavefront.  64 + 64 registers of U' and accumulators: two workgroups per CU.
 template <bool SAVE, bool SPLIT>
-__global__ __launch_bounds__(64 * WAVES, 3) void sparse_crop_k(SparseArgs a) {
+__global__ __launch_bounds__(64 * WAVES, (SPLIT || SAVE) ? 3 : 2) void sparse_crop_k(SparseArgs a) {
+  constexpr bool WINO = !SPLIT && !SAVE;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int q = lane >> 4, j = lane & 15;
@@ -127,14 +158,35 @@ __global__ __launch_bounds__(64 * WAVES, 3) void sparse_crop_k(SparseArgs a) {
   const int nb2 = SPLIT ? 2 * wave : 0, n2 = SPLIT ? (wave == 3 ? 1 : 2) : 7;              // conv2 tiles [nb2, nb2 + n2)
 
   // ---- weights as MFMA A operands: lane (j = output channel, q = K slot)
-  float wa1[3], wa2[36];
+  float wa1[3], wa2[WINO ? 1 : 36], uw[WINO ? 64 : 1];
 #pragma unroll
   for (int s = 0; s < 3; ++s) {
     const int tap = 4 * s + q;
     wa1[s] = tap < 9 ? a.W1[j * 9 + tap] : 0.f;
   }
+  if constexpr (!WINO) {
 #pragma unroll
-  for (int s = 0; s < 36; ++s) wa2[s] = a.W2[(j * NCH + 4 * (s & 3) + q) * 9 + (s >> 2)];
+    for (int s = 0; s < 36; ++s) wa2[s] = a.W2[(j * NCH + 4 * (s & 3) + q) * 9 + (s >> 2)];
+  } else {
+    // U = G w G^T of W2[o = j][c = 4 g + q], G = [[1,0,0],[.5,.5,.5],[.5,-.5,.5],[0,0,1]]: uw[xi * 4 + g], xi = 4 xi_y + xi_x
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const float* w = a.W2 + (j * NCH + 4 * g + q) * 9;
+      double gw[4][3];
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        const double w0 = w[c], w1 = w[3 + c], w2 = w[6 + c];
+        gw[0][c] = w0; gw[1][c] = 0.5 * (w0 + w1 + w2); gw[2][c] = 0.5 * (w0 - w1 + w2); gw[3][c] = w2;
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        uw[(4 * r + 0) * 4 + g] = (float)gw[r][0];
+        uw[(4 * r + 1) * 4 + g] = (float)(0.5 * (gw[r][0] + gw[r][1] + gw[r][2]));
+        uw[(4 * r + 2) * 4 + g] = (float)(0.5 * (gw[r][0] - gw[r][1] + gw[r][2]));
+        uw[(4 * r + 3) * 4 + g] = (float)gw[r][2];
+      }
+    }
+  }
   f32x4 bias1, bias2, bgv;
 #pragma unroll
   for (int r = 0; r < 4; ++r) { bias1[r] = a.b1[4 * q + r]; bias2[r] = a.b2[4 * q + r]; bgv[r] = a.bg[4 * q + r]; }
@@ -159,6 +211,14 @@ __global__ __launch_bounds__(64 * WAVES, 3) void sparse_crop_k(SparseArgs a) {
     cell = cell < NCELL ? cell : NCELL - 1;
     const int cy = cell / 5, cx = cell - 5 * cy;
     po[k] = q * PL + (2 * cy + ((j >> 1) & 1)) * A1 + 2 * cx + (j & 1);
+  }
+  int wb[2];                      // Winograd: a1_s offset of the 4x4 patch of (cell 16 nt + j, channel slot q)
+#pragma unroll
+  for (int nt = 0; nt < 2; ++nt) {
+    int cell = 16 * nt + j;
+    cell = cell < NCELL ? cell : NCELL - 1;
+    const int cy = cell / 5, cx = cell - 5 * cy;
+    wb[nt] = q * PL + 2 * cy * A1 + 2 * cx;
   }
   const int a1w = 4 * q * PL + j;                              // conv1 D store: channel 4q + r, position 16 nb + j
 
@@ -208,8 +268,56 @@ __global__ __launch_bounds__(64 * WAVES, 3) void sparse_crop_k(SparseArgs a) {
     if (SPLIT) __syncthreads();
     // ---- conv2 + 2x2 max-pool + bias - background -> pd[item][cell][channel]
     float* prow = a.pd + item * KD + 4 * q;
+    if constexpr (WINO) {
 #pragma unroll
-    for (int k = 0; k < N2; ++k) {
+      for (int nt = 0; nt < 2; ++nt) {
+        f32x4 acc[16];
+#pragma unroll
+        for (int xi = 0; xi < 16; ++xi) acc[xi] = f32x4{0.f, 0.f, 0.f, 0.f};
+        acc[5] = bias2;                                          // xi = (1,1) reaches all four outputs with weight +1
+        const float* pb = a1_s + wb[nt];
+        f32x2 plo[4], phi[4];
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+          plo[rr] = *reinterpret_cast<const f32x2*>(pb + rr * A1);
+          phi[rr] = *reinterpret_cast<const f32x2*>(pb + rr * A1 + 2);
+        }
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          float vv[16];
+          wino_in(plo, phi, vv);
+          if (g < 3) {                                           // the next channel step's patch: in flight under the MFMAs
+            const float* p = pb + 4 * (g + 1) * PL;
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) {
+              plo[rr] = *reinterpret_cast<const f32x2*>(p + rr * A1);
+              phi[rr] = *reinterpret_cast<const f32x2*>(p + rr * A1 + 2);
+            }
+          }
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int xi = 0; xi < 16; ++xi) acc[xi] = mfma(uw[xi * 4 + g], vv[xi], acc[xi]);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        f32x4 v;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {                            // A^T M A, A^T = [[1,1,1,0],[0,1,-1,-1]]; pool
+          float s0[4], s1[4];
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            s0[c] = acc[c][r] + acc[4 + c][r] + acc[8 + c][r];
+            s1[c] = acc[4 + c][r] - acc[8 + c][r] - acc[12 + c][r];
+          }
+          const float y00 = s0[0] + s0[1] + s0[2], y01 = s0[1] - s0[2] - s0[3];
+          const float y10 = s1[0] + s1[1] + s1[2], y11 = s1[1] - s1[2] - s1[3];
+          v[r] = fmaxf(fmaxf(y00, y01), fmaxf(y10, y11)) - bgv[r];
+        }
+        const int cell = 16 * nt + j;
+        if (cell < NCELL) *reinterpret_cast<f32x4*>(prow + cell * NCH) = v;
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < (WINO ? 0 : N2); ++k) {
       if (!SPLIT || k < n2) {
         f32x4 d0 = {0.f, 0.f, 0.f, 0.f}, d1 = d0;              // two chains: consecutive MFMAs are independent
         const float* bp = a1_s + po[k];
@@ -645,7 +753,8 @@ static void sparse_crop_launch(const SparseArgs& a, hipStream_t s) {
     return;
   }
   int64_t grid = (a.items + WAVES - 1) / WAVES;
-  if (grid > 256 * 3) grid = 256 * 3;
+  const int per_cu = a.arg ? 3 : 2;                              // (Winograd inference form: 64 + 64 registers of U' and M)
+  if (grid > 256 * per_cu) grid = 256 * per_cu;
   if (a.arg) hipLaunchKernelGGL((sparse_crop_k<true, false>), dim3((unsigned)grid), dim3(64 * WAVES), lds, s, a);
   else hipLaunchKernelGGL((sparse_crop_k<false, false>), dim3((unsigned)grid), dim3(64 * WAVES), lds, s, a);
 }
