@@ -320,7 +320,7 @@ def main():
     # (iii) the same full step after the DAG phase: post_process() froze a binary A and the gate is deterministic, so
     # the embedding net runs on the sparse crop kernels.  Fresh flow: A leaves the optimiser state.
     from gnf_hip import dp as _dp
-    t_det, det_error = None, None
+    t_det, det_error, t_evaldet = None, None, None
     try:                                   # a secondary figure must not take the headline down with it
         if not secondary:
             raise RuntimeError("skipped (--no-secondary)")
@@ -339,11 +339,22 @@ def main():
         t_det = timed(frozen, 10)
         if not all(c._sparse_checked[1] for c in flow_det.getConditioners()):
             raise RuntimeError("frozen-gate step did not run on the sparse embedding kernels")
+
+        # (iii') the evaluation path on that flow: no_grad, nb_steps = 150, sparse front in its evaluation form
+        def eval_det(_):
+            for nrm in flow_det.getNormalizers():
+                nrm.nb_steps = 150
+            with torch.no_grad():
+                z, ld = flow_det(x)
+                return flow_det.z_log_density(z) + ld
+        eval_det(0)
+        t_evaldet = timed(eval_det, 10)
     except Exception as exc:               # noqa: BLE001
         t_det, det_error = None, repr(exc)
     # max over ranks of every timing (a missing secondary figure travels as -1); replicas must have stayed identical:
     # compare an order-independent bit checksum of the flat parameter buffer across ranks
-    tmax = torch.tensor([dt, t_fb or -1., t_mix or -1., t_det or -1., allreduce_ms or -1., t_eval or -1.], dtype=torch.float64)
+    tmax = torch.tensor([dt, t_fb or -1., t_mix or -1., t_det or -1., allreduce_ms or -1., t_eval or -1., t_evaldet or -1.],
+                        dtype=torch.float64)
     replicas_identical = dp.replicas_identical(state, flow)
     per_rank_ms = [dt / args.steps * 1e3]
     if collective:
@@ -355,7 +366,7 @@ def main():
         tmax = tmax.to(cdev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         tmax = tmax.cpu()
-    dt, t_fb, t_mix, t_det, allreduce_ms, t_eval = [v if v > 0 else None for v in tmax.tolist()]
+    dt, t_fb, t_mix, t_det, allreduce_ms, t_eval, t_evaldet = [v if v > 0 else None for v in tmax.tolist()]
     if not replicas_identical:
         raise SystemExit("data-parallel replicas diverged (parameter checksums differ across ranks)")
 
@@ -471,6 +482,8 @@ def main():
                             "full_step_frozen_deterministic_gate_samples_per_s":
                                 round(b_rank * world / t_det, 1) if t_det else None,
                             "eval_forward_S150_samples_per_s": round(b_rank * world / t_eval, 1) if t_eval else None,
+                            "eval_forward_S150_frozen_gate_samples_per_s":
+                                round(b_rank * world / t_evaldet, 1) if t_evaldet else None,
                             "frozen_gate_error": det_error,
                             "note": "10 steps each, wall clock between barriers, max over ranks"}
         out["measured_peaks"] = measured_peaks(dev)

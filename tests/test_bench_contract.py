@@ -82,6 +82,7 @@ def test_round5_evidence_hygiene_items():
     src = open(os.path.join(ROOT, "bench.py")).read()
     assert "CPU_B = 8" in src and "threads_sweep_samples_per_s" in src
     assert "eval_forward_S150_samples_per_s" in src and "nrm.nb_steps = 150" in src and "torch.no_grad()" in src
+    assert "eval_forward_S150_frozen_gate_samples_per_s" in src      # the same path after post_process() (sparse front, evaluation form)
     readme = open(os.path.join(ROOT, "profiles", "README.md")).read()
     assert "re-measured in the same call (fc1 GEMMs: 2.07-2.12 GHz" not in readme
     # round 5: the plan-variant entry points are reported under the names of the calls they replace
