@@ -52,3 +52,12 @@ def test_random_flows_logdet_equals_jacobian_and_invert_round_trips():
     res = fuzz_flow.walk(40, 1)
     bad = [(case, desc, why) for case, desc, e1, e2, why in res if why]
     assert not bad, bad
+
+
+def test_dag_gate_random_modes_and_sizes():
+    """every importance form x gate form of the DAG gate with injected noise, dimensions that are no multiple of 4, one-hot
+    columns, sparse and dense A, against the oracle's masked inputs and their autograd (tests/fuzz_gate.py)"""
+    import fuzz_gate
+    res = fuzz_gate.walk(80, 1)
+    bad = [(case, desc, why) for case, desc, errs, why in res if why]
+    assert not bad, bad
