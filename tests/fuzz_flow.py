@@ -3,7 +3,7 @@ sizes, checked through properties that need no second implementation --
   * log|det J| returned by the flow == log|det| of the Jacobian assembled from d backward passes of the SAME flow (the forward's
     log-det reduction and the backward's data gradient have to agree with each other through every kernel on the way),
   * invert(forward(x)) == x  (NormalizingFlow.py:98-107, 166-169; exact inverse for any number of steps here),
-  * loss finite, every parameter receives a finite gradient.
+  * the loss equals its definition evaluated in fp64 on the returned z and log-det; every parameter receives a finite gradient.
 python tests/fuzz_flow.py [n] [seed]"""
 import os, sys, random
 import torch
@@ -57,6 +57,14 @@ def one(case, rng):
     loss.backward()
     if not bool(torch.isfinite(loss)):
         bad.append("loss")
+    # the loss against its definition (NormalizingFlow.py:128-146) evaluated in fp64 on the z and log-det the flow returned
+    with torch.no_grad():
+        cl = flow.constraintsLoss()
+        cl = float(cl) if torch.is_tensor(cl) else float(cl)
+        zd, ld = z.detach().double().cpu(), logdet.detach().double().cpu()
+        want = cl - float((ld + (-.5 * zd ** 2 - .5 * 1.8378770664093453).sum(1)).mean())
+    if not abs(float(loss) - want) <= 1e-5 * max(1., abs(want)):
+        bad.append("loss value %.8g vs %.8g" % (float(loss), want))
     for k, p in flow.named_parameters():
         if p.requires_grad and (p.grad is None or not bool(torch.isfinite(p.grad).all())):
             if not (ckind == "dag" and k.endswith(".A")):
