@@ -61,3 +61,13 @@ def test_dag_gate_random_modes_and_sizes():
     res = fuzz_gate.walk(80, 1)
     bad = [(case, desc, why) for case, desc, errs, why in res if why]
     assert not bad, bad
+
+
+def test_rowwise_kernels_random_shapes():
+    """the Affine normalizer (both h layouts, values beyond the clamps), the log-sum of Jacobian rows, the standard-normal
+    log-density and the one-launch loss at random (B, d) incl. odd widths and 4 099 rows, against the oracle / fp64 torch
+    (tests/fuzz_rowwise.py)"""
+    import fuzz_rowwise
+    res = fuzz_rowwise.walk(60, 1)
+    bad = [(case, desc, why) for case, desc, errs, why in res if why]
+    assert not bad, bad
