@@ -63,8 +63,8 @@ def one(case, rng):
         cl = float(cl) if torch.is_tensor(cl) else float(cl)
         zd, ld = z.detach().double().cpu(), logdet.detach().double().cpu()
         want = cl - float((ld + (-.5 * zd ** 2 - .5 * 1.8378770664093453).sum(1)).mean())
-    if not abs(float(loss) - want) <= 1e-5 * max(1., abs(want)):
-        bad.append("loss value %.8g vs %.8g" % (float(loss), want))
+    if not abs(float(loss.detach()) - want) <= 1e-5 * max(1., abs(want)):
+        bad.append("loss value %.8g vs %.8g" % (float(loss.detach()), want))
     for k, p in flow.named_parameters():
         if p.requires_grad and (p.grad is None or not bool(torch.isfinite(p.grad).all())):
             if not (ckind == "dag" and k.endswith(".A")):
