@@ -31,6 +31,7 @@
 //     against the crop and a constant-1 image) on MFMA with
 //     the accumulators in registers across all copies of the wave.  What the constant background contributes (bg
 //     depends on b1, W2, b2) is a closed form of the column sums and is added by a one-workgroup epilogue.
+#include <cstdlib>
 #include "gnf_common.h"
 #include "gnf_gemm.h"
 
@@ -541,6 +542,267 @@ __global__ __launch_bounds__(64, 2) void sparse_crop_bwd_k(SparseBwdArgs a) {
   }
 }
 
+// The same backward with TWO wavefronts per masked copy (round 5).  One wavefront per copy holds 256 registers and 25 KB of LDS:
+// six copies per CU, 1.5 wavefronts per SIMD, and its ~450 MFMAs per copy are one dependent stream (0.61 of the MFMA-bound
+// time).  Here the copy's work is two streams that meet at barriers:
+//   wavefront 0: stage e  | conv1 -> a1, bump F_a1 | wait F_dy | dW2 taps 0..6 (210 MFMAs)                                   | barrier
+//   wavefront 1: stage dY, bump F_dy | d a1 MFMAs of the box (144, need dY only) | wait F_a1 | gates, dW2 taps 7..8, dW1/db1 | barrier
+// (F_a1, F_dy: two LDS counters -- ONE workgroup barrier per copy, at its end, before the images are rewritten)
+// The gated d a1 of the box goes to its own 4 KB buffer (in place it would race with the other wavefront's dW2 reads of a1):
+// 29 KB per copy, five copies = ten wavefronts per CU.  Same arithmetic per accumulator chain: the same bits per copy; the
+// partial rows are summed by the same reduction.
+constexpr int BOXS = NCH * 64;                               // gated d a1 of the 8 x 8 box, [16][64]
+constexpr int BLDS2 = BLDS + BOXS + 4;                      // + two counters
+
+#ifndef GNF_SPARSE_BWD2_T0
+#define GNF_SPARSE_BWD2_T0 7               // 7 + 2 taps: conv1 + 7 taps = 237 MFMAs against d a1 + 2 taps + dW1 + the gates ~ 250
+#endif
+static_assert(GNF_SPARSE_BWD2_T0 >= 5 && GNF_SPARSE_BWD2_T0 <= 8, "role 1 keeps at least one tap and at most four");
+__global__ __launch_bounds__(128, 2) void sparse_crop_bwd2_k(SparseBwdArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), q = lane >> 4, j = lane & 15;
+  float* e_s = smem;
+  float* a1_s = smem + EB;
+  float* dy_s = a1_s + NCH * BPL;
+  float* bx_s = dy_s + NCH * DPL;
+  unsigned* flag = reinterpret_cast<unsigned*>(bx_s + BOXS);      // [0]: copies whose a1 is complete, [1]: copies whose dY is staged
+  if (threadIdx.x < 2) flag[threadIdx.x] = 0u;
+  for (int i = threadIdx.x; i < ESZ; i += 128) e_s[ONES + i] = 1.f;
+  for (int i = threadIdx.x; i < NCH * DPL; i += 128) dy_s[i] = 0.f;
+  for (int i = threadIdx.x; i < NCH * BPL; i += 128) a1_s[i] = 0.f;
+
+  // ---- role 0: conv1 weights, positions;  role 1: W2 as A[c_in][(tap, c_out)], box positions, cotangent scatter offsets.
+  //      The loop constants of the two roles SHARE their registers (a wavefront has one role for its whole life; declared
+  //      apart, the allocator keeps both sets live across the copy loop: 256 registers and scratch):
+  //      wreg: wa1[3] | wf[36];   ireg: pe[9], pao[9], ce[4], cl[4] | dyo[7], pb[4];   freg: xv[4], pv[4] | gv[7], av[7] (as bits)
+  float wreg[36];
+  int ireg[26];
+  float freg[14];
+  f32x4 bias1 = {0.f, 0.f, 0.f, 0.f};
+  int to[3] = {0, 0, 0};
+#define WA1(s_) wreg[s_]
+#define WF(s_) wreg[s_]
+#define PE(n_) ireg[n_]
+#define PAO(n_) ireg[9 + (n_)]
+#define CE(t_) ireg[18 + (t_)]
+#define CL(t_) ireg[22 + (t_)]
+#define DYO(t_) ireg[t_]
+#define PB(n_) ireg[7 + (n_)]
+#define XV(t_) freg[t_]
+#define PV(t_) freg[4 + (t_)]
+#define GV(t_) freg[t_]
+#define AV(t_) __float_as_int(freg[7 + (t_)])
+  if (wave == 0) {
+#pragma unroll
+    for (int s = 0; s < 3; ++s) {
+      const int tap = 4 * s + q, ty = tap < 9 ? tap / 3 : 0, tx = tap < 9 ? tap - 3 * ty : 0;
+      WA1(s) = tap < 9 ? a.W1[j * 9 + tap] : 0.f;
+      to[s] = ty * ES + tx;
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) bias1[r] = a.b1[4 * q + r];
+#pragma unroll
+    for (int nb = 0; nb < 9; ++nb) {
+      const int p = 16 * nb + j, y = p / A1, x = p - A1 * y;
+      PAO(nb) = y * A1S + x;
+      PE(nb) = y * ES + x;
+    }
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int idx = lane + 64 * t, ey = idx / CROP, ex = idx - CROP * ey;
+      CE(t) = ey * IMG + ex;
+      CL(t) = idx < CROP * CROP ? ey * ES + ex : -1;
+    }
+  } else {
+#pragma unroll
+    for (int s = 0; s < 36; ++s) WF(s) = a.W2[((4 * (s & 3) + q) * NCH + j) * 9 + (s >> 2)];
+#pragma unroll
+    for (int t = 0; t < 7; ++t) {
+      const int idx = lane + 64 * t, cell = idx >> 4, c = idx & 15, cy = cell / 5, cx = cell - 5 * cy;
+      DYO(t) = idx < KD ? c * DPL + (2 * cy + 2) * A1S + 2 * cx + 2 : -1;
+    }
+#pragma unroll
+    for (int nb = 0; nb < 4; ++nb) PB(nb) = (2 * nb + (j >> 3)) * A1S + (j & 7);
+  }
+  const int eb = j < 9 ? (j / 3) * ES + j % 3 + q : (j == 9 ? ONES + q : q);   // dW1 B operand: tap j | ones (db1) | unused
+
+  constexpr int T0 = GNF_SPARSE_BWD2_T0;     // dW2 taps of role 0 (0 .. T0-1); role 1 takes T0 .. 8 in acc2[0 .. 8-T0]
+  f32x4 acc2[T0], acc1a = {0.f, 0.f, 0.f, 0.f}, acc1b = acc1a, dsum = acc1a;
+#pragma unroll
+  for (int t = 0; t < T0; ++t) acc2[t] = acc1a;
+
+  auto fetch = [&](int64_t item) {
+    if (wave == 0) {
+      const int64_t r = item / a.B, b = item - r * a.B;
+      const int pix = a.pix[r];
+      const int corner = 2 * crop_origin(pix / IMG) * IMG + 2 * crop_origin(pix % IMG);
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const bool ok = CL(t) >= 0;
+        XV(t) = ok ? a.x[b * NPIX + corner + CE(t)] : 0.f;
+        PV(t) = ok ? a.P[(int64_t)pix * NPIX + corner + CE(t)] : 0.f;
+      }
+    } else {
+#pragma unroll
+      for (int t = 0; t < 7; ++t) {
+        const bool ok = DYO(t) >= 0;
+        GV(t) = ok ? a.dpd[item * KD + lane + 64 * t] : 0.f;
+        freg[7 + t] = __int_as_float(ok ? (int)a.arg[item * KD + lane + 64 * t] : 0);
+      }
+    }
+  };
+  __syncthreads();                                               // the constant images exist
+
+  int64_t item = blockIdx.x;
+  unsigned nth = 0;
+  if (item < a.items) fetch(item);
+  for (; item < a.items; item += gridDim.x) {
+    if (wave == 0) {
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+        if (CL(t) >= 0) e_s[CL(t)] = XV(t) * PV(t);
+    } else {
+#pragma unroll
+      for (int t = 0; t < 7; ++t)
+        if (DYO(t) >= 0) {
+          f32x2 r0, r1;
+          r0.x = AV(t) == 0 ? GV(t) : 0.f; r0.y = AV(t) == 1 ? GV(t) : 0.f;
+          r1.x = AV(t) == 2 ? GV(t) : 0.f; r1.y = AV(t) == 3 ? GV(t) : 0.f;
+          *reinterpret_cast<f32x2*>(dy_s + DYO(t)) = r0;
+          *reinterpret_cast<f32x2*>(dy_s + DYO(t) + A1S) = r1;
+        }
+    }
+    if (item + gridDim.x < a.items) fetch(item + gridDim.x);
+    int boxo, boxe;
+    {
+      const int pix = __builtin_amdgcn_readfirstlane(a.pix[item / a.B]);
+      const int yi = pix / IMG, xi = pix - IMG * yi;
+      int oy = yi - 4 - 2 * crop_origin(yi), ox = xi - 4 - 2 * crop_origin(xi);
+      oy = oy < 0 ? 0 : (oy > 4 ? 4 : oy);
+      ox = ox < 0 ? 0 : (ox > 4 ? 4 : ox);
+      boxo = oy * A1S + ox;
+      boxe = oy * ES + ox;
+    }
+    ++nth;                                                       // this copy's ordinal: what the two flags count up to
+    if (wave == 1 && lane == 0) __hip_atomic_fetch_add(flag + 1, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);   // dY staged
+    if (wave == 0) {
+      // ---- conv1 + ReLU (recomputed) -> a1_s
+#pragma unroll
+      for (int nb = 0; nb < 9; ++nb) {
+        f32x4 d = bias1;
+#pragma unroll
+        for (int s = 0; s < 3; ++s) d = mfma(WA1(s), e_s[PE(nb) + to[s]], d);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) a1_s[(4 * q + r) * BPL + PAO(nb)] = fmaxf(d[r], 0.f);
+      }
+    } else {
+      // ---- d a1[c_in][pos] = sum_{c_out,tap} W2[c_out][c_in][tap] dY2[c_out][pos - tap] on the 8 x 8 box (dY only)
+#pragma unroll
+      for (int nb = 0; nb < 4; ++nb) {
+        f32x4 d0 = {0.f, 0.f, 0.f, 0.f}, d1 = d0;
+        const float* bp = dy_s + q * DPL + boxo + PB(nb) + 2 * A1S + 2;
+#pragma unroll
+        for (int s = 0; s < 36; s += 2) {
+          const int t0 = s >> 2, t1 = (s + 1) >> 2;
+          d0 = mfma(WF(s), bp[4 * (s & 3) * DPL - (t0 / 3) * A1S - t0 % 3], d0);
+          d1 = mfma(WF(s + 1), bp[4 * ((s + 1) & 3) * DPL - (t1 / 3) * A1S - t1 % 3], d1);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {                            // ungated for now: a1 of this copy is still being written
+          const float v = d0[r] + d1[r];
+          dsum[r] += v;
+          bx_s[(4 * q + r) * 64 + 16 * nb + j] = v;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    // a1 complete (role 0 says so, role 1 waits before it reads the gates); dY staged (the other way round, before dW2).
+    // No workgroup barrier here: role 0 goes from its own conv1 straight into its dW2 taps while role 1 is in its 144 MFMAs
+    // (LDS executes a wavefront's operations in order, so the counter bump lands behind the writes it announces).
+    if (wave == 0) {
+      if (lane == 0) __hip_atomic_fetch_add(flag, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+      while (__hip_atomic_load(flag + 1, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < nth) __builtin_amdgcn_s_sleep(1);
+    } else {
+      while (__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < nth) __builtin_amdgcn_s_sleep(1);
+    }
+    // ---- dW2[c_out][c_in][tap] += sum_pos dY2[c_out][pos] a1[c_in][pos + tap]: taps 0..T0-1 (role 0), T0..8 (role 1)
+    {
+      const float* ap = dy_s + j * DPL + 2 * A1S + 2 + q;
+      const float* bp = a1_s + j * BPL + q;
+      if (wave == 0) {
+#pragma unroll
+        for (int s = 0; s < 30; ++s) {
+          const int o = (s / 3) * A1S + 4 * (s % 3);
+          const float av2 = ap[o];
+#pragma unroll
+          for (int t = 0; t < T0; ++t) acc2[t] = mfma(av2, bp[o + (t / 3) * A1S + t % 3], acc2[t]);
+          if (s % 3 == 2) __builtin_amdgcn_sched_barrier(0);
+        }
+      } else {
+        // the gates first: d a1 of the box, gated by a1 > 0, into the box buffer [c][16 nb + j]
+#pragma unroll
+        for (int nb = 0; nb < 4; ++nb)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {                          // (this lane wrote the entry itself: no barrier in between)
+            float* g = bx_s + (4 * q + r) * 64 + 16 * nb + j;
+            *g = a1_s[(4 * q + r) * BPL + boxo + PB(nb)] > 0.f ? *g : 0.f;
+          }
+#pragma unroll
+        for (int s = 0; s < 30; ++s) {
+          const int o = (s / 3) * A1S + 4 * (s % 3);
+          const float av2 = ap[o];
+#pragma unroll
+          for (int t = T0; t < 9; ++t) acc2[t - T0] = mfma(av2, bp[o + (t / 3) * A1S + t % 3], acc2[t - T0]);
+          if (s % 3 == 2) __builtin_amdgcn_sched_barrier(0);
+        }
+        // ---- dW1[c][tap] += sum_box da1[c][pos] e[pos + tap];  db1[c] += sum_box da1[c][pos]  (column 9: constant 1)
+        //      box position of K-step s, slot q: row s / 2, column 4 (s % 2) + q  ->  buffer index 8 (s / 2) + 4 (s % 2) + q
+        const float* apb = bx_s + j * 64 + q;
+        const float* bpe = e_s + boxe + eb;
+#pragma unroll
+        for (int s = 0; s < 16; s += 2) {
+          acc1a = mfma(apb[8 * (s / 2) + 4 * (s % 2)], bpe[(s / 2) * ES + 4 * (s % 2)], acc1a);
+          acc1b = mfma(apb[8 * ((s + 1) / 2) + 4 * ((s + 1) % 2)], bpe[((s + 1) / 2) * ES + 4 * ((s + 1) % 2)], acc1b);
+        }
+      }
+    }
+    __syncthreads();                                             // B3: both roles are done with this copy's images
+  }
+
+  float* prow = a.part + (int64_t)blockIdx.x * PROW;
+  if (wave == 0) {
+#pragma unroll
+    for (int t = 0; t < T0; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) prow[((4 * q + r) * NCH + j) * 9 + t] = acc2[t][r];
+  } else {
+#pragma unroll
+    for (int t = T0; t < 9; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) prow[((4 * q + r) * NCH + j) * 9 + t] = acc2[t - T0][r];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float v = acc1a[r] + acc1b[r];
+      if (j < 9) prow[NCH * NCH * 9 + (4 * q + r) * 9 + j] = v;
+      else if (j == 9) prow[NCH * NCH * 9 + NCH * 9 + 4 * q + r] = v;
+      const float ds = group_sum<16>(dsum[r]);
+      if (j == 0) prow[NCH * NCH * 9 + NCH * 9 + NCH + 4 * q + r] = ds;
+    }
+  }
+}
+#undef WA1
+#undef WF
+#undef PE
+#undef PAO
+#undef CE
+#undef CL
+#undef DYO
+#undef PB
+#undef XV
+#undef PV
+#undef GV
+#undef AV
+
 // gWfc1[n][c*144 + py*12 + px] = bg[c] S[n] + sum over the <= 25 crop origins whose 5x5 block holds cell (py, px), each
 // origin's gradient being the sum of its K chunks (oc[2g], oc[2g+1] = first chunk, number of chunks of origin g)
 __global__ void sparse_scatter_fc1_k(const float* __restrict__ dWg, const int32_t* __restrict__ oc,
@@ -929,21 +1191,29 @@ int gnf_mnistcnn_sparse_bwd(const float* x, int64_t B, const float* P, const int
   SparseBwdArgs a{x, P, pix, W1, b1, W2, dpd, argmax, part, B, items};
   // exactly one resident wave of workgroups: a second, partial wave would idle most of the chip (every workgroup
   // walks the same number of copies)
+  static const bool two = [] { const char* e = getenv("GNF_SPARSE_BWD2"); return !(e && e[0] == '0'); }();   // A/B: 0 = one wavefront per copy
   static int per_cu = 0, n_cu = 0;
   if (!per_cu) {
     int dev = 0, nb = 0;
     hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess ||
-        hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, sparse_crop_bwd_k, 64, BLDS * sizeof(float)) != hipSuccess ||
-        nb < 1)
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return GNF_EINVAL;
+    if (two) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sparse_crop_bwd2_k), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)(BLDS2 * sizeof(float)));
+      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, sparse_crop_bwd2_k, 128, BLDS2 * sizeof(float)) != hipSuccess || nb < 1)
+        return GNF_EINVAL;
+    } else if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, sparse_crop_bwd_k, 64, BLDS * sizeof(float)) != hipSuccess ||
+               nb < 1) {
       return GNF_EINVAL;
+    }
     n_cu = prop.multiProcessorCount;
     per_cu = nb;
   }
   int64_t grid = (int64_t)per_cu * n_cu;
   if (grid > BWD_GRID) grid = BWD_GRID;
   if (grid > items) grid = items;
-  hipLaunchKernelGGL(sparse_crop_bwd_k, dim3((unsigned)grid), dim3(64), BLDS * sizeof(float), s, a);
+  if (two) hipLaunchKernelGGL(sparse_crop_bwd2_k, dim3((unsigned)grid), dim3(128), BLDS2 * sizeof(float), s, a);
+  else hipLaunchKernelGGL(sparse_crop_bwd_k, dim3((unsigned)grid), dim3(64), BLDS * sizeof(float), s, a);
   GNF_LAUNCH_CHECK();
   if ((rc = gnf_rowsum_launch(part, red, grid, PROW, 0, s))) return rc;
   hipLaunchKernelGGL(sparse_finish_k, dim3(1), dim3(1024), 0, s, red, gbfc1, T, Wfc1, b1, W2, (int)F, gW1, gb1, gW2, gb2);

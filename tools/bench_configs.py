@@ -10,6 +10,9 @@ import torch
 import os
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, ROOT + '/graphical-normalizing-flows_amd']
+if os.environ.get('GNF_AB_LIB'):                      # A/B against another build of the library (tools/*.bin)
+    from gnf_hip import abi as _abi
+    _abi.LIB_PATH = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), os.environ['GNF_AB_LIB'])
 from gnf_hip import abi  # noqa: E402
 from _warm import warm_gpu  # noqa: E402
 from models import MonotonicNormalizer  # noqa: E402
