@@ -71,3 +71,13 @@ def test_rowwise_kernels_random_shapes():
     res = fuzz_rowwise.walk(60, 1)
     bad = [(case, desc, why) for case, desc, errs, why in res if why]
     assert not bad, bad
+
+
+def test_sparse_front_training_gradients_random_rows():
+    """the training path of the sparse front (argmax record, grouped fc1 GEMMs, two-wavefront crop backward, closed-form
+    background terms) against the dense kernels' gradients on random row subsets / batch sizes; copies with a pool window or
+    a ReLU (conv1, fc1) on the knife edge get a zero cotangent when a first comparison fails (tests/fuzz_sparse_grad.py)"""
+    import fuzz_sparse_grad
+    res = fuzz_sparse_grad.walk(20, 1)
+    bad = [(case, desc, why) for case, desc, errs, why in res if why]
+    assert not bad, bad
