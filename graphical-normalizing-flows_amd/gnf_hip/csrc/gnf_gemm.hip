@@ -849,7 +849,11 @@ int gnf_gemm_grouped_launch(GemmArgs g, int ngroups, hipStream_t s) {
     g.k_per_split = (g.K + BKV - 1) / BKV * BKV;
     g.c_split_stride = 0;
   }
-  const int bt = g.M >= 1024 || g.grp_k ? 128 : 64;
+  // 128 x 128 tiles only where they tile the problem without padding: the column count (row groups: the row counts sit in the
+  // device table) or both extents (K groups) a multiple of 128.  The sparse front's d pd = g Wg^T (N = 400) and dWg = pd^T g
+  // (M = 400) pad 400 to 512 with 128-wide tiles and to 448 with 64-wide ones, on top of every group's own ragged last row
+  // tile: 2.683 -> 2.635 ms per frozen-gate step (profiles/r05_sparse_bwd2.txt); the forward (N = 128) keeps the large tiles.
+  const int bt = g.grp_k ? ((g.M % 128 == 0 && g.N % 128 == 0) ? 128 : 64) : ((g.M >= 1024 && g.N % 128 == 0) ? 128 : 64);
   const dim3 grid((unsigned)((g.M + bt - 1) / bt), (unsigned)((g.N + bt - 1) / bt), (unsigned)ngroups);
 #define GNF_GRP_LAUNCH(BT)                                                                              \
   do {                                                                                                  \
