@@ -21,7 +21,7 @@ c_stream = ctypes.c_void_p
 
 MONO_MAX_LAYERS = 8
 DAG_PLAN_KC = 32          # GNF_DAG_PLAN_KC
-ABI_VERSION = 6           # GNF_ABI_VERSION of include/gnf_hip.h this binding was written against
+ABI_VERSION = 7           # GNF_ABI_VERSION of include/gnf_hip.h this binding was written against
 
 
 class MonoNet(ctypes.Structure):
@@ -110,6 +110,10 @@ SIGNATURES = {
                                         ctypes.c_void_p, c_i64, ctypes.c_void_p, c_f, c_f, c_f,
                                         c_f, c_f, c_i64, c_f, ctypes.c_void_p, c_f, c_f, c_f, c_f, c_f, c_f, c_f,
                                         ctypes.c_void_p, c_i64, c_stream]),
+    "gnf_mnistcnn_sparse_bwd_tables": (c_int, [c_f, c_i64, c_f, ctypes.c_void_p, c_i64, ctypes.c_void_p, c_i64,
+                                               ctypes.c_void_p, c_i64, ctypes.c_void_p, c_f, c_f, c_f,
+                                               c_f, c_f, c_i64, ctypes.c_void_p, c_f, ctypes.c_void_p, c_f, c_f, c_f, c_f, c_f, c_f, c_f,
+                                               ctypes.c_void_p, c_i64, c_stream]),
     "gnf_adam_step": (c_int, [c_f, c_f, c_f, c_f, c_i64, c_double, c_double, c_double, c_double, c_double, c_double, c_int,
                               c_stream]),
     "gnf_adam_step_dev": (c_int, [c_f, c_f, c_f, c_f, c_i64, c_double, c_double, c_double, c_double, c_double, c_double,

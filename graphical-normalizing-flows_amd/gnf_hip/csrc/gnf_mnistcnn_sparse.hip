@@ -1135,6 +1135,18 @@ int gnf_mnistcnn_sparse_bwd(const float* x, int64_t B, const float* P, const int
                             const float* pd, const unsigned char* argmax, const float* g_h1,
                             float* gW1, float* gb1, float* gW2, float* gb2, float* gWfc1, float* gbfc1,
                             void* ws, int64_t ws_bytes, gnf_stream_t stream) {
+  return gnf_mnistcnn_sparse_bwd_tables(x, B, P, pix, R, groups, max_group_rows, kgroups, n_kgroups, origin_chunks, W1, b1, W2, b2,
+                                        Wfc1, F, nullptr, pd, argmax, g_h1, gW1, gb1, gW2, gb2, gWfc1, gbfc1, ws, ws_bytes, stream);
+}
+
+int gnf_mnistcnn_sparse_bwd_tables(const float* x, int64_t B, const float* P, const int32_t* pix, int64_t R,
+                                   const int32_t* groups, int64_t max_group_rows,
+                                   const int32_t* kgroups, int64_t n_kgroups, const int32_t* origin_chunks,
+                                   const float* W1, const float* b1, const float* W2, const float* b2,
+                                   const float* Wfc1, int64_t F, const void* tables,
+                                   const float* pd, const unsigned char* argmax, const float* g_h1,
+                                   float* gW1, float* gb1, float* gW2, float* gb2, float* gWfc1, float* gbfc1,
+                                   void* ws, int64_t ws_bytes, gnf_stream_t stream) {
   if (n_kgroups < 0 || n_kgroups > 65535) return GNF_EINVAL;
   if (!W1 || !b1 || !W2 || !b2 || !Wfc1 || !gW1 || !gb1 || !gW2 || !gb2 || !gWfc1 || !gbfc1 || B < 0 || R < 0 || F <= 0)
     return GNF_EINVAL;
@@ -1162,11 +1174,16 @@ int gnf_mnistcnn_sparse_bwd(const float* x, int64_t B, const float* P, const int
   float* rws = red + PROW;                              // two-level column-sum scratch
   int rc;
 
-  hipLaunchKernelGGL(sparse_bg_k, dim3(1), dim3(64), 0, s, b1, W2, b2, (const float*)nullptr, (const float*)nullptr, (int)F,
-                     bg, (float*)nullptr);
-  GNF_LAUNCH_CHECK();
-  hipLaunchKernelGGL(sparse_gather_fc1_k, dim3(2048), dim3(256), 0, s, Wfc1, (int)F, Wg);
-  GNF_LAUNCH_CHECK();
+  if (tables) {                       // the forward's tables (same parameters): fc1 column blocks and the background response
+    Wg = const_cast<float*>(static_cast<const float*>(tables));
+    bg = Wg + (int64_t)NORIG * KD * F;
+  } else {
+    hipLaunchKernelGGL(sparse_bg_k, dim3(1), dim3(64), 0, s, b1, W2, b2, (const float*)nullptr, (const float*)nullptr, (int)F,
+                       bg, (float*)nullptr);
+    GNF_LAUNCH_CHECK();
+    hipLaunchKernelGGL(sparse_gather_fc1_k, dim3(2048), dim3(256), 0, s, Wfc1, (int)F, Wg);
+    GNF_LAUNCH_CHECK();
+  }
   if ((rc = gnf_rowsum_tall_launch(g_h1, gbfc1, items, F, 0, rws, s))) return rc;           // S = d bfc1
 
   GemmArgs g{};                                         // d pd = g . Wg[origin]^T

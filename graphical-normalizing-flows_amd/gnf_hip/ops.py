@@ -480,6 +480,9 @@ class SparseRows:
         self.origin_chunks = torch.tensor(per_origin, dtype=torch.int32, device=device)
 
 
+SPARSE_REUSE_TABLES = True     # the sparse front's backward reads the tables its forward built (False: builds them again; tests)
+
+
 class MnistSparseFn(torch.autograd.Function):
     """relu(fc1(flatten(maxpool(conv2(relu(conv1(x * P[i]))))))) for the masked copies i of a SparseRows, P zero outside
     the 5x5 pixel windows: [R*B, F] in the SparseRows' sorted order (row = position * B + sample).  Differentiable w.r.t.
@@ -508,13 +511,16 @@ class MnistSparseFn(torch.autograd.Function):
         pd = _empty((n, 400), x) if train else None
         arg = torch.empty((n, 400), dtype=torch.uint8, device=x.device) if train else None
         nws = abi.load().gnf_mnistcnn_sparse_ws_bytes(n, F)
-        ws = _ws(nws, x)
+        # training: the workspace is this call's own and stays alive for the backward, which reads the parameter-only tables
+        # (fc1 column blocks per crop origin, background response) the forward built in its tail instead of building them again
+        ws = torch.empty(max(int(nws) // 4, 1), dtype=torch.float32, device=x.device) if train else _ws(nws, x)
         call("gnf_mnistcnn_sparse_fwd", ptr(x), sr.B, ptr(P), abi.rawptr(sr.pix), sr.R, abi.rawptr(sr.groups),
              sr.max_group_rows, *[ptr(t) for t in ws_], F, ptr(h1), ptr(pd), abi.rawptr(arg) if train else None,
              abi.rawptr(ws), nws, stream())
         if train:
             ctx.save_for_backward(x, P, *ws_[:5], pd, arg, h1)
             ctx.sr = sr
+            ctx.tables = ws[n * 400:] if SPARSE_REUSE_TABLES else None
         return h1
 
     @staticmethod
@@ -528,9 +534,12 @@ class MnistSparseFn(torch.autograd.Function):
         gWf, gbf = grad_out(Wfc1), _empty((F,), x)
         nws = abi.load().gnf_mnistcnn_sparse_bwd_ws_bytes(n, F, sr.n_kgroups)
         ws = _ws(nws, x)
-        call("gnf_mnistcnn_sparse_bwd", ptr(x), sr.B, ptr(P), abi.rawptr(sr.pix), sr.R, abi.rawptr(sr.groups),
-             sr.max_group_rows, abi.rawptr(sr.kgroups), sr.n_kgroups, abi.rawptr(sr.origin_chunks), ptr(W1), ptr(b1), ptr(W2), ptr(b2), ptr(Wfc1), F, ptr(pd), abi.rawptr(arg), ptr(g),
+        tables = getattr(ctx, "tables", None)
+        call("gnf_mnistcnn_sparse_bwd_tables", ptr(x), sr.B, ptr(P), abi.rawptr(sr.pix), sr.R, abi.rawptr(sr.groups),
+             sr.max_group_rows, abi.rawptr(sr.kgroups), sr.n_kgroups, abi.rawptr(sr.origin_chunks), ptr(W1), ptr(b1), ptr(W2),
+             ptr(b2), ptr(Wfc1), F, abi.rawptr(tables) if tables is not None else None, ptr(pd), abi.rawptr(arg), ptr(g),
              ptr(gW1), ptr(gb1), ptr(gW2), ptr(gb2), ptr(gWf), ptr(gbf), abi.rawptr(ws), nws, stream())
+        ctx.tables = None
         return None, None, None, None, gW1, gb1, gW2, gb2, gWf, gbf, None, None
 
 

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define GNF_ABI_VERSION 6
+#define GNF_ABI_VERSION 7
 #define GNF_EINVAL (-1)   /* bad argument (null pointer, negative size, ...)          */
 #define GNF_ESHAPE (-2)   /* shape not supported by any compiled kernel instantiation */
 #define GNF_EWS    (-3)   /* workspace too small                                      */
@@ -355,6 +355,17 @@ int gnf_mnistcnn_sparse_fwd_prepared_fc2(const float* x, int64_t B, const float*
  *   kgroups [2*n_kgroups] (device): (first output row, row count) of each chunk, a chunk lying inside one origin's
  *   rows, the chunks of an origin consecutive;  origin_chunks [2*64] (device): (first chunk, number of chunks). */
 int64_t gnf_mnistcnn_sparse_bwd_ws_bytes(int64_t n_rows, int64_t F, int64_t n_kgroups);
+/* gnf_mnistcnn_sparse_bwd against the parameter-only tables the FORWARD of the same step built (tables = the forward's
+ * `(float*)ws + R*B*400`, or a gnf_mnistcnn_sparse_prepare buffer: fc1 column blocks per crop origin | background response): the
+ * two table launches (~30 us of a 2.6 ms frozen-gate step) run once per step instead of twice.  tables == NULL: builds them. */
+int gnf_mnistcnn_sparse_bwd_tables(const float* x, int64_t B, const float* P, const int32_t* pix, int64_t R,
+                                   const int32_t* groups, int64_t max_group_rows,
+                                   const int32_t* kgroups, int64_t n_kgroups, const int32_t* origin_chunks,
+                                   const float* W1, const float* b1, const float* W2, const float* b2,
+                                   const float* Wfc1, int64_t F, const void* tables,
+                                   const float* pd, const unsigned char* argmax, const float* g_h1,
+                                   float* gW1, float* gb1, float* gW2, float* gb2, float* gWfc1, float* gbfc1,
+                                   void* ws, int64_t ws_bytes, gnf_stream_t stream);
 int gnf_mnistcnn_sparse_bwd(const float* x, int64_t B, const float* P, const int32_t* pix, int64_t R,
                             const int32_t* groups, int64_t max_group_rows,
                             const int32_t* kgroups, int64_t n_kgroups, const int32_t* origin_chunks,

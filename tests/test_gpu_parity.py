@@ -1686,6 +1686,27 @@ def test_monotonic_inverse_scattered_result(hidden, R, B):
     assert torch.equal(got, want)
 
 
+def test_sparse_front_backward_reuses_the_forwards_tables():
+    """gnf_mnistcnn_sparse_bwd_tables against the tables the forward built == gnf_mnistcnn_sparse_bwd building them again,
+    bit for bit (same parameters, same kernels: only two launches fewer)"""
+    from gnf_hip import ops
+    cond = _windowed_conditioner(5, True)
+    x = cu(torch.rand(3, 784))
+    gh = cu(torch.randn(3, 784, 30))
+    out = []
+    for reuse in (True, False):
+        ops.SPARSE_REUSE_TABLES = reuse
+        try:
+            for p in cond.embedding_net.parameters():
+                p.grad = None
+            (cond(x) * gh).sum().backward()
+        finally:
+            ops.SPARSE_REUSE_TABLES = True
+        out.append([p.grad.clone() for p in cond.embedding_net.parameters()])
+    for a, b in zip(*out):
+        assert torch.equal(a, b)
+
+
 def test_sparse_front_abi_validation():
     import ctypes
     from gnf_hip import abi

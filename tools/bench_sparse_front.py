@@ -60,7 +60,7 @@ def main():
             p.grad = None
         (cond(x) * gh).sum().backward()
     out["sparse_fwd_bwd_ms"] = timed(step)
-    abi.profile_enable(["gnf_mnistcnn_sparse_fwd", "gnf_mnistcnn_sparse_bwd"])
+    abi.profile_enable(["gnf_mnistcnn_sparse_fwd", "gnf_mnistcnn_sparse_bwd", "gnf_mnistcnn_sparse_bwd_tables"])
     step()
     out["sparse_train_entry_ms"] = {k: round(v, 4) for k, v in abi.profile_collect().items()}
     cond.sparse_front = False
