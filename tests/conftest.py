@@ -82,9 +82,9 @@ EPS32 = float(torch.finfo(torch.float32).eps)
 
 def conv_front_knife_images(e, W1, b1, W2, b2, ulps=16.):
     """[n] bool: images of the MNISTCNN conv front (MLP.py:36-41) holding a decision within `ulps` fp32 ulps OF ITS TERMS'
-    MAGNITUDE of a tie in an fp64 evaluation: a conv1 pre-activation near 0, or a pool window whose two largest conv2
-    outputs are closer than that without being exactly equal (exact ties -- constant image regions -- are decided by the
-    first-maximum rule on both sides).  Also returns the per-image counts (relu, pool)."""
+    MAGNITUDE of a tie in an fp64 evaluation: a conv1 pre-activation near 0, or a pool window in which some conv2 output is
+    closer than that to the maximum without being exactly equal to it (exact ties -- constant image regions -- are decided by
+    the first-maximum rule on both sides).  Also returns the per-image counts (relu, pool)."""
     import torch.nn.functional as F
     e, W1, b1, W2, b2 = [t.detach().cpu().double() for t in (e, W1, b1, W2, b2)]
     img = e.view(-1, 1, 28, 28)
@@ -97,9 +97,11 @@ def conv_front_knife_images(e, W1, b1, W2, b2, ulps=16.):
     n = e.shape[0]
     win = c2.view(n, 16, 12, 2, 12, 2).permute(0, 1, 2, 4, 3, 5).reshape(n, 2304, 4)
     wmag = mag2.view(n, 16, 12, 2, 12, 2).permute(0, 1, 2, 4, 3, 5).reshape(n, 2304, 4).amax(2)
-    top = win.sort(dim=2, descending=True).values
-    gap = top[:, :, 0] - top[:, :, 1]
-    pool_k = (gap < ulps * EPS32 * wmag) & (gap != 0)
+    # ANY entry within the bound of the maximum without being equal to it (not only the runner-up: with an exact tie of two
+    # entries at the top, a third one 1e-8 below is rounded onto them by one fp32 evaluation order and not by another --
+    # found by tests/fuzz_sparse_grad.py, where the sparse and the dense kernels then chose differently)
+    gap = win.amax(2, keepdim=True) - win
+    pool_k = ((gap < ulps * EPS32 * wmag.unsqueeze(2)) & (gap != 0)).any(2)
     nr, npool = relu_k.flatten(1).sum(1), pool_k.sum(1)
     return (nr + npool) > 0, nr, npool
 
