@@ -98,6 +98,9 @@ SIGNATURES = {
     "gnf_mnistcnn_sparse_fwd": (c_int, [c_f, c_i64, c_f, ctypes.c_void_p, c_i64, ctypes.c_void_p, c_i64, c_f, c_f, c_f,
                                         c_f, c_f, c_f, c_i64, c_f, c_f, ctypes.c_void_p, ctypes.c_void_p, c_i64,
                                         c_stream]),
+    "gnf_mnistcnn_sparse_fwd_train": (c_int, [c_f, c_i64, c_f, ctypes.c_void_p, c_i64, ctypes.c_void_p, c_i64, c_f, c_f, c_f,
+                                              c_f, c_f, c_f, c_i64, c_f, c_f, ctypes.c_void_p, ctypes.c_void_p, c_i64,
+                                              c_stream]),
     "gnf_mnistcnn_sparse_prep_bytes": (c_i64, [c_i64]),
     "gnf_mnistcnn_sparse_prepare": (c_int, [c_f, c_f, c_f, c_f, c_f, c_i64, ctypes.c_void_p, c_i64, c_stream]),
     "gnf_mnistcnn_sparse_fwd_prepared": (c_int, [c_f, c_i64, c_f, ctypes.c_void_p, c_i64, ctypes.c_void_p, c_i64, c_f, c_f,

@@ -114,12 +114,12 @@ __device__ __forceinline__ void conv1_units(const float* e_rd, float* a1_wr, int
 }
 // The same with the position -> LDS offsets of the units handed in (a wavefront runs the SAME units for every image of its
 // persistent loop): po[k] = {read offset | write offset of block 0 << 16, blocks 1 | 2 << 16, block 3}, 16 bits each, built
-// once by conv1_offsets.  Positions past the 26 x 26 grid (the tail of unit 10) read offset 0 and write into the 8 floats of
-// slack behind row 25 of their channel (CHS >= 25 IMG + 26 + 8), so there is no predicate either: ~8 VALU instructions per
+// once by conv1_offsets.  Positions past the 26 x 26 grid (the tail of unit 10) read offset 0 and write into the first 8 floats of
+// the row BEHIND the image's 26 rows (offsets 26 IMG .. 26 IMG + 7 of their channel: CHS >= 26 IMG + 8), so there is no predicate either: ~8 VALU instructions per
 // unit instead of ~45 of address arithmetic.  Costs 3 registers per unit: for kernels that have them (the forward: 230).
 template <int CHS>
 __device__ __forceinline__ void conv1_offsets(int u, int q, int j, int lane, unsigned (&po)[3]) {
-  static_assert(CHS >= 25 * IMG + C1 + 8, "slack behind the last row of a channel");
+  static_assert(CHS >= 26 * IMG + 8, "the dummy stores of off-grid positions land at 26 IMG + (0..7) of the channel");
   const int pos = 64 * u + lane, pc = pos < C1 * C1 ? pos : 0;
   unsigned w[4];
 #pragma unroll

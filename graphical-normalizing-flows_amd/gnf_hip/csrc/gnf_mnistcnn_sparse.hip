@@ -1076,6 +1076,26 @@ int gnf_mnistcnn_sparse_prepare(const float* b1, const float* W2, const float* b
   return sparse_tables(b1, W2, b2, Wfc1, bfc1, F, (float*)prep, (hipStream_t)stream);
 }
 
+int gnf_mnistcnn_sparse_fwd_train(const float* x, int64_t B, const float* P, const int32_t* pix, int64_t R,
+                                  const int32_t* groups, int64_t max_group_rows,
+                                  const float* W1, const float* b1, const float* W2, const float* b2,
+                                  const float* Wfc1, const float* bfc1, int64_t F,
+                                  float* h1, float* pd_save, unsigned char* argmax_save,
+                                  void* tables, int64_t tables_bytes, gnf_stream_t stream) {
+  if (!W1 || !b1 || !W2 || !b2 || !Wfc1 || !bfc1 || B < 0 || R < 0 || F <= 0) return GNF_EINVAL;
+  if (F % 4 || F > 65535 * 64) return GNF_ESHAPE;
+  if (!tables || tables_bytes < gnf_mnistcnn_sparse_prep_bytes(F)) return GNF_EWS;
+  hipStream_t s = (hipStream_t)stream;
+  // the tables are built even for an empty call: the backward that follows reads them
+  if (int rc = sparse_tables(b1, W2, b2, Wfc1, bfc1, F, (float*)tables, s)) return rc;
+  const int64_t items = R * B;
+  if (items == 0) return 0;
+  if (!x || !P || !pix || !groups || !h1 || !pd_save || !argmax_save) return GNF_EINVAL;
+  if (max_group_rows <= 0 || max_group_rows > items) return GNF_EINVAL;
+  return sparse_front(x, B, P, pix, groups, max_group_rows, W1, b1, W2, b2, F, (const float*)tables, h1, pd_save, argmax_save,
+                      items, s);
+}
+
 int gnf_mnistcnn_sparse_fwd_prepared(const float* x, int64_t B, const float* P, const int32_t* pix, int64_t R,
                                      const int32_t* groups, int64_t max_group_rows,
                                      const float* W1, const float* b1, const float* W2, const float* b2, int64_t F,

@@ -508,19 +508,25 @@ class MnistSparseFn(torch.autograd.Function):
                  sr.max_group_rows, *[ptr(t) for t in ws_[:4]], F, abi.rawptr(prep), ptr(h1), abi.rawptr(ws), nws, stream())
             return h1
         ctx.pre_gated = bool(pre_gated)
-        pd = _empty((n, 400), x) if train else None
-        arg = torch.empty((n, 400), dtype=torch.uint8, device=x.device) if train else None
-        nws = abi.load().gnf_mnistcnn_sparse_ws_bytes(n, F)
-        # training: the workspace is this call's own and stays alive for the backward, which reads the parameter-only tables
-        # (fc1 column blocks per crop origin, background response) the forward built in its tail instead of building them again
-        ws = torch.empty(max(int(nws) // 4, 1), dtype=torch.float32, device=x.device) if train else _ws(nws, x)
-        call("gnf_mnistcnn_sparse_fwd", ptr(x), sr.B, ptr(P), abi.rawptr(sr.pix), sr.R, abi.rawptr(sr.groups),
-             sr.max_group_rows, *[ptr(t) for t in ws_], F, ptr(h1), ptr(pd), abi.rawptr(arg) if train else None,
-             abi.rawptr(ws), nws, stream())
-        if train:
-            ctx.save_for_backward(x, P, *ws_[:5], pd, arg, h1)
-            ctx.sr = sr
-            ctx.tables = ws[n * 400:] if SPARSE_REUSE_TABLES else None
+        if not train:
+            nws = abi.load().gnf_mnistcnn_sparse_ws_bytes(n, F)
+            ws = _ws(nws, x)
+            call("gnf_mnistcnn_sparse_fwd", ptr(x), sr.B, ptr(P), abi.rawptr(sr.pix), sr.R, abi.rawptr(sr.groups),
+                 sr.max_group_rows, *[ptr(t) for t in ws_], F, ptr(h1), None, None, abi.rawptr(ws), nws, stream())
+            return h1
+        pd = _empty((n, 400), x)
+        arg = torch.empty((n, 400), dtype=torch.uint8, device=x.device)
+        # training: ONLY the parameter-only tables (fc1 column blocks per crop origin, background response: 13 MB) are this
+        # call's own and stay alive for the backward, which reads them instead of building them again; the pooled blocks go
+        # straight to pd (round 5 held a whole workspace whose first n * 400 floats nobody touched: 125 MB per in-flight
+        # forward at B = 100)
+        nt = abi.load().gnf_mnistcnn_sparse_prep_bytes(F)
+        tables = torch.empty(max(int(nt) // 4, 1), dtype=torch.float32, device=x.device)
+        call("gnf_mnistcnn_sparse_fwd_train", ptr(x), sr.B, ptr(P), abi.rawptr(sr.pix), sr.R, abi.rawptr(sr.groups),
+             sr.max_group_rows, *[ptr(t) for t in ws_], F, ptr(h1), ptr(pd), abi.rawptr(arg), abi.rawptr(tables), nt, stream())
+        ctx.save_for_backward(x, P, *ws_[:5], pd, arg, h1)
+        ctx.sr = sr
+        ctx.tables = tables if SPARSE_REUSE_TABLES else None
         return h1
 
     @staticmethod

@@ -226,6 +226,9 @@ class NormalizingFlowStep(NormalizingFlow):
                 for obj, attr, val in saved:
                     setattr(obj, attr, val)
             if failed is not None:
+                import warnings
+                warnings.warn("NormalizingFlowStep.invert: hipGraph capture of the level schedule failed (%r); this variant "
+                              "runs eagerly from now on" % (failed,), RuntimeWarning, stacklevel=2)
                 graphs[key] = "eager"
                 torch.cuda.synchronize()
                 return self._invert_levels_body(z, levels, importance, context)
@@ -287,7 +290,11 @@ class FCNormalizingFlow(NormalizingFlow):
         c = self.constraintsLoss()
         plain_c = isinstance(c, float) and c == 0.
         dev_c = torch.is_tensor(c) and c.is_cuda and c.dim() == 0 and c.dtype == torch.float32
-        if fused and getattr(dens, "standard_normal", False) and ops.nll_loss_fits(z) and (plain_c or dev_c):
+        # the fold applies to the factories' base density and to nothing that merely inherits from it: a subclass that
+        # overrides forward (tempered / scaled / conditional density) is called as the reference calls it
+        std_normal = (getattr(dens, "standard_normal", False)
+                      and getattr(type(dens), "_std_forward", None) is type(dens).forward)
+        if fused and std_normal and ops.nll_loss_fits(z) and (plain_c or dev_c):
             # constraints - mean(log|det J| + log N(z)) in ONE launch that reads z itself (the standard-normal base density of
             # the factories; any other z_log_density module is called as the reference calls it)
             return ops.NllLossFn.apply(z, jac, None if plain_c else c)

@@ -323,6 +323,17 @@ int gnf_mnistcnn_sparse_fwd(const float* x, int64_t B, const float* P, const int
                             const float* Wfc1, const float* bfc1, int64_t F,
                             float* h1, float* pd_save, unsigned char* argmax_save,
                             void* ws, int64_t ws_bytes, gnf_stream_t stream);
+/* The training form of the same call (a backward follows): pd_save / argmax_save are required, and instead of a
+ * workspace whose first R*B*400 floats the call would never touch (pd goes to pd_save), the caller hands in ONLY the buffer
+ * of the parameter-only tables (>= gnf_mnistcnn_sparse_prep_bytes(F) bytes), which it keeps alive and passes to
+ * gnf_mnistcnn_sparse_bwd_tables.  Same h1 / pd_save / argmax_save as gnf_mnistcnn_sparse_fwd, bit for bit.
+ * (Round 6: an in-flight forward pinned 125 MB of dead workspace per conditioner at B = 100.) */
+int gnf_mnistcnn_sparse_fwd_train(const float* x, int64_t B, const float* P, const int32_t* pix, int64_t R,
+                                  const int32_t* groups, int64_t max_group_rows,
+                                  const float* W1, const float* b1, const float* W2, const float* b2,
+                                  const float* Wfc1, const float* bfc1, int64_t F,
+                                  float* h1, float* pd_save, unsigned char* argmax_save,
+                                  void* tables, int64_t tables_bytes, gnf_stream_t stream);
 /* The same front for a caller that evaluates it MANY times with unchanged parameters (the 109 levels of one sampling
  * pass, NormalizingFlow.py:98-107 under ImageExperiments.py:341-350): the parameter-only tables -- the fc1 weight columns
  * of each crop origin, conv2's response to the all-zero image and fc1 of that background -- are built once by

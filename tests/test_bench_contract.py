@@ -7,7 +7,7 @@ import re
 from conftest import ROOT
 
 
-PMC_FILE = "r05_bench_inputs.json"
+PMC_FILE = "r06_bench_inputs.json"
 
 
 def test_bench_reads_pmc_figures_from_profiles():
@@ -40,7 +40,7 @@ def test_bench_prints_issue_figures_for_every_kernel():
     number under its real name), mfma_issue_frac, the shared-ALU ceiling, the effective clock and the fraction of the peak
     AT that clock (verdict r03 item 8).  Checked on the source (the GPU run is test_bench_line_carries_issue_figures)."""
     src = open(os.path.join(ROOT, "bench.py")).read()
-    for field in ("frac_algorithmic", "mfma_issue_frac", "issue_frac_ceiling_shared_alu", "effective_clock_GHz",
+    for field in ("frac_basis", "frac_direct_conv_equivalent", "mfma_issue_frac", "issue_frac_ceiling_shared_alu", "effective_clock_GHz",
                   "effective_clock_GHz_in_pmc_pass", "cycles_per_launch", "frac_of_peak_at_clock", "valu_per_mfma", "--global-batch", '"strong" if args.global_batch else "weak"'):
         assert field in src, field
     assert "issued(dom, out[\"roofline\"])" in src and "for k, entry in kern.items()" in src
@@ -79,6 +79,7 @@ def test_round5_evidence_hygiene_items():
     assert "gnf_gemm_last_kernel" in bk and '"kernel_ran"' in bk
     assert "sa, sb = (1, M), (N, 1)" in bk and "sa, sb = (K, 1), (N, 1)" in bk          # dW: both k-major; dX: B n-contiguous
     assert "2 * 1327104 + 3 * 97344" not in bk and "2 * 1327104 + 2 * 97344" in bk
+    assert 'assert 0. < rows[-1]["frac_of_157TF"] <= 1.' in bk and "frac_direct_conv_equivalent" in bk
     src = open(os.path.join(ROOT, "bench.py")).read()
     assert "CPU_B = 8" in src and "threads_sweep_samples_per_s" in src
     assert "eval_forward_S150_samples_per_s" in src and "nrm.nb_steps = 150" in src and "torch.no_grad()" in src
@@ -87,3 +88,27 @@ def test_round5_evidence_hygiene_items():
     assert "re-measured in the same call (fc1 GEMMs: 2.07-2.12 GHz" not in readme
     # round 5: the plan-variant entry points are reported under the names of the calls they replace
     assert '"gnf_mnistcnn_conv_bwd_cols": "gnf_mnistcnn_conv_bwd"' in src
+
+
+def test_roofline_frac_is_a_fraction():
+    """review of round 5, item 1: `roofline.frac` (and every `roofline_other` row) is the flop the kernel executes in the
+    algorithm it implements / time / peak, in (0, 1]: bench.py refuses to print anything else, and on the committed evidence of
+    the round frac == MFMA instructions per image x 2048 x images / kernel time / 157.3 within 2 %."""
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    assert 'if not 0. < entry["frac"] <= 1.:' in src and "the flop basis is wrong" in src
+    assert '"rank_devices": rank_devices' in src and "share devices" in src and '"rccl_world_size"' in src
+    assert '"best_of_sweep"' in src and '"cores": phys' in src              # cpu_baseline.value is the all-physical-cores figure
+    f = os.path.join(ROOT, "profiles", "r06_bench.json")
+    if not os.path.isfile(f):                                               # written by the round's evidence collection
+        return
+    line = json.loads(open(f).read().strip().splitlines()[-1])
+    pmc = json.load(open(os.path.join(ROOT, "profiles", PMC_FILE)))
+    entries = [line["roofline"]] + line["roofline_other"]
+    for e in entries:
+        assert 0. < e["frac"] <= 1., e
+    rf = line["roofline"]
+    k = pmc["kernels"]["gnf_mnistcnn_conv_bwd"]
+    want = k["mfma_per_image"] * 2048. * pmc["n_images"] / (rf["ms_per_launch"] * 1e-3) / 1e12 / 157.3
+    assert abs(rf["frac"] / want - 1.) < .02, (rf["frac"], want)
+    cb = line["cpu_baseline"]
+    assert cb["cores"] == cb["physical_cores_assumed"] and cb["best_of_sweep"]["value"] >= cb["value"] * .999

@@ -369,6 +369,8 @@ def test_mnistcnn_golden():
     e = req(g["e"])
     out = net(e)
     assert rel_err(out.cpu(), g["out"]) < TOL
+    # element-wise too (review of round 5, item 7: the infinity norm leaves the small entries unconstrained)
+    assert_close(out, g["out"], rtol=1e-5, atol=1e-6 * g["out"].abs().max().item(), what="out")
     (out * cu(g["gout"])).sum().backward()
     assert rel_err(e.grad.cpu(), g["ge"]) < GTOL
     grads_match(net, g)
@@ -401,13 +403,17 @@ def test_mnist_conv_front_vs_torch_cpu(n, kind):
     # fp32 evaluations (different summation order).  An fp64 evaluation finds the images that hold one; they get a ZERO
     # cotangent (no contribution to any gradient on either side), their number is bounded, and everything else -- the
     # cotangent of every other image, all four parameter gradients -- is compared at GTOL.  (Until round 4: a blanket 5e-3.)
+    # The bound on their number is the measured rate at 16 ulps (2 700 ReLU gates + 2 304 pool windows per image: 5.7-8.5 % of
+    # the images of these seeds hold one), not a licence: the FORWARD values of the excluded images are compared like
+    # everybody else's -- only their cotangent is withheld.
     knife, n_relu, n_pool = conv_front_knife_images(e, W1, b1, W2, b2)
-    assert int(knife.sum()) <= max(1, n // 8), (int(knife.sum()), n)
+    assert int(knife.sum()) <= max(1, n // 10), "%d of %d images arbitrated as knife edges (measured rate <= 8.5 %%)" % (int(knife.sum()), n)
     gp = torch.randn(n, 2304) * (~knife).float().unsqueeze(1)
     (ref * gp).sum().backward()
     pg = [req(t) for t in (e, W1, b1, W2, b2)]
     out = ops.MnistConvFn.apply(*pg, kind == "sparse")        # exactly tied windows -> the tie-exact forward
     assert rel_err(out.cpu(), ref.detach()) < TOL
+    assert_close(out, ref, rtol=1e-5, atol=1e-6 * ref.detach().abs().max().item(), what="pooled (every image, knife or not)")
     (out * cu(gp)).sum().backward()
     ge, gr = pg[0].grad.cpu(), ps[0].grad
     if int((~knife).sum()):
@@ -941,6 +947,31 @@ def test_loss_and_density_read_the_z_they_are_handed(norm_kind):
             fresh = moved
 
 
+def test_loss_calls_a_subclassed_base_density():
+    """FCNormalizingFlow.loss folds the base density into its own launch only for the factories' NormalLogDensity itself: a
+    subclass that overrides forward (a tempered density here) inherits the class attribute but must be CALLED, as the
+    reference calls whatever z_log_density is (NormalizingFlow.py:144-146) -- round-5 advisor finding."""
+    from models import buildFCNormalizingFlow, CouplingConditioner, AffineNormalizer
+    from models.NormalizingFlowFactories import NormalLogDensity
+
+    class Tempered(NormalLogDensity):
+        def forward(self, z):
+            return super().forward(z) * .5 - 3.
+
+    torch.manual_seed(2)
+    flow = buildFCNormalizingFlow(1, CouplingConditioner, {"in_size": 6, "hidden": [16, 16], "out_size": 2},
+                                  AffineNormalizer, {}).to(DEV)
+    x = torch.randn(40, 6, device=DEV)
+    z, ld = flow(x)
+    plain = flow.loss(z, ld).item()
+    want_plain = (-(ld.detach().cpu() + O.normal_log_density(z.detach().cpu())).mean()).item()
+    assert abs(plain - want_plain) < 1e-5 * max(1., abs(want_plain))
+    flow.z_log_density = Tempered().to(DEV)
+    got = flow.loss(z, ld).item()
+    want = (-(ld.detach().cpu() + O.normal_log_density(z.detach().cpu()) * .5 - 3.).mean()).item()
+    assert abs(want - want_plain) > .1 and abs(got - want) < 1e-5 * max(1., abs(want)), (got, want, plain)
+
+
 # --------------------------------------------------------------------------------- Monotonic vs oracle
 def _mono_case(B, d, c, hidden, S, seed, h_layout="contig"):
     from models import MonotonicNormalizer
@@ -1231,7 +1262,8 @@ def test_monotonic_ragged_sizes(B, d, hidden):
     # their share is bounded, and every gradient is compared at GTOL -- element-wise too.  (Until round 4: 2e-3 for the
     # widest nets.)
     knife = integrand_knife_elements(x, h, [(W.detach(), b.detach()) for W, b in layers], S)
-    assert int(knife.sum()) <= max(1, B * d // 8), (int(knife.sum()), B * d)
+    # measured share at these seeds: 0-4.4 % (H <= 150), 7.0 / 8.9 % for the [200]-wide nets (22 nodes x 400-600 gates per element)
+    assert int(knife.sum()) <= max(1, B * d // 10), "%d of %d elements arbitrated as knife edges" % (int(knife.sum()), B * d)
     keep = (~knife).float()
     gz, gj = torch.randn(B, d) * keep, torch.randn(B, d) * keep
     ((z0 * gz).sum() + (j0 * gj).sum()).backward()

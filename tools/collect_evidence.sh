@@ -1,7 +1,7 @@
 #!/bin/bash
-# Round evidence in one GPU call, AFTER the last kernel commit: bash tools/collect_evidence.sh r05   (writes gpurun_out/<tag>_*;
+# Round evidence in one GPU call, AFTER the last kernel commit: bash tools/collect_evidence.sh r06   (writes gpurun_out/<tag>_*;
 # copy what is kept to profiles/)
-tag=${1:-r05}; out=gpurun_out; mkdir -p $out
+tag=${1:-r06}; out=gpurun_out; mkdir -p $out
 export TMPDIR=/tmp
 python bench.py --steps 20 --warmup 3 2> $out/${tag}_bench.err | tail -1 > $out/${tag}_bench.json
 ( cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/${tag}_kt -o p -- python3 $GRAFT_REPO_ROOT/bench.py --steps 20 --warmup 3 --no-cpu-baseline > /dev/null 2>&1 )

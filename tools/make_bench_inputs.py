@@ -1,4 +1,4 @@
-"""profiles/r05_bench_inputs.json: the PMC-derived figures bench.py prints next to its live HIP-event timings (counters
+"""profiles/r06_bench_inputs.json: the PMC-derived figures bench.py prints next to its live HIP-event timings (counters
 cannot be read from inside the benchmark process).  Per hand-written kernel of the headline step at the cfg4 per-GPU size
 (78 400 masked images / Monotonic elements): MFMA instructions issued per image (element), other VALU instructions per MFMA,
 HBM bytes per launch (2 x FETCH_SIZE + WRITE_SIZE, separate --pmc passes; MI355X_MICROARCH.md: FETCH_SIZE counts 64 B per
@@ -6,7 +6,7 @@ HBM bytes per launch (2 x FETCH_SIZE + WRITE_SIZE, separate --pmc passes; MI355X
 (GRBM_GUI_ACTIVE / 8 XCDs) and the clock of the counter pass (cycles / kernel duration in that pass).      python tools/make_bench_inputs.py [out.json]      (GPU box, from the repo root)"""
 import json, os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-out = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "gpurun_out", "r05_bench_inputs.json")
+out = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "gpurun_out", "r06_bench_inputs.json")
 PASSES = ("SQ_INSTS_MFMA,SQ_INSTS_VALU;FETCH_SIZE;WRITE_SIZE;SQ_BUSY_CU_CYCLES,SQ_VALU_MFMA_BUSY_CYCLES;"
           "SQ_LDS_BANK_CONFLICT,SQ_LDS_IDX_ACTIVE;GRBM_GUI_ACTIVE")
 env = dict(os.environ, TMPDIR="/tmp", PMC_PASSES=PASSES, PMC_SKIP="20")      # 40 launches per pass, the first 20 (clock ramp) left out
