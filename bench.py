@@ -34,7 +34,6 @@ INT_NET = [50, 50, 50]
 COND = 30
 S_NODES = 20
 PEAK_F32_TFLOPS = 157.3          # MI355X fp32 MFMA/vector peak (MI355X_MICROARCH.md)
-MFMA_OPERANDS = "f32"            # every dense contraction of the step runs on v_mfma_f32_* (true fp32 operands)
 NOMINAL_GHZ = 2.4                # the clock behind that peak: 256 CUs x 4 SIMDs x 64 flop/clk x 2.4 GHz
 PMC_INPUTS = "r06_bench_inputs.json"
 DOMINANT_OP = "gnf_mnistcnn_conv_bwd"       # the entry point of the dominant kernel (cnn_bwd_wino_k): timed live in the region
@@ -469,7 +468,10 @@ def main():
             "value": b_rank * world * args.steps / dt, "unit": "samples/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
             "scaling": "strong" if args.global_batch else "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "mfma_operands": MFMA_OPERANDS,
+            # round 6: the fc1 forward / data-gradient products run on the bf16 matrix pipe with fp32 accuracy (exact 3 x bf16 operand
+            # splits, six cross terms, fp32 accumulate: gnf_gemm_split.hip, more accurate against fp64 than the fp32-MFMA kernels
+            # they replace, profiles/r06_split_bf16_error.txt); everything else on v_mfma_f32_*.  GNF_TRUE_F32=1 turns it off.
+            "mfma_operands": "3xbf16 split (fc1), f32 elsewhere" if abi.load().gnf_gemm_split_enabled() else "f32",
             "parity_note": "UMNN 1.0 parity unpinned: the Clenshaw-Curtis integral of the Monotonic normalizer is "
                            "checked against this repo's own restatement + mathematics (CPU: tests/test_oracle_math.py; the HIP "
                            "kernels themselves against fp64 adaptive quadrature: tests/test_gpu_integral_pin.py), not against "

@@ -61,6 +61,11 @@ SIGNATURES = {
     "gnf_gemm_ws_bytes": (c_i64, [c_i64, c_i64, c_i64]),
     "gnf_gemm": (c_int, [c_f, c_i64, c_i64, c_f, c_f, c_i64, c_i64, c_f, c_i64, c_i64, c_f, c_f, c_i64, c_i64, c_f,
                          c_i64, c_i64, c_int, c_i64, c_i64, c_i64, c_f, c_i64, c_stream]),
+    "gnf_gemm_split_ws_bytes": (c_i64, [c_i64, c_i64, c_i64]),
+    "gnf_gemm_split_last_kernel": (ctypes.c_char_p, []),
+    "gnf_gemm_split_enabled": (c_int, []),
+    "gnf_gemm_split_bf16": (c_int, [c_f, c_i64, c_i64, c_f, c_i64, c_i64, c_f, c_i64, c_i64, c_f, c_int, c_i64, c_i64, c_i64,
+                                    c_int, c_int, c_i64, ctypes.c_void_p, c_i64, c_stream]),
     "gnf_dag_gate_fwd_ws_bytes": (c_i64, [c_i64]),
     "gnf_dag_gate_fwd": (c_int, [c_f, c_f, c_f, c_i64, c_int, c_int, c_float, c_float, c_f, c_f, c_u64, c_u64, c_int,
                                  c_f, c_i64, c_i64, c_stream]),

@@ -17,7 +17,7 @@ INCLUDE = os.path.join(ROOT, "include")
 LIB = os.path.join(HERE, "libgnf_hip.so")
 OBJ = os.path.join(HERE, "_obj")
 ARCH = "gfx950"
-SOURCES = ["gnf_rowwise.hip", "gnf_dag_gate.hip", "gnf_gemm.hip", "gnf_linear.hip", "gnf_linear_tall.hip", "gnf_monotonic.hip", "gnf_monotonic_wide.hip", "gnf_mnistcnn_fwd.hip",
+SOURCES = ["gnf_rowwise.hip", "gnf_dag_gate.hip", "gnf_gemm.hip", "gnf_gemm_split.hip", "gnf_linear.hip", "gnf_linear_tall.hip", "gnf_monotonic.hip", "gnf_monotonic_wide.hip", "gnf_mnistcnn_fwd.hip",
            "gnf_mnistcnn.hip", "gnf_mnistcnn_sparse.hip", "gnf_probe.hip"]
 # per-file extra flags, each with the measurement that justifies it (tools/bench_cnn.py, cfg4 size)
 EXTRA_FLAGS = {"gnf_mnistcnn_fwd.hip": ["-fno-slp-vectorize",     # conv forward 1.44 -> 1.40 ms (see the file header)

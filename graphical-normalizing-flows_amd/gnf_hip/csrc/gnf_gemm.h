@@ -31,3 +31,12 @@ int gnf_gemm_launch(GemmArgs g, int splits, hipStream_t s);
 int gnf_gemm_grouped_launch(GemmArgs g, int ngroups, hipStream_t s);
 // number of partials gnf_gemm_launch(K, splits) writes (without ACCUM)
 int64_t gnf_gemm_num_splits(int64_t K, int splits);
+
+// gnf_gemm_split.hip: fp32-accurate products on the bf16 matrix pipe (three-way exact operand splits).  gnf_gemm_split_try
+// returns 0 when a dedicated split kernel ran, 1 when the call is not its business, else an error code.
+extern "C" int64_t gnf_gemm_split_ws_bytes(int64_t M, int64_t N, int64_t K);
+extern "C" int gnf_gemm_split_enabled(void);
+extern "C" const char* gnf_gemm_split_last_kernel(void);
+int gnf_gemm_split_try(const float* A, int64_t sam, int64_t sak, const float* B, int64_t sbk, int64_t sbn, float* C, int64_t scm,
+                       int64_t scn, const float* bias, int relu, int64_t M, int64_t N, int64_t K, void* ws, int64_t ws_bytes,
+                       hipStream_t s);

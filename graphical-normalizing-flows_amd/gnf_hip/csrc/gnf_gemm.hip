@@ -904,7 +904,10 @@ static int plan_splits(int64_t M, int64_t N, int64_t K, bool kmajor_ok = true) {
 extern "C" int64_t gnf_gemm_ws_bytes(int64_t M, int64_t N, int64_t K) {
   const int a = plan_splits(M, N, K, true), b = plan_splits(M, N, K, false);
   const int s = a > b ? a : b;
-  return s > 1 ? (int64_t)(s + 1) * M * N * (int64_t)sizeof(float) : 0;     // partials + one row for their sum
+  const int64_t w = s > 1 ? (int64_t)(s + 1) * M * N * (int64_t)sizeof(float) : 0;     // partials + one row for their sum
+  // the split-bf16 kernels' pre-split planes of the small operand (round 6), when the switch is on
+  const int64_t w2 = gnf_gemm_split_enabled() ? gnf_gemm_split_ws_bytes(M, N, K) : 0;
+  return w > w2 ? w : w2;
 }
 
 extern "C" int gnf_gemm(const float* A, int64_t sam, int64_t sak, const float* B, const float* Bmask, int64_t sbk,
@@ -914,6 +917,16 @@ extern "C" int gnf_gemm(const float* A, int64_t sam, int64_t sak, const float* B
   if (M < 0 || N < 0 || K < 0) return GNF_EINVAL;
   if (M == 0 || N == 0) return 0;          // nothing to write; operands may be NULL
   if (!C || ((!A || !B) && K > 0)) return GNF_EINVAL;   // K == 0 (an empty batch as the contraction): C = epilogue(0)
+  // Round 6: the three fc1-shaped products (tall M x <= 128 x long K; tall M x wide N x 128) run on the bf16 matrix pipe with
+  // fp32 accuracy (gnf_gemm_split.hip: exact three-way operand splits, six cross terms, fp32 accumulate; measured against
+  // fp64: more accurate than the fp32-MFMA kernels below on every case, profiles/r06_split_bf16_error.txt).
+  // GNF_TRUE_F32=1 keeps everything on v_mfma_f32_*.
+  if (K > 0 && !Bmask && !Cmask && !gate) {
+    const int rc = gnf_gemm_split_try(A, sam, sak, B, sbk, sbn, C, scm, scn, bias, (flags & GNF_GEMM_RELU) ? 1 : 0, M, N, K, ws,
+                                      ws_bytes, (hipStream_t)stream);
+    if (rc == 0) { g_last_kernel = gnf_gemm_split_last_kernel(); return 0; }
+    if (rc != 1) return rc;
+  }
   GemmArgs g{A, sam, sak, B, Bmask, sbk, sbn, C, scm, scn, bias, Cmask, scmm, scmn, gate, sgm, sgn,
              flags & GNF_GEMM_RELU, M, N, K, 0, 0};
   // the few long splits of the k-major plan only for operands gemm_kmajor_k takes (the launcher's predicate on strides and

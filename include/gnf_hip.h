@@ -148,6 +148,26 @@ int gnf_gemm(const float* A, int64_t sam, int64_t sak,
              const float* gate, int64_t sgm, int64_t sgn,
              int flags, int64_t M, int64_t N, int64_t K, float* ws, int64_t ws_bytes, gnf_stream_t stream);
 
+/* ---- the same product on the bf16 matrix pipe with fp32 accuracy (round 6; models/MLP.py:44 and its autograd) ---------
+ * Every fp32 operand is split exactly into three bf16 numbers (hi + mid + lo, round-to-nearest at each level) on its way
+ * into LDS; a product is the sum of its six leading cross terms (hi hi | hi mid, mid hi | hi lo, lo hi, mid mid), each exact
+ * in the fp32 accumulator of v_mfma_f32_16x16x32_bf16; `classes` = 1 / 2 / 3 accumulators per output tile of the GENERAL
+ * kernel (3: the magnitude classes are summed separately and added once at the end; measurement), `classes` = 0: the
+ * product's choice -- a dedicated kernel (gnf_gemm_split_last_kernel names it) when the shape has one and `ws` holds
+ * gnf_gemm_split_ws_bytes(M, N, K) bytes (pre-split fragment-major planes of the small operand / split-K partials).  C[m,n] = epi(sum_k A[m,k] B[k,n]), epi = + bias[n], relu.
+ * splits > 1: K is cut into `splits` ranges, partial z goes to C + z * c_split_stride (no epilogue; the caller adds them).
+ * Operands must be finite (inf * 0 cross terms would give NaN where an fp32 product gives inf).
+ * Measured against the fp32-MFMA kernels and an fp64 product: profiles/r06_split_bf16_error.txt. */
+int64_t gnf_gemm_split_ws_bytes(int64_t M, int64_t N, int64_t K);
+const char* gnf_gemm_split_last_kernel(void);
+/* 1 unless the environment holds GNF_TRUE_F32=1: gnf_gemm (and the Linear entry points routed through it) then never leave the
+ * v_mfma_f32_* kernels. */
+int gnf_gemm_split_enabled(void);
+int gnf_gemm_split_bf16(const float* A, int64_t sam, int64_t sak, const float* B, int64_t sbk, int64_t sbn,
+                        float* C, int64_t scm, int64_t scn, const float* bias, int relu,
+                        int64_t M, int64_t N, int64_t K, int classes, int splits, int64_t c_split_stride,
+                        void* ws, int64_t ws_bytes, gnf_stream_t stream);
+
 /* ---- DAG conditioner gate: models/Conditionners/DAGConditioner.py:94-166 --------------
  * e[(b*d+i)*ld_e + j] = x[b,j] * gate(importance(A[i,j])) (+ one-hot of i in columns
  * d..2d-1 when hot != 0, ld_e >= 2d).

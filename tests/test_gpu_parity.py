@@ -176,11 +176,25 @@ def test_gemm_tall_long_k_path(M, N, K):
     torch.manual_seed(M + N + K)
     A, W, bias = torch.randn(M, K, device=DEV), torch.randn(N, K, device=DEV), torch.randn(N, device=DEV)
     C = torch.full((M, N), float("nan"), device=DEV)
-    ops.gemm(A, (K, 1), W, (1, K), C, (N, 1), M, N, K, bias=bias, relu=True)
-    ran = _last_gemm_kernel()
-    assert ran == ("gemm_tall_k" if M != 40000 else "gemm_vec_k<64,64>"), ran     # the shape reaches the kernel it is written for
+    from gnf_hip import abi
+    from gnf_hip.abi import ptr, call, stream
     rows = torch.cat([torch.arange(0, 700), torch.randint(0, M, (3000,)), torch.arange(M - 700, M)]).to(DEV)
     ref = torch.relu(A[rows].double() @ W.double().t() + bias.double())
+    # the fp32-MFMA kernel of the shape (no workspace: the split-bf16 dispatch of round 6 needs one; this is also what
+    # GNF_TRUE_F32=1 runs)
+    call("gnf_gemm", ptr(A), K, 1, ptr(W), None, 1, K, ptr(C), N, 1, ptr(bias), None, 0, 0, None, 0, 0, 1, M, N, K, None, 0, stream())
+    ran = _last_gemm_kernel()
+    assert ran == ("gemm_tall_k" if M != 40000 else "gemm_vec_k<64,64>"), ran     # the shape reaches the kernel it is written for
+    assert not torch.isnan(C).any()
+    assert rel_err(C[rows].cpu(), ref.cpu()) < 2e-6
+    # the product's dispatch (ops.gemm hands gnf_gemm its workspace): K % 128 == 0 goes to the split-bf16 tall kernel
+    C.fill_(float("nan"))
+    ops.gemm(A, (K, 1), W, (1, K), C, (N, 1), M, N, K, bias=bias, relu=True)
+    ran = _last_gemm_kernel()
+    if abi.load().gnf_gemm_split_enabled() and K % 128 == 0:
+        assert ran == "gemm_split_tall_k", ran
+    else:
+        assert ran == ("gemm_tall_k" if M != 40000 else "gemm_vec_k<64,64>"), ran
     assert not torch.isnan(C).any()
     assert rel_err(C[rows].cpu(), ref.cpu()) < 2e-6
     if M <= 50000:
@@ -218,9 +232,18 @@ def test_gemm_wide_short_k_path(M, N):
     K = 128
     A, B = torch.randn(M, K, device=DEV), torch.randn(K, N, device=DEV)
     C = torch.full((M, N), float("nan"), device=DEV)
-    ops.gemm(A, (K, 1), B, (N, 1), C, (N, 1), M, N, K)
-    assert _last_gemm_kernel() == "gemm_wide_k", _last_gemm_kernel()
+    from gnf_hip import abi
+    from gnf_hip.abi import ptr, call, stream
     ref = (A.double() @ B.double())
+    # the fp32-MFMA kernel (no workspace -> no split-bf16 dispatch; what GNF_TRUE_F32=1 runs), then the product's dispatch
+    call("gnf_gemm", ptr(A), K, 1, ptr(B), None, N, 1, ptr(C), N, 1, None, None, 0, 0, None, 0, 0, 0, M, N, K, None, 0, stream())
+    assert _last_gemm_kernel() == "gemm_wide_k", _last_gemm_kernel()
+    assert rel_err(C.cpu(), ref.cpu()) < 2e-6
+    assert not torch.isnan(C).any()
+    C.fill_(float("nan"))
+    ops.gemm(A, (K, 1), B, (N, 1), C, (N, 1), M, N, K)
+    split = abi.load().gnf_gemm_split_enabled() and M >= 10240 and N % 128 == 0
+    assert _last_gemm_kernel() == ("gemm_split_wide_k" if split else "gemm_wide_k"), _last_gemm_kernel()
     assert rel_err(C.cpu(), ref.cpu()) < 2e-6
     assert not torch.isnan(C).any()
     # strided rows of A and C (views into wider buffers)
