@@ -128,6 +128,7 @@ SIGNATURES = {
                                   ctypes.c_void_p, c_int, c_stream]),
     "gnf_probe_mfma_f32": (c_i64, [c_f, c_int, c_int, c_stream]),
     "gnf_probe_copy": (c_int, [c_f, c_f, c_i64, c_stream]),
+    "gnf_probe_empty": (c_int, [c_i64, c_int, c_stream]),
 }
 
 _lib = None

@@ -44,7 +44,17 @@ __global__ __launch_bounds__(256) void probe_copy_k(f32x4* __restrict__ dst, con
   for (; i < b1; i += 256) __builtin_nontemporal_store(__builtin_nontemporal_load(src + i), dst + i);
 }
 
+__global__ void probe_empty_k() {}
+
 }  // namespace
+
+// an EMPTY grid of a given launch shape: the launch + ramp + drain floor a kernel of that shape cannot go below
+extern "C" int gnf_probe_empty(int64_t grid, int block, gnf_stream_t stream) {
+  if (grid < 1 || block < 1 || block > 1024) return GNF_EINVAL;
+  hipLaunchKernelGGL(probe_empty_k, dim3((unsigned)grid), dim3(block), 0, (hipStream_t)stream);
+  GNF_LAUNCH_CHECK();
+  return 0;
+}
 
 extern "C" int64_t gnf_probe_mfma_f32(float* out, int iters, int blocks, gnf_stream_t stream) {
   if (!out || iters < 1 || blocks < 1) return GNF_EINVAL;

@@ -7,6 +7,7 @@
 // loads are coalesced, and the per-row reduction is a __shfl_xor butterfly inside the
 // lane group -- no LDS, no atomics, deterministic.
 #include "gnf_common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -1190,12 +1191,16 @@ int gnf_affine_fwd(const float* x, float* h, int64_t h_sb, int64_t h_sd, int64_t
   if (!x || !h || !z) return GNF_EINVAL;
   const int G = gnf_pow2_ge(d, 64);
   if (!clamp_inplace && h_sc == 1 && h_sd == 2 && h_sb == 2 * d && d <= 64 && B * d >= (1 << 16)) {
-    constexpr int U = 2;                   // short rows in the contiguous [B,d,2] layout: a row per 16-lane group
+    // short rows in the contiguous [B,d,2] layout: a row per 16-lane group.  Rows per group and trip (round 6, same-box sweep
+    // profiles/r06_affine_floor.txt): ONE below 2^24 elements -- at the BASELINE shape [50 000, 63] the launch is a handful of
+    // trips per CU and more workgroups in flight beat more bytes per wavefront (10.9 us back to back against 11.5 / 12.8 for
+    // two / four) --, FOUR above (10^6 x 63: 0.66-0.68 of 8 TB/s against 0.63)
+    const int U = B * d >= ((int64_t)1 << 24) ? 4 : 1;
     const int64_t per_block = (int64_t)(kBlock / 64) * 4 * U;
     int64_t grid = (B + per_block - 1) / per_block;
     if (grid > 256 * 16) grid = 256 * 16;
-    hipLaunchKernelGGL((affine_fwd_g16_k<U>), dim3((unsigned)grid), dim3(kBlock), 0, (hipStream_t)stream, x, h, z, jac,
-                       logdet, logn, B, (int)d);
+    if (U == 1) hipLaunchKernelGGL((affine_fwd_g16_k<1>), dim3((unsigned)grid), dim3(kBlock), 0, (hipStream_t)stream, x, h, z, jac, logdet, logn, B, (int)d);
+    else hipLaunchKernelGGL((affine_fwd_g16_k<4>), dim3((unsigned)grid), dim3(kBlock), 0, (hipStream_t)stream, x, h, z, jac, logdet, logn, B, (int)d);
     GNF_LAUNCH_CHECK();
     return 0;
   }
@@ -1237,12 +1242,13 @@ int gnf_affine_bwd(const float* x, const float* h, int64_t h_sb, int64_t h_sd, i
   if (!x || !h || !gh) return GNF_EINVAL;
   const int G = gnf_pow2_ge(d, 64);
   if (g_sc == 1 && g_sd == 2 && g_sb == 2 * d && h_sc == 1 && h_sd == 2 && h_sb == 2 * d && d <= 64 && B * d >= (1 << 16)) {
-    constexpr int U = 2;                   // short rows, contiguous [B,d,2] h and gh: a row per 16-lane group
+    // short rows, contiguous [B,d,2] h and gh: a row per 16-lane group; rows per group and trip as in the forward
+    const int U = B * d >= ((int64_t)1 << 24) ? 4 : 1;
     const int64_t per_block = (int64_t)(kBlock / 64) * 4 * U;
     int64_t grid = (B + per_block - 1) / per_block;
     if (grid > 256 * 16) grid = 256 * 16;
-    hipLaunchKernelGGL((affine_bwd_g16_k<U>), dim3((unsigned)grid), dim3(kBlock), 0, (hipStream_t)stream, x, h, gz, gjac,
-                       glogdet, glogn, gx, gh, B, (int)d);
+    if (U == 1) hipLaunchKernelGGL((affine_bwd_g16_k<1>), dim3((unsigned)grid), dim3(kBlock), 0, (hipStream_t)stream, x, h, gz, gjac, glogdet, glogn, gx, gh, B, (int)d);
+    else hipLaunchKernelGGL((affine_bwd_g16_k<4>), dim3((unsigned)grid), dim3(kBlock), 0, (hipStream_t)stream, x, h, gz, gjac, glogdet, glogn, gx, gh, B, (int)d);
     GNF_LAUNCH_CHECK();
     return 0;
   }

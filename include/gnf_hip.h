@@ -431,6 +431,8 @@ int gnf_adam_step_dev(float* p, const float* g, float* m, float* v, int64_t n,
  * (negative on error); gnf_probe_copy is a STREAM copy of n floats (n % 4 == 0). */
 int64_t gnf_probe_mfma_f32(float* out, int iters, int blocks, gnf_stream_t stream);
 int gnf_probe_copy(float* dst, const float* src, int64_t n, gnf_stream_t stream);
+/* an empty grid of `grid` workgroups of `block` threads: the launch-ramp floor of a kernel of that launch shape (measurement) */
+int gnf_probe_empty(int64_t grid, int block, gnf_stream_t stream);
 
 #ifdef __cplusplus
 }
