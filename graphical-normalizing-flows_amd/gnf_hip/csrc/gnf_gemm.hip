@@ -747,15 +747,12 @@ int gnf_gemm_launch(GemmArgs g, int splits, hipStream_t s) {
       g.sak >= g.M && g.sbk >= g.N &&       // rows past a K range must lie past the descriptor's extent (they read as zeros)
       (((uintptr_t)g.A | (uintptr_t)g.B) & 15) == 0 && (((uintptr_t)g.C | (uintptr_t)(g.c_split_stride * 4)) & 7) == 0 &&
       g.k_per_split * (g.sak > g.sbk ? g.sak : g.sbk) < (1 << 28) && ((g.N + KMN - 1) / KMN) * nsp >= 64 && nsp <= 4096) {
-    static const bool no_km = getenv("GNF_GEMM_KMAJOR") && getenv("GNF_GEMM_KMAJOR")[0] == '0';      // A/B switch
-    if (!no_km) {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kmajor_k), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                KMLDS);
-      hipLaunchKernelGGL(gemm_kmajor_k, dim3((unsigned)(((g.N + KMN - 1) / KMN) * nsp)), dim3(512), KMLDS, s, g);
-      g_last_kernel = "gemm_kmajor_k";
-      GNF_LAUNCH_CHECK();
-      return 0;
-    }
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kmajor_k), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              KMLDS);
+    hipLaunchKernelGGL(gemm_kmajor_k, dim3((unsigned)(((g.N + KMN - 1) / KMN) * nsp)), dim3(512), KMLDS, s, g);
+    g_last_kernel = "gemm_kmajor_k";
+    GNF_LAUNCH_CHECK();
+    return 0;
   }
   // short K, wide N, tall M, no epilogue options (fc1 data gradient): the persistent unit-range kernel
   if (g.K == WK && nsp == 1 && !g.grp && g.sak == 1 && g.sbn == 1 && g.scn == 1 && !g.bias && !g.Bmask && !g.Cmask &&
@@ -788,9 +785,8 @@ int gnf_gemm_launch(GemmArgs g, int splits, hipStream_t s) {
   if (vec && akf && bkf && g.N <= 128 && nsp == 1 && !g.grp && !g.Bmask && !g.Cmask && !g.gate &&
       !(g.flags & ~GNF_GEMM_RELU) && g.N > 96 && g.K % TBK == 0 && g.K >= 8 * TBK && g.sam % 4 == 0 && g.sbn % 4 == 0 &&
       (((uintptr_t)g.A | (uintptr_t)g.B) & 15) == 0 && 320 * g.sam + g.K < (1 << 28) && 128 * g.sbn + g.K < (1 << 28)) {
-    static const char tall_mode = getenv("GNF_GEMM_TALL") ? getenv("GNF_GEMM_TALL")[0] : '4';      // A/B: 0 off, 2 two 4-wave groups
-    const int wr = tall_mode == '2' ? 2 : 4;
-    const int tmw = tall_mode == '0' ? 0 : tall_tmw(g.M, wr);
+    const int wr = 4;                               // (the two-group form, 2 x 4 wavefronts per CU, lost its A/B in round 4)
+    const int tmw = tall_tmw(g.M, wr);
     if (tmw) {
       const int64_t bm = 16 * wr * tmw, tiles = (g.M + bm - 1) / bm, slots = 256 * (4 / wr);
       const unsigned tgrid = (unsigned)(tiles < slots ? tiles : slots);
@@ -800,11 +796,7 @@ int gnf_gemm_launch(GemmArgs g, int splits, hipStream_t s) {
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)tall_lds<T, W>());                  \
     hipLaunchKernelGGL((gemm_tall_k<T, W>), dim3(tgrid), dim3(128 * W), (tall_lds<T, W>()), s, g);                 \
   } while (0)
-      if (wr == 2) {
-        if (tmw == 5) GNF_TALL_LAUNCH(5, 2); else if (tmw == 4) GNF_TALL_LAUNCH(4, 2); else GNF_TALL_LAUNCH(3, 2);
-      } else {
-        if (tmw == 5) GNF_TALL_LAUNCH(5, 4); else if (tmw == 4) GNF_TALL_LAUNCH(4, 4); else GNF_TALL_LAUNCH(3, 4);
-      }
+      if (tmw == 5) GNF_TALL_LAUNCH(5, 4); else if (tmw == 4) GNF_TALL_LAUNCH(4, 4); else GNF_TALL_LAUNCH(3, 4);
 #undef GNF_TALL_LAUNCH
       g_last_kernel = "gemm_tall_k";
       GNF_LAUNCH_CHECK();
@@ -881,8 +873,7 @@ static int plan_splits(int64_t M, int64_t N, int64_t K, bool kmajor_ok = true) {
   // 64 x 64 tiles it streamed 7.7 GB of operands in 2.63 ms, 45 TFLOP/s.)
   // M <= 128 over a very long K (fc1 weight gradient 128 x 2304 x 78 400): gemm_kmajor_k runs ONE 128-KB-LDS workgroup per
   // CU, so as many (tile, split) pairs as CUs: 18 tiles x 14 splits (the generic kernels took 36 splits: 3 x the partials)
-  static const bool no_km_plan = getenv("GNF_GEMM_KMAJOR") && getenv("GNF_GEMM_KMAJOR")[0] == '0';
-  if (M <= 128 && N % 4 == 0 && N >= 512 && K >= 16384 && !no_km_plan && kmajor_ok) {
+  if (M <= 128 && N % 4 == 0 && N >= 512 && K >= 16384 && kmajor_ok) {
     int64_t s = 256 / ((N + 127) / 128);
     if (s > K / 512) s = K / 512;
     if (s >= 2) return (int)s;

@@ -370,8 +370,7 @@ inline int mask_kind(const float* mask, const float* deg_out) { return deg_out ?
 
 constexpr int kSkinnyM = 128;
 bool skinny_ok(int64_t M) {
-  static const bool off = getenv("GNF_LINEAR_SKINNY") && getenv("GNF_LINEAR_SKINNY")[0] == '0';   // A/B switch (measurement)
-  return !off && M >= 1 && M <= kSkinnyM;
+  return M >= 1 && M <= kSkinnyM;
 }
 
 }  // namespace
@@ -467,8 +466,7 @@ int gnf_linear_bwd(const float* g, const float* W, const float* a, const float* 
                    int64_t M, int64_t N, int64_t K, float* ws, int64_t ws_bytes, gnf_stream_t stream) {
   if (M < 0 || N <= 0 || K <= 0) return GNF_EINVAL;
   if (!gW || (M > 0 && (!g || !a || !W || !gx)) || (!deg_out) != (!deg_in)) return GNF_EINVAL;
-  static const bool split = getenv("GNF_LINEAR_BWD_SPLIT") && getenv("GNF_LINEAR_BWD_SPLIT")[0] == '1';   // A/B switch
-  if (M > 0 && !split && skinny_ok(M) && N % 16 == 0 && K % 2 == 0) {
+  if (M > 0 && skinny_ok(M) && N % 16 == 0 && K % 2 == 0) {
     const LinMask mk{mask, deg_out, deg_in, strict};
     const int wgx = (int)((N + 63) / 64), wgy = (int)((K + 63) / 64), xgx = (int)((K + 31) / 32), xgy = (int)((M + 15) / 16);
     const int nbx = xgx * xgy;

@@ -465,15 +465,13 @@ int tall_grid(int64_t M) {
 }  // namespace
 
 bool gnf_linear_tall_ok(int64_t M, int64_t N, int64_t K) {
-  static const bool off = getenv("GNF_LINEAR_TALL") && getenv("GNF_LINEAR_TALL")[0] == '0';      // A/B switch (measurement)
-  return !off && M >= 2048 && N >= 1 && N <= 64 && K >= 4 && K <= 128 && K % 4 == 0 && M * (K > N ? K : N) * 4 < (1ll << 31);
+  return M >= 2048 && N >= 1 && N <= 64 && K >= 4 && K <= 128 && K % 4 == 0 && M * (K > N ? K : N) * 4 < (1ll << 31);
 }
 
 // the FORWARD alone also below 2048 rows (above the small-batch kernels' 128): a level of a sampling pass is a few hundred
 // rows through fc2 (128 -> 30); the tiled GEMM splits K there and pays a reduction launch (12 + 5 us against ~7)
 bool gnf_linear_tall_fwd_ok(int64_t M, int64_t N, int64_t K) {
-  static const bool off = getenv("GNF_LINEAR_TALL") && getenv("GNF_LINEAR_TALL")[0] == '0';
-  return !off && M > 128 && N >= 1 && N <= 64 && K >= 4 && K <= 128 && K % 4 == 0 && M * (K > N ? K : N) * 4 < (1ll << 31);
+  return M > 128 && N >= 1 && N <= 64 && K >= 4 && K <= 128 && K % 4 == 0 && M * (K > N ? K : N) * 4 < (1ll << 31);
 }
 
 int64_t gnf_linear_tall_ws_floats(int64_t M, int64_t N, int64_t K) { return (int64_t)tall_grid(M) * (N * K + N + K); }
@@ -534,8 +532,7 @@ int gnf_linear_tall_bwd(const float* g, const float* W, const float* a, const fl
 }
 
 bool gnf_linear_tall_wgrad_ok(int64_t M, int64_t N, int64_t K, int64_t ldg, int64_t lda) {
-  static const bool off = getenv("GNF_LINEAR_TALL") && getenv("GNF_LINEAR_TALL")[0] == '0';
-  return !off && M >= 2048 && N >= 1 && N <= 64 && K >= 1 && K <= 64 && ldg >= N && lda >= K && M * (lda > ldg ? lda : ldg) * 4 < (1ll << 31);
+  return M >= 2048 && N >= 1 && N <= 64 && K >= 1 && K <= 64 && ldg >= N && lda >= K && M * (lda > ldg ? lda : ldg) * 4 < (1ll << 31);
 }
 
 int gnf_linear_tall_wgrad_parts(int64_t M) { return tall_grid(M); }

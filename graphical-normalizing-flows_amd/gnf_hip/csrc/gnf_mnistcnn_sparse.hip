@@ -365,184 +365,8 @@ struct SparseBwdArgs {
   float* part; int64_t B, items;
 };
 
-__global__ __launch_bounds__(64, 2) void sparse_crop_bwd_k(SparseBwdArgs a) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  const int lane = threadIdx.x, q = lane >> 4, j = lane & 15;
-  float* e_s = smem;
-  float* a1_s = smem + EB;
-  float* dy_s = a1_s + NCH * BPL;
-  for (int i = lane; i < ESZ; i += 64) e_s[ONES + i] = 1.f;
-  for (int i = lane; i < NCH * DPL; i += 64) dy_s[i] = 0.f;           // the border stays zero: only the interior is rewritten
-  for (int i = lane; i < NCH * BPL; i += 64) a1_s[i] = 0.f;           // columns 12, 13 of every row are read (times 0): finite
-
-  float wa1[3], wf[36];
-#pragma unroll
-  for (int s = 0; s < 3; ++s) {
-    const int tap = 4 * s + q;
-    wa1[s] = tap < 9 ? a.W1[j * 9 + tap] : 0.f;
-  }
-#pragma unroll
-  for (int s = 0; s < 36; ++s) wf[s] = a.W2[((4 * (s & 3) + q) * NCH + j) * 9 + (s >> 2)];   // A[c_in = j][(tap, c_out)]
-  f32x4 bias1;
-#pragma unroll
-  for (int r = 0; r < 4; ++r) bias1[r] = a.b1[4 * q + r];
-
-  int pe[9], pao[9], to[3];       // conv1 position 16 nb + j in the crop (stride 16) / in the stride-14 planes; tap offsets
-#pragma unroll
-  for (int nb = 0; nb < 9; ++nb) {
-    const int p = 16 * nb + j, y = p / A1, x = p - A1 * y;
-    pao[nb] = y * A1S + x;
-    pe[nb] = y * ES + x;
-  }
-#pragma unroll
-  for (int s = 0; s < 3; ++s) {
-    const int tap = 4 * s + q, ty = tap < 9 ? tap / 3 : 0, tx = tap < 9 ? tap - 3 * ty : 0;
-    to[s] = ty * ES + tx;
-  }
-  int dyo[7];                     // cotangent scatter: pair (cell, channel) = lane + 64 t, top-left of the cell's 2x2
-#pragma unroll
-  for (int t = 0; t < 7; ++t) {
-    const int idx = lane + 64 * t, cell = idx >> 4, c = idx & 15, cy = cell / 5, cx = cell - 5 * cy;
-    dyo[t] = idx < KD ? c * DPL + (2 * cy + 2) * A1S + 2 * cx + 2 : -1;
-  }
-  const int eb = j < 9 ? (j / 3) * ES + j % 3 + q : (j == 9 ? ONES + q : q);   // dW1 B operand: tap j | ones (db1) | unused
-  int pb[4];                      // box position 16 nb + j of the 8x8 box, in the stride-14 planes
-#pragma unroll
-  for (int nb = 0; nb < 4; ++nb) pb[nb] = (2 * nb + (j >> 3)) * A1S + (j & 7);
-  int ce[4], cl[4];
-#pragma unroll
-  for (int t = 0; t < 4; ++t) {
-    const int idx = lane + 64 * t, ey = idx / CROP, ex = idx - CROP * ey;
-    ce[t] = ey * IMG + ex;
-    cl[t] = idx < CROP * CROP ? ey * ES + ex : -1;
-  }
-
-  f32x4 acc2[9], acc1a = {0.f, 0.f, 0.f, 0.f}, acc1b = acc1a, dsum = acc1a;
-#pragma unroll
-  for (int t = 0; t < 9; ++t) acc2[t] = acc1a;
-
-  float xv[4], pv[4], gv[7];
-  int av[7];
-  auto fetch = [&](int64_t item) {
-    const int64_t r = item / a.B, b = item - r * a.B;
-    const int pix = a.pix[r];
-    const int corner = 2 * crop_origin(pix / IMG) * IMG + 2 * crop_origin(pix % IMG);
-#pragma unroll
-    for (int t = 0; t < 4; ++t) {
-      const bool ok = cl[t] >= 0;
-      xv[t] = ok ? a.x[b * NPIX + corner + ce[t]] : 0.f;
-      pv[t] = ok ? a.P[(int64_t)pix * NPIX + corner + ce[t]] : 0.f;
-    }
-#pragma unroll
-    for (int t = 0; t < 7; ++t) {
-      const bool ok = dyo[t] >= 0;
-      gv[t] = ok ? a.dpd[item * KD + lane + 64 * t] : 0.f;
-      av[t] = ok ? (int)a.arg[item * KD + lane + 64 * t] : 0;
-    }
-  };
-
-  int64_t item = blockIdx.x;
-  if (item < a.items) fetch(item);
-  for (; item < a.items; item += gridDim.x) {
-#pragma unroll
-    for (int t = 0; t < 4; ++t)
-      if (cl[t] >= 0) e_s[cl[t]] = xv[t] * pv[t];
-#pragma unroll
-    for (int t = 0; t < 7; ++t)
-      if (dyo[t] >= 0) {
-        f32x2 r0, r1;
-        r0.x = av[t] == 0 ? gv[t] : 0.f; r0.y = av[t] == 1 ? gv[t] : 0.f;
-        r1.x = av[t] == 2 ? gv[t] : 0.f; r1.y = av[t] == 3 ? gv[t] : 0.f;
-        *reinterpret_cast<f32x2*>(dy_s + dyo[t]) = r0;
-        *reinterpret_cast<f32x2*>(dy_s + dyo[t] + A1S) = r1;
-      }
-    if (item + gridDim.x < a.items) fetch(item + gridDim.x);
-
-    // ---- conv1 + ReLU (recomputed) -> a1_s
-#pragma unroll
-    for (int nb = 0; nb < 9; ++nb) {
-      f32x4 d = bias1;
-#pragma unroll
-      for (int s = 0; s < 3; ++s) d = mfma(wa1[s], e_s[pe[nb] + to[s]], d);
-#pragma unroll
-      for (int r = 0; r < 4; ++r) a1_s[(4 * q + r) * BPL + pao[nb]] = fmaxf(d[r], 0.f);
-    }
-    // ---- dW2[c_out][c_in][tap] += sum_pos dY2[c_out][pos] a1[c_in][pos + tap]: 9 independent chains
-    //      K runs over 10 rows x 12 columns (3 steps of 4 per row): columns 10, 11 are the zero border of dY2
-    {
-      const float* ap = dy_s + j * DPL + 2 * A1S + 2 + q;
-      const float* bp = a1_s + j * BPL + q;
-#pragma unroll
-      for (int s = 0; s < 30; ++s) {
-        const int o = (s / 3) * A1S + 4 * (s % 3);
-        const float av2 = ap[o];
-#pragma unroll
-        for (int t = 0; t < 9; ++t) acc2[t] = mfma(av2, bp[o + (t / 3) * A1S + t % 3], acc2[t]);
-        if (s % 3 == 2) __builtin_amdgcn_sched_barrier(0);       // bound the operand hoisting (registers)
-      }
-    }
-    // ---- d a1[c_in][pos] = sum_{c_out,tap} W2[c_out][c_in][tap] dY2[c_out][pos - tap], gated by a1 > 0, in place --
-    //      only on the 8x8 box of conv1 positions that holds every position whose activation can differ from
-    //      relu(b1) (the 7x7 neighbourhood of the pixel's window): e is zero under every other position, so they
-    //      contribute nothing to dW1, and their constant gate makes their share of db1 a closed form of the column
-    //      sums (sparse_finish_k) once the UNgated sum over the box is known (dsum).
-    int boxo, boxe;
-    {
-      const int pix = __builtin_amdgcn_readfirstlane(a.pix[item / a.B]);
-      const int yi = pix / IMG, xi = pix - IMG * yi;
-      int oy = yi - 4 - 2 * crop_origin(yi), ox = xi - 4 - 2 * crop_origin(xi);
-      oy = oy < 0 ? 0 : (oy > 4 ? 4 : oy);
-      ox = ox < 0 ? 0 : (ox > 4 ? 4 : ox);
-      boxo = oy * A1S + ox;
-      boxe = oy * ES + ox;
-    }
-#pragma unroll
-    for (int nb = 0; nb < 4; ++nb) {
-      f32x4 d0 = {0.f, 0.f, 0.f, 0.f}, d1 = d0;
-      const float* bp = dy_s + q * DPL + boxo + pb[nb] + 2 * A1S + 2;
-#pragma unroll
-      for (int s = 0; s < 36; s += 2) {
-        const int t0 = s >> 2, t1 = (s + 1) >> 2;
-        d0 = mfma(wf[s], bp[4 * (s & 3) * DPL - (t0 / 3) * A1S - t0 % 3], d0);
-        d1 = mfma(wf[s + 1], bp[4 * ((s + 1) & 3) * DPL - (t1 / 3) * A1S - t1 % 3], d1);
-      }
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        float* g = a1_s + (4 * q + r) * BPL + boxo + pb[nb];
-        const float v = d0[r] + d1[r];
-        dsum[r] += v;
-        *g = *g > 0.f ? v : 0.f;
-      }
-      __builtin_amdgcn_sched_barrier(0);
-    }
-    // ---- dW1[c][tap] += sum_box da1[c][pos] e[pos + tap];  db1[c] += sum_box da1[c][pos]  (column 9: constant 1)
-    {
-      const float* ap = a1_s + j * BPL + boxo + q;
-      const float* bp = e_s + boxe + eb;
-#pragma unroll
-      for (int s = 0; s < 16; s += 2) {
-        acc1a = mfma(ap[(s / 2) * A1S + 4 * (s % 2)], bp[(s / 2) * ES + 4 * (s % 2)], acc1a);
-        acc1b = mfma(ap[((s + 1) / 2) * A1S + 4 * ((s + 1) % 2)], bp[((s + 1) / 2) * ES + 4 * ((s + 1) % 2)], acc1b);
-      }
-    }
-  }
-
-  float* prow = a.part + (int64_t)blockIdx.x * PROW;
-#pragma unroll
-  for (int t = 0; t < 9; ++t)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) prow[((4 * q + r) * NCH + j) * 9 + t] = acc2[t][r];
-#pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    const float v = acc1a[r] + acc1b[r];
-    if (j < 9) prow[NCH * NCH * 9 + (4 * q + r) * 9 + j] = v;
-    else if (j == 9) prow[NCH * NCH * 9 + NCH * 9 + 4 * q + r] = v;
-    const float ds = group_sum<16>(dsum[r]);
-    if (j == 0) prow[NCH * NCH * 9 + NCH * 9 + NCH + 4 * q + r] = ds;
-  }
-}
-
-// The same backward with TWO wavefronts per masked copy (round 5).  One wavefront per copy holds 256 registers and 25 KB of LDS:
+// TWO wavefronts per masked copy (round 5; the one-wavefront form of rounds 1-4 -- same arithmetic, profiles/r05_sparse_bwd2.txt --
+// was deleted in round 6).  One wavefront per copy held 256 registers and 25 KB of LDS:
 // six copies per CU, 1.5 wavefronts per SIMD, and its ~450 MFMAs per copy are one dependent stream (0.61 of the MFMA-bound
 // time).  Here the copy's work is two streams that meet at barriers:
 //   wavefront 0: stage e  | conv1 -> a1, bump F_a1 | wait F_dy | dW2 taps 0..6 (210 MFMAs)                                   | barrier
@@ -1228,29 +1052,22 @@ int gnf_mnistcnn_sparse_bwd_tables(const float* x, int64_t B, const float* P, co
   SparseBwdArgs a{x, P, pix, W1, b1, W2, dpd, argmax, part, B, items};
   // exactly one resident wave of workgroups: a second, partial wave would idle most of the chip (every workgroup
   // walks the same number of copies)
-  static const bool two = [] { const char* e = getenv("GNF_SPARSE_BWD2"); return !(e && e[0] == '0'); }();   // A/B: 0 = one wavefront per copy
   static int per_cu = 0, n_cu = 0;
   if (!per_cu) {
     int dev = 0, nb = 0;
     hipDeviceProp_t prop;
     if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return GNF_EINVAL;
-    if (two) {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sparse_crop_bwd2_k), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)(BLDS2 * sizeof(float)));
-      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, sparse_crop_bwd2_k, 128, BLDS2 * sizeof(float)) != hipSuccess || nb < 1)
-        return GNF_EINVAL;
-    } else if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, sparse_crop_bwd_k, 64, BLDS * sizeof(float)) != hipSuccess ||
-               nb < 1) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sparse_crop_bwd2_k), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)(BLDS2 * sizeof(float)));
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, sparse_crop_bwd2_k, 128, BLDS2 * sizeof(float)) != hipSuccess || nb < 1)
       return GNF_EINVAL;
-    }
     n_cu = prop.multiProcessorCount;
     per_cu = nb;
   }
   int64_t grid = (int64_t)per_cu * n_cu;
   if (grid > BWD_GRID) grid = BWD_GRID;
   if (grid > items) grid = items;
-  if (two) hipLaunchKernelGGL(sparse_crop_bwd2_k, dim3((unsigned)grid), dim3(128), BLDS2 * sizeof(float), s, a);
-  else hipLaunchKernelGGL(sparse_crop_bwd_k, dim3((unsigned)grid), dim3(64), BLDS * sizeof(float), s, a);
+  hipLaunchKernelGGL(sparse_crop_bwd2_k, dim3((unsigned)grid), dim3(128), BLDS2 * sizeof(float), s, a);
   GNF_LAUNCH_CHECK();
   if ((rc = gnf_rowsum_launch(part, red, grid, PROW, 0, s))) return rc;
   hipLaunchKernelGGL(sparse_finish_k, dim3(1), dim3(1024), 0, s, red, gbfc1, T, Wfc1, b1, W2, (int)F, gW1, gb1, gW2, gb2);

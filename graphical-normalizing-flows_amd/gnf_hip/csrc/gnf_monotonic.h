@@ -56,7 +56,7 @@ __host__ __device__ inline int mono_unit_at(int p, int H, int perm) {
   return u < H ? u : -1;
 }
 
-__host__ __device__ inline MonoLayout make_layout(int HT, int NH, int c, bool frag_copies = false) {
+__host__ __device__ inline MonoLayout make_layout(int HT, int NH, int c) {
   MonoLayout L;
   L.HT = HT; L.HP = 16 * HT; L.NH = NH; L.c = c; L.HM = 0; L.EX = 0;
   L.perm = 0;
@@ -86,7 +86,7 @@ __host__ __device__ inline MonoLayout make_layout(int HT, int NH, int c, bool fr
   L.o_W1hT = o; o += L.CP * L.LDW;
   L.total_floats = o;
   for (int l = 1; l < NH; ++l) { L.o_Wf[l] = 0; L.o_WTf[l] = 0; }
-  if (HT >= 7 || frag_copies) {       // (frag_copies: the GNF_MONO_WIDE_EXP=1 A/B of the two-role kernels on a narrow net)
+  if (HT >= 7) {
     for (int l = 1; l < NH; ++l) { L.o_Wf[l] = o; o += L.HP * L.HP; L.o_WTf[l] = o; o += L.HP * L.HP; }
   }
   L.pack_floats = o;

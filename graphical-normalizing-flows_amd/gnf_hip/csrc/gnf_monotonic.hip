@@ -1956,26 +1956,18 @@ int pick_ht(const gnf_mono_net* net) {
 constexpr int kLdsBudget = 160 * 1024;
 
 // layout of a net's pack + whether its kernels peel the leftover units of the last tile (all hidden widths H with
-// H / 16 == 3 and H mod 16 in {1, 2, 3}: the reference's default [50, 50, 50]); GNF_MONO_PEEL=0 keeps the padded form
-// GNF_MONO_WIDE_EXP=1 (measurement, round 5): a 4-tile net (H = 49..64, no peel) on the TWO-ROLE pair-major kernels of
-// gnf_monotonic_wide.hip instead of the one-wavefront-per-SIMD kernels of this file -- the same-box A/B behind
-// profiles/r05_mono_two_role_ab.txt
-bool mono_wide_exp() {
-  static const bool on = [] { const char* e = std::getenv("GNF_MONO_WIDE_EXP"); return e && e[0] == '1'; }();
-  return on;
-}
-
+// H / 16 == 3 and H mod 16 in {1, 2, 3}: the reference's default [50, 50, 50]).  (The A/B switches of rounds 3-5 --
+// GNF_MONO_PEEL, GNF_MONO_WIDE_EXP, GNF_MONO_ROWPEEL, GNF_MONO_KPERM, GNF_MONO_INV_EPG4, GNF_MONO_WIDE / _WIDE_FWD -- are gone with
+// the instantiations only they reached: every one of them lost on every recorded box, profiles/r03-r05_mono_*.txt.)
 MonoLayout net_layout(const gnf_mono_net* net, int HT) {
-  MonoLayout L = make_layout(HT, net->nl - 1, net->dims[0] - 1, HT == 4 && mono_wide_exp());
-  static const bool enabled = [] { const char* e = std::getenv("GNF_MONO_PEEL"); return !(e && e[0] == '0'); }();
-  if (enabled && HT == 4 && !mono_wide_exp()) {
+  MonoLayout L = make_layout(HT, net->nl - 1, net->dims[0] - 1);
+  if (HT == 4) {
     const int H = net->dims[1];
     bool same = true;
     for (int l = 1; l < net->nl; ++l) same = same && net->dims[l] == H;
     if (same && H / 16 == 3 && H % 16 >= 1 && H % 16 <= 3) { L.HM = 3; L.EX = H % 16; }
   }
-  static const bool perm_on = [] { const char* e = std::getenv("GNF_MONO_KPERM"); return !(e && e[0] == '0'); }();
-  if (HT >= 7 && perm_on) {                  // wide nets: K order of the last unit tile (see MonoLayout::perm)
+  if (HT >= 7) {                  // wide nets: K order of the last unit tile (see MonoLayout::perm)
     L.perm = 1;
     for (int l = 1; l < net->nl; ++l) {
       const int H = net->dims[l], T = (H - 1) / 16;
@@ -1997,8 +1989,7 @@ int launch_fwd(const MonoArgs& a, hipStream_t s) {
   if (INV && !swap && ngroups <= 512 && a.S >= 7) {
     // fewer groups than a resident wave of workgroups: split the quadrature nodes over the workgroup's wavefronts
     const int pairs = (a.S + 2) / 2;
-    static const bool quarter_off = getenv("GNF_MONO_INV_EPG4") && getenv("GNF_MONO_INV_EPG4")[0] == '0';   // A/B switch
-    const bool quarter = !quarter_off && ngroups < 256;               // groups of 4 elements x 4 node pairs (see above)
+    const bool quarter = ngroups < 256;                               // groups of 4 elements x 4 node pairs (see above)
     // level-sized problems on a peeled net: two bisection steps per round (mono_inv_ks_x_k) when the 3 (S + 1) evaluations of
     // an element fit the workgroup's pair slots (S <= 31) and the weight image is LDS-resident; GNF_MONO_INV_PTS=1 keeps the
     // one-step kernel (A/B and the bit-equality test)
@@ -2147,16 +2138,11 @@ int launch_bwd_one(const MonoArgs& a, unsigned grid, hipStream_t s) {
       if constexpr (HT == 4) {
         if (a.L.EX > 0) {                       // peeled: 3 tiles on the MFMA, the H mod 16 leftover units on the VALU
           // row peel (the weight gradient's fourth out tile on the VALU) where its partials fit the register file
-          static const bool no_rp = getenv("GNF_MONO_ROWPEEL") && getenv("GNF_MONO_ROWPEEL")[0] == '0';
           constexpr bool kRP = NH <= 3;          // NH = 4: 122 registers spilled
-          if (kRP && a.L.EX <= 2 && !no_rp) {
+          if (a.L.EX <= 2) {
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mono_bwd_pair_x_k<3, NH, 2, kRP>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_pair);
             hipLaunchKernelGGL((mono_bwd_pair_x_k<3, NH, 2, kRP>), dim3(grid), dim3(64 * kWaves), lds_pair, s, a);
-          } else if (a.L.EX <= 2) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mono_bwd_pair_x_k<3, NH, 2>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_pair);
-            hipLaunchKernelGGL((mono_bwd_pair_x_k<3, NH, 2>), dim3(grid), dim3(64 * kWaves), lds_pair, s, a);
           } else {
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mono_bwd_pair_x_k<3, NH, 3>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_pair);
@@ -2348,7 +2334,6 @@ struct BwdPlan {
 // accumulates the hidden-layer weight gradients itself, nothing but Dsum is staged
 bool use_indw(const gnf_mono_net* net, const MonoLayout& L) {
   if (L.HT > 4 || L.NH < 2) return false;
-  if (L.HT == 4 && mono_wide_exp() && gnf_mono_bwd_wide_ok(L)) return false;      // (the two-role kernel takes it)
   for (int l = 1; l < L.NH; ++l)
     if (net->dims[l] >= L.HP) return false;
   const size_t lds = ((size_t)(L.total_floats + 3) / 4 * 4 + (size_t)kWaves * L.NH * 16 * kTS) * sizeof(float);

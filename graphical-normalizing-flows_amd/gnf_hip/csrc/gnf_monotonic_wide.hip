@@ -982,13 +982,10 @@ constexpr size_t kLds = 160 * 1024;
 }  // namespace
 
 bool gnf_mono_bwd_wide_ok(const gnfmono::MonoLayout& L) {
-  static const bool off = getenv("GNF_MONO_WIDE") && getenv("GNF_MONO_WIDE")[0] == '0';   // A/B switch (measurement)
-  if (off || L.c > 32) return false;
+  if (L.c > 32) return false;
 #define GNF_WIDE_CASE(HT_, NH_) \
   if (L.HT == HT_ && L.NH == NH_) return WidePlan<HT_, NH_>::total * sizeof(float) <= kLds;
   GNF_WIDE_CASE(7, 2) GNF_WIDE_CASE(7, 3) GNF_WIDE_CASE(7, 4) GNF_WIDE_CASE(10, 2) GNF_WIDE_CASE(10, 3)
-  static const bool exp4 = getenv("GNF_MONO_WIDE_EXP") && getenv("GNF_MONO_WIDE_EXP")[0] == '1';   // A/B on a narrow net (measurement)
-  if (exp4) { GNF_WIDE_CASE(4, 3) }
 #undef GNF_WIDE_CASE
   return false;
 }
@@ -1008,23 +1005,20 @@ extern "C" int gnf_debug_wide_stamps(unsigned long long* host, int enable) {
 int gnf_mono_bwd_wide_launch(const gnfmono::MonoArgs& a, unsigned grid, hipStream_t s) {
 #define GNF_WIDE_CASE(HT_, NH_) \
   if (a.L.HT == HT_ && a.L.NH == NH_) return launch_wide<HT_, NH_>(a, grid, s);
-  GNF_WIDE_CASE(7, 2) GNF_WIDE_CASE(7, 3) GNF_WIDE_CASE(7, 4) GNF_WIDE_CASE(10, 2) GNF_WIDE_CASE(10, 3) GNF_WIDE_CASE(4, 3)
+  GNF_WIDE_CASE(7, 2) GNF_WIDE_CASE(7, 3) GNF_WIDE_CASE(7, 4) GNF_WIDE_CASE(10, 2) GNF_WIDE_CASE(10, 3)
 #undef GNF_WIDE_CASE
   return GNF_ESHAPE;
 }
 
 bool gnf_mono_fwd_wide_ok(const gnfmono::MonoLayout& L) {
-  static const bool off = getenv("GNF_MONO_WIDE_FWD") && getenv("GNF_MONO_WIDE_FWD")[0] == '0';   // A/B switch (measurement)
-  if (off || L.c > 32 || L.NH < 2 || L.NH > 4) return false;
-  static const bool exp4 = getenv("GNF_MONO_WIDE_EXP") && getenv("GNF_MONO_WIDE_EXP")[0] == '1';   // A/B on a narrow net (measurement)
-  return L.HT == 7 || L.HT == 10 || (exp4 && L.HT == 4 && L.NH == 3 && L.o_Wf[1] > 0);
+  if (L.c > 32 || L.NH < 2 || L.NH > 4) return false;
+  return L.HT == 7 || L.HT == 10;
 }
 
 int gnf_mono_fwd_wide_launch(const gnfmono::MonoArgs& a, hipStream_t s) {
 #define GNF_WIDE_CASE(HT_, NH_) \
   if (a.L.HT == HT_ && a.L.NH == NH_) return launch_wide_fwd<HT_, NH_>(a, s);
   GNF_WIDE_CASE(7, 2) GNF_WIDE_CASE(7, 3) GNF_WIDE_CASE(7, 4) GNF_WIDE_CASE(10, 2) GNF_WIDE_CASE(10, 3) GNF_WIDE_CASE(10, 4)
-  GNF_WIDE_CASE(4, 3)
 #undef GNF_WIDE_CASE
   return GNF_ESHAPE;
 }

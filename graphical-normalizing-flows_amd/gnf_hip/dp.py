@@ -47,6 +47,13 @@ class FlatState:
         from . import ops
         ops.register_grad_slots(self, self.params)
 
+    def __del__(self):
+        try:
+            from . import ops
+            ops.unregister_grad_slots(self)
+        except Exception:                          # noqa: BLE001  (interpreter shutdown)
+            pass
+
     def pack_grads(self, grads=None):
         """flat gradient buffer <- the .grad tensors autograd just produced (or the given list, in self.params order).
         Gradients the backward kernels already wrote into their slot (ops.grad_out) stay where they are; the others are

@@ -31,7 +31,6 @@ def _ws(nbytes, like):
 # traffic per MADE step).  A slot is handed out once per pack: a parameter used twice in a graph, or a second micro-batch
 # accumulating into `.grad`, gets a fresh tensor and autograd adds it as usual.
 _grad_slots = {}                       # parameter data_ptr -> (weakref to the owning state, index into its params)
-_SINK = os.environ.get("GNF_GRAD_SINK", "1") != "0"      # A/B switch (measurement)
 
 
 def register_grad_slots(owner, params):
@@ -41,9 +40,17 @@ def register_grad_slots(owner, params):
         _grad_slots[p.data_ptr()] = (ref, i)
 
 
+def unregister_grad_slots(owner):
+    """drop the slots of `owner` (dp.FlatState.__del__ / close).  Lookups are safe without it -- a parameter of a live state
+    is a view of the state's own flat buffer, so its address cannot be handed to anybody else, and an entry whose owner has
+    died is deleted by the lookup that finds it -- but a dead state should not leave entries behind."""
+    for k in [k for k, (ref, _) in _grad_slots.items() if ref() is owner or ref() is None]:
+        del _grad_slots[k]
+
+
 def grad_out(p):
     """the tensor a backward writes the gradient of parameter (or saved alias of it) `p` into"""
-    ent = _grad_slots.get(p.data_ptr()) if _SINK else None
+    ent = _grad_slots.get(p.data_ptr())
     if ent is not None:
         owner = ent[0]()
         if owner is None:
@@ -75,7 +82,7 @@ def grad_out_shared(p, accumulate_ok=False):
     into -- that contribution gets a fresh tensor and autograd sums as usual.  finish(t) returns what the backward hands
     to autograd.  accumulate_ok: the caller's kernel can add into its output; a later contribution then gets the slot
     itself with accumulate = True (no scratch tensor, no add launch)."""
-    ent = _grad_slots.get(p.data_ptr()) if _SINK else None
+    ent = _grad_slots.get(p.data_ptr())
     owner = ent[0]() if ent is not None else None
     if owner is not None:
         i = ent[1]

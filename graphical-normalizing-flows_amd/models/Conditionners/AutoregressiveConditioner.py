@@ -44,8 +44,16 @@ class MaskedLinear(nn.Linear):
         return ops.mlp(input, [(self.weight, self.bias)], [self.mask], degs=[self.degree_spec()])
 
 
-def made_degrees(nin, hidden_sizes):
-    """Natural-ordering degrees of the reference MADE (random=False branch, :85-87)."""
+def made_degrees(nin, hidden_sizes, random=False, natural_ordering=False, rng=None):
+    """Degrees of the reference MADE (:79-87): the natural ordering with degrees nin - 1 - (i mod nin) (`random=False`, the
+    only form the reference's AutoregressiveConditioner builds), or a sampled ordering / connectivity drawn from `rng` exactly
+    as the reference draws it (input order: a permutation unless natural_ordering; hidden degrees uniform in
+    [min of the layer below, nin - 1))."""
+    if random:
+        m = {-1: np.arange(nin) if natural_ordering else rng.permutation(nin)}
+        for l, hsz in enumerate(hidden_sizes):
+            m[l] = rng.randint(m[l - 1].min(), nin - 1, size=hsz)
+        return m
     m = {-1: np.arange(nin)}
     for l, hsz in enumerate(hidden_sizes):
         m[l] = np.array([nin - 1 - (i % nin) for i in range(hsz)])
@@ -53,14 +61,13 @@ def made_degrees(nin, hidden_sizes):
 
 
 class MADE(nn.Module):
-    """Masked autoencoder with the reference's natural ordering (`random=False`),
-    AutoregressiveConditioner.py:28-109.  Output neurons are chunked component-major."""
+    """Masked autoencoder, reference AutoregressiveConditioner.py:28-109: natural ordering (`random=False`, what the
+    conditioner builds) or sampled orderings (`random=True`), cycling through `num_masks` seeds on update_masks().  Every
+    mask is a degree rule deg_in <= deg_out (< for the output layer), so the small-batch kernels evaluate it from the two
+    degree vectors whatever the ordering; output neurons are chunked component-major."""
 
     def __init__(self, nin, hidden_sizes, nout, num_masks=1, natural_ordering=False, random=False, device="cpu"):
         super().__init__()
-        if random or num_masks != 1:
-            raise NotImplementedError("only the natural-ordering single-mask MADE the reference's "
-                                      "AutoregressiveConditioner builds is supported")
         self.random = random
         self.nin = nin
         self.nout = nout
@@ -74,7 +81,7 @@ class MADE(nn.Module):
         self.net = nn.Sequential(*net)
         self.natural_ordering = natural_ordering
         self.num_masks = num_masks
-        self.seed = 0
+        self.seed = 0                                    # cycles through the num_masks orderings (reference :68)
         self.m = {}
         self.update_masks()
 
@@ -82,7 +89,9 @@ class MADE(nn.Module):
         if self.m and self.num_masks == 1:
             return
         L = len(self.hidden_sizes)
-        self.m = made_degrees(self.nin, self.hidden_sizes)
+        rng = np.random.RandomState(self.seed)           # (drawn from even when unused, as the reference does)
+        self.seed = (self.seed + 1) % self.num_masks
+        self.m = made_degrees(self.nin, self.hidden_sizes, self.random, self.natural_ordering, rng)
         masks = [self.m[l - 1][:, None] <= self.m[l][None, :] for l in range(L)]
         masks.append(self.m[L - 1][:, None] < self.m[-1][None, :])
         degs = [(self.m[l], self.m[l - 1], False) for l in range(L)]
@@ -93,6 +102,7 @@ class MADE(nn.Module):
         degs.append((deg_last, self.m[L - 1], True))
         for layer, mk, (do, di, strict) in zip(self.masked_layers(), masks, degs):
             layer.set_mask(mk, do, di, strict)
+        # position of input dimension k in the sampled order (a public attribute of the reference's class, :99-101)
         self.i_map = self.m[-1].copy()
         for k in range(len(self.m[-1])):
             self.i_map[self.m[-1][k]] = k

@@ -238,7 +238,19 @@ class DAGConditioner(Conditioner):
         # min(1., alpha) as a tensor op: Python's min() on a device tensor forces a host<->GPU sync every step
         alpha = torch.clamp(self.alpha, max=1.) * self.alpha_factor
         if self.hutchinson != 0:
-            raise NotImplementedError("Hutchinson trace estimator is never enabled by the reference")
+            # Hutchinson estimator of tr((I + alpha A o A)^d) (reference :179-190: `hutchinson` probe vectors e0 ~ N(0, I),
+            # d = in_size matrix-vector products each, trace ~ mean e0 . (B^d e0)).  No reference driver switches it on: plain
+            # torch ops on A's device, differentiable through autograd; the probes are `hutchinson_noise` ([h_iter, d], set by
+            # a caller that wants to reproduce a draw) or fresh torch.randn samples.
+            h_iter = int(self.hutchinson)
+            B = torch.eye(self.in_size, device=self.A.device) + alpha * self.A ** 2
+            noise = getattr(self, "hutchinson_noise", None)
+            E0 = (noise.to(self.A.device).t() if noise is not None
+                  else torch.randn(self.in_size, h_iter, device=self.A.device))          # the probes as columns
+            E = E0
+            for _ in range(self.in_size):
+                E = B @ E
+            return (E0 * E).sum() / h_iter - self.in_size
         B = (torch.eye(self.in_size, device=self.A.device) + alpha * self.A ** 2)
         return ops.PowerTraceFn.apply(B, self.exponent) - self.in_size
 

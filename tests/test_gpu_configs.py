@@ -771,15 +771,11 @@ def test_gradients_are_written_into_the_flat_buffer():
         dp.train_step(fa, sa, x, graph=graph)
         if graph is False:
             assert sa.pack_stats == {"in_place": len(sa.params), "copied": 0, "absent": 0}
-    old = ops._SINK
-    ops._SINK = False
-    try:
-        for graph in (False, "auto", "auto"):
-            dp.train_step(fb, sb, x, graph=graph)
-            if graph is False:
-                assert sb.pack_stats == {"in_place": 0, "copied": len(sb.params), "absent": 0}
-    finally:
-        ops._SINK = old
+    ops.unregister_grad_slots(sb)            # the second state without slots: its backward hands autograd fresh tensors
+    for graph in (False, "auto", "auto"):
+        dp.train_step(fb, sb, x, graph=graph)
+        if graph is False:
+            assert sb.pack_stats == {"in_place": 0, "copied": len(sb.params), "absent": 0}
     assert torch.equal(sa.flat, sb.flat) and torch.equal(sa.m, sb.m) and torch.equal(sa.v, sb.v)
 
     # a shared weight: y = L(relu(L(x))) with the same (W, b) twice
@@ -823,8 +819,10 @@ def test_shared_gradient_slot_of_the_dag_matrix():
         return f
     x = torch.randn(12, 6, device=DEV)
 
-    def run(flow):
+    def run(flow, slots=True):
         st = dp.FlatState(flow)
+        if not slots:
+            ops.unregister_grad_slots(st)        # this state's backward hands autograd fresh gradient tensors
         dp.train_step(flow, st, x, graph=False)
         stats = dict(st.pack_stats)
         for i in range(2):
@@ -833,12 +831,7 @@ def test_shared_gradient_slot_of_the_dag_matrix():
         return st, stats
     sa, stats = run(make())
     assert stats == {"in_place": len(sa.params), "copied": 0, "absent": 0}
-    old = ops._SINK
-    ops._SINK = False
-    try:
-        sb, _ = run(make())
-    finally:
-        ops._SINK = old
+    sb, _ = run(make(), slots=False)
     assert_close(sa.flat, sb.flat, rtol=1e-6, atol=1e-7, what="parameters (slots on / off)")
     assert_close(sa.m, sb.m, rtol=1e-5, atol=1e-8, what="first moments")
 

@@ -970,6 +970,59 @@ def test_loss_and_density_read_the_z_they_are_handed(norm_kind):
             fresh = moved
 
 
+def test_made_sampled_ordering_golden():
+    """MADE(random=True, num_masks=3) under its second mask set: h and every gradient against the reference's
+    (tests/golden/made_random.npz); the masks are degree rules, so the small-batch kernels evaluate them from the degrees."""
+    from models.Conditionners.AutoregressiveConditioner import MADE
+    g = load_golden("made_random")
+    cfg = [int(v) for v in g["perm.cfg"].tolist()]
+    net = MADE(cfg[0], cfg[4:], cfg[1], num_masks=cfg[2], natural_ordering=bool(cfg[3]), random=True)
+    net.load_state_dict({k[len("perm.p."):]: v for k, v in g.items() if k.startswith("perm.p.")}, strict=False)
+    net.update_masks()                                           # -> the second of the three orderings
+    net = net.to(DEV)
+    for k, layer in enumerate(net.masked_layers()):
+        assert torch.equal(layer.mask.cpu().to(torch.uint8), g["perm.mask1.%d" % k].to(torch.uint8))
+    x = req(g["perm.x"])
+    h = net(x)
+    assert_close(h, g["perm.h"], what="h")
+    (h * cu(g["perm.gh"])).sum().backward()
+    assert rel_err(x.grad.cpu(), g["perm.gx"]) < GTOL
+    for name, p in net.named_parameters():
+        assert rel_err(p.grad.cpu(), g["perm.g." + name]) < GTOL, name
+
+
+def test_dag_hutchinson_trace_estimator():
+    """DAGConditioner.get_power_trace with `hutchinson = h_iter` (reference DAGConditioner.py:179-190): with injected probe
+    vectors the estimate equals the reference expression evaluated in fp64; with its own draws it scatters around the exact
+    tr((I + alpha A o A)^d) - d; gradients reach A."""
+    from models import DAGConditioner
+    torch.manual_seed(4)
+    d = 6
+    c = DAGConditioner(d, [8, 8], 2).to(DEV)
+    with torch.no_grad():
+        c.A.copy_((torch.rand(d, d) * .9 * (1 - torch.eye(d))).to(DEV))
+    alpha = min(1., float(c.alpha)) * c.alpha_factor
+    Bm = torch.eye(d, dtype=torch.float64) + alpha * c.A.detach().cpu().double() ** 2
+    exact = torch.linalg.matrix_power(Bm, d).diagonal().sum().item() - d
+    c.hutchinson = 4
+    noise = torch.randn(4, d)
+    c.hutchinson_noise = noise
+    tr = c.get_power_trace()
+    e0 = noise.double().t()
+    ref = ((e0 * (torch.linalg.matrix_power(Bm, d) @ e0)).sum() / 4 - d).item()
+    assert abs(tr.item() - ref) < 1e-5 * max(1., abs(ref)), (tr.item(), ref)
+    tr.backward()
+    assert c.A.grad is not None and torch.isfinite(c.A.grad).all() and float(c.A.grad.abs().max()) > 0
+    c.hutchinson_noise = None
+    c.hutchinson = 4000
+    with torch.no_grad():
+        est = c.get_power_trace().item()
+    assert abs(est - exact) < .15 * max(1., abs(exact) + d), (est, exact)
+    c.hutchinson = 0
+    with torch.no_grad():
+        assert abs(c.get_power_trace().item() - (torch.linalg.matrix_power(Bm, c.exponent).diagonal().sum().item() - d)) < 1e-4
+
+
 def test_loss_calls_a_subclassed_base_density():
     """FCNormalizingFlow.loss folds the base density into its own launch only for the factories' NormalLogDensity itself: a
     subclass that overrides forward (a tempered density here) inherits the class attribute but must be CALLED, as the

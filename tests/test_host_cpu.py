@@ -263,3 +263,29 @@ def test_reference_factory_source_runs_unchanged_on_the_repo_classes():
     # the reference's density class on the reference's formula, beside the repo's (the one the restated factories build)
     z = torch.randn(5, 7)
     assert torch.allclose(ref.NormalLogDensity()(z), -.5 * (math.log(2 * math.pi) + z ** 2).sum(1), atol=1e-6)
+
+
+def test_made_sampled_orderings_cycle_like_the_reference():
+    """MADE(random=True, num_masks > 1) (reference AutoregressiveConditioner.py:70-101): the masks and the input-order map after
+    each of four consecutive update_masks() calls equal the reference's (tests/golden/made_random.npz, written by
+    make_golden_made_random.py from the reference itself), for a permuted and for the natural input order; every mask is
+    the degree rule the small-batch kernels evaluate instead of reading it."""
+    from conftest import load_golden
+    from models.Conditionners.AutoregressiveConditioner import MADE
+    g = load_golden("made_random")
+    for tag in ("perm", "nat"):
+        cfg = [int(v) for v in g[tag + ".cfg"].tolist()]
+        nin, nout, num_masks, natural, hidden = cfg[0], cfg[1], cfg[2], bool(cfg[3]), cfg[4:]
+        net = MADE(nin, hidden, nout, num_masks=num_masks, natural_ordering=natural, random=True)
+        for call in range(4):
+            if call:
+                net.update_masks()
+            for k, layer in enumerate(net.masked_layers()):
+                assert torch.equal(layer.mask.to(torch.uint8), g["%s.mask%d.%d" % (tag, call, k)].to(torch.uint8)), (tag, call, k)
+                assert layer.degree_spec() is not None, (tag, call, k)
+            assert np.array_equal(np.asarray(net.i_map), g["%s.imap%d" % (tag, call)].numpy()), (tag, call)
+    # the conditioner's own form is unchanged: natural ordering, one mask set, update_masks() a no-op
+    net = MADE(4, [8, 8], 8)
+    before = [l.mask.clone() for l in net.masked_layers()]
+    net.update_masks()
+    assert all(torch.equal(a, l.mask) for a, l in zip(before, net.masked_layers()))

@@ -1,6 +1,6 @@
 """Small-batch Linear kernels (gnf_linear.hip) at the MADE layer shape of BASELINE cfg3 (100 x 1024 x 1024, GNF_LIN_SHAPE=M,N,K
 for others): HIP-event time of each entry point with the mask as a degree rule / a tensor / absent, against the bytes a
-layer has to stream (weights once per product: 4 N K).  GNF_LINEAR_BWD_SPLIT=1 runs the two gradients as two launches.
+layer has to stream (weights once per product: 4 N K).
 python tools/bench_linear.py"""
 import os, sys, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

@@ -18,7 +18,7 @@ GNF_MONO_SHAPE=10000,6,30,20 PMC_SKIP=5 python tools/pmc_run.py "mono_" $out/${t
 PMC_SKIP=20 PMC_PASSES="GRBM_GUI_ACTIVE;SQ_BUSY_CU_CYCLES,SQ_VALU_MFMA_BUSY_CYCLES" python tools/pmc_run.py "gemm_" $out/${tag}_gemm_clock_pmc.json -- python3 tools/prof_gemm.py 40 > /dev/null 2>&1
 ( bash tools/kstats.sh ${tag}_lin_kt tools/bench_linear.py | grep "lin_" ) > $out/${tag}_linear_kernels.txt 2>&1
 python tools/bench_linear.py >> $out/${tag}_linear_kernels.txt 2>&1
-( GNF_MONO_SHAPE=10000,6,30,20 python tools/bench_mono.py 100; GNF_MONO_SHAPE=50000,63,30,20 python tools/bench_mono.py 150; GNF_MONO_WIDE=0 GNF_MONO_WIDE_FWD=0 GNF_MONO_SHAPE=50000,63,30,20 python tools/bench_mono.py 150; GNF_MONO_WIDE=0 GNF_MONO_WIDE_FWD=0 GNF_MONO_SHAPE=10000,6,30,20 python tools/bench_mono.py 100 ) 2>/dev/null | grep "H=" > $out/${tag}_mono_wide_vs_staged.txt
+( GNF_MONO_SHAPE=10000,6,30,20 python tools/bench_mono.py 100; GNF_MONO_SHAPE=50000,63,30,20 python tools/bench_mono.py 150 ) 2>/dev/null | grep "H=" > $out/${tag}_mono_wide.txt
 python tools/bench_sampling.py 2>/dev/null | grep -v amdgpu > $out/${tag}_sampling_run.txt
-python tools/bench_fc1.py 2>/dev/null | grep ms > $out/${tag}_fc1_gemms.txt
+python tools/bench_fc1_split.py 2>/dev/null | grep ms > $out/${tag}_fc1_gemms.txt
 ls -la $out/${tag}_*
