@@ -59,6 +59,7 @@ SIGNATURES = {
     "gnf_linear_gxsum_fused": (c_int, [c_i64, c_i64, c_i64, c_int]),
     "gnf_gemm_last_kernel": (ctypes.c_char_p, []),
     "gnf_gemm_ws_bytes": (c_i64, [c_i64, c_i64, c_i64]),
+    "gnf_gemm_f32_ws_bytes": (c_i64, [c_i64, c_i64, c_i64]),
     "gnf_gemm": (c_int, [c_f, c_i64, c_i64, c_f, c_f, c_i64, c_i64, c_f, c_i64, c_i64, c_f, c_f, c_i64, c_i64, c_f,
                          c_i64, c_i64, c_int, c_i64, c_i64, c_i64, c_f, c_i64, c_stream]),
     "gnf_gemm_split_ws_bytes": (c_i64, [c_i64, c_i64, c_i64]),

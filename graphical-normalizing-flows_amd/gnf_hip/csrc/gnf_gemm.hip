@@ -892,10 +892,16 @@ static int plan_splits(int64_t M, int64_t N, int64_t K, bool kmajor_ok = true) {
 }
 
 // (sized without knowing the strides: the larger of the k-major plan and the generic one)
-extern "C" int64_t gnf_gemm_ws_bytes(int64_t M, int64_t N, int64_t K) {
+// what the fp32-MFMA kernels of this file want for their split-K partials (measurement / tests: a workspace of exactly this size
+// keeps a call on the fp32 kernels where gnf_gemm_ws_bytes would also admit the split-bf16 ones)
+extern "C" int64_t gnf_gemm_f32_ws_bytes(int64_t M, int64_t N, int64_t K) {
   const int a = plan_splits(M, N, K, true), b = plan_splits(M, N, K, false);
   const int s = a > b ? a : b;
-  const int64_t w = s > 1 ? (int64_t)(s + 1) * M * N * (int64_t)sizeof(float) : 0;     // partials + one row for their sum
+  return s > 1 ? (int64_t)(s + 1) * M * N * (int64_t)sizeof(float) : 0;     // partials + one row for their sum
+}
+
+extern "C" int64_t gnf_gemm_ws_bytes(int64_t M, int64_t N, int64_t K) {
+  const int64_t w = gnf_gemm_f32_ws_bytes(M, N, K);
   // the split-bf16 kernels' pre-split planes of the small operand (round 6), when the switch is on
   const int64_t w2 = gnf_gemm_split_enabled() ? gnf_gemm_split_ws_bytes(M, N, K) : 0;
   return w > w2 ? w : w2;
@@ -926,7 +932,7 @@ extern "C" int gnf_gemm(const float* A, int64_t sam, int64_t sak, const float* B
                      !bias && !Bmask && !Cmask && !gate && !(flags & GNF_GEMM_RELU) &&
                      (((uintptr_t)A | (uintptr_t)B) & 15) == 0;
   const int splits = plan_splits(M, N, K, km_ok);
-  if (splits > 1 && ws && ws_bytes >= gnf_gemm_ws_bytes(M, N, K)) {
+  if (splits > 1 && ws && ws_bytes >= gnf_gemm_f32_ws_bytes(M, N, K)) {
     GemmArgs p = g;                       // partial products only: epilogue runs in the reduction
     p.C = ws; p.scm = N; p.scn = 1; p.c_split_stride = M * N;
     p.bias = nullptr; p.Cmask = nullptr; p.gate = nullptr; p.flags = 0;

@@ -439,6 +439,142 @@ __global__ __launch_bounds__(512) void gemm_split_wide_k(WideArgs g) {
   }
 }
 
+// ---- M <= 128, wide N, very long K, both operands k-major (MNISTCNN.fc1 weight gradient: 128 x 2304 x 78 400) ------------------
+// C[M x N] = A[K x M]^T B[K x N].  The SMALL operand A (the gated cotangent of fc1's output: 40 MB against 722 MB) is pre-split
+// into fragment-major planes by split_pack_b_k -- which also does its transposition: a fragment holds 8 consecutive k of one
+// m -- and streams from L2 as the other two kernels' B fragments do.  One 8-wavefront workgroup per (128-column tile, K range):
+// stages of 64 k-rows of B arrive as four fp32 float4s per thread (rows 4 kg .. +3 at columns 4 ng .. +3: a wave-level request
+// is eight rows x 128 B), and the (hi, mid, lo) split TRANSPOSES for free -- v_cvt_pk_bf16_f32 packs rows (k, k+1) of one
+// column -- into planes [n][64 k] (row pitch 160 B: conflict-free ds_read_b128 fragments; the ds_write_b64 of a 16-lane
+// group are 2-way, hidden behind their 6-cycle issue).  Two LDS stages, one barrier per stage; wavefront (wm, wn) of a 4 x 2
+// grid owns 2 x 4 tiles; the operands are swapped as in the wide kernel (a lane holds four consecutive columns: float4
+// stores); per-range partials are summed in a fixed order by split_reduce_k.
+// Rows k >= K read as zeros from A's planes (the pack pads) while B's row index is clamped: B must be finite.
+constexpr int KM_BN = 128, KM_SK = 64, KM_PITCH = 160, KM_PLANE = KM_BN * KM_PITCH, KM_STAGE = 3 * KM_PLANE;
+constexpr int KM_LDS = 2 * KM_STAGE;                                       // 122 880 B
+
+struct KmArgs {
+  const u32x4* Ap;                  // [3][nslab][8][64]
+  const float* B; int64_t sbk;
+  float* part;                      // [splits][M][N]
+  int64_t M, N, K;
+  int nslab;                        // K-slabs of 32 in A's planes (padded to whole K ranges)
+  int stages_per_split;             // stages of 64 k per K range (even)
+};
+
+__global__ __launch_bounds__(512) void gemm_split_kmajor_k(KmArgs g) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6), wm = wave >> 1, wn = wave & 1;
+  const int ntn = (int)(g.N / KM_BN);
+  const int nt0 = blockIdx.x % ntn, z = blockIdx.x / ntn;
+  const int64_t n0 = (int64_t)nt0 * KM_BN;
+  const int64_t st0 = (int64_t)z * g.stages_per_split;                     // first stage (of 64 k) of this K range
+  const int64_t plane_sz = (int64_t)g.nslab * 8 * 64;
+  // B loader: lane (kg, ng) of wavefront w: k rows 4 (8 (w & 1) + (lane & 7)) .. + 3, columns 4 (8 (w >> 1) + (lane >> 3)) .. + 3
+  const int kg = 8 * (wave & 1) + (lane & 7), ng = 8 * (wave >> 1) + (lane >> 3);
+  const float* bcol = g.B + n0 + 4 * ng;
+  const int woff = (4 * ng) * KM_PITCH + 8 * kg;                          // byte offset of (n = 4 ng, k = 4 kg) in a plane
+  f32x4 breg[2][4];
+  auto load_b = [&](int64_t stage, f32x4 (&b)[4]) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      int64_t k = stage * KM_SK + 4 * kg + i;
+      k = k < g.K ? k : g.K - 1;                                           // (A's planes are zero there)
+      b[i] = *reinterpret_cast<const f32x4*>(bcol + k * g.sbk);
+    }
+  };
+  auto store_b = [&](int buf, const f32x4 (&b)[4]) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      unsigned h0, m0, l0, h1, m1, l1;
+      split3_pair(b[0][e], b[1][e], h0, m0, l0);
+      split3_pair(b[2][e], b[3][e], h1, m1, l1);
+      unsigned char* base = lds + buf * KM_STAGE + woff + e * KM_PITCH;
+      *reinterpret_cast<u32x2*>(base) = u32x2{h0, h1};
+      *reinterpret_cast<u32x2*>(base + KM_PLANE) = u32x2{m0, m1};
+      *reinterpret_cast<u32x2*>(base + 2 * KM_PLANE) = u32x2{l0, l1};
+    }
+  };
+  u32x4 areg[2][2][3];
+  auto load_a = [&](int64_t slab, u32x4 (&a)[2][3]) {
+    const int64_t sl = slab < g.nslab ? slab : g.nslab - 1;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int p = 0; p < 3; ++p) a[i][p] = g.Ap[p * plane_sz + (sl * 8 + 2 * wm + i) * 64 + lane];
+  };
+  f32x4 acc[2][2][4];
+#pragma unroll
+  for (int c = 0; c < 2; ++c)
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[c][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  load_b(st0, breg[0]);
+  load_b(st0 + 1, breg[1]);
+  load_a(2 * st0, areg[0]);
+  load_a(2 * st0 + 1, areg[1]);
+  store_b(0, breg[0]);
+  __syncthreads();
+  const int frag = (16 * (4 * wn) + (lane & 15)) * KM_PITCH + 16 * (lane >> 4);
+  for (int s0 = 0; s0 < g.stages_per_split; s0 += 2) {
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int64_t st = st0 + s0 + u;
+      __builtin_amdgcn_sched_barrier(0);
+      load_b(st + 2, breg[u]);                                   // slot u held stage st: in LDS since the previous iteration
+      __builtin_amdgcn_sched_barrier(0);
+      const unsigned char* stage = lds + u * KM_STAGE + frag;
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const unsigned char* bp = stage + j * 16 * KM_PITCH + 64 * ks;
+          const bf16x8 bh = as_bf16x8(*reinterpret_cast<const u32x4*>(bp));
+          const bf16x8 bm = as_bf16x8(*reinterpret_cast<const u32x4*>(bp + KM_PLANE));
+          const bf16x8 bl = as_bf16x8(*reinterpret_cast<const u32x4*>(bp + 2 * KM_PLANE));
+#pragma unroll
+          for (int i = 0; i < 2; ++i) {
+            const bf16x8 ah = as_bf16x8(areg[ks][i][0]), am = as_bf16x8(areg[ks][i][1]), al = as_bf16x8(areg[ks][i][2]);
+            f32x4 r = acc[1][i][j];                              // (B fragment first: a lane holds four consecutive columns)
+            r = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh, al, r, 0, 0, 0);
+            r = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bl, ah, r, 0, 0, 0);
+            r = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bm, am, r, 0, 0, 0);
+            r = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh, am, r, 0, 0, 0);
+            r = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bm, ah, r, 0, 0, 0);
+            acc[1][i][j] = r;
+            acc[0][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh, ah, acc[0][i][j], 0, 0, 0);
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        load_a(2 * (st + 1) + ks, areg[ks]);                     // the same K-slab of the NEXT stage
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      store_b((u + 1) & 1, breg[(u + 1) & 1]);                   // stage st + 1 into the other LDS stage
+      __syncthreads();
+    }
+  }
+  float* part = g.part + (int64_t)z * g.M * g.N;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int64_t m = 16 * (2 * wm + i) + (lane & 15);
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      if (m < g.M) *reinterpret_cast<f32x4*>(part + m * g.N + n0 + 16 * (4 * wn + j) + 4 * (lane >> 4)) = acc[0][i][j] + acc[1][i][j];
+  }
+}
+
+// C[i] = sum_z part[z][i] in ascending z (deterministic), float4
+__global__ __launch_bounds__(256) void split_reduce_k(const float* __restrict__ part, int splits, int64_t n4, int64_t stride4,
+                                                      f32x4* __restrict__ C, int64_t scm4, int64_t n4_per_row) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n4) return;
+  const f32x4* p = reinterpret_cast<const f32x4*>(part) + i;
+  f32x4 s = p[0];
+  for (int z = 1; z < splits; ++z) s += p[(int64_t)z * stride4];
+  C[(i / n4_per_row) * scm4 + i % n4_per_row] = s;
+}
+
 }  // namespace
 
 static thread_local const char* g_split_last = "";
@@ -455,9 +591,29 @@ static bool wide_eligible(int64_t sam, int64_t sak, int64_t scm, int64_t scn, co
          (((uintptr_t)A | (uintptr_t)C) & 15) == 0 && N < (1 << 20);
 }
 
+static bool kmajor_shape(int64_t M, int64_t N, int64_t K) { return M <= 128 && M >= 16 && N % KM_BN == 0 && N >= 512 && K >= 16384; }
+static int kmajor_splits(int64_t N, int64_t K) {
+  int64_t s = 256 / (N / KM_BN);
+  if (s > K / 1024) s = K / 1024;
+  return (int)(s < 1 ? 1 : s);
+}
+static int64_t kmajor_stages(int64_t N, int64_t K) {                        // stages of 64 k per K range, even
+  const int splits = kmajor_splits(N, K);
+  return ((K + splits - 1) / splits + 127) / 128 * 2;
+}
+static bool kmajor_eligible(int64_t sam, int64_t sbk, int64_t sbn, int64_t scm, int64_t scn, const float* B, const float* C, int64_t M,
+                            int64_t N, int64_t K) {
+  return kmajor_shape(M, N, K) && sam == 1 && sbn == 1 && scn == 1 && sbk % 4 == 0 && scm % 4 == 0 &&
+         (((uintptr_t)B | (uintptr_t)C) & 15) == 0;
+}
+
 // bytes of workspace the dedicated kernels of this shape want (0: only the general kernel applies, no workspace)
 extern "C" int64_t gnf_gemm_split_ws_bytes(int64_t M, int64_t N, int64_t K) {
   int64_t w = 0;
+  if (kmajor_shape(M, N, K)) {                                              // k-major: A planes + the partials of the K ranges
+    const int64_t splits = kmajor_splits(N, K), nslab = splits * kmajor_stages(N, K) * 2;
+    w = 3 * nslab * 8 * 64 * 16 + splits * M * N * 4;
+  }
   if (K == WD_K && N % 128 == 0 && N >= 512 && M >= 64 * WD_BM) w = 3 * 4 * (N / 16) * 64 * 16 + 16 * N * 4;         // wide: B planes + dummy rows
   if (N <= 128 && N > 64 && K % (4 * KS) == 0 && K >= 8 * KS && M >= 64 * TL_BM) w = 3 * (K / KS) * 8 * 64 * 16;      // tall: B planes
   return w;
@@ -493,6 +649,27 @@ extern "C" int gnf_gemm_split_bf16(const float* A, int64_t sam, int64_t sak, con
       hipLaunchKernelGGL(gemm_split_tall_k, dim3((unsigned)((M + TL_BM - 1) / TL_BM)), dim3(TL_THREADS), TL_LDS, s, t);
       GNF_LAUNCH_CHECK();
       g_split_last = "gemm_split_tall_k";
+      return 0;
+    }
+    if (!bias && !relu && kmajor_eligible(sam, sbk, sbn, scm, scn, B, C, M, N, K)) {
+      const int splits = kmajor_splits(N, K);
+      const int stages = (int)kmajor_stages(N, K), nslab = splits * stages * 2;
+      const int64_t frags = (int64_t)nslab * 8 * 64;
+      // A[m][k] at m * sam + k * sak is the pack kernel's "B[k][n]" with n = m
+      hipLaunchKernelGGL(split_pack_b_k, dim3((unsigned)((frags + 255) / 256)), dim3(256), 0, s, A, sak, sam, (int)M, (int)K, 8,
+                         nslab, (u32x4*)ws);
+      GNF_LAUNCH_CHECK();
+      float* part = (float*)((char*)ws + 3 * frags * 16);
+      KmArgs ka{(const u32x4*)ws, B, sbk, part, M, N, K, nslab, stages};
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_split_kmajor_k), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                KM_LDS);
+      hipLaunchKernelGGL(gemm_split_kmajor_k, dim3((unsigned)((N / KM_BN) * splits)), dim3(512), KM_LDS, s, ka);
+      GNF_LAUNCH_CHECK();
+      const int64_t n4 = M * N / 4;
+      hipLaunchKernelGGL(split_reduce_k, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, part, splits, n4, n4, (f32x4*)C,
+                         scm / 4, N / 4);
+      GNF_LAUNCH_CHECK();
+      g_split_last = "gemm_split_kmajor_k";
       return 0;
     }
     if (!bias && !relu && wide_eligible(sam, sak, scm, scn, A, C, M, N, K)) {
@@ -536,6 +713,7 @@ int gnf_gemm_split_try(const float* A, int64_t sam, int64_t sak, const float* B,
   if (need <= 0 || ws_bytes < need) return 1;
   const bool tall = tall_eligible(sam, sak, sbk, scn, A, M, N, K);
   const bool wide = !bias && !relu && wide_eligible(sam, sak, scm, scn, A, C, M, N, K);
-  if (!tall && !wide) return 1;
+  const bool kmaj = !bias && !relu && kmajor_eligible(sam, sbk, sbn, scm, scn, B, C, M, N, K);
+  if (!tall && !wide && !kmaj) return 1;
   return gnf_gemm_split_bf16(A, sam, sak, B, sbk, sbn, C, scm, scn, bias, relu, M, N, K, 0, 1, 0, ws, ws_bytes, (gnf_stream_t)s);
 }

@@ -140,6 +140,9 @@ int gnf_linear_gxsum_fused(int64_t M, int64_t N, int64_t K, int masked);
  * dispatched to -- "gemm_tall_k", "gemm_wide_k", "gemm_kmajor_k", "gemm_vec_k<128,128>", ...: measurement and tests only. */
 const char* gnf_gemm_last_kernel(void);
 int64_t gnf_gemm_ws_bytes(int64_t M, int64_t N, int64_t K);
+/* the share of gnf_gemm_ws_bytes the fp32-MFMA kernels' split-K partials need: a workspace of exactly this size keeps a call on
+ * the fp32 kernels (measurement / tests) where the full size also admits the split-bf16 kernels below */
+int64_t gnf_gemm_f32_ws_bytes(int64_t M, int64_t N, int64_t K);
 int gnf_gemm(const float* A, int64_t sam, int64_t sak,
              const float* B, const float* Bmask, int64_t sbk, int64_t sbn,
              float* C, int64_t scm, int64_t scn,

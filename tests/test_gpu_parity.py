@@ -212,10 +212,22 @@ def test_gemm_kmajor_split_k_path(M, N, K):
     from gnf_hip import ops
     torch.manual_seed(M + N + K)
     dY, X = torch.randn(K, M, device=DEV), torch.randn(K, N, device=DEV)
-    C = torch.full((M, N), float("nan"), device=DEV)
-    ops.gemm(dY, (1, M), X, (N, 1), C, (N, 1), M, N, K)
-    assert _last_gemm_kernel() == "gemm_kmajor_k", _last_gemm_kernel()
+    from gnf_hip import abi
+    from gnf_hip.abi import ptr, call, stream
+    lib = abi.load()
     ref = dY.double().t() @ X.double()
+    C = torch.full((M, N), float("nan"), device=DEV)
+    # the fp32-MFMA kernel: a workspace of exactly its split-K partials (too small for the split-bf16 dispatch of round 6;
+    # what GNF_TRUE_F32=1 runs), then the product's dispatch through ops.gemm
+    nws = int(lib.gnf_gemm_f32_ws_bytes(M, N, K))
+    w = torch.empty(nws // 4, device=DEV)
+    call("gnf_gemm", ptr(dY), 1, M, ptr(X), None, N, 1, ptr(C), N, 1, None, None, 0, 0, None, 0, 0, 0, M, N, K, ptr(w), nws, stream())
+    assert _last_gemm_kernel() == "gemm_kmajor_k", _last_gemm_kernel()
+    assert rel_err(C.cpu(), ref.cpu()) < 2e-6
+    C.fill_(float("nan"))
+    ops.gemm(dY, (1, M), X, (N, 1), C, (N, 1), M, N, K)
+    split = lib.gnf_gemm_split_enabled() and N % 128 == 0 and M >= 16
+    assert _last_gemm_kernel() == ("gemm_split_kmajor_k" if split else "gemm_kmajor_k"), _last_gemm_kernel()
     assert rel_err(C.cpu(), ref.cpu()) < 2e-6
     dYw, Xw = torch.randn(K, M + 4, device=DEV), torch.randn(K, N + 8, device=DEV)
     C2 = torch.full((M, N), float("nan"), device=DEV)
@@ -273,7 +285,7 @@ def test_gemm_operand_beyond_4_GiB_on_the_generic_kernels():
     G = torch.randn(M, 16, device=DEV)
     D = torch.full((16, K), float("nan"), device=DEV)
     ops.gemm(G, (1, 16), A, (K, 1), D, (K, 1), 16, K, M)
-    assert _last_gemm_kernel() == "gemm_kmajor_k"
+    assert _last_gemm_kernel() in ("gemm_kmajor_k", "gemm_split_kmajor_k")
     assert rel_err(D.cpu(), (G.double().t() @ A.double()).cpu()) < 1e-5      # 600 000 fp32 terms per entry: 3.7e-6 measured
 
 

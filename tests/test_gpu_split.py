@@ -14,10 +14,12 @@ DEV = "cuda:0"
 
 
 def _f32(A, sa, B, sb, M, N, K, bias=None, relu=False, ws=False):
-    """gnf_gemm: with ws=False the single-pass fp32-MFMA kernels (no workspace -> no split-bf16 dispatch, no split-K)"""
+    """gnf_gemm: ws=False -> a workspace of exactly gnf_gemm_f32_ws_bytes (the fp32-MFMA kernels with their split-K partials: too
+    small for the split-bf16 dispatch; what GNF_TRUE_F32=1 runs); ws=True -> the full gnf_gemm_ws_bytes (the product's call)"""
     C = torch.empty(M, N, device=DEV)
     lib = abi.load()
-    nws = int(lib.gnf_gemm_ws_bytes(M, N, K)) if ws else 0
+    nws = int(lib.gnf_gemm_ws_bytes(M, N, K)) if ws else int(lib.gnf_gemm_f32_ws_bytes(M, N, K))
+    ws = ws or nws > 0
     w = torch.empty(max(nws // 4, 1), device=DEV) if ws else None
     call("gnf_gemm", ptr(A), sa[0], sa[1], ptr(B), None, sb[0], sb[1], ptr(C), N, 1, ptr(bias), None, 0, 0, None, 0, 0,
          1 if relu else 0, M, N, K, ptr(w), nws, stream())
@@ -84,6 +86,34 @@ def test_split_wide_kernel_vs_fp64_and_fp32_mfma(M, N):
     assert torch.equal(Cs, Cs2)
 
 
+@pytest.mark.parametrize("M,N,K", [(128, 2304, 78400),        # cfg4 fc1 weight gradient
+                                   (64, 512, 20001),          # M < 128 (zero-padded planes), K neither a multiple of 64 nor of the ranges
+                                   (112, 640, 33000), (128, 1280, 16384)])
+def test_split_kmajor_kernel_vs_fp64_and_fp32_mfma(M, N, K):
+    torch.manual_seed(M + N + K)
+    G, X = torch.randn(K, M, device=DEV), torch.randn(K, N, device=DEV)
+    ref = G.double().t() @ X.double()
+    Cs, ks = _split(G, (1, M), X, (N, 1), M, N, K)
+    Cf, kf = _f32(G, (1, M), X, (N, 1), M, N, K)
+    assert ks == "gemm_split_kmajor_k" and kf == "gemm_kmajor_k", (ks, kf)
+    es, ef = _errs(Cs, ref), _errs(Cf, ref)
+    assert es[0] <= ef[0] and es[1] <= ef[1], (es, ef)
+    assert es[0] < 6e-6 and es[1] < 1e-6, es
+    Cs2, _ = _split(G, (1, M), X, (N, 1), M, N, K)
+    assert torch.equal(Cs, Cs2)
+    # strided rows of both operands and of C (views into wider buffers)
+    Gw, Xw = torch.randn(K, M + 4, device=DEV), torch.randn(K, N + 8, device=DEV)
+    Cw = torch.zeros(M, N + 4, device=DEV)
+    lib = abi.load()
+    nws = int(lib.gnf_gemm_split_ws_bytes(M, N, K))
+    w = torch.empty(nws, dtype=torch.uint8, device=DEV)
+    call("gnf_gemm_split_bf16", ptr(Gw), 1, M + 4, ptr(Xw), N + 8, 1, ptr(Cw), N + 4, 1, None, 0, M, N, K, 0, 1, 0, abi.rawptr(w), nws,
+         stream())
+    assert lib.gnf_gemm_split_last_kernel().decode() == "gemm_split_kmajor_k"
+    refw = Gw[:, :M].double().t() @ Xw[:, :N].double()
+    assert _errs(Cw[:, :N], refw)[0] < 6e-6 and float(Cw[:, N:].abs().max()) == 0.
+
+
 def test_gnf_gemm_routes_the_fc1_shapes_to_the_split_kernels_and_honours_the_switch():
     """gnf_gemm with its workspace: the fc1 forward / data-gradient shapes run on the split kernels (the product path of
     MLPFn -> gnf_linear_* -> gnf_gemm); without a workspace, with an epilogue the split kernels do not have, or for a shape
@@ -104,6 +134,9 @@ def test_gnf_gemm_routes_the_fc1_shapes_to_the_split_kernels_and_honours_the_swi
     assert k2 == "gemm_split_wide_k", k2
     _, k3 = _f32(X, (K, 1), W, (1, K), M, F, K, ws=False)
     assert "split" not in k3, k3
+    Gk, Xk = torch.randn(20000, 128, device=DEV), torch.randn(20000, 1024, device=DEV)
+    _, k5 = _f32(Gk, (1, 128), Xk, (1024, 1), 128, 1024, 20000, ws=True)
+    assert k5 == "gemm_split_kmajor_k", k5
     _, k4 = _f32(X[:4096], (K, 1), W, (1, K), 4096, F, K, ws=True)        # too few rows for the 160-row blocks
     assert "split" not in k4, k4
     code = ("import sys; sys.path[:0] = %r; import torch; from gnf_hip import abi; "
@@ -132,13 +165,13 @@ def test_split_general_kernel_random_shapes_vs_fp64(seed):
 
 
 def test_mnistcnn_fc1_runs_on_the_split_kernels_in_the_product_path():
-    """MLPFn on the fc1 shape of the headline model: forward and data gradient dispatch to the split kernels (the weight
-    gradient stays on gemm_kmajor_k), values and gradients against an fp64 autograd at the usual tolerances."""
+    """MLPFn on the fc1 shape of the headline model: forward, data gradient and weight gradient dispatch to the split kernels,
+    values and gradients against an fp64 autograd at the usual tolerances."""
     lib = abi.load()
     if not lib.gnf_gemm_split_enabled():
         pytest.skip("GNF_TRUE_F32=1")
     torch.manual_seed(0)
-    M, K, F = 15680, 2304, 128
+    M, K, F = 17920, 2304, 128                           # (>= 16 384 rows: the weight gradient's long K)
     x = torch.randn(M, K, device=DEV, requires_grad=True)
     W = (torch.randn(F, K, device=DEV) / 48.).requires_grad_(True)
     b = torch.randn(F, device=DEV, requires_grad=True)
@@ -149,6 +182,7 @@ def test_mnistcnn_fc1_runs_on_the_split_kernels_in_the_product_path():
         orig(name, *args)
         if name.startswith("gnf_linear"):
             seen.append(lib.gnf_gemm_last_kernel().decode())
+            seen.append(lib.gnf_gemm_split_last_kernel().decode())
     ops.call = spy
     try:
         y = ops.mlp(x, [(W, b)])

@@ -19,18 +19,18 @@ lib = abi.load()
 
 
 def f32(A, sa, B, sb, M, N, K, bias=None, relu=False):
-    """the fp32-MFMA kernels: the single-pass ones (fc1 forward / data gradient) through a gnf_gemm call WITHOUT workspace --
-    with one, gnf_gemm dispatches these shapes to the split kernels since round 6 (this is what GNF_TRUE_F32=1 runs) --, the
-    split-K weight gradient through ops.gemm"""
+    """the fp32-MFMA kernels: gnf_gemm with a workspace of exactly gnf_gemm_f32_ws_bytes -- the split-K partials of the weight
+    gradient, nothing for the two single-pass kernels --, which is too small for the split-bf16 dispatch of round 6 (this is
+    what GNF_TRUE_F32=1 runs)"""
     C = torch.empty(M, N, device=dev)
-    if M <= 128:
-        ops.gemm(A, sa, B, sb, C, C.stride(), M, N, K, bias=bias, relu=relu)
-    else:
-        call("gnf_gemm", ptr(A), sa[0], sa[1], ptr(B), None, sb[0], sb[1], ptr(C), N, 1, ptr(bias), None, 0, 0, None, 0, 0,
-             1 if relu else 0, M, N, K, None, 0, stream())
+    n = int(lib.gnf_gemm_f32_ws_bytes(M, N, K))
+    ws = _wsf.setdefault(n, torch.empty(max(n // 4, 1), device=dev))
+    call("gnf_gemm", ptr(A), sa[0], sa[1], ptr(B), None, sb[0], sb[1], ptr(C), N, 1, ptr(bias), None, 0, 0, None, 0, 0,
+         1 if relu else 0, M, N, K, ptr(ws) if n else None, n, stream())
     return C
 
 
+_wsf = {}
 _ws = {}
 
 
