@@ -14,7 +14,7 @@ from _warm import warm_gpu  # noqa: E402
 from models import MonotonicNormalizer  # noqa: E402
 
 DEV = "cuda:0"
-HBM_PEAK, F32_PEAK = 8000., 157.3       # GB/s (spec), TFLOP/s (fp32 MFMA)
+HBM_PEAK, F32_PEAK, BF16_PEAK = 8000., 157.3, 2500.   # GB/s (spec), TFLOP/s (fp32 MFMA), TFLOP/s (dense bf16 MFMA)
 
 
 def timeit(fn, n=20, warm=3):
@@ -55,6 +55,23 @@ def hbm(name, shape, ms, nbytes):
                  "frac_of_8TBps": round(gbs / HBM_PEAK, 3)})
 
 
+def b2b(fn, n=50, reps=9):
+    """milliseconds per launch with `n` launches per HIP-event pair (launches pipeline; an event pair around ONE launch on an
+    otherwise idle stream includes ~6 us of launch + ramp that an EMPTY grid of the same shape also takes)"""
+    warm_gpu(.15)
+    ts = []
+    for _ in range(reps):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(n):
+            fn()
+        b.record()
+        torch.cuda.synchronize()
+        ts.append(a.elapsed_time(b) / n)
+    ts.sort()
+    return ts[len(ts) // 2]
+
+
 def mfma(name, shape, ms, flops, direct=None):
     """flops = what the kernel must execute in the algorithm it implements; direct = the direct-convolution count of
     SURVEY.md 8(d) for the Winograd kernels (reported beside it, never as the fraction: it exceeds 1)"""
@@ -70,6 +87,8 @@ def mfma(name, shape, ms, flops, direct=None):
 
 def main():
     torch.manual_seed(0)
+    global lib0
+    lib0 = abi.load()
     # ---- Affine normalizer (16 B/elem fwd, 28 B/elem bwd)
     for B, d in [(100, 784), (50000, 63), (1000000, 63), (4000000, 63)]:     # the last one: 1 GB per array, beyond the 256 MB Infinity Cache
         x = torch.randn(B, d, device=DEV, requires_grad=True)
@@ -83,6 +102,27 @@ def main():
             28. * B * d + 4 * B)
         hbm("affine_bwd (through autograd)", [B, d], timeit(lambda: torch.autograd.grad((z, ld), (x, h), (gz, gl), retain_graph=True)),
             28. * B * d + 4 * B)
+        if d <= 64 and B * d >= (1 << 16):
+            # the C-ABI entry points back to back on preallocated outputs, next to the floors of their launch shape (review of round
+            # 5, item 7): an EMPTY grid of the same shape and the STREAM copy kernel moving the same bytes, all timed the same way
+            P, st = abi.ptr, abi.stream
+            zz, ll = torch.empty(B, d, device=DEV), torch.empty(B, device=DEV)
+            gx_, gh_ = torch.empty(B, d, device=DEV), torch.empty(B, d, 2, device=DEV)
+            xd, hd = x.detach(), h.detach()
+            U = 4 if B * d >= (1 << 24) else 1
+            grid = min((B + 16 * U - 1) // (16 * U), 4096)
+            fb, bb = 16. * B * d + 4 * B, 28. * B * d + 4 * B
+            src = torch.empty(int(bb) // 8 // 4 * 4 + 4, device=DEV)
+            dst = torch.empty_like(src)
+            for nm, fn, nbytes in (
+                    ("gnf_affine_fwd, back to back", lambda: abi.call("gnf_affine_fwd", P(xd), P(hd), 2 * d, 2, 1, P(zz), None, P(ll), None, 0, B, d, st()), fb),
+                    ("gnf_affine_bwd, back to back", lambda: abi.call("gnf_affine_bwd", P(xd), P(hd), 2 * d, 2, 1, P(gz), None, P(gl), None, P(gx_), P(gh_), 2 * d, 2, 1, B, d, st()), bb),
+                    ("floor: STREAM copy of the forward's bytes, back to back", lambda: lib0.gnf_probe_copy(P(dst), P(src), int(fb) // 8 // 4 * 4, st()), 8. * (int(fb) // 8 // 4 * 4)),
+                    ("floor: STREAM copy of the backward's bytes, back to back", lambda: lib0.gnf_probe_copy(P(dst), P(src), int(bb) // 8 // 4 * 4, st()), 8. * (int(bb) // 8 // 4 * 4))):
+                hbm(nm, [B, d], b2b(fn), nbytes)
+            rows.append({"kernel": "floor: EMPTY grid of the Affine launch shape (%d x 256)" % grid, "shape": [B, d], "bound": "launch",
+                         "ms": round(timeit(lambda: lib0.gnf_probe_empty(grid, 256, st())), 4),
+                         "ms_back_to_back": round(b2b(lambda: lib0.gnf_probe_empty(grid, 256, st())), 4)})
         with torch.no_grad():
             hbm("normal_logdensity_fwd", [B, d], time_entry("gnf_normal_logdensity_fwd", lambda: ops.NormalLogDensityFn.apply(x)), 4. * B * d)
             jj = torch.rand(B, d, device=DEV) + .1
@@ -114,8 +154,19 @@ def main():
             Am, Bm = torch.randn(K, M, device=DEV), torch.randn(K, N, device=DEV)
             sa, sb = (1, M), (N, 1)
         ms = timeit(lambda: ops.gemm(Am, sa, Bm, sb, C, (N, 1), M, N, K))
-        mfma("gemm " + what, [M, N, K], ms, 2. * M * N * K)
-        rows[-1]["kernel_ran"] = lib.gnf_gemm_last_kernel().decode()
+        ran = lib.gnf_gemm_last_kernel().decode()
+        if ran.startswith("gemm_split"):
+            # round 6: the fc1 trio on the bf16 matrix pipe -- six v_mfma_f32_16x16x32_bf16 terms per fp32 product: priced at
+            # what it executes (6 x 2 M N K) against the dense bf16 peak; the fp32-equivalent rate beside it.  These kernels run at
+            # the board's 1400 W cap (1.9-2.05 GHz, profiles/r06_split_bf16_ab.txt); the time includes their pack / reduce launches
+            tf = 6. * 2. * M * N * K / ms / 1e9
+            rows.append({"kernel": "gemm " + what, "shape": [M, N, K], "ms": round(ms, 4), "bound": "mfma (bf16, 6 terms per fp32 product)",
+                         "achieved_TFLOPs_bf16": round(tf, 1), "frac_of_2500TF_bf16": round(tf / BF16_PEAK, 3),
+                         "fp32_equivalent_TFLOPs": round(2. * M * N * K / ms / 1e9, 1)})
+            assert 0. < rows[-1]["frac_of_2500TF_bf16"] <= 1., rows[-1]
+        else:
+            mfma("gemm " + what, [M, N, K], ms, 2. * M * N * K)
+        rows[-1]["kernel_ran"] = ran
         rows[-1]["operand_strides"] = {"A": list(sa), "B": list(sb)}
     # ---- small-batch masked Linear (cfg3's MADE hidden layer, mask as degree vectors): weights streamed once (4 N K bytes)
     M, N, K = 100, 1024, 1024
