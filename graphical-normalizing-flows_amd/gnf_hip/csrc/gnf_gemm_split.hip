@@ -182,8 +182,8 @@ __global__ __launch_bounds__(256) void split_pack_b_k(const float* __restrict__ 
 //     reads 5 x 3 A fragments (ds_read_b128 from the three bf16 planes of the current LDS stage, row pitch 96 B:
 //     conflict-free) and issues 60 MFMAs; its B fragments come pre-split and fragment-major from L2 (split_pack_b_k), two
 //     slabs ahead in a ring of two register sets.  No VALU work at all in this role.
-//   * wavefronts 8..11 (one per SIMD), the LOADER role: A K-slabs arrive as fp32 float4s from HBM (each element ONCE, four
-//     slabs ahead: an HBM request under load takes several slab times), are split into (hi, mid, lo) and written into the
+//   * wavefronts 8..11 (one per SIMD), the LOADER role: A K-slabs arrive as fp32 float4s from HBM (each element ONCE, two to
+//     four slabs ahead, in pairs of slabs: an HBM request under load takes several slab times), are split into (hi, mid, lo) and written into the
 //     OTHER LDS stage while the MFMA wavefronts of the same SIMD keep the matrix pipe busy -- the split (5.5 VALU
 //     instructions per element) runs in the shadow of the bf16 MFMAs, which do not use the vector ALU.
 // Two LDS stages, ONE barrier per slab.  Two accumulator classes: hi*hi | the five cross terms.
@@ -227,8 +227,8 @@ __global__ __launch_bounds__(TL_THREADS) void gemm_split_tall_k(TallArgs g) {
       aoff[i] = row * TL_PITCH + 8 * c;
     }
     f32x4 areg[4][5];
-    auto load_a = [&](int slab, f32x4 (&a)[5]) {
-      const int sl = slab < g.nslab ? slab : g.nslab - 1;       // (the tail re-requests the last slab: no branch in the body)
+    auto load_a = [&](int slab, f32x4 (&a)[5]) {                  // (prologue; the tail of the loop re-requests the last slab)
+      const int sl = slab < g.nslab ? slab : g.nslab - 1;
 #pragma unroll
       for (int i = 0; i < 5; ++i) a[i] = *reinterpret_cast<const f32x4*>(arow[i] + 32 * sl);
     };
@@ -251,7 +251,17 @@ __global__ __launch_bounds__(TL_THREADS) void gemm_split_tall_k(TallArgs g) {
     for (int s0 = 0; s0 < g.nslab; s0 += 4) {
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
-        load_a(s0 + u + 4, areg[u]);                            // slot u held slab s: in LDS since the previous iteration
+        // Slabs are requested in PAIRS, every odd iteration, into the two slots the last two stores freed: the two requests of a
+        // thread are the adjacent 128-B halves of one 256-B run of its row, back to back -- the second one finds the DRAM page open
+        // (one slab per iteration, four ahead: 0.305-0.310 ms; pairs: 0.276-0.288, same box, profiles/r06_split_bf16_ab.txt)
+        if (u & 1) {
+          const int sa = s0 + u + 3 < g.nslab ? s0 + u + 3 : g.nslab - 1, sb = s0 + u + 4 < g.nslab ? s0 + u + 4 : g.nslab - 1;
+#pragma unroll
+          for (int i = 0; i < 5; ++i) {
+            areg[u - 1][i] = *reinterpret_cast<const f32x4*>(arow[i] + 32 * sa);
+            areg[u][i] = *reinterpret_cast<const f32x4*>(arow[i] + 32 * sb);
+          }
+        }
         store_a((u + 1) & 1, areg[(u + 1) & 3]);                // slab s + 1 into the stage the MFMA role is NOT reading
         __syncthreads();
       }
