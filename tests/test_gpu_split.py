@@ -197,3 +197,44 @@ def test_mnistcnn_fc1_runs_on_the_split_kernels_in_the_product_path():
     for got, ref, name in ((y, y64, "y"), (x.grad, x64.grad, "dx"), (W.grad, W64.grad, "dW"), (b.grad, b64.grad, "db")):
         d = (got.double() - ref.detach()).abs().max().item()
         assert d <= 1e-5 * ref.detach().abs().max().item(), (name, d)
+
+
+def test_split_kernels_inside_a_captured_graph():
+    """the three split kernels (pack + main + reduce launches, workspace from the caching allocator) captured into a hipGraph and
+    replayed on new inputs: same bits as the eager calls (GraphedStep captures whole optimisation steps that contain them)"""
+    lib = abi.load()
+    if not lib.gnf_gemm_split_enabled():
+        pytest.skip("GNF_TRUE_F32=1")
+    torch.manual_seed(3)
+    M, K, F = 20480, 512, 128
+    x = torch.randn(M, K, device=DEV)
+    W = (torch.randn(F, K, device=DEV) / 20.).requires_grad_(True)
+    b = torch.randn(F, device=DEV, requires_grad=True)
+    xs = x.clone().requires_grad_(True)
+
+    def step():
+        W.grad = b.grad = xs.grad = None
+        y = ops.mlp(xs, [(W, b)])
+        y.square().sum().backward()
+        return y.detach(), xs.grad, W.grad, b.grad
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for _ in range(2):
+            step()
+    torch.cuda.current_stream().wait_stream(side)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        outs = step()
+    x2 = torch.randn(M, K, device=DEV)
+    with torch.no_grad():
+        xs.copy_(x2)
+    g.replay()
+    got = [t.clone() for t in outs]
+    ref = [t.clone() for t in step()]
+    for a, r, name in zip(got, ref, ("y", "dx", "dW", "db")):
+        assert torch.equal(a, r), name
+    x64, W64, b64 = x2.double().requires_grad_(True), W.detach().double().requires_grad_(True), b.detach().double().requires_grad_(True)
+    (x64 @ W64.t() + b64).square().sum().backward()
+    assert (got[2].double() - W64.grad).abs().max() <= 1e-5 * W64.grad.abs().max()
+    assert (got[1].double() - x64.grad).abs().max() <= 1e-5 * x64.grad.abs().max()
