@@ -72,6 +72,13 @@ def assert_close(a, b, rtol=1e-5, atol=1e-6, what=""):
                                 int((excess > 0).sum()), excess.numel()))
 
 
+def assert_fwd(a, b, what="forward value"):
+    """element-wise form of the forward tolerance (review of round 5, item 7): |a - b| <= 1e-6 max|b| + 1e-5 |b| for EVERY entry --
+    the infinity-norm check rel_err(a, b) < 1e-5 beside it leaves the small entries of a tensor unconstrained"""
+    b = torch.as_tensor(b)
+    assert_close(a, b, rtol=1e-5, atol=1e-6 * float(b.detach().abs().max()) if b.numel() else 0., what=what)
+
+
 # ------------------------------------------------------------------------------- fp64 arbitration of knife-edge decisions
 # A ReLU gate / max-pool argmax decided on a quantity that lies within fp32 roundoff of the tie may legitimately differ
 # between two correct fp32 evaluations (different summation orders).  Instead of a loose blanket tolerance on the gradients,

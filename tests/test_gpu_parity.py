@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import (load_golden, params_of, linear_layers, rel_err, assert_close, conv_front_knife_images,
+from conftest import (load_golden, params_of, linear_layers, rel_err, assert_close, assert_fwd, conv_front_knife_images,
                       integrand_knife_elements)
 from oracle import gnf_oracle as O
 
@@ -51,12 +51,18 @@ def test_affine_golden():
     norm = AffineNormalizer()
     z, jac = norm(x, h)
     assert rel_err(z.cpu(), g["z"]) < TOL and rel_err(jac.cpu(), g["jac"]) < TOL
+    assert_fwd(z, g["z"], what='z')
+    assert_fwd(jac, g["jac"], what='jac')
     gx, gh = torch.autograd.grad((z * cu(g["gz"])).sum(), (x, h), retain_graph=True)
     assert rel_err(gx.cpu(), g["gx_from_z"]) < TOL and rel_err(gh.cpu(), g["gh_from_z"]) < TOL
+    assert_fwd(gx, g["gx_from_z"], what='gx')
+    assert_fwd(gh, g["gh_from_z"], what='gh')
     z2, ld = norm.forward_logdet(x, h)
     gh2, = torch.autograd.grad((ld * cu(g["gld"])).sum(), h)
     assert rel_err(gh2.cpu(), g["gh_from_logdet"]) < TOL
+    assert_fwd(gh2, g["gh_from_logdet"], what='gh2')
     assert rel_err(ld.detach().cpu(), torch.log(g["jac"]).sum(1)) < TOL
+    assert_fwd(ld, torch.log(g["jac"]).sum(1), what='ld')
     assert rel_err(norm.inverse_transform(cu(g["z"]), cu(g["h"])).cpu(), g["x_inverse"]) < TOL
     # in-place clamp option reproduces the reference's mutation of h
     norm.inplace_clamp = True
@@ -79,12 +85,17 @@ def test_affine_strided_h_and_large():
     xg, hg = req(x), cu(hraw).requires_grad_(True)
     z, jac, ld, _ = ops.AffineFn.apply(xg, hg.view(B, 2, d).permute(0, 2, 1))
     assert rel_err(z.cpu(), z0) < TOL and rel_err(jac.cpu(), j0) < TOL
+    assert_fwd(z, z0, what='z')
+    assert_fwd(jac, j0, what='jac')
     assert rel_err(ld.cpu(), torch.log(j0).sum(1)) < TOL
+    assert_fwd(ld, torch.log(j0).sum(1), what='ld')
     (z.sum() + ld.sum()).backward()
     xr, hr = x.clone().requires_grad_(True), hraw.clone().requires_grad_(True)
     zr, jr = O.affine_forward(xr, hr.view(B, 2, d).permute(0, 2, 1))
     (zr.sum() + torch.log(jr).sum()).backward()
     assert rel_err(xg.grad.cpu(), xr.grad) < TOL and rel_err(hg.grad.cpu(), hr.grad) < TOL
+    assert_fwd(xg.grad, xr.grad, what='xg.grad')
+    assert_fwd(hg.grad, hr.grad, what='hg.grad')
 
 
 @pytest.mark.parametrize("B,d", [(4163, 63), (20001, 63), (4500, 62), (4100, 64), (50003, 6), (70001, 5), (300001, 1)])
@@ -99,7 +110,10 @@ def test_affine_flat_vectorised_path_vs_oracle(B, d):
     xg, hg = req(x), req(h)
     z, jac, ld, _ = ops.AffineFn.apply(xg, hg)
     assert rel_err(z.cpu(), z0) < TOL and rel_err(jac.cpu(), j0) < TOL
+    assert_fwd(z, z0, what='z')
+    assert_fwd(jac, j0, what='jac')
     assert rel_err(ld.cpu(), torch.log(j0).sum(1)) < TOL
+    assert_fwd(ld, torch.log(j0).sum(1), what='ld')
     assert_close(ld, torch.log(j0).sum(1), atol=2e-6 * d ** .5, what="logdet")
     gz, gj, gl = torch.randn(B, d), torch.randn(B, d), torch.randn(B)
     ((z * cu(gz)).sum() + (jac * cu(gj)).sum() + (ld * cu(gl)).sum()).backward()
@@ -107,6 +121,8 @@ def test_affine_flat_vectorised_path_vs_oracle(B, d):
     zr, jr = O.affine_forward(xr, hr)
     ((zr * gz).sum() + (jr * gj).sum() + (torch.log(jr).sum(1) * gl).sum()).backward()
     assert rel_err(xg.grad.cpu(), xr.grad) < TOL and rel_err(hg.grad.cpu(), hr.grad) < TOL
+    assert_fwd(xg.grad, xr.grad, what='xg.grad')
+    assert_fwd(hg.grad, hr.grad, what='hg.grad')
     # the fused step's variant (no jac output) and determinism
     with torch.no_grad():
         z2, _, ld2, _ = ops.AffineFn.apply(cu(x), cu(h), False, False)
@@ -121,16 +137,20 @@ def test_normal_log_density_and_logsum():
     z = req(g["z"])
     out = NormalLogDensity().to(DEV)(z)
     assert rel_err(out.cpu(), g["out"]) < TOL
+    assert_fwd(out, g["out"], what='out')
     out.sum().backward()
     assert rel_err(z.grad.cpu(), -g["z"]) < TOL
+    assert_fwd(z.grad, -g["z"], what='z.grad')
     for B, d in [(5, 1), (7, 2), (33, 6), (100, 784), (1000, 63)]:
         jac = torch.rand(B, d) + .1
         j = req(jac)
         o = ops.LogSumRowsFn.apply(j)
         assert rel_err(o.cpu(), torch.log(jac).sum(1)) < TOL
+        assert_fwd(o, torch.log(jac).sum(1), what='o')
         w = torch.randn(B)
         (o * cu(w)).sum().backward()
         assert rel_err(j.grad.cpu(), w[:, None] / jac) < TOL
+        assert_fwd(j.grad, w[:, None] / jac, what='j.grad')
 
 
 # --------------------------------------------------------------------------------- GEMM
@@ -304,6 +324,7 @@ def test_coupling_golden():
     x = req(g["x"])
     h = c(x)
     assert rel_err(h.cpu(), g["h"]) < TOL
+    assert_fwd(h, g["h"], what='h')
     (h * cu(g["gh"])).sum().backward()
     assert rel_err(x.grad.cpu(), g["gx"]) < GTOL
     grads_match(c, g)
@@ -339,9 +360,12 @@ def test_dag_golden(tag):
     x = req(g["x"])
     h = c(x)
     assert rel_err(h.cpu(), g["h"]) < TOL
+    assert_fwd(h, g["h"], what='h')
     loss = c.loss()
     assert rel_err(loss.detach().cpu(), g["loss"]) < TOL
+    assert_fwd(loss, g["loss"], what='loss')
     assert rel_err(c.get_power_trace().detach().cpu(), g["trace"]) < TOL
+    assert_fwd(c.get_power_trace(), g["trace"], what='c.get_power_trace()')
     ((h * cu(g["gh"])).sum() + loss).backward()
     assert rel_err(x.grad.cpu(), g["gx"]) < GTOL
     grads_match(c, g)
@@ -404,6 +428,7 @@ def test_mnistcnn_golden():
     e = req(g["e"])
     out = net(e)
     assert rel_err(out.cpu(), g["out"]) < TOL
+    assert_fwd(out, g["out"], what='out')
     # element-wise too (review of round 5, item 7: the infinity norm leaves the small entries unconstrained)
     assert_close(out, g["out"], rtol=1e-5, atol=1e-6 * g["out"].abs().max().item(), what="out")
     (out * cu(g["gout"])).sum().backward()
@@ -448,6 +473,7 @@ def test_mnist_conv_front_vs_torch_cpu(n, kind):
     pg = [req(t) for t in (e, W1, b1, W2, b2)]
     out = ops.MnistConvFn.apply(*pg, kind == "sparse")        # exactly tied windows -> the tie-exact forward
     assert rel_err(out.cpu(), ref.detach()) < TOL
+    assert_fwd(out, ref.detach(), what='out')
     assert_close(out, ref, rtol=1e-5, atol=1e-6 * ref.detach().abs().max().item(), what="pooled (every image, knife or not)")
     (out * cu(gp)).sum().backward()
     ge, gr = pg[0].grad.cpu(), ps[0].grad
@@ -493,10 +519,13 @@ def test_flow_golden(name):
     x = req(g["x"])
     z, ld = flow(x)
     assert rel_err(z.cpu(), g["z"]) < TOL and rel_err(ld.cpu(), g["logdet"]) < TOL
+    assert_fwd(z, g["z"], what='z')
+    assert_fwd(ld, g["logdet"], what='ld')
     assert_close(z, g["z"], what="z")                      # element-wise: |a-b| <= 1e-6 + 1e-5 |b|
     assert_close(ld, g["logdet"], what="logdet")
     loss = flow.loss(z, ld)
     assert rel_err(loss.detach().cpu(), g["loss"]) < TOL
+    assert_fwd(loss, g["loss"], what='loss')
     assert_close(loss, g["loss"], what="loss")
     loss.backward()
     assert rel_err(x.grad.cpu(), g["gx"]) < GTOL
@@ -509,6 +538,7 @@ def test_flow_inverse_golden(name):
     flow = load_into(_build(name), g)
     x = flow.invert(cu(gi["z"]))
     assert rel_err(x.cpu(), gi["x"]) < TOL
+    assert_fwd(x, gi["x"], what='x')
     assert rel_err(x.cpu(), g["x"]) < 1e-4
 
 
@@ -539,10 +569,13 @@ def test_mnist_affine_dag_flow_golden():
     cond.gate_noise = (cu(u1), cu(u2))
     z, ld = flow(cu(g["x"]))
     assert rel_err(z.cpu(), g["z"]) < TOL and rel_err(ld.cpu(), g["logdet"]) < TOL
+    assert_fwd(z, g["z"], what='z')
+    assert_fwd(ld, g["logdet"], what='ld')
     assert_close(z, g["z"], atol=2e-6, what="z")
     assert_close(ld, g["logdet"], what="logdet")
     loss = flow.loss(z, ld)
     assert rel_err(loss.detach().cpu(), g["loss"]) < TOL
+    assert_fwd(loss, g["loss"], what='loss')
     loss.backward()
     gA = cond.A.grad.cpu()
     idx = g["gA_idx"].long()
@@ -573,8 +606,11 @@ def test_mnist_three_scale_flow_golden():
         c.stoch_gate = False
     z, ld = flow(cu(g["x"]))
     assert rel_err(z.cpu(), g["z"]) < TOL and rel_err(ld.cpu(), g["logdet"]) < TOL
+    assert_fwd(z, g["z"], what='z')
+    assert_fwd(ld, g["logdet"], what='ld')
     loss = flow.loss(z, ld)
     assert rel_err(loss.detach().cpu(), g["loss"]) < TOL
+    assert_fwd(loss, g["loss"], what='loss')
     loss.backward()
     named = dict(flow.named_parameters())
     for k, v in g.items():
@@ -1111,7 +1147,9 @@ def test_monotonic_forward_backward_vs_oracle(hidden, S, layout):
     hgv = hg.view(B, c, d).permute(0, 2, 1) if layout == "made" else hg
     z, jac = norm(xg, hgv)
     assert rel_err(z.cpu(), z0.detach()) < TOL, rel_err(z.cpu(), z0.detach())
+    assert_fwd(z, z0.detach(), what='z')
     assert rel_err(jac.cpu(), j0.detach()) < TOL
+    assert_fwd(jac, j0.detach(), what='jac')
     assert_close(z, z0, atol=2e-6, what="z")               # element-wise (the integral sums ~20 terms of O(1))
     assert_close(jac, j0, what="jac")
     assert_close(torch.log(jac).sum(1), torch.log(j0.detach()).sum(1), what="logdet")
@@ -1140,10 +1178,13 @@ def test_monotonic_golden_jacobian():
     x = cu(g["x"])
     h = flow.steps[0].conditioner(x)
     assert rel_err(h.cpu(), g["h"]) < TOL
+    assert_fwd(h, g["h"], what='h')
     z, jac = flow.steps[0].normalizer(x, h)
     assert rel_err(jac.cpu(), g["jac"]) < TOL
+    assert_fwd(jac, g["jac"], what='jac')
     _, ld = flow(x)
     assert rel_err(ld.cpu(), g["logdet"]) < TOL
+    assert_fwd(ld, g["logdet"], what='ld')
 
 
 def test_monotonic_golden_integrand_grads():
@@ -1155,6 +1196,7 @@ def test_monotonic_golden_integrand_grads():
     x, h = req(g["x"]), req(g["h"])
     _, jac = norm(x, h)
     assert rel_err(jac.cpu(), g["jac"]) < TOL
+    assert_fwd(jac, g["jac"], what='jac')
     (torch.log(jac) * cu(g["gj"])).sum().backward()
     assert rel_err(x.grad.cpu(), g["gx"]) < GTOL and rel_err(h.grad.cpu(), g["gh"]) < GTOL
     grads_match(norm.integrand_net, g)
@@ -1224,6 +1266,7 @@ def test_dag_noise_gate_vs_oracle():
     xg, Ag = req(x), req(A)
     e = ops.DagGateFn.apply(xg, Ag, ops.IMP_SOFT, ops.GATE_NOISE, 0., 1., False, cu(nz), None, 0, 0)
     assert rel_err(e.cpu(), e0.detach()) < TOL
+    assert_fwd(e, e0.detach(), what='e')
     (e * cu(w)).sum().backward()
     assert rel_err(xg.grad.cpu(), xr.grad) < GTOL and rel_err(Ag.grad.cpu(), Ar.grad) < GTOL
 
@@ -1359,6 +1402,8 @@ def test_monotonic_ragged_sizes(B, d, hidden):
     xg, hg = req(x), req(h)
     z, jac = norm(xg, hg)
     assert rel_err(z.cpu(), z0.detach()) < TOL and rel_err(jac.cpu(), j0.detach()) < TOL
+    assert_fwd(z, z0.detach(), what='z')
+    assert_fwd(jac, j0.detach(), what='jac')
     ((z * cu(gz)).sum() + (jac * cu(gj)).sum()).backward()
     if int(keep.sum()) == 0:
         return
@@ -1385,6 +1430,8 @@ def test_monotonic_forward_half_groups(B, d, hidden):
         z0, j0 = O.monotonic_forward(x, h, _layers_cpu(norm), S)
         z, jac = norm.to(DEV)(cu(x), cu(h))
     assert rel_err(z.cpu(), z0) < TOL and rel_err(jac.cpu(), j0) < TOL
+    assert_fwd(z, z0, what='z')
+    assert_fwd(jac, j0, what='jac')
     assert_close(z, z0, atol=3e-6, what="z")
     assert_close(jac, j0, what="jac")
 
@@ -1542,7 +1589,9 @@ def test_sparse_front_matches_oracle_and_dense(post_processed):
     ref = ref.view(B, 784, 30)
     assert h_sparse.shape == (B, 784, 30)
     assert rel_err(h_sparse.cpu(), ref) < TOL, rel_err(h_sparse.cpu(), ref)
+    assert_fwd(h_sparse, ref, what='h_sparse')
     assert rel_err(h_dense.cpu(), ref) < TOL
+    assert_fwd(h_dense, ref, what='h_dense')
     # per-row check as well (a wrong row permutation of a few copies would hide in a global norm)
     err = (h_sparse.cpu() - ref).abs().amax(2) / ref.abs().amax(2).clamp_min(1e-6)
     assert err.max() < 1e-4, err.max()
@@ -1561,6 +1610,7 @@ def test_sparse_front_row_subsets_and_fallbacks():
         cond.sparse_front = True
         assert got.shape == want.shape == (B, rows.numel(), 30)
         assert rel_err(got.cpu(), want.cpu()) < TOL
+        assert_fwd(got, want.cpu(), what='got')
         # an entry outside the 5x5 window: the sparse front must step aside (dense result unchanged)
         cond.A[0, 300] = 1.
         assert cond._sparse_plan(x, None, cond.deterministic_importance()) is None
@@ -1623,6 +1673,7 @@ def test_sparse_front_edge_sizes(B, rows):
         want = cond.forward_rows(x, r, P)
     assert got.shape == want.shape == (B, r.numel(), 30)
     assert rel_err(got.cpu(), want.cpu()) < TOL
+    assert_fwd(got, want.cpu(), what='got')
     # and the parameter gradients on the same subset (masked copies holding a knife-edge pool window: zero cotangent)
     cond.sparse_front = True
     gh = cu(torch.randn(B, r.numel(), 30))
@@ -1660,8 +1711,11 @@ def test_sparse_front_reference_golden():
     assert cond._sparse_plan(x, None, cond.deterministic_importance()) is not None
     z, ld = flow(x)
     assert rel_err(z.cpu(), g["z"]) < TOL and rel_err(ld.cpu(), g["logdet"]) < TOL
+    assert_fwd(z, g["z"], what='z')
+    assert_fwd(ld, g["logdet"], what='ld')
     loss = flow.loss(z, ld)
     assert rel_err(loss.detach().cpu(), g["loss"]) < TOL
+    assert_fwd(loss, g["loss"], what='loss')
     loss.backward()
     named = dict(flow.named_parameters())
     n = 0
@@ -1674,6 +1728,8 @@ def test_sparse_front_reference_golden():
     with torch.no_grad():                              # evaluation path (no saved tensors)
         z2, ld2 = flow(x)
     assert rel_err(z2.cpu(), g["z"]) < TOL and rel_err(ld2.cpu(), g["logdet"]) < TOL
+    assert_fwd(z2, g["z"], what='z2')
+    assert_fwd(ld2, g["logdet"], what='ld2')
 
 
 def test_sparse_front_prepared_tables_give_the_same_bits(monkeypatch):
@@ -1957,6 +2013,7 @@ def test_dag_loss_fused_vs_reference_expression(d, l1):
     ref = cond.dag_const * (cond.lambd * lag + cond.c / 2 * lag ** 2) + cond.l1_weight * cond.A.abs().mean()
     ref.backward()
     assert rel_err(loss.detach().cpu(), ref.detach().cpu()) < TOL, (loss.item(), ref.item())
+    assert_fwd(loss, ref.detach().cpu(), what='loss')
     assert rel_err(got_g.cpu(), cond.A.grad.cpu()) < GTOL
 
 
@@ -1981,12 +2038,14 @@ def test_dag_loss_of_a_frozen_gate_is_evaluated_once_per_state():
         lag = cond.get_power_trace()
         ref = cond.dag_const * (cond.lambd * lag + cond.c / 2 * lag ** 2) + cond.l1_weight * cond.A.abs().mean()
         assert rel_err(v1.cpu(), ref.cpu()) < TOL
+        assert_fwd(v1, ref.cpu(), what='v1')
         with torch.no_grad():
             cond.lambd.add_(1.)                    # in-place change of a dual buffer: new state
         v3 = cond.loss()
         assert len(calls) == 2
         ref3 = cond.dag_const * (cond.lambd * lag + cond.c / 2 * lag ** 2) + cond.l1_weight * cond.A.abs().mean()
         assert rel_err(v3.cpu(), ref3.cpu()) < TOL
+        assert_fwd(v3, ref3.cpu(), what='v3')
         cond.exponent += 50                        # what update_dual_param() does when the trace vanishes
         cond.loss()
         assert len(calls) == 3
@@ -2033,6 +2092,7 @@ def test_mnistcnn_other_geometries(size_img, fc_in):
     ref = O.mnistcnn_forward(ec, params, tuple(size_img))
     (ref * gout).sum().backward()
     assert rel_err(out.detach().cpu(), ref.detach()) < TOL
+    assert_fwd(out, ref.detach(), what='out')
     assert rel_err(eg.grad.cpu(), ec.grad) < GTOL
     for k, p in net.named_parameters():
         assert rel_err(p.grad.cpu(), params[k].grad) < GTOL, k
