@@ -8,7 +8,7 @@ import sys
 import pytest
 import torch
 
-from conftest import ROOT, rel_err, assert_close
+from conftest import ROOT, rel_err, assert_close, assert_fwd
 from oracle import gnf_oracle as O
 
 pytestmark = pytest.mark.gpu
@@ -74,6 +74,9 @@ def test_cfg4_composite_vs_oracle():
     loss = flow.loss(z, ld)
     loss.backward()
     assert rel_err(z.cpu(), z0) < TOL and rel_err(ld.cpu(), ld0) < TOL and rel_err(loss.detach().cpu(), loss0) < TOL
+    assert_fwd(z, z0, what='z')
+    assert_fwd(ld, ld0, what='ld')
+    assert_fwd(loss, loss0, what='loss')
     assert_close(z, z0, what="z")
     assert_close(ld, ld0, what="logdet")
     assert_close(loss, loss0, what="loss")
@@ -207,6 +210,8 @@ def test_cfg5_full_size_monotonic_step():
     h0 = O.made_forward(xs, made, masks)                 # [64, 63, 30] view, component-major chunks
     z0, j0 = O.monotonic_forward(xs, h0, layers, 20)
     assert rel_err(z[:64].cpu(), z0) < TOL and rel_err(ld[:64].cpu(), torch.log(j0).sum(1)) < TOL
+    assert_fwd(z[:64], z0, what='z[:64]')
+    assert_fwd(ld[:64], torch.log(j0).sum(1), what='ld[:64]')
     assert_close(z[:64], z0, what="z")
     assert_close(ld[:64], torch.log(j0).sum(1), what="logdet")
     with torch.no_grad():
@@ -341,6 +346,7 @@ def test_data_writes_to_a_frozen_gate_need_invalidate_caches():
         c.lambd.fill_(.25)
     v0 = c.loss()
     assert rel_err(v0.cpu(), oracle_loss(c)) < TOL
+    assert_fwd(v0, oracle_loss(c), what='v0')
     version, address = c.A._version, c.A.data_ptr()
     c.A.data.mul_(.5)
     assert (c.A._version, c.A.data_ptr()) == (version, address)      # invisible to the cache keys ...
@@ -642,6 +648,7 @@ def test_dag_clipped_normal_gate_golden():
         x = g[tag + ".x"].to(DEV).requires_grad_(True)
         h = c(x)
         assert rel_err(h.cpu(), g[tag + ".h"]) < TOL
+        assert_fwd(h, g[tag + ".h"], what='h')
         (h * g[tag + ".gh"].to(DEV)).sum().backward()
         assert rel_err(x.grad.cpu(), g[tag + ".gx"]) < GTOL and rel_err(c.A.grad.cpu(), g[tag + ".gA"]) < GTOL
         for k, p in c.named_parameters():

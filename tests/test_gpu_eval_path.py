@@ -10,7 +10,7 @@ import sys
 import pytest
 import torch
 
-from conftest import ROOT, rel_err, assert_close
+from conftest import ROOT, rel_err, assert_close, assert_fwd
 from oracle import gnf_oracle as O
 
 pytestmark = pytest.mark.gpu
@@ -42,6 +42,8 @@ def test_monotonic_eval_node_counts_vs_oracle(hidden, S):
         norm.nb_steps = S                               # the attribute the drivers poke (Image:235, UCI:157)
         z, jac = norm(x.to(DEV), h.to(DEV))
     assert rel_err(z.cpu(), z0) < TOL and rel_err(jac.cpu(), j0) < TOL
+    assert_fwd(z, z0, what='z')
+    assert_fwd(jac, j0, what='jac')
     assert_close(z, z0, atol=3e-6, what="z")
     assert_close(jac, j0, what="jac")
     ld0, ld = torch.log(j0).sum(1), torch.log(jac).sum(1)
@@ -116,6 +118,9 @@ def test_cfg4_composite_eval_path_S150(gate):
         z, ld = flow(x.to(DEV))
         loss = flow.loss(z, ld)
     assert rel_err(z.cpu(), z0) < TOL and rel_err(ld.cpu(), ld0) < TOL and rel_err(loss.cpu(), loss0) < TOL
+    assert_fwd(z, z0, what='z')
+    assert_fwd(ld, ld0, what='ld')
+    assert_fwd(loss, loss0, what='loss')
     assert_close(z, z0, atol=3e-6, what="z")
     assert_close(ld, ld0, what="logdet")
     assert_close(loss, loss0, what="loss")
