@@ -39,7 +39,10 @@ constexpr int kNP = 64;            // (element, node) pairs per batch: node slot
 // LDS plan (floats)
 template <int HT, int NH>
 struct WidePlan {
-  static constexpr int HP = 16 * HT, P = HP + 4;           // P: row pitch of the pair-major buffers
+#ifndef GNF_WIDE_PITCH_PAD
+#define GNF_WIDE_PITCH_PAD 4
+#endif
+  static constexpr int HP = 16 * HT, P = HP + GNF_WIDE_PITCH_PAD;           // P: row pitch of the pair-major buffers
   static constexpr int o_w1x = 0, o_wL = HP, o_b = 2 * HP;  // b_l at o_b + (l-1) HP, l = 1..NH-1
   static constexpr int o_bL = o_b + (NH - 1) * HP;
   static constexpr int o_c1 = o_bL + 4;                     // [32][P]  W1h h + b1 of the group's elements
@@ -759,7 +762,7 @@ __global__ __launch_bounds__(64 * kWideWaves, 1) void mono_bwd_wide_k(MonoArgs a
 // =========================================================================================================================
 template <int HT, int NH>
 struct WidePlanF {
-  static constexpr int HP = 16 * HT, P = HP + 4;
+  static constexpr int HP = 16 * HT, P = HP + GNF_WIDE_PITCH_PAD;
   static constexpr int o_w1x = 0, o_wL = HP, o_b = 2 * HP;
   static constexpr int o_bL = o_b + (NH - 1) * HP;
   static constexpr int o_c1 = o_bL + 4;                     // [32][P]
