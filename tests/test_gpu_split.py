@@ -238,3 +238,22 @@ def test_split_kernels_inside_a_captured_graph():
     (x64 @ W64.t() + b64).square().sum().backward()
     assert (got[2].double() - W64.grad).abs().max() <= 1e-5 * W64.grad.abs().max()
     assert (got[1].double() - x64.grad).abs().max() <= 1e-5 * x64.grad.abs().max()
+
+
+def test_training_trajectory_matches_the_true_f32_build():
+    """end to end: five Adam steps of the cfg4 flow at B = 16 (12 544 masked copies: the fc1 products are on the split kernels)
+    in a child process with the default library and in one with GNF_TRUE_F32=1 -- same seeds, same Philox gate noise: the loss
+    of every step agrees to 1e-5 relative and the parameters after the steps to 1e-6 of their L1 norm"""
+    import os
+    import sys
+    from conftest import ROOT
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import split_trajectory as T
+    if not abi.load().gnf_gemm_split_enabled():
+        pytest.skip("GNF_TRUE_F32=1")
+    a, fa = T.run(5, 16, False)
+    b, fb = T.run(5, 16, True)
+    assert len(a) == len(b) == 5
+    for u, v in zip(a, b):
+        assert abs(u - v) <= 1e-5 * abs(v), (a, b)
+    assert abs(fa[1] - fb[1]) <= 1e-6 * fb[1], (fa, fb)
