@@ -83,6 +83,9 @@ SIGNATURES = {
     "gnf_monotonic_pack": (c_int, [ctypes.POINTER(MonoNet), c_f, c_stream]),
     "gnf_monotonic_fwd": (c_int, [c_f, ctypes.POINTER(MonoNet), c_f, c_f, c_i64, c_i64, c_i64, c_f, c_f, c_int, c_f,
                                   c_f, c_i64, c_i64, c_stream]),
+    "gnf_monotonic_fwd_f32": (c_int, [c_f, ctypes.POINTER(MonoNet), c_f, c_f, c_i64, c_i64, c_i64, c_f, c_f, c_int, c_f,
+                                      c_f, c_i64, c_i64, c_stream]),
+    "gnf_monotonic_fwd_kernel": (ctypes.c_char_p, []),
     "gnf_monotonic_inv": (c_int, [c_f, ctypes.POINTER(MonoNet), c_f, c_f, c_i64, c_i64, c_i64, c_f, c_f, c_int, c_f,
                                   c_i64, c_i64, c_stream]),
     "gnf_monotonic_inv_scatter": (c_int, [c_f, ctypes.POINTER(MonoNet), c_f, c_f, c_i64, c_i64, c_i64, c_f, c_f, c_int, c_f,

@@ -29,6 +29,11 @@ struct MonoLayout {
   //   WTf[l][mt][t][lane][r] = W_l[16 t + 4 q + r][16 mt + j]       (backward:  in tile mt,  k tile t over the out units)
   // so that one global_load_dwordx4 per lane fetches a whole fragment as 1 KB of consecutive bytes.
   int o_Wf[kMaxNH], o_WTf[kMaxNH];
+  // Round 6: the same matrices as exact 3 x bf16 splits (W = hi + mid + lo, round to nearest at each level) for the forward
+  // on the bf16 matrix pipe (mono_fwd_wide_split_k), fragment-major for v_mfma_f32_16x16x32_bf16:
+  //   Wp[l][plane][mt][t][lane] = 16 bytes = plane of W_l[16 mt + j][32 t + 8 q .. + 7]   (t < KT32 = ceil(HP / 32); zeros past HP)
+  // offsets in 4-byte words like everything else in the pack; 3 * HT * KT32 * 256 words per layer.
+  int o_Wp[kMaxNH], KT32;
   int pack_floats;                    // size of the whole pack
   // K order of the last unit tile (HT >= 7 only, round 5).  An MFMA k-step r of k-tile t contracts the padded positions
   // 16 t + 4 q + r, q = 0..3: with the units of a width-H layer at positions 0 .. H-1 the H mod 16 units of the last tile are
@@ -85,9 +90,11 @@ __host__ __device__ inline MonoLayout make_layout(int HT, int NH, int c) {
   for (int l = 1; l < NH; ++l) { L.o_WT[l] = o; o += L.HP * L.LDW; }
   L.o_W1hT = o; o += L.CP * L.LDW;
   L.total_floats = o;
-  for (int l = 1; l < NH; ++l) { L.o_Wf[l] = 0; L.o_WTf[l] = 0; }
+  L.KT32 = (L.HP + 31) / 32;
+  for (int l = 1; l < NH; ++l) { L.o_Wf[l] = 0; L.o_WTf[l] = 0; L.o_Wp[l] = 0; }
   if (HT >= 7) {
     for (int l = 1; l < NH; ++l) { L.o_Wf[l] = o; o += L.HP * L.HP; L.o_WTf[l] = o; o += L.HP * L.HP; }
+    for (int l = 1; l < NH; ++l) { L.o_Wp[l] = o; o += 3 * HT * L.KT32 * 256; }
   }
   L.pack_floats = o;
   return L;
@@ -158,4 +165,5 @@ unsigned gnf_mono_bwd_wide_grid(const gnfmono::MonoLayout& L, int64_t n);
 int gnf_mono_bwd_wide_launch(const gnfmono::MonoArgs& a, unsigned grid, hipStream_t s);
 // forward (z, jac) of the same nets in the same formulation, two workgroups per CU
 bool gnf_mono_fwd_wide_ok(const gnfmono::MonoLayout& L);
-int gnf_mono_fwd_wide_launch(const gnfmono::MonoArgs& a, hipStream_t s);
+// true_f32: the fp32-MFMA kernel even when the split-bf16 one is enabled.  *kernel: the family launched.
+int gnf_mono_fwd_wide_launch(const gnfmono::MonoArgs& a, hipStream_t s, bool true_f32, const char** kernel);

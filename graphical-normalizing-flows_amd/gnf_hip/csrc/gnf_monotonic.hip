@@ -48,6 +48,29 @@ __global__ void mono_pack_k(PackArgs a, float* __restrict__ pack) {
   auto unit = [&](int p, int l) { return mono_unit_at(p, N.dims[l], L.perm); };   // unit of hidden layer l at padded position p
   for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < L.pack_floats; idx += gridDim.x * blockDim.x) {
     float v = 0.f;
+    if (L.NH > 1 && L.o_Wp[1] && idx >= L.o_Wp[1]) {   // bf16 split planes of the hidden->hidden matrices (see MonoLayout)
+      const int per = 3 * L.HT * L.KT32 * 256;
+      const int l = 1 + (idx - L.o_Wp[1]) / per, k = (idx - L.o_Wp[1]) % per;
+      const int plane = k / (L.HT * L.KT32 * 256), kk = k % (L.HT * L.KT32 * 256);
+      const int frag = kk >> 8, lane = (kk >> 2) & 63, w2 = kk & 3, mt = frag / L.KT32, t = frag - mt * L.KT32;
+      const int q = lane >> 4, j = lane & 15;
+      const int row = unit(16 * mt + j, l + 1);
+      float x[2] = {0.f, 0.f};
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int cp = 32 * t + 8 * q + 2 * w2 + i;
+        const int col = cp < L.HP ? unit(cp, l) : -1;
+        if (row >= 0 && col >= 0) x[i] = N.W[l][(int64_t)row * N.dims[l] + col];
+      }
+      unsigned word = 0;
+      for (int pl = 0; pl <= plane; ++pl) {           // hi, then the rounded remainders (exact subtractions)
+        asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(word) : "v"(x[0]), "v"(x[1]));
+        x[0] -= __uint_as_float(word << 16);
+        x[1] -= __uint_as_float(word & 0xffff0000u);
+      }
+      reinterpret_cast<unsigned*>(pack)[idx] = word;
+      continue;
+    }
     if (idx >= L.total_floats) {                  // fragment-major copies of the hidden->hidden matrices (see MonoLayout)
       for (int l = 1; l < L.NH; ++l) {
         const bool tr = idx >= L.o_WTf[l];
@@ -2400,9 +2423,27 @@ int gnf_monotonic_pack(const gnf_mono_net* net, float* pack, gnf_stream_t stream
   return 0;
 }
 
+static thread_local const char* g_fwd_kernel = "";
+const char* gnf_monotonic_fwd_kernel(void) { return g_fwd_kernel; }
+
+static int mono_fwd_any(const float* pack, const gnf_mono_net* net, const float* x, const float* h, int64_t h_sb,
+                        int64_t h_sd, int64_t h_sc, const float* cc_w, const float* cc_t, int S, float* z,
+                        float* jac, int64_t B, int64_t d, gnf_stream_t stream, bool true_f32);
+
 int gnf_monotonic_fwd(const float* pack, const gnf_mono_net* net, const float* x, const float* h, int64_t h_sb,
                       int64_t h_sd, int64_t h_sc, const float* cc_w, const float* cc_t, int S, float* z,
                       float* jac, int64_t B, int64_t d, gnf_stream_t stream) {
+  return mono_fwd_any(pack, net, x, h, h_sb, h_sd, h_sc, cc_w, cc_t, S, z, jac, B, d, stream, false);
+}
+int gnf_monotonic_fwd_f32(const float* pack, const gnf_mono_net* net, const float* x, const float* h, int64_t h_sb,
+                          int64_t h_sd, int64_t h_sc, const float* cc_w, const float* cc_t, int S, float* z,
+                          float* jac, int64_t B, int64_t d, gnf_stream_t stream) {
+  return mono_fwd_any(pack, net, x, h, h_sb, h_sd, h_sc, cc_w, cc_t, S, z, jac, B, d, stream, true);
+}
+
+static int mono_fwd_any(const float* pack, const gnf_mono_net* net, const float* x, const float* h, int64_t h_sb,
+                        int64_t h_sd, int64_t h_sc, const float* cc_w, const float* cc_t, int S, float* z,
+                        float* jac, int64_t B, int64_t d, gnf_stream_t stream, bool true_f32) {
   const int HT = pick_ht(net);
   if (HT < 0) return GNF_ESHAPE;
   if (!pack || !cc_w || !cc_t || S < 1 || B < 0 || d <= 0) return GNF_EINVAL;
@@ -2412,7 +2453,8 @@ int gnf_monotonic_fwd(const float* pack, const gnf_mono_net* net, const float* x
   a.pack = pack; a.L = net_layout(net, HT);
   a.x = x; a.h = h; a.h_sb = h_sb; a.h_sd = h_sd; a.h_sc = h_sc;
   a.ccw = cc_w; a.cct = cc_t; a.S = S; a.z = z; a.jac = jac; a.n = B * d; a.d = d;
-  if (gnf_mono_fwd_wide_ok(a.L)) return gnf_mono_fwd_wide_launch(a, (hipStream_t)stream);
+  if (gnf_mono_fwd_wide_ok(a.L)) return gnf_mono_fwd_wide_launch(a, (hipStream_t)stream, true_f32, &g_fwd_kernel);
+  g_fwd_kernel = "mono_fwd_k";
   return launch_fwd<false>(a, (hipStream_t)stream);
 }
 

@@ -957,6 +957,320 @@ __global__ __launch_bounds__(64 * kWaves, 2) void mono_fwd_wide_k(MonoArgs a) {
   }
 }
 
+// =========================================================================================================================
+// Forward on the bf16 matrix pipe with fp32 accuracy (round 6; the fc1 kernels' method, gnf_gemm_split.hip): every fp32
+// operand of a hidden->hidden product is split exactly into three bf16 numbers (x = hi + mid + lo, round to nearest at each
+// level), a product is the sum of its six leading cross terms on v_mfma_f32_16x16x32_bf16 (16x the fp32 MFMA rate), hi*hi
+// in one fp32 accumulator and the five small terms in a second one.  Against an fp64 chain of three 160 x 160 layers the
+// result is 3x CLOSER than the fp32-MFMA chain's (tools/wide_split_probe.hip: 1.0e-7 against 3.3e-7 relative L2).
+//  * Weights: pre-split by mono_pack_k into fragment-major planes (MonoLayout::o_Wp), 1 KB per (plane, out tile, 32-wide k
+//    tile), streamed from L2 through the buffer descriptor like the fp32 fragments.
+//  * Activations: the layer inputs of the batch live in LDS as THREE bf16 planes [3][64 pairs][32 KT32 + 16] -- written by
+//    the lane that holds the values after the ReLU (split: 5.5 VALU instructions per value, three ds_write_b64 per tile), read
+//    back as B operands with one ds_read_b128 per plane and k tile (row pitch = 2 (mod 4) 16-byte slots: conflict-free for
+//    the hardware's 4 x 16 lane groups).  70.7 KB at H = 160: two workgroups per CU as before.
+//  * The first layer's conditioner part c1 stays in registers (the fp32 kernel parks it in LDS to leave room for a third
+//    workgroup; here the planes decide the occupancy).
+//  * Single-buffered weight fragments: a plane's registers are re-requested for the next k tile right behind its last
+//    product (lo: 1 of 6 products, mid: 2, hi: 3), so each request has at least a third of a k tile's MFMAs to land.
+// Layer 1 (rank-1 in x on top of c1), the last layer (a dot product per pair) and the quadrature stay fp32 VALU work.
+// GNF_TRUE_F32=1 keeps mono_fwd_wide_k.
+// =========================================================================================================================
+typedef unsigned u32x4w __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2w __attribute__((ext_vector_type(2)));
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8w;
+
+template <int HT, int NH>
+struct WidePlanS {
+  static constexpr int HP = 16 * HT, KT = (HP + 31) / 32, KP = 32 * KT;
+  static constexpr int PB = 2 * KP + 32;                    // bytes; PB / 16 = KP / 8 + 2 = 2 (mod 4)
+  static constexpr int PLANE = kNP * PB;                    // bytes
+  static constexpr int o_w1x = 0, o_wL = HP, o_b = 2 * HP;  // floats
+  static constexpr int o_bL = o_b + (NH - 1) * HP;
+  static constexpr int o_sred = o_bL + 4;                   // [2][64]
+  static constexpr int o_planes = o_sred + 2 * kNP;         // floats: a multiple of 4 (16-byte aligned)
+  static constexpr int total_bytes = 4 * o_planes + 3 * PLANE;
+};
+
+__device__ __forceinline__ unsigned cvt_pk_bf16w(float a, float b) {
+  unsigned r; asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r;
+}
+__device__ __forceinline__ void split3_pairw(float x0, float x1, unsigned& h, unsigned& m, unsigned& l) {
+  h = cvt_pk_bf16w(x0, x1);
+  const float r0 = x0 - __uint_as_float(h << 16), r1 = x1 - __uint_as_float(h & 0xffff0000u);   // exact
+  m = cvt_pk_bf16w(r0, r1);
+  const float q0 = r0 - __uint_as_float(m << 16), q1 = r1 - __uint_as_float(m & 0xffff0000u);   // exact
+  l = cvt_pk_bf16w(q0, q1);
+}
+__device__ __forceinline__ u32x4w ldfragu(rsrc_t rs, int voff, int soff) {
+  return __builtin_amdgcn_raw_buffer_load_b128(rs, voff, soff, 0);
+}
+__device__ __forceinline__ f32x4 mfma_bf(const u32x4w& a, const u32x4w& b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8w, a), __builtin_bit_cast(bf16x8w, b), c, 0, 0, 0);
+}
+
+// fragments (plane p, the wavefront's tiles, k tile t) of one matrix: full tile mi at soff + ((p HT + mi) KT + t) KB, the shared
+// tile at soffx + (p HT KT + t) KB
+template <int HT, int MF, int XT, int KT>
+__device__ __forceinline__ void fragp_load(rsrc_t rs, int voff, int soff, int soffx, int p, int t, u32x4w (&A)[MF + XT]) {
+#pragma unroll
+  for (int mi = 0; mi < MF; ++mi) A[mi] = ldfragu(rs, voff, soff + ((p * HT + mi) * KT + t) * 1024);
+  if constexpr (XT) A[MF] = ldfragu(rs, voff, soffx + (p * HT * KT + t) * 1024);
+}
+
+// acc[.][.][0] += hi hi, acc[.][.][1] += the five small terms, over all k tiles.  A: fragments of k tile 0 (requested by the
+// caller ahead of its serial section).  bsrc: LDS byte address of (plane 0, pair (slot 0, element j), position 8 q); slot 1 adds
+// 32 PB, plane p adds PLANE, k tile t adds 64;  bsrcx: the same for the shared tile's slot.
+template <int HT, int MF, int XT, int KT, int PB, int PLANE>
+__device__ __forceinline__ void layer_pass_split(rsrc_t rs, int voff, int soff, int soffx, const unsigned char* bsrc,
+                                                 const unsigned char* bsrcx, u32x4w (&A)[3][MF + XT],
+                                                 f32x4 (&acc)[MF + XT][2][2]) {
+  u32x4w B[3][2 + XT];
+  auto loadB = [&](int t) {
+#pragma unroll
+    for (int p = 0; p < 3; ++p) {
+#pragma unroll
+      for (int sl = 0; sl < 2; ++sl) B[p][sl] = *reinterpret_cast<const u32x4w*>(bsrc + p * PLANE + sl * kGE * PB + 64 * t);
+      if constexpr (XT) B[p][2] = *reinterpret_cast<const u32x4w*>(bsrcx + p * PLANE + 64 * t);
+    }
+  };
+  // products of (A plane pa) x (B plane pb) for every tile of the wavefront, into class cl
+  auto prod = [&](int pa, int pb, int cl) {
+#pragma unroll
+    for (int mi = 0; mi < MF; ++mi)
+#pragma unroll
+      for (int sl = 0; sl < 2; ++sl) acc[mi][sl][cl] = mfma_bf(A[pa][mi], B[pb][sl], acc[mi][sl][cl]);
+    if constexpr (XT) acc[MF][0][cl] = mfma_bf(A[pa][MF], B[pb][2], acc[MF][0][cl]);
+  };
+  loadB(0);
+#pragma unroll
+  for (int t = 0; t < KT; ++t) {
+    __builtin_amdgcn_sched_barrier(0);
+    prod(2, 0, 1);                                                        // lo hi
+    __builtin_amdgcn_sched_barrier(0);
+    if (t + 1 < KT) fragp_load<HT, MF, XT, KT>(rs, voff, soff, soffx, 2, t + 1, A[2]);
+    __builtin_amdgcn_sched_barrier(0);
+    prod(1, 1, 1); prod(1, 0, 1);                                         // mid mid, mid hi
+    __builtin_amdgcn_sched_barrier(0);
+    if (t + 1 < KT) fragp_load<HT, MF, XT, KT>(rs, voff, soff, soffx, 1, t + 1, A[1]);
+    __builtin_amdgcn_sched_barrier(0);
+    prod(0, 2, 1); prod(0, 1, 1); prod(0, 0, 0);                          // hi lo, hi mid | hi hi
+    __builtin_amdgcn_sched_barrier(0);
+    // the activation planes are single-buffered too (registers): their LDS latency at the head of the next k tile is covered
+    // by the CU's second workgroup
+    if (t + 1 < KT) { fragp_load<HT, MF, XT, KT>(rs, voff, soff, soffx, 0, t + 1, A[0]); loadB(t + 1); }
+  }
+  __builtin_amdgcn_sched_barrier(0);
+}
+
+template <int HT, int NH>
+__global__ __launch_bounds__(64 * kWaves, 2) void mono_fwd_wide_split_k(MonoArgs a) {
+  using PL = WidePlanS<HT, NH>;
+  constexpr int HP = PL::HP, KT = PL::KT, PB = PL::PB, PLANE = PL::PLANE;
+  constexpr int MF = HT / 2, XT = HT & 1, MT = MF + XT;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const MonoLayout& L = a.L;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int q = lane >> 4, j = lane & 15;
+  float* const sred = smem + PL::o_sred;
+  unsigned char* const planes = reinterpret_cast<unsigned char*>(smem + PL::o_planes);
+  for (int i = threadIdx.x; i < HP; i += blockDim.x) {
+    smem[PL::o_w1x + i] = a.pack[L.o_w1x + i];
+    smem[PL::o_wL + i] = a.pack[L.o_wL + i];
+#pragma unroll
+    for (int l = 1; l < NH; ++l) smem[PL::o_b + (l - 1) * HP + i] = a.pack[L.o_b[l] + i];
+  }
+  if (threadIdx.x == 0) smem[PL::o_bL] = a.pack[L.o_bL];
+  // positions HP .. KP-1 of every row (and the pad) meet zero weights, but must not hold NaN patterns: cleared once, never written
+  for (int i = threadIdx.x; i < 3 * kNP * (PB - 2 * HP) / 4; i += blockDim.x) {
+    const int row = i / ((PB - 2 * HP) / 4), w = i - row * ((PB - 2 * HP) / 4);
+    *reinterpret_cast<unsigned*>(planes + row * PB + 2 * HP + 4 * w) = 0u;
+  }
+
+  const int mh = wave & 1, nh = wave >> 1;
+  const int m0 = mh * (MF + XT);
+  const rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.pack), 0, L.pack_floats * 4, 0x00020000);
+  const int prow = (16 * nh + j) * PB, xrow = prow + mh * kGE * PB;       // bytes
+  const int ucol_c = 16 * m0 + 4 * q, xcol_c = 16 * MF + 4 * q;
+  auto col = [&](int mi, int uc, int xc) { return mi < MF ? uc + 16 * mi : xc; };
+  const WideSched ws = wide_sched(a.n, gridDim.x);
+  const float fS = (float)a.S;
+  const int NK = (a.S + 2 + 1) / 2 * 2;
+  auto wfrag = [&](int l) { return opaque_s(4 * (L.o_Wp[l] + m0 * KT * 256)); };
+  auto wfragx = [&](int l) { return opaque_s(4 * (L.o_Wp[l] + MF * KT * 256)); };
+
+  for (int64_t grp = blockIdx.x; grp < ws.nfull + ws.nhalf; grp += gridDim.x) {
+    const bool half = grp >= ws.nfull;
+    const int64_t ebase = half ? ws.nfull * kGE + 16 * (grp - ws.nfull) : grp * kGE;
+    const int nbat = half ? (NK + 3) / 4 : NK / 2;
+    const int knh = half ? 2 * nh : 0, kstep = half ? 4 : 2;
+    const int64_t el = ebase + (half ? j : 16 * nh + j);
+    const bool valid = el < a.n;
+    const int64_t e = valid ? el : a.n - 1;
+    const int64_t b = e / a.d, i = e - b * a.d;
+    const int64_t hbase = b * a.h_sb + i * a.h_sd;
+    const float xv = a.x[e];
+    const float xT = fS * (xv / fS);
+    const float h0 = a.h[hbase];
+    f32x4 c1[MT];                                       // W1h h + b1 of the lane's element and units
+#pragma unroll
+    for (int mi = 0; mi < MT; ++mi) c1[mi] = ld4(a.pack + L.o_b1 + col(mi, ucol_c, xcol_c));
+    for (int s = 0; s < L.CP / 16; ++s) {
+      float hv[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int cc = 16 * s + 4 * q + r;
+        hv[r] = cc < L.c ? a.h[hbase + cc * a.h_sc] : 0.f;
+      }
+#pragma unroll
+      for (int mi = 0; mi < MT; ++mi) {
+        const int tile = mi < MF ? m0 + mi : MF;
+        const f32x4 A = ld4(a.pack + L.o_W1h + (16 * tile + j) * L.LDH + 16 * s + 4 * q);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) c1[mi] = mfma(A[r], hv[r], c1[mi]);
+      }
+    }
+
+    float xk[2], wq[2];
+    bool isj[2];
+    f32x4 acc[MT][2][2];                                // [tile][node slot][class: hi hi | small terms]
+    f32x4 val[MT][2];                                   // the layer's outputs after the ReLU
+    u32x4w Apre[3][MT];
+    auto node_params = [&](int k0) {
+#pragma unroll
+      for (int sl = 0; sl < 2; ++sl) {
+        const int k = k0 + knh + sl;
+        const bool isq = k <= a.S;
+        isj[sl] = k == a.S + 1;
+        wq[sl] = isq ? a.ccw[k] : 0.f;
+        xk[sl] = isq ? xT * (a.cct[isq ? k : 0] + 1.f) * .5f : xv;
+      }
+    };
+    auto layer0 = [&](int ucol, int xcol) {
+      const float xkx = mh ? xk[1] : xk[0];
+#pragma unroll
+      for (int mi = 0; mi < MT; ++mi) {
+        const f32x4 wx = ld4(smem + PL::o_w1x + col(mi, ucol, xcol));
+#pragma unroll
+        for (int sl = 0; sl < (mi < MF ? 2 : 1); ++sl) {
+          const float xs = mi < MF ? xk[sl] : xkx;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) val[mi][sl][r] = relu1(fmaf(wx[r], xs, c1[mi][r]));
+        }
+      }
+    };
+    auto store_split = [&](int ucol, int xcol) {
+#pragma unroll
+      for (int mi = 0; mi < MT; ++mi)
+#pragma unroll
+        for (int sl = 0; sl < (mi < MF ? 2 : 1); ++sl) {
+          unsigned h0_, m0_, l0_, h1_, m1_, l1_;
+          split3_pairw(val[mi][sl][0], val[mi][sl][1], h0_, m0_, l0_);
+          split3_pairw(val[mi][sl][2], val[mi][sl][3], h1_, m1_, l1_);
+          unsigned char* dst = planes + (mi < MF ? prow + sl * kGE * PB : xrow) + 2 * col(mi, ucol, xcol);
+          *reinterpret_cast<u32x2w*>(dst) = u32x2w{h0_, h1_};
+          *reinterpret_cast<u32x2w*>(dst + PLANE) = u32x2w{m0_, m1_};
+          *reinterpret_cast<u32x2w*>(dst + 2 * PLANE) = u32x2w{l0_, l1_};
+        }
+    };
+    auto prefetch = [&](int l) {
+#pragma unroll
+      for (int p = 0; p < 3; ++p) fragp_load<HT, MF, XT, KT>(rs, 16 * lane, wfrag(l), wfragx(l), p, 0, Apre[p]);
+    };
+    node_params(0);
+    layer0(opaque_v(ucol_c), opaque_v(xcol_c));
+    prefetch(1);
+    float zacc = 0.f, fjac = 0.f;
+
+    for (int bt = 0; bt < nbat; ++bt) {
+      const int k0 = kstep * bt;
+      const int ucol = opaque_v(ucol_c), xcol = opaque_v(xcol_c);
+      __syncthreads();                                  // the previous batch's (group's) planes and partial dots are read
+      store_split(ucol, xcol);                          // input of hidden layer 1 (computed ahead)
+      __syncthreads();
+#pragma unroll
+      for (int l = 1; l < NH; ++l) {
+#pragma unroll
+        for (int mi = 0; mi < MT; ++mi) {
+          acc[mi][0][0] = ld4(smem + PL::o_b + (l - 1) * HP + col(mi, ucol, xcol));
+          acc[mi][1][0] = acc[mi][0][0];
+          acc[mi][0][1] = acc[mi][1][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        layer_pass_split<HT, MF, XT, KT, PB, PLANE>(rs, 16 * lane, wfrag(l), wfragx(l), planes + prow + 16 * q, planes + xrow + 16 * q,
+                                                    Apre, acc);
+        prefetch(l < NH - 1 ? l + 1 : 1);
+#pragma unroll
+        for (int mi = 0; mi < MT; ++mi)
+#pragma unroll
+          for (int sl = 0; sl < (mi < MF ? 2 : 1); ++sl)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) val[mi][sl][r] = relu1(acc[mi][sl][0][r] + acc[mi][sl][1][r]);
+        if (l < NH - 1) {
+          __syncthreads();                              // every wavefront has read the layer's inputs
+          store_split(ucol, xcol);
+          __syncthreads();
+        }
+      }
+      {
+        float sp[2] = {0.f, 0.f}, spx = 0.f;
+#pragma unroll
+        for (int mi = 0; mi < MT; ++mi) {
+          const f32x4 wl = ld4(smem + PL::o_wL + col(mi, ucol, xcol));
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            if (mi < MF) {
+              sp[0] = fmaf(wl[r], val[mi][0][r], sp[0]);
+              sp[1] = fmaf(wl[r], val[mi][1][r], sp[1]);
+            } else {
+              spx = fmaf(wl[r], val[mi][0][r], spx);
+            }
+          }
+        }
+        if constexpr (XT) { sp[0] += mh ? 0.f : spx; sp[1] += mh ? spx : 0.f; }
+#pragma unroll
+        for (int sl = 0; sl < 2; ++sl) {
+          sp[sl] = qsum(sp[sl]);
+          if (q == 0) sred[mh * kNP + kGE * sl + 16 * nh + j] = sp[sl];
+        }
+      }
+      __syncthreads();                                  // partial dots written (and the layer inputs no longer read)
+#pragma unroll
+      for (int sl = 0; sl < 2; ++sl) {
+        const float s = (sred[kGE * sl + 16 * nh + j] + sred[kNP + kGE * sl + 16 * nh + j]) + smem[PL::o_bL];
+        const float f = elu_plus(s);
+        zacc = fmaf(wq[sl], f, zacc);
+        if (isj[sl]) fjac = f;
+      }
+      if (bt + 1 < nbat) {
+        node_params(k0 + kstep);
+        layer0(ucol, xcol);
+      }
+    }
+    if (half) {                                         // the two node halves of an element meet (nh = 1 -> nh = 0)
+      __syncthreads();
+      if (nh == 1 && mh == 0 && q == 0) { sred[j] = zacc; sred[16 + j] = fjac; }
+      __syncthreads();
+      if (nh == 0) { zacc += sred[j]; fjac += sred[16 + j]; }
+    }
+    if (valid && mh == 0 && q == 0 && (!half || nh == 0)) {
+      a.z[el] = zacc * xT * .5f + h0;
+      a.jac[el] = fjac;
+    }
+  }
+}
+
+template <int HT, int NH>
+int launch_wide_fwd_split(const MonoArgs& a, hipStream_t s) {
+  const size_t lds = (size_t)WidePlanS<HT, NH>::total_bytes;
+  const int64_t groups = (a.n + kGE - 1) / kGE;
+  const unsigned grid = (unsigned)(groups < 512 ? groups : 512);        // persistent, two workgroups per CU
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mono_fwd_wide_split_k<HT, NH>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipLaunchKernelGGL((mono_fwd_wide_split_k<HT, NH>), dim3(grid), dim3(64 * kWaves), lds, s, a);
+  GNF_LAUNCH_CHECK();
+  return 0;
+}
+
 template <int HT, int NH>
 int launch_wide_fwd(const MonoArgs& a, hipStream_t s) {
   const size_t lds = (size_t)WidePlanF<HT, NH>::total * sizeof(float);
@@ -1018,7 +1332,18 @@ bool gnf_mono_fwd_wide_ok(const gnfmono::MonoLayout& L) {
   return L.HT == 7 || L.HT == 10;
 }
 
-int gnf_mono_fwd_wide_launch(const gnfmono::MonoArgs& a, hipStream_t s) {
+extern "C" int gnf_gemm_split_enabled(void);
+
+int gnf_mono_fwd_wide_launch(const gnfmono::MonoArgs& a, hipStream_t s, bool true_f32, const char** kernel) {
+  *kernel = "mono_fwd_wide_k";
+  if (!true_f32 && gnf_gemm_split_enabled()) {
+    *kernel = "mono_fwd_wide_split_k";                     // bf16 matrix pipe, exact 3 x bf16 splits (GNF_TRUE_F32=1: fp32 MFMA)
+#define GNF_WIDE_CASE(HT_, NH_) \
+  if (a.L.HT == HT_ && a.L.NH == NH_) return launch_wide_fwd_split<HT_, NH_>(a, s);
+    GNF_WIDE_CASE(7, 2) GNF_WIDE_CASE(7, 3) GNF_WIDE_CASE(7, 4) GNF_WIDE_CASE(10, 2) GNF_WIDE_CASE(10, 3) GNF_WIDE_CASE(10, 4)
+#undef GNF_WIDE_CASE
+    *kernel = "mono_fwd_wide_k";
+  }
 #define GNF_WIDE_CASE(HT_, NH_) \
   if (a.L.HT == HT_ && a.L.NH == NH_) return launch_wide_fwd<HT_, NH_>(a, s);
   GNF_WIDE_CASE(7, 2) GNF_WIDE_CASE(7, 3) GNF_WIDE_CASE(7, 4) GNF_WIDE_CASE(10, 2) GNF_WIDE_CASE(10, 3) GNF_WIDE_CASE(10, 4)

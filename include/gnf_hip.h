@@ -267,6 +267,17 @@ int gnf_monotonic_fwd(const float* pack, const gnf_mono_net* net,
                       const float* x, const float* h, int64_t h_sb, int64_t h_sd, int64_t h_sc,
                       const float* cc_w, const float* cc_t, int S,
                       float* z, float* jac, int64_t B, int64_t d, gnf_stream_t stream);
+/* Wide integrand nets (hidden widths 97..112, 145..160: the [100]^3 / [150]^3 nets of UCIExperiments.yml) run their
+ * hidden->hidden products on the bf16 matrix pipe with exact 3 x bf16 operand splits, six cross terms and fp32 accumulation
+ * (closer to an fp64 evaluation than the fp32-MFMA kernel, tests/test_gpu_mono_split.py).  GNF_TRUE_F32=1 (read once per
+ * process) selects the fp32-MFMA kernel for gnf_monotonic_fwd; gnf_monotonic_fwd_f32 always does (same arguments: the A/B
+ * handle of the tests and tools).  gnf_monotonic_fwd_kernel(): name of the kernel family the last forward call of this
+ * thread launched ("mono_fwd_wide_split_k", "mono_fwd_wide_k", "mono_fwd_k"). */
+int gnf_monotonic_fwd_f32(const float* pack, const gnf_mono_net* net,
+                          const float* x, const float* h, int64_t h_sb, int64_t h_sd, int64_t h_sc,
+                          const float* cc_w, const float* cc_t, int S,
+                          float* z, float* jac, int64_t B, int64_t d, gnf_stream_t stream);
+const char* gnf_monotonic_fwd_kernel(void);
 /* 20-step bisection on [-20,20] with the quadrature inside (MonotonicNormalizer.py:69-83). */
 int gnf_monotonic_inv(const float* pack, const gnf_mono_net* net,
                       const float* z, const float* h, int64_t h_sb, int64_t h_sd, int64_t h_sc,

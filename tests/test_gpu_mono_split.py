@@ -1,0 +1,130 @@
+"""GPU: the Monotonic forward of WIDE integrand nets on the bf16 matrix pipe (mono_fwd_wide_split_k: exact 3 x bf16 operand
+splits, six cross terms, fp32 accumulate) against an fp64 evaluation of the reference's arithmetic
+(models/Normalizers/MonotonicNormalizer.py:21-66; the Clenshaw-Curtis rule as the kernels receive it) and against the fp32-MFMA
+kernel it replaces (gnf_monotonic_fwd_f32 = what GNF_TRUE_F32=1 runs).  Adoption criterion, as for the fc1 products
+(tests/test_gpu_split.py): the split kernel's error against fp64 is not larger than the fp32-MFMA kernel's."""
+import ctypes
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _params(hidden, c, seed, scale=1.):
+    g = torch.Generator().manual_seed(seed)
+    dims = [1 + c] + list(hidden) + [1]
+    ps = []
+    for i in range(len(dims) - 1):
+        bound = scale / dims[i] ** .5
+        ps.append(((torch.rand(dims[i + 1], dims[i], generator=g) * 2 - 1) * bound * 1.7).to(DEV))
+        ps.append(((torch.rand(dims[i + 1], generator=g) * 2 - 1) * bound).to(DEV))
+    return ps
+
+
+def _fwd(entry, params, x, h, S):
+    from gnf_hip import abi, ops
+    from gnf_hip.abi import call, ptr, stream
+    net = ops._mono_net(params)
+    pack = ops._mono_pack(net, x)
+    w, t = ops.cc_rule(S, x.device)
+    z, jac = torch.empty_like(x), torch.empty_like(x)
+    call(entry, ptr(pack), ctypes.byref(net), ptr(x), ptr(h), h.stride(0), h.stride(1), h.stride(2), ptr(w), ptr(t), int(S),
+         ptr(z), ptr(jac), x.shape[0], x.shape[1], stream())
+    return z, jac, abi.load().gnf_monotonic_fwd_kernel().decode()
+
+
+def _fp64(params, x, h, S):
+    """the same quadrature in fp64 (weights / nodes = the fp32 rule the kernels receive, promoted)"""
+    from gnf_hip import ops
+    w, t = ops.cc_rule(S, x.device)
+    w, t = w.double(), t.double()
+    P = [p.double() for p in params]
+    xd, hd = x.double(), h.double()
+    fS = torch.tensor(float(S), dtype=torch.float32, device=x.device)
+    xT = (fS * (x / fS)).double()                      # xT is formed in fp32 by the reference (x0 + nb_steps * step)
+
+    def f(tt):                                         # tt [B, d, K]
+        a = torch.cat([tt.unsqueeze(-1), hd.unsqueeze(2).expand(-1, -1, tt.shape[2], -1)], -1)
+        for k in range(0, len(P), 2):
+            a = a @ P[k].t() + P[k + 1]
+            if k + 2 < len(P):
+                a = torch.relu(a)
+        a = a[..., 0]
+        return torch.where(a > 0, a, torch.expm1(torch.clamp(a, max=0.))) + 1.05
+    nodes = xT.unsqueeze(-1) * (t + 1.) / 2.
+    z = (f(nodes) * w).sum(-1) * xT / 2. + hd[..., 0]
+    jac = f(xd.unsqueeze(-1))[..., 0]
+    return z, jac
+
+
+CASES = [([100, 100, 100], 30, 6, 700, 20), ([150, 150, 150], 30, 9, 300, 20), ([160, 160], 8, 5, 333, 9), ([112] * 4, 30, 3, 257, 20),
+         ([97, 105, 112], 17, 4, 129, 15), ([145, 160, 150], 30, 7, 64, 150), ([150, 150, 150], 30, 63, 50, 250)]
+
+
+@pytest.mark.parametrize("hidden,c,d,B,S", CASES)
+def test_split_forward_vs_fp64_and_fp32_mfma(hidden, c, d, B, S):
+    from gnf_hip import abi
+    if not abi.load().gnf_gemm_split_enabled():
+        pytest.skip("GNF_TRUE_F32=1")
+    params = _params(hidden, c, seed=sum(hidden) + S, scale=1.3)
+    g = torch.Generator().manual_seed(B)
+    x = (torch.randn(B, d, generator=g) * 2.).to(DEV)
+    h = torch.randn(B, d, c, generator=g).to(DEV)
+    zs, js, ks = _fwd("gnf_monotonic_fwd", params, x, h, S)
+    zf, jf, kf = _fwd("gnf_monotonic_fwd_f32", params, x, h, S)
+    assert ks == "mono_fwd_wide_split_k" and kf == "mono_fwd_wide_k", (ks, kf)
+    z64, j64 = _fp64(params, x, h, S)
+
+    def errs(a, ref):
+        e = (a.double() - ref).abs()
+        return float(e.max() / ref.abs().max()), float((e.pow(2).mean() / ref.pow(2).mean()).sqrt())
+    ez_s, ez_f, ej_s, ej_f = errs(zs, z64), errs(zf, z64), errs(js, j64), errs(jf, j64)
+    print("\n[mono split %s S=%d] z: split max %.2e rms %.2e | fp32-MFMA max %.2e rms %.2e;  jac: split max %.2e rms %.2e | fp32-MFMA max %.2e rms %.2e"
+          % (hidden, S, *ez_s, *ez_f, *ej_s, *ej_f))
+    # the split kernel is as close to fp64 as the kernel it replaces.  Both sit at the roundoff of the fp32 parts they share
+    # (layer 1, the last layer's dot product, the quadrature sum: ~1e-7 of the result), so "not larger" is asked up to a quarter
+    # of the fp32 kernel's own error plus a fraction of one fp32 epsilon (1.2e-7)
+    assert ez_s[1] <= 1.25 * ez_f[1] + 2e-8 and ej_s[1] <= 1.25 * ej_f[1] + 2e-8, (ez_s, ez_f, ej_s, ej_f)
+    assert ez_s[0] <= 1.5 * ez_f[0] + 1.2e-7 and ej_s[0] <= 1.5 * ej_f[0] + 1.2e-7, (ez_s, ez_f, ej_s, ej_f)
+    assert ez_s[0] < 2e-6 and ej_s[0] < 2e-6, (ez_s, ej_s)
+    # deterministic
+    zs2, js2, _ = _fwd("gnf_monotonic_fwd", params, x, h, S)
+    assert torch.equal(zs, zs2) and torch.equal(js, js2)
+
+
+def test_split_forward_ragged_sizes_and_strided_h():
+    """element counts around the group / half-group boundaries of the persistent schedule, h as a permuted view (MADE's output)"""
+    from gnf_hip import abi
+    if not abi.load().gnf_gemm_split_enabled():
+        pytest.skip("GNF_TRUE_F32=1")
+    params = _params([150, 150, 150], 30, seed=11)
+    for B, d in [(1, 1), (1, 31), (3, 11), (5, 13), (16385, 1), (513, 33)]:
+        g = torch.Generator().manual_seed(B + d)
+        x = (torch.randn(B, d, generator=g) * 2.).to(DEV)
+        hT = torch.randn(B, 30, d, generator=g).to(DEV)
+        h = hT.permute(0, 2, 1)                          # [B, d, c] view with strides (30 d, 1, d)
+        zs, js, ks = _fwd("gnf_monotonic_fwd", params, x, h, 20)
+        zf, jf, _ = _fwd("gnf_monotonic_fwd_f32", params, x, h, 20)
+        assert ks == "mono_fwd_wide_split_k"
+        assert torch.allclose(zs, zf, rtol=2e-6, atol=2e-6) and torch.allclose(js, jf, rtol=2e-6, atol=2e-6), (B, d)
+
+
+def test_true_f32_switch_selects_the_fp32_kernel():
+    import subprocess
+    import sys
+    code = ("import sys, torch; sys.path[:0] = [%r, %r]\n"
+            "from tests.test_gpu_mono_split import _params, _fwd\n"
+            "p = _params([150, 150, 150], 30, 1)\n"
+            "x = torch.randn(40, 7, device='cuda:0'); h = torch.randn(40, 7, 30, device='cuda:0')\n"
+            "print(_fwd('gnf_monotonic_fwd', p, x, h, 20)[2])\n") % (ROOT, ROOT + "/graphical-normalizing-flows_amd")
+    out = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, GNF_TRUE_F32="1"), capture_output=True, text=True,
+                         timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert out.stdout.strip().splitlines()[-1] == "mono_fwd_wide_k", out.stdout
+
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
