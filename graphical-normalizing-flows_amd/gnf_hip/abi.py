@@ -94,6 +94,10 @@ SIGNATURES = {
     "gnf_monotonic_bwd": (c_int, [c_f, ctypes.POINTER(MonoNet), c_f, c_f, c_i64, c_i64, c_i64, c_f, c_f, c_int, c_f,
                                   c_f, c_f, c_f, c_i64, c_i64, c_i64, ctypes.POINTER(ctypes.c_void_p),
                                   ctypes.POINTER(ctypes.c_void_p), ctypes.c_void_p, c_i64, c_i64, c_i64, c_stream]),
+    "gnf_monotonic_bwd_f32": (c_int, [c_f, ctypes.POINTER(MonoNet), c_f, c_f, c_i64, c_i64, c_i64, c_f, c_f, c_int, c_f,
+                                      c_f, c_f, c_f, c_i64, c_i64, c_i64, ctypes.POINTER(ctypes.c_void_p),
+                                      ctypes.POINTER(ctypes.c_void_p), ctypes.c_void_p, c_i64, c_i64, c_i64, c_stream]),
+    "gnf_monotonic_bwd_kernel": (ctypes.c_char_p, []),
     "gnf_dag_loss_prep": (c_int, [c_f, c_f, c_float, c_f, c_i64, c_stream]),
     "gnf_dag_loss_value": (c_int, [c_f, c_f, c_f, c_f, c_float, c_f, c_f, c_f, c_f, c_int, c_f, c_f, c_i64, c_stream]),
     "gnf_dag_loss_bwd": (c_int, [c_f, c_f, c_f, c_f, c_f, c_i64, c_stream]),

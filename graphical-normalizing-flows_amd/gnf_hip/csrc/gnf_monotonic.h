@@ -33,7 +33,8 @@ struct MonoLayout {
   // on the bf16 matrix pipe (mono_fwd_wide_split_k), fragment-major for v_mfma_f32_16x16x32_bf16:
   //   Wp[l][plane][mt][t][lane] = 16 bytes = plane of W_l[16 mt + j][32 t + 8 q .. + 7]   (t < KT32 = ceil(HP / 32); zeros past HP)
   // offsets in 4-byte words like everything else in the pack; 3 * HT * KT32 * 256 words per layer.
-  int o_Wp[kMaxNH], KT32;
+  //   WTp[l][plane][mt][t][lane] = plane of W_l[32 t + 8 q .. + 7][16 mt + j]  (the data gradient's transposed products)
+  int o_Wp[kMaxNH], o_WTp[kMaxNH], KT32;
   int pack_floats;                    // size of the whole pack
   // K order of the last unit tile (HT >= 7 only, round 5).  An MFMA k-step r of k-tile t contracts the padded positions
   // 16 t + 4 q + r, q = 0..3: with the units of a width-H layer at positions 0 .. H-1 the H mod 16 units of the last tile are
@@ -91,10 +92,11 @@ __host__ __device__ inline MonoLayout make_layout(int HT, int NH, int c) {
   L.o_W1hT = o; o += L.CP * L.LDW;
   L.total_floats = o;
   L.KT32 = (L.HP + 31) / 32;
-  for (int l = 1; l < NH; ++l) { L.o_Wf[l] = 0; L.o_WTf[l] = 0; L.o_Wp[l] = 0; }
+  for (int l = 1; l < NH; ++l) { L.o_Wf[l] = 0; L.o_WTf[l] = 0; L.o_Wp[l] = 0; L.o_WTp[l] = 0; }
   if (HT >= 7) {
     for (int l = 1; l < NH; ++l) { L.o_Wf[l] = o; o += L.HP * L.HP; L.o_WTf[l] = o; o += L.HP * L.HP; }
     for (int l = 1; l < NH; ++l) { L.o_Wp[l] = o; o += 3 * HT * L.KT32 * 256; }
+    for (int l = 1; l < NH; ++l) { L.o_WTp[l] = o; o += 3 * HT * L.KT32 * 256; }
   }
   L.pack_floats = o;
   return L;
@@ -162,7 +164,7 @@ __device__ __forceinline__ float elu_plus(float s) { return (s > 0.f ? s : expm1
 // ok(): the net's shape has an instantiation and its LDS plan fits.  grid(): persistent workgroups (= rows of a.wpart).
 bool gnf_mono_bwd_wide_ok(const gnfmono::MonoLayout& L);
 unsigned gnf_mono_bwd_wide_grid(const gnfmono::MonoLayout& L, int64_t n);
-int gnf_mono_bwd_wide_launch(const gnfmono::MonoArgs& a, unsigned grid, hipStream_t s);
+int gnf_mono_bwd_wide_launch(const gnfmono::MonoArgs& a, unsigned grid, hipStream_t s, bool true_f32, const char** kernel);
 // forward (z, jac) of the same nets in the same formulation, two workgroups per CU
 bool gnf_mono_fwd_wide_ok(const gnfmono::MonoLayout& L);
 // true_f32: the fp32-MFMA kernel even when the split-bf16 one is enabled.  *kernel: the family launched.

@@ -50,17 +50,18 @@ __global__ void mono_pack_k(PackArgs a, float* __restrict__ pack) {
     float v = 0.f;
     if (L.NH > 1 && L.o_Wp[1] && idx >= L.o_Wp[1]) {   // bf16 split planes of the hidden->hidden matrices (see MonoLayout)
       const int per = 3 * L.HT * L.KT32 * 256;
-      const int l = 1 + (idx - L.o_Wp[1]) / per, k = (idx - L.o_Wp[1]) % per;
+      const bool tr = idx >= L.o_WTp[1];               // transposed planes behind the forward ones
+      const int l = 1 + (idx - (tr ? L.o_WTp[1] : L.o_Wp[1])) / per, k = (idx - L.o_Wp[1]) % per;
       const int plane = k / (L.HT * L.KT32 * 256), kk = k % (L.HT * L.KT32 * 256);
       const int frag = kk >> 8, lane = (kk >> 2) & 63, w2 = kk & 3, mt = frag / L.KT32, t = frag - mt * L.KT32;
       const int q = lane >> 4, j = lane & 15;
-      const int row = unit(16 * mt + j, l + 1);
+      const int row = unit(16 * mt + j, tr ? l : l + 1);          // fragment row: out unit (transposed: in unit)
       float x[2] = {0.f, 0.f};
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
         const int cp = 32 * t + 8 * q + 2 * w2 + i;
-        const int col = cp < L.HP ? unit(cp, l) : -1;
-        if (row >= 0 && col >= 0) x[i] = N.W[l][(int64_t)row * N.dims[l] + col];
+        const int col = cp < L.HP ? unit(cp, tr ? l + 1 : l) : -1;  // contraction index: in unit (transposed: out unit)
+        if (row >= 0 && col >= 0) x[i] = tr ? N.W[l][(int64_t)col * N.dims[l] + row] : N.W[l][(int64_t)row * N.dims[l] + col];
       }
       unsigned word = 0;
       for (int pl = 0; pl <= plane; ++pl) {           // hi, then the rounded remainders (exact subtractions)
@@ -2495,6 +2496,22 @@ int64_t gnf_monotonic_bwd_ws_bytes(const gnf_mono_net* net, int S, int64_t B, in
   return kWsTarget > min_bytes ? kWsTarget : min_bytes;
 }
 
+static thread_local bool g_bwd_true_f32 = false;
+static thread_local const char* g_bwd_kernel = "";
+const char* gnf_monotonic_bwd_kernel(void) { return g_bwd_kernel; }
+
+int gnf_monotonic_bwd_f32(const float* pack, const gnf_mono_net* net, const float* x, const float* h, int64_t h_sb,
+                          int64_t h_sd, int64_t h_sc, const float* cc_w, const float* cc_t, int S, const float* gz,
+                          const float* gjac, float* gx, float* gh, int64_t g_sb, int64_t g_sd, int64_t g_sc,
+                          float* const* gW, float* const* gb, void* ws, int64_t ws_bytes, int64_t B, int64_t d,
+                          gnf_stream_t stream) {
+  g_bwd_true_f32 = true;
+  const int rc = gnf_monotonic_bwd(pack, net, x, h, h_sb, h_sd, h_sc, cc_w, cc_t, S, gz, gjac, gx, gh, g_sb, g_sd, g_sc, gW, gb, ws,
+                                   ws_bytes, B, d, stream);
+  g_bwd_true_f32 = false;
+  return rc;
+}
+
 int gnf_monotonic_bwd(const float* pack, const gnf_mono_net* net, const float* x, const float* h, int64_t h_sb,
                       int64_t h_sd, int64_t h_sc, const float* cc_w, const float* cc_t, int S, const float* gz,
                       const float* gjac, float* gx, float* gh, int64_t g_sb, int64_t g_sd, int64_t g_sc,
@@ -2561,8 +2578,11 @@ int gnf_monotonic_bwd(const float* pack, const gnf_mono_net* net, const float* x
     a.ecount = n - a.e0 < P.chunk_elems ? n - a.e0 : P.chunk_elems;
     if (wide) {                        // its wavefronts write only their own half of the partial rows
       if (hipMemsetAsync(a.part, 0, sizeof(float) * part_rows * vecw, s) != hipSuccess) return GNF_EINVAL;
-      if ((rc = gnf_mono_bwd_wide_launch(a, bwd_grid, s))) return rc;
-    } else if ((rc = launch_bwd(a, bwd_grid, s))) return rc;
+      if ((rc = gnf_mono_bwd_wide_launch(a, bwd_grid, s, g_bwd_true_f32, &g_bwd_kernel))) return rc;
+    } else {
+      g_bwd_kernel = "mono_bwd_k";
+      if ((rc = launch_bwd(a, bwd_grid, s))) return rc;
+    }
     const int64_t groups = (a.ecount + 15) / 16;
     const int64_t rows = groups * NK * 16;
     const int accum = ck > 0 ? GNF_GEMM_ACCUM : 0;     // chunk 0 is the largest: it defines the split count

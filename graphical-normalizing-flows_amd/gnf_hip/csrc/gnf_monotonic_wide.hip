@@ -141,6 +141,98 @@ __device__ __forceinline__ void layer_pass(rsrc_t rs, int voff, int soff, int so
   __builtin_amdgcn_sched_barrier(0);
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// bf16 matrix pipe with exact 3 x bf16 operand splits (round 6; see mono_fwd_wide_split_k below for the method)
+// ---------------------------------------------------------------------------------------------------------------------
+typedef unsigned u32x4w __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2w __attribute__((ext_vector_type(2)));
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8w;
+
+__device__ __forceinline__ unsigned cvt_pk_bf16w(float a, float b) {
+  unsigned r; asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r;
+}
+typedef float f32x2w __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void split3_pairw(float x0, float x1, unsigned& h, unsigned& m, unsigned& l) {
+  // the two remainders of a level as ONE packed subtraction (v_pk_add_f32): 9 instead of 11 instructions per pair
+  h = cvt_pk_bf16w(x0, x1);
+  const f32x2w r = f32x2w{x0, x1} - f32x2w{__uint_as_float(h << 16), __uint_as_float(h & 0xffff0000u)};   // exact
+  m = cvt_pk_bf16w(r[0], r[1]);
+  const f32x2w q = r - f32x2w{__uint_as_float(m << 16), __uint_as_float(m & 0xffff0000u)};                // exact
+  l = cvt_pk_bf16w(q[0], q[1]);
+}
+__device__ __forceinline__ u32x4w ldfragu(rsrc_t rs, int voff, int soff) {
+  return __builtin_amdgcn_raw_buffer_load_b128(rs, voff, soff, 0);
+}
+__device__ __forceinline__ f32x4 mfma_bf(const u32x4w& a, const u32x4w& b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8w, a), __builtin_bit_cast(bf16x8w, b), c, 0, 0, 0);
+}
+
+// fragments (plane p, the wavefront's tiles, k tile t) of one matrix: full tile mi at soff + ((p HT + mi) KT + t) KB, the shared
+// tile at soffx + (p HT KT + t) KB
+template <int HT, int MF, int XT, int KT>
+__device__ __forceinline__ void fragp_load(rsrc_t rs, int voff, int soff, int soffx, int p, int t, u32x4w (&A)[MF + XT]) {
+#pragma unroll
+  for (int mi = 0; mi < MF; ++mi) A[mi] = ldfragu(rs, voff, soff + ((p * HT + mi) * KT + t) * 1024);
+  if constexpr (XT) A[MF] = ldfragu(rs, voff, soffx + (p * HT * KT + t) * 1024);
+}
+
+
+// The same products for the BACKWARD's chain wavefronts, whose layer inputs and dpre stay fp32 in LDS (the weight-gradient
+// wavefronts contract them as fp32, the ReLU gates read them): a B fragment is 8 consecutive floats of the pair's row
+// (two ds_read_b128), split in registers (44 VALU instructions) and used by every tile of the wavefront -- 6 (MF + shared)
+// MFMAs of 16 cycles each per split.  One accumulator class (registers: the chain wavefronts carry 60 registers of
+// per-lane gradient partials through the loop): against fp64 the same error as the fp32 MFMA's (tools/wide_split_probe.hip).
+//   bsrc: LDS address (floats) of (pair (slot 0, element j), position 8 q); slot 1 adds 32 P; k tile t adds 32
+template <int HT, int MF, int XT, int KT, int P>
+__device__ __forceinline__ void layer_pass_split32(rsrc_t rs, int voff, int soff, int soffx, const float* bsrc, const float* bsrcx,
+                                                   u32x4w (&A)[3][MF + XT], f32x4 (&acc)[MF + XT][2]) {
+  constexpr int HP = 16 * HT;
+  u32x4w B[3][2 + XT];
+  const int qv = (int)(threadIdx.x & 63) >> 4;
+  auto loadB = [&](int t) {
+#pragma unroll
+    for (int sl = 0; sl < 2 + XT; ++sl) {
+      const float* src = (sl < 2 ? bsrc + sl * kGE * P : bsrcx) + 32 * t;
+      f32x4 lo = ld4(src), hi = ld4(src + 4);
+      if (32 * t + 32 > HP) {                        // the last k tile of an odd tile count: positions >= HP belong to the next row
+        if (32 * t + 8 * qv >= HP) { lo = f32x4{0.f, 0.f, 0.f, 0.f}; hi = lo; }
+      }
+      unsigned h[4], m[4], l[4];
+      split3_pairw(lo[0], lo[1], h[0], m[0], l[0]);
+      split3_pairw(lo[2], lo[3], h[1], m[1], l[1]);
+      split3_pairw(hi[0], hi[1], h[2], m[2], l[2]);
+      split3_pairw(hi[2], hi[3], h[3], m[3], l[3]);
+      B[0][sl] = u32x4w{h[0], h[1], h[2], h[3]};
+      B[1][sl] = u32x4w{m[0], m[1], m[2], m[3]};
+      B[2][sl] = u32x4w{l[0], l[1], l[2], l[3]};
+    }
+  };
+  auto prod = [&](int pa, int pb) {
+#pragma unroll
+    for (int mi = 0; mi < MF; ++mi)
+#pragma unroll
+      for (int sl = 0; sl < 2; ++sl) acc[mi][sl] = mfma_bf(A[pa][mi], B[pb][sl], acc[mi][sl]);
+    if constexpr (XT) acc[MF][0] = mfma_bf(A[pa][MF], B[pb][2], acc[MF][0]);
+  };
+  loadB(0);
+#pragma unroll
+  for (int t = 0; t < KT; ++t) {
+    __builtin_amdgcn_sched_barrier(0);
+    prod(2, 0);                                                           // small terms first, hi hi last
+    __builtin_amdgcn_sched_barrier(0);
+    if (t + 1 < KT) fragp_load<HT, MF, XT, KT>(rs, voff, soff, soffx, 2, t + 1, A[2]);
+    __builtin_amdgcn_sched_barrier(0);
+    prod(1, 1); prod(1, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    if (t + 1 < KT) fragp_load<HT, MF, XT, KT>(rs, voff, soff, soffx, 1, t + 1, A[1]);
+    __builtin_amdgcn_sched_barrier(0);
+    prod(0, 2); prod(0, 1); prod(0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    if (t + 1 < KT) { fragp_load<HT, MF, XT, KT>(rs, voff, soff, soffx, 0, t + 1, A[0]); loadB(t + 1); }
+  }
+  __builtin_amdgcn_sched_barrier(0);
+}
+
 // In-place MFMA for the long-lived weight-gradient accumulators.  The builtin leaves vdst and srcC untied; with 200 of the
 // 256 registers holding accumulators the allocator then splits their live ranges (v_mov chains through the whole tile
 // set and scratch spills in the first build of the role).  Tied through the "+v" constraint every tile stays where it is.
@@ -393,7 +485,9 @@ __device__ __forceinline__ void dw_role(const MonoArgs& a, float* smem, int w, W
         wrow[l * HP * HP + (16 * (ti0 + D::lrow(i)) + 4 * q + r) * HP + 16 * (tn0 + D::lcol(i)) + j] = accW[l][i][r];
 }
 
-template <int HT, int NH>
+// SPLIT: the chain wavefronts' hidden->hidden products (recompute and data gradient) on the bf16 matrix pipe
+// (layer_pass_split32); the weight-gradient wavefronts are the same in both forms.
+template <int HT, int NH, bool SPLIT>
 __global__ __launch_bounds__(64 * kWideWaves, 1) void mono_bwd_wide_k(MonoArgs a) {
   static_assert(NH >= 2, "at least one hidden->hidden layer");
   using PL = WidePlan<HT, NH>;
@@ -517,7 +611,28 @@ __global__ __launch_bounds__(64 * kWideWaves, 1) void mono_bwd_wide_k(MonoArgs a
     float xk[2], cot[2];
     bool isj[2];
     f32x4 acc[MT][2];                                 // layer-1 input -> pre-activation -> activation -> dpre of (own units, own pairs)
-    f32x4 Apre[MT];                                   // first weight fragments of the next pass
+    f32x4 Apre[SPLIT ? 1 : MT];                       // first weight fragments of the next pass
+    u32x4w Asp[SPLIT ? 3 : 1][MT];                    // ... and, split form, the fragment registers themselves
+    constexpr int KT = (HP + 31) / 32;
+    // request the first fragments of a pass over matrix `om` (fp32: o_Wf / o_WTf, split: o_Wp / o_WTp of the same layer)
+    auto prefetch = [&](int of32, int osp) {
+      if constexpr (SPLIT) {
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl)
+          fragp_load<HT, MF, XT, KT>(rs, 16 * lane, opaque_s(4 * (osp + m0 * KT * 256)), opaque_s(4 * (osp + MF * KT * 256)), pl, 0, Asp[pl]);
+      } else {
+        frag_prefetch<HT, MF, XT>(rs, 16 * lane, opaque_s(4 * (of32 + m0 * HT * 256)), opaque_s(4 * (of32 + MF * HT * 256)), Apre);
+      }
+    };
+    auto pass = [&](int of32, int osp, const float* buf, int ksv) {
+      if constexpr (SPLIT) {
+        layer_pass_split32<HT, MF, XT, KT, P>(rs, 16 * lane, opaque_s(4 * (osp + m0 * KT * 256)), opaque_s(4 * (osp + MF * KT * 256)),
+                                              buf + prow + 8 * q, buf + xrow + 8 * q, Asp, acc);
+      } else {
+        layer_pass<HT, MF, XT, P>(rs, 16 * lane, opaque_s(4 * (of32 + m0 * HT * 256)), opaque_s(4 * (of32 + MF * HT * 256)),
+                                  buf + prow + 4 * q, buf + xrow + 4 * q, Apre, acc, ksv);
+      }
+    };
     auto node_params = [&](int k0) {
 #pragma unroll
       for (int sl = 0; sl < 2; ++sl) {
@@ -546,7 +661,7 @@ __global__ __launch_bounds__(64 * kWideWaves, 1) void mono_bwd_wide_k(MonoArgs a
     };
     node_params(0);
     layer0(opaque_v(ucol_c), opaque_v(xcol_c));
-    frag_prefetch<HT, MF, XT>(rs, 16 * lane, opaque_s(4 * (L.o_Wf[1] + m0 * HT * 256)), opaque_s(4 * (L.o_Wf[1] + MF * HT * 256)), Apre);
+    prefetch(L.o_Wf[1], L.o_Wp[1]);
 
     for (int bt = 0; bt < nbat; ++bt) {
       const int k0 = kstep * bt;
@@ -574,13 +689,9 @@ __global__ __launch_bounds__(64 * kWideWaves, 1) void mono_bwd_wide_k(MonoArgs a
           acc[mi][0] = ld4(smem + PL::o_b + (l - 1) * HP + col(mi, ucol, xcol));
           acc[mi][1] = acc[mi][0];
         }
-        layer_pass<HT, MF, XT, P>(rs, 16 * lane, opaque_s(4 * (L.o_Wf[l] + m0 * HT * 256)),
-                                  opaque_s(4 * (L.o_Wf[l] + MF * HT * 256)), actbuf(l) + prow + 4 * q,
-                                  actbuf(l) + xrow + 4 * q, Apre, acc, L.ksv[l]);
-        {                                             // next pass: the next layer, or the top layer's transpose
-          const int on = l < NH - 1 ? L.o_Wf[l < NH - 1 ? l + 1 : l] : L.o_WTf[NH - 1];
-          frag_prefetch<HT, MF, XT>(rs, 16 * lane, opaque_s(4 * (on + m0 * HT * 256)), opaque_s(4 * (on + MF * HT * 256)), Apre);
-        }
+        pass(L.o_Wf[l], L.o_Wp[l], actbuf(l), L.ksv[l]);
+        // next pass: the next layer, or the top layer's transpose
+        prefetch(l < NH - 1 ? L.o_Wf[l < NH - 1 ? l + 1 : l] : L.o_WTf[NH - 1], l < NH - 1 ? L.o_Wp[l < NH - 1 ? l + 1 : l] : L.o_WTp[NH - 1]);
         STAMP(3 + 3 * (l - 1));
 #pragma unroll
         for (int mi = 0; mi < MT; ++mi)
@@ -666,13 +777,9 @@ __global__ __launch_bounds__(64 * kWideWaves, 1) void mono_bwd_wide_k(MonoArgs a
         // d input_l = W_l^T dpre_l, gated by input_l > 0 (for l = 1 that is the first layer's dpre)
 #pragma unroll
         for (int mi = 0; mi < MT; ++mi) { acc[mi][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[mi][1] = acc[mi][0]; }
-        layer_pass<HT, MF, XT, P>(rs, 16 * lane, opaque_s(4 * (L.o_WTf[l] + m0 * HT * 256)),
-                                  opaque_s(4 * (L.o_WTf[l] + MF * HT * 256)), dpbuf + prow + 4 * q, dpbuf + xrow + 4 * q, Apre, acc,
-                                  L.ksv[l + 1]);
-        {                                             // next pass: the layer below, or layer 1 of the next batch
-          const int on = l > 1 ? L.o_WTf[l > 1 ? l - 1 : l] : L.o_Wf[1];
-          frag_prefetch<HT, MF, XT>(rs, 16 * lane, opaque_s(4 * (on + m0 * HT * 256)), opaque_s(4 * (on + MF * HT * 256)), Apre);
-        }
+        pass(L.o_WTf[l], L.o_WTp[l], dpbuf, L.ksv[l + 1]);
+        // next pass: the layer below, or layer 1 of the next batch
+        prefetch(l > 1 ? L.o_WTf[l > 1 ? l - 1 : l] : L.o_Wf[1], l > 1 ? L.o_WTp[l > 1 ? l - 1 : l] : L.o_Wp[1]);
         STAMP(16 + 5 * (NH - 1 - l));
         const float* ag = actbuf(l);
 #pragma unroll
@@ -976,10 +1083,6 @@ __global__ __launch_bounds__(64 * kWaves, 2) void mono_fwd_wide_k(MonoArgs a) {
 // Layer 1 (rank-1 in x on top of c1), the last layer (a dot product per pair) and the quadrature stay fp32 VALU work.
 // GNF_TRUE_F32=1 keeps mono_fwd_wide_k.
 // =========================================================================================================================
-typedef unsigned u32x4w __attribute__((ext_vector_type(4)));
-typedef unsigned u32x2w __attribute__((ext_vector_type(2)));
-typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8w;
-
 template <int HT, int NH>
 struct WidePlanS {
   static constexpr int HP = 16 * HT, KT = (HP + 31) / 32, KP = 32 * KT;
@@ -991,32 +1094,6 @@ struct WidePlanS {
   static constexpr int o_planes = o_sred + 2 * kNP;         // floats: a multiple of 4 (16-byte aligned)
   static constexpr int total_bytes = 4 * o_planes + 3 * PLANE;
 };
-
-__device__ __forceinline__ unsigned cvt_pk_bf16w(float a, float b) {
-  unsigned r; asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r;
-}
-__device__ __forceinline__ void split3_pairw(float x0, float x1, unsigned& h, unsigned& m, unsigned& l) {
-  h = cvt_pk_bf16w(x0, x1);
-  const float r0 = x0 - __uint_as_float(h << 16), r1 = x1 - __uint_as_float(h & 0xffff0000u);   // exact
-  m = cvt_pk_bf16w(r0, r1);
-  const float q0 = r0 - __uint_as_float(m << 16), q1 = r1 - __uint_as_float(m & 0xffff0000u);   // exact
-  l = cvt_pk_bf16w(q0, q1);
-}
-__device__ __forceinline__ u32x4w ldfragu(rsrc_t rs, int voff, int soff) {
-  return __builtin_amdgcn_raw_buffer_load_b128(rs, voff, soff, 0);
-}
-__device__ __forceinline__ f32x4 mfma_bf(const u32x4w& a, const u32x4w& b, f32x4 c) {
-  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8w, a), __builtin_bit_cast(bf16x8w, b), c, 0, 0, 0);
-}
-
-// fragments (plane p, the wavefront's tiles, k tile t) of one matrix: full tile mi at soff + ((p HT + mi) KT + t) KB, the shared
-// tile at soffx + (p HT KT + t) KB
-template <int HT, int MF, int XT, int KT>
-__device__ __forceinline__ void fragp_load(rsrc_t rs, int voff, int soff, int soffx, int p, int t, u32x4w (&A)[MF + XT]) {
-#pragma unroll
-  for (int mi = 0; mi < MF; ++mi) A[mi] = ldfragu(rs, voff, soff + ((p * HT + mi) * KT + t) * 1024);
-  if constexpr (XT) A[MF] = ldfragu(rs, voff, soffx + (p * HT * KT + t) * 1024);
-}
 
 // acc[.][.][0] += hi hi, acc[.][.][1] += the five small terms, over all k tiles.  A: fragments of k tile 0 (requested by the
 // caller ahead of its serial section).  bsrc: LDS byte address of (plane 0, pair (slot 0, element j), position 8 q); slot 1 adds
@@ -1284,12 +1361,12 @@ int launch_wide_fwd(const MonoArgs& a, hipStream_t s) {
   return 0;
 }
 
-template <int HT, int NH>
+template <int HT, int NH, bool SPLIT>
 int launch_wide(const MonoArgs& a, unsigned grid, hipStream_t s) {
   const size_t lds = (size_t)WidePlan<HT, NH>::total * sizeof(float);
-  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mono_bwd_wide_k<HT, NH>),
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mono_bwd_wide_k<HT, NH, SPLIT>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  hipLaunchKernelGGL((mono_bwd_wide_k<HT, NH>), dim3(grid), dim3(64 * kWideWaves), lds, s, a);
+  hipLaunchKernelGGL((mono_bwd_wide_k<HT, NH, SPLIT>), dim3(grid), dim3(64 * kWideWaves), lds, s, a);
   GNF_LAUNCH_CHECK();
   return 0;
 }
@@ -1319,9 +1396,22 @@ extern "C" int gnf_debug_wide_stamps(unsigned long long* host, int enable) {
 }
 #endif
 
-int gnf_mono_bwd_wide_launch(const gnfmono::MonoArgs& a, unsigned grid, hipStream_t s) {
+extern "C" int gnf_gemm_split_enabled(void);
+
+int gnf_mono_bwd_wide_launch(const gnfmono::MonoArgs& a, unsigned grid, hipStream_t s, bool true_f32, const char** kernel) {
+  *kernel = "mono_bwd_wide_k<f32>";
+  if (!true_f32 && gnf_gemm_split_enabled()) {
+    *kernel = "mono_bwd_wide_k<split>";
 #define GNF_WIDE_CASE(HT_, NH_) \
-  if (a.L.HT == HT_ && a.L.NH == NH_) return launch_wide<HT_, NH_>(a, grid, s);
+  if (a.L.HT == HT_ && a.L.NH == NH_) return launch_wide<HT_, NH_, true>(a, grid, s);
+    // H = 97..112 stays fp32: its contraction pads 112 to 128 and the in-register splits cost what the matrix pipe saves
+    // (tools/bench_mono_split.py, cfg2: 1.74 ms against 1.59)
+    GNF_WIDE_CASE(10, 2) GNF_WIDE_CASE(10, 3)
+#undef GNF_WIDE_CASE
+    *kernel = "mono_bwd_wide_k<f32>";
+  }
+#define GNF_WIDE_CASE(HT_, NH_) \
+  if (a.L.HT == HT_ && a.L.NH == NH_) return launch_wide<HT_, NH_, false>(a, grid, s);
   GNF_WIDE_CASE(7, 2) GNF_WIDE_CASE(7, 3) GNF_WIDE_CASE(7, 4) GNF_WIDE_CASE(10, 2) GNF_WIDE_CASE(10, 3)
 #undef GNF_WIDE_CASE
   return GNF_ESHAPE;

@@ -303,6 +303,18 @@ int gnf_monotonic_bwd(const float* pack, const gnf_mono_net* net,
                       float* gx, float* gh, int64_t g_sb, int64_t g_sd, int64_t g_sc,
                       float* const* gW, float* const* gb,
                       void* ws, int64_t ws_bytes, int64_t B, int64_t d, gnf_stream_t stream);
+/* Wide integrand nets: the chain wavefronts of the backward (recompute and data gradient through the hidden->hidden layers)
+ * run on the bf16 matrix pipe with exact 3 x bf16 splits, like gnf_monotonic_fwd; the weight-gradient contraction stays
+ * fp32 MFMA.  GNF_TRUE_F32=1 / gnf_monotonic_bwd_f32 (same arguments): all fp32 MFMA.  gnf_monotonic_bwd_kernel(): the
+ * chain kernel the last backward call of this thread launched ("mono_bwd_wide_k<split>", "mono_bwd_wide_k<f32>", "mono_bwd_k"). */
+int gnf_monotonic_bwd_f32(const float* pack, const gnf_mono_net* net,
+                          const float* x, const float* h, int64_t h_sb, int64_t h_sd, int64_t h_sc,
+                          const float* cc_w, const float* cc_t, int S,
+                          const float* gz, const float* gjac,
+                          float* gx, float* gh, int64_t g_sb, int64_t g_sd, int64_t g_sc,
+                          float* const* gW, float* const* gb,
+                          void* ws, int64_t ws_bytes, int64_t B, int64_t d, gnf_stream_t stream);
+const char* gnf_monotonic_bwd_kernel(void);
 
 /* ---- MNISTCNN convolutional front: models/MLP.py:36-41 as the DAG embedding net --------
  * (ImageExperiments / NormalizingFlowFactories.py:83-86: size_img = [1,28,28]).

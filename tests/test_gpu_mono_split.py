@@ -1,5 +1,5 @@
-"""GPU: the Monotonic forward of WIDE integrand nets on the bf16 matrix pipe (mono_fwd_wide_split_k: exact 3 x bf16 operand
-splits, six cross terms, fp32 accumulate) against an fp64 evaluation of the reference's arithmetic
+"""GPU: the Monotonic forward and backward of WIDE integrand nets on the bf16 matrix pipe (mono_fwd_wide_split_k, the chain
+wavefronts of mono_bwd_wide_k<split>: exact 3 x bf16 operand splits, six cross terms, fp32 accumulate) against an fp64 evaluation of the reference's arithmetic
 (models/Normalizers/MonotonicNormalizer.py:21-66; the Clenshaw-Curtis rule as the kernels receive it) and against the fp32-MFMA
 kernel it replaces (gnf_monotonic_fwd_f32 = what GNF_TRUE_F32=1 runs).  Adoption criterion, as for the fc1 products
 (tests/test_gpu_split.py): the split kernel's error against fp64 is not larger than the fp32-MFMA kernel's."""
@@ -113,6 +113,97 @@ def test_split_forward_ragged_sizes_and_strided_h():
         assert torch.allclose(zs, zf, rtol=2e-6, atol=2e-6) and torch.allclose(js, jf, rtol=2e-6, atol=2e-6), (B, d)
 
 
+def _bwd(entry, params, x, h, S, gz, gjac):
+    from gnf_hip import abi, ops
+    from gnf_hip.abi import call, ptr, stream
+    net = ops._mono_net(params)
+    pack = ops._mono_pack(net, x)
+    w, t = ops.cc_rule(S, x.device)
+    B, d = x.shape
+    gx, gh = torch.empty_like(x), torch.empty_like(h)
+    gp = [torch.empty_like(p) for p in params]
+    nl = net.nl
+    gW = (ctypes.c_void_p * nl)(*[gp[2 * l].data_ptr() for l in range(nl)])
+    gb = (ctypes.c_void_p * nl)(*[gp[2 * l + 1].data_ptr() for l in range(nl)])
+    nbytes = abi.load().gnf_monotonic_bwd_ws_bytes(ctypes.byref(net), S, B, d)
+    ws = torch.empty(max(nbytes // 4, 1), device=x.device)
+    call(entry, ptr(pack), ctypes.byref(net), ptr(x), ptr(h), h.stride(0), h.stride(1), h.stride(2), ptr(w), ptr(t), S, ptr(gz), ptr(gjac),
+         ptr(gx), ptr(gh), gh.stride(0), gh.stride(1), gh.stride(2), gW, gb, ctypes.c_void_p(ws.data_ptr()), ws.numel() * 4, B, d, stream())
+    return [gx, gh] + gp, abi.load().gnf_monotonic_bwd_kernel().decode()
+
+
+def _bwd64(params, x, h, S, gz, gjac):
+    """fp64 autograd of the fp64 quadrature, with UMNN's Leibniz rule for x (dz/dx = f(x; h)): the z-path treats the nodes as
+    constants in x, the jac path differentiates f at x"""
+    P = [p.double().requires_grad_(True) for p in params]
+    hd = h.double().requires_grad_(True)
+    xd = x.double().requires_grad_(True)
+    from gnf_hip import ops
+    w, t = ops.cc_rule(S, x.device)
+    w, t = w.double(), t.double()
+    fS = torch.tensor(float(S), dtype=torch.float32, device=x.device)
+    xT = (fS * (x / fS)).double()
+
+    def f(tt):
+        a = torch.cat([tt.unsqueeze(-1), hd.unsqueeze(2).expand(-1, -1, tt.shape[2], -1)], -1)
+        for k in range(0, len(P), 2):
+            a = a @ P[k].t() + P[k + 1]
+            if k + 2 < len(P):
+                a = torch.relu(a)
+        a = a[..., 0]
+        return torch.where(a > 0, a, torch.expm1(torch.clamp(a, max=0.))) + 1.05
+    nodes = xT.unsqueeze(-1) * (t + 1.) / 2.
+    z = (f(nodes) * w).sum(-1) * xT / 2. + hd[..., 0]
+    jac = f(xd.unsqueeze(-1))[..., 0]
+    obj = (z * gz.double()).sum() + (jac * gjac.double()).sum()
+    g = torch.autograd.grad(obj, [xd, hd] + P)
+    gx = g[0] + gz.double() * jac.detach()             # Leibniz: + gz f(x; h)
+    return [gx, g[1]] + list(g[2:])
+
+
+BCASES = [([100, 100, 100], 30, 6, 700, 20), ([150, 150, 150], 30, 9, 300, 20), ([160, 160], 8, 5, 333, 9), ([112] * 4, 30, 3, 257, 20),
+          ([97, 105, 112], 17, 4, 129, 15), ([145, 160, 150], 30, 63, 50, 25)]
+
+
+@pytest.mark.parametrize("hidden,c,d,B,S", BCASES)
+def test_split_backward_vs_fp64_and_fp32_mfma(hidden, c, d, B, S):
+    from gnf_hip import abi
+    if not abi.load().gnf_gemm_split_enabled():
+        pytest.skip("GNF_TRUE_F32=1")
+    params = _params(hidden, c, seed=sum(hidden) + S + 1, scale=1.3)
+    g = torch.Generator().manual_seed(B + 7)
+    x = (torch.randn(B, d, generator=g) * 2.).to(DEV)
+    h = torch.randn(B, d, c, generator=g).to(DEV)
+    gz, gjac = torch.randn(B, d, generator=g).to(DEV), torch.randn(B, d, generator=g).to(DEV)
+    gs, ks = _bwd("gnf_monotonic_bwd", params, x, h, S, gz, gjac)
+    gf, kf = _bwd("gnf_monotonic_bwd_f32", params, x, h, S, gz, gjac)
+    # (the backward's split form is adopted for H = 145..160 only: at H <= 112 it measured slower than the fp32 chain)
+    assert ks == ("mono_bwd_wide_k<split>" if max(hidden) > 112 else "mono_bwd_wide_k<f32>") and kf == "mono_bwd_wide_k<f32>", (ks, kf)
+    g64 = _bwd64(params, x, h, S, gz, gjac)
+    names = ["gx", "gh"] + ["gW%d" % (i // 2) if i % 2 == 0 else "gb%d" % (i // 2) for i in range(len(params))]
+    worst = []
+    for nm, a, b, r in zip(names, gs, gf, g64):
+        scale = float(r.abs().max()) + 1e-30
+        es, ef = float((a.double() - r).abs().max()) / scale, float((b.double() - r).abs().max()) / scale
+        rs = float(((a.double() - r).pow(2).mean() / (r.pow(2).mean() + 1e-60)).sqrt())
+        rf = float(((b.double() - r).pow(2).mean() / (r.pow(2).mean() + 1e-60)).sqrt())
+        worst.append((nm, es, ef, rs, rf))
+        # The backward's chain products use ONE accumulator class (registers): 30 roundings per output instead of the fp32
+        # MFMA's 40 -- the same error level, not a better one.  Per tensor: within 2x of the fp32 kernel's error + one epsilon;
+        # over the tensors of a case: not worse on (geometric) average.  (Errors of 1e-4 against fp64 are common to both
+        # kernels: ReLU gates of pre-activations within roundoff of zero.)
+        assert rs <= 2. * rf + 1.2e-7, (nm, es, ef, rs, rf)
+        assert es <= 2. * ef + 2.4e-7, (nm, es, ef, rs, rf)
+        assert es < 5e-3, (nm, es)
+    ratio = float(np.exp(np.mean([np.log((w_[3] + 1e-9) / (w_[4] + 1e-9)) for w_ in worst])))
+    assert ratio <= 1.15, (ratio, worst)
+    print("\n[mono split bwd %s S=%d] geometric mean of rms(split) / rms(fp32-MFMA) over the tensors: %.2f; max rel. error split | fp32-MFMA (rms split | fp32): " % (hidden, S, ratio)
+          + ", ".join("%s %.1e|%.1e (%.1e|%.1e)" % w_ for w_ in worst))
+    gs2, _ = _bwd("gnf_monotonic_bwd", params, x, h, S, gz, gjac)
+    for a, b in zip(gs, gs2):
+        assert torch.equal(a, b)
+
+
 def test_true_f32_switch_selects_the_fp32_kernel():
     import subprocess
     import sys
@@ -120,11 +211,13 @@ def test_true_f32_switch_selects_the_fp32_kernel():
             "from tests.test_gpu_mono_split import _params, _fwd\n"
             "p = _params([150, 150, 150], 30, 1)\n"
             "x = torch.randn(40, 7, device='cuda:0'); h = torch.randn(40, 7, 30, device='cuda:0')\n"
-            "print(_fwd('gnf_monotonic_fwd', p, x, h, 20)[2])\n") % (ROOT, ROOT + "/graphical-normalizing-flows_amd")
+            "print(_fwd('gnf_monotonic_fwd', p, x, h, 20)[2])\n"
+            "from tests.test_gpu_mono_split import _bwd\n"
+            "print(_bwd('gnf_monotonic_bwd', p, x, h, 20, torch.ones_like(x), torch.ones_like(x))[1])\n") % (ROOT, ROOT + "/graphical-normalizing-flows_amd")
     out = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, GNF_TRUE_F32="1"), capture_output=True, text=True,
                          timeout=300)
     assert out.returncode == 0, out.stderr[-2000:]
-    assert out.stdout.strip().splitlines()[-1] == "mono_fwd_wide_k", out.stdout
+    assert out.stdout.strip().splitlines()[-2:] == ["mono_fwd_wide_k", "mono_bwd_wide_k<f32>"], out.stdout
 
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

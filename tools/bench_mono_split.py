@@ -44,6 +44,31 @@ def main():
                     run()
                 torch.cuda.synchronize()
                 res.setdefault(entry, []).append((time.perf_counter() - t0) / n * 1e3)
+        if S <= 30:                                                       # training shapes: the backward too
+            gz, gjac = torch.randn_like(x), torch.randn_like(x)
+            gx, gh = torch.empty_like(x), torch.empty_like(h)
+            gp = [torch.empty_like(p) for p in ps]
+            nl = net.nl
+            gW = (ctypes.c_void_p * nl)(*[gp[2 * l].data_ptr() for l in range(nl)])
+            gb = (ctypes.c_void_p * nl)(*[gp[2 * l + 1].data_ptr() for l in range(nl)])
+            nbytes = abi.load().gnf_monotonic_bwd_ws_bytes(ctypes.byref(net), S, B, d)
+            ws = torch.empty(max(nbytes // 4, 1), device=DEV)
+            for rep in range(3):
+                for entry in ("gnf_monotonic_bwd", "gnf_monotonic_bwd_f32"):
+                    def runb():
+                        call(entry, ptr(pack), ctypes.byref(net), ptr(x), ptr(h), h.stride(0), h.stride(1), h.stride(2), ptr(w), ptr(t), S,
+                             ptr(gz), ptr(gjac), ptr(gx), ptr(gh), gh.stride(0), gh.stride(1), gh.stride(2), gW, gb,
+                             ctypes.c_void_p(ws.data_ptr()), ws.numel() * 4, B, d, stream())
+                    runb(); torch.cuda.synchronize()
+                    n = 3 if B * d > 1e6 else 20
+                    t0 = time.perf_counter()
+                    for _ in range(n):
+                        runb()
+                    torch.cuda.synchronize()
+                    res.setdefault(entry, []).append((time.perf_counter() - t0) / n * 1e3)
+            sb, fb = min(res["gnf_monotonic_bwd"]), min(res["gnf_monotonic_bwd_f32"])
+            print("%s backward: split chain %.3f ms (%s)  fp32-MFMA %.3f ms (%s)  x%.2f" % (
+                tag, sb, " ".join("%.3f" % v for v in res["gnf_monotonic_bwd"]), fb, " ".join("%.3f" % v for v in res["gnf_monotonic_bwd_f32"]), fb / sb))
         macs = sum(a * b for a, b in zip(hidden[:-1], hidden[1:]))        # hidden->hidden MACs per evaluation
         ev = B * d * (S + 2)
         s_, f_ = min(res["gnf_monotonic_fwd"]), min(res["gnf_monotonic_fwd_f32"])
