@@ -214,6 +214,11 @@ __device__ __forceinline__ void layer_pass_split32(rsrc_t rs, int voff, int soff
       for (int sl = 0; sl < 2; ++sl) acc[mi][sl] = mfma_bf(A[pa][mi], B[pb][sl], acc[mi][sl]);
     if constexpr (XT) acc[MF][0] = mfma_bf(A[pa][MF], B[pb][2], acc[MF][0]);
   };
+  // Only the lo plane of k tile 0 was requested ahead of the serial section (A[2]; 20 registers live across it instead of
+  // 60: with all three the chain role spilled 100 registers and wrote 12 GB of scratch per cfg5 launch); mid and hi follow
+  // here, behind them the first B fragments' reads and splits
+  fragp_load<HT, MF, XT, KT>(rs, voff, soff, soffx, 1, 0, A[1]);
+  fragp_load<HT, MF, XT, KT>(rs, voff, soff, soffx, 0, 0, A[0]);
   loadB(0);
 #pragma unroll
   for (int t = 0; t < KT; ++t) {
@@ -616,10 +621,8 @@ __global__ __launch_bounds__(64 * kWideWaves, 1) void mono_bwd_wide_k(MonoArgs a
     constexpr int KT = (HP + 31) / 32;
     // request the first fragments of a pass over matrix `om` (fp32: o_Wf / o_WTf, split: o_Wp / o_WTp of the same layer)
     auto prefetch = [&](int of32, int osp) {
-      if constexpr (SPLIT) {
-#pragma unroll
-        for (int pl = 0; pl < 3; ++pl)
-          fragp_load<HT, MF, XT, KT>(rs, 16 * lane, opaque_s(4 * (osp + m0 * KT * 256)), opaque_s(4 * (osp + MF * KT * 256)), pl, 0, Asp[pl]);
+      if constexpr (SPLIT) {                        // (the lo plane only: see layer_pass_split32)
+        fragp_load<HT, MF, XT, KT>(rs, 16 * lane, opaque_s(4 * (osp + m0 * KT * 256)), opaque_s(4 * (osp + MF * KT * 256)), 2, 0, Asp[2]);
       } else {
         frag_prefetch<HT, MF, XT>(rs, 16 * lane, opaque_s(4 * (of32 + m0 * HT * 256)), opaque_s(4 * (of32 + MF * HT * 256)), Apre);
       }
@@ -1168,6 +1171,13 @@ __global__ __launch_bounds__(64 * kWaves, 2) void mono_fwd_wide_split_k(MonoArgs
   const int m0 = mh * (MF + XT);
   const rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.pack), 0, L.pack_floats * 4, 0x00020000);
   const int prow = (16 * nh + j) * PB, xrow = prow + mh * kGE * PB;       // bytes
+  // 16-byte slots of a row are swapped in pairs for rows 4..7, 12..15 (slot ^= (row >> 2) & 1): the plane stores are
+  // ds_write_b64 of 16 rows at one column -- 4-way bank conflicts at any 16-byte-aligned pitch, 2-way (their floor: the 16
+  // lanes of a store group share one 8-byte half) with the swap; the fragment reads stay conflict-free.  Both offsets are
+  // lane constants.
+  const int sws = (j >> 2) & 1;
+  const int rd16 = 16 * (q ^ sws);                                        // read: slot 4 t + q
+  const int wr8 = 16 * ((q >> 1) ^ sws) + 8 * (q & 1);                    // write: slot 2 tile + (q >> 1), half q & 1
   const int ucol_c = 16 * m0 + 4 * q, xcol_c = 16 * MF + 4 * q;
   auto col = [&](int mi, int uc, int xc) { return mi < MF ? uc + 16 * mi : xc; };
   const WideSched ws = wide_sched(a.n, gridDim.x);
@@ -1244,7 +1254,7 @@ __global__ __launch_bounds__(64 * kWaves, 2) void mono_fwd_wide_split_k(MonoArgs
           unsigned h0_, m0_, l0_, h1_, m1_, l1_;
           split3_pairw(val[mi][sl][0], val[mi][sl][1], h0_, m0_, l0_);
           split3_pairw(val[mi][sl][2], val[mi][sl][3], h1_, m1_, l1_);
-          unsigned char* dst = planes + (mi < MF ? prow + sl * kGE * PB : xrow) + 2 * col(mi, ucol, xcol);
+          unsigned char* dst = planes + (mi < MF ? prow + sl * kGE * PB : xrow) + 32 * (mi < MF ? m0 + mi : MF) + opaque_v(wr8);
           *reinterpret_cast<u32x2w*>(dst) = u32x2w{h0_, h1_};
           *reinterpret_cast<u32x2w*>(dst + PLANE) = u32x2w{m0_, m1_};
           *reinterpret_cast<u32x2w*>(dst + 2 * PLANE) = u32x2w{l0_, l1_};
@@ -1273,7 +1283,7 @@ __global__ __launch_bounds__(64 * kWaves, 2) void mono_fwd_wide_split_k(MonoArgs
           acc[mi][1][0] = acc[mi][0][0];
           acc[mi][0][1] = acc[mi][1][1] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
-        layer_pass_split<HT, MF, XT, KT, PB, PLANE>(rs, 16 * lane, wfrag(l), wfragx(l), planes + prow + 16 * q, planes + xrow + 16 * q,
+        layer_pass_split<HT, MF, XT, KT, PB, PLANE>(rs, 16 * lane, wfrag(l), wfragx(l), planes + prow + rd16, planes + xrow + rd16,
                                                     Apre, acc);
         prefetch(l < NH - 1 ? l + 1 : 1);
 #pragma unroll

@@ -205,15 +205,34 @@ def main():
         x, h = torch.randn(B, d, device=DEV), torch.randn(B, d, c, device=DEV)
         dims = [1 + c] + hid + [1]
         macs = sum(a * b for a, b in zip(dims[:-1], dims[1:]))
+        split_fwd = hid[0] > 96 and lib0.gnf_gemm_split_enabled()
+        split_bwd = hid[0] > 112 and lib0.gnf_gemm_split_enabled()
+
+        def mono_row(name, ms, passes, split):
+            """fp32 kernels: algorithmic flop against the fp32 MFMA peak.  Split kernels (round 6): the hidden->hidden products run
+            as six v_mfma_f32_16x16x32_bf16 terms on padded tiles -- priced at what they execute against the dense bf16 peak, the
+            fp32-equivalent algorithmic rate beside it (it may exceed the fp32 peak: that is the point of the kernels)"""
+            flops = passes * macs * (S + 2) * B * d
+            if not split:
+                return mfma(name, [B, d, hid[0]], ms, flops)
+            HP = (hid[0] + 15) // 16 * 16
+            KP = (HP + 31) // 32 * 32
+            chain_passes = passes if passes == 2. else 4.         # backward: recompute + data gradient on bf16, weight gradient fp32
+            exe = 6. * chain_passes * (len(hid) - 1) * HP * KP * (S + 2) * B * d
+            rows.append({"kernel": name, "shape": [B, d, hid[0]], "ms": round(ms, 4),
+                         "bound": "mfma (bf16, 6 terms per fp32 product" + (")" if passes == 2. else "; weight gradient on fp32 MFMA)"),
+                         "achieved_TFLOPs_bf16": round(exe / ms / 1e9, 1), "frac_of_2500TF_bf16": round(exe / ms / 1e9 / BF16_PEAK, 3),
+                         "fp32_equivalent_TFLOPs": round(flops / ms / 1e9, 1)})
+            assert 0. < rows[-1]["frac_of_2500TF_bf16"] <= 1., rows[-1]
         with torch.no_grad():
-            mfma("monotonic_fwd " + tag, [B, d, hid[0]], time_entry("gnf_monotonic_fwd", lambda: norm(x, h), n=10), 2. * macs * (S + 2) * B * d)
+            mono_row("monotonic_fwd " + tag, time_entry("gnf_monotonic_fwd", lambda: norm(x, h), n=10), 2., split_fwd)
         xg, hg = x.clone().requires_grad_(True), h.clone().requires_grad_(True)
         z, jac = norm(xg, hg)
         gz = torch.randn_like(z)
         ps = list(norm.parameters())
-        mfma("monotonic_bwd " + tag, [B, d, hid[0]],
-             time_entry("gnf_monotonic_bwd", lambda: torch.autograd.grad((z, jac), [xg, hg] + ps, (gz, gz), retain_graph=True), n=5, warm=1),
-             4. * macs * (S + 2) * B * d)
+        mono_row("monotonic_bwd " + tag,
+                 time_entry("gnf_monotonic_bwd", lambda: torch.autograd.grad((z, jac), [xg, hg] + ps, (gz, gz), retain_graph=True), n=5, warm=1),
+                 4., split_bwd)
     # ---- MNISTCNN conv front at cfg4 (78 400 images)
     n = 78400
     e = torch.randn(n, 784, device=DEV).requires_grad_(True)
