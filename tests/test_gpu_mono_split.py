@@ -204,6 +204,29 @@ def test_split_backward_vs_fp64_and_fp32_mfma(hidden, c, d, B, S):
         assert torch.equal(a, b)
 
 
+def test_split_backward_ragged_sizes():
+    """element counts around the group / half-group boundaries of the persistent schedule (h contiguous: the backward entry
+    asks for a collapsible element stride, ops.MonotonicFn.backward makes the copy)"""
+    from gnf_hip import abi
+    if not abi.load().gnf_gemm_split_enabled():
+        pytest.skip("GNF_TRUE_F32=1")
+    params = _params([150, 150, 150], 30, seed=12)
+    for B, d in [(1, 1), (1, 31), (3, 11), (5, 13), (8193, 1), (513, 33)]:
+        g = torch.Generator().manual_seed(B + d)
+        x = (torch.randn(B, d, generator=g) * 2.).to(DEV)
+        h = torch.randn(B, d, 30, generator=g).to(DEV)
+        gz, gjac = torch.randn(B, d, generator=g).to(DEV), torch.randn(B, d, generator=g).to(DEV)
+        gs, ks = _bwd("gnf_monotonic_bwd", params, x, h, 20, gz, gjac)
+        gf, _ = _bwd("gnf_monotonic_bwd_f32", params, x, h, 20, gz, gjac)
+        assert ks == "mono_bwd_wide_k<split>"
+        # the two kernels agree to fp32 roundoff in the norm; single entries may differ by more where a ReLU gate of a
+        # pre-activation within roundoff of zero falls on different sides in the two arithmetic orders
+        for nm, (a, b) in enumerate(zip(gs, gf)):
+            num, den = float((a - b).double().pow(2).sum().sqrt()), float(b.double().pow(2).sum().sqrt())
+            mx = float((a - b).abs().max()) / (float(b.abs().max()) + 1e-30)
+            assert num <= 1e-4 * den + 1e-7 and mx <= 2e-3, (B, d, nm, num / (den + 1e-30), mx)
+
+
 def test_true_f32_switch_selects_the_fp32_kernel():
     import subprocess
     import sys
