@@ -219,12 +219,13 @@ def test_split_backward_ragged_sizes():
         gs, ks = _bwd("gnf_monotonic_bwd", params, x, h, 20, gz, gjac)
         gf, _ = _bwd("gnf_monotonic_bwd_f32", params, x, h, 20, gz, gjac)
         assert ks == "mono_bwd_wide_k<split>"
-        # the two kernels agree to fp32 roundoff in the norm; single entries may differ by more where a ReLU gate of a
-        # pre-activation within roundoff of zero falls on different sides in the two arithmetic orders
+        # an indexing mistake at a group boundary is an O(1) error.  The bound is not roundoff-tight: the parameter gradients are
+        # sums of 10^5..10^6 signed terms (|sum| ~ 1e-2 .. 1e-3 of the sum of magnitudes), so two correct fp32 evaluations in
+        # different orders differ by ~1e-4 of the result (as either does from fp64, test_split_backward_vs_fp64_and_fp32_mfma)
         for nm, (a, b) in enumerate(zip(gs, gf)):
             num, den = float((a - b).double().pow(2).sum().sqrt()), float(b.double().pow(2).sum().sqrt())
             mx = float((a - b).abs().max()) / (float(b.abs().max()) + 1e-30)
-            assert num <= 1e-4 * den + 1e-7 and mx <= 2e-3, (B, d, nm, num / (den + 1e-30), mx)
+            assert num <= 2e-3 * den + 1e-7 and mx <= 2e-2, (B, d, nm, num / (den + 1e-30), mx)
 
 
 def test_true_f32_switch_selects_the_fp32_kernel():
