@@ -34,6 +34,7 @@ INT_NET = [50, 50, 50]
 COND = 30
 S_NODES = 20
 PEAK_F32_TFLOPS = 157.3          # MI355X fp32 MFMA/vector peak (MI355X_MICROARCH.md)
+PEAK_BF16_TFLOPS = 2500.         # dense bf16 MFMA peak (same guide); the split-bf16 Monotonic forward is priced against it
 NOMINAL_GHZ = 2.4                # the clock behind that peak: 256 CUs x 4 SIMDs x 64 flop/clk x 2.4 GHz
 PMC_INPUTS = "r06_bench_inputs.json"
 DOMINANT_OP = "gnf_mnistcnn_conv_bwd"       # the entry point of the dominant kernel (cnn_bwd_wino_k): timed live in the region
@@ -435,12 +436,33 @@ def main():
         WINO = 4. / 9.
         executed_fallback = {"gnf_mnistcnn_conv_fwd": 2. * (CONV1 + CONV2 * WINO) * n_elem,
                              "gnf_mnistcnn_conv_bwd": 2. * (CONV2 * WINO * (1. + 169. / 144.) + 2. * CONV1) * n_elem}
+        # round 6: the Monotonic forward of the peeled [50]^3 net runs its 48 x 48 main blocks as six bf16 MFMA terms per product
+        # (mono_fwd_x_k<split>): priced at what it EXECUTES against the dense bf16 peak, the algorithmic fp32 rate beside it
+        lib = abi.load()
+        mono_fwd_split = bool(lib.gnf_gemm_split_enabled()) and lib.gnf_monotonic_fwd_kernel().decode() == "mono_fwd_x_k<split>"
+        # per (element, node) and hidden->hidden layer: 3 out tiles x 6 terms x 2 instructions (the 32- and the 16-wide part of the
+        # 48-unit contraction, both on v_mfma_f32_16x16x32_bf16: 16 384 flop) per 16 elements
+        mono_split_exec = (len(INT_NET) - 1) * 36 * 16384. / 16. * (S_NODES + 2) * n_elem
         kern = {}
         for k, (label, fl) in work.items():
             if k not in prof:
                 continue
             sec = prof[k] * 1e-3
             entry = {"kernel": label, "ms": round(prof[k], 4), "unit": "TFLOP/s"}
+            if k == "gnf_monotonic_fwd" and mono_fwd_split:
+                entry["kernel"] = ("mono_fwd_x_k<3,2,split> (Clenshaw-Curtis quadrature; the 48 x 48 main blocks as exact 3 x bf16 splits on "
+                                   "v_mfma_f32_16x16x32_bf16, units 48-49 peeled onto the VALU)")
+                if k in pmc and pmc[k].get("mfma_flop") == 16384:
+                    ex, entry["frac_basis"] = pmc[k]["mfma_per_image"] * 16384. * n_elem, \
+                        "executed: bf16 MFMA instructions per element (%s) x 16384 flop, against the dense bf16 peak" % PMC_INPUTS
+                else:
+                    ex, entry["frac_basis"] = mono_split_exec, "executed: six bf16 terms per product of the padded main blocks (no counter file), against the dense bf16 peak"
+                entry["bound"], entry["peak"] = "mfma (bf16, 6 terms per fp32 product)", PEAK_BF16_TFLOPS
+                entry["achieved"] = round(ex / sec / 1e12, 2)
+                entry["fp32_equivalent_TFLOPs_algorithmic"] = round(fl / sec / 1e12, 2)
+                entry["frac"] = round(entry["achieved"] / PEAK_BF16_TFLOPS, 4)
+                kern[k] = entry
+                continue
             if k in executed_fallback:
                 if k in pmc:
                     ex, entry["frac_basis"] = pmc[k]["mfma_per_image"] * 2048. * n_elem, \
@@ -513,6 +535,25 @@ def main():
             (cycles per launch from the counter pass / live launch time)."""
             p = pmc.get(k)
             if not p:
+                return
+            if entry.get("peak") == PEAK_BF16_TFLOPS:             # split-bf16 kernel: bf16 issue slots; counters of the fp32 kernel do not apply
+                if p.get("mfma_flop") != 16384:
+                    return
+                mi = p["mfma_per_image"] * 16384. * n_elem / (prof[k] * 1e-3) / 1e12 / PEAK_BF16_TFLOPS
+                entry["mfma_issue_frac"] = round(mi, 4)
+                entry["valu_per_mfma"] = round(p["valu_per_mfma"], 3)
+                # next to bf16 MFMAs about two VALU instructions per MFMA issue for free and the rest cost ~3 cycles each
+                # (tools/mfma_k16_rate.hip, profiles/r06_mfma_k16_rate.txt): 16.4 / (16.4 + 3 max(0, V - 2))
+                entry["issue_frac_ceiling_shared_alu"] = round(16.4 / (16.4 + 3. * max(0., p["valu_per_mfma"] - 2.)), 3)
+                if p.get("cycles_per_launch"):
+                    ghz = p["cycles_per_launch"] / (prof[k] * 1e6)
+                    entry["effective_clock_GHz"] = round(ghz, 3)
+                    entry["effective_clock_GHz_in_pmc_pass"] = round(p["effective_clock_GHz_in_pmc_pass"], 3)
+                    entry["frac_of_peak_at_clock"] = round(mi * NOMINAL_GHZ / ghz, 4)
+                if p.get("mfma_pipe_busy_frac_of_simd_cycles") is not None:
+                    entry["mfma_pipe_busy_frac_of_simd_cycles"] = p["mfma_pipe_busy_frac_of_simd_cycles"]
+                return
+            if p.get("mfma_flop", 2048) != 2048:                  # counters of the split kernel, fp32 kernel running (GNF_TRUE_F32=1)
                 return
             mi = p["mfma_per_image"] * 2048. * n_elem / (prof[k] * 1e-3) / 1e12 / PEAK_F32_TFLOPS
             entry["mfma_issue_frac"] = round(mi, 4)

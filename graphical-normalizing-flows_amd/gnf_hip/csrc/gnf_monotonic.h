@@ -9,6 +9,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int kWaves = 4;          // wavefronts per workgroup
 constexpr int kMaxNH = GNF_MONO_MAX_LAYERS - 1;
+constexpr int kNarrowQ = 3 * 3 * (256 + 128);   // words of one bf16-split 48 x 48 block (MonoLayout::o_Wq)
 
 // ---------------------------------------------------------------------------------------
 // Padded weight image ("pack"): every matrix row-major with leading dimension LD = pad+4
@@ -35,6 +36,11 @@ struct MonoLayout {
   // offsets in 4-byte words like everything else in the pack; 3 * HT * KT32 * 256 words per layer.
   //   WTp[l][plane][mt][t][lane] = plane of W_l[32 t + 8 q .. + 7][16 mt + j]  (the data gradient's transposed products)
   int o_Wp[kMaxNH], o_WTp[kMaxNH], KT32;
+  // ... and for the peeled narrow nets (HT = 4, H = 49..51: the 48 x 48 main block on the MFMA): per matrix 3 planes x 3 out
+  // tiles x [a K = 32 fragment (1 KB: lane (q, j) = W[16 mt + j][4 q + i] for i < 4, W[16 mt + j][16 + 4 q + i - 4] for i >= 4 --
+  // the order in which a lane holds the activations of tiles 0 and 1 in its MFMA C/D registers) + a K = 16 fragment (512 B:
+  // W[16 mt + j][32 + 4 q + i])] = kNarrowQ words.  Wq: forward; WTq: the transposed products of the data gradient.
+  int o_Wq[kMaxNH], o_WTq[kMaxNH];
   int pack_floats;                    // size of the whole pack
   // K order of the last unit tile (HT >= 7 only, round 5).  An MFMA k-step r of k-tile t contracts the padded positions
   // 16 t + 4 q + r, q = 0..3: with the units of a width-H layer at positions 0 .. H-1 the H mod 16 units of the last tile are
@@ -98,6 +104,11 @@ __host__ __device__ inline MonoLayout make_layout(int HT, int NH, int c) {
     for (int l = 1; l < NH; ++l) { L.o_Wp[l] = o; o += 3 * HT * L.KT32 * 256; }
     for (int l = 1; l < NH; ++l) { L.o_WTp[l] = o; o += 3 * HT * L.KT32 * 256; }
   }
+  for (int l = 1; l < NH; ++l) { L.o_Wq[l] = 0; L.o_WTq[l] = 0; }
+  if (HT == 4) {
+    for (int l = 1; l < NH; ++l) { L.o_Wq[l] = o; o += kNarrowQ; }
+    for (int l = 1; l < NH; ++l) { L.o_WTq[l] = o; o += kNarrowQ; }
+  }
   L.pack_floats = o;
   return L;
 }
@@ -121,6 +132,7 @@ struct MonoArgs {
   float* wpart;                         // [workgroups * kWaves][(NH-1) * HP * HP] accumulator rows of that variant
                                         // (indw = 3, or wcomb: one row per workgroup)
   int wcomb;                            // mono_bwd_pair_x_k: the wavefronts' accumulator rows are added in LDS at the end
+  int f32only;                          // host side: keep the fp32-MFMA kernels (gnf_monotonic_fwd_f32 / _bwd_f32)
 };
 
 __device__ __forceinline__ void store_inverse(const MonoArgs& a, int64_t e, float v) {

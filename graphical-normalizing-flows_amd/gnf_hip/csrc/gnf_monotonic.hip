@@ -32,6 +32,9 @@
 #include "gnf_monotonic.h"
 #include <cstdlib>
 
+extern "C" int gnf_gemm_split_enabled(void);
+static thread_local const char* g_fwd_kernel = "";     // kernel family of this thread's last forward launch (gnf_monotonic_fwd_kernel)
+
 namespace {
 
 using namespace gnfmono;
@@ -48,6 +51,29 @@ __global__ void mono_pack_k(PackArgs a, float* __restrict__ pack) {
   auto unit = [&](int p, int l) { return mono_unit_at(p, N.dims[l], L.perm); };   // unit of hidden layer l at padded position p
   for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < L.pack_floats; idx += gridDim.x * blockDim.x) {
     float v = 0.f;
+    if (L.NH > 1 && L.o_Wq[1] && idx >= L.o_Wq[1]) {   // bf16 split planes of a peeled narrow net's 48 x 48 main blocks
+      const bool tr = idx >= L.o_WTq[1];
+      const int l = 1 + (idx - (tr ? L.o_WTq[1] : L.o_Wq[1])) / kNarrowQ, k = (idx - L.o_Wq[1]) % kNarrowQ;
+      const int plane = k / (3 * 384), kk = k % (3 * 384), mt = kk / 384, w = kk % 384;
+      int lane, c0;                                    // the word holds contraction positions c0, c0 + 1
+      if (w < 256) { lane = w >> 2; const int i = 2 * (w & 3); c0 = (i < 4 ? 0 : 16) + 4 * (lane >> 4) + (i & 3); }
+      else { lane = (w - 256) >> 1; c0 = 32 + 4 * (lane >> 4) + 2 * ((w - 256) & 1); }
+      const int row = 16 * mt + (lane & 15);
+      float x[2] = {0.f, 0.f};
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int r_ = unit(row, tr ? l : l + 1), c_ = unit(c0 + i, tr ? l + 1 : l);
+        if (r_ >= 0 && c_ >= 0) x[i] = tr ? N.W[l][(int64_t)c_ * N.dims[l] + r_] : N.W[l][(int64_t)r_ * N.dims[l] + c_];
+      }
+      unsigned word = 0;
+      for (int pl = 0; pl <= plane; ++pl) {
+        asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(word) : "v"(x[0]), "v"(x[1]));
+        x[0] -= __uint_as_float(word << 16);
+        x[1] -= __uint_as_float(word & 0xffff0000u);
+      }
+      reinterpret_cast<unsigned*>(pack)[idx] = word;
+      continue;
+    }
     if (L.NH > 1 && L.o_Wp[1] && idx >= L.o_Wp[1]) {   // bf16 split planes of the hidden->hidden matrices (see MonoLayout)
       const int per = 3 * L.HT * L.KT32 * 256;
       const bool tr = idx >= L.o_WTp[1];               // transposed planes behind the forward ones
@@ -320,6 +346,194 @@ __device__ __forceinline__ void eval2x(const float* wp, const MonoLayout& L, con
   fb = elu_plus(qsum(s1) + t1);
 }
 
+// The same evaluation with the 48 x 48 main block of every hidden->hidden layer on the bf16 matrix pipe (round 6; the method
+// of gnf_gemm_split.hip / mono_fwd_wide_split_k): the lane splits the 12 activations it holds in its C/D registers exactly
+// into three bf16 numbers each (x = hi + mid + lo) -- tiles 0 and 1 side by side are the 8-value B operand of a K = 32 MFMA,
+// tile 2 that of a K = 16 MFMA, no LDS round trip --, the weights come pre-split from the pack (MonoLayout::o_Wq, LDS
+// resident: one conflict-free lane-linear read per fragment), a product is its six leading cross terms, hi hi in one fp32
+// accumulator and the five small terms in another.  72 MFMAs of 17 cycles per layer and node pair instead of 72 of 32.5, and
+// VALU work next to bf16 MFMAs is not serialised the way it is next to fp32 MFMAs (profiles/r06_mfma_k16_rate.txt).  The
+// peeled units, layer 1, the last layer and the quadrature are the fp32 code of eval2x.
+typedef unsigned u32x4n __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2n __attribute__((ext_vector_type(2)));
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8n;
+typedef __attribute__((ext_vector_type(4))) short s16x4n;
+typedef float f32x2n __attribute__((ext_vector_type(2)));
+// (v_cvt_pk_bf16_f32 through the conversion builtin, NOT inline asm: the results feed MFMAs a few instructions later, and the
+// compiler's hazard recognizer inserts the VALU-write -> MFMA-read wait states only for instructions it can see.  With the asm
+// form this kernel read stale operands: errors of 1e-2 .. 1 that moved with every rebuild)
+typedef __bf16 bf16x2n __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned cvt_pk_bf16n(float a, float b) {
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2n{a, b}, bf16x2n));
+}
+__device__ __forceinline__ void split3_pairn(float x0, float x1, unsigned& h, unsigned& m, unsigned& l) {
+  h = cvt_pk_bf16n(x0, x1);
+  const f32x2n r = f32x2n{x0, x1} - f32x2n{__uint_as_float(h << 16), __uint_as_float(h & 0xffff0000u)};   // exact
+  m = cvt_pk_bf16n(r[0], r[1]);
+  const f32x2n q = r - f32x2n{__uint_as_float(m << 16), __uint_as_float(m & 0xffff0000u)};                // exact
+  l = cvt_pk_bf16n(q[0], q[1]);
+}
+// the lane's 12 values of one node (tiles 0..2 of a 48-unit layer) -> B operands: K = 32 (tiles 0, 1) and K = 16 (tile 2), 3 planes
+__device__ __forceinline__ void split_acts48(const f32x4 (&a)[3], u32x4n (&b32)[3], u32x2n (&b16)[3]) {
+  unsigned h[6], m[6], l[6];
+#pragma unroll
+  for (int t = 0; t < 3; ++t) {
+    split3_pairn(a[t][0], a[t][1], h[2 * t], m[2 * t], l[2 * t]);
+    split3_pairn(a[t][2], a[t][3], h[2 * t + 1], m[2 * t + 1], l[2 * t + 1]);
+  }
+  b32[0] = u32x4n{h[0], h[1], h[2], h[3]}; b16[0] = u32x2n{h[4], h[5]};
+  b32[1] = u32x4n{m[0], m[1], m[2], m[3]}; b16[1] = u32x2n{m[4], m[5]};
+  b32[2] = u32x4n{l[0], l[1], l[2], l[3]}; b16[2] = u32x2n{l[4], l[5]};
+}
+__device__ __forceinline__ f32x4 mfma_bf32(const u32x4n& a, const u32x4n& b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8n, a), __builtin_bit_cast(bf16x8n, b), c, 0, 0, 0);
+}
+// The 16-wide remainder of the contraction (tile 2) ALSO goes through the K = 32 instruction, upper half zero.  The legacy
+// v_mfma_f32_16x16x16_bf16 takes the same 17 cycles on gfx950 (profiles/r06_mfma_k16_rate.txt), so nothing is lost -- and
+// chained on one accumulator with the K = 32 form it produced wrong sums in this kernel (build-dependent: right in every
+// instrumented build, wrong in the optimised one; alone it is correct -- the two forms back to back on one accumulator are the
+// suspect, and this kernel does not need the pair).
+__device__ __forceinline__ f32x4 mfma_bf16k(const u32x2n& a, const u32x2n& b, f32x4 c) {
+  return mfma_bf32(u32x4n{a[0], a[1], 0u, 0u}, u32x4n{b[0], b[1], 0u, 0u}, c);
+}
+// out[mt] (+)= W_main[16 mt + ., :48] x acts for two nodes; big: hi hi, sml: the five small terms.  Q: the matrix' planes (LDS)
+__device__ __forceinline__ void block48_split(const unsigned* Q, int lane, const u32x4n (&b32)[2][3], const u32x2n (&b16)[2][3],
+                                              f32x4 (&big)[2][3], f32x4 (&sml)[2][3]) {
+#pragma unroll
+  for (int mt = 0; mt < 3; ++mt) {
+    u32x4n A32[3];
+    u32x2n A16[3];
+#pragma unroll
+    for (int p = 0; p < 3; ++p) {
+      A32[p] = *reinterpret_cast<const u32x4n*>(Q + (p * 3 + mt) * 384 + 4 * lane);
+      A16[p] = *reinterpret_cast<const u32x2n*>(Q + (p * 3 + mt) * 384 + 256 + 2 * lane);
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      auto term = [&](int pa, int pb, f32x4& c) {
+        c = mfma_bf32(A32[pa], b32[u][pb], c);
+        c = mfma_bf16k(A16[pa], b16[u][pb], c);
+      };
+      term(2, 0, sml[u][mt]); term(0, 2, sml[u][mt]); term(1, 1, sml[u][mt]); term(1, 0, sml[u][mt]); term(0, 1, sml[u][mt]);
+      term(0, 0, big[u][mt]);
+    }
+  }
+}
+
+template <int EX>
+__device__ __forceinline__ void eval2x_split(const float* wp, const unsigned* wq, const MonoLayout& L, const f32x4 (&c1)[3],
+                                             const float (&c1x)[EX], float xa, float xb, int q, int j, float& fa, float& fb) {
+  constexpr int HM = 3, U0 = 48;
+  const int lane = 16 * q + j;
+  f32x4 a[2][HM];
+  float x0[EX], x1[EX];
+#pragma unroll
+  for (int t = 0; t < HM; ++t) {
+    const f32x4 wx = ld4(wp + L.o_w1x + 16 * t + 4 * q);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      a[0][t][r] = fmaxf(fmaf(wx[r], xa, c1[t][r]), 0.f);
+      a[1][t][r] = fmaxf(fmaf(wx[r], xb, c1[t][r]), 0.f);
+    }
+  }
+  {
+    const f32x4 wx = ld4(wp + L.o_w1x + U0);
+#pragma unroll
+    for (int e = 0; e < EX; ++e) {
+      x0[e] = fmaxf(fmaf(wx[e], xa, c1x[e]), 0.f);
+      x1[e] = fmaxf(fmaf(wx[e], xb, c1x[e]), 0.f);
+    }
+  }
+  for (int l = 1; l < L.NH; ++l) {
+    const float* W = wp + L.o_W[l];
+    u32x4n b32[2][3];
+    u32x2n b16[2][3];
+    split_acts48(a[0], b32[0], b16[0]);
+    split_acts48(a[1], b32[1], b16[1]);
+    f32x4 big[2][HM], sml[2][HM];
+#pragma unroll
+    for (int mt = 0; mt < HM; ++mt) {
+      big[0][mt] = ld4(wp + L.o_b[l] + 16 * mt + 4 * q);
+      big[1][mt] = big[0][mt];
+      sml[0][mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+      sml[1][mt] = sml[0][mt];
+    }
+#ifdef GNF_NSPLIT_DBG3
+    if (blockIdx.x == 0 && threadIdx.x == 21 && l == 1 && xa == 0.f && xb != 77.f) {
+      const unsigned* Q = wq;
+      for (int mt = 0; mt < 2; ++mt) {
+        const float* wrow = W + (16 * mt + j) * L.LDW;
+        f32x4 ww[3] = {ld4(wrow + 4 * q), ld4(wrow + 16 + 4 * q), ld4(wrow + 32 + 4 * q)};
+        u32x4n A32[3]; u32x2n A16[3];
+        split_acts48(ww, A32, A16);
+        for (int p = 0; p < 3; ++p) {
+          const u32x4n g = *reinterpret_cast<const u32x4n*>(Q + (p * 3 + mt) * 384 + 4 * lane);
+          const u32x2n g2 = *reinterpret_cast<const u32x2n*>(Q + (p * 3 + mt) * 384 + 256 + 2 * lane);
+          printf("mt %d p %d lane %d: planes %08x %08x %08x %08x | %08x %08x   in-kernel %08x %08x %08x %08x | %08x %08x\n", mt, p, lane, g[0], g[1], g[2], g[3],
+                 g2[0], g2[1], A32[p][0], A32[p][1], A32[p][2], A32[p][3], A16[p][0], A16[p][1]);
+        }
+      }
+    }
+#endif
+    block48_split(wq + (l - 1) * kNarrowQ, lane, b32, b16, big, sml);
+    // (the peeled part's weights are read BEHIND the block here: ahead of it, as in eval2x, their 80 registers push the
+    // kernel over 256 and a second workgroup off the CU -- the other workgroup's MFMAs cover these reads instead)
+    __builtin_amdgcn_sched_barrier(0);
+    f32x4 wr[EX][HM], wxr[EX], wc[HM][4];
+    const f32x4 bx = ld4(wp + L.o_b[l] + U0);
+#pragma unroll
+    for (int e = 0; e < EX; ++e) {
+#pragma unroll
+      for (int t = 0; t < HM; ++t) wr[e][t] = ld4(W + (U0 + e) * L.LDW + 16 * t + 4 * q);
+      wxr[e] = ld4(W + (U0 + e) * L.LDW + U0);
+    }
+#pragma unroll
+    for (int mt = 0; mt < HM; ++mt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) wc[mt][r] = ld4(W + (16 * mt + 4 * q + r) * L.LDW + U0);
+    // the peeled units' own pre-activations (from the OLD a / x), then their rank-EX contribution to the main units
+    float y0[EX], y1[EX];
+#pragma unroll
+    for (int e = 0; e < EX; ++e) {
+      float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+      for (int t = 0; t < HM; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { s0 = fmaf(wr[e][t][r], a[0][t][r], s0); s1 = fmaf(wr[e][t][r], a[1][t][r], s1); }
+      float k0 = bx[e], k1 = bx[e];
+#pragma unroll
+      for (int e2 = 0; e2 < EX; ++e2) { k0 = fmaf(wxr[e][e2], x0[e2], k0); k1 = fmaf(wxr[e][e2], x1[e2], k1); }
+      y0[e] = fmaxf(qsum(s0) + k0, 0.f);
+      y1[e] = fmaxf(qsum(s1) + k1, 0.f);
+    }
+#pragma unroll
+    for (int mt = 0; mt < HM; ++mt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float v0 = big[0][mt][r] + sml[0][mt][r], v1 = big[1][mt][r] + sml[1][mt][r];
+#pragma unroll
+        for (int e = 0; e < EX; ++e) { v0 = fmaf(wc[mt][r][e], x0[e], v0); v1 = fmaf(wc[mt][r][e], x1[e], v1); }
+        a[0][mt][r] = fmaxf(v0, 0.f);
+        a[1][mt][r] = fmaxf(v1, 0.f);
+      }
+#pragma unroll
+    for (int e = 0; e < EX; ++e) { x0[e] = y0[e]; x1[e] = y1[e]; }
+  }
+  float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+  for (int t = 0; t < HM; ++t) {
+    const f32x4 wl = ld4(wp + L.o_wL + 16 * t + 4 * q);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { s0 = fmaf(wl[r], a[0][t][r], s0); s1 = fmaf(wl[r], a[1][t][r], s1); }
+  }
+  const f32x4 wlx = ld4(wp + L.o_wL + U0);
+  float t0 = wp[L.o_bL], t1 = t0;
+#pragma unroll
+  for (int e = 0; e < EX; ++e) { t0 = fmaf(wlx[e], x0[e], t0); t1 = fmaf(wlx[e], x1[e], t1); }
+  fa = elu_plus(qsum(s0) + t0);
+  fb = elu_plus(qsum(s1) + t1);
+}
+
 // first-layer pre-activations without the x term: HM main tiles + EX peeled scalars (the once-per-group MFMA runs
 // over HM + 1 tiles; the peeled rows sit in lanes q = 0 of the last tile and are broadcast to the element's other lanes)
 template <int HM, int EX>
@@ -334,17 +548,29 @@ __device__ __forceinline__ void cond_bias_x(const float* wp, const MonoLayout& L
   for (int e = 0; e < EX; ++e) c1x[e] = __shfl(full[HM][e], j, 64);
 }
 
-template <int HM, int EX, int WM, bool INV>
+// SP: the main blocks on the bf16 matrix pipe (eval2x_split; WM = 1, HM = 3, forward only): the planes of the NH - 1 matrices
+// follow the fp32 image in LDS
+template <int HM, int EX, int WM, bool INV, bool SP = false>
 __global__ __launch_bounds__(64 * kWaves) void mono_fwd_x_k(MonoArgs a) {
   static_assert(WM == 0 || WM == 1, "peeled nets are narrow: the forward image is resident (1) or cached (0)");
+  static_assert(!SP || (WM == 1 && HM == 3 && !INV), "split form: resident image, 48-unit main block, forward");
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const MonoLayout& L = a.L;
   const float* wp = a.pack;
+  const unsigned* wq = nullptr;
   if (WM == 1) {
+    float* img = smem;
+    if (SP) {                                          // the planes FIRST (see block48_split on their addresses), the fp32 image behind
+      const int nq = (L.NH - 1) * kNarrowQ;
+      for (int i = threadIdx.x * 4; i < nq; i += blockDim.x * 4)
+        *reinterpret_cast<f32x4*>(smem + i) = ld4(a.pack + L.o_Wq[1] + i);
+      wq = reinterpret_cast<const unsigned*>(smem);
+      img = smem + nq;
+    }
     for (int i = threadIdx.x * 4; i < L.fwd_floats; i += blockDim.x * 4)
-      *reinterpret_cast<f32x4*>(smem + i) = ld4(a.pack + i);
+      *reinterpret_cast<f32x4*>(img + i) = ld4(a.pack + i);
     __syncthreads();
-    wp = smem;
+    wp = img;
   }
   auto getW = [&](int l) -> const float* { return wp + L.o_W[l]; };
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -371,7 +597,8 @@ __global__ __launch_bounds__(64 * kWaves) void mono_fwd_x_k(MonoArgs a) {
         const float xa = k <= a.S ? xT * (a.cct[k] + 1.f) * .5f : xj;
         const float xb = k1 <= a.S ? xT * (a.cct[k1] + 1.f) * .5f : xj;
         float fa, fb;
-        eval2x<HM, EX>(wp, L, c1, c1x, xa, xb, q, j, fa, fb, getW);
+        if constexpr (SP) eval2x_split<EX>(wp, wq, L, c1, c1x, xa, xb, q, j, fa, fb);
+        else eval2x<HM, EX>(wp, L, c1, c1x, xa, xb, q, j, fa, fb, getW);
         acc = fmaf(wa, fa, acc);
         acc = fmaf(wb, fb, acc);
         if (with_jac) {
@@ -2115,6 +2342,22 @@ int launch_fwd(const MonoArgs& a, hipStream_t s) {
   const int64_t per_cu = ((wlds && lds > (size_t)kLdsBudget / 2) || swap) ? 1 : 2;   // resident workgroups per CU
   if (grid > 256 * per_cu) grid = 256 * per_cu;                      // persistent
   if (a.L.EX > 0 && !swap) {                                          // peeled narrow net (HM = 3: H in {49, 50, 51})
+    if constexpr (!INV) {
+      const size_t lds_sp = lds + (size_t)(a.L.NH - 1) * kNarrowQ * 4;
+      if (wlds && a.L.NH > 1 && !a.f32only && gnf_gemm_split_enabled() && lds_sp <= (size_t)kLdsBudget / 2) {
+        g_fwd_kernel = "mono_fwd_x_k<split>";
+#define GNF_FWDXS(EX_)                                                                                         \
+        {                                                                                                      \
+          (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mono_fwd_x_k<3, EX_, 1, false, true>),      \
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_sp);                  \
+          hipLaunchKernelGGL((mono_fwd_x_k<3, EX_, 1, false, true>), dim3((unsigned)grid), dim3(64 * kWaves), lds_sp, s, a); \
+        }
+        if (a.L.EX <= 2) GNF_FWDXS(2) else GNF_FWDXS(3)
+#undef GNF_FWDXS
+        GNF_LAUNCH_CHECK();
+        return 0;
+      }
+    }
 #define GNF_FWDX(EX_)                                                                                          \
     if (wlds) {                                                                                                \
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mono_fwd_x_k<3, EX_, 1, INV>),                  \
@@ -2424,7 +2667,6 @@ int gnf_monotonic_pack(const gnf_mono_net* net, float* pack, gnf_stream_t stream
   return 0;
 }
 
-static thread_local const char* g_fwd_kernel = "";
 const char* gnf_monotonic_fwd_kernel(void) { return g_fwd_kernel; }
 
 static int mono_fwd_any(const float* pack, const gnf_mono_net* net, const float* x, const float* h, int64_t h_sb,
@@ -2454,8 +2696,9 @@ static int mono_fwd_any(const float* pack, const gnf_mono_net* net, const float*
   a.pack = pack; a.L = net_layout(net, HT);
   a.x = x; a.h = h; a.h_sb = h_sb; a.h_sd = h_sd; a.h_sc = h_sc;
   a.ccw = cc_w; a.cct = cc_t; a.S = S; a.z = z; a.jac = jac; a.n = B * d; a.d = d;
+  a.f32only = true_f32;
   if (gnf_mono_fwd_wide_ok(a.L)) return gnf_mono_fwd_wide_launch(a, (hipStream_t)stream, true_f32, &g_fwd_kernel);
-  g_fwd_kernel = "mono_fwd_k";
+  g_fwd_kernel = "mono_fwd_k";                        // (launch_fwd overrides it for the split form of the peeled nets)
   return launch_fwd<false>(a, (hipStream_t)stream);
 }
 

@@ -566,6 +566,9 @@ def test_bench_line_carries_issue_figures():
         if "frac_direct_conv_equivalent" in e:                # the conv pair: executed basis == the issued MFMAs
             assert e["frac_basis"].startswith("executed") and abs(e["frac"] - e["mfma_issue_frac"]) < 2e-3
             assert e["frac_direct_conv_equivalent"] > e["frac"] * 1.8           # Winograd issues ~2x fewer multiplies
+        elif e.get("peak") == 2500.:                          # the split-bf16 Monotonic forward: executed bf16 flop against the bf16 peak
+            assert e["frac_basis"].startswith("executed: bf16") and e["bound"].startswith("mfma (bf16")
+            assert e["fp32_equivalent_TFLOPs_algorithmic"] > 100.     # ... and above what the fp32 kernel reached (96)
         else:                                                 # Monotonic: the algorithmic flop of SURVEY.md 8(d) (the backward issues
             assert e["frac_basis"].startswith("algorithmic")  # more -- recompute --, the forward runs part of it on the VALU)
         # the clock of the run (cycles of a launch from the counter pass / live launch time) sits within a few per cent of the

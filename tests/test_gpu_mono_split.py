@@ -96,6 +96,47 @@ def test_split_forward_vs_fp64_and_fp32_mfma(hidden, c, d, B, S):
     assert torch.equal(zs, zs2) and torch.equal(js, js2)
 
 
+NCASES = [([50, 50, 50], 30, 784, 12, 20), ([50, 50, 50], 30, 784, 3, 150), ([49, 49], 8, 5, 333, 9), ([51] * 3, 30, 3, 257, 20),
+          ([50, 50, 50], 30, 1, 1, 20), ([50, 50, 50], 5, 7, 19, 21)]
+
+
+@pytest.mark.parametrize("hidden,c,d,B,S", NCASES)
+def test_narrow_split_forward_vs_fp64_and_fp32_mfma(hidden, c, d, B, S):
+    """the peeled narrow nets (H = 49..51: the reference's default integrand net, cfg4): mono_fwd_x_k<split>"""
+    from gnf_hip import abi
+    if not abi.load().gnf_gemm_split_enabled():
+        pytest.skip("GNF_TRUE_F32=1")
+    params = _params(hidden, c, seed=sum(hidden) + S + 3, scale=1.3)
+    g = torch.Generator().manual_seed(B + 5)
+    x = (torch.randn(B, d, generator=g) * 2.).to(DEV)
+    h = torch.randn(B, d, c, generator=g).to(DEV)
+    zs, js, ks = _fwd("gnf_monotonic_fwd", params, x, h, S)
+    zf, jf, kf = _fwd("gnf_monotonic_fwd_f32", params, x, h, S)
+    assert ks == "mono_fwd_x_k<split>" and kf == "mono_fwd_k", (ks, kf)
+    z64, j64 = _fp64(params, x, h, S)
+
+    def errs(a, ref):
+        e = (a.double() - ref).abs()
+        return float(e.max() / ref.abs().max()), float((e.pow(2).mean() / ref.pow(2).mean()).sqrt())
+    ez_s, ez_f, ej_s, ej_f = errs(zs, z64), errs(zf, z64), errs(js, j64), errs(jf, j64)
+    print("\n[mono narrow split %s S=%d] z: split max %.2e rms %.2e | fp32-MFMA max %.2e rms %.2e;  jac: split max %.2e rms %.2e | fp32-MFMA max %.2e rms %.2e"
+          % (hidden, S, *ez_s, *ez_f, *ej_s, *ej_f))
+    assert ez_s[1] <= 1.25 * ez_f[1] + 2e-8 and ej_s[1] <= 1.25 * ej_f[1] + 2e-8, (ez_s, ez_f, ej_s, ej_f)
+    assert ez_s[0] <= 1.5 * ez_f[0] + 1.2e-7 and ej_s[0] <= 1.5 * ej_f[0] + 1.2e-7, (ez_s, ez_f, ej_s, ej_f)
+    assert ez_s[0] < 2e-6 and ej_s[0] < 2e-6, (ez_s, ej_s)
+    zs2, js2, _ = _fwd("gnf_monotonic_fwd", params, x, h, S)
+    assert torch.equal(zs, zs2) and torch.equal(js, js2)
+
+
+def test_narrow_split_declines_what_does_not_fit_two_workgroups_per_cu():
+    """four hidden layers: the fp32 image + three matrices' planes exceed half the LDS -- the fp32 kernel runs"""
+    params = _params([51] * 4, 30, seed=2)
+    x, h = torch.randn(9, 5, device=DEV), torch.randn(9, 5, 30, device=DEV)
+    zs, js, ks = _fwd("gnf_monotonic_fwd", params, x, h, 20)
+    zf, jf, kf = _fwd("gnf_monotonic_fwd_f32", params, x, h, 20)
+    assert ks == "mono_fwd_k" and kf == "mono_fwd_k" and torch.equal(zs, zf) and torch.equal(js, jf)
+
+
 def test_split_forward_ragged_sizes_and_strided_h():
     """element counts around the group / half-group boundaries of the persistent schedule, h as a permuted view (MADE's output)"""
     from gnf_hip import abi

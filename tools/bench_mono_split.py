@@ -22,7 +22,8 @@ def params(hidden, c):
 
 def main():
     warm_gpu()
-    for tag, hidden, c, B, d, S in [("cfg5 train", [150] * 3, 30, 50000, 63, 20), ("cfg5 eval ", [150] * 3, 30, 5000, 63, 150),
+    for tag, hidden, c, B, d, S in [("cfg4 train", [50] * 3, 30, 100, 784, 20), ("cfg4 eval ", [50] * 3, 30, 100, 784, 150),
+                                    ("cfg5 train", [150] * 3, 30, 50000, 63, 20), ("cfg5 eval ", [150] * 3, 30, 5000, 63, 150),
                                     ("cfg2 train", [100] * 3, 30, 10000, 6, 20), ("cfg2 eval ", [100] * 3, 30, 10000, 6, 150)]:
         ps = params(hidden, c)
         x = torch.randn(B, d, device=DEV) * 2.

@@ -22,13 +22,16 @@ for which, regex, entries in (("cnn", "cnn_", (("gnf_mnistcnn_conv_bwd", "cnn_bw
     pmc = json.load(open(tmp))
     hows.append(pmc["how"])
     for entry, kname in entries:
-        cand = [v for name, v in pmc["kernels"].items() if name.startswith(kname)]
+        cand = [(name, v) for name, v in pmc["kernels"].items() if name.startswith(kname)]
         if not cand:
             continue
-        k = cand[0]
+        full_name, k = cand[0]
         c = k["counters"]
+        # flop per MFMA instruction: 2048 for v_mfma_f32_16x16x4_f32 / 16x16x1_4b_f32; 16384 for the v_mfma_f32_16x16x32_bf16 of the
+        # split-bf16 Monotonic forward (mono_fwd_x_k<3, EX, 1, false, true>: last template argument)
+        split = kname == "mono_fwd_x_k" and full_name.replace(" ", "").endswith("true>")
         res["kernels"][entry] = {
-            "kernel": kname,
+            "kernel": kname, "kernel_full_name": full_name, "mfma_flop": 16384 if split else 2048,
             "mfma_per_image": c["SQ_INSTS_MFMA"] / n,
             "valu_per_mfma": (c["SQ_INSTS_VALU"] - c["SQ_INSTS_MFMA"]) / c["SQ_INSTS_MFMA"],     # SQ_INSTS_VALU counts the MFMAs too
             "hbm_bytes_per_launch": 2 * c["FETCH_SIZE"] * 1024 + c["WRITE_SIZE"] * 1024,
