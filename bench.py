@@ -408,7 +408,8 @@ def main():
             "gnf_mnistcnn_conv_fwd": ("cnn_fwd_wino_k (conv1+ReLU, conv2 as Winograd F(2x2,3x3) on MFMA, maxpool)", 2. * (CONV1 + CONV2) * n_elem),
             "gnf_monotonic_fwd": ("mono_fwd_x_k<3,2> (Clenshaw-Curtis quadrature; 3 tiles on MFMA, units 48-49 peeled onto the VALU)",
                                   2. * macs * (S_NODES + 2) * n_elem),
-            "gnf_monotonic_bwd": ("mono_bwd_pair_x_k<3,3,2> (two nodes per pass, weight gradients in-kernel) + unpack",
+            "gnf_monotonic_bwd": ("mono_bwd_pair_x_k<3,3,2> (two nodes per pass, weight gradients in-kernel; since round 6 recompute and data "
+                                  "gradient of the main blocks as 3 x bf16 splits) + unpack",
                                   4. * macs * (S_NODES + 2) * n_elem),
         }
         # PMC counters cannot be read from inside this process: HBM bytes per launch, MFMA instructions per image, other VALU
@@ -552,6 +553,27 @@ def main():
                     entry["frac_of_peak_at_clock"] = round(mi * NOMINAL_GHZ / ghz, 4)
                 if p.get("mfma_pipe_busy_frac_of_simd_cycles") is not None:
                     entry["mfma_pipe_busy_frac_of_simd_cycles"] = p["mfma_pipe_busy_frac_of_simd_cycles"]
+                return
+            if p.get("mfma_flop") == "mixed":                     # the peeled backward with its chain on bf16 MFMAs, weight gradients fp32
+                if lib.gnf_monotonic_bwd_kernel().decode() != "mono_bwd_pair_x_k<split>":
+                    return
+                nb, nf = p["mfma_bf16_per_image"], p["mfma_per_image"] - p["mfma_bf16_per_image"]
+                # share of the matrix pipe's time at the nominal clock: every instruction at its own peak rate
+                mi = (nf * 2048. / PEAK_F32_TFLOPS + nb * 16384. / PEAK_BF16_TFLOPS) * n_elem / (prof[k] * 1e-3) / 1e12
+                entry["mfma_issue_frac"] = round(mi, 4)
+                entry["mfma_issue_frac_basis"] = "fp32 MFMAs (weight gradients) at 157.3 + bf16 MFMAs (recompute, data gradient) at 2500 TFLOP/s"
+                entry["valu_per_mfma"] = round(p["valu_per_mfma"], 3)
+                cyc = (nf * 32.5 + nb * 16.4) / (nf + nb)         # mean cycles per MFMA; ~2 VALU instructions per bf16 MFMA are free
+                entry["issue_frac_ceiling_shared_alu"] = round(cyc / (cyc + 3. * max(0., p["valu_per_mfma"] - 2. * nb / (nf + nb))), 3)
+                if p.get("cycles_per_launch"):
+                    ghz = p["cycles_per_launch"] / (prof[k] * 1e6)
+                    entry["effective_clock_GHz"] = round(ghz, 3)
+                    entry["effective_clock_GHz_in_pmc_pass"] = round(p["effective_clock_GHz_in_pmc_pass"], 3)
+                    entry["frac_of_peak_at_clock"] = round(mi * NOMINAL_GHZ / ghz, 4)
+                if p.get("mfma_pipe_busy_frac_of_simd_cycles") is not None:
+                    entry["mfma_pipe_busy_frac_of_simd_cycles"] = p["mfma_pipe_busy_frac_of_simd_cycles"]
+                if p.get("lds_bank_conflict_frac_of_lds_cycles") is not None:
+                    entry["lds_bank_conflict_frac_of_lds_cycles"] = round(p["lds_bank_conflict_frac_of_lds_cycles"], 4)
                 return
             if p.get("mfma_flop", 2048) != 2048:                  # counters of the split kernel, fp32 kernel running (GNF_TRUE_F32=1)
                 return

@@ -176,8 +176,8 @@ __device__ __forceinline__ float elu_plus(float s) { return (s > 0.f ? s : expm1
 // ok(): the net's shape has an instantiation and its LDS plan fits.  grid(): persistent workgroups (= rows of a.wpart).
 bool gnf_mono_bwd_wide_ok(const gnfmono::MonoLayout& L);
 unsigned gnf_mono_bwd_wide_grid(const gnfmono::MonoLayout& L, int64_t n);
-int gnf_mono_bwd_wide_launch(const gnfmono::MonoArgs& a, unsigned grid, hipStream_t s, bool true_f32, const char** kernel);
+int gnf_mono_bwd_wide_launch(const gnfmono::MonoArgs& a, unsigned grid, hipStream_t s, bool true_f32, const char* volatile* kernel);
 // forward (z, jac) of the same nets in the same formulation, two workgroups per CU
 bool gnf_mono_fwd_wide_ok(const gnfmono::MonoLayout& L);
 // true_f32: the fp32-MFMA kernel even when the split-bf16 one is enabled.  *kernel: the family launched.
-int gnf_mono_fwd_wide_launch(const gnfmono::MonoArgs& a, hipStream_t s, bool true_f32, const char** kernel);
+int gnf_mono_fwd_wide_launch(const gnfmono::MonoArgs& a, hipStream_t s, bool true_f32, const char* volatile* kernel);

@@ -33,7 +33,10 @@
 #include <cstdlib>
 
 extern "C" int gnf_gemm_split_enabled(void);
-static thread_local const char* g_fwd_kernel = "";     // kernel family of this thread's last forward launch (gnf_monotonic_fwd_kernel)
+// kernel family of the process' last forward / backward launch (gnf_monotonic_fwd_kernel / _bwd_kernel: reporting only; NOT
+// thread-local -- autograd runs the backward on its own thread and the caller asks from another)
+static const char* volatile g_fwd_kernel = "";
+static const char* volatile g_bwd_kernel = "";
 
 namespace {
 
@@ -397,6 +400,8 @@ __device__ __forceinline__ f32x4 mfma_bf16k(const u32x2n& a, const u32x2n& b, f3
   return mfma_bf32(u32x4n{a[0], a[1], 0u, 0u}, u32x4n{b[0], b[1], 0u, 0u}, c);
 }
 // out[mt] (+)= W_main[16 mt + ., :48] x acts for two nodes; big: hi hi, sml: the five small terms.  Q: the matrix' planes (LDS)
+// (ONE: a single accumulator class -- the backward kernel, whose registers are full: the same error level as the fp32 MFMA)
+template <bool ONE = false>
 __device__ __forceinline__ void block48_split(const unsigned* Q, int lane, const u32x4n (&b32)[2][3], const u32x2n (&b16)[2][3],
                                               f32x4 (&big)[2][3], f32x4 (&sml)[2][3]) {
 #pragma unroll
@@ -414,7 +419,8 @@ __device__ __forceinline__ void block48_split(const unsigned* Q, int lane, const
         c = mfma_bf32(A32[pa], b32[u][pb], c);
         c = mfma_bf16k(A16[pa], b16[u][pb], c);
       };
-      term(2, 0, sml[u][mt]); term(0, 2, sml[u][mt]); term(1, 1, sml[u][mt]); term(1, 0, sml[u][mt]); term(0, 1, sml[u][mt]);
+      f32x4& cs = ONE ? big[u][mt] : sml[u][mt];
+      term(2, 0, cs); term(0, 2, cs); term(1, 1, cs); term(1, 0, cs); term(0, 1, cs);
       term(0, 0, big[u][mt]);
     }
   }
@@ -458,24 +464,7 @@ __device__ __forceinline__ void eval2x_split(const float* wp, const unsigned* wq
       sml[0][mt] = f32x4{0.f, 0.f, 0.f, 0.f};
       sml[1][mt] = sml[0][mt];
     }
-#ifdef GNF_NSPLIT_DBG3
-    if (blockIdx.x == 0 && threadIdx.x == 21 && l == 1 && xa == 0.f && xb != 77.f) {
-      const unsigned* Q = wq;
-      for (int mt = 0; mt < 2; ++mt) {
-        const float* wrow = W + (16 * mt + j) * L.LDW;
-        f32x4 ww[3] = {ld4(wrow + 4 * q), ld4(wrow + 16 + 4 * q), ld4(wrow + 32 + 4 * q)};
-        u32x4n A32[3]; u32x2n A16[3];
-        split_acts48(ww, A32, A16);
-        for (int p = 0; p < 3; ++p) {
-          const u32x4n g = *reinterpret_cast<const u32x4n*>(Q + (p * 3 + mt) * 384 + 4 * lane);
-          const u32x2n g2 = *reinterpret_cast<const u32x2n*>(Q + (p * 3 + mt) * 384 + 256 + 2 * lane);
-          printf("mt %d p %d lane %d: planes %08x %08x %08x %08x | %08x %08x   in-kernel %08x %08x %08x %08x | %08x %08x\n", mt, p, lane, g[0], g[1], g[2], g[3],
-                 g2[0], g2[1], A32[p][0], A32[p][1], A32[p][2], A32[p][3], A16[p][0], A16[p][1]);
-        }
-      }
-    }
-#endif
-    block48_split(wq + (l - 1) * kNarrowQ, lane, b32, b16, big, sml);
+    block48_split<false>(wq + (l - 1) * kNarrowQ, lane, b32, b16, big, sml);
     // (the peeled part's weights are read BEHIND the block here: ahead of it, as in eval2x, their 80 registers push the
     // kernel over 256 and a second workgroup off the CU -- the other workgroup's MFMAs cover these reads instead)
     __builtin_amdgcn_sched_barrier(0);
@@ -560,7 +549,7 @@ __global__ __launch_bounds__(64 * kWaves) void mono_fwd_x_k(MonoArgs a) {
   const unsigned* wq = nullptr;
   if (WM == 1) {
     float* img = smem;
-    if (SP) {                                          // the planes FIRST (see block48_split on their addresses), the fp32 image behind
+    if (SP) {                                          // the planes first, the fp32 image behind them
       const int nq = (L.NH - 1) * kNarrowQ;
       for (int i = threadIdx.x * 4; i < nq; i += blockDim.x * 4)
         *reinterpret_cast<f32x4*>(smem + i) = ld4(a.pack + L.o_Wq[1] + i);
@@ -1688,9 +1677,14 @@ __global__ __launch_bounds__(64 * kWaves, 1) void mono_bwd_pair_k(MonoArgs a) {
 // The pack, the LDS image, the per-wavefront element-major tiles and every output (accumulator rows in the padded
 // [HP][HP] form with the bias gradient in column HP-1, Dsum, the partial vector row) are those of mono_bwd_pair_k.
 // ---------------------------------------------------------------------------------------
-template <int HM, int NH, int EX, bool RP = false>
+// SP (round 6): the 48 x 48 main blocks of the recompute and of the data gradient on the bf16 matrix pipe (block48_split:
+// activations / dpre split in the C/D registers, weights as LDS-resident bf16 planes of W_l and W_l^T from the pack); the
+// weight-gradient contraction (K = the 16 elements) and everything peeled stay fp32.  LDS then holds, per layer, only the
+// peeled rows of W_l and W_l^T and the bias in fp32 (the fp32 main blocks are gone: 157 -> 143 KB).
+template <int HM, int NH, int EX, bool RP = false, bool SP = false>
 __global__ __launch_bounds__(64 * kWaves, 1) void mono_bwd_pair_x_k(MonoArgs a) {
   static_assert(HM >= 1 && HM <= 3 && NH >= 2 && EX >= 1 && EX <= 3, "peeled narrow nets");
+  static_assert(!SP || HM == 3, "split form: 48-unit main block");
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const MonoLayout& L = a.L;
   #ifdef GNF_MONO_OLD_LDS
@@ -1704,19 +1698,37 @@ __global__ __launch_bounds__(64 * kWaves, 1) void mono_bwd_pair_x_k(MonoArgs a) 
   const int small = L.o_W1h;
   float* sW = smem + small;                      // W_l at sW + (l-1) * (matf + HP), b_l right behind it
   float* sWT = sW + (NH - 1) * (matf + HP);      // W_l^T at sWT + (l-1) * matf
+  // SP: per layer [4 peeled rows of W_l][4 peeled rows of W_l^T][b_l] = kRS floats at sW, the planes of W_1.., W_1^T.. behind them
+  constexpr int kRS = 8 * LDW + HP;
+  float* sQ = sW + (NH - 1) * kRS;               // SP: (NH-1) x kNarrowQ words of W_l planes, then as many of W_l^T planes
   for (int i = threadIdx.x * 4; i < small; i += blockDim.x * 4) *reinterpret_cast<f32x4*>(smem + i) = ld4(a.pack + i);
-  for (int l = 1; l < NH; ++l) {
-    for (int i = threadIdx.x * 4; i < matf + HP; i += blockDim.x * 4)
-      *reinterpret_cast<f32x4*>(sW + (l - 1) * (matf + HP) + i) = ld4(a.pack + L.o_W[l] + i);
-    for (int i = threadIdx.x * 4; i < matf; i += blockDim.x * 4)
-      *reinterpret_cast<f32x4*>(sWT + (l - 1) * matf + i) = ld4(a.pack + L.o_WT[l] + i);
+  if constexpr (SP) {
+    for (int l = 1; l < NH; ++l) {
+      float* rs = sW + (l - 1) * kRS;
+      for (int i = threadIdx.x * 4; i < 4 * LDW; i += blockDim.x * 4) {
+        *reinterpret_cast<f32x4*>(rs + i) = ld4(a.pack + L.o_W[l] + U0 * LDW + i);
+        *reinterpret_cast<f32x4*>(rs + 4 * LDW + i) = ld4(a.pack + L.o_WT[l] + U0 * LDW + i);
+      }
+      for (int i = threadIdx.x * 4; i < HP; i += blockDim.x * 4) *reinterpret_cast<f32x4*>(rs + 8 * LDW + i) = ld4(a.pack + L.o_b[l] + i);
+    }
+    for (int i = threadIdx.x * 4; i < (NH - 1) * kNarrowQ; i += blockDim.x * 4) {
+      *reinterpret_cast<f32x4*>(sQ + i) = ld4(a.pack + L.o_Wq[1] + i);
+      *reinterpret_cast<f32x4*>(sQ + (NH - 1) * kNarrowQ + i) = ld4(a.pack + L.o_WTq[1] + i);
+    }
+  } else {
+    for (int l = 1; l < NH; ++l) {
+      for (int i = threadIdx.x * 4; i < matf + HP; i += blockDim.x * 4)
+        *reinterpret_cast<f32x4*>(sW + (l - 1) * (matf + HP) + i) = ld4(a.pack + L.o_W[l] + i);
+      for (int i = threadIdx.x * 4; i < matf; i += blockDim.x * 4)
+        *reinterpret_cast<f32x4*>(sWT + (l - 1) * matf + i) = ld4(a.pack + L.o_WT[l] + i);
+    }
   }
   __syncthreads();
   const float* wp = smem;
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int q = lane >> 4, j = lane & 15;
   constexpr int NT = 2 * (NH - 1) + 1;           // tiles per wavefront: layer inputs of node 0 / node 1, one dpre tile
-  float* tiles = sWT + (NH - 1) * matf + wave * (NT * 16 * kTS);
+  float* tiles = (SP ? sQ + 2 * (NH - 1) * kNarrowQ : sWT + (NH - 1) * matf) + wave * (NT * 16 * kTS);
   for (int i = lane; i < NT * 16 * kTS; i += 64) tiles[i] = 0.f;
   float* td = tiles + (NT - 1) * 16 * kTS;
   const int64_t ngroups = (a.ecount + 15) / 16;
@@ -1806,19 +1818,26 @@ __global__ __launch_bounds__(64 * kWaves, 1) void mono_bwd_pair_x_k(MonoArgs a) 
       }
 #pragma unroll
       for (int l = 1; l < NH; ++l) {
-        const float* W = sW + (l - 1) * (matf + HP);
-        const float* WTf = sWT + (l - 1) * matf;
+        const float* W = sW + (l - 1) * (matf + HP);         // (fp32 form only)
+        // the peeled rows of W_l and W_l^T and the bias: inside the full images, or (SP) the compact per-layer slice
+        const float* Wrow = SP ? sW + (l - 1) * kRS : W + U0 * LDW;
+        const float* WTrow = SP ? sW + (l - 1) * kRS + 4 * LDW : sWT + (l - 1) * matf + U0 * LDW;
+        const float* Wbias = SP ? sW + (l - 1) * kRS + 8 * LDW : W + matf;
         f32x4 wr[EX][HM], wxr[EX], wc[EX][HM];      // W[U][k] (k = lane's units), W[U][U'], W[o][U] (o = lane's units)
-        const f32x4 bx = ld4(W + matf + U0);
+        f32x4 bx;
+        auto load_peeled = [&]() {
+          bx = ld4(Wbias + U0);
 #pragma unroll
-        for (int ee = 0; ee < EX; ++ee) {
+          for (int ee = 0; ee < EX; ++ee) {
 #pragma unroll
-          for (int t = 0; t < HM; ++t) {
-            wr[ee][t] = ld4(W + (U0 + ee) * LDW + 16 * t + 4 * q);
-            wc[ee][t] = ld4(WTf + (U0 + ee) * LDW + 16 * t + 4 * q);
+            for (int t = 0; t < HM; ++t) {
+              wr[ee][t] = ld4(Wrow + ee * LDW + 16 * t + 4 * q);
+              wc[ee][t] = ld4(WTrow + ee * LDW + 16 * t + 4 * q);
+            }
+            wxr[ee] = ld4(Wrow + ee * LDW + U0);
           }
-          wxr[ee] = ld4(W + (U0 + ee) * LDW + U0);
-        }
+        };
+        if constexpr (!SP) load_peeled();            // fp32 form: ahead of the MFMA block (their latency hides under it)
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
           float* ta = tiles + (2 * (l - 1) + u) * 16 * kTS;
@@ -1832,19 +1851,28 @@ __global__ __launch_bounds__(64 * kWaves, 1) void mono_bwd_pair_x_k(MonoArgs a) 
         }
         f32x4 o[2][HM];
 #pragma unroll
-        for (int mt = 0; mt < HM; ++mt) { o[0][mt] = ld4(W + matf + 16 * mt + 4 * q); o[1][mt] = o[0][mt]; }
+        for (int mt = 0; mt < HM; ++mt) { o[0][mt] = ld4(Wbias + 16 * mt + 4 * q); o[1][mt] = o[0][mt]; }
         __builtin_amdgcn_sched_barrier(0);
+        if constexpr (SP) {
+          u32x4n b32[2][3];
+          u32x2n b16[2][3];
+          split_acts48(act[0], b32[0], b16[0]);
+          split_acts48(act[1], b32[1], b16[1]);
+          block48_split<true>(reinterpret_cast<const unsigned*>(sQ) + (l - 1) * kNarrowQ, lane, b32, b16, o, o);
+          load_peeled();                             // SP: behind the block (registers: the split operands are live in it)
+        } else {
 #pragma unroll
-        for (int t = 0; t < HM; ++t)
+          for (int t = 0; t < HM; ++t)
 #pragma unroll
-          for (int mt = 0; mt < HM; ++mt) {
-            const f32x4 A = ld4(W + (16 * mt + j) * LDW + 16 * t + 4 * q);
+            for (int mt = 0; mt < HM; ++mt) {
+              const f32x4 A = ld4(W + (16 * mt + j) * LDW + 16 * t + 4 * q);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-              o[0][mt] = mfma(A[r], act[0][t][r], o[0][mt]);
-              o[1][mt] = mfma(A[r], act[1][t][r], o[1][mt]);
+              for (int r = 0; r < 4; ++r) {
+                o[0][mt] = mfma(A[r], act[0][t][r], o[0][mt]);
+                o[1][mt] = mfma(A[r], act[1][t][r], o[1][mt]);
+              }
             }
-          }
+        }
         __builtin_amdgcn_sched_barrier(0);
         float y[2][EX];
 #pragma unroll
@@ -1925,8 +1953,9 @@ __global__ __launch_bounds__(64 * kWaves, 1) void mono_bwd_pair_x_k(MonoArgs a) 
       // ---- hidden->hidden layers, top down
 #pragma unroll
       for (int l = NH - 1; l >= 1; --l) {
-        const float* W = sW + (l - 1) * (matf + HP);
-        const float* WT = sWT + (l - 1) * matf;
+        const float* WT = sWT + (l - 1) * matf;              // (fp32 form only)
+        const float* Wrow = SP ? sW + (l - 1) * kRS : sW + (l - 1) * (matf + HP) + U0 * LDW;
+        const float* WTrow = SP ? sW + (l - 1) * kRS + 4 * LDW : WT + U0 * LDW;
         // dW_l main block += dpre_l^T * input_l, K = the 16 elements, node by node through the one dpre tile
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
@@ -1956,27 +1985,35 @@ __global__ __launch_bounds__(64 * kWaves, 1) void mono_bwd_pair_x_k(MonoArgs a) 
         f32x4 da[2][HM];
 #pragma unroll
         for (int mt = 0; mt < HM; ++mt) { da[0][mt] = z4; da[1][mt] = z4; }
+        if constexpr (SP) {
+          u32x4n b32[2][3];
+          u32x2n b16[2][3];
+          split_acts48(dp[0], b32[0], b16[0]);
+          split_acts48(dp[1], b32[1], b16[1]);
+          block48_split<true>(reinterpret_cast<const unsigned*>(sQ) + (NH - 1 + l - 1) * kNarrowQ, lane, b32, b16, da, da);
+        } else {
 #pragma unroll
-        for (int t = 0; t < HM; ++t)
+          for (int t = 0; t < HM; ++t)
 #pragma unroll
-          for (int mt = 0; mt < HM; ++mt) {
-            const f32x4 A = ld4(WT + (16 * mt + j) * LDW + 16 * t + 4 * q);
+            for (int mt = 0; mt < HM; ++mt) {
+              const f32x4 A = ld4(WT + (16 * mt + j) * LDW + 16 * t + 4 * q);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-              da[0][mt] = mfma(A[r], dp[0][t][r], da[0][mt]);
-              da[1][mt] = mfma(A[r], dp[1][t][r], da[1][mt]);
+              for (int r = 0; r < 4; ++r) {
+                da[0][mt] = mfma(A[r], dp[0][t][r], da[0][mt]);
+                da[1][mt] = mfma(A[r], dp[1][t][r], da[1][mt]);
+              }
             }
-          }
+        }
         // peeled parts of da: the main inputs get a rank-EX update, the peeled inputs a q-summed partial dot
         f32x4 wr[EX][HM], wcT[EX][HM], wxr[EX];
 #pragma unroll
         for (int ee = 0; ee < EX; ++ee) {
 #pragma unroll
           for (int t = 0; t < HM; ++t) {
-            wr[ee][t] = ld4(W + (U0 + ee) * LDW + 16 * t + 4 * q);       // W[U][k],  k = the lane's main units
-            wcT[ee][t] = ld4(WT + (U0 + ee) * LDW + 16 * t + 4 * q);     // W[o][U],  o = the lane's main units
+            wr[ee][t] = ld4(Wrow + ee * LDW + 16 * t + 4 * q);           // W[U][k],  k = the lane's main units
+            wcT[ee][t] = ld4(WTrow + ee * LDW + 16 * t + 4 * q);         // W[o][U],  o = the lane's main units
           }
-          wxr[ee] = ld4(W + (U0 + ee) * LDW + U0);                        // W[U][U']
+          wxr[ee] = ld4(Wrow + ee * LDW + U0);                            // W[U][U']
         }
         float dax[2][EX];
 #pragma unroll
@@ -2406,6 +2443,25 @@ int launch_bwd_one(const MonoArgs& a, unsigned grid, hipStream_t s) {
         if (a.L.EX > 0) {                       // peeled: 3 tiles on the MFMA, the H mod 16 leftover units on the VALU
           // row peel (the weight gradient's fourth out tile on the VALU) where its partials fit the register file
           constexpr bool kRP = NH <= 3;          // NH = 4: 122 registers spilled
+          if constexpr (NH <= 3) {               // the split-bf16 chain (SP): the reference's [H]^3 / [H]^2 nets
+            const size_t lds_sp = ((size_t)a.L.o_W1h + (size_t)(NH - 1) * (8 * a.L.LDW + a.L.HP + 2 * kNarrowQ) +
+                                   (size_t)kWaves * (2 * (NH - 1) + 1) * 16 * kTS) * sizeof(float);
+            const size_t lds_wcomb = (size_t)kWaves * (NH - 1) * a.L.HP * a.L.HP * sizeof(float);
+            if (!a.f32only && gnf_gemm_split_enabled() && lds_sp <= (size_t)kLdsBudget && (!a.wcomb || lds_wcomb <= lds_sp)) {
+              g_bwd_kernel = "mono_bwd_pair_x_k<split>";
+              if (a.L.EX <= 2) {
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mono_bwd_pair_x_k<3, NH, 2, kRP, true>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_sp);
+                hipLaunchKernelGGL((mono_bwd_pair_x_k<3, NH, 2, kRP, true>), dim3(grid), dim3(64 * kWaves), lds_sp, s, a);
+              } else {
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mono_bwd_pair_x_k<3, NH, 3, false, true>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_sp);
+                hipLaunchKernelGGL((mono_bwd_pair_x_k<3, NH, 3, false, true>), dim3(grid), dim3(64 * kWaves), lds_sp, s, a);
+              }
+              GNF_LAUNCH_CHECK();
+              return 0;
+            }
+          }
           if (a.L.EX <= 2) {
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mono_bwd_pair_x_k<3, NH, 2, kRP>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_pair);
@@ -2740,7 +2796,6 @@ int64_t gnf_monotonic_bwd_ws_bytes(const gnf_mono_net* net, int S, int64_t B, in
 }
 
 static thread_local bool g_bwd_true_f32 = false;
-static thread_local const char* g_bwd_kernel = "";
 const char* gnf_monotonic_bwd_kernel(void) { return g_bwd_kernel; }
 
 int gnf_monotonic_bwd_f32(const float* pack, const gnf_mono_net* net, const float* x, const float* h, int64_t h_sb,
@@ -2796,6 +2851,7 @@ int gnf_monotonic_bwd(const float* pack, const gnf_mono_net* net, const float* x
   a.ones = HT <= 4 && NH > 1 && !wide;       // (the two-role kernels carry the bias gradients in their partial vector rows)
   for (int l = 1; l < NH; ++l) a.ones = a.ones && net->dims[l] < HP;
   a.indw = wide ? 3 : (int)indw;
+  a.f32only = g_bwd_true_f32;
   if (indw && !wide) {                            // the two-node kernel when its LDS plan fits (A/B: GNF_MONO_INDW=1 keeps one node)
     const size_t lds_pair = ((size_t)L.o_W1h + (size_t)(NH - 1) * (2 * L.HP * L.LDW + L.HP) +
                              (size_t)kWaves * (2 * (NH - 1) + 1) * 16 * kTS) * sizeof(float);

@@ -1408,7 +1408,7 @@ extern "C" int gnf_debug_wide_stamps(unsigned long long* host, int enable) {
 
 extern "C" int gnf_gemm_split_enabled(void);
 
-int gnf_mono_bwd_wide_launch(const gnfmono::MonoArgs& a, unsigned grid, hipStream_t s, bool true_f32, const char** kernel) {
+int gnf_mono_bwd_wide_launch(const gnfmono::MonoArgs& a, unsigned grid, hipStream_t s, bool true_f32, const char* volatile* kernel) {
   *kernel = "mono_bwd_wide_k<f32>";
   if (!true_f32 && gnf_gemm_split_enabled()) {
     *kernel = "mono_bwd_wide_k<split>";
@@ -1434,7 +1434,7 @@ bool gnf_mono_fwd_wide_ok(const gnfmono::MonoLayout& L) {
 
 extern "C" int gnf_gemm_split_enabled(void);
 
-int gnf_mono_fwd_wide_launch(const gnfmono::MonoArgs& a, hipStream_t s, bool true_f32, const char** kernel) {
+int gnf_mono_fwd_wide_launch(const gnfmono::MonoArgs& a, hipStream_t s, bool true_f32, const char* volatile* kernel) {
   *kernel = "mono_fwd_wide_k";
   if (!true_f32 && gnf_gemm_split_enabled()) {
     *kernel = "mono_fwd_wide_split_k";                     // bf16 matrix pipe, exact 3 x bf16 splits (GNF_TRUE_F32=1: fp32 MFMA)

@@ -267,12 +267,14 @@ int gnf_monotonic_fwd(const float* pack, const gnf_mono_net* net,
                       const float* x, const float* h, int64_t h_sb, int64_t h_sd, int64_t h_sc,
                       const float* cc_w, const float* cc_t, int S,
                       float* z, float* jac, int64_t B, int64_t d, gnf_stream_t stream);
-/* Wide integrand nets (hidden widths 97..112, 145..160: the [100]^3 / [150]^3 nets of UCIExperiments.yml) run their
- * hidden->hidden products on the bf16 matrix pipe with exact 3 x bf16 operand splits, six cross terms and fp32 accumulation
- * (closer to an fp64 evaluation than the fp32-MFMA kernel, tests/test_gpu_mono_split.py).  GNF_TRUE_F32=1 (read once per
- * process) selects the fp32-MFMA kernel for gnf_monotonic_fwd; gnf_monotonic_fwd_f32 always does (same arguments: the A/B
- * handle of the tests and tools).  gnf_monotonic_fwd_kernel(): name of the kernel family the last forward call of this
- * thread launched ("mono_fwd_wide_split_k", "mono_fwd_wide_k", "mono_fwd_k"). */
+/* Wide integrand nets (hidden widths 97..112, 145..160: the [100]^3 / [150]^3 nets of UCIExperiments.yml) and the peeled
+ * narrow nets (all hidden widths equal, 49..51: the reference's default [50, 50, 50]) run their hidden->hidden products on
+ * the bf16 matrix pipe with exact 3 x bf16 operand splits, six cross terms and fp32 accumulation (as close to an fp64
+ * evaluation as the fp32-MFMA kernels or closer, tests/test_gpu_mono_split.py).  GNF_TRUE_F32=1 (read once per process)
+ * selects the fp32-MFMA kernels for gnf_monotonic_fwd; gnf_monotonic_fwd_f32 always does (same arguments: the A/B handle
+ * of the tests and tools).  gnf_monotonic_fwd_kernel(): name of the kernel family the last forward call of this PROCESS
+ * launched ("mono_fwd_wide_split_k", "mono_fwd_wide_k", "mono_fwd_x_k<split>", "mono_fwd_k"); reporting only, not
+ * synchronised. */
 int gnf_monotonic_fwd_f32(const float* pack, const gnf_mono_net* net,
                           const float* x, const float* h, int64_t h_sb, int64_t h_sd, int64_t h_sc,
                           const float* cc_w, const float* cc_t, int S,
@@ -303,10 +305,12 @@ int gnf_monotonic_bwd(const float* pack, const gnf_mono_net* net,
                       float* gx, float* gh, int64_t g_sb, int64_t g_sd, int64_t g_sc,
                       float* const* gW, float* const* gb,
                       void* ws, int64_t ws_bytes, int64_t B, int64_t d, gnf_stream_t stream);
-/* Wide integrand nets: the chain wavefronts of the backward (recompute and data gradient through the hidden->hidden layers)
- * run on the bf16 matrix pipe with exact 3 x bf16 splits, like gnf_monotonic_fwd; the weight-gradient contraction stays
+/* Wide integrand nets (H = 145..160): the chain wavefronts of the backward (recompute and data gradient through the
+ * hidden->hidden layers) run on the bf16 matrix pipe with exact 3 x bf16 splits, like gnf_monotonic_fwd; peeled narrow nets
+ * (H = 49..51, at most three hidden layers): the same for the 48 x 48 main blocks.  The weight-gradient contraction stays
  * fp32 MFMA.  GNF_TRUE_F32=1 / gnf_monotonic_bwd_f32 (same arguments): all fp32 MFMA.  gnf_monotonic_bwd_kernel(): the
- * chain kernel the last backward call of this thread launched ("mono_bwd_wide_k<split>", "mono_bwd_wide_k<f32>", "mono_bwd_k"). */
+ * chain kernel the last backward call of this PROCESS launched (autograd calls from its own thread): "mono_bwd_wide_k<split>",
+ * "mono_bwd_wide_k<f32>", "mono_bwd_pair_x_k<split>", "mono_bwd_k". */
 int gnf_monotonic_bwd_f32(const float* pack, const gnf_mono_net* net,
                           const float* x, const float* h, int64_t h_sb, int64_t h_sd, int64_t h_sc,
                           const float* cc_w, const float* cc_t, int S,

@@ -245,6 +245,44 @@ def test_split_backward_vs_fp64_and_fp32_mfma(hidden, c, d, B, S):
         assert torch.equal(a, b)
 
 
+NBCASES = [([50, 50, 50], 30, 784, 6, 20), ([50, 50, 50], 30, 13, 40, 21), ([49, 49], 8, 5, 333, 9), ([51] * 3, 30, 3, 257, 20),
+           ([50, 50, 50], 30, 1, 1, 20)]
+
+
+@pytest.mark.parametrize("hidden,c,d,B,S", NBCASES)
+def test_narrow_split_backward_vs_fp64_and_fp32_mfma(hidden, c, d, B, S):
+    """the peeled narrow nets (cfg4): mono_bwd_pair_x_k<split> -- recompute and data gradient of the 48 x 48 main blocks on the
+    bf16 matrix pipe (two accumulator classes), weight gradients fp32"""
+    from gnf_hip import abi
+    if not abi.load().gnf_gemm_split_enabled():
+        pytest.skip("GNF_TRUE_F32=1")
+    params = _params(hidden, c, seed=sum(hidden) + S + 5, scale=1.3)
+    g = torch.Generator().manual_seed(B + 9)
+    x = (torch.randn(B, d, generator=g) * 2.).to(DEV)
+    h = torch.randn(B, d, c, generator=g).to(DEV)
+    gz, gjac = torch.randn(B, d, generator=g).to(DEV), torch.randn(B, d, generator=g).to(DEV)
+    gs, ks = _bwd("gnf_monotonic_bwd", params, x, h, S, gz, gjac)
+    gf, kf = _bwd("gnf_monotonic_bwd_f32", params, x, h, S, gz, gjac)
+    assert ks == "mono_bwd_pair_x_k<split>" and kf == "mono_bwd_k", (ks, kf)
+    g64 = _bwd64(params, x, h, S, gz, gjac)
+    names = ["gx", "gh"] + ["gW%d" % (i // 2) if i % 2 == 0 else "gb%d" % (i // 2) for i in range(len(params))]
+    worst = []
+    for nm, a, b, r in zip(names, gs, gf, g64):
+        scale = float(r.abs().max()) + 1e-30
+        es, ef = float((a.double() - r).abs().max()) / scale, float((b.double() - r).abs().max()) / scale
+        rs = float(((a.double() - r).pow(2).mean() / (r.pow(2).mean() + 1e-60)).sqrt())
+        rf = float(((b.double() - r).pow(2).mean() / (r.pow(2).mean() + 1e-60)).sqrt())
+        worst.append((nm, es, ef, rs, rf))
+        assert rs <= 2. * rf + 2.4e-7 and es <= 2. * ef + 4.8e-7, (nm, es, ef, rs, rf)
+    ratio = float(np.exp(np.mean([np.log((w_[3] + 1e-9) / (w_[4] + 1e-9)) for w_ in worst])))
+    assert ratio <= 1.15, (ratio, worst)
+    print("\n[mono narrow split bwd %s S=%d] geometric mean of rms(split) / rms(fp32-MFMA): %.2f; " % (hidden, S, ratio)
+          + ", ".join("%s %.1e|%.1e" % (w_[0], w_[3], w_[4]) for w_ in worst))
+    gs2, _ = _bwd("gnf_monotonic_bwd", params, x, h, S, gz, gjac)
+    for a, b in zip(gs, gs2):
+        assert torch.equal(a, b)
+
+
 def test_split_backward_ragged_sizes():
     """element counts around the group / half-group boundaries of the persistent schedule (h contiguous: the backward entry
     asks for a collapsible element stride, ops.MonotonicFn.backward makes the copy)"""

@@ -30,8 +30,13 @@ for which, regex, entries in (("cnn", "cnn_", (("gnf_mnistcnn_conv_bwd", "cnn_bw
         # flop per MFMA instruction: 2048 for v_mfma_f32_16x16x4_f32 / 16x16x1_4b_f32; 16384 for the v_mfma_f32_16x16x32_bf16 of the
         # split-bf16 Monotonic forward (mono_fwd_x_k<3, EX, 1, false, true>: last template argument)
         split = kname == "mono_fwd_x_k" and full_name.replace(" ", "").endswith("true>")
+        # the split-bf16 chain of the peeled backward (mono_bwd_pair_x_k<3, NH, EX, RP, true>): recompute + data gradient of the
+        # 48 x 48 main blocks = 2 x 72 bf16 MFMAs per (16 elements, node pair, hidden->hidden layer) -- at S = 20 (11 node pairs) and
+        # two such layers 11 x 2 x 144 / 16 = 198 per element; the rest of the counted instructions (weight gradients, W1h) are fp32
+        mixed = kname == "mono_bwd_pair_x_k" and full_name.replace(" ", "").endswith("true,true>")
         res["kernels"][entry] = {
-            "kernel": kname, "kernel_full_name": full_name, "mfma_flop": 16384 if split else 2048,
+            "kernel": kname, "kernel_full_name": full_name, "mfma_flop": "mixed" if mixed else (16384 if split else 2048),
+            "mfma_bf16_per_image": 198. if mixed else None,
             "mfma_per_image": c["SQ_INSTS_MFMA"] / n,
             "valu_per_mfma": (c["SQ_INSTS_VALU"] - c["SQ_INSTS_MFMA"]) / c["SQ_INSTS_MFMA"],     # SQ_INSTS_VALU counts the MFMAs too
             "hbm_bytes_per_launch": 2 * c["FETCH_SIZE"] * 1024 + c["WRITE_SIZE"] * 1024,
