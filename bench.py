@@ -497,7 +497,7 @@ def main():
             # round 6: the fc1 forward / data-gradient products run on the bf16 matrix pipe with fp32 accuracy (exact 3 x bf16 operand
             # splits, six cross terms, fp32 accumulate: gnf_gemm_split.hip, more accurate against fp64 than the fp32-MFMA kernels
             # they replace, profiles/r06_split_bf16_error.txt); everything else on v_mfma_f32_*.  GNF_TRUE_F32=1 turns it off.
-            "mfma_operands": "3xbf16 split (fc1), f32 elsewhere" if abi.load().gnf_gemm_split_enabled() else "f32",
+            "mfma_operands": "3xbf16 split (fc1, Monotonic main blocks), f32 elsewhere" if abi.load().gnf_gemm_split_enabled() else "f32",
             "parity_note": "UMNN 1.0 parity unpinned: the Clenshaw-Curtis integral of the Monotonic normalizer is "
                            "checked against this repo's own restatement + mathematics (CPU: tests/test_oracle_math.py; the HIP "
                            "kernels themselves against fp64 adaptive quadrature: tests/test_gpu_integral_pin.py), not against "

@@ -549,7 +549,7 @@ def test_bench_line_carries_issue_figures():
     assert r.returncode == 0, r.stderr[-3000:]
     out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     assert out["scaling"] == "weak" and out["config"]["global_batch"] == 100
-    assert out["mfma_operands"] in ("f32", "3xbf16 split (fc1), f32 elsewhere") and out["dtype"] == "f32"
+    assert out["mfma_operands"] in ("f32", "3xbf16 split (fc1, Monotonic main blocks), f32 elsewhere") and out["dtype"] == "f32"
     # one rank, one device, no collective: the device is named all the same
     assert len(out["rank_devices"]) == 1 and "name=" in out["rank_devices"][0] and out["rccl_world_size"] is None
     entries = [out["roofline"]] + out["roofline_other"]
