@@ -392,10 +392,11 @@ __device__ __forceinline__ f32x4 mfma_bf32(const u32x4n& a, const u32x4n& b, f32
   return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8n, a), __builtin_bit_cast(bf16x8n, b), c, 0, 0, 0);
 }
 // The 16-wide remainder of the contraction (tile 2) ALSO goes through the K = 32 instruction, upper half zero.  The legacy
-// v_mfma_f32_16x16x16_bf16 takes the same 17 cycles on gfx950 (profiles/r06_mfma_k16_rate.txt), so nothing is lost -- and
-// chained on one accumulator with the K = 32 form it produced wrong sums in this kernel (build-dependent: right in every
-// instrumented build, wrong in the optimised one; alone it is correct -- the two forms back to back on one accumulator are the
-// suspect, and this kernel does not need the pair).
+// v_mfma_f32_16x16x16_bf16 takes the same 17 cycles on gfx950 (profiles/r06_mfma_k16_rate.txt), so nothing is lost -- and with
+// it this kernel produced wrong sums in the optimised build (errors of 1e-2 .. 1; right in every instrumented build; the
+// operand planes verified bit-identical by device printf).  Cause NOT isolated: the instruction alone and the two forms
+// chained on one accumulator are correct in stand-alone kernels (tools/mfma_chain_check.hip).  The K = 32 form is correct in
+// every build of this kernel; tests/test_gpu_mono_split.py::test_narrow_* pin it against fp64.
 __device__ __forceinline__ f32x4 mfma_bf16k(const u32x2n& a, const u32x2n& b, f32x4 c) {
   return mfma_bf32(u32x4n{a[0], a[1], 0u, 0u}, u32x4n{b[0], b[1], 0u, 0u}, c);
 }
