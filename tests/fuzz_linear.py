@@ -55,20 +55,24 @@ def one(case, rng, only=None):
             masks.append(m)
             dprev = do
     gy = torch.randn(M, dims[-1], generator=g)
-    # fp64 reference.  Rows with a hidden pre-activation within 16 fp32 ulps (of its terms' magnitude) of zero get a zero
-    # cotangent: there an fp32 chain and the fp64 one may gate differently, and ONE flipped gate moves that row's gradient by
-    # several per cent (at 60 000 rows x 256 units a walk meets a handful of such rows per case)
+    # fp64 reference.  Rows with a hidden pre-activation within the fp32 chain's error bound of zero get a zero cotangent: there an
+    # fp32 chain and the fp64 one may gate differently, and ONE flipped gate moves that row's gradient by several per cent (at
+    # 60 000 rows x 256 units a walk meets a handful of such rows per case).  The bound of a layer = 16 fp32 ulps of its own terms'
+    # magnitude + the bound INHERITED from its inputs through |W|: behind a narrow bottleneck (walk 703, case 113: 255 -> 1 -> 198)
+    # the single input carries the roundoff of a 255-term sum, which is far more than 16 ulps of its own small value
     xr = x.double().requires_grad_(need_x)
     ps = [(W.double().requires_grad_(True), b.double().requires_grad_(True)) for W, b in layers]
     a = xr
     knife = torch.zeros(M, dtype=torch.bool)
+    aerr = torch.zeros(M, dims[0], dtype=torch.float64)          # bound on the fp32 chain's absolute error of the layer inputs
     for l, (W, b) in enumerate(ps):
         Wm = W * masks[l].double() if masks else W
         pre = torch.nn.functional.linear(a, Wm, b)
         if l < nl - 1:
             with torch.no_grad():
                 mag = a.detach().abs() @ Wm.detach().abs().t() + b.detach().abs()
-                knife |= ((pre.detach().abs() < 16 * 2. ** -23 * mag) & (pre.detach() != 0)).any(1)
+                aerr = 16 * 2. ** -23 * mag + aerr @ Wm.detach().abs().t()
+                knife |= ((pre.detach().abs() < aerr) & (pre.detach() != 0)).any(1)
             a = torch.relu(pre)
         else:
             a = pre
