@@ -21,7 +21,7 @@ c_stream = ctypes.c_void_p
 
 MONO_MAX_LAYERS = 8
 DAG_PLAN_KC = 32          # GNF_DAG_PLAN_KC
-ABI_VERSION = 7           # GNF_ABI_VERSION of include/gnf_hip.h this binding was written against
+ABI_VERSION = 8           # GNF_ABI_VERSION of include/gnf_hip.h this binding was written against
 
 
 class MonoNet(ctypes.Structure):

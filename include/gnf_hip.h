@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define GNF_ABI_VERSION 7
+#define GNF_ABI_VERSION 8
 #define GNF_EINVAL (-1)   /* bad argument (null pointer, negative size, ...)          */
 #define GNF_ESHAPE (-2)   /* shape not supported by any compiled kernel instantiation */
 #define GNF_EWS    (-3)   /* workspace too small                                      */
